@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Benchmark of the ANM hot path: ANM continuation steps / second.
+
+  python bench.py --gpus N --steps K --warmup W
+
+A "step" is one completed ANMDriverHelper::solve_expansion_coeffs
+(libsanm/anm.cpp:193-312): order-0 evaluation, Jacobian, CSR assembly, linear
+solver preparation and N=order (bias, solve, coefficient) rounds, plus the
+range estimate / Pade.  The workload is the BASELINE metric's configuration:
+config/armadillo.json (Neo-Hookean compressible, order 20, Pade and sanity
+checks on).  The full Armadillo mesh is missing from the reference snapshot
+(.MISSING_LARGE_BLOBS), so the stand-in is the shipped Armadillo-small.1
+(config/armadillo_small.json: same material, load and boundary rule).
+
+The continuation runs from the rest state exactly as `fea` does; when a solve
+converges before W+K steps are done, the next solve starts again from the rest
+state on the same solver (sanm_anm_restart), so exactly K completed steps are
+timed.  For N > 1 every rank runs the whole problem on its own GPU (replicas:
+see DESIGN.md "Multi-GPU"), value = N*K / max-over-ranks time.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=12)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--workload", default="armadillo_small")
+    p.add_argument("--solver-rtol", type=float, default=1e-12)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-steps", type=int, default=1)
+    return p.parse_args()
+
+
+def cpu_baseline(workload, cpu_steps):
+    """The oracle (numpy port of the reference algorithm, SuperLU direct solve)
+    timed on the host for `cpu_steps` ANM steps of the same workload."""
+    import numpy as np  # noqa: F401
+    from oracle import fea as ofea
+    from sanm_amd import fea as dfea
+    cfg, mesh = dfea.load_named_config(workload)
+    omesh = ofea.TetMesh(mesh.V, mesh.tets, mesh.surface_vtx)
+    t0 = time.perf_counter()
+    model, solver, _ = ofea.make_gravity_solver(omesh, cfg)  # ctor = first step
+    steps = 1
+    while steps < cpu_steps and not solver.converged:
+        solver.next_iter()
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "ANM steps/s", "cores": 1, "kind": "port",
+            "sample": f"{steps} ANM step(s) of {workload} (order {cfg.get('order', 20)}) from the rest state, "
+                      f"numpy oracle + SuperLU, {dt:.1f} s incl. graph/remap setup",
+            "profile": {k: round(v, 3) for k, v in solver.profile.items()}}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import sanm_amd
+    from sanm_amd import fea as dfea
+    api = sanm_amd.get_api(local_rank)
+    cfg, mesh = dfea.load_named_config(args.workload)
+    run = dfea.GravityRun(api, mesh, cfg, solver_rtol=args.solver_rtol)
+    x0 = run.model.x0()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- continuation with restarts: exactly W + K completed steps ----------
+    state = {"started": False, "solves": 0, "steps_per_solve": []}
+
+    def one_step():
+        if not state["started"]:
+            run.construct()  # first step of the first solve
+            state["started"] = True
+            state["cur"] = 1
+            return
+        s = run.solver
+        if not s.converged():
+            before = s.get_nr_iter()
+            s.next_iter()
+            if s.get_nr_iter() > before:
+                state["cur"] += 1
+                return
+        # converged (the converged call only evaluates f(x0)): begin a new solve
+        state["solves"] += 1
+        state["steps_per_solve"].append(state["cur"])
+        s.restart(x0)
+        state["cur"] = 1
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    it0 = run.solver.get_nr_iter() if state["started"] else 0
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    assert run.solver.get_nr_iter() - it0 == args.steps
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    stats = run.solver.stats()
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (PCG SpMV+dot), HIP events ------
+        n, nnz = stats["nr_unknown"], stats["jacobian_nnz"]
+        reps = 500
+        avg_ms = run.solver.time_kernel(2, reps)
+        # algorithmic bytes per launch: CSR values + column indices + row
+        # pointers, gathered p (once), p[row] for the dot, q written
+        alg_bytes = 12.0 * nnz + 4.0 * (n + 1) + 24.0 * n
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        iters_per_solve = stats["linear_iters_total"] / max(stats["nr_linear_solve"], 1)
+        out = {
+            "metric": "ANM continuation steps/sec (armadillo, Neo-Hookean, order 20)",
+            "value": world * args.steps / dt, "unit": "ANM steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "real mesh Armadillo-small.1 (stand-in for the missing Armadillo.1), rest state",
+            "config": {"workload": f"config/{args.workload}.json: {cfg['energy_model']}, order "
+                                   f"{cfg.get('order', 20)}, T={stats['nr_tet']}, n={n}, nnz={nnz}, "
+                                   f"pade on, sanity check on",
+                       "parallelism": "replicas" if world > 1 else "single",
+                       "linear_solver": "jacobi-pcg", "solver_rtol": args.solver_rtol,
+                       "pcg_iters_per_solve": iters_per_solve,
+                       "steps_per_solve": state["steps_per_solve"]},
+            "roofline": {"bound": "hbm", "kernel": "pcg_spmv_dot_kernel", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "avg_launch_us": avg_ms * 1e3,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_steps)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,213 @@
+/*
+ * sanm_hip.h -- C ABI of the MI355X-native ANM hot path (libsanm_hip.so).
+ *
+ * Every entry point replaces a piece of the C++ interface the reference's ANM
+ * inner loop sits behind (jia-kai/SANM; paths relative to the reference
+ * root).  The reference has no C ABI of its own: INTEGRATION.md shows the
+ * C++ adapter a maintainer would put in front of these calls.
+ *
+ * Conventions
+ *   - every function returns 0 on success, otherwise an error code; the text
+ *     of the last error of the calling thread is sanm_hip_last_error().
+ *     Codes map to the reference's exception types (libsanm/utils.h:34-50).
+ *   - all pointers are HOST pointers owned by the caller; tensors are
+ *     row-major fp64, batch first: (T,3,3) matrices are T*9 doubles.
+ *   - handles are opaque; device memory is owned by the handle.
+ *   - one host thread per context; no callbacks into the caller.
+ *   - there is no CPU fallback: sanm_hip_init() fails if no HIP device exists.
+ */
+#ifndef SANM_HIP_H
+#define SANM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SANM_HIP_OK 0
+#define SANM_HIP_ERR_ASSERT 1      /* SANMAssertionError, libsanm/utils.cpp:55-68 */
+#define SANM_HIP_ERR_NUMERICAL 2   /* SANMNumericalError, libsanm/anm.cpp:354 */
+#define SANM_HIP_ERR_HIP 3         /* HIP runtime failure / no device */
+#define SANM_HIP_ERR_UNSUPPORTED 4 /* valid in the reference, not on the device path */
+#define SANM_HIP_ERR_UNKNOWN 5
+
+typedef struct sanm_graph sanm_graph;               /* ComputingGraph, libsanm/symbolic.h:283-293 */
+typedef struct sanm_sparse_desc sanm_sparse_desc;   /* SparseLinearDescCompressed, libsanm/anm.h:76-85 */
+typedef struct sanm_taylor_prop sanm_taylor_prop;   /* TaylorCoeffProp, libsanm/symbolic.h:337-383 */
+typedef struct sanm_anm_solver sanm_anm_solver;     /* ANM*Solver, libsanm/anm.h:209-305 */
+typedef struct sanm_fea_model sanm_fea_model;       /* ElasticForceModel, fea/mesh.h:149-226 */
+
+/* ---- context ----------------------------------------------------------- */
+/* select the device (one process per GPU); replaces sanm::set_num_threads
+ * (libsanm/tensor.cpp:86-94) as the place where parallel resources are bound */
+int sanm_hip_init(int device);
+const char* sanm_hip_last_error(void);
+const char* sanm_hip_backend_name(void);
+
+/* ---- operator API: libsanm/oprs.h:14-103, oprs.cpp:16-102 --------------- */
+/* variables are int ids local to the graph (VarNode*, symbolic.h:222-251) */
+int sanm_graph_create(sanm_graph** g);
+void sanm_graph_destroy(sanm_graph* g);
+int sanm_graph_placeholder(sanm_graph* g, int* var);                       /* oprs.h:80 */
+/* val: (batch, size) with size in {1,3,9}; batch is T or 1 */
+int sanm_graph_constant(sanm_graph* g, const double* val, int64_t batch, int size, int* var); /* oprs.h:88 */
+int sanm_graph_linear_combine(sanm_graph* g, int n, const double* coeffs, const int* vars,
+                              double bias, int* var);                     /* oprs.h:76-77 */
+int sanm_graph_multiply(sanm_graph* g, int a, int b, int* var);            /* SymbolVar::operator* */
+int sanm_graph_pow(sanm_graph* g, int x, double exponent, int* var);       /* SymbolVar::pow */
+int sanm_graph_log(sanm_graph* g, int x, int* var);                        /* SymbolVar::log */
+int sanm_graph_reduce_sum(sanm_graph* g, int x, int axis, int* var);       /* SymbolVar::reduce_sum */
+int sanm_graph_batched_matmul(sanm_graph* g, int a, int b, int* var);      /* SymbolVar::batched_matmul */
+/* a < 0 means "a is the identity" (oprs.h:66-71) */
+int sanm_graph_batched_mat_inv_mul(sanm_graph* g, int x, int a, int is_left, int* var);
+int sanm_graph_batched_det(sanm_graph* g, int x, int* var);                /* SymbolVar::batched_det */
+int sanm_graph_batched_transpose(sanm_graph* g, int x, int* var);          /* SymbolVar::batched_transpose */
+int sanm_graph_batched_mul_eye(sanm_graph* g, int x, int dim, int* var);   /* SymbolVar::batched_mul_eye */
+/* usw[3] = ids of U, S, W (SymbolVar::batched_svd_w, oprs.h:55) */
+int sanm_graph_batched_svd_w(sanm_graph* g, int x, int require_rotation, int usw[3]);
+
+/* ---- sparse remaps: libsanm/anm.h:24-85 --------------------------------- */
+/* CSR by output element: output i = sum_{p in [rowptr[i],rowptr[i+1])} coeff[p]*x[idx[p]] */
+int sanm_sparse_desc_create(int64_t out_size, int64_t in_size, const uint64_t* rowptr,
+                            const uint64_t* idx, const double* coeff, sanm_sparse_desc** d);
+void sanm_sparse_desc_destroy(sanm_sparse_desc* d);
+
+/* ---- TaylorCoeffProp on the device: libsanm/symbolic.h:337-383 ---------- */
+/* remap_inp maps the flat input vector to the (T,3,3) placeholder
+ * (SparseLinearDesc::apply is fused into the pass, libsanm/anm.cpp:55-75) */
+int sanm_taylor_create(const sanm_graph* g, int out_var, const sanm_sparse_desc* remap_inp,
+                       int max_order, sanm_taylor_prop** prop);
+void sanm_taylor_destroy(sanm_taylor_prop* p);
+/* push_xi (symbolic.cpp:162-204): x has remap_inp.in_size doubles; y_k (T,3,3) may be NULL */
+int sanm_taylor_push_xi(sanm_taylor_prop* p, const double* x, double* y_k);
+/* compute_next_order_bias (symbolic.cpp:249-289): bias (T,3,3) */
+int sanm_taylor_compute_next_order_bias(sanm_taylor_prop* p, double* bias);
+/* get_jacobian (symbolic.cpp:297-303): (T, 9, 9) = d out / d placeholder */
+int sanm_taylor_get_jacobian(sanm_taylor_prop* p, double* jac);
+/* coefficient `order` of any graph variable, (T, size); order < 0: current bias */
+int sanm_taylor_get_var(sanm_taylor_prop* p, int var, int order, double* dst);
+/* start over at order 0 (a new TaylorCoeffProp in the reference, anm.cpp:205) */
+int sanm_taylor_reset(sanm_taylor_prop* p);
+
+/* ---- ANM solvers: libsanm/anm.h:96-305 ---------------------------------- */
+typedef struct sanm_hyper_param { /* ANMDriverHelper::HyperParam, anm.h:100-114, :247-251 */
+    int use_pade;
+    int sanity_check;
+    int order;
+    double maxr;
+    double solution_check_tol;
+    double xcoeff_l2_penalty;
+    double converge_rms;
+    double solver_rtol; /* device linear solver: relative residual target */
+    int solver_maxit;
+    int solver_kind;    /* 0 = Jacobi-PCG */
+    int profile;        /* sync + time each phase (ScopedProfiler tags, utils.h:225-249) */
+} sanm_hyper_param;
+void sanm_hyper_param_default(sanm_hyper_param* hp, int eqn_solver);
+
+/* ANMEqnSolver: solve f(x) + y = 0 (anm.cpp:446-491) */
+int sanm_anm_eqn_solver_create(const sanm_graph* g, int out_var, const sanm_sparse_desc* remap_inp,
+                               const sanm_sparse_desc* remap_out, const double* x0, const double* y,
+                               int64_t n, const sanm_hyper_param* hp, sanm_anm_solver** s);
+/* ANMSolverVecScale: f(x) + t*v = 0 (anm.cpp:322-341) */
+int sanm_anm_vecscale_solver_create(const sanm_graph* g, int out_var,
+                                    const sanm_sparse_desc* remap_inp,
+                                    const sanm_sparse_desc* remap_out, const double* x0, double t0,
+                                    const double* v, int64_t n, const sanm_hyper_param* hp,
+                                    sanm_anm_solver** s);
+/* ANMImplicitSolver: F(x,t) = F(x0,t0) (anm.cpp:494-508); remap_inp has n+1 inputs */
+int sanm_anm_implicit_solver_create(const sanm_graph* g, int out_var,
+                                    const sanm_sparse_desc* remap_inp,
+                                    const sanm_sparse_desc* remap_out, const double* x0, double t0,
+                                    int64_t n, const sanm_hyper_param* hp, sanm_anm_solver** s);
+void sanm_anm_solver_destroy(sanm_anm_solver* s);
+
+int sanm_anm_next_iter(sanm_anm_solver* s);                      /* ANMEqnSolver::next_iter */
+int sanm_anm_update_approx(sanm_anm_solver* s);                  /* ANMDriverHelper::update_approx */
+/* begin a new solve from x0 on the same model: what constructing a new
+ * ANMEqnSolver does in the reference (fea/main.cpp:418), minus rebuilding the
+ * device program / CSR pattern, which depend on the mesh only */
+int sanm_anm_restart(sanm_anm_solver* s, const double* x0);
+/* measurement hook for bench.py: average duration (ms) of `reps` back-to-back
+ * launches of one kernel on the solver's own data, HIP events on its stream.
+ * kernel 0: Taylor pass (mode 0..3 = eval0/grad/bias/coeff at `order`),
+ * kernel 1: CSR SpMV, kernel 2: PCG SpMV+dot.  The solver state is clobbered:
+ * call sanm_anm_restart() afterwards. */
+int sanm_anm_time_kernel(sanm_anm_solver* s, int kernel, int reps, int mode, int order,
+                         double* avg_ms);
+int sanm_anm_converged(const sanm_anm_solver* s, int* flag);     /* ANMEqnSolver::converged */
+int sanm_anm_residual_rms(const sanm_anm_solver* s, double* r);  /* ANMEqnSolver::residual_rms */
+int sanm_anm_get_x(const sanm_anm_solver* s, double* x);         /* ANMEqnSolver::get_x (n) */
+int sanm_anm_get_t_upper(const sanm_anm_solver* s, double* t);   /* get_t_upper */
+int sanm_anm_get_t_max_a(const sanm_anm_solver* s, double* a);
+int sanm_anm_solve_a(const sanm_anm_solver* s, double t, double* a); /* solve_a */
+int sanm_anm_eval(const sanm_anm_solver* s, double a, double* x, double* t); /* eval */
+int sanm_anm_nr_iter(const sanm_anm_solver* s, int64_t* iter);   /* get_nr_ieter (sic), anm.h:139 */
+int sanm_anm_nr_xt_coeffs(const sanm_anm_solver* s, int* nr);
+int sanm_anm_xt_coeff(const sanm_anm_solver* s, int i, double* xt); /* xt_coeffs()[i], n+1 doubles */
+int sanm_anm_has_pade(const sanm_anm_solver* s, int* flag);
+/* statistics of the run so far */
+typedef struct sanm_anm_stats {
+    int64_t nr_unknown, nr_tet, jacobian_nnz, assembly_contribs;
+    int64_t nr_linear_solve, linear_iters_total, linear_iters_last;
+    double linear_relres_last;
+    double arena_bytes;
+} sanm_anm_stats;
+int sanm_anm_get_stats(const sanm_anm_solver* s, sanm_anm_stats* st);
+/* profile tags: returns the number of tags; names/seconds may be NULL */
+int sanm_anm_profile(const sanm_anm_solver* s, int max_tags, const char** names, double* seconds);
+/* per-order trace of the last expansion (needs hp.profile): |b_k|, |x_k|, t_k; returns count */
+int sanm_anm_trace(const sanm_anm_solver* s, int max_n, double* b_norm, double* x_norm, double* t);
+/* Jacobian CSR of the current step (SparseSolver contents, sparse_solver.cpp:327-421);
+ * pass NULL pointers to query sizes only */
+int sanm_anm_jacobian_csr(const sanm_anm_solver* s, int64_t* n, int64_t* nnz, uint32_t* rowptr,
+                          uint32_t* col, double* val);
+
+/* ---- fea model construction: fea/mesh_template.h, fea/material.cpp ------ */
+#define SANM_ENERGY_NEOHOOKEAN_I 0
+#define SANM_ENERGY_NEOHOOKEAN_C 1
+#define SANM_ENERGY_ARAP 2
+#define SANM_ENERGY_STVK_STRETCH 3
+/* DeformableBody::make_forward / make_inverse (fea/mesh_template.h:174-219):
+ * vertices (nv,3), tets (T,4) int32, fixed_mask (nv,3) uint8;
+ * init_vtx_coord, vtx_delta: (nv,3) or NULL */
+int sanm_fea_model_create(int64_t nv, const double* vertices, int64_t nr_tet, const int32_t* tets,
+                          const uint8_t* fixed_mask, int energy_model, double young, double poisson,
+                          int inverse, const double* init_vtx_coord, const double* vtx_delta,
+                          sanm_fea_model** m);
+void sanm_fea_model_destroy(sanm_fea_model* m);
+int sanm_fea_model_nr_unknown(const sanm_fea_model* m, int64_t* n);
+const sanm_graph* sanm_fea_model_graph(const sanm_fea_model* m);
+int sanm_fea_model_output_var(const sanm_fea_model* m);
+int sanm_fea_model_F_var(const sanm_fea_model* m);
+const sanm_sparse_desc* sanm_fea_model_remap_inp(const sanm_fea_model* m);
+const sanm_sparse_desc* sanm_fea_model_remap_out(const sanm_fea_model* m);
+int sanm_fea_model_x0(const sanm_fea_model* m, double* x0);                 /* lt_inp->x0() */
+/* MeshShapeMatTrans::copy_vtx_values (mesh_template.h:113-128): (nv,3) -> (n) */
+int sanm_fea_model_copy_vtx_values(const sanm_fea_model* m, const double* vtx_values, double* out);
+/* scatter unknowns back into a (nv,3) vertex array (replace_with_mask, fea/mesh.cpp:14-25) */
+int sanm_fea_model_scatter(const sanm_fea_model* m, const double* x, double* vertices_inout);
+/* sparse descriptor contents, for tests (pass NULL to query sizes) */
+int sanm_sparse_desc_get(const sanm_sparse_desc* d, int64_t* out_size, int64_t* in_size,
+                         int64_t* nnz, uint64_t* rowptr, uint64_t* idx, double* coeff);
+/* nodal gravity load (fea/main.cpp:1025-1036): f_load (nv,3) */
+int sanm_fea_gravity_load(int64_t nv, const double* vertices, int64_t nr_tet, const int32_t* tets,
+                          double density, const double g[3], double* f_load);
+/* setup_boundary_by_config (fea/main.cpp:921-982): filter_dir may be NULL */
+int sanm_fea_boundary_by_threshold(int64_t nv, const double* vertices, const uint8_t* is_surface,
+                                   const double proj_dir[3], double thresh,
+                                   const double* filter_dir, double filter_min, double filter_max,
+                                   uint8_t* fixed_mask);
+
+/* ---- host scalar helpers (exposed for tests): libsanm/unary_polynomial.h - */
+int sanm_poly_solve_eqn(const double* f, int n, double xmin, double xmax, double b, double eps,
+                        double* x);
+/* roots must hold n-1 doubles; *nr_roots < 0 if the iteration failed */
+int sanm_poly_real_roots(const double* f, int n, double* roots, int* nr_roots);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SANM_HIP_H */

@@ -1,0 +1,38 @@
+"""sanm_amd: MI355X-native ANM hot path of jia-kai/SANM.
+
+The package is a thin ctypes layer over ``libsanm_hip.so`` (hand-written HIP
+for gfx950 behind the C ABI in ``include/sanm_hip.h``).  There is no CPU
+fallback: loading fails loudly if the library has not been built and
+``get_api()`` fails if no HIP device is present.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+from . import api as _api
+from .api import (ANMEqnSolver, ANMImplicitSolver, ANMSolverVecScale, Api, SanmError,  # noqa: F401
+                  SanmAssertionError, SanmNumericalError, SanmUnsupportedError, SymbolVar,
+                  TaylorCoeffProp, batched_mat_inv_mul, constant, linear_combine, placeholder)
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsanm_hip.so")
+_API = None
+
+
+def load_library() -> ctypes.CDLL:
+    """dlopen the HIP product library (no device needed for this step)."""
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m sanm_amd.build` (needs hipcc). "
+            "sanm_amd has no CPU fallback.")
+    return ctypes.CDLL(LIB_PATH)
+
+
+def get_api(device: int = 0) -> Api:
+    """Load the library and bind HIP device ``device``; raises if there is no GPU."""
+    global _API
+    if _API is None:
+        a = Api(load_library())
+        a.init(device)
+        _API = a
+    return _API

@@ -1,0 +1,586 @@
+"""ctypes binding of the C ABI in include/sanm_hip.h, plus thin Python classes
+that mirror the reference's C++ interface for this path (same names and
+argument meaning): ``SymbolVar`` / ``ComputingGraph`` (libsanm/oprs.h),
+``TaylorCoeffProp`` (libsanm/symbolic.h:337-383), ``ANMEqnSolver`` /
+``ANMSolverVecScale`` / ``ANMImplicitSolver`` (libsanm/anm.h:209-305) and the
+fea model builders (fea/mesh_template.h:174-219).
+
+This module only talks to the shared library it is given; it contains no
+numerical fallback.  ``sanm_amd.get_api()`` loads the HIP product library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int)
+c_u64p = C.POINTER(C.c_uint64)
+c_u32p = C.POINTER(C.c_uint32)
+c_i32p = C.POINTER(C.c_int32)
+c_u8p = C.POINTER(C.c_uint8)
+
+
+class SanmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[sanm_hip error {code}] {msg}")
+        self.code = code
+        self.msg = msg
+
+
+class SanmAssertionError(SanmError):
+    """SANMAssertionError (libsanm/utils.h:34-50)"""
+
+
+class SanmNumericalError(SanmError):
+    """SANMNumericalError (libsanm/utils.h:34-50)"""
+
+
+class SanmUnsupportedError(SanmError):
+    pass
+
+
+_ERR = {1: SanmAssertionError, 2: SanmNumericalError, 4: SanmUnsupportedError}
+
+
+class HyperParamC(C.Structure):
+    _fields_ = [("use_pade", C.c_int), ("sanity_check", C.c_int), ("order", C.c_int),
+                ("maxr", C.c_double), ("solution_check_tol", C.c_double),
+                ("xcoeff_l2_penalty", C.c_double), ("converge_rms", C.c_double),
+                ("solver_rtol", C.c_double), ("solver_maxit", C.c_int), ("solver_kind", C.c_int),
+                ("profile", C.c_int)]
+
+
+class StatsC(C.Structure):
+    _fields_ = [("nr_unknown", C.c_int64), ("nr_tet", C.c_int64), ("jacobian_nnz", C.c_int64),
+                ("assembly_contribs", C.c_int64), ("nr_linear_solve", C.c_int64),
+                ("linear_iters_total", C.c_int64), ("linear_iters_last", C.c_int64),
+                ("linear_relres_last", C.c_double), ("arena_bytes", C.c_double)]
+
+
+ENERGY = {"neohookean_i": 0, "neohookean_c": 1, "arap": 2, "stvk_stretch": 3}
+
+# every symbol include/sanm_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "sanm_hip_init", "sanm_hip_last_error", "sanm_hip_backend_name",
+    "sanm_graph_create", "sanm_graph_destroy", "sanm_graph_placeholder", "sanm_graph_constant",
+    "sanm_graph_linear_combine", "sanm_graph_multiply", "sanm_graph_pow", "sanm_graph_log",
+    "sanm_graph_reduce_sum", "sanm_graph_batched_matmul", "sanm_graph_batched_mat_inv_mul",
+    "sanm_graph_batched_det", "sanm_graph_batched_transpose", "sanm_graph_batched_mul_eye",
+    "sanm_graph_batched_svd_w",
+    "sanm_sparse_desc_create", "sanm_sparse_desc_destroy", "sanm_sparse_desc_get",
+    "sanm_taylor_create", "sanm_taylor_destroy", "sanm_taylor_push_xi",
+    "sanm_taylor_compute_next_order_bias", "sanm_taylor_get_jacobian", "sanm_taylor_get_var",
+    "sanm_taylor_reset",
+    "sanm_hyper_param_default", "sanm_anm_eqn_solver_create", "sanm_anm_vecscale_solver_create",
+    "sanm_anm_implicit_solver_create", "sanm_anm_solver_destroy", "sanm_anm_next_iter",
+    "sanm_anm_update_approx", "sanm_anm_restart", "sanm_anm_time_kernel", "sanm_anm_converged", "sanm_anm_residual_rms", "sanm_anm_get_x",
+    "sanm_anm_get_t_upper", "sanm_anm_get_t_max_a", "sanm_anm_solve_a", "sanm_anm_eval",
+    "sanm_anm_nr_iter", "sanm_anm_nr_xt_coeffs", "sanm_anm_xt_coeff", "sanm_anm_has_pade",
+    "sanm_anm_get_stats", "sanm_anm_profile", "sanm_anm_trace", "sanm_anm_jacobian_csr",
+    "sanm_fea_model_create", "sanm_fea_model_destroy", "sanm_fea_model_nr_unknown",
+    "sanm_fea_model_graph", "sanm_fea_model_output_var", "sanm_fea_model_F_var",
+    "sanm_fea_model_remap_inp", "sanm_fea_model_remap_out", "sanm_fea_model_x0",
+    "sanm_fea_model_copy_vtx_values", "sanm_fea_model_scatter", "sanm_fea_gravity_load",
+    "sanm_fea_boundary_by_threshold", "sanm_poly_solve_eqn", "sanm_poly_real_roots",
+]
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_dp)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Api:
+    """One loaded shared library."""
+
+    def __init__(self, lib: C.CDLL):
+        self.lib = lib
+        lib.sanm_hip_last_error.restype = C.c_char_p
+        lib.sanm_hip_backend_name.restype = C.c_char_p
+        for name in ("sanm_fea_model_graph", "sanm_fea_model_remap_inp", "sanm_fea_model_remap_out"):
+            getattr(lib, name).restype = C.c_void_p
+        for name in SYMBOLS:
+            fn = getattr(lib, name)
+            if fn.restype is C.c_int and name.endswith("_destroy"):
+                fn.restype = None
+        self._initialised = False
+
+    # -- plumbing ---------------------------------------------------------
+    def check(self, rc):
+        if rc != 0:
+            msg = self.lib.sanm_hip_last_error().decode()
+            raise _ERR.get(rc, SanmError)(rc, msg)
+
+    def init(self, device=0):
+        self.check(self.lib.sanm_hip_init(C.c_int(device)))
+        self._initialised = True
+        return self
+
+    def backend_name(self):
+        return self.lib.sanm_hip_backend_name().decode()
+
+    # -- builders ---------------------------------------------------------
+    def graph(self):
+        return ComputingGraph(self)
+
+    def sparse_desc(self, mat):
+        return SparseLinearDesc(self, mat=mat)
+
+    def default_hyper(self, **kw):
+        hp = HyperParamC()
+        self.lib.sanm_hyper_param_default(C.byref(hp), 1)
+        for k, v in kw.items():
+            if not hasattr(hp, k):
+                raise AttributeError(k)
+            setattr(hp, k, v)
+        return hp
+
+    # -- host scalar helpers ----------------------------------------------
+    def poly_solve_eqn(self, f, xmin, xmax, b=0.0, eps=1e-6):
+        f = _f64(f)
+        out = C.c_double()
+        self.check(self.lib.sanm_poly_solve_eqn(_dp(f), C.c_int(f.size), C.c_double(xmin),
+                                                C.c_double(xmax), C.c_double(b), C.c_double(eps),
+                                                C.byref(out)))
+        return out.value
+
+    def poly_real_roots(self, f):
+        f = _f64(f)
+        roots = np.zeros(max(f.size, 1))
+        nr = C.c_int()
+        self.check(self.lib.sanm_poly_real_roots(_dp(f), C.c_int(f.size), _dp(roots), C.byref(nr)))
+        return None if nr.value < 0 else roots[:nr.value].copy()
+
+    # -- fea helpers --------------------------------------------------------
+    def gravity_load(self, vertices, tets, density, g):
+        V = _f64(vertices)
+        t = np.ascontiguousarray(tets, dtype=np.int32)
+        g = _f64(g)
+        out = np.zeros_like(V)
+        self.check(self.lib.sanm_fea_gravity_load(C.c_int64(V.shape[0]), _dp(V), C.c_int64(t.shape[0]),
+                                                  t.ctypes.data_as(c_i32p), C.c_double(density), _dp(g),
+                                                  _dp(out)))
+        return out
+
+    def boundary_by_threshold(self, vertices, surface_vtx, proj_dir, thresh, filter_dir=None,
+                              filter_min=0.0, filter_max=0.0):
+        V = _f64(vertices)
+        surf = np.zeros(V.shape[0], dtype=np.uint8)
+        surf[np.asarray(surface_vtx, dtype=np.int64)] = 1
+        pd = _f64(proj_dir)
+        fd = None if filter_dir is None else _f64(filter_dir)
+        out = np.zeros((V.shape[0], 3), dtype=np.uint8)
+        self.check(self.lib.sanm_fea_boundary_by_threshold(
+            C.c_int64(V.shape[0]), _dp(V), surf.ctypes.data_as(c_u8p), _dp(pd), C.c_double(thresh),
+            None if fd is None else _dp(fd), C.c_double(filter_min), C.c_double(filter_max),
+            out.ctypes.data_as(c_u8p)))
+        return out.astype(bool)
+
+    def fea_model(self, vertices, tets, fixed_mask, energy, young, poisson, inverse=False,
+                  init_vtx_coord=None, vtx_delta=None):
+        return FeaModel(self, vertices, tets, fixed_mask, energy, young, poisson, inverse,
+                        init_vtx_coord, vtx_delta)
+
+
+class SymbolVar:
+    """libsanm/oprs.h:14-63"""
+
+    def __init__(self, graph, vid):
+        self.graph = graph
+        self.id = int(vid)
+
+    def _mk(self, fn, *args):
+        out = C.c_int()
+        self.graph.api.check(fn(self.graph.h, *args, C.byref(out)))
+        return SymbolVar(self.graph, out.value)
+
+    def __add__(self, rhs):
+        if isinstance(rhs, SymbolVar):
+            return linear_combine([(1.0, self), (1.0, rhs)])
+        return linear_combine([(1.0, self)], float(rhs))
+
+    def __sub__(self, rhs):
+        if isinstance(rhs, SymbolVar):
+            return linear_combine([(1.0, self), (-1.0, rhs)])
+        return self + (-float(rhs))
+
+    def __rsub__(self, lhs):
+        return linear_combine([(-1.0, self)], float(lhs))
+
+    def __mul__(self, rhs):
+        lib = self.graph.api.lib
+        if isinstance(rhs, SymbolVar):
+            return self._mk(lib.sanm_graph_multiply, C.c_int(self.id), C.c_int(rhs.id))
+        return linear_combine([(float(rhs), self)], 0.0)
+
+    def reduce_sum(self, axis, keepdim=True):
+        return self._mk(self.graph.api.lib.sanm_graph_reduce_sum, C.c_int(self.id), C.c_int(axis))
+
+    def batched_transpose(self):
+        return self._mk(self.graph.api.lib.sanm_graph_batched_transpose, C.c_int(self.id))
+
+    def batched_matinv(self):
+        return batched_mat_inv_mul(self, None, True)
+
+    def batched_matmul(self, rhs):
+        return self._mk(self.graph.api.lib.sanm_graph_batched_matmul, C.c_int(self.id), C.c_int(rhs.id))
+
+    def batched_det(self):
+        return self._mk(self.graph.api.lib.sanm_graph_batched_det, C.c_int(self.id))
+
+    def batched_mul_eye(self, dim):
+        return self._mk(self.graph.api.lib.sanm_graph_batched_mul_eye, C.c_int(self.id), C.c_int(dim))
+
+    def pow(self, exp):
+        return self._mk(self.graph.api.lib.sanm_graph_pow, C.c_int(self.id), C.c_double(exp))
+
+    def log(self):
+        return self._mk(self.graph.api.lib.sanm_graph_log, C.c_int(self.id))
+
+    def batched_svd_w(self, require_rotation=False):
+        usw = (C.c_int * 3)()
+        self.graph.api.check(self.graph.api.lib.sanm_graph_batched_svd_w(
+            self.graph.h, C.c_int(self.id), C.c_int(1 if require_rotation else 0), usw))
+        return [SymbolVar(self.graph, usw[i]) for i in range(3)]
+
+
+def batched_mat_inv_mul(x, a, is_left):
+    """libsanm/oprs.h:66-71"""
+    return x._mk(x.graph.api.lib.sanm_graph_batched_mat_inv_mul, C.c_int(x.id),
+                 C.c_int(-1 if a is None else a.id), C.c_int(1 if is_left else 0))
+
+
+def linear_combine(vars_, bias=0.0):
+    """libsanm/oprs.h:76-77"""
+    g = vars_[0][1].graph
+    n = len(vars_)
+    cs = (C.c_double * n)(*[float(c) for c, _ in vars_])
+    vs = (C.c_int * n)(*[v.id for _, v in vars_])
+    out = C.c_int()
+    g.api.check(g.api.lib.sanm_graph_linear_combine(g.h, C.c_int(n), cs, vs, C.c_double(bias), C.byref(out)))
+    return SymbolVar(g, out.value)
+
+
+class ComputingGraph:
+    def __init__(self, api, handle=None, owned=True):
+        self.api = api
+        self.owned = owned
+        if handle is None:
+            h = C.c_void_p()
+            api.check(api.lib.sanm_graph_create(C.byref(h)))
+            handle = h
+        self.h = handle
+
+    def __del__(self):
+        if getattr(self, "owned", False) and self.h:
+            self.api.lib.sanm_graph_destroy(self.h)
+            self.h = None
+
+    def placeholder(self):
+        out = C.c_int()
+        self.api.check(self.api.lib.sanm_graph_placeholder(self.h, C.byref(out)))
+        return SymbolVar(self, out.value)
+
+    def constant(self, val):
+        val = _f64(val)
+        batch = val.shape[0]
+        size = int(np.prod(val.shape[1:]))
+        out = C.c_int()
+        self.api.check(self.api.lib.sanm_graph_constant(self.h, _dp(val), C.c_int64(batch),
+                                                        C.c_int(size), C.byref(out)))
+        return SymbolVar(self, out.value)
+
+
+def placeholder(cg):
+    return cg.placeholder()
+
+
+def constant(cg, val):
+    return cg.constant(val)
+
+
+class SparseLinearDesc:
+    """libsanm/anm.h:24-85; built from a scipy CSR matrix (out_size, in_size)."""
+
+    def __init__(self, api, mat=None, handle=None, owned=True):
+        self.api = api
+        self.owned = owned
+        if handle is not None:
+            self.h = handle
+            return
+        m = mat.tocsr()
+        m.sort_indices()
+        self.shape = m.shape
+        rp = np.ascontiguousarray(m.indptr, dtype=np.uint64)
+        ix = np.ascontiguousarray(m.indices, dtype=np.uint64)
+        cf = _f64(m.data)
+        h = C.c_void_p()
+        api.check(api.lib.sanm_sparse_desc_create(C.c_int64(m.shape[0]), C.c_int64(m.shape[1]),
+                                                  rp.ctypes.data_as(c_u64p), ix.ctypes.data_as(c_u64p),
+                                                  _dp(cf), C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        if getattr(self, "owned", False) and self.h:
+            self.api.lib.sanm_sparse_desc_destroy(self.h)
+            self.h = None
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        o, i, nnz = C.c_int64(), C.c_int64(), C.c_int64()
+        self.api.check(self.api.lib.sanm_sparse_desc_get(self.h, C.byref(o), C.byref(i), C.byref(nnz),
+                                                         None, None, None))
+        rp = np.zeros(o.value + 1, dtype=np.uint64)
+        ix = np.zeros(nnz.value, dtype=np.uint64)
+        cf = np.zeros(nnz.value)
+        self.api.check(self.api.lib.sanm_sparse_desc_get(self.h, None, None, None,
+                                                         rp.ctypes.data_as(c_u64p),
+                                                         ix.ctypes.data_as(c_u64p), _dp(cf)))
+        return sp.csr_matrix((cf, ix.astype(np.int64), rp.astype(np.int64)), shape=(o.value, i.value))
+
+
+class TaylorCoeffProp:
+    """libsanm/symbolic.h:337-383 on the device."""
+
+    def __init__(self, api, y: SymbolVar, remap_inp: SparseLinearDesc, max_order, nr_tet):
+        self.api = api
+        self.T = int(nr_tet)
+        h = C.c_void_p()
+        api.check(api.lib.sanm_taylor_create(y.graph.h, C.c_int(y.id), remap_inp.h, C.c_int(max_order),
+                                             C.byref(h)))
+        self.h = h
+        self._keep = (y.graph, remap_inp)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.api.lib.sanm_taylor_destroy(self.h)
+            self.h = None
+
+    def push_xi(self, x):
+        x = _f64(x).ravel()
+        y = np.zeros((self.T, 3, 3))
+        self.api.check(self.api.lib.sanm_taylor_push_xi(self.h, _dp(x), _dp(y)))
+        return y
+
+    def compute_next_order_bias(self):
+        b = np.zeros((self.T, 3, 3))
+        self.api.check(self.api.lib.sanm_taylor_compute_next_order_bias(self.h, _dp(b)))
+        return b
+
+    def get_jacobian(self):
+        j = np.zeros((self.T, 9, 9))
+        self.api.check(self.api.lib.sanm_taylor_get_jacobian(self.h, _dp(j)))
+        return j
+
+    def get_var(self, var: SymbolVar, order, size):
+        out = np.zeros((self.T, size))
+        self.api.check(self.api.lib.sanm_taylor_get_var(self.h, C.c_int(var.id), C.c_int(order), _dp(out)))
+        return out
+
+    def reset(self):
+        self.api.check(self.api.lib.sanm_taylor_reset(self.h))
+
+
+class _ANMSolver:
+    def __init__(self, api):
+        self.api = api
+        self.h = C.c_void_p()
+        self._keep = None
+        self.n = 0
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.api.lib.sanm_anm_solver_destroy(self.h)
+            self.h = None
+
+    def _get(self, fn, ctype):
+        out = ctype()
+        self.api.check(fn(self.h, C.byref(out)))
+        return out.value
+
+    # ANMDriverHelper (libsanm/anm.h:116-139)
+    def update_approx(self):
+        self.api.check(self.api.lib.sanm_anm_update_approx(self.h))
+
+    def get_t_upper(self):
+        return self._get(self.api.lib.sanm_anm_get_t_upper, C.c_double)
+
+    def get_t_max_a(self):
+        return self._get(self.api.lib.sanm_anm_get_t_max_a, C.c_double)
+
+    def solve_a(self, t):
+        out = C.c_double()
+        self.api.check(self.api.lib.sanm_anm_solve_a(self.h, C.c_double(t), C.byref(out)))
+        return out.value
+
+    def eval(self, a):
+        x = np.zeros(self.n)
+        t = C.c_double()
+        self.api.check(self.api.lib.sanm_anm_eval(self.h, C.c_double(a), _dp(x), C.byref(t)))
+        return x, t.value
+
+    def get_nr_iter(self):
+        return self._get(self.api.lib.sanm_anm_nr_iter, C.c_int64)
+
+    def xt_coeffs(self):
+        nr = self._get(self.api.lib.sanm_anm_nr_xt_coeffs, C.c_int)
+        out = []
+        for i in range(nr):
+            v = np.zeros(self.n + 1)
+            self.api.check(self.api.lib.sanm_anm_xt_coeff(self.h, C.c_int(i), _dp(v)))
+            out.append(v)
+        return out
+
+    def has_pade(self):
+        return bool(self._get(self.api.lib.sanm_anm_has_pade, C.c_int))
+
+    def stats(self):
+        st = StatsC()
+        self.api.check(self.api.lib.sanm_anm_get_stats(self.h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in StatsC._fields_}
+
+    def profile(self):
+        n = self.api.lib.sanm_anm_profile(self.h, C.c_int(0), None, None)
+        names = (C.c_char_p * max(n, 1))()
+        secs = (C.c_double * max(n, 1))()
+        n = self.api.lib.sanm_anm_profile(self.h, C.c_int(n), names, secs)
+        return {names[i].decode(): secs[i] for i in range(n)}
+
+    def trace(self):
+        n = self.api.lib.sanm_anm_trace(self.h, C.c_int(0), None, None, None)
+        b, x, t = np.zeros(max(n, 1)), np.zeros(max(n, 1)), np.zeros(max(n, 1))
+        n = self.api.lib.sanm_anm_trace(self.h, C.c_int(n), _dp(b), _dp(x), _dp(t))
+        return {"b_norm": b[:n].tolist(), "x_norm": x[:n].tolist(), "t": t[:n].tolist()}
+
+    def time_kernel(self, kernel, reps, mode=2, order=1):
+        out = C.c_double()
+        self.api.check(self.api.lib.sanm_anm_time_kernel(self.h, C.c_int(kernel), C.c_int(reps), C.c_int(mode),
+                                                         C.c_int(order), C.byref(out)))
+        return out.value
+
+    def jacobian_csr(self):
+        import scipy.sparse as sp
+        n, nnz = C.c_int64(), C.c_int64()
+        self.api.check(self.api.lib.sanm_anm_jacobian_csr(self.h, C.byref(n), C.byref(nnz), None, None, None))
+        rp = np.zeros(n.value + 1, dtype=np.uint32)
+        col = np.zeros(nnz.value, dtype=np.uint32)
+        val = np.zeros(nnz.value)
+        self.api.check(self.api.lib.sanm_anm_jacobian_csr(self.h, None, None, rp.ctypes.data_as(c_u32p),
+                                                          col.ctypes.data_as(c_u32p), _dp(val)))
+        return sp.csr_matrix((val, col.astype(np.int64), rp.astype(np.int64)), shape=(n.value, n.value))
+
+
+class ANMEqnSolver(_ANMSolver):
+    """libsanm/anm.h:245-283"""
+
+    def __init__(self, api, y: SymbolVar, remap_inp, remap_out, x0, f_y, hyper):
+        super().__init__(api)
+        x0, f_y = _f64(x0).ravel(), _f64(f_y).ravel()
+        self.n = x0.size
+        self._keep = (y.graph, remap_inp, remap_out)
+        api.check(api.lib.sanm_anm_eqn_solver_create(y.graph.h, C.c_int(y.id), remap_inp.h, remap_out.h,
+                                                     _dp(x0), _dp(f_y), C.c_int64(self.n),
+                                                     C.byref(hyper), C.byref(self.h)))
+
+    def next_iter(self):
+        self.api.check(self.api.lib.sanm_anm_next_iter(self.h))
+        return self
+
+    def converged(self):
+        return bool(self._get(self.api.lib.sanm_anm_converged, C.c_int))
+
+    def residual_rms(self):
+        return self._get(self.api.lib.sanm_anm_residual_rms, C.c_double)
+
+    def restart(self, x0):
+        x0 = _f64(x0).ravel()
+        self.api.check(self.api.lib.sanm_anm_restart(self.h, _dp(x0)))
+        return self
+
+    def get_x(self):
+        x = np.zeros(self.n)
+        self.api.check(self.api.lib.sanm_anm_get_x(self.h, _dp(x)))
+        return x
+
+
+class ANMSolverVecScale(_ANMSolver):
+    """libsanm/anm.h:209-243"""
+
+    def __init__(self, api, y, remap_inp, remap_out, x0, t0, v, hyper):
+        super().__init__(api)
+        x0, v = _f64(x0).ravel(), _f64(v).ravel()
+        self.n = x0.size
+        self._keep = (y.graph, remap_inp, remap_out)
+        api.check(api.lib.sanm_anm_vecscale_solver_create(
+            y.graph.h, C.c_int(y.id), remap_inp.h, remap_out.h, _dp(x0), C.c_double(t0), _dp(v),
+            C.c_int64(self.n), C.byref(hyper), C.byref(self.h)))
+
+
+class ANMImplicitSolver(_ANMSolver):
+    """libsanm/anm.h:285-305"""
+
+    def __init__(self, api, y, remap_inp, remap_out, x0, t0, hyper):
+        super().__init__(api)
+        x0 = _f64(x0).ravel()
+        self.n = x0.size
+        self._keep = (y.graph, remap_inp, remap_out)
+        api.check(api.lib.sanm_anm_implicit_solver_create(
+            y.graph.h, C.c_int(y.id), remap_inp.h, remap_out.h, _dp(x0), C.c_double(t0),
+            C.c_int64(self.n), C.byref(hyper), C.byref(self.h)))
+
+
+class FeaModel:
+    """ElasticForceModel (fea/mesh.h:149-226) built by make_forward / make_inverse."""
+
+    def __init__(self, api, vertices, tets, fixed_mask, energy, young, poisson, inverse,
+                 init_vtx_coord, vtx_delta):
+        self.api = api
+        V = _f64(vertices)
+        t = np.ascontiguousarray(tets, dtype=np.int32)
+        fm = np.ascontiguousarray(fixed_mask, dtype=np.uint8)
+        assert V.shape[1] == 3 and t.shape[1] == 4 and fm.shape == V.shape
+        iv = None if init_vtx_coord is None else _f64(init_vtx_coord)
+        vd = None if vtx_delta is None else _f64(vtx_delta)
+        h = C.c_void_p()
+        api.check(api.lib.sanm_fea_model_create(
+            C.c_int64(V.shape[0]), _dp(V), C.c_int64(t.shape[0]), t.ctypes.data_as(c_i32p),
+            fm.ctypes.data_as(c_u8p), C.c_int(ENERGY[energy]), C.c_double(young), C.c_double(poisson),
+            C.c_int(1 if inverse else 0), None if iv is None else _dp(iv),
+            None if vd is None else _dp(vd), C.byref(h)))
+        self.h = h
+        self.nv, self.T = V.shape[0], t.shape[0]
+        n = C.c_int64()
+        api.check(api.lib.sanm_fea_model_nr_unknown(h, C.byref(n)))
+        self.n = n.value
+        self.cg = ComputingGraph(api, C.c_void_p(api.lib.sanm_fea_model_graph(h)), owned=False)
+        self.y = SymbolVar(self.cg, api.lib.sanm_fea_model_output_var(h))
+        self.F = SymbolVar(self.cg, api.lib.sanm_fea_model_F_var(h))
+        self.lt_inp = SparseLinearDesc(api, handle=C.c_void_p(api.lib.sanm_fea_model_remap_inp(h)), owned=False)
+        self.lt_out = SparseLinearDesc(api, handle=C.c_void_p(api.lib.sanm_fea_model_remap_out(h)), owned=False)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.api.lib.sanm_fea_model_destroy(self.h)
+            self.h = None
+
+    def x0(self):
+        x = np.zeros(self.n)
+        self.api.check(self.api.lib.sanm_fea_model_x0(self.h, _dp(x)))
+        return x
+
+    def copy_vtx_values(self, vtx_values):
+        v = _f64(vtx_values)
+        out = np.zeros(self.n)
+        self.api.check(self.api.lib.sanm_fea_model_copy_vtx_values(self.h, _dp(v), _dp(out)))
+        return out
+
+    def full_vertices(self, x, base):
+        out = _f64(base).copy()
+        x = _f64(x)
+        self.api.check(self.api.lib.sanm_fea_model_scatter(self.h, _dp(x), _dp(out)))
+        return out

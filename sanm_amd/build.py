@@ -1,0 +1,62 @@
+"""Build libsanm_hip.so (gfx950) in-tree with hipcc.
+
+Usage: python -m sanm_amd.build [--force]
+The .so is git-ignored but travels to the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libsanm_hip.so")
+SOURCES = ["graph.cpp", "sparse.cpp", "backend_common.cpp", "poly.cpp", "anm.cpp", "fea.cpp",
+           "capi.cpp", "backend_hip.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-fno-gpu-rdc"]
+
+
+def _newer(src_list, target):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in src_list)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(HERE, "..", "include", "sanm_hip.h"))
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    objs, jobs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, s + ".o")
+        objs.append(obj)
+        if force or _newer([src] + hdrs, obj):
+            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+            jobs.append(cmd)
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("build failed: %s\n%s" % (" ".join(cmd), r.stderr))
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for err in ex.map(run, jobs):
+            if verbose and err:
+                print(err)
+    if jobs or not os.path.exists(OUT):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", OUT] + objs)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,541 @@
+#include "anm.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <limits>
+
+#include "poly.h"
+
+namespace sanm_hip {
+
+// ------------------------------------------------------------ profiling --
+class AnmDriver::ScopedTimer {
+    AnmDriver* m_d;
+    const char* m_tag;
+    std::chrono::steady_clock::time_point m_t0;
+
+public:
+    ScopedTimer(AnmDriver* d, const char* tag) : m_d{d}, m_tag{tag} {
+        if (m_d->m_hp.profile) {
+            m_d->m_be->sync();
+            m_t0 = std::chrono::steady_clock::now();
+        }
+    }
+    ~ScopedTimer() {
+        if (m_d->m_hp.profile) {
+            m_d->m_be->sync();
+            m_d->m_profile[m_tag] +=
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - m_t0).count();
+        }
+    }
+};
+
+// ------------------------------------------------------------------ PCG --
+namespace {
+class PcgSolver final : public LinearSolver {
+    Backend* m_be;
+    const JacobianPattern& m_pat;
+    const HyperParam m_hp;
+    DVec m_dinv;
+    double m_sign = -1;
+
+public:
+    PcgSolver(Backend* be, const JacobianPattern& pat, const HyperParam& hp)
+            : m_be{be}, m_pat{pat}, m_hp{hp}, m_dinv{be, (size_t)pat.n()} {}
+
+    void prepare() override {
+        // dinv = 1/diag(A); a definite matrix has a diagonal of one sign, which
+        // tells which of +A / -A conjugate gradients must run on
+        CsrDev A = m_pat.csr();
+        m_be->csr_inv_diag(A, 1.0, m_dinv.p());
+        double first;
+        m_be->d2h(&first, m_dinv.p(), 8);
+        m_sign = first < 0 ? -1.0 : 1.0;
+        if (m_sign < 0) m_be->axpby(A.n, -1.0, m_dinv.p(), 0, nullptr, m_dinv.p());
+    }
+
+    void solve(const double* b, double* x) override {
+        int iters = 0;
+        double relres = 0;
+        m_be->pcg(m_pat.csr(), m_sign, m_dinv.p(), b, x, m_hp.solver_rtol, m_hp.solver_maxit, &iters,
+                  &relres);
+        if (iters < 0) {
+            sanm_throw(SANM_ERR_NUMERICAL,
+                       "PCG breakdown after %d iterations: the Jacobian is not definite (use the "
+                       "direct solver)",
+                       -iters);
+        }
+        if (!(relres <= std::max(m_hp.solver_rtol * 100, 1e-8))) {
+            sanm_throw(SANM_ERR_NUMERICAL, "PCG did not converge: %d iterations, relres=%g", iters,
+                       relres);
+        }
+        ++nr_solve;
+        tot_iters += iters;
+        last_iters = iters;
+        last_relres = relres;
+    }
+};
+}  // namespace
+
+std::unique_ptr<LinearSolver> make_pcg_solver(Backend* be, const JacobianPattern& pat,
+                                              const HyperParam& hp) {
+    return std::make_unique<PcgSolver>(be, pat, hp);
+}
+
+// ----------------------------------------------------------------- Pade --
+PadeApproximation::PadeApproximation(Backend* be, const std::vector<DVec>& xs, bool anm_cond)
+        : m_be{be}, m_xs{xs}, m_len{xs[0].size()} {
+    // libsanm/pade.cpp:13-105
+    const int nx = xs.size();
+    sanm_check(nx >= 3, "pade needs at least 3 terms");
+    if (m_len < (size_t)nx * 2 || nx <= 4) return;
+    const int n = nx - 1;
+    std::vector<double> a((size_t)nx * nx, 0.0);
+    auto A = [&](int i, int j) -> double& { return a[(size_t)i * nx + j]; };
+    const double eps = std::numeric_limits<double>::epsilon();
+    std::vector<DVec> orth(nx);
+    for (int i = 1; i <= n; ++i) {
+        DVec uii{be, m_len};
+        be->d2d(uii.p(), xs[i].p(), m_len * 8);
+        // classical Gram-Schmidt: the projections use xs[i], not the running uii
+        for (int j = 1; j < i; ++j) {
+            A(i, j) = be->dot(m_len, xs[i].p(), orth[j].p());
+            if (anm_cond && j == 1) {
+                sanm_check(std::fabs(A(i, j)) < 1e-4, "pade: anm condition violated: %g", A(i, j));
+                A(i, j) = 0;
+            } else {
+                be->axpby(m_len, 1.0, uii.p(), -A(i, j), orth[j].p(), uii.p());
+            }
+        }
+        double aii = std::sqrt(be->dot(m_len, uii.p(), uii.p()));
+        if (aii == 0) {
+            m_d.clear();
+            return;
+        }
+        A(i, i) = aii;
+        be->axpby(m_len, 1.0 / std::max(aii, eps), uii.p(), 0, nullptr, uii.p());
+        if (aii < eps) {
+            double nn = std::sqrt(be->dot(m_len, uii.p(), uii.p()));
+            be->axpby(m_len, 1.0 / nn, uii.p(), 0, nullptr, uii.p());
+        }
+        orth[i] = std::move(uii);
+    }
+    auto solve_d = [&](std::vector<double>& d, int nn) {
+        d.assign(nn, 0.0);
+        d[0] = 1;
+        for (int i = 1; i < nn; ++i) {
+            double s = 0;
+            for (int j = 0; j < i; ++j) s += A(nn - j, nn - i) * d[j];
+            double y = A(nn - i, nn - i);
+            d[i] = -s * y / (y * y + 1e-20);
+        }
+    };
+    solve_d(m_d, n);
+    solve_d(m_d_lo, n - 1);
+    m_t_nume.assign(n, 0.0);
+    for (int i = 0; i < n; ++i) {
+        double ti;
+        be->d2h(&ti, xs[i].p() + (m_len - 1), 8);
+        if (!i) {
+            m_t0 = ti;
+        } else {
+            for (int j = 0; j < n - i; ++j) m_t_nume[i + j] += m_d[j] * ti;
+        }
+    }
+}
+
+void PadeApproximation::eval_nume(double a, const double* d, int n, double* out) const {
+    // libsanm/pade.cpp:181-189
+    m_be->zero(out, m_len * 8);
+    for (int i = n; i >= 1; --i) {
+        double scale = poly::eval(d, n - i + 1, a);
+        m_be->axpby(m_len, a, out, scale, m_xs[i].p(), out);
+    }
+}
+
+double PadeApproximation::eval_t(double a) const {
+    return poly::eval(m_t_nume, a) / poly::eval(m_d, a) + m_t0;
+}
+
+bool PadeApproximation::estimate_valid_range(double start, double eps, double limit) {
+    // libsanm/pade.cpp:107-173
+    sanm_check(start > 0 && eps > 0, "pade: bad start/eps");
+    if (m_d.empty()) return false;
+    std::vector<double> roots;
+    if (!poly::real_roots(m_d, roots)) return false;
+    double pole = 0;
+    for (double r : roots)
+        if (r > 0 && (pole == 0 || r < pole)) pole = r;
+    if (pole == 0) pole = start * 4;
+    if (pole <= start) return false;
+
+    const int n = (int)m_xs.size() - 2;
+    const double eps2 = eps * eps;
+    DVec pn{m_be, m_len}, pn_lo{m_be, m_len};
+    auto check = [&](double a) {
+        double denom_n = poly::eval(m_d, a), denom_lo = poly::eval(m_d_lo, a);
+        eval_nume(a, m_d.data(), n, pn.p());
+        eval_nume(a, m_d_lo.data(), n - 1, pn_lo.p());
+        m_be->axpby(m_len, denom_n / denom_lo, pn_lo.p(), -1.0, pn.p(), pn_lo.p());
+        return m_be->dot(m_len, pn_lo.p(), pn_lo.p()) <= m_be->dot(m_len, pn.p(), pn.p()) * eps2;
+    };
+    double left = start * 1.001, right = start + (pole - start) * 0.99;
+    if (!check(left)) return false;
+    if (limit && right > limit) right = limit;
+    if (right > start * 2) {
+        if (check(start * 2)) left = start * 2;
+        else right = start * 2;
+    }
+    int iter = 0;
+    while (iter < 8 && right - left > 1e-3) {
+        double mid = (left + right) / 2;
+        if (check(mid)) left = mid;
+        else right = mid;
+        ++iter;
+    }
+    m_t_max_a = left;
+    m_t_max = eval_t(left);
+    return true;
+}
+
+double PadeApproximation::solve_a(double t) const {
+    // libsanm/pade.cpp:191-201
+    sanm_check(t >= m_t0 && t <= m_t_max, "pade solve_a: t=%g out of [%g, %g]", t, m_t0, m_t_max);
+    if (t == m_t_max) return m_t_max_a;
+    std::vector<double> c = m_t_nume;
+    for (size_t i = 0; i < c.size(); ++i) c[i] -= (t - m_t0) * m_d[i];
+    return poly::solve_eqn(c, 0, m_t_max_a, 0);
+}
+
+void PadeApproximation::eval_xt(double a, double* out) const {
+    // libsanm/pade.cpp:214-219
+    eval_nume(a, m_d.data(), (int)m_xs.size() - 2, out);
+    m_be->axpby(m_len, a / poly::eval(m_d, a), out, 1.0, m_xs[0].p(), out);
+}
+
+// ------------------------------------------------------------ AnmDriver --
+AnmDriver::AnmDriver(Backend* be, const Graph& g, int out_var, const SparseDesc& remap_inp,
+                     const SparseDesc& remap_out, int64_t nr_unknown, const HyperParam& hp)
+        : m_be{be}, m_hp{hp}, m_n{nr_unknown}, m_max_a_bound{poly::stable_x_range(hp.order)} {
+    sanm_check(hp.order >= 2, "order=%d", hp.order);  // anm.cpp:108-110
+    sanm_check(remap_inp.out_size % 9 == 0, "remap_inp must produce a (T,3,3) tensor");
+    if (hp.xcoeff_l2_penalty != 0)
+        sanm_throw(SANM_ERR_UNSUPPORTED, "xcoeff_l2_penalty (Tikhonov path) is not on the device path");
+    const int64_t T = remap_inp.out_size / 9;
+    m_prog = std::make_unique<Program>(be, g, out_var, T, hp.order);
+    m_prog->set_remap_in(remap_inp.in_size, remap_inp.rowptr.data(), remap_inp.idx.data(),
+                         remap_inp.coef.data());
+    m_remap_out = std::make_unique<DeviceRows>(be, remap_out, T, m_prog->Tpad());
+    m_pattern = std::make_unique<JacobianPattern>(be, remap_out, remap_inp, m_n, T, m_prog->Tpad(),
+                                                  m_prog->dev().odim);
+    m_solver = make_pcg_solver(be, *m_pattern, hp);
+    const size_t n1 = m_n + 1;
+    m_xt0 = DVec{be, n1};
+    m_fx0 = DVec{be, (size_t)m_n};
+    m_bi = DVec{be, (size_t)m_n};
+    m_xbi = DVec{be, (size_t)m_n};
+    m_xgt = DVec{be, (size_t)m_n};
+    m_grad_t_buf = DVec{be, (size_t)m_n};
+    m_tmp0 = DVec{be, n1};
+    m_tmp1 = DVec{be, n1};
+    m_xt_coeffs.resize(hp.order + 1);
+    for (auto& v : m_xt_coeffs) v = DVec{be, n1};
+}
+
+AnmDriver::~AnmDriver() = default;
+
+void AnmDriver::init_xt0(const double* x_host, double t) {
+    std::vector<double> h(m_n + 1);
+    std::copy(x_host, x_host + m_n, h.begin());
+    h[m_n] = t;
+    m_be->h2d(m_xt0.p(), h.data(), h.size() * 8);
+}
+
+void AnmDriver::solve_expansion_coeffs() {
+    // libsanm/anm.cpp:193-312
+    ScopedTimer timer_all{this, "solve_expansion_coeffs"};
+    const int N = m_hp.order;
+    const size_t n = m_n, n1 = m_n + 1;
+    Backend* be = m_be;
+    ProgramDev P = m_prog->dev();
+
+    be->d2d(m_xt_coeffs[0].p(), m_xt0.p(), n1 * 8);
+    m_nr_valid_coeffs = 1;
+    m_t_coeffs.assign(1, 0.0);
+    be->d2h(&m_t_coeffs[0], m_xt0.p() + n, 8);
+    trace_b_norm.clear();
+    trace_x_norm.clear();
+    trace_t.clear();
+
+    {
+        ScopedTimer t{this, "taylor_order0"};
+        be->run_pass(P, PASS_EVAL0, 0, m_xt0.p());
+        be->gather_rows(m_remap_out->dev(), m_prog->out_coef0(), m_fx0.p());
+    }
+    if (!on_fx0_computed(m_fx0.p())) return;
+
+    double t1 = 0, xgt_dot_x1 = 0;
+    const double* grad_t = nullptr;
+    for (int i = 1; i <= N; ++i) {
+        if (i == 1) {
+            ScopedTimer t{this, "jacobian"};
+            m_prog->zero_jacobians();
+            be->run_pass(P, PASS_GRAD, 0, nullptr);
+        }
+        {
+            ScopedTimer t{this, "taylor_next_order"};
+            be->run_pass(P, PASS_BIAS, i, nullptr);
+            be->gather_rows(m_remap_out->dev(), m_prog->out_bias(), m_bi.p());
+        }
+        double ti;
+        const double* xbi;
+        if (i == 1) {
+            {
+                ScopedTimer t{this, "build_sparse_coeff"};
+                be->assemble(m_pattern->assembly(), m_prog->placeholder_jac(), m_pattern->csr().val);
+                if (m_pattern->has_t())
+                    be->assemble(m_pattern->assembly_grad_t(), m_prog->placeholder_jac(),
+                                 m_grad_t_buf.p());
+                sanm_check(be->count_nonfinite(m_pattern->nnz(), m_pattern->csr().val) == 0,
+                           "non-finite Jacobian coefficient");  // sparse_solver.cpp:288-289
+            }
+            grad_t = get_grad_t();
+            {
+                ScopedTimer t{this, "sparse_prep"};
+                m_solver->prepare();
+            }
+            {
+                ScopedTimer t{this, "sparse_solve"};
+                m_solver->solve(grad_t, m_xgt.p());
+            }
+            xbi = m_bi.p();  // zero at first order (anm.cpp:235)
+            t1 = ti = 1.0 / std::sqrt(be->dot(n, m_xgt.p(), m_xgt.p()) + 1.0);
+        } else {
+            {
+                ScopedTimer t{this, "sparse_solve"};
+                sanm_check(be->count_nonfinite(n, m_bi.p()) == 0,
+                           "non-finite right-hand side at order %d", i);  // sparse_solver.cpp:160-161
+                m_solver->solve(m_bi.p(), m_xbi.p());
+            }
+            xbi = m_xbi.p();
+            ti = be->dot(n, xbi, m_xt_coeffs[1].p()) / (t1 - xgt_dot_x1);
+        }
+        // x_i = -ti*xgt - xbi ; t_i appended  (anm.cpp:261-264)
+        double* xi = m_xt_coeffs[i].p();
+        be->axpby(n, -ti, m_xgt.p(), -1.0, xbi, xi);
+        be->h2d(xi + n, &ti, 8);
+        m_nr_valid_coeffs = i + 1;
+        if (i == 1) xgt_dot_x1 = be->dot(n, xi, m_xgt.p());
+
+        if (m_hp.sanity_check) {
+            // anm.cpp:271-285
+            ScopedTimer t{this, "anm_sanity_check"};
+            be->spmv(m_pattern->csr(), xi, m_tmp0.p());
+            be->axpby(n, -ti, grad_t, -1.0, m_bi.p(), m_tmp1.p());
+            double ex = be->allclose_excess(n, m_tmp0.p(), m_tmp1.p(), 1e-4);
+            sanm_check(ex < 0, "ANM check coeff eqn: order %d: excess %g", i, ex);
+            double xdot = be->dot(n1, m_xt_coeffs[1].p(), xi);
+            if (i == 1) sanm_check(std::fabs(xdot - 1) < 1e-4, "xdot=%g", xdot);
+            else sanm_check(std::fabs(xdot) < 1e-4, "i=%d: xdot=%g", i, xdot);
+        }
+        if (m_hp.profile) {
+            trace_b_norm.push_back(std::sqrt(be->dot(n, m_bi.p(), m_bi.p())));
+            trace_x_norm.push_back(std::sqrt(be->dot(n1, xi, xi)));
+            trace_t.push_back(ti);
+        }
+        if (i < N) {
+            ScopedTimer t{this, "taylor_push"};
+            be->run_pass(P, PASS_COEFF, i, xi);
+        }
+    }
+    {
+        ScopedTimer t{this, "estimate_valid_range"};
+        estimate_valid_range();
+    }
+    ++m_iter;
+}
+
+void AnmDriver::estimate_valid_range() {
+    // libsanm/anm.cpp:117-154
+    const size_t n1 = m_n + 1;
+    const int N = m_hp.order;
+    double x1 = std::sqrt(m_be->dot(n1, m_xt_coeffs[1].p(), m_xt_coeffs[1].p()));
+    double xback = std::max(std::sqrt(m_be->dot(n1, m_xt_coeffs[N].p(), m_xt_coeffs[N].p())), 1e-15);
+    double a_bound = std::pow(m_hp.maxr / xback * x1, 1.0 / double(N - 1));
+    a_bound = std::min(a_bound, m_max_a_bound);
+    m_t_coeffs.resize(N + 1);
+    for (int i = 0; i <= N; ++i) m_be->d2h(&m_t_coeffs[i], m_xt_coeffs[i].p() + m_n, 8);
+    sanm_check(m_t_coeffs[1] > 0, "t1=%g is not positive", m_t_coeffs[1]);
+    m_t_max_a = a_bound;
+    m_t_max = poly::eval(m_t_coeffs, a_bound);
+    sanm_check(m_t_max > m_t_coeffs[0], "t does not incr at iter %zu: t0=%g tmax=%g bound=%g", m_iter,
+               m_t_coeffs[0], m_t_max, a_bound);
+    m_pade.reset();
+    static const bool env_pade = getenv("SANM_PADE") != nullptr;
+    if ((m_hp.use_pade || env_pade) && a_bound < m_max_a_bound) {
+        auto pade = std::make_unique<PadeApproximation>(m_be, m_xt_coeffs, !m_hp.xcoeff_l2_penalty);
+        if (pade->estimate_valid_range(a_bound, m_hp.maxr, m_max_a_bound)) {
+            m_t_max_a = pade->get_t_max_a();
+            m_t_max = pade->get_t_max();
+            m_pade = std::move(pade);
+        }
+    }
+}
+
+void AnmDriver::update_approx() {
+    // libsanm/anm.cpp:156-159
+    eval_xt(m_t_max_a, m_tmp0.p());
+    m_be->d2d(m_xt0.p(), m_tmp0.p(), (m_n + 1) * 8);
+    solve_expansion_coeffs();
+}
+
+void AnmDriver::eval_xt(double a, double* out) const {
+    // libsanm/anm.cpp:166-172; unary_polynomial::eval_tensor :115-126
+    if (m_pade) {
+        m_pade->eval_xt(a, out);
+        return;
+    }
+    const size_t n1 = m_n + 1;
+    const int N = m_nr_valid_coeffs - 1;
+    m_be->d2d(out, m_xt_coeffs[N].p(), n1 * 8);
+    for (int i = N - 1; i >= 0; --i) m_be->axpby(n1, a, out, 1.0, m_xt_coeffs[i].p(), out);
+}
+
+double AnmDriver::eval(double a, double* x_host) const {
+    eval_xt(a, m_tmp1.p());
+    std::vector<double> h(m_n + 1);
+    m_be->d2h(h.data(), m_tmp1.p(), h.size() * 8);
+    std::copy(h.begin(), h.begin() + m_n, x_host);
+    return h[m_n];
+}
+
+double AnmDriver::solve_a(double t) const {
+    // libsanm/anm.cpp:174-191
+    if (t == m_t_max) return m_t_max_a;
+    if (m_pade) return m_pade->solve_a(t);
+    sanm_check(t >= m_t_coeffs[0] && t < m_t_max, "solve_a: t=%g out of [%g, %g)", t, m_t_coeffs[0],
+               m_t_max);
+    double l, r;
+    if (m_t_max_a > 0) {
+        l = 0;
+        r = m_t_max_a;
+    } else {
+        l = -m_t_max_a;
+        r = 0;
+    }
+    return poly::solve_eqn(m_t_coeffs, l, r, t);
+}
+
+void AnmDriver::get_xt_coeff(int i, double* dst) const {
+    sanm_check(i >= 0 && i < m_nr_valid_coeffs, "coefficient %d not available", i);
+    m_be->d2h(dst, m_xt_coeffs[i].p(), (m_n + 1) * 8);
+}
+
+// ---------------------------------------------------- AnmSolverVecScale --
+AnmSolverVecScale::AnmSolverVecScale(Backend* be, const Graph& g, int out_var,
+                                     const SparseDesc& remap_inp, const SparseDesc& remap_out,
+                                     const double* x0, int64_t n, double t0, const double* v,
+                                     const HyperParam& hp, bool defer_solve)
+        : AnmDriver(be, g, out_var, remap_inp, remap_out, n, hp) {
+    // libsanm/anm.cpp:322-341
+    sanm_check(remap_inp.in_size == n, "linear map expects %ld inputs, got x0 of %ld",
+               (long)remap_inp.in_size, (long)n);
+    sanm_check(remap_out.out_size == n, "currently we assume the system is a full-rank mapping");
+    m_v = DVec{be, (size_t)n};
+    if (v) be->h2d(m_v.p(), v, n * 8);
+    if (!defer_solve) {
+        init_xt0(x0, t0);
+        solve_expansion_coeffs();
+    }
+}
+
+void AnmSolverVecScale::check_t0v_match(const double* fx_dev) {
+    // libsanm/anm.cpp:343-360
+    double ex = m_be->t0v_excess(m_n, fx_dev, m_v.p(), get_t0(), m_hp.solution_check_tol);
+    if (!(ex <= 0)) {
+        sanm_throw(SANM_ERR_NUMERICAL, "f(x0)+t0*v is not zero: excess=%g iter=%zu", ex, m_iter);
+    }
+}
+
+bool AnmSolverVecScale::on_fx0_computed(const double* fx_dev) {
+    check_t0v_match(fx_dev);
+    return true;
+}
+
+// --------------------------------------------------------- AnmEqnSolver --
+AnmEqnSolver::AnmEqnSolver(Backend* be, const Graph& g, int out_var, const SparseDesc& remap_inp,
+                           const SparseDesc& remap_out, const double* x0, const double* y,
+                           int64_t n, const HyperParam& hp)
+        : AnmSolverVecScale(be, g, out_var, remap_inp, remap_out, x0, n, 0, nullptr, hp, true),
+          m_converge_rms{hp.converge_rms} {
+    // libsanm/anm.cpp:446-462: f(x) - f(x0) + t*(y + f(x0)) = 0, t from 0
+    init_xt0(x0, 0);
+    m_eqn_y = DVec{be, (size_t)n};
+    be->h2d(m_eqn_y.p(), y, n * 8);
+    solve_expansion_coeffs();
+}
+
+AnmEqnSolver& AnmEqnSolver::next_iter() {
+    // libsanm/anm.cpp:464-478
+    if (m_converged) return *this;
+    double a = get_t_upper() >= 1 ? solve_a(1) : get_t_max_a();
+    eval_xt(a, m_tmp0.p());
+    m_be->d2d(m_xt0.p(), m_tmp0.p(), (m_n + 1) * 8);
+    double zero = 0;
+    m_be->h2d(m_xt0.p() + m_n, &zero, 8);  // set t0 to 0
+    solve_expansion_coeffs();
+    return *this;
+}
+
+bool AnmEqnSolver::on_fx0_computed(const double* fx_dev) {
+    // libsanm/anm.cpp:480-491
+    if (m_converged) return false;
+    m_be->axpby(m_n, 1.0, fx_dev, 1.0, m_eqn_y.p(), m_v.p());
+    m_residual_rms = std::sqrt(m_be->dot(m_n, m_v.p(), m_v.p()) / double(m_n));
+    if (m_residual_rms < m_converge_rms) {
+        m_converged = true;
+        return false;
+    }
+    return true;
+}
+
+void AnmEqnSolver::restart(const double* x0) {
+    m_converged = false;
+    m_residual_rms = 0;
+    init_xt0(x0, 0);
+    solve_expansion_coeffs();
+}
+
+void AnmEqnSolver::get_x(double* x_host) const { m_be->d2h(x_host, m_xt0.p(), m_n * 8); }
+
+// ---------------------------------------------------- AnmImplicitSolver --
+AnmImplicitSolver::AnmImplicitSolver(Backend* be, const Graph& g, int out_var,
+                                     const SparseDesc& remap_inp, const SparseDesc& remap_out,
+                                     const double* x0, int64_t n, double t0, const HyperParam& hp)
+        : AnmDriver(be, g, out_var, remap_inp, remap_out, n, hp) {
+    // libsanm/anm.cpp:494-508
+    sanm_check(remap_inp.in_size == n + 1 && remap_out.out_size == n,
+               "implicit solver needs remap_inp with n+1 inputs and remap_out with n outputs");
+    m_fx0_first = DVec{be, (size_t)n};
+    init_xt0(x0, t0);
+    solve_expansion_coeffs();
+}
+
+const double* AnmImplicitSolver::get_grad_t() { return m_grad_t_buf.p(); }
+
+bool AnmImplicitSolver::on_fx0_computed(const double* fx_dev) {
+    // libsanm/anm.cpp:510-518
+    if (!m_has_fx0) {
+        m_be->d2d(m_fx0_first.p(), fx_dev, m_n * 8);
+        m_has_fx0 = true;
+    } else {
+        double ex = m_be->allclose_excess(m_n, m_fx0_first.p(), fx_dev, m_hp.solution_check_tol);
+        sanm_check(ex < 0, "check f(x0, t0)=f(x, t): excess %g", ex);
+    }
+    return true;
+}
+
+void AnmImplicitSolver::get_fx0(double* dst) const { m_be->d2h(dst, m_fx0_first.p(), m_n * 8); }
+
+}  // namespace sanm_hip

@@ -1,0 +1,213 @@
+// ANM continuation drivers on device-resident state.
+//
+// Mirrors libsanm/anm.h:96-305 (ANMDriverHelper, ANMSolverVecScale,
+// ANMEqnSolver, ANMImplicitSolver) with the same member names and the same
+// arithmetic; what differs is where the data lives.  The reference drives
+// host tensors through ParallelTaylorCoeffProp worker threads and PARDISO;
+// here every vector of the per-order loop (x_k, b_k, the Jacobian CSR, the
+// Taylor state) stays in HBM and only scalars (t_k, norms, convergence flags)
+// come back to the host.
+#pragma once
+#include <chrono>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "backend.h"
+#include "graph.h"
+#include "sparse.h"
+
+namespace sanm_hip {
+
+struct HyperParam {  // libsanm/anm.h:100-114, :247-251
+    int use_pade = 0;
+    int sanity_check = 1;
+    int order = 8;
+    double maxr = 1e-6;
+    double solution_check_tol = 1e-4;
+    double xcoeff_l2_penalty = 0;
+    double converge_rms = 1e-5;
+    // device linear solver (no counterpart in the reference, which uses a
+    // direct LU: libsanm/sparse_solver.cpp:107-127)
+    double solver_rtol = 1e-12;
+    int solver_maxit = 100000;
+    int solver_kind = 0;  // 0: Jacobi-PCG, 1: multifrontal LDL' (direct)
+    int profile = 0;      // synchronise + time every phase
+};
+
+class DVec {
+public:
+    DVec() = default;
+    DVec(Backend* be, size_t n) : m_be{be}, m_n{n} { m_p = static_cast<double*>(be->alloc(n * 8)); }
+    DVec(DVec&& o) noexcept : m_be{o.m_be}, m_p{o.m_p}, m_n{o.m_n} { o.m_p = nullptr; }
+    DVec& operator=(DVec&& o) noexcept {
+        if (this != &o) {
+            reset();
+            m_be = o.m_be; m_p = o.m_p; m_n = o.m_n;
+            o.m_p = nullptr;
+        }
+        return *this;
+    }
+    DVec(const DVec&) = delete;
+    ~DVec() { reset(); }
+    void reset() {
+        if (m_p) m_be->free(m_p);
+        m_p = nullptr;
+    }
+    double* p() const { return m_p; }
+    size_t size() const { return m_n; }
+    bool empty() const { return !m_p; }
+
+private:
+    Backend* m_be = nullptr;
+    double* m_p = nullptr;
+    size_t m_n = 0;
+};
+
+//! libsanm/sparse_solver.h:17-87 on a fixed device CSR pattern
+class LinearSolver {
+public:
+    virtual ~LinearSolver() = default;
+    virtual void prepare() = 0;                       // after new values were assembled
+    virtual void solve(const double* b, double* x) = 0;
+    int64_t nr_solve = 0, tot_iters = 0, last_iters = 0;
+    double last_relres = 0;
+};
+std::unique_ptr<LinearSolver> make_pcg_solver(Backend* be, const JacobianPattern& pat,
+                                              const HyperParam& hp);
+
+//! libsanm/pade.h on device vectors
+class PadeApproximation {
+public:
+    PadeApproximation(Backend* be, const std::vector<DVec>& xs, bool anm_cond);
+    bool estimate_valid_range(double start, double eps, double limit);
+    double get_t_max() const { return m_t_max; }
+    double get_t_max_a() const { return m_t_max_a; }
+    double solve_a(double t) const;
+    void eval_xt(double a, double* out) const;
+    double eval_t(double a) const;
+    bool valid() const { return !m_d.empty(); }
+
+private:
+    Backend* m_be;
+    const std::vector<DVec>& m_xs;
+    size_t m_len;
+    std::vector<double> m_d, m_d_lo, m_t_nume;
+    double m_t0 = 0, m_t_max = 0, m_t_max_a = 0;
+    void eval_nume(double a, const double* d, int n, double* out) const;
+};
+
+class AnmDriver {  // ANMDriverHelper, libsanm/anm.h:96-207
+public:
+    AnmDriver(Backend* be, const Graph& g, int out_var, const SparseDesc& remap_inp,
+              const SparseDesc& remap_out, int64_t nr_unknown, const HyperParam& hp);
+    virtual ~AnmDriver();
+
+    void update_approx();
+    double get_t_upper() const { return m_t_max; }
+    double get_t_max_a() const { return m_t_max_a; }
+    double solve_a(double t) const;
+    //! x(a) (n doubles, host) and t(a)
+    double eval(double a, double* x_host) const;
+    size_t get_nr_iter() const { return m_iter; }
+    int64_t nr_unknown() const { return m_n; }
+    int order() const { return m_hp.order; }
+    //! copy coefficient i of [x(a); t(a)] to the host (n+1 doubles)
+    void get_xt_coeff(int i, double* dst) const;
+    int nr_valid_xt_coeffs() const { return m_nr_valid_coeffs; }
+    bool has_pade() const { return (bool)m_pade; }
+
+    const std::map<std::string, double>& profile() const { return m_profile; }
+    const LinearSolver& linear_solver() const { return *m_solver; }
+    const JacobianPattern& pattern() const { return *m_pattern; }
+    Program& program() { return *m_prog; }
+    Backend* backend() const { return m_be; }
+    const double* last_xt_coeff_dev(int i) const { return m_xt_coeffs[i].p(); }
+    double* scratch_dev(int i) const { return i == 0 ? m_tmp0.p() : m_tmp1.p(); }
+    //! per-order records of the last solve_expansion_coeffs (|b_k|, |x_k|, t_k)
+    std::vector<double> trace_b_norm, trace_x_norm, trace_t;
+
+protected:
+    Backend* m_be;
+    const HyperParam m_hp;
+    const int64_t m_n;
+    const double m_max_a_bound;
+    std::unique_ptr<Program> m_prog;
+    std::unique_ptr<DeviceRows> m_remap_out;
+    std::unique_ptr<JacobianPattern> m_pattern;
+    std::unique_ptr<LinearSolver> m_solver;
+
+    DVec m_xt0;
+    size_t m_iter = 0;
+    std::vector<DVec> m_xt_coeffs;
+    int m_nr_valid_coeffs = 0;
+    std::vector<double> m_t_coeffs;
+    double m_t_max = 0, m_t_max_a = 0;
+    std::unique_ptr<PadeApproximation> m_pade;
+    DVec m_fx0, m_bi, m_xbi, m_xgt, m_grad_t_buf, m_tmp0, m_tmp1;
+    std::map<std::string, double> m_profile;
+
+    void init_xt0(const double* x_host, double t);
+    void solve_expansion_coeffs();
+    void estimate_valid_range();
+    void eval_xt(double a, double* out_dev) const;
+    double get_t0() const { return m_t_coeffs[0]; }
+
+    //! device pointer of dF/dt (n doubles)
+    virtual const double* get_grad_t() = 0;
+    //! called with f(x0) on the device; false stops the expansion
+    virtual bool on_fx0_computed(const double* fx_dev) = 0;
+
+    class ScopedTimer;
+};
+
+class AnmSolverVecScale : public AnmDriver {  // libsanm/anm.h:209-243
+public:
+    AnmSolverVecScale(Backend* be, const Graph& g, int out_var, const SparseDesc& remap_inp,
+                      const SparseDesc& remap_out, const double* x0, int64_t n, double t0,
+                      const double* v, const HyperParam& hp, bool defer_solve = false);
+
+protected:
+    DVec m_v;
+    const double* get_grad_t() override { return m_v.p(); }
+    bool on_fx0_computed(const double* fx_dev) override;
+    void check_t0v_match(const double* fx_dev);
+};
+
+class AnmEqnSolver final : public AnmSolverVecScale {  // libsanm/anm.h:245-283
+public:
+    AnmEqnSolver(Backend* be, const Graph& g, int out_var, const SparseDesc& remap_inp,
+                 const SparseDesc& remap_out, const double* x0, const double* y, int64_t n,
+                 const HyperParam& hp);
+    double residual_rms() const { return m_residual_rms; }
+    bool converged() const { return m_converged; }
+    AnmEqnSolver& next_iter();
+    //! start a new solve from x0 on the same model (a new ANMEqnSolver in the
+    //! reference; here the device program, CSR pattern and solver analysis are kept)
+    void restart(const double* x0);
+    void get_x(double* x_host) const;
+
+private:
+    const double m_converge_rms;
+    bool m_converged = false;
+    DVec m_eqn_y;
+    double m_residual_rms = 0;
+    bool on_fx0_computed(const double* fx_dev) override;
+};
+
+class AnmImplicitSolver final : public AnmDriver {  // libsanm/anm.h:285-305
+public:
+    AnmImplicitSolver(Backend* be, const Graph& g, int out_var, const SparseDesc& remap_inp,
+                      const SparseDesc& remap_out, const double* x0, int64_t n, double t0,
+                      const HyperParam& hp);
+    void get_fx0(double* dst) const;
+
+protected:
+    DVec m_fx0_first, m_grad_t;
+    bool m_has_fx0 = false;
+    const double* get_grad_t() override;
+    bool on_fx0_computed(const double* fx_dev) override;
+};
+
+}  // namespace sanm_hip

@@ -1,0 +1,106 @@
+// Device abstraction used by the ANM driver.
+//
+// The product implementation is HipBackend (backend_hip.hip): HIP memory,
+// HIP kernels, one stream.  The only other implementation lives under
+// tests/hostsim and exists so the host logic (graph compilation, assembly
+// pattern, ANM driver, Pade) can be exercised in the GPU-less authoring
+// container; it is never linked into libsanm_hip.so.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+#include "program.h"
+
+namespace sanm_hip {
+
+// rows of a sparse gather: dst[i] = sum_{p in [ptr[i], ptr[i+1])} coef[p] * src[idx[p]]
+struct SparseRowsDev {
+    const uint32_t* ptr;  // n+1
+    const uint32_t* idx;
+    const double* coef;
+    int64_t nrows;
+};
+
+struct CsrDev {
+    const uint32_t* rowptr;  // n+1
+    const uint32_t* col;
+    double* val;
+    int64_t n, nnz;
+};
+
+// value assembly: val[s] = sum_{p in [ptr[s], ptr[s+1])} drop(coef[p] * jac[jidx[p]])
+// where drop(c) = |c| < 1e-9 ? 0 : c   (libsanm/sparse_solver.cpp:291-293)
+struct AssemblyDev {
+    const uint32_t* ptr;  // nslots+1
+    const uint32_t* jidx;
+    const double* coef;
+    int64_t nslots;
+};
+
+class Backend {
+public:
+    virtual ~Backend() = default;
+    virtual const char* name() const = 0;
+
+    virtual void* alloc(size_t bytes) = 0;
+    virtual void free(void* p) = 0;
+    virtual void h2d(void* dst, const void* src, size_t bytes) = 0;
+    virtual void d2h(void* dst, const void* src, size_t bytes) = 0;
+    virtual void d2d(void* dst, const void* src, size_t bytes) = 0;
+    virtual void zero(void* dst, size_t bytes) = 0;
+    virtual void sync() = 0;
+
+    //! one whole graph pass over all tets (tet_ops.h: exec_program_tet)
+    virtual void run_pass(const ProgramDev& P, int mode, int order, const double* xvec) = 0;
+    //! remap_out apply (SparseLinearDesc::apply, libsanm/anm.cpp:55-75)
+    virtual void gather_rows(const SparseRowsDev& R, const double* src, double* dst) = 0;
+    //! Jacobian values into a fixed CSR pattern (anm.cpp:362-438 + sparse_solver.cpp:250-305)
+    virtual void assemble(const AssemblyDev& A, const double* jac, double* val) = 0;
+    //! y = A x  (SparseSolver::apply, sparse_solver.cpp:202-215)
+    virtual void spmv(const CsrDev& A, const double* x, double* y) = 0;
+
+    // BLAS-1 on device vectors (libsanm/tensor.cpp:644-668, tensor_elemwise.cpp)
+    virtual double dot(size_t n, const double* x, const double* y) = 0;
+    //! out = a*x + b*y  (y may be null iff b == 0; out may alias x or y)
+    virtual void axpby(size_t n, double a, const double* x, double b, const double* y,
+                       double* out) = 0;
+    //! out = x .* y
+    virtual void vmul(size_t n, const double* x, const double* y, double* out) = 0;
+    //! d[i] = 1 / A[i,i]  (scaled by `scale`)
+    virtual void csr_inv_diag(const CsrDev& A, double scale, double* d) = 0;
+    //! number of non-finite entries
+    virtual int64_t count_nonfinite(size_t n, const double* x) = 0;
+    //! max_i ( |a_i - b_i| - eps*max(1, min(|a_i|,|b_i|)) ) ; <0 means allclose
+    //! (TensorND::assert_allclose, libsanm/tensor.cpp:670-684)
+    virtual double allclose_excess(size_t n, const double* a, const double* b, double eps) = 0;
+    /*!
+     * Jacobi-preconditioned conjugate gradients on (sign*A) x = sign*b.
+     *
+     * The forward-FEA Jacobian is minus the (scaled) energy Hessian, hence
+     * symmetric negative definite at stable states (hard part 2):
+     * sign = -1 there.  dinv holds 1/(sign*diag(A)).  Stops when
+     * |r| <= rtol*|b|.  Returns the iteration count in *iters (negative if
+     * the operator is found indefinite: p'Ap <= 0) and the final relative
+     * residual in *relres.  The default implementation is built from the
+     * primitives above; HipBackend overrides it with device-resident scalars.
+     */
+    virtual void pcg(const CsrDev& A, double sign, const double* dinv, const double* b, double* x,
+                     double rtol, int maxit, int* iters, double* relres);
+
+    //! average duration in ms of `reps` back-to-back launches of one kernel,
+    //! measured with device events on the backend's stream (bench.py roofline).
+    //! kernel: 0 = taylor pass (mode, order given), 1 = spmv, 2 = pcg spmv+dot.
+    virtual double time_kernel(int kernel, int reps, const ProgramDev* P, int mode, int order,
+                               const CsrDev* A, const double* x, double* y) {
+        (void)kernel; (void)reps; (void)P; (void)mode; (void)order; (void)A; (void)x; (void)y;
+        return -1.0;
+    }
+
+    //! like allclose_excess for check_t0v_match (anm.cpp:343-360): a + b*t0 vs 0
+    virtual double t0v_excess(size_t n, const double* fx, const double* v, double t0, double tol) = 0;
+};
+
+//! factory of the one backend linked into the library
+Backend* make_backend(int device);
+
+}  // namespace sanm_hip

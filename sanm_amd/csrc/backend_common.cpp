@@ -1,0 +1,49 @@
+#include <cmath>
+
+#include "backend.h"
+
+namespace sanm_hip {
+
+void Backend::pcg(const CsrDev& A, double sign, const double* dinv, const double* b, double* x,
+                  double rtol, int maxit, int* iters, double* relres) {
+    const size_t n = A.n;
+    double* r = static_cast<double*>(alloc(n * 8));
+    double* z = static_cast<double*>(alloc(n * 8));
+    double* p = static_cast<double*>(alloc(n * 8));
+    double* q = static_cast<double*>(alloc(n * 8));
+    zero(x, n * 8);
+    axpby(n, sign, b, 0, nullptr, r);  // r = sign*b - M*0
+    double bnorm = std::sqrt(dot(n, r, r));
+    int it = 0;
+    double rr = bnorm * bnorm;
+    if (bnorm > 0) {
+        vmul(n, dinv, r, z);
+        d2d(p, z, n * 8);
+        double rz = dot(n, r, z);
+        for (it = 1; it <= maxit; ++it) {
+            spmv(A, p, q);
+            double pq = sign * dot(n, p, q);
+            if (!(pq > 0)) {
+                it = -it;
+                break;
+            }
+            double alpha = rz / pq;
+            axpby(n, 1.0, x, alpha, p, x);
+            axpby(n, 1.0, r, -alpha * sign, q, r);
+            rr = dot(n, r, r);
+            if (std::sqrt(rr) <= rtol * bnorm) break;
+            vmul(n, dinv, r, z);
+            double rz_new = dot(n, r, z);
+            axpby(n, 1.0, z, rz_new / rz, p, p);
+            rz = rz_new;
+        }
+    }
+    *iters = it;
+    *relres = bnorm > 0 ? std::sqrt(rr) / bnorm : 0.0;
+    free(r);
+    free(z);
+    free(p);
+    free(q);
+}
+
+}  // namespace sanm_hip

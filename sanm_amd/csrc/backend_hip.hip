@@ -1,0 +1,500 @@
+// HIP backend: the product execution path (gfx950 / MI355X).
+//
+// Kernels here are HBM/L2-bandwidth bound fp64 streaming kernels (no dense
+// contraction, MFMA unused):
+//  * taylor_pass_kernel   one lane per tet, SoA state => every load/store of
+//                         a wavefront is one contiguous 512-byte segment;
+//                         64-thread workgroups so that even the small meshes
+//                         (42k tets = 661 wavefronts) spread over all 256 CUs.
+//  * gather_rows_kernel   remap_out: one lane per unknown, ~45 gathered
+//                         entries from a 9*Tpad*8-byte (L2 resident) tensor.
+//  * assemble_kernel      one lane per CSR non-zero over a fixed gather list.
+//  * spmv_kernel          CSR, 8 lanes per row + DPP-free shuffle reduction.
+//  * BLAS-1               grid-stride, wavefront shuffle + LDS block reduce,
+//                         one double atomic per block.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <vector>
+
+#include "backend.h"
+#include "graph.h"
+#include "row_ops.h"
+#include "tet_ops.h"
+
+namespace sanm_hip {
+
+#define HIP_CHECK(expr)                                                              \
+    do {                                                                             \
+        hipError_t e_ = (expr);                                                      \
+        if (e_ != hipSuccess)                                                        \
+            sanm_throw(SANM_ERR_HIP, "HIP error %s at %s:%d: %s", hipGetErrorName(e_), \
+                       __FILE__, __LINE__, hipGetErrorString(e_));                   \
+    } while (0)
+
+namespace {
+
+__global__ void __launch_bounds__(64) taylor_pass_kernel(ProgramDev P, int mode, int order,
+                                                         const double* __restrict__ xvec) {
+    int64_t tet = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tet < P.T) exec_program_tet(P, mode, order, tet, xvec);
+}
+
+__global__ void gather_rows_kernel(SparseRowsDev R, const double* __restrict__ src,
+                                   double* __restrict__ dst) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < R.nrows) dst[i] = gather_row(R, src, i);
+}
+
+__global__ void assemble_kernel(AssemblyDev A, const double* __restrict__ jac,
+                                double* __restrict__ val) {
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < A.nslots) val[s] = assemble_slot(A, jac, s);
+}
+
+constexpr int SPMV_LANES = 8;
+__global__ void spmv_kernel(CsrDev A, const double* __restrict__ x, double* __restrict__ y) {
+    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t row = gid / SPMV_LANES;
+    int sub = gid % SPMV_LANES;
+    double s = 0;
+    if (row < A.n) {
+        for (uint32_t p = A.rowptr[row] + sub, e = A.rowptr[row + 1]; p < e; p += SPMV_LANES)
+            s += A.val[p] * x[A.col[p]];
+    }
+    for (int off = SPMV_LANES / 2; off > 0; off >>= 1) s += __shfl_down(s, off, SPMV_LANES);
+    if (row < A.n && sub == 0) y[row] = s;
+}
+
+__device__ __forceinline__ double wave_reduce_sum(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_reduce_max(double v) {
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    return v;
+}
+
+// block reduce (256 threads = 4 waves) then one atomic per block
+template <bool IS_MAX>
+__device__ __forceinline__ void block_reduce_commit(double v, double* out) {
+    __shared__ double sh[4];
+    v = IS_MAX ? wave_reduce_max(v) : wave_reduce_sum(v);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = sh[0];
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = IS_MAX ? fmax(r, sh[i]) : r + sh[i];
+        if (IS_MAX) {
+            // atomic max on doubles through CAS on the bit pattern
+            unsigned long long* a = reinterpret_cast<unsigned long long*>(out);
+            unsigned long long old = *a, assumed;
+            do {
+                assumed = old;
+                if (__longlong_as_double(assumed) >= r) break;
+                old = atomicCAS(a, assumed, __double_as_longlong(r));
+            } while (assumed != old);
+        } else {
+            atomicAdd(out, r);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) dot_kernel(size_t n, const double* __restrict__ x,
+                                                  const double* __restrict__ y, double* out) {
+    double s = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x)
+        s += x[i] * y[i];
+    block_reduce_commit<false>(s, out);
+}
+
+__global__ void axpby_kernel(size_t n, double a, const double* x, double b, const double* y,
+                             double* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = b == 0.0 ? a * x[i] : a * x[i] + b * y[i];
+}
+
+__global__ void vmul_kernel(size_t n, const double* x, const double* y, double* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = x[i] * y[i];
+}
+
+__global__ void inv_diag_kernel(CsrDev A, double scale, double* d) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < A.n) d[i] = 1.0 / (scale * csr_diag(A, i));
+}
+
+__global__ void __launch_bounds__(256) nonfinite_kernel(size_t n, const double* x, double* out) {
+    double s = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x)
+        s += isfinite(x[i]) ? 0.0 : 1.0;
+    block_reduce_commit<false>(s, out);
+}
+
+__global__ void __launch_bounds__(256) allclose_kernel(size_t n, const double* a, const double* b,
+                                                       double eps, double* out) {
+    double m = -1e300;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x)
+        m = fmax(m, allclose_excess1(a[i], b[i], eps));
+    block_reduce_commit<true>(m, out);
+}
+
+__global__ void __launch_bounds__(256) t0v_kernel(size_t n, const double* fx, const double* v,
+                                                  double t0, double tol, double* out) {
+    double m = -1e300;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        // anm.cpp:349-353
+        double a = fx[i], b = v[i] * t0;
+        double me = fmax(fmin(fabs(a), fabs(b)), 1.0) * tol;
+        double d = fabs(a + b);
+        m = fmax(m, (d == d) ? d - me : 1e300);
+    }
+    block_reduce_commit<true>(m, out);
+}
+
+
+// ---- Jacobi-PCG with device-resident scalars --------------------------------
+// 3 launches per iteration and no host synchronisation inside the loop: the
+// host only reads |r|^2 every PCG_CHECK_EVERY iterations.  Scalars live in a
+// small device array; slots indexed by iteration parity are zeroed by the
+// kernel that runs while they are dead (see pcg() below).
+struct PcgScalars {
+    double rz[2];  // r.z of the current / next iteration
+    double pq[2];  // p.(M p)
+    double rr[2];  // |r|^2
+    double bb;     // |b|^2
+    int breakdown; // set when p.(M p) <= 0
+};
+
+__global__ void __launch_bounds__(256) pcg_init_kernel(size_t n, double sign,
+                                                       const double* __restrict__ b,
+                                                       const double* __restrict__ dinv, double* x,
+                                                       double* r, double* z, double* p,
+                                                       PcgScalars* sc) {
+    double rz = 0, rr = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        double ri = sign * b[i], zi = dinv[i] * ri;
+        x[i] = 0;
+        r[i] = ri;
+        z[i] = zi;
+        p[i] = zi;
+        rz += ri * zi;
+        rr += ri * ri;
+    }
+    block_reduce_commit<false>(rz, &sc->rz[0]);
+    __syncthreads();
+    block_reduce_commit<false>(rr, &sc->bb);
+}
+
+// q = A p ; pq[it&1] += sign * p.q ; zeroes rz[(it+1)&1] and rr[it&1]
+__global__ void __launch_bounds__(256) pcg_spmv_dot_kernel(CsrDev A, double sign,
+                                                           const double* __restrict__ p,
+                                                           double* __restrict__ q, PcgScalars* sc,
+                                                           int it) {
+    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid == 0) {
+        sc->rz[(it + 1) & 1] = 0;
+        sc->rr[it & 1] = 0;
+    }
+    int64_t row = gid / SPMV_LANES;
+    int sub = gid % SPMV_LANES;
+    double s = 0;
+    if (row < A.n) {
+        for (uint32_t k = A.rowptr[row] + sub, e = A.rowptr[row + 1]; k < e; k += SPMV_LANES)
+            s += A.val[k] * p[A.col[k]];
+    }
+    for (int off = SPMV_LANES / 2; off > 0; off >>= 1) s += __shfl_down(s, off, SPMV_LANES);
+    double contrib = 0;
+    if (row < A.n && sub == 0) {
+        q[row] = s;
+        contrib = sign * s * p[row];
+    }
+    block_reduce_commit<false>(contrib, &sc->pq[it & 1]);
+}
+
+// alpha = rz/pq ; x += alpha p ; r -= alpha*sign*q ; z = dinv r ;
+// rz[(it+1)&1] += r.z ; rr[it&1] += r.r ; zeroes pq[(it+1)&1]
+__global__ void __launch_bounds__(256) pcg_update_kernel(size_t n, double sign,
+                                                         const double* __restrict__ dinv,
+                                                         const double* __restrict__ p,
+                                                         const double* __restrict__ q, double* x,
+                                                         double* r, double* z, PcgScalars* sc, int it) {
+    const double pq = sc->pq[it & 1], rz = sc->rz[it & 1];
+    const bool bad = !(pq > 0);
+    const double alpha = bad ? 0.0 : rz / pq;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc->pq[(it + 1) & 1] = 0;
+        if (bad && rz != 0) sc->breakdown = 1;
+    }
+    double rzn = 0, rr = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        x[i] += alpha * p[i];
+        double ri = r[i] - alpha * sign * q[i];
+        double zi = dinv[i] * ri;
+        r[i] = ri;
+        z[i] = zi;
+        rzn += ri * zi;
+        rr += ri * ri;
+    }
+    block_reduce_commit<false>(rzn, &sc->rz[(it + 1) & 1]);
+    __syncthreads();
+    block_reduce_commit<false>(rr, &sc->rr[it & 1]);
+}
+
+// beta = rz_new / rz ; p = z + beta p
+__global__ void pcg_dir_kernel(size_t n, const double* __restrict__ z, double* p,
+                               const PcgScalars* sc, int it) {
+    const double rz = sc->rz[it & 1], rzn = sc->rz[(it + 1) & 1];
+    const double beta = rz != 0 ? rzn / rz : 0.0;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = z[i] + beta * p[i];
+}
+constexpr int PCG_CHECK_EVERY = 64;
+
+inline unsigned nblk(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+inline unsigned red_grid(size_t n) {
+    size_t g = (n + 255) / 256;
+    return (unsigned)(g < 1 ? 1 : (g > 1024 ? 1024 : g));
+}
+
+class HipBackend final : public Backend {
+    hipStream_t m_stream = nullptr;
+    double* m_scalar = nullptr;  // device scratch for reductions
+    double* m_scalar_host = nullptr;  // pinned
+    double* m_pcg_w[4] = {nullptr, nullptr, nullptr, nullptr};
+    PcgScalars* m_pcg_sc = nullptr;
+    PcgScalars* m_pcg_sc_host = nullptr;
+    size_t m_pcg_n = 0;
+
+public:
+    explicit HipBackend(int device) {
+        int count = 0;
+        hipError_t e = hipGetDeviceCount(&count);
+        if (e != hipSuccess || count <= 0) {
+            sanm_throw(SANM_ERR_HIP,
+                       "no HIP device available (%s); the sanm_hip product path has no CPU "
+                       "fallback",
+                       e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        }
+        HIP_CHECK(hipSetDevice(device));
+        HIP_CHECK(hipStreamCreate(&m_stream));
+        HIP_CHECK(hipMalloc(&m_scalar, 64));
+        HIP_CHECK(hipHostMalloc(&m_scalar_host, 64));
+    }
+    ~HipBackend() override {
+        (void)hipFree(m_scalar);
+        for (double* w : m_pcg_w)
+            if (w) (void)hipFree(w);
+        if (m_pcg_sc) (void)hipFree(m_pcg_sc);
+        if (m_pcg_sc_host) (void)hipHostFree(m_pcg_sc_host);
+        (void)hipHostFree(m_scalar_host);
+        (void)hipStreamDestroy(m_stream);
+    }
+    const char* name() const override { return "hip"; }
+
+    void* alloc(size_t bytes) override {
+        void* p = nullptr;
+        HIP_CHECK(hipMalloc(&p, bytes ? bytes : 8));
+        return p;
+    }
+    void free(void* p) override {
+        if (p) (void)hipFree(p);
+    }
+    void h2d(void* dst, const void* src, size_t bytes) override {
+        if (!bytes) return;
+        HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, m_stream));
+        HIP_CHECK(hipStreamSynchronize(m_stream));
+    }
+    void d2h(void* dst, const void* src, size_t bytes) override {
+        if (!bytes) return;
+        HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, m_stream));
+        HIP_CHECK(hipStreamSynchronize(m_stream));
+    }
+    void d2d(void* dst, const void* src, size_t bytes) override {
+        if (!bytes) return;
+        HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, m_stream));
+    }
+    void zero(void* dst, size_t bytes) override {
+        if (!bytes) return;
+        HIP_CHECK(hipMemsetAsync(dst, 0, bytes, m_stream));
+    }
+    void sync() override { HIP_CHECK(hipStreamSynchronize(m_stream)); }
+    hipStream_t stream() const { return m_stream; }
+
+    void run_pass(const ProgramDev& P, int mode, int order, const double* xvec) override {
+        hipLaunchKernelGGL(taylor_pass_kernel, dim3(nblk(P.T, 64)), dim3(64), 0, m_stream, P, mode,
+                           order, xvec);
+        HIP_CHECK(hipGetLastError());
+    }
+    void gather_rows(const SparseRowsDev& R, const double* src, double* dst) override {
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(nblk(R.nrows, 64)), dim3(64), 0, m_stream, R,
+                           src, dst);
+        HIP_CHECK(hipGetLastError());
+    }
+    void assemble(const AssemblyDev& A, const double* jac, double* val) override {
+        hipLaunchKernelGGL(assemble_kernel, dim3(nblk(A.nslots, 256)), dim3(256), 0, m_stream, A,
+                           jac, val);
+        HIP_CHECK(hipGetLastError());
+    }
+    void spmv(const CsrDev& A, const double* x, double* y) override {
+        hipLaunchKernelGGL(spmv_kernel, dim3(nblk((size_t)A.n * SPMV_LANES, 256)), dim3(256), 0,
+                           m_stream, A, x, y);
+        HIP_CHECK(hipGetLastError());
+    }
+
+
+    // Backend::pcg with device-resident scalars (see the kernels above)
+    void pcg(const CsrDev& A, double sign, const double* dinv, const double* b, double* x,
+             double rtol, int maxit, int* iters, double* relres) override {
+        const size_t n = A.n;
+        if (m_pcg_n != n) {
+            for (double*& w : m_pcg_w) {
+                if (w) (void)hipFree(w);
+                HIP_CHECK(hipMalloc(&w, n * sizeof(double)));
+            }
+            if (!m_pcg_sc) HIP_CHECK(hipMalloc(&m_pcg_sc, sizeof(PcgScalars)));
+            if (!m_pcg_sc_host) HIP_CHECK(hipHostMalloc(&m_pcg_sc_host, sizeof(PcgScalars)));
+            m_pcg_n = n;
+        }
+        double *r = m_pcg_w[0], *z = m_pcg_w[1], *p = m_pcg_w[2], *q = m_pcg_w[3];
+        HIP_CHECK(hipMemsetAsync(m_pcg_sc, 0, sizeof(PcgScalars), m_stream));
+        hipLaunchKernelGGL(pcg_init_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, sign, b,
+                           dinv, x, r, z, p, m_pcg_sc);
+        auto fetch = [&]() {
+            HIP_CHECK(hipMemcpyAsync(m_pcg_sc_host, m_pcg_sc, sizeof(PcgScalars),
+                                     hipMemcpyDeviceToHost, m_stream));
+            HIP_CHECK(hipStreamSynchronize(m_stream));
+            return *m_pcg_sc_host;
+        };
+        PcgScalars sc = fetch();
+        const double bb = sc.bb;
+        int it = 0;
+        double rr = bb;
+        if (bb > 0) {
+            const unsigned g_spmv = nblk(n * SPMV_LANES, 256), g_red = red_grid(n), g_n = nblk(n, 256);
+            while (it < maxit) {
+                int stop = std::min(maxit, it + PCG_CHECK_EVERY);
+                for (; it < stop; ++it) {
+                    hipLaunchKernelGGL(pcg_spmv_dot_kernel, dim3(g_spmv), dim3(256), 0, m_stream, A,
+                                       sign, p, q, m_pcg_sc, it);
+                    hipLaunchKernelGGL(pcg_update_kernel, dim3(g_red), dim3(256), 0, m_stream, n,
+                                       sign, dinv, p, q, x, r, z, m_pcg_sc, it);
+                    hipLaunchKernelGGL(pcg_dir_kernel, dim3(g_n), dim3(256), 0, m_stream, n, z, p,
+                                       m_pcg_sc, it);
+                }
+                HIP_CHECK(hipGetLastError());
+                sc = fetch();
+                rr = sc.rr[(it - 1) & 1];
+                if (sc.breakdown) {
+                    it = -it;
+                    break;
+                }
+                if (!(rr == rr) || std::sqrt(rr) <= rtol * std::sqrt(bb)) break;
+            }
+        }
+        *iters = it;
+        *relres = bb > 0 ? std::sqrt(rr / bb) : 0.0;
+    }
+
+    double time_kernel(int kernel, int reps, const ProgramDev* P, int mode, int order,
+                       const CsrDev* A, const double* x, double* y) override {
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        if (kernel == 2 && !m_pcg_sc) HIP_CHECK(hipMalloc(&m_pcg_sc, sizeof(PcgScalars)));
+        auto launch = [&]() {
+            if (kernel == 0) {
+                hipLaunchKernelGGL(taylor_pass_kernel, dim3(nblk(P->T, 64)), dim3(64), 0, m_stream,
+                                   *P, mode, order, x);
+            } else if (kernel == 1) {
+                hipLaunchKernelGGL(spmv_kernel, dim3(nblk((size_t)A->n * SPMV_LANES, 256)),
+                                   dim3(256), 0, m_stream, *A, x, y);
+            } else {
+                hipLaunchKernelGGL(pcg_spmv_dot_kernel, dim3(nblk((size_t)A->n * SPMV_LANES, 256)),
+                                   dim3(256), 0, m_stream, *A, -1.0, x, y, m_pcg_sc, 0);
+            }
+        };
+        for (int i = 0; i < 3; ++i) launch();  // warm up
+        HIP_CHECK(hipEventRecord(e0, m_stream));
+        for (int i = 0; i < reps; ++i) launch();
+        HIP_CHECK(hipEventRecord(e1, m_stream));
+        HIP_CHECK(hipEventSynchronize(e1));
+        HIP_CHECK(hipGetLastError());
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        return (double)ms / reps;
+    }
+
+    double fetch_scalar() {
+        HIP_CHECK(hipMemcpyAsync(m_scalar_host, m_scalar, sizeof(double), hipMemcpyDeviceToHost,
+                                 m_stream));
+        HIP_CHECK(hipStreamSynchronize(m_stream));
+        return *m_scalar_host;
+    }
+    void set_scalar(double v) {
+        *m_scalar_host = v;
+        HIP_CHECK(hipMemcpyAsync(m_scalar, m_scalar_host, sizeof(double), hipMemcpyHostToDevice,
+                                 m_stream));
+    }
+
+    double dot(size_t n, const double* x, const double* y) override {
+        HIP_CHECK(hipMemsetAsync(m_scalar, 0, sizeof(double), m_stream));
+        hipLaunchKernelGGL(dot_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, y, m_scalar);
+        HIP_CHECK(hipGetLastError());
+        return fetch_scalar();
+    }
+    void axpby(size_t n, double a, const double* x, double b, const double* y,
+               double* out) override {
+        hipLaunchKernelGGL(axpby_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, a, x, b, y,
+                           out);
+        HIP_CHECK(hipGetLastError());
+    }
+    void vmul(size_t n, const double* x, const double* y, double* out) override {
+        hipLaunchKernelGGL(vmul_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, x, y, out);
+        HIP_CHECK(hipGetLastError());
+    }
+    void csr_inv_diag(const CsrDev& A, double scale, double* d) override {
+        hipLaunchKernelGGL(inv_diag_kernel, dim3(nblk(A.n, 256)), dim3(256), 0, m_stream, A, scale,
+                           d);
+        HIP_CHECK(hipGetLastError());
+    }
+    int64_t count_nonfinite(size_t n, const double* x) override {
+        HIP_CHECK(hipMemsetAsync(m_scalar, 0, sizeof(double), m_stream));
+        hipLaunchKernelGGL(nonfinite_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x,
+                           m_scalar);
+        HIP_CHECK(hipGetLastError());
+        return (int64_t)fetch_scalar();
+    }
+    double allclose_excess(size_t n, const double* a, const double* b, double eps) override {
+        set_scalar(-1e300);
+        hipLaunchKernelGGL(allclose_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, a, b, eps,
+                           m_scalar);
+        HIP_CHECK(hipGetLastError());
+        return fetch_scalar();
+    }
+    double t0v_excess(size_t n, const double* fx, const double* v, double t0,
+                      double tol) override {
+        set_scalar(-1e300);
+        hipLaunchKernelGGL(t0v_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, fx, v, t0, tol,
+                           m_scalar);
+        HIP_CHECK(hipGetLastError());
+        return fetch_scalar();
+    }
+};
+
+}  // namespace
+
+Backend* make_backend(int device) { return new HipBackend(device); }
+
+}  // namespace sanm_hip

@@ -1,0 +1,512 @@
+// extern "C" entry points declared in include/sanm_hip.h.
+#include "../../include/sanm_hip.h"
+
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "anm.h"
+#include "fea.h"
+#include "graph.h"
+#include "poly.h"
+#include "sparse.h"
+
+using namespace sanm_hip;
+
+struct sanm_graph {
+    Graph g;
+};
+struct sanm_sparse_desc {
+    SparseDesc d;
+};
+struct sanm_fea_model {
+    ElasticForceModel m;
+    sanm_graph graph_view;  // unused; graph accessed through cast below
+    sanm_sparse_desc inp, out;
+};
+
+namespace {
+thread_local std::string g_last_error;
+std::unique_ptr<Backend> g_backend;
+
+Backend* backend() {
+    if (!g_backend) sanm_throw(SANM_ERR_ASSERT, "sanm_hip_init() has not been called");
+    return g_backend.get();
+}
+
+template <class F>
+int guard(F&& f) {
+    try {
+        f();
+        return SANM_HIP_OK;
+    } catch (const SanmError& e) {
+        g_last_error = e.msg;
+        return e.code;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return SANM_HIP_ERR_UNKNOWN;
+    } catch (...) {
+        g_last_error = "unknown exception";
+        return SANM_HIP_ERR_UNKNOWN;
+    }
+}
+
+HyperParam to_hp(const sanm_hyper_param* h) {
+    HyperParam r;
+    r.use_pade = h->use_pade;
+    r.sanity_check = h->sanity_check;
+    r.order = h->order;
+    r.maxr = h->maxr;
+    r.solution_check_tol = h->solution_check_tol;
+    r.xcoeff_l2_penalty = h->xcoeff_l2_penalty;
+    r.converge_rms = h->converge_rms;
+    r.solver_rtol = h->solver_rtol;
+    r.solver_maxit = h->solver_maxit;
+    r.solver_kind = h->solver_kind;
+    r.profile = h->profile;
+    return r;
+}
+}  // namespace
+
+// TaylorCoeffProp on the device (libsanm/symbolic.cpp:142-304)
+struct sanm_taylor_prop {
+    std::unique_ptr<Program> prog;
+    DVec x;
+    int order = 0;
+    bool xi_known = false, jacobian_done = false;
+    int64_t n_in = 0;
+
+    void ensure_jacobian() {
+        if (jacobian_done) return;
+        sanm_check(order == 0, "jacobian must be taken at order 0");
+        prog->zero_jacobians();
+        backend()->run_pass(prog->dev(), PASS_GRAD, 0, nullptr);
+        jacobian_done = true;
+    }
+};
+
+struct sanm_anm_solver {
+    std::unique_ptr<AnmDriver> drv;
+    AnmEqnSolver* eqn = nullptr;
+    std::vector<std::string> tag_storage;
+};
+
+extern "C" {
+
+int sanm_hip_init(int device) {
+    return guard([&] {
+        if (!g_backend) g_backend.reset(make_backend(device));
+    });
+}
+const char* sanm_hip_last_error(void) { return g_last_error.c_str(); }
+const char* sanm_hip_backend_name(void) { return g_backend ? g_backend->name() : "uninitialised"; }
+
+// ---- graph ---------------------------------------------------------------
+int sanm_graph_create(sanm_graph** g) {
+    return guard([&] { *g = new sanm_graph; });
+}
+void sanm_graph_destroy(sanm_graph* g) { delete g; }
+int sanm_graph_placeholder(sanm_graph* g, int* var) {
+    return guard([&] { *var = g->g.placeholder(); });
+}
+int sanm_graph_constant(sanm_graph* g, const double* val, int64_t batch, int size, int* var) {
+    return guard([&] { *var = g->g.constant(val, batch, size); });
+}
+int sanm_graph_linear_combine(sanm_graph* g, int n, const double* coeffs, const int* vars,
+                              double bias, int* var) {
+    return guard([&] { *var = g->g.linear_combine(n, coeffs, vars, bias); });
+}
+int sanm_graph_multiply(sanm_graph* g, int a, int b, int* var) {
+    return guard([&] { *var = g->g.multiply(a, b); });
+}
+int sanm_graph_pow(sanm_graph* g, int x, double e, int* var) {
+    return guard([&] { *var = g->g.pow(x, e); });
+}
+int sanm_graph_log(sanm_graph* g, int x, int* var) {
+    return guard([&] { *var = g->g.log(x); });
+}
+int sanm_graph_reduce_sum(sanm_graph* g, int x, int axis, int* var) {
+    return guard([&] { *var = g->g.reduce_sum(x, axis); });
+}
+int sanm_graph_batched_matmul(sanm_graph* g, int a, int b, int* var) {
+    return guard([&] { *var = g->g.batched_matmul(a, b); });
+}
+int sanm_graph_batched_mat_inv_mul(sanm_graph* g, int x, int a, int is_left, int* var) {
+    return guard([&] { *var = g->g.batched_mat_inv_mul(x, a, is_left != 0); });
+}
+int sanm_graph_batched_det(sanm_graph* g, int x, int* var) {
+    return guard([&] { *var = g->g.batched_det(x); });
+}
+int sanm_graph_batched_transpose(sanm_graph* g, int x, int* var) {
+    return guard([&] { *var = g->g.batched_transpose(x); });
+}
+int sanm_graph_batched_mul_eye(sanm_graph* g, int x, int dim, int* var) {
+    return guard([&] { *var = g->g.batched_mul_eye(x, dim); });
+}
+int sanm_graph_batched_svd_w(sanm_graph* g, int x, int require_rotation, int usw[3]) {
+    return guard([&] { g->g.batched_svd_w(x, require_rotation != 0, usw); });
+}
+
+// ---- sparse desc -----------------------------------------------------------
+int sanm_sparse_desc_create(int64_t out_size, int64_t in_size, const uint64_t* rowptr,
+                            const uint64_t* idx, const double* coeff, sanm_sparse_desc** d) {
+    return guard([&] {
+        auto p = std::make_unique<sanm_sparse_desc>();
+        p->d = SparseDesc(out_size, in_size, rowptr, idx, coeff);
+        *d = p.release();
+    });
+}
+void sanm_sparse_desc_destroy(sanm_sparse_desc* d) { delete d; }
+int sanm_sparse_desc_get(const sanm_sparse_desc* d, int64_t* out_size, int64_t* in_size,
+                         int64_t* nnz, uint64_t* rowptr, uint64_t* idx, double* coeff) {
+    return guard([&] {
+        if (out_size) *out_size = d->d.out_size;
+        if (in_size) *in_size = d->d.in_size;
+        if (nnz) *nnz = d->d.idx.size();
+        if (rowptr) std::memcpy(rowptr, d->d.rowptr.data(), d->d.rowptr.size() * 8);
+        if (idx) std::memcpy(idx, d->d.idx.data(), d->d.idx.size() * 8);
+        if (coeff) std::memcpy(coeff, d->d.coef.data(), d->d.coef.size() * 8);
+    });
+}
+
+// ---- taylor ----------------------------------------------------------------
+int sanm_taylor_create(const sanm_graph* g, int out_var, const sanm_sparse_desc* remap_inp,
+                       int max_order, sanm_taylor_prop** prop) {
+    return guard([&] {
+        Backend* be = backend();
+        sanm_check(remap_inp->d.out_size % 9 == 0, "remap_inp must produce a (T,3,3) tensor");
+        auto p = std::make_unique<sanm_taylor_prop>();
+        p->prog = std::make_unique<Program>(be, g->g, out_var, remap_inp->d.out_size / 9, max_order);
+        p->prog->set_remap_in(remap_inp->d.in_size, remap_inp->d.rowptr.data(),
+                              remap_inp->d.idx.data(), remap_inp->d.coef.data());
+        p->n_in = remap_inp->d.in_size;
+        p->x = DVec{be, (size_t)p->n_in};
+        *prop = p.release();
+    });
+}
+void sanm_taylor_destroy(sanm_taylor_prop* p) { delete p; }
+
+int sanm_taylor_push_xi(sanm_taylor_prop* p, const double* x, double* y_k) {
+    return guard([&] {
+        Backend* be = backend();
+        sanm_check(!p->xi_known, "push_xi called twice for one order");
+        sanm_check(p->order <= p->prog->max_order(), "order exceeds max_order");
+        be->h2d(p->x.p(), x, p->n_in * 8);
+        be->run_pass(p->prog->dev(), p->order == 0 ? PASS_EVAL0 : PASS_COEFF, p->order, p->x.p());
+        be->sync();
+        p->xi_known = true;
+        if (y_k) {
+            int T = p->prog->T();
+            (void)T;
+            // the output is a local var; find its graph id through download of local index
+            const ProgramDev d = p->prog->dev();
+            const VarDesc& vd = p->prog->vars()[d.out_var];
+            std::vector<double> soa((size_t)9 * d.Tpad);
+            be->d2h(soa.data(), d.arena + vd.coef + (int64_t)p->order * 9 * d.Tpad,
+                    soa.size() * 8);
+            for (int64_t e = 0; e < d.T; ++e)
+                for (int c = 0; c < 9; ++c) y_k[e * 9 + c] = soa[c * d.Tpad + e];
+        }
+    });
+}
+
+int sanm_taylor_compute_next_order_bias(sanm_taylor_prop* p, double* bias) {
+    return guard([&] {
+        Backend* be = backend();
+        p->ensure_jacobian();
+        sanm_check(p->xi_known, "push_xi must precede compute_next_order_bias");
+        sanm_check(p->order < p->prog->max_order(), "order exceeds max_order");
+        ++p->order;
+        p->xi_known = false;
+        be->run_pass(p->prog->dev(), PASS_BIAS, p->order, nullptr);
+        be->sync();
+        if (bias) {
+            const ProgramDev d = p->prog->dev();
+            const VarDesc& vd = p->prog->vars()[d.out_var];
+            std::vector<double> soa((size_t)9 * d.Tpad);
+            be->d2h(soa.data(), d.arena + vd.bias, soa.size() * 8);
+            for (int64_t e = 0; e < d.T; ++e)
+                for (int c = 0; c < 9; ++c) bias[e * 9 + c] = soa[c * d.Tpad + e];
+        }
+    });
+}
+
+int sanm_taylor_get_jacobian(sanm_taylor_prop* p, double* jac) {
+    return guard([&] {
+        sanm_check(p->jacobian_done || p->order == 0, "jacobian must be taken at order 0");
+        sanm_check(p->xi_known || p->jacobian_done, "push_xi must precede get_jacobian");
+        p->ensure_jacobian();
+        backend()->sync();
+        p->prog->download_jacobian(jac);
+    });
+}
+
+int sanm_taylor_get_var(sanm_taylor_prop* p, int var, int order, double* dst) {
+    return guard([&] { p->prog->download_var(var, order, dst); });
+}
+
+int sanm_taylor_reset(sanm_taylor_prop* p) {
+    return guard([&] {
+        p->order = 0;
+        p->xi_known = false;
+        p->jacobian_done = false;
+    });
+}
+
+// ---- ANM -------------------------------------------------------------------
+void sanm_hyper_param_default(sanm_hyper_param* hp, int eqn_solver) {
+    HyperParam d;
+    hp->use_pade = d.use_pade;
+    hp->sanity_check = d.sanity_check;
+    hp->order = d.order;
+    hp->maxr = d.maxr;
+    hp->solution_check_tol = d.solution_check_tol;
+    hp->xcoeff_l2_penalty = d.xcoeff_l2_penalty;
+    hp->converge_rms = d.converge_rms;
+    hp->solver_rtol = d.solver_rtol;
+    hp->solver_maxit = d.solver_maxit;
+    hp->solver_kind = d.solver_kind;
+    hp->profile = d.profile;
+    (void)eqn_solver;
+}
+
+int sanm_anm_eqn_solver_create(const sanm_graph* g, int out_var, const sanm_sparse_desc* remap_inp,
+                               const sanm_sparse_desc* remap_out, const double* x0, const double* y,
+                               int64_t n, const sanm_hyper_param* hp, sanm_anm_solver** s) {
+    return guard([&] {
+        auto p = std::make_unique<sanm_anm_solver>();
+        auto* e = new AnmEqnSolver(backend(), g->g, out_var, remap_inp->d, remap_out->d, x0, y, n,
+                                   to_hp(hp));
+        p->drv.reset(e);
+        p->eqn = e;
+        *s = p.release();
+    });
+}
+int sanm_anm_vecscale_solver_create(const sanm_graph* g, int out_var,
+                                    const sanm_sparse_desc* remap_inp,
+                                    const sanm_sparse_desc* remap_out, const double* x0, double t0,
+                                    const double* v, int64_t n, const sanm_hyper_param* hp,
+                                    sanm_anm_solver** s) {
+    return guard([&] {
+        auto p = std::make_unique<sanm_anm_solver>();
+        p->drv = std::make_unique<AnmSolverVecScale>(backend(), g->g, out_var, remap_inp->d,
+                                                     remap_out->d, x0, n, t0, v, to_hp(hp));
+        *s = p.release();
+    });
+}
+int sanm_anm_implicit_solver_create(const sanm_graph* g, int out_var,
+                                    const sanm_sparse_desc* remap_inp,
+                                    const sanm_sparse_desc* remap_out, const double* x0, double t0,
+                                    int64_t n, const sanm_hyper_param* hp, sanm_anm_solver** s) {
+    return guard([&] {
+        auto p = std::make_unique<sanm_anm_solver>();
+        p->drv = std::make_unique<AnmImplicitSolver>(backend(), g->g, out_var, remap_inp->d,
+                                                     remap_out->d, x0, n, t0, to_hp(hp));
+        *s = p.release();
+    });
+}
+void sanm_anm_solver_destroy(sanm_anm_solver* s) { delete s; }
+
+int sanm_anm_next_iter(sanm_anm_solver* s) {
+    return guard([&] {
+        sanm_check(s->eqn, "next_iter is only defined for ANMEqnSolver");
+        s->eqn->next_iter();
+    });
+}
+int sanm_anm_restart(sanm_anm_solver* s, const double* x0) {
+    return guard([&] {
+        sanm_check(s->eqn, "restart is only defined for ANMEqnSolver");
+        s->eqn->restart(x0);
+    });
+}
+int sanm_anm_time_kernel(sanm_anm_solver* s, int kernel, int reps, int mode, int order,
+                         double* avg_ms) {
+    return guard([&] {
+        auto& d = *s->drv;
+        ProgramDev P = d.program().dev();
+        CsrDev A = d.pattern().csr();
+        sanm_check(reps > 0 && kernel >= 0 && kernel <= 2, "bad kernel/reps");
+        const double* x = d.last_xt_coeff_dev(kernel == 0 && mode == PASS_EVAL0 ? 0 : 1);
+        *avg_ms = d.backend()->time_kernel(kernel, reps, &P, mode, order, &A, x, d.scratch_dev(0));
+    });
+}
+int sanm_anm_update_approx(sanm_anm_solver* s) {
+    return guard([&] { s->drv->update_approx(); });
+}
+int sanm_anm_converged(const sanm_anm_solver* s, int* flag) {
+    return guard([&] {
+        sanm_check(s->eqn, "converged is only defined for ANMEqnSolver");
+        *flag = s->eqn->converged();
+    });
+}
+int sanm_anm_residual_rms(const sanm_anm_solver* s, double* r) {
+    return guard([&] {
+        sanm_check(s->eqn, "residual_rms is only defined for ANMEqnSolver");
+        *r = s->eqn->residual_rms();
+    });
+}
+int sanm_anm_get_x(const sanm_anm_solver* s, double* x) {
+    return guard([&] {
+        sanm_check(s->eqn, "get_x is only defined for ANMEqnSolver");
+        s->eqn->get_x(x);
+    });
+}
+int sanm_anm_get_t_upper(const sanm_anm_solver* s, double* t) {
+    return guard([&] { *t = s->drv->get_t_upper(); });
+}
+int sanm_anm_get_t_max_a(const sanm_anm_solver* s, double* a) {
+    return guard([&] { *a = s->drv->get_t_max_a(); });
+}
+int sanm_anm_solve_a(const sanm_anm_solver* s, double t, double* a) {
+    return guard([&] { *a = s->drv->solve_a(t); });
+}
+int sanm_anm_eval(const sanm_anm_solver* s, double a, double* x, double* t) {
+    return guard([&] { *t = s->drv->eval(a, x); });
+}
+int sanm_anm_nr_iter(const sanm_anm_solver* s, int64_t* iter) {
+    return guard([&] { *iter = s->drv->get_nr_iter(); });
+}
+int sanm_anm_nr_xt_coeffs(const sanm_anm_solver* s, int* nr) {
+    return guard([&] { *nr = s->drv->nr_valid_xt_coeffs(); });
+}
+int sanm_anm_xt_coeff(const sanm_anm_solver* s, int i, double* xt) {
+    return guard([&] { s->drv->get_xt_coeff(i, xt); });
+}
+int sanm_anm_has_pade(const sanm_anm_solver* s, int* flag) {
+    return guard([&] { *flag = s->drv->has_pade(); });
+}
+int sanm_anm_get_stats(const sanm_anm_solver* s, sanm_anm_stats* st) {
+    return guard([&] {
+        auto& d = *s->drv;
+        st->nr_unknown = d.nr_unknown();
+        st->nr_tet = d.program().T();
+        st->jacobian_nnz = d.pattern().nnz();
+        st->assembly_contribs = d.pattern().nr_contrib();
+        st->nr_linear_solve = d.linear_solver().nr_solve;
+        st->linear_iters_total = d.linear_solver().tot_iters;
+        st->linear_iters_last = d.linear_solver().last_iters;
+        st->linear_relres_last = d.linear_solver().last_relres;
+        st->arena_bytes = d.program().arena_bytes();
+    });
+}
+int sanm_anm_profile(const sanm_anm_solver* s, int max_tags, const char** names, double* seconds) {
+    auto* ms = const_cast<sanm_anm_solver*>(s);
+    ms->tag_storage.clear();
+    int k = 0;
+    for (auto& kv : s->drv->profile()) {
+        ms->tag_storage.push_back(kv.first);
+        if (k < max_tags && seconds) seconds[k] = kv.second;
+        ++k;
+    }
+    if (names)
+        for (int i = 0; i < k && i < max_tags; ++i) names[i] = ms->tag_storage[i].c_str();
+    return k;
+}
+int sanm_anm_trace(const sanm_anm_solver* s, int max_n, double* b_norm, double* x_norm, double* t) {
+    int k = s->drv->trace_t.size();
+    for (int i = 0; i < k && i < max_n; ++i) {
+        if (b_norm) b_norm[i] = s->drv->trace_b_norm[i];
+        if (x_norm) x_norm[i] = s->drv->trace_x_norm[i];
+        if (t) t[i] = s->drv->trace_t[i];
+    }
+    return k;
+}
+int sanm_anm_jacobian_csr(const sanm_anm_solver* s, int64_t* n, int64_t* nnz, uint32_t* rowptr,
+                          uint32_t* col, double* val) {
+    return guard([&] {
+        const JacobianPattern& p = s->drv->pattern();
+        if (n) *n = p.n();
+        if (nnz) *nnz = p.nnz();
+        if (rowptr) std::memcpy(rowptr, p.h_rowptr().data(), (p.n() + 1) * 4);
+        if (col) std::memcpy(col, p.h_col().data(), p.nnz() * 4);
+        if (val) backend()->d2h(val, p.csr().val, p.nnz() * 8);
+    });
+}
+
+// ---- fea -------------------------------------------------------------------
+int sanm_fea_model_create(int64_t nv, const double* vertices, int64_t nr_tet, const int32_t* tets,
+                          const uint8_t* fixed_mask, int energy_model, double young, double poisson,
+                          int inverse, const double* init_vtx_coord, const double* vtx_delta,
+                          sanm_fea_model** m) {
+    return guard([&] {
+        auto p = std::make_unique<sanm_fea_model>();
+        Material mat = Material::from_young_poisson(young, poisson);
+        if (inverse) {
+            sanm_check(!init_vtx_coord && !vtx_delta, "inverse model takes no init coord / delta");
+            make_inverse(p->m, nv, vertices, nr_tet, tets, fixed_mask, (EnergyModel)energy_model, mat);
+        } else {
+            make_forward(p->m, nv, vertices, nr_tet, tets, fixed_mask, (EnergyModel)energy_model, mat,
+                         init_vtx_coord, vtx_delta);
+        }
+        p->graph_view.g = p->m.graph;
+        p->inp.d = p->m.lt_inp;
+        p->out.d = p->m.lt_out;
+        *m = p.release();
+    });
+}
+void sanm_fea_model_destroy(sanm_fea_model* m) { delete m; }
+int sanm_fea_model_nr_unknown(const sanm_fea_model* m, int64_t* n) {
+    return guard([&] { *n = m->m.n; });
+}
+const sanm_graph* sanm_fea_model_graph(const sanm_fea_model* m) { return &m->graph_view; }
+int sanm_fea_model_output_var(const sanm_fea_model* m) { return m->m.y; }
+int sanm_fea_model_F_var(const sanm_fea_model* m) { return m->m.F; }
+const sanm_sparse_desc* sanm_fea_model_remap_inp(const sanm_fea_model* m) { return &m->inp; }
+const sanm_sparse_desc* sanm_fea_model_remap_out(const sanm_fea_model* m) { return &m->out; }
+int sanm_fea_model_x0(const sanm_fea_model* m, double* x0) {
+    return guard([&] { std::memcpy(x0, m->m.x0.data(), m->m.n * 8); });
+}
+int sanm_fea_model_copy_vtx_values(const sanm_fea_model* m, const double* vtx_values, double* out) {
+    return guard([&] {
+        for (int64_t i = 0; i < m->m.n; ++i) {
+            auto [v, c] = m->m.vertex_loc[i];
+            out[i] = vtx_values[(int64_t)v * 3 + c];
+        }
+    });
+}
+int sanm_fea_model_scatter(const sanm_fea_model* m, const double* x, double* vertices) {
+    return guard([&] {
+        for (int64_t i = 0; i < m->m.n; ++i) {
+            auto [v, c] = m->m.vertex_loc[i];
+            vertices[(int64_t)v * 3 + c] = x[i];
+        }
+    });
+}
+int sanm_fea_gravity_load(int64_t nv, const double* vertices, int64_t nr_tet, const int32_t* tets,
+                          double density, const double g[3], double* f_load) {
+    return guard([&] {
+        std::vector<double> f;
+        gravity_load(nv, vertices, nr_tet, tets, density, g, f);
+        std::memcpy(f_load, f.data(), f.size() * 8);
+    });
+}
+int sanm_fea_boundary_by_threshold(int64_t nv, const double* vertices, const uint8_t* is_surface,
+                                   const double proj_dir[3], double thresh,
+                                   const double* filter_dir, double filter_min, double filter_max,
+                                   uint8_t* fixed_mask) {
+    return guard([&] {
+        std::vector<uint8_t> f;
+        boundary_by_threshold(nv, vertices, is_surface, proj_dir, thresh, filter_dir, filter_min,
+                              filter_max, f);
+        std::memcpy(fixed_mask, f.data(), f.size());
+    });
+}
+
+// ---- host scalar helpers -----------------------------------------------------
+int sanm_poly_solve_eqn(const double* f, int n, double xmin, double xmax, double b, double eps,
+                        double* x) {
+    return guard([&] { *x = poly::solve_eqn(std::vector<double>(f, f + n), xmin, xmax, b, eps); });
+}
+int sanm_poly_real_roots(const double* f, int n, double* roots, int* nr_roots) {
+    return guard([&] {
+        std::vector<double> r;
+        if (!poly::real_roots(std::vector<double>(f, f + n), r)) {
+            *nr_roots = -1;
+            return;
+        }
+        *nr_roots = r.size();
+        for (size_t i = 0; i < r.size(); ++i) roots[i] = r[i];
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,422 @@
+#include "graph.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+
+namespace sanm_hip {
+
+void sanm_throw(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    throw SanmError{code, buf};
+}
+
+// ------------------------------------------------------------------ Graph --
+void Graph::chk(int v) const {
+    sanm_check(v >= 0 && v < (int)vars.size(), "invalid var id %d", v);
+}
+
+int Graph::add(GraphOp op, std::initializer_list<int> out_sizes) {
+    int oi = ops.size();
+    int k = 0;
+    for (int sz : out_sizes) {
+        op.out.push_back(vars.size());
+        vars.push_back({sz, oi, k++});
+    }
+    int first = op.out[0];
+    ops.push_back(std::move(op));
+    return first;
+}
+
+int Graph::placeholder() {
+    GraphOp op;
+    op.type = OP_PLACEHOLDER;
+    return add(std::move(op), {9});
+}
+
+int Graph::constant(const double* val, int64_t batch, int size) {
+    sanm_check(size == 1 || size == 3 || size == 9, "constant: unsupported per-tet size %d", size);
+    GraphOp op;
+    op.type = OP_CONSTANT;
+    op.batch = batch;
+    op.value.assign(val, val + batch * size);
+    return add(std::move(op), {size});
+}
+
+int Graph::linear_combine(int n, const double* coeffs, const int* vs, double bias) {
+    sanm_check(n >= 1 && n <= MAX_OP_IN, "linear_combine: 1..%d inputs supported, got %d",
+               MAX_OP_IN, n);
+    GraphOp op;
+    op.type = OP_LINCOMB;
+    op.bias = bias;
+    int osz = 1;
+    for (int i = 0; i < n; ++i) {
+        chk(vs[i]);
+        op.in.push_back(vs[i]);
+        op.coeffs.push_back(coeffs[i]);
+        int sz = vars[vs[i]].size;
+        // only batched scalars broadcast (oprs/elem_arith.cpp:13-38)
+        sanm_check(sz == osz || sz == 1 || osz == 1, "invalid shape in elem arith: %d vs %d", osz,
+                   sz);
+        osz = std::max(osz, sz);
+    }
+    return add(std::move(op), {osz});
+}
+
+int Graph::multiply(int a, int b) {
+    chk(a);
+    chk(b);
+    int sa = vars[a].size, sb = vars[b].size;
+    sanm_check(sa == sb || sa == 1 || sb == 1, "invalid shape in elem arith: %d vs %d", sa, sb);
+    GraphOp op;
+    op.type = OP_MULTIPLY;
+    op.in = {a, b};
+    return add(std::move(op), {std::max(sa, sb)});
+}
+
+int Graph::pow(int x, double e) {
+    chk(x);
+    if (e == 1.0) return x;  // oprs.cpp:30-32
+    sanm_check(std::fabs(e) > 1e-9, "zero power not handled");
+    GraphOp op;
+    op.type = OP_POW;
+    op.exponent = e;
+    op.in = {x};
+    return add(std::move(op), {vars[x].size});
+}
+
+int Graph::log(int x) {
+    chk(x);
+    GraphOp op;
+    op.type = OP_LOG;
+    op.in = {x};
+    return add(std::move(op), {vars[x].size});
+}
+
+int Graph::reduce_sum(int x, int axis) {
+    chk(x);
+    sanm_check(axis != 0, "can not reduce on batch dim");
+    if (axis != -1) sanm_throw(SANM_ERR_UNSUPPORTED, "reduce_sum: only axis=-1 is on the hot path");
+    GraphOp op;
+    op.type = OP_REDUCE_SUM;
+    op.in = {x};
+    return add(std::move(op), {1});
+}
+
+int Graph::batched_matmul(int a, int b) {
+    chk(a);
+    chk(b);
+    sanm_check(vars[a].size == 9 && vars[b].size == 9, "invalid operand shapes for matmul");
+    GraphOp op;
+    op.type = OP_MATMUL;
+    op.in = {a, b};
+    return add(std::move(op), {9});
+}
+
+int Graph::batched_mat_inv_mul(int x, int a, bool is_left) {
+    chk(x);
+    sanm_check(vars[x].size == 9, "invalid shape for matinv");
+    GraphOp op;
+    op.type = OP_MATINVMUL;
+    op.flags = is_left ? OP_FLAG_IS_LEFT : 0;
+    op.in = {x};
+    if (a >= 0) {
+        chk(a);
+        sanm_check(vars[a].size == 9, "invalid shape for matinv");
+        op.in.push_back(a);
+    } else {
+        op.flags |= OP_FLAG_USE_IDENTITY;
+    }
+    return add(std::move(op), {9});
+}
+
+int Graph::batched_det(int x) {
+    chk(x);
+    sanm_check(vars[x].size == 9, "invalid shape for determinant");
+    GraphOp op;
+    op.type = OP_DET;
+    op.in = {x};
+    return add(std::move(op), {1});
+}
+
+int Graph::batched_transpose(int x) {
+    chk(x);
+    sanm_check(vars[x].size == 9, "invalid shape for transpose");
+    GraphOp op;
+    op.type = OP_TRANSPOSE;
+    op.in = {x};
+    return add(std::move(op), {9});
+}
+
+int Graph::batched_mul_eye(int x, int dim) {
+    chk(x);
+    sanm_check(vars[x].size == 1, "the input shape must be a scalar");
+    sanm_check(dim == 3, "only dim=3 is supported");
+    GraphOp op;
+    op.type = OP_MULEYE;
+    op.in = {x};
+    return add(std::move(op), {9});
+}
+
+void Graph::batched_svd_w(int x, bool require_rotation, int out[3]) {
+    chk(x);
+    sanm_check(vars[x].size == 9, "invalid shape for SVD-W");
+    GraphOp op;
+    op.type = OP_SVDW;
+    op.flags = require_rotation ? OP_FLAG_REQUIRE_ROT : 0;
+    op.in = {x};
+    int first = add(std::move(op), {9, 3, 9});
+    out[0] = first;
+    out[1] = first + 1;
+    out[2] = first + 2;
+}
+
+// ---------------------------------------------------------------- Program --
+Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_order) : m_be{be} {
+    sanm_check(out_var >= 0 && out_var < (int)g.vars.size(), "invalid output var");
+    sanm_check(T > 0 && max_order >= 1, "invalid T/order");
+    const int64_t Tpad = (T + 63) / 64 * 64;
+    const int N = max_order;
+
+    // topological order of the operators the output depends on
+    // (libsanm/symbolic.cpp:63-118)
+    std::vector<int> topo;
+    std::vector<char> seen(g.ops.size(), 0);
+    std::function<void(int)> visit = [&](int oi) {
+        if (seen[oi]) return;
+        seen[oi] = 1;
+        for (int v : g.ops[oi].in) visit(g.vars[v].producer);
+        topo.push_back(oi);
+    };
+    visit(g.vars[out_var].producer);
+
+    // local variable table, reader counts, constness
+    m_var_map.assign(g.vars.size(), -1);
+    std::vector<int> nr_reader;
+    auto local = [&](int gv) {
+        if (m_var_map[gv] < 0) {
+            m_var_map[gv] = m_vars.size();
+            VarDesc d{};
+            d.size = g.vars[gv].size;
+            d.jac = -1;
+            m_vars.push_back(d);
+            nr_reader.push_back(0);
+        }
+        return m_var_map[gv];
+    };
+    int nr_placeholder = 0;
+    for (int oi : topo) {
+        const GraphOp& op = g.ops[oi];
+        for (int v : op.in) nr_reader[local(v)]++;
+        bool all_const = op.type != OP_PLACEHOLDER;
+        for (int v : op.in) all_const = all_const && m_vars[local(v)].is_const;
+        for (int v : op.out) m_vars[local(v)].is_const = all_const ? 1 : 0;
+        if (op.type == OP_PLACEHOLDER) {
+            ++nr_placeholder;
+            m_placeholder_var = local(op.out[0]);
+        }
+    }
+    sanm_check(nr_placeholder == 1, "exactly one placeholder input is supported, got %d",
+               nr_placeholder);
+    const int lout = m_var_map[out_var];
+    const int odim = m_vars[lout].size;
+    sanm_check(odim == 9, "the graph output must be a batched 3x3 matrix");
+    sanm_check(!m_vars[lout].is_const, "the output does not depend on the input");
+
+    // arena layout
+    int64_t off = 0;
+    auto take = [&](int64_t n) {
+        int64_t r = off;
+        off += n;
+        return r;
+    };
+    for (auto& d : m_vars) {
+        d.coef = take((int64_t)(d.is_const ? 1 : N + 1) * d.size * Tpad);
+        d.bias = take((int64_t)d.size * Tpad);
+    }
+    m_jac_begin = off;
+    for (auto& d : m_vars)
+        if (!d.is_const) d.jac = take((int64_t)odim * d.size * Tpad);
+    m_jac_end = off;
+
+    for (int oi : topo) {
+        const GraphOp& op = g.ops[oi];
+        OpDesc o{};
+        o.type = op.type;
+        o.flags = op.flags;
+        o.nin = op.in.size();
+        o.nout = op.out.size();
+        for (int i = 0; i < o.nin; ++i) o.in[i] = m_var_map[op.in[i]];
+        for (int i = 0; i < o.nout; ++i) o.out[i] = m_var_map[op.out[i]];
+        for (int i = 0; i < 4; ++i) o.aux[i] = -1;
+        const int osz = m_vars[o.out[0]].size;
+        switch (op.type) {
+            case OP_LINCOMB:
+                for (int i = 0; i < o.nin; ++i) o.p[i] = op.coeffs[i];
+                o.p[MAX_OP_IN] = op.bias;
+                break;
+            case OP_MULTIPLY:
+                o.aux[0] = take((int64_t)osz * Tpad);
+                break;
+            case OP_POW:
+                o.p[0] = op.exponent;
+                [[fallthrough]];
+            case OP_LOG:
+                o.aux[0] = take((int64_t)osz * Tpad);
+                o.aux[1] = take((int64_t)osz * Tpad);
+                break;
+            case OP_MATMUL:
+                o.aux[0] = take(9 * Tpad);
+                break;
+            case OP_MATINVMUL:
+                o.aux[0] = take(9 * Tpad);
+                o.aux[1] = take(9 * Tpad);
+                break;
+            case OP_DET:
+                o.aux[0] = take(9 * Tpad);
+                o.aux[1] = take(Tpad);
+                o.aux[2] = take((int64_t)(N + 1) * 3 * Tpad);
+                o.aux[3] = take(3 * Tpad);
+                break;
+            case OP_SVDW:
+                // pw_mode only (oprs/linalg.cpp:533): U and S must have no reader
+                if (nr_reader[o.out[0]] || nr_reader[o.out[1]] || lout == o.out[0] ||
+                    lout == o.out[1]) {
+                    sanm_throw(SANM_ERR_UNSUPPORTED,
+                               "batched_svd_w: only the W output may be read on the device path "
+                               "(polar-decomposition mode)");
+                }
+                o.aux[0] = take((int64_t)(N + 1) * 9 * Tpad);
+                o.aux[1] = take(9 * Tpad);
+                o.aux[2] = take(9 * Tpad);
+                o.aux[3] = take(9 * Tpad);
+                break;
+            default:
+                break;
+        }
+        m_ops.push_back(o);
+    }
+    m_arena_doubles = off;
+
+    // device buffers
+    double* arena = static_cast<double*>(be->alloc(off * sizeof(double)));
+    be->zero(arena, off * sizeof(double));
+    m_d_ops = be->alloc(m_ops.size() * sizeof(OpDesc));
+    be->h2d(m_d_ops, m_ops.data(), m_ops.size() * sizeof(OpDesc));
+    m_d_vars = be->alloc(m_vars.size() * sizeof(VarDesc));
+    be->h2d(m_d_vars, m_vars.data(), m_vars.size() * sizeof(VarDesc));
+
+    // constants: AoS (T,size) or (1,size) -> SoA coefficient 0
+    std::vector<double> soa;
+    for (int oi : topo) {
+        const GraphOp& op = g.ops[oi];
+        if (op.type != OP_CONSTANT) continue;
+        const VarDesc& d = m_vars[m_var_map[op.out[0]]];
+        sanm_check(op.batch == T || op.batch == 1,
+                   "ConstantOprMeta shape mismatch: tot_batch=%ld value_shape=%ld", (long)T,
+                   (long)op.batch);
+        soa.assign((size_t)d.size * Tpad, 0.0);
+        for (int64_t e = 0; e < T; ++e)
+            for (int c = 0; c < d.size; ++c)
+                soa[c * Tpad + e] = op.value[(op.batch == 1 ? 0 : e) * d.size + c];
+        // pad lanes replicate tet 0 so that padded lanes stay finite
+        for (int64_t e = T; e < Tpad; ++e)
+            for (int c = 0; c < d.size; ++c) soa[c * Tpad + e] = soa[c * Tpad];
+        be->h2d(arena + d.coef, soa.data(), soa.size() * sizeof(double));
+    }
+
+    m_dev.ops = static_cast<const OpDesc*>(m_d_ops);
+    m_dev.vars = static_cast<const VarDesc*>(m_d_vars);
+    m_dev.arena = arena;
+    m_dev.nops = m_ops.size();
+    m_dev.out_var = lout;
+    m_dev.odim = odim;
+    m_dev.max_order = N;
+    m_dev.T = T;
+    m_dev.Tpad = Tpad;
+    m_dev.rin = {nullptr, nullptr, 0};
+}
+
+Program::~Program() {
+    m_be->free(m_dev.arena);
+    m_be->free(m_d_ops);
+    m_be->free(m_d_vars);
+    if (m_d_rin_idx) m_be->free(m_d_rin_idx);
+    if (m_d_rin_coef) m_be->free(m_d_rin_coef);
+}
+
+void Program::set_remap_in(int64_t n_in, const uint64_t* rowptr, const uint64_t* idx,
+                           const double* coef) {
+    const int64_t T = m_dev.T, Tpad = m_dev.Tpad;
+    int nslot = 0;
+    for (int64_t o = 0; o < T * 9; ++o) {
+        sanm_check(rowptr[o + 1] >= rowptr[o], "remap_in: rowptr not monotone");
+        nslot = std::max<int>(nslot, rowptr[o + 1] - rowptr[o]);
+    }
+    sanm_check(nslot <= 64, "remap_in: %d entries for one output element", nslot);
+    nslot = std::max(nslot, 1);
+    std::vector<uint32_t> hidx((size_t)nslot * 9 * Tpad, 0);
+    std::vector<double> hcoef((size_t)nslot * 9 * Tpad, 0.0);
+    for (int64_t e = 0; e < T; ++e)
+        for (int c = 0; c < 9; ++c) {
+            int64_t o = e * 9 + c;
+            int s = 0;
+            for (uint64_t p = rowptr[o]; p < rowptr[o + 1]; ++p, ++s) {
+                sanm_check((int64_t)idx[p] < n_in, "remap_in: index %lu out of range",
+                           (unsigned long)idx[p]);
+                hidx[((size_t)s * 9 + c) * Tpad + e] = idx[p];
+                hcoef[((size_t)s * 9 + c) * Tpad + e] = coef[p];
+            }
+        }
+    if (m_d_rin_idx) m_be->free(m_d_rin_idx);
+    if (m_d_rin_coef) m_be->free(m_d_rin_coef);
+    m_d_rin_idx = m_be->alloc(hidx.size() * sizeof(uint32_t));
+    m_d_rin_coef = m_be->alloc(hcoef.size() * sizeof(double));
+    m_be->h2d(m_d_rin_idx, hidx.data(), hidx.size() * sizeof(uint32_t));
+    m_be->h2d(m_d_rin_coef, hcoef.data(), hcoef.size() * sizeof(double));
+    m_dev.rin = {static_cast<const uint32_t*>(m_d_rin_idx),
+                 static_cast<const double*>(m_d_rin_coef), nslot};
+    m_n_in = n_in;
+}
+
+void Program::zero_jacobians() {
+    m_be->zero(m_dev.arena + m_jac_begin, (m_jac_end - m_jac_begin) * sizeof(double));
+}
+
+void Program::download_var(int graph_var, int order, double* dst) const {
+    sanm_check(graph_var >= 0 && graph_var < (int)m_var_map.size() && m_var_map[graph_var] >= 0,
+               "var %d is not part of the compiled program", graph_var);
+    const VarDesc& d = m_vars[m_var_map[graph_var]];
+    const int64_t T = m_dev.T, Tpad = m_dev.Tpad;
+    std::vector<double> soa((size_t)d.size * Tpad);
+    if (order >= 1 && d.is_const) {
+        std::fill(dst, dst + T * d.size, 0.0);
+        return;
+    }
+    sanm_check(order <= m_dev.max_order, "order %d out of range", order);
+    int64_t off = order < 0 ? d.bias : d.coef + (int64_t)order * d.size * Tpad;
+    m_be->d2h(soa.data(), m_dev.arena + off, soa.size() * sizeof(double));
+    for (int64_t e = 0; e < T; ++e)
+        for (int c = 0; c < d.size; ++c) dst[e * d.size + c] = soa[c * Tpad + e];
+}
+
+void Program::download_jacobian(double* dst) const {
+    const VarDesc& d = m_vars[m_placeholder_var];
+    const int64_t T = m_dev.T, Tpad = m_dev.Tpad;
+    const int odim = m_dev.odim;
+    std::vector<double> soa((size_t)odim * d.size * Tpad);
+    m_be->d2h(soa.data(), m_dev.arena + d.jac, soa.size() * sizeof(double));
+    for (int64_t e = 0; e < T; ++e)
+        for (int r = 0; r < odim; ++r)
+            for (int c = 0; c < d.size; ++c)
+                dst[(e * odim + r) * d.size + c] = soa[((size_t)r * d.size + c) * Tpad + e];
+}
+
+}  // namespace sanm_hip

@@ -1,0 +1,125 @@
+// Host-side computing graph and its compilation into a device program.
+//
+// Mirrors the operator-construction API of the reference (libsanm/oprs.h:14-103,
+// oprs.cpp:16-102): the same operators with the same argument meaning, but
+// variables are small integer ids instead of VarNode pointers so the graph can
+// cross the C ABI.  `compile()` plays the role of TaylorCoeffProp's constructor
+// (libsanm/symbolic.cpp:142-160): it topologically sorts the operators needed
+// by the output, counts readers, and lays the per-variable state out in one
+// device arena (see program.h).
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "backend.h"
+#include "program.h"
+
+namespace sanm_hip {
+
+struct SanmError {
+    int code;
+    std::string msg;
+};
+constexpr int SANM_OK = 0;
+constexpr int SANM_ERR_ASSERT = 1;     // SANMAssertionError (libsanm/utils.h:34-50)
+constexpr int SANM_ERR_NUMERICAL = 2;  // SANMNumericalError
+constexpr int SANM_ERR_HIP = 3;
+constexpr int SANM_ERR_UNSUPPORTED = 4;
+
+[[noreturn]] void sanm_throw(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+#define sanm_check(cond, ...)                                        \
+    do {                                                             \
+        if (!(cond)) ::sanm_hip::sanm_throw(SANM_ERR_ASSERT, __VA_ARGS__); \
+    } while (0)
+
+struct GraphVar {
+    int size;      // per-tet element count: 1, 3 or 9
+    int producer;  // index into Graph::ops
+    int out_idx;
+};
+
+struct GraphOp {
+    OpType type;
+    int flags = 0;
+    std::vector<int> in, out;
+    std::vector<double> coeffs;  // LINCOMB
+    double bias = 0;             // LINCOMB
+    double exponent = 0;         // POW
+    std::vector<double> value;   // CONSTANT, row-major (T, size)
+    int64_t batch = 0;           // CONSTANT
+};
+
+class Graph {
+public:
+    std::vector<GraphOp> ops;
+    std::vector<GraphVar> vars;
+
+    int placeholder();
+    int constant(const double* val, int64_t batch, int size);
+    int linear_combine(int n, const double* coeffs, const int* vars, double bias);
+    int multiply(int a, int b);
+    int pow(int x, double e);
+    int log(int x);
+    int reduce_sum(int x, int axis);
+    int batched_matmul(int a, int b);
+    int batched_mat_inv_mul(int x, int a /* -1: identity */, bool is_left);
+    int batched_det(int x);
+    int batched_transpose(int x);
+    int batched_mul_eye(int x, int dim);
+    void batched_svd_w(int x, bool require_rotation, int out[3]);
+
+private:
+    int add(GraphOp op, std::initializer_list<int> out_sizes);
+    void chk(int v) const;
+};
+
+// A graph compiled for T tets and a maximum expansion order, resident on the
+// device.  Owns the arena.
+class Program {
+public:
+    Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_order);
+    ~Program();
+    Program(const Program&) = delete;
+
+    //! attach the remap_in table (ELL), converting flattened AoS output
+    //! indices e*9+c (fea/mesh_template.h:73-110) to the SoA layout
+    void set_remap_in(int64_t n_in, const uint64_t* rowptr, const uint64_t* idx,
+                      const double* coef);
+
+    ProgramDev dev() const { return m_dev; }
+    int64_t T() const { return m_dev.T; }
+    int64_t Tpad() const { return m_dev.Tpad; }
+    int max_order() const { return m_dev.max_order; }
+    int placeholder_var() const { return m_placeholder_var; }
+    int local_var(int graph_var) const { return m_var_map.at(graph_var); }
+    const std::vector<VarDesc>& vars() const { return m_vars; }
+    int64_t n_in() const { return m_n_in; }
+
+    void zero_jacobians();
+    //! device pointer of the output's order-0 value / bias, SoA [9][Tpad]
+    const double* out_coef0() const { return m_dev.arena + m_vars[m_dev.out_var].coef; }
+    const double* out_bias() const { return m_dev.arena + m_vars[m_dev.out_var].bias; }
+    const double* placeholder_jac() const { return m_dev.arena + m_vars[m_placeholder_var].jac; }
+    //! copy a coefficient (or bias when order < 0) of a graph var to host, AoS (T,size)
+    void download_var(int graph_var, int order, double* dst) const;
+    void download_jacobian(double* dst) const;  // (T, odim, 9)
+    size_t arena_bytes() const { return m_arena_doubles * sizeof(double); }
+
+private:
+    Backend* m_be;
+    ProgramDev m_dev{};
+    std::vector<OpDesc> m_ops;
+    std::vector<VarDesc> m_vars;
+    std::vector<int> m_var_map;  // graph var -> local var (-1 if unused)
+    int m_placeholder_var = -1;
+    int64_t m_arena_doubles = 0, m_jac_begin = 0, m_jac_end = 0;
+    int64_t m_n_in = 0;
+    void* m_d_ops = nullptr;
+    void* m_d_vars = nullptr;
+    void* m_d_rin_idx = nullptr;
+    void* m_d_rin_coef = nullptr;
+};
+
+}  // namespace sanm_hip

@@ -1,0 +1,154 @@
+#include "poly.h"
+
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <limits>
+
+#include "graph.h"
+
+namespace sanm_hip {
+namespace poly {
+
+double eval(const double* f, int n, double x) {
+    double r = 0;
+    for (int i = n - 1; i >= 0; --i) r = r * x + f[i];
+    return r;
+}
+
+double stable_x_range(int order) { return std::pow(1e15, 1.0 / static_cast<double>(order)); }
+
+double brent_zero(double a, double b, double t, const std::function<double(double)>& f) {
+    const double macheps = std::numeric_limits<double>::epsilon();
+    double sa = a, sb = b, fa = f(sa), fb = f(sb);
+    double c = sa, fc = fa, e = sb - sa, d = e;
+    for (;;) {
+        if (std::fabs(fc) < std::fabs(fb)) {
+            sa = sb; sb = c; c = sa;
+            fa = fb; fb = fc; fc = fa;
+        }
+        double tol = 2.0 * macheps * std::fabs(sb) + t;
+        double m = 0.5 * (c - sb);
+        if (std::fabs(m) <= tol || fb == 0.0) break;
+        if (std::fabs(e) < tol || std::fabs(fa) <= std::fabs(fb)) {
+            e = m;
+            d = e;
+        } else {
+            double p, q, r, s = fb / fa;
+            if (sa == c) {
+                p = 2.0 * m * s;
+                q = 1.0 - s;
+            } else {
+                q = fa / fc;
+                r = fb / fc;
+                p = s * (2.0 * m * q * (q - r) - (sb - sa) * (r - 1.0));
+                q = (q - 1.0) * (r - 1.0) * (s - 1.0);
+            }
+            if (0.0 < p) q = -q; else p = -p;
+            s = e;
+            e = d;
+            if (2.0 * p < 3.0 * m * q - std::fabs(tol * q) && p < std::fabs(0.5 * s * q)) {
+                d = p / q;
+            } else {
+                e = m;
+                d = e;
+            }
+        }
+        sa = sb;
+        fa = fb;
+        if (tol < std::fabs(d)) sb += d;
+        else if (0.0 < m) sb += tol;
+        else sb -= tol;
+        fb = f(sb);
+        if ((0.0 < fb && 0.0 < fc) || (fb <= 0.0 && fc <= 0.0)) {
+            c = sa;
+            fc = fa;
+            e = sb - sa;
+            d = e;
+        }
+    }
+    return sb;
+}
+
+double solve_eqn(const std::vector<double>& f, double xmin, double xmax, double b, double eps) {
+    sanm_check(!f.empty() && xmin < xmax, "solve_eqn: bad interval [%g, %g]", xmin, xmax);
+    auto fn = [&](double x) { return eval(f, x) - b; };
+    double f0 = fn(xmin), f1 = fn(xmax);
+    sanm_check(f0 * f1 <= 0, "no zero point: f0=%g f1=%g", f0, f1);
+    return brent_zero(xmin, xmax, eps, fn);
+}
+
+// All complex roots by the Aberth-Ehrlich simultaneous iteration, then the
+// real ones are kept.  The reference uses ACM algorithm 30 (Bairstow+Newton);
+// only the set of real roots matters to its caller (pade.cpp:113-126).
+bool real_roots(const std::vector<double>& f, std::vector<double>& roots) {
+    roots.clear();
+    int n = (int)f.size() - 1;
+    while (n >= 0 && f[n] == 0.0) --n;
+    if (n <= 0) return true;
+    // strip zero roots
+    int lo = 0;
+    while (lo < n && f[lo] == 0.0) ++lo;
+    for (int i = 0; i < lo; ++i) roots.push_back(0.0);
+    std::vector<double> c(f.begin() + lo, f.begin() + n + 1);
+    n -= lo;
+    if (n == 0) return true;
+    using cd = std::complex<long double>;
+    // monic, long double for a little headroom
+    std::vector<long double> a(n + 1);
+    for (int i = 0; i <= n; ++i) a[i] = (long double)c[i] / (long double)c[n];
+    // Cauchy bound based start radius
+    long double radius = 0;
+    for (int i = 0; i < n; ++i) radius = std::max(radius, std::pow(std::fabs(a[i]), 1.0L / (n - i)));
+    if (radius == 0) {
+        for (int i = 0; i < n; ++i) roots.push_back(0.0);
+        return true;
+    }
+    std::vector<cd> z(n);
+    for (int i = 0; i < n; ++i) {
+        long double ang = 2.0L * 3.14159265358979323846264338327950288L * i / n + 0.4L;
+        z[i] = cd(radius * std::cos(ang), radius * std::sin(ang));
+    }
+    bool converged = false;
+    for (int it = 0; it < 2000 && !converged; ++it) {
+        long double maxstep = 0;
+        for (int i = 0; i < n; ++i) {
+            cd p = 1.0L, dp = 0.0L;  // Horner for p and p'
+            for (int k = n - 1; k >= 0; --k) {
+                dp = dp * z[i] + p;
+                p = p * z[i] + cd(a[k]);
+            }
+            if (std::abs(p) == 0) continue;
+            cd ratio = p / dp;
+            cd sum = 0.0L;
+            for (int j = 0; j < n; ++j)
+                if (j != i) sum += cd(1.0L) / (z[i] - z[j]);
+            cd step = ratio / (cd(1.0L) - ratio * sum);
+            z[i] -= step;
+            maxstep = std::max(maxstep, std::abs(step) / std::max<long double>(std::abs(z[i]), 1e-300L));
+        }
+        if (maxstep < 1e-17L) converged = true;
+    }
+    if (!converged) {
+        // accept if every root has a tiny residual anyway
+        for (int i = 0; i < n; ++i) {
+            cd p = 1.0L;
+            long double scale = 1.0L;
+            for (int k = n - 1; k >= 0; --k) {
+                p = p * z[i] + cd(a[k]);
+                scale = scale * std::abs(z[i]) + std::fabs(a[k]);
+            }
+            if (std::abs(p) > 1e-10L * scale) return false;
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        long double re = z[i].real(), im = z[i].imag();
+        if (std::fabs(im) <= 1e-8L * std::max<long double>(1.0L, std::fabs(re)))
+            roots.push_back((double)re);
+    }
+    std::sort(roots.begin(), roots.end());
+    return true;
+}
+
+}  // namespace poly
+}  // namespace sanm_hip

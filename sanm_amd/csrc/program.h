@@ -1,0 +1,82 @@
+// Device-visible description of a compiled computing graph ("program").
+//
+// The reference interprets its graph operator by operator on host tensors
+// (libsanm/symbolic.cpp:162-289).  Here the topologically sorted graph is
+// compiled once into a flat array of OpDesc / VarDesc records; a single HIP
+// kernel launch (one lane per tet) then runs a whole pass (order-0 eval,
+// reverse-mode Jacobian, order-k bias, order-k coefficient) over it.
+//
+// Storage: one arena of doubles in HBM.  Every per-tet quantity is stored
+// SoA: element c of tet e of a tensor at arena offset `off` lives at
+// off + c*Tpad + e, so the 64 lanes of a wavefront read 512 contiguous bytes.
+#pragma once
+#include <cstdint>
+
+namespace sanm_hip {
+
+enum OpType : int32_t {
+    OP_PLACEHOLDER = 0,  // libsanm/oprs/misc.cpp:13-44
+    OP_CONSTANT = 1,     // libsanm/oprs/misc.cpp:48-100
+    OP_LINCOMB = 2,      // libsanm/oprs/elem_arith.cpp:42-124
+    OP_MULTIPLY = 3,     // libsanm/oprs/elem_arith.cpp:128-217
+    OP_LOG = 4,          // libsanm/analytic_unary.cpp:13-34
+    OP_POW = 5,          // libsanm/analytic_unary.cpp:36-139
+    OP_REDUCE_SUM = 6,   // libsanm/oprs/reduce.cpp:11-102 (axis=-1)
+    OP_MATMUL = 7,       // libsanm/oprs/linalg.cpp:339-418
+    OP_MATINVMUL = 8,    // libsanm/oprs/linalg.cpp:67-217
+    OP_DET = 9,          // libsanm/oprs/linalg.cpp:221-282
+    OP_TRANSPOSE = 10,   // libsanm/oprs/linalg.cpp:286-335
+    OP_MULEYE = 11,      // libsanm/oprs/linalg.cpp:422-479
+    OP_SVDW = 12,        // libsanm/oprs/linalg.cpp:483-615 (pw_mode)
+};
+
+enum PassMode : int32_t {
+    PASS_EVAL0 = 0,  // infer_shape_eval_bias, symbolic.cpp:172-176
+    PASS_GRAD = 1,   // ensure_jacobian reverse sweep, symbolic.cpp:206-247
+    PASS_BIAS = 2,   // compute_next_order_bias, symbolic.cpp:249-289
+    PASS_COEFF = 3,  // push_xi at order >= 1, symbolic.cpp:177-178
+};
+
+constexpr int OP_FLAG_IS_LEFT = 1;         // MATINVMUL: Y X = A
+constexpr int OP_FLAG_USE_IDENTITY = 2;    // MATINVMUL: A = I
+constexpr int OP_FLAG_REQUIRE_ROT = 4;     // SVDW: force det(W) = +1
+constexpr int MAX_OP_IN = 4;
+
+struct VarDesc {
+    int64_t coef;  // arena offset of coefficient 0; order k at coef + k*size*Tpad
+    int64_t bias;  // arena offset of cur_order_bias
+    int64_t jac;   // arena offset of the Jacobian [odim][size][Tpad]; -1 if none
+    int32_t size;  // 1 (batched scalar), 3 (singular values) or 9 (3x3)
+    int32_t is_const;  // coefficients of order >= 1 are identically zero
+};
+
+struct OpDesc {
+    int32_t type, nin, nout, flags;
+    int32_t in[MAX_OP_IN];
+    int32_t out[3];
+    int32_t pad_;
+    double p[MAX_OP_IN + 2];  // LINCOMB: coeffs then bias at p[MAX_OP_IN]; POW: p[0]=exponent
+    int64_t aux[4];           // arena offsets of per-operator scratch (see tet_ops.h)
+};
+
+// remap_in as an ELL table: for output element (tet e, comp c) and slot s,
+// idx/coef at [(s*9 + c)*Tpad + e]; unused slots carry coef 0.
+struct RemapInDev {
+    const uint32_t* idx;
+    const double* coef;
+    int32_t nslot;
+};
+
+struct ProgramDev {
+    const OpDesc* ops;
+    const VarDesc* vars;
+    double* arena;
+    int32_t nops;
+    int32_t out_var;   // the graph output (3x3)
+    int32_t odim;      // size of the output var (9)
+    int32_t max_order;
+    int64_t T, Tpad;
+    RemapInDev rin;
+};
+
+}  // namespace sanm_hip

@@ -1,0 +1,75 @@
+// Sparse linear maps and the Jacobian CSR pattern.
+//
+// SparseDesc is the host form of the reference's SparseLinearDescCompressed
+// (libsanm/anm.h:76-85): for every output element a list of (coeff, input
+// index).  JacobianPattern is the symbolic product
+//     remap_out . blockdiag(J_e) . remap_in
+// of libsanm/anm.cpp:362-438 / :520-608, computed ONCE per model: the sparsity
+// pattern never changes between ANM steps (only J_e does), so the reference's
+// per-step sort+merge (sparse_solver.cpp:250-305) becomes a fixed gather list
+// per non-zero that a HIP kernel evaluates every step.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "backend.h"
+#include "graph.h"
+
+namespace sanm_hip {
+
+struct SparseDesc {
+    int64_t out_size = 0, in_size = 0;
+    std::vector<uint64_t> rowptr;  // out_size+1
+    std::vector<uint64_t> idx;
+    std::vector<double> coef;
+
+    SparseDesc() = default;
+    SparseDesc(int64_t out_size, int64_t in_size, const uint64_t* rowptr, const uint64_t* idx,
+               const double* coef);
+};
+
+//! device copy of the rows of a SparseDesc whose *inputs* are a flattened
+//! (T,9) AoS tensor, re-indexed to the SoA layout [c][Tpad]
+class DeviceRows {
+public:
+    DeviceRows(Backend* be, const SparseDesc& d, int64_t T, int64_t Tpad);
+    ~DeviceRows();
+    SparseRowsDev dev() const { return m_dev; }
+
+private:
+    Backend* m_be;
+    SparseRowsDev m_dev{};
+    void *m_ptr = nullptr, *m_idx = nullptr, *m_coef = nullptr;
+};
+
+class JacobianPattern {
+public:
+    //! n = number of unknowns; remap_in may have n or n+1 columns (column n is
+    //! the continuation parameter t of ANMImplicitSolver, anm.cpp:575-579)
+    JacobianPattern(Backend* be, const SparseDesc& remap_out, const SparseDesc& remap_in, int64_t n,
+                    int64_t T, int64_t Tpad, int odim);
+    ~JacobianPattern();
+
+    CsrDev csr() const { return m_csr; }
+    AssemblyDev assembly() const { return m_asm; }
+    bool has_t() const { return m_has_t; }
+    AssemblyDev assembly_grad_t() const { return m_asm_t; }
+    int64_t n() const { return m_csr.n; }
+    int64_t nnz() const { return m_csr.nnz; }
+    int64_t nr_contrib() const { return m_nr_contrib; }
+    const std::vector<uint32_t>& h_rowptr() const { return m_h_rowptr; }
+    const std::vector<uint32_t>& h_col() const { return m_h_col; }
+
+private:
+    Backend* m_be;
+    CsrDev m_csr{};
+    AssemblyDev m_asm{}, m_asm_t{};
+    bool m_has_t = false;
+    int64_t m_nr_contrib = 0;
+    std::vector<uint32_t> m_h_rowptr, m_h_col;
+    std::vector<void*> m_bufs;
+    template <class T>
+    T* upload(const std::vector<T>& v);
+};
+
+}  // namespace sanm_hip

@@ -1,0 +1,860 @@
+// Per-tet bodies of every graph operator, for all four passes.
+//
+// One lane handles one tet; every operator is tet-local, so a lane only ever
+// re-reads values it wrote itself and a whole pass needs no inter-lane
+// synchronisation.  The functions are __host__ __device__ so that the
+// GPU-less authoring container can run the very same bodies in a test-only
+// host harness (tests/hostsim); the product path is the HIP kernel in
+// backend_hip.hip.
+//
+// Math follows the reference operator by operator (file:line on each block);
+// the 3x3 kernels are closed forms instead of Eigen calls.
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#include "program.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SANM_HD __host__ __device__ __forceinline__
+#define SANM_HD_NOINLINE __host__ __device__ inline
+#else
+#define SANM_HD inline
+#define SANM_HD_NOINLINE inline
+#endif
+
+namespace sanm_hip {
+
+struct TetCtx {
+    double* arena;
+    const VarDesc* vars;
+    int64_t Tpad;
+    int64_t tet;
+    int32_t order;  // current order k (BIAS / COEFF passes)
+    int32_t odim;
+};
+
+// ---------------------------------------------------------------- access --
+SANM_HD double* p_coef(const TetCtx& c, int v, int k) {
+    const VarDesc& d = c.vars[v];
+    return c.arena + d.coef + (int64_t)k * d.size * c.Tpad + c.tet;
+}
+SANM_HD double* p_bias(const TetCtx& c, int v) { return c.arena + c.vars[v].bias + c.tet; }
+SANM_HD double* p_jac(const TetCtx& c, int v) { return c.arena + c.vars[v].jac + c.tet; }
+SANM_HD double* p_aux(const TetCtx& c, int64_t off) { return c.arena + off + c.tet; }
+// value pointer of the "current" term: bias buffer (BIAS pass) or coef[k]
+SANM_HD double* p_cur(const TetCtx& c, int v, bool in_coeff) {
+    return in_coeff ? p_coef(c, v, c.order) : p_bias(c, v);
+}
+
+SANM_HD void ld(const double* p, int64_t s, int n, double* m) {
+    for (int i = 0; i < n; ++i) m[i] = p[i * s];
+}
+SANM_HD void st(double* p, int64_t s, int n, const double* m) {
+    for (int i = 0; i < n; ++i) p[i * s] = m[i];
+}
+SANM_HD void ld9(const double* p, int64_t s, double* m) { ld(p, s, 9, m); }
+SANM_HD void st9(double* p, int64_t s, const double* m) { st(p, s, 9, m); }
+
+// ------------------------------------------------------------- 3x3 math --
+// c (+)= op(a) * op(b), row-major 3x3  (reference: as_batched_mm,
+// libsanm/tensor_linalg.cpp:107-210, static 3x3 path :194)
+template <bool TA, bool TB, bool ACC>
+SANM_HD void mm3(double* c, const double* a, const double* b) {
+    double r[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = ACC ? c[i * 3 + j] : 0.0;
+            for (int k = 0; k < 3; ++k) {
+                double av = TA ? a[k * 3 + i] : a[i * 3 + k];
+                double bv = TB ? b[j * 3 + k] : b[k * 3 + j];
+                s += av * bv;
+            }
+            r[i * 3 + j] = s;
+        }
+    for (int i = 0; i < 9; ++i) c[i] = r[i];
+}
+
+SANM_HD double det3(const double* a) {  // tensor_linalg.cpp:319-353
+    return a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) +
+           a[2] * (a[3] * a[7] - a[4] * a[6]);
+}
+
+// cofactor matrix by minors.  The reference goes through an SVD with a rank
+// test (tensor_linalg.cpp:18-59); for 3x3 the minors are the same matrix up
+// to round-off, including rank 2, and are exactly what rank <= 1 collapses to.
+SANM_HD void cof3(const double* a, double* c) {
+    c[0] = a[4] * a[8] - a[5] * a[7];
+    c[1] = a[5] * a[6] - a[3] * a[8];
+    c[2] = a[3] * a[7] - a[4] * a[6];
+    c[3] = a[2] * a[7] - a[1] * a[8];
+    c[4] = a[0] * a[8] - a[2] * a[6];
+    c[5] = a[1] * a[6] - a[0] * a[7];
+    c[6] = a[1] * a[5] - a[2] * a[4];
+    c[7] = a[2] * a[3] - a[0] * a[5];
+    c[8] = a[0] * a[4] - a[1] * a[3];
+}
+
+SANM_HD void inv3(const double* a, double* r) {  // tensor_linalg.cpp:285-317
+    double c[9];
+    cof3(a, c);
+    double d = a[0] * c[0] + a[1] * c[1] + a[2] * c[2];
+    double id = 1.0 / d;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) r[i * 3 + j] = c[j * 3 + i] * id;
+}
+
+SANM_HD double clip_div(double x, double y) {  // tensor_svd.cpp:28-31
+    return x * y / (y * y + 1e-12);
+}
+
+// One-sided Jacobi SVD of a 3x3: a = U diag(s) V', s sorted descending,
+// s >= 0.  (Reference: Eigen JacobiSVD, tensor_svd.cpp:66-87.)
+SANM_HD_NOINLINE void svd3(const double* a, double* U, double* S, double* V) {
+    double B[9];  // working copy, columns get orthogonalised: B = A V
+    for (int i = 0; i < 9; ++i) B[i] = a[i];
+    for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int i = 0; i < 3; ++i) {
+                    alpha += B[i * 3 + p] * B[i * 3 + p];
+                    beta += B[i * 3 + q] * B[i * 3 + q];
+                    gamma += B[i * 3 + p] * B[i * 3 + q];
+                }
+                double lim = 1e-32 + 1e-30 * alpha * beta;
+                if (gamma * gamma <= lim) continue;
+                double rel = fabs(gamma) / sqrt(alpha * beta);
+                if (rel > off) off = rel;
+                double zeta = (beta - alpha) / (2.0 * gamma);
+                double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                for (int i = 0; i < 3; ++i) {
+                    double bp = B[i * 3 + p], bq = B[i * 3 + q];
+                    B[i * 3 + p] = cs * bp - sn * bq;
+                    B[i * 3 + q] = sn * bp + cs * bq;
+                    double vp = V[i * 3 + p], vq = V[i * 3 + q];
+                    V[i * 3 + p] = cs * vp - sn * vq;
+                    V[i * 3 + q] = sn * vp + cs * vq;
+                }
+            }
+        if (off < 1e-15) break;
+    }
+    double s[3];
+    for (int j = 0; j < 3; ++j)
+        s[j] = sqrt(B[j] * B[j] + B[3 + j] * B[3 + j] + B[6 + j] * B[6 + j]);
+    // sort descending (3 elements)
+    int idx[3] = {0, 1, 2};
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2 - i; ++j)
+            if (s[idx[j]] < s[idx[j + 1]]) {
+                int t = idx[j];
+                idx[j] = idx[j + 1];
+                idx[j + 1] = t;
+            }
+    double Vs[9];
+    for (int j = 0; j < 3; ++j) {
+        int k = idx[j];
+        S[j] = s[k];
+        for (int i = 0; i < 3; ++i) {
+            Vs[i * 3 + j] = V[i * 3 + k];
+            U[i * 3 + j] = (s[k] > 0) ? B[i * 3 + k] / s[k] : 0.0;
+        }
+    }
+    for (int i = 0; i < 9; ++i) V[i] = Vs[i];
+    // complete U for (numerically) zero singular values
+    double smax = S[0];
+    if (!(S[2] > 1e-300 + 1e-15 * smax)) {
+        if (!(S[1] > 1e-300 + 1e-15 * smax)) {
+            if (!(S[0] > 0)) {
+                U[0] = 1; U[3] = 0; U[6] = 0;
+            }
+            // pick u1 orthogonal to u0
+            double u0[3] = {U[0], U[3], U[6]};
+            int m = (fabs(u0[0]) <= fabs(u0[1]) && fabs(u0[0]) <= fabs(u0[2])) ? 0
+                    : (fabs(u0[1]) <= fabs(u0[2]) ? 1 : 2);
+            double e[3] = {0, 0, 0};
+            e[m] = 1;
+            double d = u0[m];
+            double w[3] = {e[0] - d * u0[0], e[1] - d * u0[1], e[2] - d * u0[2]};
+            double nw = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+            U[1] = w[0] / nw; U[4] = w[1] / nw; U[7] = w[2] / nw;
+        }
+        // u2 = u0 x u1
+        U[2] = U[3] * U[7] - U[6] * U[4];
+        U[5] = U[6] * U[1] - U[0] * U[7];
+        U[8] = U[0] * U[4] - U[3] * U[1];
+    }
+}
+
+// Which singular values get negated so that det(W)=+1: literal restatement of
+// the selection loop at libsanm/tensor_svd.cpp:88-128 for n = 3 (note the
+// reference's `i = j` inside a `for(...; ++i)`).  Returns a 3-bit mask.
+SANM_HD int svdw_rotation_fix_mask(const double* ms) {
+    const int n = 3;
+    const double EPS = 1e-3;
+    int best_idx = -1, best_idx_nr = n + 1;
+    for (int i = 0; i < n; ++i) {
+        int j = i + 1;
+        while (j < n && fabs(ms[i] - ms[j]) < EPS) ++j;
+        int nr = j - i;
+        if (nr <= best_idx_nr || (nr == best_idx_nr + 1 && nr % 2 == 1)) {
+            best_idx = i;
+            best_idx_nr = nr;
+            if (nr == 1) break;
+        }
+        i = j;
+    }
+    int mask = 0;
+    if (best_idx_nr == 1 || best_idx_nr % 2 == 0) {
+        mask = 1 << best_idx;
+    } else {
+        for (int i = best_idx; i < best_idx + best_idx_nr; ++i) mask |= 1 << i;
+    }
+    return mask;
+}
+
+// M = U S U' W (tensor_svd.cpp:48-145)
+SANM_HD_NOINLINE void svdw3(const double* m, bool require_rotation, double* U, double* S,
+                            double* W) {
+    double V[9];
+    svd3(m, U, S, V);
+    if (require_rotation) {
+        double du = det3(U), dv = det3(V);
+        if ((du < 0) != (dv < 0)) {
+            int mask = svdw_rotation_fix_mask(S);
+            for (int j = 0; j < 3; ++j)
+                if (mask & (1 << j)) {
+                    S[j] = -S[j];
+                    U[j] = -U[j]; U[3 + j] = -U[3 + j]; U[6 + j] = -U[6 + j];
+                }
+        }
+    }
+    mm3<false, true, false>(W, U, V);  // W = U V'
+}
+
+// order-k terms of the polar decomposition (tensor_svd.cpp:389-475), written
+// on the logical (row-major) matrices -- see SURVEY.md appendix A.3.
+SANM_HD_NOINLINE void svdw_fwd_p3(const double* Mk, const double* U0, const double* S0,
+                                  const double* W0, const double* Bm, const double* Bp,
+                                  const double* Bpw, double* Pk, double* Wk) {
+    double V0[9], D[9], E[9], Q[9], T1[9], X[9];
+    mm3<true, false, false>(V0, W0, U0);  // V0 = W0' U0
+    for (int i = 0; i < 9; ++i) D[i] = Bm[i] - Bp[i];
+    mm3<true, true, false>(T1, U0, D);    // U0' (Bm-Bp)'
+    mm3<false, false, false>(E, T1, U0);  // ... U0
+    mm3<true, true, false>(T1, V0, Mk);   // V0' Mk'
+    mm3<false, false, false>(Q, T1, U0);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Q[i * 3 + j] *= S0[i];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double e = E[i * 3 + j] + Q[i * 3 + j] + Q[j * 3 + i];
+            X[i * 3 + j] = clip_div(e, S0[i] + S0[j]);
+        }
+    mm3<false, false, false>(T1, U0, X);
+    mm3<false, true, false>(D, T1, U0);  // Pk' = U0 X U0'
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Pk[i * 3 + j] = D[j * 3 + i];
+    // Wk = U0 diag(1/s) U0' (Mk - Bpw - Pk W0)
+    mm3<false, false, false>(T1, Pk, W0);
+    for (int i = 0; i < 9; ++i) T1[i] = Mk[i] - Bpw[i] - T1[i];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) D[i * 3 + j] = U0[i * 3 + j] * clip_div(1.0, S0[j]);
+    mm3<false, true, false>(X, D, U0);
+    mm3<false, false, false>(Wk, X, T1);
+}
+
+// ----------------------------------------------------- operator bodies --
+// broadcast helper: value c of a var of size sz (scalar -> all elements)
+SANM_HD double bval(const double* p, int64_t s, int sz, int c) { return sz == 1 ? p[0] : p[c * s]; }
+
+// jac accumulate:  in.jac[r][ci] += v
+SANM_HD void jadd(const TetCtx& c, int v, int r, int ci, double val) {
+    double* p = p_jac(c, v) + ((int64_t)r * c.vars[v].size + ci) * c.Tpad;
+    *p += val;
+}
+SANM_HD double jget(const TetCtx& c, int v, int r, int ci) {
+    return p_jac(c, v)[((int64_t)r * c.vars[v].size + ci) * c.Tpad];
+}
+
+// ---- LINCOMB: elem_arith.cpp:42-124
+SANM_HD void op_lincomb(const TetCtx& c, const OpDesc& o, int mode) {
+    const int64_t s = c.Tpad;
+    const int ov = o.out[0], osz = c.vars[ov].size;
+    if (mode == PASS_GRAD) {
+        for (int k = 0; k < o.nin; ++k) {
+            int iv = o.in[k], isz = c.vars[iv].size;
+            if (c.vars[iv].is_const) continue;
+            double ck = o.p[k];
+            for (int r = 0; r < c.odim; ++r) {
+                if (isz == osz) {
+                    for (int e = 0; e < osz; ++e) jadd(c, iv, r, e, ck * jget(c, ov, r, e));
+                } else {
+                    double sum = 0;
+                    for (int e = 0; e < osz; ++e) sum += jget(c, ov, r, e);
+                    jadd(c, iv, r, 0, ck * sum);
+                }
+            }
+        }
+        return;
+    }
+    double acc[9];
+    const bool ev0 = mode == PASS_EVAL0, in_coeff = mode == PASS_COEFF;
+    for (int e = 0; e < osz; ++e) acc[e] = ev0 ? o.p[MAX_OP_IN] : 0.0;
+    for (int k = 0; k < o.nin; ++k) {
+        int iv = o.in[k], isz = c.vars[iv].size;
+        if (!ev0 && c.vars[iv].is_const) continue;
+        const double* p = ev0 ? p_coef(c, iv, 0) : p_cur(c, iv, in_coeff);
+        for (int e = 0; e < osz; ++e) acc[e] += o.p[k] * bval(p, s, isz, e);
+    }
+    st(ev0 ? p_coef(c, ov, 0) : p_cur(c, ov, in_coeff), s, osz, acc);
+}
+
+// ---- MULTIPLY: elem_arith.cpp:128-217   aux0 = self_bias[osz]
+SANM_HD void op_multiply(const TetCtx& c, const OpDesc& o, int mode) {
+    const int64_t s = c.Tpad;
+    const int a = o.in[0], b = o.in[1], ov = o.out[0];
+    const int asz = c.vars[a].size, bsz = c.vars[b].size, osz = c.vars[ov].size;
+    if (mode == PASS_EVAL0) {
+        const double *pa = p_coef(c, a, 0), *pb = p_coef(c, b, 0);
+        double* po = p_coef(c, ov, 0);
+        for (int e = 0; e < osz; ++e) po[e * s] = bval(pa, s, asz, e) * bval(pb, s, bsz, e);
+        return;
+    }
+    if (mode == PASS_GRAD) {
+        for (int k = 0; k < 2; ++k) {
+            int iv = k ? b : a, other = k ? a : b;
+            if (c.vars[iv].is_const) continue;
+            int isz = c.vars[iv].size, otsz = c.vars[other].size;
+            const double* po = p_coef(c, other, 0);
+            for (int r = 0; r < c.odim; ++r) {
+                if (isz == osz) {
+                    for (int e = 0; e < osz; ++e)
+                        jadd(c, iv, r, e, jget(c, ov, r, e) * bval(po, s, otsz, e));
+                } else {
+                    double sum = 0;
+                    for (int e = 0; e < osz; ++e) sum += jget(c, ov, r, e) * bval(po, s, otsz, e);
+                    jadd(c, iv, r, 0, sum);
+                }
+            }
+        }
+        return;
+    }
+    const bool in_coeff = mode == PASS_COEFF;
+    double sb[9];
+    double* psb = p_aux(c, o.aux[0]);
+    if (!in_coeff) {
+        for (int e = 0; e < osz; ++e) sb[e] = 0;
+        if (!c.vars[a].is_const && !c.vars[b].is_const) {
+            for (int i = 1; i < c.order; ++i) {
+                const double *pa = p_coef(c, a, i), *pb = p_coef(c, b, c.order - i);
+                for (int e = 0; e < osz; ++e) sb[e] += bval(pa, s, asz, e) * bval(pb, s, bsz, e);
+            }
+        }
+        st(psb, s, osz, sb);
+    } else {
+        ld(psb, s, osz, sb);
+    }
+    const double *a0 = p_coef(c, a, 0), *b0 = p_coef(c, b, 0);
+    if (!c.vars[b].is_const) {
+        const double* bk = p_cur(c, b, in_coeff);
+        for (int e = 0; e < osz; ++e) sb[e] += bval(a0, s, asz, e) * bval(bk, s, bsz, e);
+    }
+    if (!c.vars[a].is_const) {
+        const double* ak = p_cur(c, a, in_coeff);
+        for (int e = 0; e < osz; ++e) sb[e] += bval(ak, s, asz, e) * bval(b0, s, bsz, e);
+    }
+    st(p_cur(c, ov, in_coeff), s, osz, sb);
+}
+
+// ---- LOG / POW: oprs/analytic_unary.cpp:113-158, analytic_unary.cpp:13-139
+//      aux0 = k = f'(x0) [sz], aux1 = self_bias [sz]
+SANM_HD void op_unary(const TetCtx& c, const OpDesc& o, int mode) {
+    const int64_t s = c.Tpad;
+    const int x = o.in[0], ov = o.out[0], sz = c.vars[ov].size;
+    const bool is_log = o.type == OP_LOG;
+    const double pw = o.p[0];
+    double* pk = p_aux(c, o.aux[0]);
+    double* psb = p_aux(c, o.aux[1]);
+    if (mode == PASS_EVAL0) {
+        const double* px = p_coef(c, x, 0);
+        double* po = p_coef(c, ov, 0);
+        for (int e = 0; e < sz; ++e) {
+            double v = px[e * s];
+            if (is_log) {
+                po[e * s] = log(v);
+                pk[e * s] = 1.0 / v;
+            } else if (pw == 2.0) {
+                po[e * s] = v * v;
+                pk[e * s] = 2.0 * v;
+            } else {
+                po[e * s] = pow(v, pw);
+                pk[e * s] = pw * pow(v, pw - 1.0);
+            }
+        }
+        return;
+    }
+    if (mode == PASS_GRAD) {
+        if (c.vars[x].is_const) return;
+        for (int r = 0; r < c.odim; ++r)
+            for (int e = 0; e < sz; ++e) jadd(c, x, r, e, jget(c, ov, r, e) * pk[e * s]);
+        return;
+    }
+    const bool in_coeff = mode == PASS_COEFF;
+    const int k = c.order;
+    double sb[9];
+    if (!in_coeff) {
+        for (int e = 0; e < sz; ++e) sb[e] = 0;
+        if (!c.vars[x].is_const) {
+            const bool int2 = (!is_log && pw == 2.0);
+            for (int i = 1; i < k; ++i) {
+                // log: x[k-i]*f[i]*(-i/k); pow: f[k-i]*x[i]*((i/k)(p+1)-1); pow 2: x[i]*x[k-i]
+                const double* p1 = int2 ? p_coef(c, x, i) : (is_log ? p_coef(c, x, k - i) : p_coef(c, ov, k - i));
+                const double* p2 = int2 ? p_coef(c, x, k - i) : (is_log ? p_coef(c, ov, i) : p_coef(c, x, i));
+                double w = int2 ? 1.0 : (is_log ? -(double)i / (double)k
+                                                : (double)i / (double)k * (pw + 1.0) - 1.0);
+                for (int e = 0; e < sz; ++e) sb[e] += p1[e * s] * p2[e * s] * w;
+            }
+            if (!int2) {
+                const double* x0 = p_coef(c, x, 0);
+                for (int e = 0; e < sz; ++e) sb[e] /= x0[e * s];
+            }
+        }
+        st(psb, s, sz, sb);
+    } else {
+        ld(psb, s, sz, sb);
+    }
+    if (!c.vars[x].is_const) {
+        const double* xk = p_cur(c, x, in_coeff);
+        for (int e = 0; e < sz; ++e) sb[e] += pk[e * s] * xk[e * s];
+    }
+    st(p_cur(c, ov, in_coeff), s, sz, sb);
+}
+
+// ---- REDUCE_SUM axis=-1: oprs/reduce.cpp:11-102
+SANM_HD void op_reduce(const TetCtx& c, const OpDesc& o, int mode) {
+    const int64_t s = c.Tpad;
+    const int x = o.in[0], ov = o.out[0], isz = c.vars[x].size;
+    if (mode == PASS_GRAD) {
+        if (c.vars[x].is_const) return;
+        for (int r = 0; r < c.odim; ++r) {
+            double g = jget(c, ov, r, 0);
+            for (int e = 0; e < isz; ++e) jadd(c, x, r, e, g);
+        }
+        return;
+    }
+    const bool ev0 = mode == PASS_EVAL0, in_coeff = mode == PASS_COEFF;
+    const double* p = ev0 ? p_coef(c, x, 0) : p_cur(c, x, in_coeff);
+    double sum = 0;
+    if (ev0 || !c.vars[x].is_const)
+        for (int e = 0; e < isz; ++e) sum += p[e * s];
+    *(ev0 ? p_coef(c, ov, 0) : p_cur(c, ov, in_coeff)) = sum;
+}
+
+// ---- MATMUL: oprs/linalg.cpp:339-418   aux0 = self_bias[9]
+SANM_HD void op_matmul(const TetCtx& c, const OpDesc& o, int mode) {
+    const int64_t s = c.Tpad;
+    const int a = o.in[0], b = o.in[1], ov = o.out[0];
+    double A[9], B[9], R[9];
+    if (mode == PASS_EVAL0) {
+        ld9(p_coef(c, a, 0), s, A);
+        ld9(p_coef(c, b, 0), s, B);
+        mm3<false, false, false>(R, A, B);
+        st9(p_coef(c, ov, 0), s, R);
+        return;
+    }
+    if (mode == PASS_GRAD) {
+        ld9(p_coef(c, a, 0), s, A);
+        ld9(p_coef(c, b, 0), s, B);
+        for (int r = 0; r < c.odim; ++r) {
+            double G[9];
+            for (int e = 0; e < 9; ++e) G[e] = jget(c, ov, r, e);
+            if (!c.vars[a].is_const) {  // ga[m,k] = sum_n g[m,n] b[k,n]
+                mm3<false, true, false>(R, G, B);
+                for (int e = 0; e < 9; ++e) jadd(c, a, r, e, R[e]);
+            }
+            if (!c.vars[b].is_const) {  // gb[k,n] = sum_m g[m,n] a[m,k]
+                mm3<true, false, false>(R, A, G);
+                for (int e = 0; e < 9; ++e) jadd(c, b, r, e, R[e]);
+            }
+        }
+        return;
+    }
+    const bool in_coeff = mode == PASS_COEFF;
+    double* psb = p_aux(c, o.aux[0]);
+    if (!in_coeff) {
+        for (int e = 0; e < 9; ++e) R[e] = 0;
+        if (!c.vars[a].is_const && !c.vars[b].is_const) {
+            for (int i = 1; i < c.order; ++i) {
+                ld9(p_coef(c, a, i), s, A);
+                ld9(p_coef(c, b, c.order - i), s, B);
+                mm3<false, false, true>(R, A, B);
+            }
+        }
+        st9(psb, s, R);
+    } else {
+        ld9(psb, s, R);
+    }
+    if (!c.vars[a].is_const) {
+        ld9(p_cur(c, a, in_coeff), s, A);
+        ld9(p_coef(c, b, 0), s, B);
+        mm3<false, false, true>(R, A, B);
+    }
+    if (!c.vars[b].is_const) {
+        ld9(p_coef(c, a, 0), s, A);
+        ld9(p_cur(c, b, in_coeff), s, B);
+        mm3<false, false, true>(R, A, B);
+    }
+    st9(p_cur(c, ov, in_coeff), s, R);
+}
+
+// ---- MATINVMUL: oprs/linalg.cpp:67-217   aux0 = xinv[9], aux1 = self_bias[9]
+SANM_HD void op_matinvmul(const TetCtx& c, const OpDesc& o, int mode) {
+    const int64_t s = c.Tpad;
+    const bool is_left = o.flags & OP_FLAG_IS_LEFT, ident = o.flags & OP_FLAG_USE_IDENTITY;
+    const int x = o.in[0], av = ident ? -1 : o.in[1], ov = o.out[0];
+    double X[9], Y[9], R[9], Tm[9];
+    double* pxinv = p_aux(c, o.aux[0]);
+    double* psb = p_aux(c, o.aux[1]);
+    if (mode == PASS_EVAL0) {
+        ld9(p_coef(c, x, 0), s, X);
+        inv3(X, Y);
+        st9(pxinv, s, Y);
+        if (!ident) {
+            ld9(p_coef(c, av, 0), s, X);
+            if (is_left) mm3<false, false, false>(R, X, Y);
+            else mm3<false, false, false>(R, Y, X);
+            st9(p_coef(c, ov, 0), s, R);
+        } else {
+            st9(p_coef(c, ov, 0), s, Y);
+        }
+        return;
+    }
+    if (mode == PASS_GRAD) {
+        double XI[9], Y0[9];
+        ld9(pxinv, s, XI);
+        ld9(p_coef(c, ov, 0), s, Y0);
+        for (int e = 0; e < 9; ++e) Y0[e] = -Y0[e];
+        const double *m0 = is_left ? Y0 : XI, *m1 = is_left ? XI : Y0;
+        for (int r = 0; r < c.odim; ++r) {
+            double G[9];
+            for (int e = 0; e < 9; ++e) G[e] = jget(c, ov, r, e);
+            if (!c.vars[x].is_const) {
+                // gx[i,j] = sum_pq g[p,q] m0[p,i] m1[j,q] = (m0' G m1')[i,j]
+                mm3<true, false, false>(Tm, m0, G);
+                mm3<false, true, false>(R, Tm, m1);
+                for (int e = 0; e < 9; ++e) jadd(c, x, r, e, R[e]);
+            }
+            if (!ident && !c.vars[av].is_const) {
+                if (is_left) mm3<false, true, false>(R, G, XI);  // ga[i,j] = sum_q g[i,q] xinv[j,q]
+                else mm3<true, false, false>(R, XI, G);           // ga[i,j] = sum_p g[p,j] xinv[p,i]
+                for (int e = 0; e < 9; ++e) jadd(c, av, r, e, R[e]);
+            }
+        }
+        return;
+    }
+    const bool in_coeff = mode == PASS_COEFF;
+    if (!in_coeff) {
+        for (int e = 0; e < 9; ++e) R[e] = 0;
+        if (!c.vars[x].is_const) {
+            for (int i = 1; i < c.order; ++i) {
+                if (is_left) {
+                    ld9(p_coef(c, ov, i), s, Y);
+                    ld9(p_coef(c, x, c.order - i), s, X);
+                    mm3<false, false, true>(R, Y, X);
+                } else {
+                    ld9(p_coef(c, x, i), s, X);
+                    ld9(p_coef(c, ov, c.order - i), s, Y);
+                    mm3<false, false, true>(R, X, Y);
+                }
+            }
+        }
+        for (int e = 0; e < 9; ++e) R[e] = -R[e];
+        st9(psb, s, R);
+    } else {
+        ld9(psb, s, R);
+    }
+    if (!ident && !c.vars[av].is_const) {
+        ld9(p_cur(c, av, in_coeff), s, X);
+        for (int e = 0; e < 9; ++e) R[e] += X[e];
+    }
+    if (!c.vars[x].is_const) {
+        ld9(p_coef(c, ov, 0), s, Y);
+        ld9(p_cur(c, x, in_coeff), s, X);
+        if (is_left) mm3<false, false, false>(Tm, Y, X);
+        else mm3<false, false, false>(Tm, X, Y);
+        for (int e = 0; e < 9; ++e) R[e] -= Tm[e];
+    }
+    ld9(pxinv, s, X);
+    if (is_left) mm3<false, false, false>(Tm, R, X);
+    else mm3<false, false, false>(Tm, X, R);
+    st9(p_cur(c, ov, in_coeff), s, Tm);
+}
+
+// ---- DET: oprs/linalg.cpp:221-282, tensor_polymat.cpp:344-379
+//      aux0 = cof(x0)[9], aux1 = self_bias[1],
+//      aux2 = c series [(N+1)][3]: c_m = sum_{j+l=m} r1_j x r2_l (rows 1,2 of x),
+//      aux3 = partial c_k [3] (terms with j,l <= k-1).
+// The order-k coefficient of det(sum_{i<k} x_i a^i) equals
+//   sum_{i=1}^{k-1} r0_i . c_{k-i}  +  r0_0 . c_k^partial
+// which is the Leibniz expansion of the reference regrouped so that each
+// order costs O(k) instead of O(k^2).
+SANM_HD void cross3(const double* a, const double* b, double* r) {
+    r[0] = a[1] * b[2] - a[2] * b[1];
+    r[1] = a[2] * b[0] - a[0] * b[2];
+    r[2] = a[0] * b[1] - a[1] * b[0];
+}
+SANM_HD void op_det(const TetCtx& c, const OpDesc& o, int mode) {
+    const int64_t s = c.Tpad;
+    const int x = o.in[0], ov = o.out[0];
+    double* pcof = p_aux(c, o.aux[0]);
+    double* psb = p_aux(c, o.aux[1]);
+    double* pcs = p_aux(c, o.aux[2]);
+    double* pck = p_aux(c, o.aux[3]);
+    double X[9], C[9];
+    if (mode == PASS_EVAL0) {
+        ld9(p_coef(c, x, 0), s, X);
+        cof3(X, C);
+        st9(pcof, s, C);
+        *p_coef(c, ov, 0) = X[0] * C[0] + X[1] * C[1] + X[2] * C[2];
+        st(pcs, s, 3, C);  // c_0 = r1_0 x r2_0 = first cofactor row
+        return;
+    }
+    if (mode == PASS_GRAD) {
+        if (c.vars[x].is_const) return;
+        ld9(pcof, s, C);
+        for (int r = 0; r < c.odim; ++r) {
+            double g = jget(c, ov, r, 0);
+            for (int e = 0; e < 9; ++e) jadd(c, x, r, e, g * C[e]);
+        }
+        return;
+    }
+    const bool in_coeff = mode == PASS_COEFF;
+    const int k = c.order;
+    double sb = 0;
+    if (c.vars[x].is_const) {
+        *p_cur(c, ov, in_coeff) = 0;
+        return;
+    }
+    if (!in_coeff) {
+        double ck[3] = {0, 0, 0}, t[3];
+        for (int j = 1; j < k; ++j) {
+            double r1[3], r2[3];
+            ld(p_coef(c, x, j) + 3 * s, s, 3, r1);
+            ld(p_coef(c, x, k - j) + 6 * s, s, 3, r2);
+            cross3(r1, r2, t);
+            ck[0] += t[0]; ck[1] += t[1]; ck[2] += t[2];
+        }
+        st(pck, s, 3, ck);
+        double r0[3];
+        ld(p_coef(c, x, 0), s, 3, r0);
+        sb = r0[0] * ck[0] + r0[1] * ck[1] + r0[2] * ck[2];
+        for (int i = 1; i < k; ++i) {
+            double cm[3];
+            ld(p_coef(c, x, i), s, 3, r0);
+            ld(pcs + (int64_t)(k - i) * 3 * s, s, 3, cm);
+            sb += r0[0] * cm[0] + r0[1] * cm[1] + r0[2] * cm[2];
+        }
+        *psb = sb;
+    } else {
+        sb = *psb;
+        // finish c_k now that x_k is known
+        double ck[3], r1[3], r2[3], t[3];
+        ld(pck, s, 3, ck);
+        ld(p_coef(c, x, 0) + 3 * s, s, 3, r1);
+        ld(p_coef(c, x, k) + 6 * s, s, 3, r2);
+        cross3(r1, r2, t);
+        ck[0] += t[0]; ck[1] += t[1]; ck[2] += t[2];
+        ld(p_coef(c, x, k) + 3 * s, s, 3, r1);
+        ld(p_coef(c, x, 0) + 6 * s, s, 3, r2);
+        cross3(r1, r2, t);
+        ck[0] += t[0]; ck[1] += t[1]; ck[2] += t[2];
+        st(pcs + (int64_t)k * 3 * s, s, 3, ck);
+    }
+    ld9(pcof, s, C);
+    ld9(p_cur(c, x, in_coeff), s, X);
+    double d = sb;
+    for (int e = 0; e < 9; ++e) d += C[e] * X[e];
+    *p_cur(c, ov, in_coeff) = d;
+}
+
+// ---- TRANSPOSE: oprs/linalg.cpp:286-335
+SANM_HD void op_transpose(const TetCtx& c, const OpDesc& o, int mode) {
+    const int64_t s = c.Tpad;
+    const int x = o.in[0], ov = o.out[0];
+    if (mode == PASS_GRAD) {
+        if (c.vars[x].is_const) return;
+        for (int r = 0; r < c.odim; ++r)
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) jadd(c, x, r, i * 3 + j, jget(c, ov, r, j * 3 + i));
+        return;
+    }
+    const bool ev0 = mode == PASS_EVAL0, in_coeff = mode == PASS_COEFF;
+    const double* p = ev0 ? p_coef(c, x, 0) : p_cur(c, x, in_coeff);
+    double* q = ev0 ? p_coef(c, ov, 0) : p_cur(c, ov, in_coeff);
+    double X[9];
+    ld9(p, s, X);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) q[(i * 3 + j) * s] = X[j * 3 + i];
+}
+
+// ---- MULEYE: oprs/linalg.cpp:422-479
+SANM_HD void op_muleye(const TetCtx& c, const OpDesc& o, int mode) {
+    const int64_t s = c.Tpad;
+    const int x = o.in[0], ov = o.out[0];
+    if (mode == PASS_GRAD) {
+        if (c.vars[x].is_const) return;
+        for (int r = 0; r < c.odim; ++r)
+            jadd(c, x, r, 0, jget(c, ov, r, 0) + jget(c, ov, r, 4) + jget(c, ov, r, 8));
+        return;
+    }
+    const bool ev0 = mode == PASS_EVAL0, in_coeff = mode == PASS_COEFF;
+    double v = *(ev0 ? p_coef(c, x, 0) : p_cur(c, x, in_coeff));
+    double* q = ev0 ? p_coef(c, ov, 0) : p_cur(c, ov, in_coeff);
+    for (int e = 0; e < 9; ++e) q[e * s] = (e % 4 == 0) ? v : 0.0;
+}
+
+// ---- SVDW (pw_mode): oprs/linalg.cpp:483-615, tensor_svd.cpp
+//      out = {U, S, W}; aux0 = P series [(N+1)][9] (P_0 unused),
+//      aux1 = Bm[9], aux2 = Bp[9], aux3 = Bpw[9]
+SANM_HD void op_svdw(const TetCtx& c, const OpDesc& o, int mode) {
+    const int64_t s = c.Tpad;
+    const int x = o.in[0], uv = o.out[0], sv = o.out[1], wv = o.out[2];
+    double M[9], U[9], S[3], W[9];
+    if (mode == PASS_EVAL0) {
+        ld9(p_coef(c, x, 0), s, M);
+        svdw3(M, o.flags & OP_FLAG_REQUIRE_ROT, U, S, W);
+        st9(p_coef(c, uv, 0), s, U);
+        st(p_coef(c, sv, 0), s, 3, S);
+        st9(p_coef(c, wv, 0), s, W);
+        return;
+    }
+    ld9(p_coef(c, uv, 0), s, U);
+    ld(p_coef(c, sv, 0), s, 3, S);
+    ld9(p_coef(c, wv, 0), s, W);
+    if (mode == PASS_GRAD) {
+        // dW/dM chained with the upstream Jacobian (tensor_svd.cpp:147-273):
+        //   gM_r += U Z V',  Z_ij = (G_ij - G_ji) d_ij,  G = U' gW_r V,
+        //   d_ij = clip_div(1, s_i + s_j), V = W' U.
+        if (c.vars[x].is_const) return;
+        double V[9], G[9], Tm[9], Z[9];
+        mm3<true, false, false>(V, W, U);
+        for (int r = 0; r < c.odim; ++r) {
+            for (int e = 0; e < 9; ++e) G[e] = jget(c, wv, r, e);
+            mm3<true, false, false>(Tm, U, G);
+            mm3<false, false, false>(G, Tm, V);
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j)
+                    Z[i * 3 + j] = (i == j) ? 0.0 : clip_div(G[i * 3 + j] - G[j * 3 + i], S[i] + S[j]);
+            mm3<false, false, false>(Tm, U, Z);
+            mm3<false, true, false>(G, Tm, V);
+            for (int e = 0; e < 9; ++e) jadd(c, x, r, e, G[e]);
+        }
+        return;
+    }
+    const bool in_coeff = mode == PASS_COEFF;
+    const int k = c.order;
+    double* pP = p_aux(c, o.aux[0]);
+    double Bm[9], Bp[9], Bpw[9], A[9], B[9];
+    if (!in_coeff) {
+        for (int e = 0; e < 9; ++e) Bm[e] = Bp[e] = Bpw[e] = 0;
+        for (int i = 1; i < k; ++i) {
+            ld9(p_coef(c, x, i), s, A);
+            ld9(p_coef(c, x, k - i), s, B);
+            mm3<false, true, true>(Bm, A, B);  // M_i M_{k-i}'
+            ld9(pP + (int64_t)i * 9 * s, s, A);
+            ld9(pP + (int64_t)(k - i) * 9 * s, s, B);
+            mm3<true, false, true>(Bp, A, B);  // P_i' P_{k-i}
+            ld9(p_coef(c, wv, k - i), s, B);
+            mm3<false, false, true>(Bpw, A, B);  // P_i W_{k-i}
+        }
+        st9(p_aux(c, o.aux[1]), s, Bm);
+        st9(p_aux(c, o.aux[2]), s, Bp);
+        st9(p_aux(c, o.aux[3]), s, Bpw);
+    } else {
+        ld9(p_aux(c, o.aux[1]), s, Bm);
+        ld9(p_aux(c, o.aux[2]), s, Bp);
+        ld9(p_aux(c, o.aux[3]), s, Bpw);
+    }
+    ld9(p_cur(c, x, in_coeff), s, M);
+    double Pk[9], Wk[9];
+    svdw_fwd_p3(M, U, S, W, Bm, Bp, Bpw, Pk, Wk);
+    st9(p_cur(c, wv, in_coeff), s, Wk);
+    if (in_coeff) st9(pP + (int64_t)k * 9 * s, s, Pk);
+}
+
+// ---- PLACEHOLDER: oprs/misc.cpp:13-44 fused with remap_in
+//      (SparseLinearDesc::apply, anm.cpp:55-75): coef[k] = gather of x_k.
+SANM_HD void op_placeholder(const TetCtx& c, const OpDesc& o, int mode, const RemapInDev& rin,
+                            const double* xvec) {
+    const int64_t s = c.Tpad;
+    const int ov = o.out[0];
+    if (mode == PASS_GRAD) return;
+    if (mode == PASS_BIAS) {
+        double* q = p_bias(c, ov);
+        for (int e = 0; e < 9; ++e) q[e * s] = 0.0;
+        return;
+    }
+    double* q = p_coef(c, ov, mode == PASS_EVAL0 ? 0 : c.order);
+    for (int e = 0; e < 9; ++e) {
+        double acc = 0;
+        for (int sl = 0; sl < rin.nslot; ++sl) {
+            int64_t off = ((int64_t)sl * 9 + e) * s + c.tet;
+            acc += rin.coef[off] * xvec[rin.idx[off]];
+        }
+        q[e * s] = acc;
+    }
+}
+
+// ---- CONSTANT: oprs/misc.cpp:48-100 (value uploaded at compile time)
+SANM_HD void op_constant(const TetCtx& c, const OpDesc& o, int mode) {
+    if (mode != PASS_BIAS) return;
+    const int ov = o.out[0], sz = c.vars[ov].size;
+    double* q = p_bias(c, ov);
+    for (int e = 0; e < sz; ++e) q[e * c.Tpad] = 0.0;
+}
+
+SANM_HD void exec_op(const TetCtx& c, const OpDesc& o, int mode, const RemapInDev& rin,
+                     const double* xvec) {
+    // operators fed by constants only are evaluated once (order 0); their
+    // higher-order terms are identically zero and never stored
+    if (mode != PASS_EVAL0 && c.vars[o.out[0]].is_const) return;
+    switch (o.type) {
+        case OP_PLACEHOLDER: op_placeholder(c, o, mode, rin, xvec); break;
+        case OP_CONSTANT: op_constant(c, o, mode); break;
+        case OP_LINCOMB: op_lincomb(c, o, mode); break;
+        case OP_MULTIPLY: op_multiply(c, o, mode); break;
+        case OP_LOG:
+        case OP_POW: op_unary(c, o, mode); break;
+        case OP_REDUCE_SUM: op_reduce(c, o, mode); break;
+        case OP_MATMUL: op_matmul(c, o, mode); break;
+        case OP_MATINVMUL: op_matinvmul(c, o, mode); break;
+        case OP_DET: op_det(c, o, mode); break;
+        case OP_TRANSPOSE: op_transpose(c, o, mode); break;
+        case OP_MULEYE: op_muleye(c, o, mode); break;
+        case OP_SVDW: op_svdw(c, o, mode); break;
+        default: break;
+    }
+}
+
+// One whole pass for one tet.  `xvec` is the (n[+1]) coefficient vector the
+// placeholder gathers from (EVAL0 / COEFF passes).
+SANM_HD void exec_program_tet(const ProgramDev& P, int mode, int order, int64_t tet,
+                              const double* xvec) {
+    TetCtx c{P.arena, P.vars, P.Tpad, tet, order, P.odim};
+    if (mode == PASS_GRAD) {
+        // seed: d(out)/d(out) = I  (symbolic.cpp:219-220)
+        double* j = p_jac(c, P.out_var);
+        for (int r = 0; r < P.odim; ++r)
+            for (int e = 0; e < P.odim; ++e) j[((int64_t)r * P.odim + e) * P.Tpad] = (r == e) ? 1.0 : 0.0;
+        for (int i = P.nops - 1; i >= 0; --i) exec_op(c, P.ops[i], mode, P.rin, xvec);
+    } else {
+        for (int i = 0; i < P.nops; ++i) exec_op(c, P.ops[i], mode, P.rin, xvec);
+    }
+}
+
+}  // namespace sanm_hip

@@ -1,0 +1,158 @@
+"""Solver-level parity of the device path against the oracle and the golden
+fixtures: identical continuation-step counts, final vertex positions within
+1e-6 relative (north_star tolerance), Jacobian CSR, Pade decisions.
+
+Runs on the HIP library with -m gpu and on the test-only host harness otherwise.
+The linear solver tolerance is tightened to 1e-15 here: the discrete Pade /
+range decisions are compared step by step and need solves as accurate as the
+oracle's LU (see DESIGN.md "Linear solve").
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fea as ofea
+from oracle import symbolic as S
+from oracle.anm import build_jacobian_csr
+from sanm_amd import api as A
+from sanm_amd import fea as dfea
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+VTX_RTOL = 1e-6  # BASELINE.json north_star: relative vertex-position tolerance
+
+
+def _run_device(api, dims, spacing, cfg, **over):
+    mesh = dfea.make_cuboid(*dims, spacing)
+    run = dfea.GravityRun(api, mesh, dict(cfg), solver_rtol=1e-15, **over)
+    run.run()
+    return run
+
+
+@pytest.mark.parametrize("name", ["cuboid_nc", "cuboid_ni", "cuboid_arap", "cuboid_nc_nopade_o8"])
+def test_gravity_cuboid_vs_golden_and_oracle(api, name):
+    gold = json.load(open(os.path.join(GOLD, f"anm_{name}.json")))
+    run = _run_device(api, gold["dims"], gold["spacing"], gold["config"], profile=1)
+    assert run.solver.get_nr_iter() == gold["iter"], "continuation-step count differs"
+    V = run.vertices()
+    Vg = np.array(gold["vertices"])
+    assert np.abs(V - Vg).max() <= VTX_RTOL * np.abs(Vg).max()
+    assert len(run.rms) == len(gold["residual_rms"])
+    assert np.allclose(run.rms[:-2], gold["residual_rms"][:-2], rtol=1e-5)
+    assert run.rms[-1] < 1e-10
+    assert run.model.n == gold["nr_unknown"]
+
+
+def test_first_step_coefficients_and_jacobian(api):
+    """per-order t_k, |x_k| of the first ANM step and the assembled Jacobian
+    against the live oracle (same inputs, no restart error yet)."""
+    cfg = {"material": {"young": 3e3, "poisson": 0.45, "density": 900.0}, "g": [0, -9.81, 0],
+           "boundary_thresh": 0.05, "boundary_proj_dir": [-1, 0, 0], "energy_model": "neohookean_i",
+           "order": 12}
+    dims, sp = (5, 3, 3), 0.03
+    omesh = ofea.make_cuboid(*dims, sp)
+    omodel, osolver, of = ofea.make_gravity_solver(omesh, cfg)
+    run = dfea.GravityRun(api, dfea.make_cuboid(*dims, sp), dict(cfg), solver_rtol=1e-15, profile=1).construct()
+    tr = run.solver.trace()
+    assert np.allclose(tr["t"], osolver.trace[0]["t"], rtol=1e-8)
+    assert np.allclose(tr["x_norm"], osolver.trace[0]["x_norm"], rtol=1e-8)
+    assert np.allclose(tr["b_norm"], osolver.trace[0]["b_norm"], rtol=1e-7, atol=1e-12)
+    assert run.solver.get_t_max_a() == pytest.approx(osolver.t_max_a, rel=1e-7)
+    assert run.solver.has_pade() == (osolver.pade is not None)
+    xc = run.solver.xt_coeffs()
+    for i in (1, 2, 6, 12):
+        assert np.allclose(xc[i], osolver.xt_coeffs[i], rtol=1e-7, atol=1e-9 * np.abs(osolver.xt_coeffs[i]).max())
+    # Jacobian CSR (build_sparse_coeff, anm.cpp:362-438) incl. the 1e-9 drop rule
+    prop = S.TaylorCoeffProp(omodel.y)
+    prop.push_xi([(omodel.lt_inp.mat @ omodel.lt_inp.x0).reshape(-1, 3, 3)])
+    Ao, _ = build_jacobian_csr(omodel.lt_out, prop.get_jacobian(), omodel.lt_inp.mat, omodel.lt_inp.n)
+    Ad = run.solver.jacobian_csr()
+    assert abs(Ad - Ao).max() <= 1e-10 * abs(Ao).max()
+    st = run.solver.stats()
+    assert st["nr_unknown"] == omodel.lt_inp.n and st["nr_tet"] == omesh.nr_tet
+
+
+def test_vecscale_solver_path_following(api):
+    """ANMSolverVecScale: f(x) + t*v = 0 followed with update_approx (the
+    save_interm branch of run_and_save, fea/main.cpp:386-414)."""
+    cfg = {"material": {"young": 5e3, "poisson": 0.4, "density": 1000.0}, "g": [0, -9.81, 0],
+           "boundary_thresh": 0.05, "boundary_proj_dir": [-1, 0, 0], "energy_model": "neohookean_c", "order": 10}
+    dims, sp = (5, 3, 3), 0.03
+    omesh = ofea.make_cuboid(*dims, sp)
+    mat, fixed, fl = ofea.setup_gravity_task(omesh, cfg)
+    om = ofea.make_forward(omesh, mat, fixed, "neohookean_c")
+    from oracle.anm import ANMSolverVecScale, HyperParam
+    ohp = HyperParam(order=10, use_pade=True, solution_check_tol=0.01)
+    osol = ANMSolverVecScale(om.y, om.lt_inp.mat, om.lt_out, om.lt_inp.out_shape, om.lt_inp.x0, 0.0,
+                             om.lt_inp.copy_vtx_values(fl), ohp)
+    dmesh = dfea.make_cuboid(*dims, sp)
+    dfixed, dfl = dfea.setup_gravity(api, dmesh, cfg)
+    dm = api.fea_model(dmesh.V, dmesh.tets, dfixed, "neohookean_c", 5e3, 0.4)
+    hp = api.default_hyper(order=10, use_pade=1, solution_check_tol=0.01, solver_rtol=1e-15)
+    dsol = A.ANMSolverVecScale(api, dm.y, dm.lt_inp, dm.lt_out, dm.x0(), 0.0, dm.copy_vtx_values(dfl), hp)
+    for _ in range(3):
+        assert dsol.get_t_upper() == pytest.approx(osol.get_t_upper(), rel=1e-6)
+        t = 0.5 * (osol.t_coeffs[0] + min(osol.get_t_upper(), dsol.get_t_upper()))
+        ao, ad = osol.solve_a(t), dsol.solve_a(t)
+        assert ad == pytest.approx(ao, rel=1e-6, abs=1e-9)
+        xo, to = osol.eval(ao)
+        xd, td = dsol.eval(ad)
+        assert td == pytest.approx(to, rel=1e-8)
+        assert np.abs(xd - xo).max() <= VTX_RTOL * np.abs(xo).max()
+        osol.update_approx()
+        dsol.update_approx()
+    assert dsol.get_nr_iter() == osol.get_nr_iter() == 4
+
+
+def test_cuboid_twist_baseline_config1(api):
+    """BASELINE config 1: ANMImplicitSolver (displacement driven, t column ->
+    grad_t) followed by the order-6 ANMEqnSolver refinement."""
+    gold = json.load(open(os.path.join(GOLD, "anm_cuboid_twist.json")))
+    cfg = dict(gold["config"])
+    V, stats = dfea.test_cuboid_twist(api, cfg)
+    assert [s["iter_deform"] for s in stats] == [s["iter_deform"] for s in gold["stats"]]
+    assert [s["iter_refine"] for s in stats] == [s["iter_refine"] for s in gold["stats"]]
+    assert np.allclose(stats[0]["t_upper"], gold["stats"][0]["t_upper"], rtol=1e-6)
+    Vg = np.array(gold["vertices"])
+    assert np.abs(V - Vg).max() <= VTX_RTOL * np.abs(Vg).max()
+    assert stats[-1]["force_rms_recomp"] < 1e-10
+
+
+def test_inverse_single_tet(api):
+    gold = json.load(open(os.path.join(GOLD, "anm_single_tet_inverse.json")))
+    cfg = gold["config"]
+    sp, ang = cfg["spacing"], np.pi * 2 / 3
+    V = np.zeros((4, 3))
+    V[:3, 0] = np.cos(ang * np.arange(3)) * sp
+    V[:3, 1] = np.sin(ang * np.arange(3)) * sp
+    V[3, 2] = sp
+    fixed = np.zeros((4, 3), bool)
+    fixed[:3] = True
+    for load, want in ((-1000.0, np.array(gold["vertices"])[3, 2]), (1000.0, 0.022755286528750494)):
+        f = np.zeros((4, 3))
+        f[3, 2] = load
+        m = api.fea_model(V, np.array([[0, 1, 2, 3]]), fixed, cfg["energy_model"], cfg["material"]["young"],
+                          cfg["material"]["poisson"], inverse=True)
+        hp = dfea.hyper_from_config(api, cfg, solver_rtol=1e-15)
+        s = A.ANMEqnSolver(api, m.y, m.lt_inp, m.lt_out, m.x0(), m.copy_vtx_values(f), hp)
+        while not s.converged():
+            s.next_iter()
+        z = m.full_vertices(s.get_x(), V)[3, 2]
+        assert z == pytest.approx(want, rel=2e-8)
+
+
+def test_error_paths(api):
+    mesh = dfea.make_cuboid(3, 3, 3, 0.05)
+    fixed = np.zeros((mesh.nr_vertices, 3), bool)
+    fixed[mesh.V[:, 0] < 0.01] = True
+    m = api.fea_model(mesh.V, mesh.tets, fixed, "neohookean_c", 1e4, 0.4)
+    v = np.ones(m.n)
+    # f(x0) + t0*v != 0 -> SANMNumericalError (anm.cpp:343-360)
+    with pytest.raises(A.SanmNumericalError):
+        A.ANMSolverVecScale(api, m.y, m.lt_inp, m.lt_out, m.x0(), 1.0, v, api.default_hyper(order=4))
+    # order < 2 -> assertion (anm.cpp:108-110)
+    with pytest.raises(A.SanmAssertionError):
+        A.ANMEqnSolver(api, m.y, m.lt_inp, m.lt_out, m.x0(), v, api.default_hyper(order=1))
+    with pytest.raises(A.SanmUnsupportedError):
+        A.ANMEqnSolver(api, m.y, m.lt_inp, m.lt_out, m.x0(), v, api.default_hyper(order=4, xcoeff_l2_penalty=0.1))

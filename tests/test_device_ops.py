@@ -1,0 +1,205 @@
+"""Operator-level parity: every OperatorMeta of the device program against the
+oracle's op-by-op restatement, through the C ABI (TaylorCoeffProp entry points).
+
+Runs on the HIP library with -m gpu and on the test-only host harness otherwise.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import fea as ofea
+from oracle import symbolic as S
+from sanm_amd import api as A
+
+RTOL = 1e-11
+
+
+def _identity_remap(api, T):
+    return api.sparse_desc(sp.identity(T * 9, format="csr"))
+
+
+def _series(rng, T, N, near_identity=True, scale=0.3):
+    x0 = rng.standard_normal((T, 3, 3)) * 0.2
+    if near_identity:
+        x0 += np.eye(3)[None]
+    return [x0] + [rng.standard_normal((T, 3, 3)) * scale for _ in range(N)]
+
+
+def _run_both(api, build, T=37, N=6, seed=0, near_identity=True, rtol=RTOL):
+    """build(ops, X, const) -> output var, for ops in {oracle S, device A}."""
+    rng = np.random.default_rng(seed)
+    cvals = [np.eye(3)[None] + 0.1 * rng.standard_normal((T, 3, 3)), rng.uniform(0.5, 2.0, (T, 1))]
+    xs = _series(rng, T, N, near_identity)
+    # oracle
+    ocg = S.ComputingGraph()
+    oy = build(S, S.placeholder(ocg), [S.constant(ocg, c) for c in cvals])
+    oprop = S.TaylorCoeffProp(oy)
+    # device
+    dcg = api.graph()
+    dy = build(A, dcg.placeholder(), [dcg.constant(c) for c in cvals])
+    dprop = A.TaylorCoeffProp(api, dy, _identity_remap(api, T), N, T)
+
+    def close(a, b, what):
+        scale = max(np.abs(b).max(), 1e-300)
+        err = np.abs(a - b).max() / scale
+        assert err <= rtol, f"{what}: rel err {err:.3e}"
+
+    close(dprop.push_xi(xs[0]), oprop.push_xi([xs[0]]), "order 0")
+    for k in range(1, N + 1):
+        ob = oprop.compute_next_order_bias()
+        db = dprop.compute_next_order_bias()
+        if k == 1:
+            close(dprop.get_jacobian(), oprop.get_jacobian(), "jacobian")
+            assert not np.any(db)
+        else:
+            close(db, ob, f"bias {k}")
+        close(dprop.push_xi(xs[k]), oprop.push_xi([xs[k]]), f"coeff {k}")
+
+
+def test_matmul_const(api):
+    _run_both(api, lambda M, X, c: X.batched_matmul(c[0]))
+
+
+def test_matmul_var_var(api):
+    _run_both(api, lambda M, X, c: X.batched_matmul(X.batched_transpose()).batched_matmul(X))
+
+
+def test_transpose_lincomb_bias(api):
+    _run_both(api, lambda M, X, c: M.linear_combine([(2.0, X), (-0.5, X.batched_transpose()), (1.5, c[0])], 0.25))
+
+
+def test_matinv_identity_left(api):
+    _run_both(api, lambda M, X, c: M.batched_mat_inv_mul(X, None, True))
+
+
+def test_matinvmul_left_right(api):
+    _run_both(api, lambda M, X, c: M.batched_mat_inv_mul(X, X.batched_matmul(c[0]), True)
+              + M.batched_mat_inv_mul(X, c[0], False))
+
+
+def test_det_muleye(api):
+    _run_both(api, lambda M, X, c: X.batched_det().batched_mul_eye(3), N=8)
+
+
+def test_det_log_multiply_broadcast(api):
+    _run_both(api, lambda M, X, c: X.batched_det().log() * X)
+
+
+def test_pow_fractional_and_square(api):
+    _run_both(api, lambda M, X, c: (X.batched_det().pow(-2.0 / 3.0) * X.pow(2).reduce_sum(-1)) * X)
+
+
+def test_scalar_constant_broadcast(api):
+    _run_both(api, lambda M, X, c: (c[1] * X.batched_det()) * X + X * c[1])
+
+
+def test_svdw_polar(api):
+    # polar decomposition rotation, incl. inverted inputs (det < 0 -> rotation fix)
+    _run_both(api, lambda M, X, c: X - X.batched_svd_w(True)[2], N=6, rtol=1e-9)
+    _run_both(api, lambda M, X, c: X.batched_svd_w(True)[2], N=3, near_identity=False, seed=3, rtol=1e-8)
+
+
+@pytest.mark.parametrize("energy", ["neohookean_c", "neohookean_i", "arap", "stvk_stretch"])
+def test_pk1_graphs(api, energy):
+    mat = ofea.Material(1e3, 0.45)
+
+    def build(M, X, c):
+        F = X.batched_matmul(c[0])
+        if M is S:
+            return ofea.pk1(energy, mat, F)
+        # the same graph built with the device operator API
+        mu, lam, k = mat.shear, mat.lame_first, mat.bulk
+        if energy == "neohookean_c":
+            FTinv = M.batched_mat_inv_mul(F, None, True).batched_transpose()
+            J = F.batched_det()
+            return M.linear_combine([(mu, F), (-mu, FTinv), (lam, J.log() * FTinv)])
+        if energy == "neohookean_i":
+            FTinv = M.batched_mat_inv_mul(F, None, True).batched_transpose()
+            J = F.batched_det()
+            Ic = F.pow(2).reduce_sum(-1)
+            J23 = J.pow(-2.0 / 3.0)
+            t2 = M.linear_combine([(mu / -3.0, J23 * Ic), (k, J * J), (-k, J)], 0) * FTinv
+            return M.linear_combine([(mu, J23 * F), (1.0, t2)])
+        if energy == "arap":
+            return (F - F.batched_svd_w(True)[2]) * mu
+        return M.linear_combine([(mu, F.batched_matmul(F.batched_transpose()).batched_matmul(F)), (-mu, F)])
+
+    _run_both(api, build, N=10, rtol=1e-9)
+
+
+@pytest.mark.parametrize("energy", ["neohookean_c", "neohookean_i"])
+def test_cauchy_graphs_via_fea_model(api, energy):
+    """inverse model (make_inverse + cauchy_stress) built by the C++ front-end."""
+    rng = np.random.default_rng(4)
+    mesh = ofea.make_cuboid(3, 3, 2, 0.05)
+    fixed = np.zeros((mesh.nr_vertices, 3), bool)
+    fixed[mesh.V[:, 0] < 0.01] = True
+    mat = ofea.Material(1e4, 0.4)
+    om = ofea.make_inverse(mesh, mat, fixed, energy)
+    dm = api.fea_model(mesh.V, mesh.tets, fixed, energy, 1e4, 0.4, inverse=True)
+    N, T, n = 5, mesh.nr_tet, om.lt_inp.n
+    assert dm.n == n
+    xs = [om.lt_inp.x0 + 0.002 * rng.standard_normal(n)] + [0.01 * rng.standard_normal(n) for _ in range(N)]
+    oprop = S.TaylorCoeffProp(om.y)
+    dprop = A.TaylorCoeffProp(api, dm.y, dm.lt_inp, N, T)
+    app = lambda x: (om.lt_inp.mat @ x).reshape(T, 3, 3)
+    assert np.allclose(dprop.push_xi(xs[0]), oprop.push_xi([app(xs[0])]), rtol=1e-10, atol=1e-6)
+    for k in range(1, N + 1):
+        ob, db = oprop.compute_next_order_bias(), dprop.compute_next_order_bias()
+        assert np.allclose(db, ob, rtol=1e-8, atol=1e-8 * np.abs(ob).max() + 1e-300)
+        oy, dy = oprop.push_xi([app(xs[k])]), dprop.push_xi(xs[k])
+        assert np.allclose(dy, oy, rtol=1e-8, atol=1e-8 * np.abs(oy).max())
+
+
+def test_remap_tables_match_oracle(api):
+    """MeshShapeMatTrans / MeshForceOutputTrans built in C++ vs the oracle's."""
+    mesh = ofea.make_cuboid(4, 3, 3, 0.03)
+    rng = np.random.default_rng(9)
+    fixed = np.zeros((mesh.nr_vertices, 3), bool)
+    fixed[mesh.V[:, 0] < 0.01] = True
+    fixed[5, 1] = True  # a partially fixed vertex
+    delta = rng.standard_normal(mesh.V.shape) * fixed
+    for vd in (None, delta):
+        om = ofea.make_forward(mesh, ofea.Material(1e4, 0.4), fixed, "neohookean_c", None, vd)
+        dm = api.fea_model(mesh.V, mesh.tets, fixed, "neohookean_c", 1e4, 0.4, vtx_delta=vd)
+        assert abs(dm.lt_inp.to_scipy() - om.lt_inp.mat).max() < 1e-15
+        assert abs(dm.lt_out.to_scipy() - om.lt_out).max() < 1e-18
+        assert np.array_equal(dm.x0(), om.lt_inp.x0)
+    fl = api.gravity_load(mesh.V, mesh.tets, 1234.0, [0.1, -9.81, 0.3])
+    assert np.allclose(fl, ofea.gravity_load(mesh, ofea.Material(1, 0.3, 1234.0), [0.1, -9.81, 0.3]), rtol=1e-13)
+    cfg = {"boundary_thresh": 0.3, "boundary_proj_dir": [1, 1, 0],
+           "boundary_filter": {"dir": [0, 0, 1], "min": 0.0, "max": 0.6}}
+    got = api.boundary_by_threshold(mesh.V, mesh.surface_vtx, [1, 1, 0], 0.3, [0, 0, 1], 0.0, 0.6)
+    assert np.array_equal(got, ofea.boundary_by_config(mesh, None, cfg))
+
+
+def test_unsupported_and_invalid_graphs(api):
+    g = api.graph()
+    X = g.placeholder()
+    with pytest.raises(A.SanmAssertionError):
+        X.batched_det().batched_matmul(X)  # scalar into matmul
+    with pytest.raises(A.SanmAssertionError):
+        X.pow(0.0)
+    u, s, w = X.batched_svd_w(False)
+    with pytest.raises(A.SanmUnsupportedError):  # reading U is not on the device path
+        A.TaylorCoeffProp(api, u.batched_matmul(w), _identity_remap(api, 4), 3, 4)
+
+
+def test_host_poly_helpers(api):
+    rng = np.random.default_rng(5)
+    cf0 = rng.uniform(-1, 1, 8)
+    cf0[7] = 2.3
+    coeffs = np.convolve(cf0, [-12, 1, 1])  # tests/pade.cpp:16-62
+    roots = api.poly_real_roots(coeffs)
+    assert roots is not None and len(roots) >= 2
+    assert min(abs(roots - 3)) < 1e-9 and min(abs(roots + 4)) < 1e-9
+    from oracle import unary_polynomial as up
+    want = sorted(up.real_roots(coeffs))
+    assert len(want) == len(roots) and np.allclose(sorted(roots), want, atol=1e-8)
+    f = rng.uniform(-1, 1, 7)
+    f[0] = -abs(f[0])
+    hi = 1.0
+    while up.eval_poly(f, hi) <= 0:
+        hi *= 2
+        f[-1] = abs(f[-1]) + 0.1
+    assert api.poly_solve_eqn(f, 0.0, hi) == up.solve_eqn(f, 0.0, hi)
