@@ -73,6 +73,24 @@ int sanm_graph_batched_svd_w(sanm_graph* g, int x, int require_rotation, int usw
 int sanm_sparse_desc_create(int64_t out_size, int64_t in_size, const uint64_t* rowptr,
                             const uint64_t* idx, const double* coeff, sanm_sparse_desc** d);
 void sanm_sparse_desc_destroy(sanm_sparse_desc* d);
+/* optional ordering hint: spatial position (out_size,3) of every output element
+ * of a remap_out; NULL clears it.  The fea model builder sets it by itself. */
+int sanm_sparse_desc_set_out_coords(sanm_sparse_desc* d, const double* coords);
+
+/* ---- sparse direct solver: SparseSolver, libsanm/sparse_solver.h:17-87 ---- */
+/* ctor + make_builder: the pattern (CSR, uint32) is analysed once;
+ * coords (n,3) is an optional nested-dissection hint */
+typedef struct sanm_direct_solver sanm_direct_solver;
+int sanm_direct_solver_create(int64_t n, const uint32_t* rowptr, const uint32_t* col,
+                              const double* coords, sanm_direct_solver** s);
+void sanm_direct_solver_destroy(sanm_direct_solver* s);
+/* prepare (sparse_solver.cpp:327-421): numeric LU of the values (nnz doubles) */
+int sanm_direct_solver_factor(sanm_direct_solver* s, const double* val, int* nr_bad_pivot);
+/* solve (sparse_solver.cpp:154-180) */
+int sanm_direct_solver_solve(sanm_direct_solver* s, const double* b, double* x);
+int sanm_direct_solver_stats(const sanm_direct_solver* s, int64_t* nnz_factors, double* flops,
+                             int32_t* nr_front, int32_t* nr_level, int32_t* max_front,
+                             int32_t* root_pivots, int32_t* nr_supervar);
 
 /* ---- TaylorCoeffProp on the device: libsanm/symbolic.h:337-383 ---------- */
 /* remap_inp maps the flat input vector to the (T,3,3) placeholder
@@ -102,7 +120,7 @@ typedef struct sanm_hyper_param { /* ANMDriverHelper::HyperParam, anm.h:100-114,
     double converge_rms;
     double solver_rtol; /* device linear solver: relative residual target */
     int solver_maxit;
-    int solver_kind;    /* 0 = Jacobi-PCG */
+    int solver_kind;    /* 0 = Jacobi-PCG, 1 = multifrontal LU (default) */
     int profile;        /* sync + time each phase (ScopedProfiler tags, utils.h:225-249) */
 } sanm_hyper_param;
 void sanm_hyper_param_default(sanm_hyper_param* hp, int eqn_solver);
@@ -154,6 +172,9 @@ typedef struct sanm_anm_stats {
     int64_t nr_linear_solve, linear_iters_total, linear_iters_last;
     double linear_relres_last;
     double arena_bytes;
+    /* direct solver analysis (0 with the iterative solver) */
+    int64_t factor_nnz, nr_front, nr_level, max_front;
+    double factor_flops;
 } sanm_anm_stats;
 int sanm_anm_get_stats(const sanm_anm_solver* s, sanm_anm_stats* st);
 /* profile tags: returns the number of tags; names/seconds may be NULL */

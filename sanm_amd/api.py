@@ -56,7 +56,9 @@ class StatsC(C.Structure):
     _fields_ = [("nr_unknown", C.c_int64), ("nr_tet", C.c_int64), ("jacobian_nnz", C.c_int64),
                 ("assembly_contribs", C.c_int64), ("nr_linear_solve", C.c_int64),
                 ("linear_iters_total", C.c_int64), ("linear_iters_last", C.c_int64),
-                ("linear_relres_last", C.c_double), ("arena_bytes", C.c_double)]
+                ("linear_relres_last", C.c_double), ("arena_bytes", C.c_double),
+                ("factor_nnz", C.c_int64), ("nr_front", C.c_int64), ("nr_level", C.c_int64),
+                ("max_front", C.c_int64), ("factor_flops", C.c_double)]
 
 
 ENERGY = {"neohookean_i": 0, "neohookean_c": 1, "arap": 2, "stvk_stretch": 3}
@@ -70,6 +72,8 @@ SYMBOLS = [
     "sanm_graph_batched_det", "sanm_graph_batched_transpose", "sanm_graph_batched_mul_eye",
     "sanm_graph_batched_svd_w",
     "sanm_sparse_desc_create", "sanm_sparse_desc_destroy", "sanm_sparse_desc_get",
+    "sanm_sparse_desc_set_out_coords", "sanm_direct_solver_create", "sanm_direct_solver_destroy",
+    "sanm_direct_solver_factor", "sanm_direct_solver_solve", "sanm_direct_solver_stats",
     "sanm_taylor_create", "sanm_taylor_destroy", "sanm_taylor_push_xi",
     "sanm_taylor_compute_next_order_bias", "sanm_taylor_get_jacobian", "sanm_taylor_get_var",
     "sanm_taylor_reset",
@@ -342,6 +346,53 @@ class SparseLinearDesc:
                                                          rp.ctypes.data_as(c_u64p),
                                                          ix.ctypes.data_as(c_u64p), _dp(cf)))
         return sp.csr_matrix((cf, ix.astype(np.int64), rp.astype(np.int64)), shape=(o.value, i.value))
+
+
+class DirectSolver:
+    """SparseSolver (libsanm/sparse_solver.h:17-87): analyse a pattern once,
+    factor / solve many times."""
+
+    def __init__(self, api, A, coords=None):
+        self.api = api
+        A = A.tocsr()
+        A.sort_indices()
+        self.n = A.shape[0]
+        self.rp = np.ascontiguousarray(A.indptr, dtype=np.uint32)
+        self.col = np.ascontiguousarray(A.indices, dtype=np.uint32)
+        cd = None if coords is None else _f64(coords)
+        h = C.c_void_p()
+        api.check(api.lib.sanm_direct_solver_create(C.c_int64(self.n), self.rp.ctypes.data_as(c_u32p),
+                                                    self.col.ctypes.data_as(c_u32p),
+                                                    None if cd is None else _dp(cd), C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.api.lib.sanm_direct_solver_destroy(self.h)
+            self.h = None
+
+    def factor(self, A):
+        A = A.tocsr()
+        A.sort_indices()
+        val = _f64(A.data)
+        assert val.size == self.col.size
+        bad = C.c_int()
+        self.api.check(self.api.lib.sanm_direct_solver_factor(self.h, _dp(val), C.byref(bad)))
+        return bad.value
+
+    def solve(self, b):
+        b = _f64(b)
+        x = np.zeros(self.n)
+        self.api.check(self.api.lib.sanm_direct_solver_solve(self.h, _dp(b), _dp(x)))
+        return x
+
+    def stats(self):
+        nnz, fl = C.c_int64(), C.c_double()
+        nf, nl, mf, rp, nsv = (C.c_int32() for _ in range(5))
+        self.api.check(self.api.lib.sanm_direct_solver_stats(self.h, C.byref(nnz), C.byref(fl), C.byref(nf),
+                                                             C.byref(nl), C.byref(mf), C.byref(rp), C.byref(nsv)))
+        return {"nnz_factors": nnz.value, "flops": fl.value, "nr_front": nf.value, "nr_level": nl.value,
+                "max_front": mf.value, "root_pivots": rp.value, "nr_supervar": nsv.value}
 
 
 class TaylorCoeffProp:

@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libsanm_hip.so")
-SOURCES = ["graph.cpp", "sparse.cpp", "backend_common.cpp", "poly.cpp", "anm.cpp", "fea.cpp",
+SOURCES = ["graph.cpp", "sparse.cpp", "backend_common.cpp", "poly.cpp", "anm.cpp", "multifrontal.cpp", "fea.cpp",
            "capi.cpp", "backend_hip.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-function",

@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <limits>
 
+#include "multifrontal.h"
 #include "poly.h"
 
 namespace sanm_hip {
@@ -77,6 +78,38 @@ public:
     }
 };
 }  // namespace
+
+namespace {
+class DirectSolver final : public LinearSolver {
+    Backend* m_be;
+    const JacobianPattern& m_pat;
+    Multifrontal m_mf;
+
+public:
+    DirectSolver(Backend* be, const JacobianPattern& pat, const double* coords)
+            : m_be{be}, m_pat{pat}, m_mf{be, pat.n(), pat.h_rowptr(), pat.h_col(), coords} {
+        nnz_factors = m_mf.nnz_factors;
+        nr_front = m_mf.nr_front;
+        nr_level = m_mf.nr_level;
+        max_front = m_mf.max_front;
+        factor_flops = m_mf.factor_flops;
+    }
+    void prepare() override {
+        int bad = m_be->mf_factor(m_mf.dev(), m_mf.schedule(), m_pat.csr());
+        if (bad)
+            sanm_throw(SANM_ERR_NUMERICAL, "multifrontal LU: %d zero pivot(s); the Jacobian is singular", bad);
+    }
+    void solve(const double* b, double* x) override {
+        m_be->mf_solve(m_mf.dev(), m_mf.schedule(), b, x);
+        ++nr_solve;
+    }
+};
+}  // namespace
+
+std::unique_ptr<LinearSolver> make_direct_solver(Backend* be, const JacobianPattern& pat,
+                                                 const HyperParam&, const double* coords) {
+    return std::make_unique<DirectSolver>(be, pat, coords);
+}
 
 std::unique_ptr<LinearSolver> make_pcg_solver(Backend* be, const JacobianPattern& pat,
                                               const HyperParam& hp) {
@@ -229,7 +262,14 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g, int out_var, const SparseDesc&
     m_remap_out = std::make_unique<DeviceRows>(be, remap_out, T, m_prog->Tpad());
     m_pattern = std::make_unique<JacobianPattern>(be, remap_out, remap_inp, m_n, T, m_prog->Tpad(),
                                                   m_prog->dev().odim);
-    m_solver = make_pcg_solver(be, *m_pattern, hp);
+    if (hp.solver_kind == 1) {
+        const double* coords = remap_out.out_coords.size() == (size_t)m_n * 3 ? remap_out.out_coords.data() : nullptr;
+        m_solver = make_direct_solver(be, *m_pattern, hp, coords);
+    } else if (hp.solver_kind == 0) {
+        m_solver = make_pcg_solver(be, *m_pattern, hp);
+    } else {
+        sanm_throw(SANM_ERR_ASSERT, "unknown solver_kind %d", hp.solver_kind);
+    }
     const size_t n1 = m_n + 1;
     m_xt0 = DVec{be, n1};
     m_fx0 = DVec{be, (size_t)m_n};

@@ -32,7 +32,7 @@ struct HyperParam {  // libsanm/anm.h:100-114, :247-251
     // direct LU: libsanm/sparse_solver.cpp:107-127)
     double solver_rtol = 1e-12;
     int solver_maxit = 100000;
-    int solver_kind = 0;  // 0: Jacobi-PCG, 1: multifrontal LDL' (direct)
+    int solver_kind = 1;  // 0: Jacobi-PCG, 1: multifrontal LU (direct)
     int profile = 0;      // synchronise + time every phase
 };
 
@@ -73,9 +73,15 @@ public:
     virtual void solve(const double* b, double* x) = 0;
     int64_t nr_solve = 0, tot_iters = 0, last_iters = 0;
     double last_relres = 0;
+    // direct solver analysis (0 for iterative solvers)
+    int64_t nnz_factors = 0, nr_front = 0, nr_level = 0, max_front = 0;
+    double factor_flops = 0;
 };
 std::unique_ptr<LinearSolver> make_pcg_solver(Backend* be, const JacobianPattern& pat,
                                               const HyperParam& hp);
+//! multifrontal LU (multifrontal.h); coords: (n,3) ordering hint or null
+std::unique_ptr<LinearSolver> make_direct_solver(Backend* be, const JacobianPattern& pat,
+                                                 const HyperParam& hp, const double* coords);
 
 //! libsanm/pade.h on device vectors
 class PadeApproximation {

@@ -9,6 +9,7 @@
 #include <cstddef>
 #include <cstdint>
 
+#include "mf_types.h"
 #include "program.h"
 
 namespace sanm_hip {
@@ -86,6 +87,13 @@ public:
      */
     virtual void pcg(const CsrDev& A, double sign, const double* dinv, const double* b, double* x,
                      double rtol, int maxit, int* iters, double* relres);
+
+    //! numeric multifrontal LU of A (values in A.val, pattern analysed in mf):
+    //! scatter + extend-add + blocked partial LU of every front, level by level.
+    //! Returns the number of (near-)zero pivots met.
+    virtual int mf_factor(const MfDev& mf, const MfSchedule& sch, const CsrDev& A) = 0;
+    //! x = A^-1 b with the factors of the last mf_factor (b, x: n doubles, may alias)
+    virtual void mf_solve(const MfDev& mf, const MfSchedule& sch, const double* b, double* x) = 0;
 
     //! average duration in ms of `reps` back-to-back launches of one kernel,
     //! measured with device events on the backend's stream (bench.py roofline).

@@ -21,6 +21,7 @@
 
 #include "backend.h"
 #include "graph.h"
+#include "mf_kernels.h"
 #include "row_ops.h"
 #include "tet_ops.h"
 
@@ -403,6 +404,68 @@ public:
         }
         *iters = it;
         *relres = bb > 0 ? std::sqrt(rr / bb) : 0.0;
+    }
+
+
+    // ---- multifrontal LU (mf_kernels.h) ---------------------------------------
+    int mf_factor(const MfDev& mf, const MfSchedule& sch, const CsrDev& A) override {
+        using namespace mfk;
+        HIP_CHECK(hipMemsetAsync(mf.front_store, 0, mf.front_store_size * sizeof(double), m_stream));
+        HIP_CHECK(hipMemsetAsync(mf.status, 0, sizeof(int32_t), m_stream));
+        hipLaunchKernelGGL(scatter_kernel, dim3(nblk(mf.nnzA, 256)), dim3(256), 0, m_stream, mf.nnzA,
+                           mf.a_dst, A.val, mf.front_store);
+        for (const auto& L : sch.levels) {
+            for (size_t r = 0; r < L.ea_rounds.size(); ++r) {
+                int cnt = L.ea_rounds[r].second - L.ea_rounds[r].first;
+                int64_t mb = L.ea_max_b[r];
+                if (cnt == 0 || mb == 0) continue;
+                hipLaunchKernelGGL(extend_add_kernel, dim3(nblk(mb * mb, 256), cnt), dim3(256), 0,
+                                   m_stream, mf, sch.ea_children + L.ea_rounds[r].first);
+            }
+            const int nt = (L.max_m + NB - 1) / NB;
+            for (int p = 0; p < L.nr_panel; ++p) {
+                const int cnt = L.panel_cnt[p];
+                hipLaunchKernelGGL(diag_kernel, dim3(cnt), dim3(256), 0, m_stream, mf, L.front_begin, p);
+                const int rem = nt - p - 1;
+                if (rem > 0) {
+                    hipLaunchKernelGGL(trsm_kernel, dim3(rem, 2, cnt), dim3(256), 0, m_stream, mf,
+                                       L.front_begin, p);
+                    hipLaunchKernelGGL(update_kernel, dim3(rem, rem, cnt), dim3(256), 0, m_stream, mf,
+                                       L.front_begin, p);
+                }
+            }
+        }
+        HIP_CHECK(hipGetLastError());
+        int32_t* hs = reinterpret_cast<int32_t*>(m_scalar_host);
+        HIP_CHECK(hipMemcpyAsync(hs, mf.status, sizeof(int32_t), hipMemcpyDeviceToHost, m_stream));
+        HIP_CHECK(hipStreamSynchronize(m_stream));
+        return *hs;
+    }
+
+    void mf_solve(const MfDev& mf, const MfSchedule& sch, const double* b, double* x) override {
+        using namespace mfk;
+        hipLaunchKernelGGL(permute_in_kernel, dim3(nblk(mf.n, 256)), dim3(256), 0, m_stream, mf.n,
+                           mf.perm, b, mf.work);
+        for (const auto& L : sch.levels) {
+            const int cnt = L.front_end - L.front_begin;
+            hipLaunchKernelGGL(fwd_own_kernel, dim3(cnt), dim3(256), (size_t)L.max_k * sizeof(double),
+                               m_stream, mf, L.front_begin);
+            if (L.max_b > 0)
+                hipLaunchKernelGGL(fwd_bnd_kernel, dim3((L.max_b + 3) / 4, cnt), dim3(256), 0, m_stream,
+                                   mf, L.front_begin);
+        }
+        for (int li = (int)sch.levels.size() - 1; li >= 0; --li) {
+            const auto& L = sch.levels[li];
+            const int cnt = L.front_end - L.front_begin;
+            if (L.max_b > 0)
+                hipLaunchKernelGGL(bwd_bnd_kernel, dim3((L.max_k + 3) / 4, cnt), dim3(256), 0, m_stream,
+                                   mf, L.front_begin);
+            hipLaunchKernelGGL(bwd_own_kernel, dim3(cnt), dim3(256), (size_t)L.max_k * sizeof(double),
+                               m_stream, mf, L.front_begin);
+        }
+        hipLaunchKernelGGL(permute_out_kernel, dim3(nblk(mf.n, 256)), dim3(256), 0, m_stream, mf.n,
+                           mf.perm, mf.work, x);
+        HIP_CHECK(hipGetLastError());
     }
 
     double time_kernel(int kernel, int reps, const ProgramDev* P, int mode, int order,

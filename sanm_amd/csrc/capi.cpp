@@ -8,6 +8,7 @@
 #include "anm.h"
 #include "fea.h"
 #include "graph.h"
+#include "multifrontal.h"
 #include "poly.h"
 #include "sparse.h"
 
@@ -166,6 +167,78 @@ int sanm_sparse_desc_get(const sanm_sparse_desc* d, int64_t* out_size, int64_t* 
         if (rowptr) std::memcpy(rowptr, d->d.rowptr.data(), d->d.rowptr.size() * 8);
         if (idx) std::memcpy(idx, d->d.idx.data(), d->d.idx.size() * 8);
         if (coeff) std::memcpy(coeff, d->d.coef.data(), d->d.coef.size() * 8);
+    });
+}
+
+int sanm_sparse_desc_set_out_coords(sanm_sparse_desc* d, const double* coords) {
+    return guard([&] {
+        if (coords) d->d.out_coords.assign(coords, coords + d->d.out_size * 3);
+        else d->d.out_coords.clear();
+    });
+}
+
+// ---- direct solver (SparseSolver, libsanm/sparse_solver.h:17-87) ----------
+struct sanm_direct_solver {
+    std::vector<uint32_t> rowptr, col;
+    std::unique_ptr<Multifrontal> mf;
+    CsrDev csr{};
+    DVec val, b, x;
+};
+int sanm_direct_solver_create(int64_t n, const uint32_t* rowptr, const uint32_t* col,
+                              const double* coords, sanm_direct_solver** out) {
+    return guard([&] {
+        Backend* be = backend();
+        auto s = std::make_unique<sanm_direct_solver>();
+        s->rowptr.assign(rowptr, rowptr + n + 1);
+        s->col.assign(col, col + rowptr[n]);
+        s->mf = std::make_unique<Multifrontal>(be, n, s->rowptr, s->col, coords);
+        void* drp = be->alloc((n + 1) * 4);
+        void* dcol = be->alloc(std::max<size_t>(s->col.size(), 1) * 4);
+        be->h2d(drp, s->rowptr.data(), (n + 1) * 4);
+        be->h2d(dcol, s->col.data(), s->col.size() * 4);
+        s->val = DVec{be, std::max<size_t>(s->col.size(), 1)};
+        s->b = DVec{be, (size_t)n};
+        s->x = DVec{be, (size_t)n};
+        s->csr = {static_cast<uint32_t*>(drp), static_cast<uint32_t*>(dcol), s->val.p(), n,
+                  (int64_t)s->col.size()};
+        *out = s.release();
+    });
+}
+void sanm_direct_solver_destroy(sanm_direct_solver* s) {
+    if (!s) return;
+    if (g_backend) {
+        g_backend->free(const_cast<uint32_t*>(s->csr.rowptr));
+        g_backend->free(const_cast<uint32_t*>(s->csr.col));
+    }
+    delete s;
+}
+int sanm_direct_solver_factor(sanm_direct_solver* s, const double* val, int* nr_bad_pivot) {
+    return guard([&] {
+        Backend* be = backend();
+        be->h2d(s->val.p(), val, s->col.size() * 8);
+        int bad = be->mf_factor(s->mf->dev(), s->mf->schedule(), s->csr);
+        if (nr_bad_pivot) *nr_bad_pivot = bad;
+    });
+}
+int sanm_direct_solver_solve(sanm_direct_solver* s, const double* b, double* x) {
+    return guard([&] {
+        Backend* be = backend();
+        be->h2d(s->b.p(), b, s->csr.n * 8);
+        be->mf_solve(s->mf->dev(), s->mf->schedule(), s->b.p(), s->x.p());
+        be->d2h(x, s->x.p(), s->csr.n * 8);
+    });
+}
+int sanm_direct_solver_stats(const sanm_direct_solver* s, int64_t* nnz_factors, double* flops,
+                             int32_t* nr_front, int32_t* nr_level, int32_t* max_front,
+                             int32_t* root_pivots, int32_t* nr_supervar) {
+    return guard([&] {
+        if (nnz_factors) *nnz_factors = s->mf->nnz_factors;
+        if (flops) *flops = s->mf->factor_flops;
+        if (nr_front) *nr_front = s->mf->nr_front;
+        if (nr_level) *nr_level = s->mf->nr_level;
+        if (max_front) *max_front = s->mf->max_front;
+        if (root_pivots) *root_pivots = s->mf->root_pivots;
+        if (nr_supervar) *nr_supervar = s->mf->nr_supervar;
     });
 }
 
@@ -387,6 +460,11 @@ int sanm_anm_get_stats(const sanm_anm_solver* s, sanm_anm_stats* st) {
         st->linear_iters_last = d.linear_solver().last_iters;
         st->linear_relres_last = d.linear_solver().last_relres;
         st->arena_bytes = d.program().arena_bytes();
+        st->factor_nnz = d.linear_solver().nnz_factors;
+        st->factor_flops = d.linear_solver().factor_flops;
+        st->nr_front = d.linear_solver().nr_front;
+        st->nr_level = d.linear_solver().nr_level;
+        st->max_front = d.linear_solver().max_front;
     });
 }
 int sanm_anm_profile(const sanm_anm_solver* s, int max_tags, const char** names, double* seconds) {
@@ -441,6 +519,12 @@ int sanm_fea_model_create(int64_t nv, const double* vertices, int64_t nr_tet, co
         p->graph_view.g = p->m.graph;
         p->inp.d = p->m.lt_inp;
         p->out.d = p->m.lt_out;
+        // ordering hint for the direct solver: position of the vertex of every unknown
+        p->out.d.out_coords.resize(p->m.n * 3);
+        const double* pos = init_vtx_coord ? init_vtx_coord : vertices;
+        for (int64_t i = 0; i < p->m.n; ++i)
+            for (int d = 0; d < 3; ++d)
+                p->out.d.out_coords[i * 3 + d] = pos[(int64_t)p->m.vertex_loc[i].first * 3 + d];
         *m = p.release();
     });
 }

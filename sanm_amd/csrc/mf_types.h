@@ -1,0 +1,63 @@
+// Device-visible structures of the multifrontal solver (see multifrontal.h).
+#pragma once
+#include <cstdint>
+#include <utility>
+#include <vector>
+
+namespace sanm_hip {
+
+constexpr int MF_NB = 32;  // panel / tile width
+
+struct MfFrontDev {
+    int64_t off;        // offset of the dense m*m front (row-major) in the front storage
+    int64_t dinv_off;   // offset of the inverted diagonal blocks: per panel [Linv | Uinv], NB*NB each
+    int32_t k, m;       // pivots, front size
+    int32_t own_start;  // first own variable (new numbering)
+    int32_t bnd_off;    // offset into bnd_idx (m-k entries, new numbering, ascending)
+    int32_t parent;     // -1 for roots
+    int32_t rel_off;    // offset into rel (m-k entries): position of each boundary row in the parent front
+    int32_t upd_off;    // offset of this front's update vector (m-k doubles) in the solve workspace
+    int32_t gat_off;    // offset into gat_ptr (m+1 entries): children's update entries feeding each row
+};
+
+// Everything the numeric kernels need, resident on the device.
+struct MfDev {
+    int64_t n, nnzA;
+    int32_t nr_front, nr_level;
+    const MfFrontDev* fronts;
+    const int32_t* level_fronts;  // front ids grouped by level, by decreasing k inside a level
+    const int32_t* bnd_idx;
+    const int32_t* rel;
+    const int32_t* gat_ptr;       // per front row: range of gat_src
+    const int32_t* gat_src;       // indices into the update-vector workspace
+    const int32_t* perm;          // original -> new numbering
+    // scatter of A: front_store[a_dst[p]] = A.val[p]
+    const int64_t* a_dst;
+    // extend-add: child lists per level and round
+    double* front_store;          // sum of m*m
+    double* dinv_store;
+    double* upd_store;            // solve workspace: concatenated update vectors
+    double* work;                 // n doubles (permuted rhs / solution)
+    int32_t* status;              // [0]: number of bad pivots
+    int64_t front_store_size, dinv_store_size, upd_store_size;
+};
+
+// Host-side schedule (what to launch, in which order).  Within a level the
+// fronts are sorted by decreasing pivot count, so the fronts that still have a
+// panel p form a prefix of the level's list.
+struct MfSchedule {
+    struct Level {
+        int32_t front_begin, front_end;  // into level_fronts
+        int32_t nr_panel;
+        int32_t max_m, max_k, max_b;
+        std::vector<int32_t> panel_cnt;  // number of fronts with k > p*NB
+        // extend-add rounds: round r holds the r-th child of every front of the
+        // level; [begin,end) into ea_children
+        std::vector<std::pair<int32_t, int32_t>> ea_rounds;
+        std::vector<int32_t> ea_max_b;   // max boundary size of the children of a round
+    };
+    std::vector<Level> levels;
+    const int32_t* ea_children = nullptr;  // device
+};
+
+}  // namespace sanm_hip

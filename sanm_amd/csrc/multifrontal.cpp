@@ -1,0 +1,587 @@
+#include "multifrontal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+namespace sanm_hip {
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// compressed (supervariable) graph
+// ---------------------------------------------------------------------------
+struct SvGraph {
+    int32_t nsv = 0;
+    std::vector<int32_t> sv_of;      // unknown -> supervariable
+    std::vector<int32_t> sv_ptr;     // members of each supervariable (original unknown ids)
+    std::vector<int32_t> sv_members;
+    std::vector<int32_t> adj_ptr, adj;  // symmetric adjacency without self loops
+    std::vector<double> xyz;         // nsv*3 centroid coordinates (empty if unknown)
+    int32_t size(int32_t s) const { return sv_ptr[s + 1] - sv_ptr[s]; }
+};
+
+SvGraph build_sv_graph(int64_t n, const std::vector<uint32_t>& rowptr,
+                       const std::vector<uint32_t>& col, const double* coords) {
+    // symmetrised adjacency including the diagonal
+    std::vector<int32_t> deg(n + 1, 0);
+    for (int64_t i = 0; i < n; ++i)
+        for (uint32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+            int64_t j = col[p];
+            sanm_check(j < n, "column index out of range");
+            if (j != i) {
+                deg[i + 1]++;
+                deg[j + 1]++;
+            }
+        }
+    for (int64_t i = 0; i < n; ++i) deg[i + 1] += deg[i] + 1;  // +1: self
+    std::vector<int32_t> nb(deg[n]);
+    {
+        std::vector<int32_t> fill(deg.begin(), deg.end() - 1);
+        for (int64_t i = 0; i < n; ++i) nb[fill[i]++] = i;
+        for (int64_t i = 0; i < n; ++i)
+            for (uint32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+                int64_t j = col[p];
+                if (j != i) {
+                    nb[fill[i]++] = j;
+                    nb[fill[j]++] = i;
+                }
+            }
+    }
+    // sort + unique every list, hash it
+    std::vector<int32_t> uptr(n + 1, 0);
+    std::vector<uint64_t> hash(n);
+    {
+        int32_t w = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            int32_t b = deg[i], e = deg[i + 1];
+            std::sort(nb.begin() + b, nb.begin() + e);
+            int32_t ne = std::unique(nb.begin() + b, nb.begin() + e) - nb.begin();
+            uint64_t h = 1469598103934665603ull;
+            for (int32_t q = b; q < ne; ++q) {
+                h = (h ^ (uint64_t)nb[q]) * 1099511628211ull;
+                nb[w++] = nb[q];
+            }
+            hash[i] = h;
+            uptr[i + 1] = w;
+        }
+        nb.resize(w);
+    }
+    // group indistinguishable unknowns (same closed neighbourhood)
+    std::vector<int32_t> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+        if (hash[a] != hash[b]) return hash[a] < hash[b];
+        return a < b;
+    });
+    SvGraph g;
+    g.sv_of.assign(n, -1);
+    auto same = [&](int32_t a, int32_t b) {
+        int32_t la = uptr[a + 1] - uptr[a], lb = uptr[b + 1] - uptr[b];
+        return la == lb && std::equal(nb.begin() + uptr[a], nb.begin() + uptr[a + 1], nb.begin() + uptr[b]);
+    };
+    std::vector<int32_t> rep;  // representative unknown of each supervariable
+    for (int64_t q = 0; q < n;) {
+        int64_t e = q + 1;
+        while (e < n && hash[order[e]] == hash[order[q]]) ++e;
+        // within one hash bucket compare against the bucket's representatives
+        size_t first_rep = rep.size();
+        for (int64_t t = q; t < e; ++t) {
+            int32_t u = order[t];
+            int32_t found = -1;
+            for (size_t r = first_rep; r < rep.size(); ++r)
+                if (same(rep[r], u)) {
+                    found = r;
+                    break;
+                }
+            if (found < 0) {
+                found = rep.size();
+                rep.push_back(u);
+            }
+            g.sv_of[u] = found;
+        }
+        q = e;
+    }
+    // renumber supervariables by their smallest member to keep locality
+    g.nsv = rep.size();
+    {
+        std::vector<int32_t> minmem(g.nsv, INT32_MAX);
+        for (int64_t i = 0; i < n; ++i) minmem[g.sv_of[i]] = std::min<int32_t>(minmem[g.sv_of[i]], i);
+        std::vector<int32_t> o(g.nsv);
+        std::iota(o.begin(), o.end(), 0);
+        std::sort(o.begin(), o.end(), [&](int32_t a, int32_t b) { return minmem[a] < minmem[b]; });
+        std::vector<int32_t> newid(g.nsv);
+        for (int32_t k = 0; k < g.nsv; ++k) newid[o[k]] = k;
+        for (int64_t i = 0; i < n; ++i) g.sv_of[i] = newid[g.sv_of[i]];
+    }
+    g.sv_ptr.assign(g.nsv + 1, 0);
+    for (int64_t i = 0; i < n; ++i) g.sv_ptr[g.sv_of[i] + 1]++;
+    for (int32_t s = 0; s < g.nsv; ++s) g.sv_ptr[s + 1] += g.sv_ptr[s];
+    g.sv_members.resize(n);
+    {
+        std::vector<int32_t> fill(g.sv_ptr.begin(), g.sv_ptr.end() - 1);
+        for (int64_t i = 0; i < n; ++i) g.sv_members[fill[g.sv_of[i]]++] = i;
+    }
+    // compressed adjacency from the first member of each supervariable
+    g.adj_ptr.assign(g.nsv + 1, 0);
+    std::vector<int32_t> tmp;
+    for (int32_t s = 0; s < g.nsv; ++s) {
+        int32_t u = g.sv_members[g.sv_ptr[s]];
+        tmp.clear();
+        for (int32_t q = uptr[u]; q < uptr[u + 1]; ++q) {
+            int32_t t = g.sv_of[nb[q]];
+            if (t != s) tmp.push_back(t);
+        }
+        std::sort(tmp.begin(), tmp.end());
+        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+        g.adj.insert(g.adj.end(), tmp.begin(), tmp.end());
+        g.adj_ptr[s + 1] = g.adj.size();
+    }
+    if (coords) {
+        g.xyz.assign((size_t)g.nsv * 3, 0.0);
+        for (int32_t s = 0; s < g.nsv; ++s) {
+            for (int32_t q = g.sv_ptr[s]; q < g.sv_ptr[s + 1]; ++q)
+                for (int d = 0; d < 3; ++d) g.xyz[s * 3 + d] += coords[(int64_t)g.sv_members[q] * 3 + d];
+            for (int d = 0; d < 3; ++d) g.xyz[s * 3 + d] /= g.size(s);
+        }
+    }
+    return g;
+}
+
+// ---------------------------------------------------------------------------
+// nested dissection
+// ---------------------------------------------------------------------------
+struct NdNode {
+    std::vector<int32_t> vars;  // own supervariables
+    int32_t parent = -1;
+    std::vector<int32_t> children;
+};
+
+class NestedDissection {
+    const SvGraph& g;
+    std::vector<int32_t> stamp, dist, queue;
+    int32_t cur_stamp = 0;
+    static constexpr int LEAF = 32;
+
+public:
+    std::vector<NdNode> nodes;
+    explicit NestedDissection(const SvGraph& g_) : g{g_}, stamp(g_.nsv, 0), dist(g_.nsv, 0) {}
+
+    // BFS inside the set marked with `mark`; returns visit order in `queue`
+    int32_t bfs(int32_t start, int32_t mark) {
+        ++cur_stamp;
+        queue.clear();
+        queue.push_back(start);
+        stamp[start] = cur_stamp;
+        dist[start] = 0;
+        for (size_t h = 0; h < queue.size(); ++h) {
+            int32_t u = queue[h];
+            for (int32_t q = g.adj_ptr[u]; q < g.adj_ptr[u + 1]; ++q) {
+                int32_t v = g.adj[q];
+                if (in_set[v] == mark && stamp[v] != cur_stamp) {
+                    stamp[v] = cur_stamp;
+                    dist[v] = dist[u] + 1;
+                    queue.push_back(v);
+                }
+            }
+        }
+        return queue.back();
+    }
+
+    std::vector<int32_t> in_set;  // set id of every supervariable (-1: none)
+    int32_t next_set = 0;
+
+    void run() {
+        in_set.assign(g.nsv, -1);
+        // connected components of the whole graph are independent roots
+        std::vector<int32_t> all(g.nsv);
+        std::iota(all.begin(), all.end(), 0);
+        std::vector<std::pair<std::vector<int32_t>, int32_t>> work;  // (connected set, parent)
+        split_components(all, -1, work);
+        while (!work.empty()) {
+            auto [set, parent] = std::move(work.back());
+            work.pop_back();
+            int32_t id = nodes.size();
+            nodes.emplace_back();
+            nodes[id].parent = parent;
+            if (parent >= 0) nodes[parent].children.push_back(id);
+            if ((int)set.size() <= LEAF) {
+                nodes[id].vars = std::move(set);
+                continue;
+            }
+            std::vector<int32_t> sep, pa, pb;
+            bisect(set, sep, pa, pb);
+            if (pa.empty() || pb.empty()) {
+                nodes[id].vars = std::move(set);
+                continue;
+            }
+            nodes[id].vars = std::move(sep);
+            split_components(pa, id, work);
+            split_components(pb, id, work);
+        }
+    }
+
+private:
+    void split_components(const std::vector<int32_t>& set, int32_t parent,
+                          std::vector<std::pair<std::vector<int32_t>, int32_t>>& out) {
+        int32_t mark = next_set++;
+        for (int32_t u : set) in_set[u] = mark;
+        // every found component is re-marked with a fresh id, so "still marked
+        // with `mark`" means "not visited yet"
+        for (int32_t u : set) {
+            if (in_set[u] != mark) continue;
+            bfs(u, mark);
+            std::vector<int32_t> comp(queue.begin(), queue.end());
+            int32_t cm = next_set++;
+            for (int32_t v : comp) in_set[v] = cm;
+            out.emplace_back(std::move(comp), parent);
+        }
+    }
+
+    void bisect(const std::vector<int32_t>& set, std::vector<int32_t>& sep, std::vector<int32_t>& pa,
+                std::vector<int32_t>& pb) {
+        const int32_t mark = in_set[set[0]];
+        const size_t ns = set.size();
+        std::vector<double> key(ns), key2(ns, 0.0);
+        if (!g.xyz.empty()) {
+            // principal axis of the point cloud (power iteration on the 3x3 covariance)
+            double mean[3] = {0, 0, 0};
+            for (int32_t u : set)
+                for (int d = 0; d < 3; ++d) mean[d] += g.xyz[u * 3 + d];
+            for (double& v : mean) v /= ns;
+            double C[9] = {0};
+            for (int32_t u : set) {
+                double c[3];
+                for (int d = 0; d < 3; ++d) c[d] = g.xyz[u * 3 + d] - mean[d];
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) C[a * 3 + b] += c[a] * c[b];
+            }
+            double v[3] = {1.0, 0.7, 0.4};
+            for (int it = 0; it < 60; ++it) {
+                double w[3];
+                for (int a = 0; a < 3; ++a) w[a] = C[a * 3] * v[0] + C[a * 3 + 1] * v[1] + C[a * 3 + 2] * v[2];
+                double nr = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+                if (!(nr > 0)) break;
+                for (int a = 0; a < 3; ++a) v[a] = w[a] / nr;
+            }
+            for (size_t i = 0; i < ns; ++i) {
+                int32_t u = set[i];
+                key[i] = (g.xyz[u * 3] - mean[0]) * v[0] + (g.xyz[u * 3 + 1] - mean[1]) * v[1] +
+                         (g.xyz[u * 3 + 2] - mean[2]) * v[2];
+            }
+        } else {
+            // two far-apart sources s, t; key = d(s,.) - d(t,.)
+            int32_t s = bfs(set[0], mark);
+            int32_t t = bfs(s, mark);
+            std::vector<int32_t> ds(ns);
+            for (size_t i = 0; i < ns; ++i) ds[i] = dist[set[i]];
+            int32_t s2 = bfs(t, mark);
+            std::vector<int32_t> dt(ns);
+            for (size_t i = 0; i < ns; ++i) dt[i] = dist[set[i]];
+            (void)s2;
+            for (size_t i = 0; i < ns; ++i) {
+                key[i] = ds[i] - dt[i];
+                key2[i] = ds[i];
+            }
+        }
+        std::vector<int32_t> ord(ns);
+        std::iota(ord.begin(), ord.end(), 0);
+        std::sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) {
+            if (key[a] != key[b]) return key[a] < key[b];
+            if (key2[a] != key2[b]) return key2[a] < key2[b];
+            return set[a] < set[b];
+        });
+        // side marks: 0 = A (first half), 1 = B
+        const int32_t markA = next_set++, markB = next_set++;
+        for (size_t i = 0; i < ns; ++i) in_set[set[ord[i]]] = i < ns / 2 ? markA : markB;
+        std::vector<int32_t> bA, bB;
+        for (size_t i = 0; i < ns; ++i) {
+            int32_t u = set[i];
+            int32_t other = in_set[u] == markA ? markB : markA;
+            bool touch = false;
+            for (int32_t q = g.adj_ptr[u]; q < g.adj_ptr[u + 1] && !touch; ++q)
+                touch = in_set[g.adj[q]] == other;
+            if (touch) (in_set[u] == markA ? bA : bB).push_back(u);
+        }
+        int64_t wA = 0, wB = 0;
+        for (int32_t u : bA) wA += g.size(u);
+        for (int32_t u : bB) wB += g.size(u);
+        const std::vector<int32_t>& chosen = wA <= wB ? bA : bB;
+        const int32_t markS = next_set++;
+        for (int32_t u : chosen) in_set[u] = markS;
+        sep = chosen;
+        for (int32_t u : set) {
+            if (in_set[u] == markA) pa.push_back(u);
+            else if (in_set[u] == markB) pb.push_back(u);
+        }
+    }
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+template <class T>
+T* Multifrontal::upload(const std::vector<T>& v) {
+    void* p = m_be->alloc(std::max<size_t>(v.size(), 1) * sizeof(T));
+    if (!v.empty()) m_be->h2d(p, v.data(), v.size() * sizeof(T));
+    m_bufs.push_back(p);
+    return static_cast<T*>(p);
+}
+
+Multifrontal::~Multifrontal() {
+    for (void* p : m_bufs) m_be->free(p);
+}
+
+Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& rowptr,
+                           const std::vector<uint32_t>& col, const double* coords)
+        : m_be{be} {
+    sanm_check(n > 0 && (int64_t)rowptr.size() == n + 1, "bad CSR pattern");
+    sanm_check(n < INT32_MAX / 2, "system too large for 32-bit indices");
+    SvGraph g = build_sv_graph(n, rowptr, col, coords);
+    nr_supervar = g.nsv;
+    used_coords = coords != nullptr;
+    NestedDissection nd{g};
+    nd.run();
+    const int32_t F = nd.nodes.size();
+    nr_front = F;
+
+    // postorder: children before parents; front ids follow the postorder
+    std::vector<int32_t> post;
+    post.reserve(F);
+    {
+        std::vector<std::pair<int32_t, size_t>> st;
+        for (int32_t r = 0; r < F; ++r) {
+            if (nd.nodes[r].parent >= 0) continue;
+            st.emplace_back(r, 0);
+            while (!st.empty()) {
+                auto& [u, ci] = st.back();
+                if (ci < nd.nodes[u].children.size()) {
+                    int32_t c = nd.nodes[u].children[ci++];
+                    st.emplace_back(c, 0);
+                } else {
+                    post.push_back(u);
+                    st.pop_back();
+                }
+            }
+        }
+    }
+    sanm_check((int32_t)post.size() == F, "postorder failed");
+    std::vector<int32_t> fid(F);  // nd node -> front id
+    for (int32_t i = 0; i < F; ++i) fid[post[i]] = i;
+
+    std::vector<int32_t> parent(F, -1), height(F, 0);
+    std::vector<std::vector<int32_t>> children(F);
+    for (int32_t u = 0; u < F; ++u) {
+        if (nd.nodes[u].parent >= 0) {
+            parent[fid[u]] = fid[nd.nodes[u].parent];
+            children[fid[nd.nodes[u].parent]].push_back(fid[u]);
+        }
+    }
+    for (int32_t f = 0; f < F; ++f) {
+        std::sort(children[f].begin(), children[f].end());
+        if (parent[f] >= 0) height[parent[f]] = std::max(height[parent[f]], height[f] + 1);
+    }
+
+    // new numbering of the unknowns; owner front of every supervariable
+    std::vector<int32_t> sv_front(g.nsv, -1), sv_start(g.nsv, 0);
+    std::vector<int32_t> own_start(F), kf(F, 0);
+    std::vector<int32_t> perm(n, -1);
+    {
+        int32_t next = 0;
+        for (int32_t f = 0; f < F; ++f) {
+            own_start[f] = next;
+            auto vars = nd.nodes[post[f]].vars;
+            std::sort(vars.begin(), vars.end());
+            for (int32_t s : vars) {
+                sanm_check(sv_front[s] < 0, "supervariable assigned twice");
+                sv_front[s] = f;
+                sv_start[s] = next;
+                for (int32_t q = g.sv_ptr[s]; q < g.sv_ptr[s + 1]; ++q) perm[g.sv_members[q]] = next++;
+            }
+            kf[f] = next - own_start[f];
+            sanm_check(kf[f] > 0, "empty front");
+        }
+        sanm_check(next == n, "ordering does not cover all unknowns");
+    }
+
+    // boundaries (in supervariables, then expanded)
+    std::vector<std::vector<int32_t>> bnd_sv(F);
+    for (int32_t f = 0; f < F; ++f) {
+        std::vector<int32_t>& b = bnd_sv[f];
+        for (int32_t s : nd.nodes[post[f]].vars)
+            for (int32_t q = g.adj_ptr[s]; q < g.adj_ptr[s + 1]; ++q) {
+                int32_t t = g.adj[q];
+                if (sv_front[t] > f) b.push_back(t);
+            }
+        for (int32_t c : children[f])
+            for (int32_t t : bnd_sv[c])
+                if (sv_front[t] != f) b.push_back(t);
+        // order by new index so that expanded lists are ascending
+        std::sort(b.begin(), b.end(), [&](int32_t a, int32_t c2) { return sv_start[a] < sv_start[c2]; });
+        b.erase(std::unique(b.begin(), b.end()), b.end());
+        for (int32_t t : b) sanm_check(sv_front[t] > f, "boundary variable is not in an ancestor");
+    }
+
+    std::vector<MfFrontDev> fr(F);
+    std::vector<int32_t> bnd_idx;
+    int64_t off = 0, doff = 0;
+    int32_t upd = 0, gat = 0;
+    for (int32_t f = 0; f < F; ++f) {
+        fr[f].bnd_off = bnd_idx.size();
+        for (int32_t t : bnd_sv[f])
+            for (int32_t q = 0; q < g.size(t); ++q) bnd_idx.push_back(sv_start[t] + q);
+        int32_t b = bnd_idx.size() - fr[f].bnd_off;
+        fr[f].k = kf[f];
+        fr[f].m = kf[f] + b;
+        fr[f].own_start = own_start[f];
+        fr[f].parent = parent[f];
+        fr[f].off = off;
+        off += (int64_t)fr[f].m * fr[f].m;
+        fr[f].dinv_off = doff;
+        doff += (int64_t)((fr[f].k + MF_NB - 1) / MF_NB) * 2 * MF_NB * MF_NB;
+        fr[f].rel_off = fr[f].bnd_off;  // rel is parallel to bnd_idx
+        fr[f].upd_off = upd;
+        upd += b;
+        fr[f].gat_off = gat;
+        gat += fr[f].m + 1;
+        max_front = std::max(max_front, fr[f].m);
+        if (parent[f] < 0) root_pivots = std::max(root_pivots, fr[f].k);
+        double k = fr[f].k, bb = b;
+        nnz_factors += (int64_t)(k * k + 2 * k * bb);
+        factor_flops += 2.0 / 3 * k * k * k + 2 * k * k * bb + 2 * k * bb * bb;
+    }
+    front_doubles = off;
+
+    // position of a (new-numbered) variable x inside front f
+    auto pos_in_front = [&](int32_t f, int32_t x) -> int32_t {
+        if (x >= fr[f].own_start && x < fr[f].own_start + fr[f].k) return x - fr[f].own_start;
+        const int32_t* b = bnd_idx.data() + fr[f].bnd_off;
+        int32_t nb = fr[f].m - fr[f].k;
+        const int32_t* it = std::lower_bound(b, b + nb, x);
+        sanm_check(it != b + nb && *it == x, "variable %d is not part of front %d", x, f);
+        return fr[f].k + (it - b);
+    };
+
+    std::vector<int32_t> rel(bnd_idx.size(), -1);
+    for (int32_t f = 0; f < F; ++f) {
+        if (parent[f] < 0) {
+            sanm_check(fr[f].m == fr[f].k, "root front has a boundary");
+            continue;
+        }
+        for (int32_t j = 0; j < fr[f].m - fr[f].k; ++j)
+            rel[fr[f].rel_off + j] = pos_in_front(parent[f], bnd_idx[fr[f].bnd_off + j]);
+    }
+
+    // gather lists of the solve: which child update entries feed row r of front f
+    std::vector<int32_t> gat_ptr(gat, 0), gat_src;
+    {
+        for (int32_t f = 0; f < F; ++f)
+            for (int32_t c : children[f])
+                for (int32_t j = 0; j < fr[c].m - fr[c].k; ++j)
+                    gat_ptr[fr[f].gat_off + rel[fr[c].rel_off + j] + 1]++;
+        int32_t run = 0;
+        for (int32_t f = 0; f < F; ++f) {
+            // local prefix sums, made global by adding the running total
+            int32_t base = fr[f].gat_off;
+            gat_ptr[base] = run;
+            for (int32_t r = 0; r < fr[f].m; ++r) {
+                run += gat_ptr[base + r + 1];
+                gat_ptr[base + r + 1] = run;
+            }
+        }
+        gat_src.assign(run, -1);
+        std::vector<int32_t> fill(gat_ptr);
+        for (int32_t f = 0; f < F; ++f)
+            for (int32_t c : children[f])
+                for (int32_t j = 0; j < fr[c].m - fr[c].k; ++j)
+                    gat_src[fill[fr[f].gat_off + rel[fr[c].rel_off + j]]++] = fr[c].upd_off + j;
+    }
+
+    // owner front of every new index
+    std::vector<int32_t> owner(n);
+    for (int32_t f = 0; f < F; ++f)
+        for (int32_t q = 0; q < fr[f].k; ++q) owner[fr[f].own_start + q] = f;
+
+    // scatter map of A
+    const int64_t nnzA = col.size();
+    std::vector<int64_t> a_dst(nnzA);
+    for (int64_t i = 0; i < n; ++i)
+        for (uint32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+            int32_t pi = perm[i], pj = perm[col[p]];
+            int32_t f = owner[std::min(pi, pj)];
+            a_dst[p] = fr[f].off + (int64_t)pos_in_front(f, pi) * fr[f].m + pos_in_front(f, pj);
+        }
+
+    // levels: fronts by height, by decreasing k inside a level
+    int32_t H = 0;
+    for (int32_t f = 0; f < F; ++f) H = std::max(H, height[f] + 1);
+    nr_level = H;
+    std::vector<int32_t> level_fronts;
+    std::vector<int32_t> ea_children;
+    m_sched.levels.resize(H);
+    for (int32_t h = 0; h < H; ++h) {
+        auto& L = m_sched.levels[h];
+        L.front_begin = level_fronts.size();
+        std::vector<int32_t> fs;
+        for (int32_t f = 0; f < F; ++f)
+            if (height[f] == h) fs.push_back(f);
+        std::stable_sort(fs.begin(), fs.end(), [&](int32_t a, int32_t b) { return fr[a].k > fr[b].k; });
+        level_fronts.insert(level_fronts.end(), fs.begin(), fs.end());
+        L.front_end = level_fronts.size();
+        L.max_m = L.max_k = L.max_b = 0;
+        size_t max_children = 0;
+        for (int32_t f : fs) {
+            L.max_m = std::max(L.max_m, fr[f].m);
+            L.max_k = std::max(L.max_k, fr[f].k);
+            L.max_b = std::max(L.max_b, fr[f].m - fr[f].k);
+            max_children = std::max(max_children, children[f].size());
+        }
+        L.nr_panel = (L.max_k + MF_NB - 1) / MF_NB;
+        L.panel_cnt.assign(L.nr_panel, 0);
+        for (int32_t f : fs)
+            for (int32_t p = 0; p * MF_NB < fr[f].k; ++p) L.panel_cnt[p]++;
+        for (size_t r = 0; r < max_children; ++r) {
+            int32_t b = ea_children.size(), mb = 0;
+            for (int32_t f : fs)
+                if (r < children[f].size()) {
+                    int32_t c = children[f][r];
+                    ea_children.push_back(c);
+                    mb = std::max(mb, fr[c].m - fr[c].k);
+                }
+            L.ea_rounds.emplace_back(b, (int32_t)ea_children.size());
+            L.ea_max_b.push_back(mb);
+        }
+    }
+
+    // device copies
+    m_dev.n = n;
+    m_dev.nnzA = nnzA;
+    m_dev.nr_front = F;
+    m_dev.nr_level = H;
+    m_dev.fronts = upload(fr);
+    m_dev.level_fronts = upload(level_fronts);
+    m_dev.bnd_idx = upload(bnd_idx);
+    m_dev.rel = upload(rel);
+    m_dev.gat_ptr = upload(gat_ptr);
+    m_dev.gat_src = upload(gat_src);
+    m_dev.perm = upload(perm);
+    m_dev.a_dst = upload(a_dst);
+    m_sched.ea_children = upload(ea_children);
+    m_dev.front_store_size = off;
+    m_dev.dinv_store_size = doff;
+    m_dev.upd_store_size = std::max(upd, 1);
+    m_dev.front_store = static_cast<double*>(be->alloc(off * sizeof(double)));
+    m_dev.dinv_store = static_cast<double*>(be->alloc(std::max<int64_t>(doff, 1) * sizeof(double)));
+    m_dev.upd_store = static_cast<double*>(be->alloc(m_dev.upd_store_size * sizeof(double)));
+    m_dev.work = static_cast<double*>(be->alloc(n * sizeof(double)));
+    m_dev.status = static_cast<int32_t*>(be->alloc(64));
+    be->zero(m_dev.status, 64);
+    m_bufs.push_back(m_dev.front_store);
+    m_bufs.push_back(m_dev.dinv_store);
+    m_bufs.push_back(m_dev.upd_store);
+    m_bufs.push_back(m_dev.work);
+    m_bufs.push_back(m_dev.status);
+}
+
+}  // namespace sanm_hip

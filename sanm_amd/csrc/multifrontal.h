@@ -1,0 +1,63 @@
+// Sparse direct solver for the ANM Jacobian: multifrontal LU on the device.
+//
+// Role in the reference: SparseSolver::prepare / solve (libsanm/sparse_solver.cpp:
+// 327-421, :154-180), i.e. MKL PARDISO with mtype 11 (unsymmetric LU), one
+// factorisation and `order` forward/backward substitutions per ANM step.  The
+// sparsity pattern is fixed per model, so everything symbolic happens once on
+// the host (this file); each step only re-runs the numeric kernels on the GPU.
+//
+// Method (classic multifrontal, structurally symmetric pattern, no pivoting):
+//   * indistinguishable rows are merged into supervariables (the 3 dofs of a
+//     vertex), the compressed graph is ordered by nested dissection --
+//     principal-axis median cuts when coordinates of the unknowns are known,
+//     two-source graph-distance cuts otherwise;
+//   * every dissection-tree node is a front: a dense m x m matrix whose first
+//     k rows/cols are its own (pivot) variables and the rest its boundary in
+//     the ancestors.  Fronts of equal height are independent and are
+//     processed by the same kernel launches;
+//   * factor: scatter A, extend-add the children's Schur complements, blocked
+//     right-looking LU of the leading k columns (NB x NB diagonal blocks are
+//     inverted so panel solves become small GEMMs);
+//   * solve: forward sweep up the tree, backward sweep down, two launches per
+//     level and direction (triangular part: one workgroup per front; the
+//     rectangular L21 / U12 products: row tiles spread over workgroups).
+// The forward-FEA Jacobian is minus a Hessian (definite at stable states), so
+// unpivoted LU is stable there; tiny pivots are detected and reported.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "backend.h"
+#include "graph.h"
+#include "mf_types.h"
+
+namespace sanm_hip {
+
+class Multifrontal {
+public:
+    //! pattern of the n x n matrix (CSR, original numbering); coords (n,3) or null
+    Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& rowptr,
+                 const std::vector<uint32_t>& col, const double* coords);
+    ~Multifrontal();
+    Multifrontal(const Multifrontal&) = delete;
+
+    const MfDev& dev() const { return m_dev; }
+    const MfSchedule& schedule() const { return m_sched; }
+
+    // statistics of the analysis
+    int64_t nnz_factors = 0;   // entries of L + U
+    double factor_flops = 0;
+    int64_t front_doubles = 0;
+    int32_t nr_front = 0, nr_level = 0, max_front = 0, root_pivots = 0, nr_supervar = 0;
+    bool used_coords = false;
+
+private:
+    Backend* m_be;
+    MfDev m_dev{};
+    MfSchedule m_sched;
+    std::vector<void*> m_bufs;
+    template <class T>
+    T* upload(const std::vector<T>& v);
+};
+
+}  // namespace sanm_hip

@@ -22,6 +22,9 @@ struct SparseDesc {
     std::vector<uint64_t> rowptr;  // out_size+1
     std::vector<uint64_t> idx;
     std::vector<double> coef;
+    //! optional (out_size,3) spatial position of every output element; used as an
+    //! ordering hint by the direct solver when this map is remap_out
+    std::vector<double> out_coords;
 
     SparseDesc() = default;
     SparseDesc(int64_t out_size, int64_t in_size, const uint64_t* rowptr, const uint64_t* idx,

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "backend.h"
 #include "graph.h"
@@ -18,6 +19,8 @@
 #include "tet_ops.h"
 
 namespace sanm_hip {
+int hostsim_mf_factor(const MfDev& mf, const MfSchedule& sch, const CsrDev& A);
+void hostsim_mf_solve(const MfDev& mf, const MfSchedule& sch, const double* b, double* x);
 namespace {
 class HostSimBackend final : public Backend {
 public:
@@ -67,6 +70,12 @@ public:
         for (size_t i = 0; i < n; ++i) m = std::fmax(m, allclose_excess1(a[i], b[i], eps));
         return m;
     }
+    int mf_factor(const MfDev& mf, const MfSchedule& sch, const CsrDev& A) override {
+        return hostsim_mf_factor(mf, sch, A);
+    }
+    void mf_solve(const MfDev& mf, const MfSchedule& sch, const double* b, double* x) override {
+        hostsim_mf_solve(mf, sch, b, x);
+    }
     double t0v_excess(size_t n, const double* fx, const double* v, double t0,
                       double tol) override {
         double m = -1e300;
@@ -82,4 +91,95 @@ public:
 }  // namespace
 
 Backend* make_backend(int) { return new HostSimBackend(); }
+}  // namespace sanm_hip
+
+// ---- multifrontal: straightforward serial reference of the numeric phases ----
+// (same data structures as the HIP kernels; validates the host symbolic analysis)
+namespace sanm_hip {
+namespace {
+struct HostMf {
+    static int factor(const MfDev& mf, const MfSchedule& sch, const CsrDev& A) {
+        std::memset(mf.front_store, 0, mf.front_store_size * sizeof(double));
+        for (int64_t p = 0; p < mf.nnzA; ++p) mf.front_store[mf.a_dst[p]] += A.val[p];
+        int bad = 0;
+        for (const auto& L : sch.levels) {
+            // extend-add the children of this level's fronts
+            for (auto [b, e] : L.ea_rounds)
+                for (int32_t q = b; q < e; ++q) {
+                    const MfFrontDev& c = mf.fronts[sch.ea_children[q]];
+                    const MfFrontDev& p = mf.fronts[c.parent];
+                    const int32_t* rel = mf.rel + c.rel_off;
+                    int nb = c.m - c.k;
+                    for (int i = 0; i < nb; ++i)
+                        for (int j = 0; j < nb; ++j)
+                            mf.front_store[p.off + (int64_t)rel[i] * p.m + rel[j]] +=
+                                    mf.front_store[c.off + (int64_t)(c.k + i) * c.m + c.k + j];
+                }
+            for (int32_t q = L.front_begin; q < L.front_end; ++q) {
+                const MfFrontDev& f = mf.fronts[mf.level_fronts[q]];
+                double* F = mf.front_store + f.off;
+                const int m = f.m;
+                for (int j = 0; j < f.k; ++j) {
+                    double piv = F[(int64_t)j * m + j];
+                    if (!(std::fabs(piv) > 1e-300)) ++bad;
+                    double inv = 1.0 / piv;
+                    for (int i = j + 1; i < m; ++i) {
+                        double l = F[(int64_t)i * m + j] * inv;
+                        F[(int64_t)i * m + j] = l;
+                        if (l != 0)
+                            for (int c2 = j + 1; c2 < m; ++c2) F[(int64_t)i * m + c2] -= l * F[(int64_t)j * m + c2];
+                    }
+                }
+            }
+        }
+        return bad;
+    }
+
+    static void solve(const MfDev& mf, const MfSchedule& sch, const double* b, double* x) {
+        double* w = mf.work;
+        for (int64_t i = 0; i < mf.n; ++i) w[mf.perm[i]] = b[i];
+        std::vector<double> t;
+        for (const auto& L : sch.levels)  // forward
+            for (int32_t q = L.front_begin; q < L.front_end; ++q) {
+                const MfFrontDev& f = mf.fronts[mf.level_fronts[q]];
+                const double* F = mf.front_store + f.off;
+                const int m = f.m, k = f.k;
+                t.assign(m, 0.0);
+                for (int r = 0; r < k; ++r) t[r] = w[f.own_start + r];
+                const int32_t* gp = mf.gat_ptr + f.gat_off;
+                for (int r = 0; r < m; ++r)
+                    for (int32_t s = gp[r]; s < gp[r + 1]; ++s) t[r] += mf.upd_store[mf.gat_src[s]];
+                for (int r = 0; r < k; ++r) {  // unit lower L11
+                    double v = t[r];
+                    for (int c2 = 0; c2 < r; ++c2) v -= F[(int64_t)r * m + c2] * t[c2];
+                    t[r] = v;
+                }
+                for (int r = k; r < m; ++r) {
+                    double v = t[r];
+                    for (int c2 = 0; c2 < k; ++c2) v -= F[(int64_t)r * m + c2] * t[c2];
+                    mf.upd_store[f.upd_off + r - k] = v;
+                }
+                for (int r = 0; r < k; ++r) w[f.own_start + r] = t[r];
+            }
+        for (int li = (int)sch.levels.size() - 1; li >= 0; --li) {  // backward
+            const auto& L = sch.levels[li];
+            for (int32_t q = L.front_begin; q < L.front_end; ++q) {
+                const MfFrontDev& f = mf.fronts[mf.level_fronts[q]];
+                const double* F = mf.front_store + f.off;
+                const int m = f.m, k = f.k;
+                const int32_t* bi = mf.bnd_idx + f.bnd_off;
+                for (int r = k - 1; r >= 0; --r) {
+                    double v = w[f.own_start + r];
+                    for (int c2 = k; c2 < m; ++c2) v -= F[(int64_t)r * m + c2] * w[bi[c2 - k]];
+                    for (int c2 = r + 1; c2 < k; ++c2) v -= F[(int64_t)r * m + c2] * w[f.own_start + c2];
+                    w[f.own_start + r] = v / F[(int64_t)r * m + r];
+                }
+            }
+        }
+        for (int64_t i = 0; i < mf.n; ++i) x[i] = w[mf.perm[i]];
+    }
+};
+}  // namespace
+int hostsim_mf_factor(const MfDev& mf, const MfSchedule& sch, const CsrDev& A) { return HostMf::factor(mf, sch, A); }
+void hostsim_mf_solve(const MfDev& mf, const MfSchedule& sch, const double* b, double* x) { HostMf::solve(mf, sch, b, x); }
 }  // namespace sanm_hip

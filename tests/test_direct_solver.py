@@ -1,0 +1,92 @@
+"""Multifrontal LU (SparseSolver role, libsanm/sparse_solver.cpp) against
+scipy's sparse LU: the reference's own check is Ax = b on random systems
+(tests/tensor.cpp:44-85)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from oracle import fea as ofea
+from oracle import symbolic as S
+from oracle.anm import build_jacobian_csr
+from sanm_amd.api import DirectSolver
+
+
+def _check(api, A, coords=None, tol=1e-9, nrhs=3, seed=0):
+    rng = np.random.default_rng(seed)
+    A = A.tocsr()
+    A.sort_indices()
+    ds = DirectSolver(api, A, coords)
+    assert ds.factor(A) == 0
+    lu = spla.splu(A.tocsc())
+    for _ in range(nrhs):
+        b = rng.standard_normal(A.shape[0])
+        x = ds.solve(b)
+        xr = lu.solve(b)
+        assert np.abs(x - xr).max() <= tol * np.abs(xr).max()
+    # refactor with new values on the same pattern (one analysis, many steps)
+    A2 = A.copy()
+    A2.data = A.data * (1 + 0.1 * rng.standard_normal(A.nnz))
+    A2 = A2 + sp.diags(np.abs(A2).sum(axis=1).A1) * np.sign(A.diagonal()[0])
+    A2 = sp.csr_matrix(A2)
+    A2.sort_indices()
+    if A2.nnz == A.nnz:
+        assert ds.factor(A2) == 0
+        b = rng.standard_normal(A.shape[0])
+        assert np.abs(ds.solve(b) - spla.spsolve(A2.tocsc(), b)).max() <= tol * 10
+    return ds
+
+
+def test_random_block_unsymmetric(api):
+    rng = np.random.default_rng(1)
+    nb = 70
+    B = sp.random(nb, nb, density=0.07, random_state=2)
+    B = ((B + B.T) != 0).astype(float) + sp.identity(nb)
+    A = sp.kron(B, np.ones((3, 3))).tocsr()
+    A.data = rng.standard_normal(A.nnz)
+    A = A + sp.diags(np.full(3 * nb, 45.0))
+    ds = _check(api, A)
+    st = ds.stats()
+    assert st["nr_supervar"] <= nb and st["nr_front"] >= 1
+
+
+def test_scalar_pattern_no_blocks(api):
+    # 2-D 5-point Laplacian: supervariables are single unknowns, several levels
+    k = 23
+    T = sp.diags([-1, 2, -1], [-1, 0, 1], shape=(k, k))
+    A = sp.kron(sp.identity(k), T) + sp.kron(T, sp.identity(k)) + 0.1 * sp.identity(k * k)
+    ds = _check(api, sp.csr_matrix(A))
+    assert ds.stats()["nr_level"] >= 3
+
+
+def test_tiny_and_diagonal(api):
+    _check(api, sp.csr_matrix(np.array([[4.0, 1.0], [2.0, 3.0]])))
+    _check(api, sp.csr_matrix(sp.diags(np.arange(1.0, 40.0))))
+    # disconnected components -> forest
+    A = sp.block_diag([sp.csr_matrix(np.array([[3.0, 1], [1, 2]])), sp.diags([5.0, 6.0]),
+                       sp.csr_matrix(np.array([[2.0, -1, 0], [-1, 2, -1], [0, -1, 2]]))])
+    _check(api, sp.csr_matrix(A))
+
+
+@pytest.mark.parametrize("with_coords", [True, False])
+def test_fem_jacobian(api, with_coords):
+    """the actual ANM Jacobian of a cuboid (negative definite), with and
+    without the coordinate hint (principal-axis vs graph-distance dissection)"""
+    mesh = ofea.make_cuboid(9, 5, 4, 0.02)
+    fixed = np.zeros((mesh.nr_vertices, 3), bool)
+    fixed[mesh.V[:, 0] < 0.01] = True
+    om = ofea.make_forward(mesh, ofea.Material(1e4, 0.45), fixed, "neohookean_c")
+    prop = S.TaylorCoeffProp(om.y)
+    prop.push_xi([(om.lt_inp.mat @ om.lt_inp.x0).reshape(-1, 3, 3)])
+    A, _ = build_jacobian_csr(om.lt_out, prop.get_jacobian(), om.lt_inp.mat, om.lt_inp.n)
+    coords = mesh.V[om.lt_inp.vertex_loc[:, 0]] if with_coords else None
+    ds = _check(api, A, coords, tol=1e-8)
+    st = ds.stats()
+    assert st["nr_supervar"] <= A.shape[0]
+    assert st["nr_level"] >= 3 and st["max_front"] < A.shape[0]
+
+
+def test_singular_matrix_reports_bad_pivot(api):
+    A = sp.csr_matrix(np.array([[1.0, 2.0, 0], [2.0, 4.0, 0], [0, 0, 1.0]]))
+    ds = DirectSolver(api, A)
+    assert ds.factor(A) >= 1
