@@ -155,6 +155,11 @@ int sanm_anm_restart(sanm_anm_solver* s, const double* x0);
  * call sanm_anm_restart() afterwards. */
 int sanm_anm_time_kernel(sanm_anm_solver* s, int kernel, int reps, int mode, int order,
                          double* avg_ms);
+/* measurement hook for bench.py: when enabled, every launch of the Taylor pass
+ * kernel (the graph interpreter) is bracketed by HIP events on the solver's
+ * stream.  Each call first returns the summed duration / launch count gathered
+ * since the previous call (pass NULL to skip), then sets the enable flag. */
+int sanm_anm_pass_timing(sanm_anm_solver* s, int enable, double* total_ms, int64_t* count);
 int sanm_anm_converged(const sanm_anm_solver* s, int* flag);     /* ANMEqnSolver::converged */
 int sanm_anm_residual_rms(const sanm_anm_solver* s, double* r);  /* ANMEqnSolver::residual_rms */
 int sanm_anm_get_x(const sanm_anm_solver* s, double* x);         /* ANMEqnSolver::get_x (n) */

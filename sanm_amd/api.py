@@ -79,7 +79,7 @@ SYMBOLS = [
     "sanm_taylor_reset",
     "sanm_hyper_param_default", "sanm_anm_eqn_solver_create", "sanm_anm_vecscale_solver_create",
     "sanm_anm_implicit_solver_create", "sanm_anm_solver_destroy", "sanm_anm_next_iter",
-    "sanm_anm_update_approx", "sanm_anm_restart", "sanm_anm_time_kernel", "sanm_anm_converged", "sanm_anm_residual_rms", "sanm_anm_get_x",
+    "sanm_anm_update_approx", "sanm_anm_restart", "sanm_anm_time_kernel", "sanm_anm_pass_timing", "sanm_anm_converged", "sanm_anm_residual_rms", "sanm_anm_get_x",
     "sanm_anm_get_t_upper", "sanm_anm_get_t_max_a", "sanm_anm_solve_a", "sanm_anm_eval",
     "sanm_anm_nr_iter", "sanm_anm_nr_xt_coeffs", "sanm_anm_xt_coeff", "sanm_anm_has_pade",
     "sanm_anm_get_stats", "sanm_anm_profile", "sanm_anm_trace", "sanm_anm_jacobian_csr",
@@ -513,6 +513,13 @@ class _ANMSolver:
         self.api.check(self.api.lib.sanm_anm_time_kernel(self.h, C.c_int(kernel), C.c_int(reps), C.c_int(mode),
                                                          C.c_int(order), C.byref(out)))
         return out.value
+
+    def pass_timing(self, enable, fetch=True):
+        tot, cnt = C.c_double(), C.c_int64()
+        self.api.check(self.api.lib.sanm_anm_pass_timing(self.h, C.c_int(1 if enable else 0),
+                                                         C.byref(tot) if fetch else None,
+                                                         C.byref(cnt) if fetch else None))
+        return tot.value, cnt.value
 
     def jacobian_csr(self):
         import scipy.sparse as sp

@@ -117,7 +117,8 @@ std::unique_ptr<LinearSolver> make_pcg_solver(Backend* be, const JacobianPattern
 }
 
 // ----------------------------------------------------------------- Pade --
-PadeApproximation::PadeApproximation(Backend* be, const std::vector<DVec>& xs, bool anm_cond)
+PadeApproximation::PadeApproximation(Backend* be, const std::vector<DVec>& xs,
+                                     const std::vector<double>& t_coeffs, bool anm_cond)
         : m_be{be}, m_xs{xs}, m_len{xs[0].size()} {
     // libsanm/pade.cpp:13-105
     const int nx = xs.size();
@@ -128,19 +129,28 @@ PadeApproximation::PadeApproximation(Backend* be, const std::vector<DVec>& xs, b
     auto A = [&](int i, int j) -> double& { return a[(size_t)i * nx + j]; };
     const double eps = std::numeric_limits<double>::epsilon();
     std::vector<DVec> orth(nx);
+    std::vector<const double*> ptrs(nx);
+    std::vector<double> coefs(nx), dots(nx);
     for (int i = 1; i <= n; ++i) {
         DVec uii{be, m_len};
-        be->d2d(uii.p(), xs[i].p(), m_len * 8);
-        // classical Gram-Schmidt: the projections use xs[i], not the running uii
+        // classical Gram-Schmidt (the projections use xs[i], not the running uii):
+        // all i-1 projections in one reduction kernel, the update in one fused kernel
+        for (int j = 1; j < i; ++j) ptrs[j - 1] = orth[j].p();
+        be->multi_dot(m_len, xs[i].p(), i - 1, ptrs.data(), dots.data());
+        int nv = 0;
+        ptrs[nv] = xs[i].p();
+        coefs[nv++] = 1.0;
         for (int j = 1; j < i; ++j) {
-            A(i, j) = be->dot(m_len, xs[i].p(), orth[j].p());
+            A(i, j) = dots[j - 1];
             if (anm_cond && j == 1) {
                 sanm_check(std::fabs(A(i, j)) < 1e-4, "pade: anm condition violated: %g", A(i, j));
                 A(i, j) = 0;
             } else {
-                be->axpby(m_len, 1.0, uii.p(), -A(i, j), orth[j].p(), uii.p());
+                ptrs[nv] = orth[j].p();
+                coefs[nv++] = -A(i, j);
             }
         }
+        be->lincomb(m_len, nv, ptrs.data(), coefs.data(), uii.p());
         double aii = std::sqrt(be->dot(m_len, uii.p(), uii.p()));
         if (aii == 0) {
             m_d.clear();
@@ -168,8 +178,7 @@ PadeApproximation::PadeApproximation(Backend* be, const std::vector<DVec>& xs, b
     solve_d(m_d_lo, n - 1);
     m_t_nume.assign(n, 0.0);
     for (int i = 0; i < n; ++i) {
-        double ti;
-        be->d2h(&ti, xs[i].p() + (m_len - 1), 8);
+        double ti = t_coeffs[i];
         if (!i) {
             m_t0 = ti;
         } else {
@@ -179,12 +188,17 @@ PadeApproximation::PadeApproximation(Backend* be, const std::vector<DVec>& xs, b
 }
 
 void PadeApproximation::eval_nume(double a, const double* d, int n, double* out) const {
-    // libsanm/pade.cpp:181-189
-    m_be->zero(out, m_len * 8);
-    for (int i = n; i >= 1; --i) {
-        double scale = poly::eval(d, n - i + 1, a);
-        m_be->axpby(m_len, a, out, scale, m_xs[i].p(), out);
+    // libsanm/pade.cpp:181-189: sum_{i=1}^{n} a^(i-1) * poly(d[0..n-i], a) * xs[i],
+    // evaluated as one fused linear combination instead of a Horner chain of axpys
+    std::vector<const double*> ptrs(n);
+    std::vector<double> coefs(n);
+    double ap = 1.0;
+    for (int i = 1; i <= n; ++i) {
+        ptrs[i - 1] = m_xs[i].p();
+        coefs[i - 1] = ap * poly::eval(d, n - i + 1, a);
+        ap *= a;
     }
+    m_be->lincomb(m_len, n, ptrs.data(), coefs.data(), out);
 }
 
 double PadeApproximation::eval_t(double a) const {
@@ -365,6 +379,7 @@ void AnmDriver::solve_expansion_coeffs() {
         double* xi = m_xt_coeffs[i].p();
         be->axpby(n, -ti, m_xgt.p(), -1.0, xbi, xi);
         be->h2d(xi + n, &ti, 8);
+        m_t_coeffs.push_back(ti);
         m_nr_valid_coeffs = i + 1;
         if (i == 1) xgt_dot_x1 = be->dot(n, xi, m_xgt.p());
 
@@ -404,8 +419,7 @@ void AnmDriver::estimate_valid_range() {
     double xback = std::max(std::sqrt(m_be->dot(n1, m_xt_coeffs[N].p(), m_xt_coeffs[N].p())), 1e-15);
     double a_bound = std::pow(m_hp.maxr / xback * x1, 1.0 / double(N - 1));
     a_bound = std::min(a_bound, m_max_a_bound);
-    m_t_coeffs.resize(N + 1);
-    for (int i = 0; i <= N; ++i) m_be->d2h(&m_t_coeffs[i], m_xt_coeffs[i].p() + m_n, 8);
+    sanm_check((int)m_t_coeffs.size() == N + 1, "t coefficients incomplete");
     sanm_check(m_t_coeffs[1] > 0, "t1=%g is not positive", m_t_coeffs[1]);
     m_t_max_a = a_bound;
     m_t_max = poly::eval(m_t_coeffs, a_bound);
@@ -414,7 +428,8 @@ void AnmDriver::estimate_valid_range() {
     m_pade.reset();
     static const bool env_pade = getenv("SANM_PADE") != nullptr;
     if ((m_hp.use_pade || env_pade) && a_bound < m_max_a_bound) {
-        auto pade = std::make_unique<PadeApproximation>(m_be, m_xt_coeffs, !m_hp.xcoeff_l2_penalty);
+        auto pade = std::make_unique<PadeApproximation>(m_be, m_xt_coeffs, m_t_coeffs,
+                                                        !m_hp.xcoeff_l2_penalty);
         if (pade->estimate_valid_range(a_bound, m_hp.maxr, m_max_a_bound)) {
             m_t_max_a = pade->get_t_max_a();
             m_t_max = pade->get_t_max();
@@ -438,8 +453,15 @@ void AnmDriver::eval_xt(double a, double* out) const {
     }
     const size_t n1 = m_n + 1;
     const int N = m_nr_valid_coeffs - 1;
-    m_be->d2d(out, m_xt_coeffs[N].p(), n1 * 8);
-    for (int i = N - 1; i >= 0; --i) m_be->axpby(n1, a, out, 1.0, m_xt_coeffs[i].p(), out);
+    std::vector<const double*> ptrs(N + 1);
+    std::vector<double> coefs(N + 1);
+    double ap = 1.0;
+    for (int i = 0; i <= N; ++i) {
+        ptrs[i] = m_xt_coeffs[i].p();
+        coefs[i] = ap;
+        ap *= a;
+    }
+    m_be->lincomb(n1, N + 1, ptrs.data(), coefs.data(), out);
 }
 
 double AnmDriver::eval(double a, double* x_host) const {

@@ -86,7 +86,9 @@ std::unique_ptr<LinearSolver> make_direct_solver(Backend* be, const JacobianPatt
 //! libsanm/pade.h on device vectors
 class PadeApproximation {
 public:
-    PadeApproximation(Backend* be, const std::vector<DVec>& xs, bool anm_cond);
+    //! t_coeffs: host copy of the last element of every xs[i]
+    PadeApproximation(Backend* be, const std::vector<DVec>& xs, const std::vector<double>& t_coeffs,
+                      bool anm_cond);
     bool estimate_valid_range(double start, double eps, double limit);
     double get_t_max() const { return m_t_max; }
     double get_t_max_a() const { return m_t_max_a; }

@@ -65,6 +65,13 @@ public:
     //! out = a*x + b*y  (y may be null iff b == 0; out may alias x or y)
     virtual void axpby(size_t n, double a, const double* x, double b, const double* y,
                        double* out) = 0;
+    //! out = sum_j coefs[j] * ptrs[j]  (nvec <= 24; out may alias one of the inputs
+    //! only if that input has index 0)
+    virtual void lincomb(size_t n, int nvec, const double* const* ptrs, const double* coefs,
+                         double* out);
+    //! out_host[j] = x . ys[j]  for j < nvec (nvec <= 24), one synchronisation
+    virtual void multi_dot(size_t n, const double* x, int nvec, const double* const* ys,
+                           double* out_host);
     //! out = x .* y
     virtual void vmul(size_t n, const double* x, const double* y, double* out) = 0;
     //! d[i] = 1 / A[i,i]  (scaled by `scale`)
@@ -94,6 +101,15 @@ public:
     virtual int mf_factor(const MfDev& mf, const MfSchedule& sch, const CsrDev& A) = 0;
     //! x = A^-1 b with the factors of the last mf_factor (b, x: n doubles, may alias)
     virtual void mf_solve(const MfDev& mf, const MfSchedule& sch, const double* b, double* x) = 0;
+
+    //! bracket every run_pass launch with device events (measurement runs only);
+    //! pass_timing() returns the summed duration in ms and the launch count since
+    //! the last enable
+    virtual void enable_pass_timing(bool on) { (void)on; }
+    virtual void pass_timing(double* total_ms, int64_t* count) {
+        *total_ms = 0;
+        *count = 0;
+    }
 
     //! average duration in ms of `reps` back-to-back launches of one kernel,
     //! measured with device events on the backend's stream (bench.py roofline).

@@ -4,6 +4,21 @@
 
 namespace sanm_hip {
 
+void Backend::lincomb(size_t n, int nvec, const double* const* ptrs, const double* coefs,
+                      double* out) {
+    if (nvec == 0) {
+        zero(out, n * 8);
+        return;
+    }
+    axpby(n, coefs[0], ptrs[0], 0, nullptr, out);
+    for (int j = 1; j < nvec; ++j) axpby(n, 1.0, out, coefs[j], ptrs[j], out);
+}
+
+void Backend::multi_dot(size_t n, const double* x, int nvec, const double* const* ys,
+                        double* out_host) {
+    for (int j = 0; j < nvec; ++j) out_host[j] = dot(n, x, ys[j]);
+}
+
 void Backend::pcg(const CsrDev& A, double sign, const double* dinv, const double* b, double* x,
                   double rtol, int maxit, int* iters, double* relres) {
     const size_t n = A.n;

@@ -43,16 +43,35 @@ __global__ void __launch_bounds__(64) taylor_pass_kernel(ProgramDev P, int mode,
     if (tet < P.T) exec_program_tet(P, mode, order, tet, xvec);
 }
 
-__global__ void gather_rows_kernel(SparseRowsDev R, const double* __restrict__ src,
-                                   double* __restrict__ dst) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < R.nrows) dst[i] = gather_row(R, src, i);
+// remap_out: ROW_LANES lanes per output row (~45 gathered entries each), shuffle reduce
+constexpr int ROW_LANES = 8;
+__global__ void __launch_bounds__(256) gather_rows_kernel(SparseRowsDev R, const double* __restrict__ src,
+                                                          double* __restrict__ dst) {
+    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t i = gid / ROW_LANES;
+    int sub = gid % ROW_LANES;
+    double s = 0;
+    if (i < R.nrows)
+        for (uint32_t p = R.ptr[i] + sub, e = R.ptr[i + 1]; p < e; p += ROW_LANES)
+            s += R.coef[p] * src[R.idx[p]];
+    for (int off = ROW_LANES / 2; off > 0; off >>= 1) s += __shfl_down(s, off, ROW_LANES);
+    if (i < R.nrows && sub == 0) dst[i] = s;
 }
 
-__global__ void assemble_kernel(AssemblyDev A, const double* __restrict__ jac,
-                                double* __restrict__ val) {
-    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < A.nslots) val[s] = assemble_slot(A, jac, s);
+// CSR assembly: ROW_LANES lanes per non-zero (~25 contributions each)
+__global__ void __launch_bounds__(256) assemble_kernel(AssemblyDev A, const double* __restrict__ jac,
+                                                       double* __restrict__ val) {
+    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t s = gid / ROW_LANES;
+    int sub = gid % ROW_LANES;
+    double v = 0;
+    if (s < A.nslots)
+        for (uint32_t p = A.ptr[s] + sub, e = A.ptr[s + 1]; p < e; p += ROW_LANES) {
+            double c = A.coef[p] * jac[A.jidx[p]];
+            if (fabs(c) >= 1e-9) v += c;  // libsanm/sparse_solver.cpp:291-293
+        }
+    for (int off = ROW_LANES / 2; off > 0; off >>= 1) v += __shfl_down(v, off, ROW_LANES);
+    if (s < A.nslots && sub == 0) val[s] = v;
 }
 
 constexpr int SPMV_LANES = 8;
@@ -117,6 +136,37 @@ __global__ void axpby_kernel(size_t n, double a, const double* x, double b, cons
                              double* out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = b == 0.0 ? a * x[i] : a * x[i] + b * y[i];
+}
+
+constexpr int MAX_VEC = 24;
+struct VecList {
+    const double* p[MAX_VEC];
+    double c[MAX_VEC];
+    int n;
+};
+__global__ void lincomb_kernel(size_t n, VecList v, double* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double acc = 0;
+    for (int j = 0; j < v.n; ++j) acc += v.c[j] * v.p[j][i];
+    out[i] = acc;
+}
+// out[j] += x . ys[j]; x is read once per element
+__global__ void __launch_bounds__(256) multi_dot_kernel(size_t n, const double* __restrict__ x, VecList v,
+                                                        double* out) {
+    double acc[MAX_VEC];
+    for (int j = 0; j < MAX_VEC; ++j) acc[j] = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        double xi = x[i];
+#pragma unroll
+        for (int j = 0; j < MAX_VEC; ++j)
+            if (j < v.n) acc[j] += xi * v.p[j][i];
+    }
+    for (int j = 0; j < v.n; ++j) {
+        block_reduce_commit<false>(acc[j], out + j);
+        __syncthreads();
+    }
 }
 
 __global__ void vmul_kernel(size_t n, const double* x, const double* y, double* out) {
@@ -275,6 +325,11 @@ class HipBackend final : public Backend {
     PcgScalars* m_pcg_sc = nullptr;
     PcgScalars* m_pcg_sc_host = nullptr;
     size_t m_pcg_n = 0;
+    bool m_time_passes = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> m_pass_events;
+    double* m_pool = nullptr;
+    double* m_pool_host = nullptr;
+    int m_pool_next = 0;
 
 public:
     explicit HipBackend(int device) {
@@ -293,6 +348,8 @@ public:
     }
     ~HipBackend() override {
         (void)hipFree(m_scalar);
+        if (m_pool) (void)hipFree(m_pool);
+        if (m_pool_host) (void)hipHostFree(m_pool_host);
         for (double* w : m_pcg_w)
             if (w) (void)hipFree(w);
         if (m_pcg_sc) (void)hipFree(m_pcg_sc);
@@ -332,18 +389,47 @@ public:
     hipStream_t stream() const { return m_stream; }
 
     void run_pass(const ProgramDev& P, int mode, int order, const double* xvec) override {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (m_time_passes) {
+            HIP_CHECK(hipEventCreate(&e0));
+            HIP_CHECK(hipEventCreate(&e1));
+            HIP_CHECK(hipEventRecord(e0, m_stream));
+        }
         hipLaunchKernelGGL(taylor_pass_kernel, dim3(nblk(P.T, 64)), dim3(64), 0, m_stream, P, mode,
                            order, xvec);
         HIP_CHECK(hipGetLastError());
+        if (m_time_passes) {
+            HIP_CHECK(hipEventRecord(e1, m_stream));
+            m_pass_events.emplace_back(e0, e1);
+        }
+    }
+    void enable_pass_timing(bool on) override {
+        for (auto& ev : m_pass_events) {
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
+        m_pass_events.clear();
+        m_time_passes = on;
+    }
+    void pass_timing(double* total_ms, int64_t* count) override {
+        HIP_CHECK(hipStreamSynchronize(m_stream));
+        double tot = 0;
+        for (auto& ev : m_pass_events) {
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, ev.first, ev.second));
+            tot += ms;
+        }
+        *total_ms = tot;
+        *count = m_pass_events.size();
     }
     void gather_rows(const SparseRowsDev& R, const double* src, double* dst) override {
-        hipLaunchKernelGGL(gather_rows_kernel, dim3(nblk(R.nrows, 64)), dim3(64), 0, m_stream, R,
-                           src, dst);
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(nblk((size_t)R.nrows * ROW_LANES, 256)), dim3(256), 0,
+                           m_stream, R, src, dst);
         HIP_CHECK(hipGetLastError());
     }
     void assemble(const AssemblyDev& A, const double* jac, double* val) override {
-        hipLaunchKernelGGL(assemble_kernel, dim3(nblk(A.nslots, 256)), dim3(256), 0, m_stream, A,
-                           jac, val);
+        hipLaunchKernelGGL(assemble_kernel, dim3(nblk((size_t)A.nslots * ROW_LANES, 256)), dim3(256), 0,
+                           m_stream, A, jac, val);
         HIP_CHECK(hipGetLastError());
     }
     void spmv(const CsrDev& A, const double* x, double* y) override {
@@ -414,6 +500,7 @@ public:
         HIP_CHECK(hipMemsetAsync(mf.status, 0, sizeof(int32_t), m_stream));
         hipLaunchKernelGGL(scatter_kernel, dim3(nblk(mf.nnzA, 256)), dim3(256), 0, m_stream, mf.nnzA,
                            mf.a_dst, A.val, mf.front_store);
+        hipLaunchKernelGGL(aug_identity_kernel, dim3(nblk(mf.n, 256)), dim3(256), 0, m_stream, mf);
         for (const auto& L : sch.levels) {
             for (size_t r = 0; r < L.ea_rounds.size(); ++r) {
                 int cnt = L.ea_rounds[r].second - L.ea_rounds[r].first;
@@ -422,7 +509,7 @@ public:
                 hipLaunchKernelGGL(extend_add_kernel, dim3(nblk(mb * mb, 256), cnt), dim3(256), 0,
                                    m_stream, mf, sch.ea_children + L.ea_rounds[r].first);
             }
-            const int nt = (L.max_m + NB - 1) / NB;
+            const int nt = (L.max_m + L.max_k + NB - 1) / NB;  // augmented extent
             for (int p = 0; p < L.nr_panel; ++p) {
                 const int cnt = L.panel_cnt[p];
                 hipLaunchKernelGGL(diag_kernel, dim3(cnt), dim3(256), 0, m_stream, mf, L.front_begin, p);
@@ -446,22 +533,20 @@ public:
         using namespace mfk;
         hipLaunchKernelGGL(permute_in_kernel, dim3(nblk(mf.n, 256)), dim3(256), 0, m_stream, mf.n,
                            mf.perm, b, mf.work);
-        for (const auto& L : sch.levels) {
+        for (size_t li = 0; li < sch.levels.size(); ++li) {
+            const auto& L = sch.levels[li];
             const int cnt = L.front_end - L.front_begin;
-            hipLaunchKernelGGL(fwd_own_kernel, dim3(cnt), dim3(256), (size_t)L.max_k * sizeof(double),
-                               m_stream, mf, L.front_begin);
-            if (L.max_b > 0)
-                hipLaunchKernelGGL(fwd_bnd_kernel, dim3((L.max_b + 3) / 4, cnt), dim3(256), 0, m_stream,
-                                   mf, L.front_begin);
+            if (li > 0)  // leaves have no children to gather from
+                hipLaunchKernelGGL(fwd_gather_kernel, dim3((L.max_k + 255) / 256, cnt), dim3(256), 0,
+                                   m_stream, mf, L.front_begin);
+            hipLaunchKernelGGL(fwd_mv_kernel, dim3((L.max_m + 3) / 4, cnt), dim3(256), 0, m_stream, mf,
+                               L.front_begin);
         }
         for (int li = (int)sch.levels.size() - 1; li >= 0; --li) {
             const auto& L = sch.levels[li];
             const int cnt = L.front_end - L.front_begin;
-            if (L.max_b > 0)
-                hipLaunchKernelGGL(bwd_bnd_kernel, dim3((L.max_k + 3) / 4, cnt), dim3(256), 0, m_stream,
-                                   mf, L.front_begin);
-            hipLaunchKernelGGL(bwd_own_kernel, dim3(cnt), dim3(256), (size_t)L.max_k * sizeof(double),
-                               m_stream, mf, L.front_begin);
+            hipLaunchKernelGGL(bwd_mv_kernel, dim3((L.max_k + 3) / 4, cnt), dim3(256), 0, m_stream, mf,
+                               L.front_begin);
         }
         hipLaunchKernelGGL(permute_out_kernel, dim3(nblk(mf.n, 256)), dim3(256), 0, m_stream, mf.n,
                            mf.perm, mf.work, x);
@@ -511,17 +596,63 @@ public:
                                  m_stream));
     }
 
+    // pre-zeroed accumulator slots: one memset per POOL_SLOTS reductions instead of
+    // one per reduction
+    static constexpr int POOL_SLOTS = 4096;
+    double* take_slots(int cnt) {
+        if (!m_pool) {
+            HIP_CHECK(hipMalloc(&m_pool, POOL_SLOTS * sizeof(double)));
+            HIP_CHECK(hipHostMalloc(&m_pool_host, 64 * sizeof(double)));
+            m_pool_next = POOL_SLOTS;
+        }
+        if (m_pool_next + cnt > POOL_SLOTS) {
+            HIP_CHECK(hipMemsetAsync(m_pool, 0, POOL_SLOTS * sizeof(double), m_stream));
+            m_pool_next = 0;
+        }
+        double* r = m_pool + m_pool_next;
+        m_pool_next += cnt;
+        return r;
+    }
     double dot(size_t n, const double* x, const double* y) override {
-        HIP_CHECK(hipMemsetAsync(m_scalar, 0, sizeof(double), m_stream));
-        hipLaunchKernelGGL(dot_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, y, m_scalar);
+        double* slot = take_slots(1);
+        hipLaunchKernelGGL(dot_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, y, slot);
         HIP_CHECK(hipGetLastError());
-        return fetch_scalar();
+        HIP_CHECK(hipMemcpyAsync(m_pool_host, slot, sizeof(double), hipMemcpyDeviceToHost, m_stream));
+        HIP_CHECK(hipStreamSynchronize(m_stream));
+        return *m_pool_host;
     }
     void axpby(size_t n, double a, const double* x, double b, const double* y,
                double* out) override {
         hipLaunchKernelGGL(axpby_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, a, x, b, y,
                            out);
         HIP_CHECK(hipGetLastError());
+    }
+    void lincomb(size_t n, int nvec, const double* const* ptrs, const double* coefs,
+                 double* out) override {
+        if (nvec > MAX_VEC) sanm_throw(SANM_ERR_ASSERT, "lincomb: too many vectors");
+        VecList v{};
+        v.n = nvec;
+        for (int j = 0; j < nvec; ++j) {
+            v.p[j] = ptrs[j];
+            v.c[j] = coefs[j];
+        }
+        hipLaunchKernelGGL(lincomb_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, v, out);
+        HIP_CHECK(hipGetLastError());
+    }
+    void multi_dot(size_t n, const double* x, int nvec, const double* const* ys,
+                   double* out_host) override {
+        if (nvec > MAX_VEC) sanm_throw(SANM_ERR_ASSERT, "multi_dot: too many vectors");
+        if (nvec == 0) return;
+        VecList v{};
+        v.n = nvec;
+        for (int j = 0; j < nvec; ++j) v.p[j] = ys[j];
+        double* slots = take_slots(nvec);
+        hipLaunchKernelGGL(multi_dot_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, slots);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(m_pool_host, slots, nvec * sizeof(double), hipMemcpyDeviceToHost,
+                                 m_stream));
+        HIP_CHECK(hipStreamSynchronize(m_stream));
+        for (int j = 0; j < nvec; ++j) out_host[j] = m_pool_host[j];
     }
     void vmul(size_t n, const double* x, const double* y, double* out) override {
         hipLaunchKernelGGL(vmul_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, x, y, out);

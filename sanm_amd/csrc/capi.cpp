@@ -403,6 +403,13 @@ int sanm_anm_time_kernel(sanm_anm_solver* s, int kernel, int reps, int mode, int
         *avg_ms = d.backend()->time_kernel(kernel, reps, &P, mode, order, &A, x, d.scratch_dev(0));
     });
 }
+int sanm_anm_pass_timing(sanm_anm_solver* s, int enable, double* total_ms, int64_t* count) {
+    return guard([&] {
+        Backend* be = s->drv->backend();
+        if (total_ms && count) be->pass_timing(total_ms, count);
+        be->enable_pass_timing(enable != 0);
+    });
+}
 int sanm_anm_update_approx(sanm_anm_solver* s) {
     return guard([&] { s->drv->update_approx(); });
 }

@@ -9,9 +9,12 @@ namespace sanm_hip {
 constexpr int MF_NB = 32;  // panel / tile width
 
 struct MfFrontDev {
-    int64_t off;        // offset of the dense m*m front (row-major) in the front storage
+    int64_t off;        // offset of the dense ld*ld augmented front (row-major) in the front storage
     int64_t dinv_off;   // offset of the inverted diagonal blocks: per panel [Linv | Uinv], NB*NB each
     int32_t k, m;       // pivots, front size
+    int32_t ld;         // m + k: the front is augmented by k identity columns / rows, so that
+                        // the elimination leaves  F[0:k, m:]  = L11^-1,  F[k:m, m:] = -L21 L11^-1,
+                        //                         F[m:, 0:k]  = U11^-1,  F[m:, k:m] = -U11^-1 U12
     int32_t own_start;  // first own variable (new numbering)
     int32_t bnd_off;    // offset into bnd_idx (m-k entries, new numbering, ascending)
     int32_t parent;     // -1 for roots
@@ -31,6 +34,7 @@ struct MfDev {
     const int32_t* gat_ptr;       // per front row: range of gat_src
     const int32_t* gat_src;       // indices into the update-vector workspace
     const int32_t* perm;          // original -> new numbering
+    const int32_t* own_front;     // new index -> owning front (identity init of the augmentation)
     // scatter of A: front_store[a_dst[p]] = A.val[p]
     const int64_t* a_dst;
     // extend-add: child lists per level and round
@@ -38,6 +42,7 @@ struct MfDev {
     double* dinv_store;
     double* upd_store;            // solve workspace: concatenated update vectors
     double* work;                 // n doubles (permuted rhs / solution)
+    double* work2;                // n doubles (forward-solved vector z)
     int32_t* status;              // [0]: number of bad pivots
     int64_t front_store_size, dinv_store_size, upd_store_size;
 };

@@ -434,10 +434,11 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
         int32_t b = bnd_idx.size() - fr[f].bnd_off;
         fr[f].k = kf[f];
         fr[f].m = kf[f] + b;
+        fr[f].ld = fr[f].m + fr[f].k;
         fr[f].own_start = own_start[f];
         fr[f].parent = parent[f];
         fr[f].off = off;
-        off += (int64_t)fr[f].m * fr[f].m;
+        off += (int64_t)fr[f].ld * fr[f].ld;
         fr[f].dinv_off = doff;
         doff += (int64_t)((fr[f].k + MF_NB - 1) / MF_NB) * 2 * MF_NB * MF_NB;
         fr[f].rel_off = fr[f].bnd_off;  // rel is parallel to bnd_idx
@@ -449,7 +450,8 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
         if (parent[f] < 0) root_pivots = std::max(root_pivots, fr[f].k);
         double k = fr[f].k, bb = b;
         nnz_factors += (int64_t)(k * k + 2 * k * bb);
-        factor_flops += 2.0 / 3 * k * k * k + 2 * k * k * bb + 2 * k * bb * bb;
+        // LU of the front plus the row / column operations on the augmentation
+        factor_flops += 2.0 / 3 * k * k * k + 2 * k * k * bb + 2 * k * bb * bb + 2 * k * k * (k + bb);
     }
     front_doubles = off;
 
@@ -510,7 +512,7 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
         for (uint32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
             int32_t pi = perm[i], pj = perm[col[p]];
             int32_t f = owner[std::min(pi, pj)];
-            a_dst[p] = fr[f].off + (int64_t)pos_in_front(f, pi) * fr[f].m + pos_in_front(f, pj);
+            a_dst[p] = fr[f].off + (int64_t)pos_in_front(f, pi) * fr[f].ld + pos_in_front(f, pj);
         }
 
     // levels: fronts by height, by decreasing k inside a level
@@ -566,6 +568,7 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     m_dev.gat_ptr = upload(gat_ptr);
     m_dev.gat_src = upload(gat_src);
     m_dev.perm = upload(perm);
+    m_dev.own_front = upload(owner);
     m_dev.a_dst = upload(a_dst);
     m_sched.ea_children = upload(ea_children);
     m_dev.front_store_size = off;
@@ -575,6 +578,8 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     m_dev.dinv_store = static_cast<double*>(be->alloc(std::max<int64_t>(doff, 1) * sizeof(double)));
     m_dev.upd_store = static_cast<double*>(be->alloc(m_dev.upd_store_size * sizeof(double)));
     m_dev.work = static_cast<double*>(be->alloc(n * sizeof(double)));
+    m_dev.work2 = static_cast<double*>(be->alloc(n * sizeof(double)));
+    m_bufs.push_back(m_dev.work2);
     m_dev.status = static_cast<int32_t*>(be->alloc(64));
     be->zero(m_dev.status, 64);
     m_bufs.push_back(m_dev.front_store);

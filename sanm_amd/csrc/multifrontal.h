@@ -17,10 +17,13 @@
 //     processed by the same kernel launches;
 //   * factor: scatter A, extend-add the children's Schur complements, blocked
 //     right-looking LU of the leading k columns (NB x NB diagonal blocks are
-//     inverted so panel solves become small GEMMs);
-//   * solve: forward sweep up the tree, backward sweep down, two launches per
-//     level and direction (triangular part: one workgroup per front; the
-//     rectangular L21 / U12 products: row tiles spread over workgroups).
+//     inverted so panel solves become small GEMMs).  Each front carries k
+//     extra identity columns and rows; the same row/column operations turn
+//     them into L11^-1, -L21 L11^-1, U11^-1 and -U11^-1 U12;
+//   * solve: with those blocks every level of the forward (resp. backward)
+//     sweep is one dense mat-vec per front, all rows in parallel: the `order`
+//     sequential solves of an ANM step are launch- and bandwidth-bound instead
+//     of being chains of dependent triangular substitutions.
 // The forward-FEA Jacobian is minus a Hessian (definite at stable states), so
 // unpivoted LU is stable there; tiny pivots are detected and reported.
 #pragma once

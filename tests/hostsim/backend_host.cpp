@@ -112,22 +112,22 @@ struct HostMf {
                     int nb = c.m - c.k;
                     for (int i = 0; i < nb; ++i)
                         for (int j = 0; j < nb; ++j)
-                            mf.front_store[p.off + (int64_t)rel[i] * p.m + rel[j]] +=
-                                    mf.front_store[c.off + (int64_t)(c.k + i) * c.m + c.k + j];
+                            mf.front_store[p.off + (int64_t)rel[i] * p.ld + rel[j]] +=
+                                    mf.front_store[c.off + (int64_t)(c.k + i) * c.ld + c.k + j];
                 }
             for (int32_t q = L.front_begin; q < L.front_end; ++q) {
                 const MfFrontDev& f = mf.fronts[mf.level_fronts[q]];
                 double* F = mf.front_store + f.off;
-                const int m = f.m;
+                const int m = f.m, ld = f.ld;
                 for (int j = 0; j < f.k; ++j) {
-                    double piv = F[(int64_t)j * m + j];
-                    if (!(std::fabs(piv) > 1e-300)) ++bad;
+                    double piv = F[(int64_t)j * ld + j];
+                    if (!(std::fabs(piv) > 1e-290)) ++bad;
                     double inv = 1.0 / piv;
                     for (int i = j + 1; i < m; ++i) {
-                        double l = F[(int64_t)i * m + j] * inv;
-                        F[(int64_t)i * m + j] = l;
+                        double l = F[(int64_t)i * ld + j] * inv;
+                        F[(int64_t)i * ld + j] = l;
                         if (l != 0)
-                            for (int c2 = j + 1; c2 < m; ++c2) F[(int64_t)i * m + c2] -= l * F[(int64_t)j * m + c2];
+                            for (int c2 = j + 1; c2 < m; ++c2) F[(int64_t)i * ld + c2] -= l * F[(int64_t)j * ld + c2];
                     }
                 }
             }
@@ -151,12 +151,12 @@ struct HostMf {
                     for (int32_t s = gp[r]; s < gp[r + 1]; ++s) t[r] += mf.upd_store[mf.gat_src[s]];
                 for (int r = 0; r < k; ++r) {  // unit lower L11
                     double v = t[r];
-                    for (int c2 = 0; c2 < r; ++c2) v -= F[(int64_t)r * m + c2] * t[c2];
+                    for (int c2 = 0; c2 < r; ++c2) v -= F[(int64_t)r * f.ld + c2] * t[c2];
                     t[r] = v;
                 }
                 for (int r = k; r < m; ++r) {
                     double v = t[r];
-                    for (int c2 = 0; c2 < k; ++c2) v -= F[(int64_t)r * m + c2] * t[c2];
+                    for (int c2 = 0; c2 < k; ++c2) v -= F[(int64_t)r * f.ld + c2] * t[c2];
                     mf.upd_store[f.upd_off + r - k] = v;
                 }
                 for (int r = 0; r < k; ++r) w[f.own_start + r] = t[r];
@@ -170,9 +170,9 @@ struct HostMf {
                 const int32_t* bi = mf.bnd_idx + f.bnd_off;
                 for (int r = k - 1; r >= 0; --r) {
                     double v = w[f.own_start + r];
-                    for (int c2 = k; c2 < m; ++c2) v -= F[(int64_t)r * m + c2] * w[bi[c2 - k]];
-                    for (int c2 = r + 1; c2 < k; ++c2) v -= F[(int64_t)r * m + c2] * w[f.own_start + c2];
-                    w[f.own_start + r] = v / F[(int64_t)r * m + r];
+                    for (int c2 = k; c2 < m; ++c2) v -= F[(int64_t)r * f.ld + c2] * w[bi[c2 - k]];
+                    for (int c2 = r + 1; c2 < k; ++c2) v -= F[(int64_t)r * f.ld + c2] * w[f.own_start + c2];
+                    w[f.own_start + r] = v / F[(int64_t)r * f.ld + r];
                 }
             }
         }
