@@ -37,10 +37,13 @@ namespace sanm_hip {
 
 namespace {
 
+// The current-order values travel from operator to operator through LDS
+// (cur_size doubles per lane, lane-interleaved: conflict-free), not through HBM.
 __global__ void __launch_bounds__(64) taylor_pass_kernel(ProgramDev P, int mode, int order,
                                                          const double* __restrict__ xvec) {
+    extern __shared__ double cur_lds[];
     int64_t tet = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tet < P.T) exec_program_tet(P, mode, order, tet, xvec);
+    if (tet < P.T) exec_program_tet(P, mode, order, tet, xvec, cur_lds + threadIdx.x, 64);
 }
 
 // remap_out: ROW_LANES lanes per output row (~45 gathered entries each), shuffle reduce
@@ -326,6 +329,7 @@ class HipBackend final : public Backend {
     PcgScalars* m_pcg_sc_host = nullptr;
     size_t m_pcg_n = 0;
     bool m_time_passes = false;
+    size_t m_pass_lds_limit = 48 * 1024;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> m_pass_events;
     double* m_pool = nullptr;
     double* m_pool_host = nullptr;
@@ -395,7 +399,14 @@ public:
             HIP_CHECK(hipEventCreate(&e1));
             HIP_CHECK(hipEventRecord(e0, m_stream));
         }
-        hipLaunchKernelGGL(taylor_pass_kernel, dim3(nblk(P.T, 64)), dim3(64), 0, m_stream, P, mode,
+        const size_t lds = (size_t)P.cur_size * 64 * sizeof(double);
+        if (lds > 160 * 1024) sanm_throw(SANM_ERR_UNSUPPORTED, "graph too large for the LDS scratch");
+        if (lds > m_pass_lds_limit) {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(taylor_pass_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            m_pass_lds_limit = lds;
+        }
+        hipLaunchKernelGGL(taylor_pass_kernel, dim3(nblk(P.T, 64)), dim3(64), lds, m_stream, P, mode,
                            order, xvec);
         HIP_CHECK(hipGetLastError());
         if (m_time_passes) {
@@ -561,8 +572,8 @@ public:
         if (kernel == 2 && !m_pcg_sc) HIP_CHECK(hipMalloc(&m_pcg_sc, sizeof(PcgScalars)));
         auto launch = [&]() {
             if (kernel == 0) {
-                hipLaunchKernelGGL(taylor_pass_kernel, dim3(nblk(P->T, 64)), dim3(64), 0, m_stream,
-                                   *P, mode, order, x);
+                hipLaunchKernelGGL(taylor_pass_kernel, dim3(nblk(P->T, 64)), dim3(64),
+                                   (size_t)P->cur_size * 64 * sizeof(double), m_stream, *P, mode, order, x);
             } else if (kernel == 1) {
                 hipLaunchKernelGGL(spmv_kernel, dim3(nblk((size_t)A->n * SPMV_LANES, 256)),
                                    dim3(256), 0, m_stream, *A, x, y);

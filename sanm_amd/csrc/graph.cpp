@@ -241,6 +241,11 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
         d.coef = take((int64_t)(d.is_const ? 1 : N + 1) * d.size * Tpad);
         d.bias = take((int64_t)d.size * Tpad);
     }
+    int32_t cur_size = 0;
+    for (auto& d : m_vars) {
+        d.cur = cur_size;
+        if (!d.is_const) cur_size += d.size;
+    }
     m_jac_begin = off;
     for (auto& d : m_vars)
         if (!d.is_const) d.jac = take((int64_t)odim * d.size * Tpad);
@@ -339,6 +344,7 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
     m_dev.out_var = lout;
     m_dev.odim = odim;
     m_dev.max_order = N;
+    m_dev.cur_size = cur_size;
     m_dev.T = T;
     m_dev.Tpad = Tpad;
     m_dev.rin = {nullptr, nullptr, 0};

@@ -48,6 +48,8 @@ struct VarDesc {
     int64_t jac;   // arena offset of the Jacobian [odim][size][Tpad]; -1 if none
     int32_t size;  // 1 (batched scalar), 3 (singular values) or 9 (3x3)
     int32_t is_const;  // coefficients of order >= 1 are identically zero
+    int32_t cur;       // offset (in doubles) of the current-order value in the per-lane scratch
+    int32_t pad_;
 };
 
 struct OpDesc {
@@ -75,6 +77,7 @@ struct ProgramDev {
     int32_t out_var;   // the graph output (3x3)
     int32_t odim;      // size of the output var (9)
     int32_t max_order;
+    int32_t cur_size;  // doubles of per-lane scratch (sum of the sizes of the non-constant vars)
     int64_t T, Tpad;
     RemapInDev rin;
 };

@@ -33,6 +33,13 @@ struct TetCtx {
     int64_t tet;
     int32_t order;  // current order k (BIAS / COEFF passes)
     int32_t odim;
+    // "current" values of the pass being run (the order-k bias in a BIAS pass, the
+    // order-k coefficient in a COEFF pass) are forwarded from operator to operator
+    // through a per-lane scratch (LDS on the device) instead of a store->load round
+    // trip through HBM: element e of variable v at cur[(vars[v].cur + e) * cur_stride]
+    double* cur;
+    int64_t cur_stride;
+    int32_t out_var;
 };
 
 // ---------------------------------------------------------------- access --
@@ -272,6 +279,20 @@ SANM_HD_NOINLINE void svdw_fwd_p3(const double* Mk, const double* U0, const doub
 // broadcast helper: value c of a var of size sz (scalar -> all elements)
 SANM_HD double bval(const double* p, int64_t s, int sz, int c) { return sz == 1 ? p[0] : p[c * s]; }
 
+// ---- access to the current-order values (see TetCtx::cur)
+SANM_HD double* p_curv(const TetCtx& c, int v) { return c.cur + (int64_t)c.vars[v].cur * c.cur_stride; }
+SANM_HD void ld_cur(const TetCtx& c, int v, int n, double* m) { ld(p_curv(c, v), c.cur_stride, n, m); }
+SANM_HD double cur_bval(const TetCtx& c, int v, int sz, int e) {
+    return bval(p_curv(c, v), c.cur_stride, sz, e);
+}
+// publish the current value of v: scratch always; HBM when it is history for later
+// orders (COEFF pass) or the graph output read by the remap_out kernel (BIAS pass)
+SANM_HD void st_cur(const TetCtx& c, int v, int n, const double* m, bool in_coeff) {
+    st(p_curv(c, v), c.cur_stride, n, m);
+    if (in_coeff) st(p_coef(c, v, c.order), c.Tpad, n, m);
+    else if (v == c.out_var) st(p_bias(c, v), c.Tpad, n, m);
+}
+
 // jac accumulate:  in.jac[r][ci] += v
 SANM_HD void jadd(const TetCtx& c, int v, int r, int ci, double val) {
     double* p = p_jac(c, v) + ((int64_t)r * c.vars[v].size + ci) * c.Tpad;
@@ -303,15 +324,23 @@ SANM_HD void op_lincomb(const TetCtx& c, const OpDesc& o, int mode) {
         return;
     }
     double acc[9];
-    const bool ev0 = mode == PASS_EVAL0, in_coeff = mode == PASS_COEFF;
-    for (int e = 0; e < osz; ++e) acc[e] = ev0 ? o.p[MAX_OP_IN] : 0.0;
+    if (mode == PASS_EVAL0) {
+        for (int e = 0; e < osz; ++e) acc[e] = o.p[MAX_OP_IN];
+        for (int k = 0; k < o.nin; ++k) {
+            int iv = o.in[k], isz = c.vars[iv].size;
+            const double* p = p_coef(c, iv, 0);
+            for (int e = 0; e < osz; ++e) acc[e] += o.p[k] * bval(p, s, isz, e);
+        }
+        st(p_coef(c, ov, 0), s, osz, acc);
+        return;
+    }
+    for (int e = 0; e < osz; ++e) acc[e] = 0.0;
     for (int k = 0; k < o.nin; ++k) {
         int iv = o.in[k], isz = c.vars[iv].size;
-        if (!ev0 && c.vars[iv].is_const) continue;
-        const double* p = ev0 ? p_coef(c, iv, 0) : p_cur(c, iv, in_coeff);
-        for (int e = 0; e < osz; ++e) acc[e] += o.p[k] * bval(p, s, isz, e);
+        if (c.vars[iv].is_const) continue;
+        for (int e = 0; e < osz; ++e) acc[e] += o.p[k] * cur_bval(c, iv, isz, e);
     }
-    st(ev0 ? p_coef(c, ov, 0) : p_cur(c, ov, in_coeff), s, osz, acc);
+    st_cur(c, ov, osz, acc, mode == PASS_COEFF);
 }
 
 // ---- MULTIPLY: elem_arith.cpp:128-217   aux0 = self_bias[osz]
@@ -348,27 +377,34 @@ SANM_HD void op_multiply(const TetCtx& c, const OpDesc& o, int mode) {
     double sb[9];
     double* psb = p_aux(c, o.aux[0]);
     if (!in_coeff) {
-        for (int e = 0; e < osz; ++e) sb[e] = 0;
+        double sb2[9];
+        for (int e = 0; e < osz; ++e) sb[e] = sb2[e] = 0;
         if (!c.vars[a].is_const && !c.vars[b].is_const) {
-            for (int i = 1; i < c.order; ++i) {
+            int i = 1;
+            for (; i + 1 < c.order; i += 2) {  // two independent terms in flight
+                const double *pa = p_coef(c, a, i), *pb = p_coef(c, b, c.order - i);
+                const double *pa2 = p_coef(c, a, i + 1), *pb2 = p_coef(c, b, c.order - i - 1);
+                for (int e = 0; e < osz; ++e) {
+                    sb[e] += bval(pa, s, asz, e) * bval(pb, s, bsz, e);
+                    sb2[e] += bval(pa2, s, asz, e) * bval(pb2, s, bsz, e);
+                }
+            }
+            for (; i < c.order; ++i) {
                 const double *pa = p_coef(c, a, i), *pb = p_coef(c, b, c.order - i);
                 for (int e = 0; e < osz; ++e) sb[e] += bval(pa, s, asz, e) * bval(pb, s, bsz, e);
             }
+            for (int e = 0; e < osz; ++e) sb[e] += sb2[e];
         }
         st(psb, s, osz, sb);
     } else {
         ld(psb, s, osz, sb);
     }
     const double *a0 = p_coef(c, a, 0), *b0 = p_coef(c, b, 0);
-    if (!c.vars[b].is_const) {
-        const double* bk = p_cur(c, b, in_coeff);
-        for (int e = 0; e < osz; ++e) sb[e] += bval(a0, s, asz, e) * bval(bk, s, bsz, e);
-    }
-    if (!c.vars[a].is_const) {
-        const double* ak = p_cur(c, a, in_coeff);
-        for (int e = 0; e < osz; ++e) sb[e] += bval(ak, s, asz, e) * bval(b0, s, bsz, e);
-    }
-    st(p_cur(c, ov, in_coeff), s, osz, sb);
+    if (!c.vars[b].is_const)
+        for (int e = 0; e < osz; ++e) sb[e] += bval(a0, s, asz, e) * cur_bval(c, b, bsz, e);
+    if (!c.vars[a].is_const)
+        for (int e = 0; e < osz; ++e) sb[e] += cur_bval(c, a, asz, e) * bval(b0, s, bsz, e);
+    st_cur(c, ov, osz, sb, in_coeff);
 }
 
 // ---- LOG / POW: oprs/analytic_unary.cpp:113-158, analytic_unary.cpp:13-139
@@ -428,11 +464,9 @@ SANM_HD void op_unary(const TetCtx& c, const OpDesc& o, int mode) {
     } else {
         ld(psb, s, sz, sb);
     }
-    if (!c.vars[x].is_const) {
-        const double* xk = p_cur(c, x, in_coeff);
-        for (int e = 0; e < sz; ++e) sb[e] += pk[e * s] * xk[e * s];
-    }
-    st(p_cur(c, ov, in_coeff), s, sz, sb);
+    if (!c.vars[x].is_const)
+        for (int e = 0; e < sz; ++e) sb[e] += pk[e * s] * cur_bval(c, x, sz, e);
+    st_cur(c, ov, sz, sb, in_coeff);
 }
 
 // ---- REDUCE_SUM axis=-1: oprs/reduce.cpp:11-102
@@ -447,12 +481,16 @@ SANM_HD void op_reduce(const TetCtx& c, const OpDesc& o, int mode) {
         }
         return;
     }
-    const bool ev0 = mode == PASS_EVAL0, in_coeff = mode == PASS_COEFF;
-    const double* p = ev0 ? p_coef(c, x, 0) : p_cur(c, x, in_coeff);
     double sum = 0;
-    if (ev0 || !c.vars[x].is_const)
+    if (mode == PASS_EVAL0) {
+        const double* p = p_coef(c, x, 0);
         for (int e = 0; e < isz; ++e) sum += p[e * s];
-    *(ev0 ? p_coef(c, ov, 0) : p_cur(c, ov, in_coeff)) = sum;
+        *p_coef(c, ov, 0) = sum;
+        return;
+    }
+    if (!c.vars[x].is_const)
+        for (int e = 0; e < isz; ++e) sum += cur_bval(c, x, isz, e);
+    st_cur(c, ov, 1, &sum, mode == PASS_COEFF);
 }
 
 // ---- MATMUL: oprs/linalg.cpp:339-418   aux0 = self_bias[9]
@@ -487,29 +525,40 @@ SANM_HD void op_matmul(const TetCtx& c, const OpDesc& o, int mode) {
     const bool in_coeff = mode == PASS_COEFF;
     double* psb = p_aux(c, o.aux[0]);
     if (!in_coeff) {
-        for (int e = 0; e < 9; ++e) R[e] = 0;
+        double R2[9], A2[9], B2[9];
+        for (int e = 0; e < 9; ++e) R[e] = R2[e] = 0;
         if (!c.vars[a].is_const && !c.vars[b].is_const) {
-            for (int i = 1; i < c.order; ++i) {
+            int i = 1;
+            for (; i + 1 < c.order; i += 2) {
+                ld9(p_coef(c, a, i), s, A);
+                ld9(p_coef(c, b, c.order - i), s, B);
+                ld9(p_coef(c, a, i + 1), s, A2);
+                ld9(p_coef(c, b, c.order - i - 1), s, B2);
+                mm3<false, false, true>(R, A, B);
+                mm3<false, false, true>(R2, A2, B2);
+            }
+            for (; i < c.order; ++i) {
                 ld9(p_coef(c, a, i), s, A);
                 ld9(p_coef(c, b, c.order - i), s, B);
                 mm3<false, false, true>(R, A, B);
             }
+            for (int e = 0; e < 9; ++e) R[e] += R2[e];
         }
         st9(psb, s, R);
     } else {
         ld9(psb, s, R);
     }
     if (!c.vars[a].is_const) {
-        ld9(p_cur(c, a, in_coeff), s, A);
+        ld_cur(c, a, 9, A);
         ld9(p_coef(c, b, 0), s, B);
         mm3<false, false, true>(R, A, B);
     }
     if (!c.vars[b].is_const) {
         ld9(p_coef(c, a, 0), s, A);
-        ld9(p_cur(c, b, in_coeff), s, B);
+        ld_cur(c, b, 9, B);
         mm3<false, false, true>(R, A, B);
     }
-    st9(p_cur(c, ov, in_coeff), s, R);
+    st_cur(c, ov, 9, R, in_coeff);
 }
 
 // ---- MATINVMUL: oprs/linalg.cpp:67-217   aux0 = xinv[9], aux1 = self_bias[9]
@@ -559,9 +608,29 @@ SANM_HD void op_matinvmul(const TetCtx& c, const OpDesc& o, int mode) {
     }
     const bool in_coeff = mode == PASS_COEFF;
     if (!in_coeff) {
-        for (int e = 0; e < 9; ++e) R[e] = 0;
+        double R2[9], X2[9], Y2[9];
+        for (int e = 0; e < 9; ++e) R[e] = R2[e] = 0;
         if (!c.vars[x].is_const) {
-            for (int i = 1; i < c.order; ++i) {
+            // sum_{i=1}^{k-1} Y_i X_{k-i} (left) or X_i Y_{k-i}; two terms in flight
+            int i = 1;
+            for (; i + 1 < c.order; i += 2) {
+                if (is_left) {
+                    ld9(p_coef(c, ov, i), s, Y);
+                    ld9(p_coef(c, x, c.order - i), s, X);
+                    ld9(p_coef(c, ov, i + 1), s, Y2);
+                    ld9(p_coef(c, x, c.order - i - 1), s, X2);
+                    mm3<false, false, true>(R, Y, X);
+                    mm3<false, false, true>(R2, Y2, X2);
+                } else {
+                    ld9(p_coef(c, x, i), s, X);
+                    ld9(p_coef(c, ov, c.order - i), s, Y);
+                    ld9(p_coef(c, x, i + 1), s, X2);
+                    ld9(p_coef(c, ov, c.order - i - 1), s, Y2);
+                    mm3<false, false, true>(R, X, Y);
+                    mm3<false, false, true>(R2, X2, Y2);
+                }
+            }
+            for (; i < c.order; ++i) {
                 if (is_left) {
                     ld9(p_coef(c, ov, i), s, Y);
                     ld9(p_coef(c, x, c.order - i), s, X);
@@ -573,18 +642,18 @@ SANM_HD void op_matinvmul(const TetCtx& c, const OpDesc& o, int mode) {
                 }
             }
         }
-        for (int e = 0; e < 9; ++e) R[e] = -R[e];
+        for (int e = 0; e < 9; ++e) R[e] = -(R[e] + R2[e]);
         st9(psb, s, R);
     } else {
         ld9(psb, s, R);
     }
     if (!ident && !c.vars[av].is_const) {
-        ld9(p_cur(c, av, in_coeff), s, X);
+        ld_cur(c, av, 9, X);
         for (int e = 0; e < 9; ++e) R[e] += X[e];
     }
     if (!c.vars[x].is_const) {
         ld9(p_coef(c, ov, 0), s, Y);
-        ld9(p_cur(c, x, in_coeff), s, X);
+        ld_cur(c, x, 9, X);
         if (is_left) mm3<false, false, false>(Tm, Y, X);
         else mm3<false, false, false>(Tm, X, Y);
         for (int e = 0; e < 9; ++e) R[e] -= Tm[e];
@@ -592,7 +661,7 @@ SANM_HD void op_matinvmul(const TetCtx& c, const OpDesc& o, int mode) {
     ld9(pxinv, s, X);
     if (is_left) mm3<false, false, false>(Tm, R, X);
     else mm3<false, false, false>(Tm, X, R);
-    st9(p_cur(c, ov, in_coeff), s, Tm);
+    st_cur(c, ov, 9, Tm, in_coeff);
 }
 
 // ---- DET: oprs/linalg.cpp:221-282, tensor_polymat.cpp:344-379
@@ -637,7 +706,7 @@ SANM_HD void op_det(const TetCtx& c, const OpDesc& o, int mode) {
     const int k = c.order;
     double sb = 0;
     if (c.vars[x].is_const) {
-        *p_cur(c, ov, in_coeff) = 0;
+        st_cur(c, ov, 1, &sb, in_coeff);
         return;
     }
     if (!in_coeff) {
@@ -662,24 +731,24 @@ SANM_HD void op_det(const TetCtx& c, const OpDesc& o, int mode) {
         *psb = sb;
     } else {
         sb = *psb;
+    }
+    ld9(pcof, s, C);
+    ld_cur(c, x, 9, X);
+    if (in_coeff) {
         // finish c_k now that x_k is known
         double ck[3], r1[3], r2[3], t[3];
         ld(pck, s, 3, ck);
         ld(p_coef(c, x, 0) + 3 * s, s, 3, r1);
-        ld(p_coef(c, x, k) + 6 * s, s, 3, r2);
-        cross3(r1, r2, t);
+        cross3(r1, X + 6, t);
         ck[0] += t[0]; ck[1] += t[1]; ck[2] += t[2];
-        ld(p_coef(c, x, k) + 3 * s, s, 3, r1);
         ld(p_coef(c, x, 0) + 6 * s, s, 3, r2);
-        cross3(r1, r2, t);
+        cross3(X + 3, r2, t);
         ck[0] += t[0]; ck[1] += t[1]; ck[2] += t[2];
         st(pcs + (int64_t)k * 3 * s, s, 3, ck);
     }
-    ld9(pcof, s, C);
-    ld9(p_cur(c, x, in_coeff), s, X);
     double d = sb;
     for (int e = 0; e < 9; ++e) d += C[e] * X[e];
-    *p_cur(c, ov, in_coeff) = d;
+    st_cur(c, ov, 1, &d, in_coeff);
 }
 
 // ---- TRANSPOSE: oprs/linalg.cpp:286-335
@@ -693,13 +762,13 @@ SANM_HD void op_transpose(const TetCtx& c, const OpDesc& o, int mode) {
                 for (int j = 0; j < 3; ++j) jadd(c, x, r, i * 3 + j, jget(c, ov, r, j * 3 + i));
         return;
     }
-    const bool ev0 = mode == PASS_EVAL0, in_coeff = mode == PASS_COEFF;
-    const double* p = ev0 ? p_coef(c, x, 0) : p_cur(c, x, in_coeff);
-    double* q = ev0 ? p_coef(c, ov, 0) : p_cur(c, ov, in_coeff);
-    double X[9];
-    ld9(p, s, X);
+    double X[9], Y[9];
+    if (mode == PASS_EVAL0) ld9(p_coef(c, x, 0), s, X);
+    else ld_cur(c, x, 9, X);
     for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) q[(i * 3 + j) * s] = X[j * 3 + i];
+        for (int j = 0; j < 3; ++j) Y[i * 3 + j] = X[j * 3 + i];
+    if (mode == PASS_EVAL0) st9(p_coef(c, ov, 0), s, Y);
+    else st_cur(c, ov, 9, Y, mode == PASS_COEFF);
 }
 
 // ---- MULEYE: oprs/linalg.cpp:422-479
@@ -712,10 +781,11 @@ SANM_HD void op_muleye(const TetCtx& c, const OpDesc& o, int mode) {
             jadd(c, x, r, 0, jget(c, ov, r, 0) + jget(c, ov, r, 4) + jget(c, ov, r, 8));
         return;
     }
-    const bool ev0 = mode == PASS_EVAL0, in_coeff = mode == PASS_COEFF;
-    double v = *(ev0 ? p_coef(c, x, 0) : p_cur(c, x, in_coeff));
-    double* q = ev0 ? p_coef(c, ov, 0) : p_cur(c, ov, in_coeff);
-    for (int e = 0; e < 9; ++e) q[e * s] = (e % 4 == 0) ? v : 0.0;
+    double v = (mode == PASS_EVAL0) ? *p_coef(c, x, 0) : *p_curv(c, x);
+    double Y[9];
+    for (int e = 0; e < 9; ++e) Y[e] = (e % 4 == 0) ? v : 0.0;
+    if (mode == PASS_EVAL0) st9(p_coef(c, ov, 0), s, Y);
+    else st_cur(c, ov, 9, Y, mode == PASS_COEFF);
 }
 
 // ---- SVDW (pw_mode): oprs/linalg.cpp:483-615, tensor_svd.cpp
@@ -780,10 +850,10 @@ SANM_HD void op_svdw(const TetCtx& c, const OpDesc& o, int mode) {
         ld9(p_aux(c, o.aux[2]), s, Bp);
         ld9(p_aux(c, o.aux[3]), s, Bpw);
     }
-    ld9(p_cur(c, x, in_coeff), s, M);
+    ld_cur(c, x, 9, M);
     double Pk[9], Wk[9];
     svdw_fwd_p3(M, U, S, W, Bm, Bp, Bpw, Pk, Wk);
-    st9(p_cur(c, wv, in_coeff), s, Wk);
+    st_cur(c, wv, 9, Wk, in_coeff);
     if (in_coeff) st9(pP + (int64_t)k * 9 * s, s, Pk);
 }
 
@@ -794,38 +864,32 @@ SANM_HD void op_placeholder(const TetCtx& c, const OpDesc& o, int mode, const Re
     const int64_t s = c.Tpad;
     const int ov = o.out[0];
     if (mode == PASS_GRAD) return;
+    double X[9];
     if (mode == PASS_BIAS) {
-        double* q = p_bias(c, ov);
-        for (int e = 0; e < 9; ++e) q[e * s] = 0.0;
+        for (int e = 0; e < 9; ++e) X[e] = 0.0;
+        st_cur(c, ov, 9, X, false);
         return;
     }
-    double* q = p_coef(c, ov, mode == PASS_EVAL0 ? 0 : c.order);
     for (int e = 0; e < 9; ++e) {
         double acc = 0;
         for (int sl = 0; sl < rin.nslot; ++sl) {
             int64_t off = ((int64_t)sl * 9 + e) * s + c.tet;
             acc += rin.coef[off] * xvec[rin.idx[off]];
         }
-        q[e * s] = acc;
+        X[e] = acc;
     }
-}
-
-// ---- CONSTANT: oprs/misc.cpp:48-100 (value uploaded at compile time)
-SANM_HD void op_constant(const TetCtx& c, const OpDesc& o, int mode) {
-    if (mode != PASS_BIAS) return;
-    const int ov = o.out[0], sz = c.vars[ov].size;
-    double* q = p_bias(c, ov);
-    for (int e = 0; e < sz; ++e) q[e * c.Tpad] = 0.0;
+    if (mode == PASS_EVAL0) st9(p_coef(c, ov, 0), s, X);
+    else st_cur(c, ov, 9, X, true);
 }
 
 SANM_HD void exec_op(const TetCtx& c, const OpDesc& o, int mode, const RemapInDev& rin,
                      const double* xvec) {
     // operators fed by constants only are evaluated once (order 0); their
-    // higher-order terms are identically zero and never stored
+    // higher-order terms are identically zero, never stored and never read
     if (mode != PASS_EVAL0 && c.vars[o.out[0]].is_const) return;
     switch (o.type) {
         case OP_PLACEHOLDER: op_placeholder(c, o, mode, rin, xvec); break;
-        case OP_CONSTANT: op_constant(c, o, mode); break;
+        case OP_CONSTANT: break;  // uploaded at compile time
         case OP_LINCOMB: op_lincomb(c, o, mode); break;
         case OP_MULTIPLY: op_multiply(c, o, mode); break;
         case OP_LOG:
@@ -842,10 +906,11 @@ SANM_HD void exec_op(const TetCtx& c, const OpDesc& o, int mode, const RemapInDe
 }
 
 // One whole pass for one tet.  `xvec` is the (n[+1]) coefficient vector the
-// placeholder gathers from (EVAL0 / COEFF passes).
+// placeholder gathers from (EVAL0 / COEFF passes); `cur` the per-lane scratch
+// for the current-order values (P.cur_size doubles at stride cur_stride).
 SANM_HD void exec_program_tet(const ProgramDev& P, int mode, int order, int64_t tet,
-                              const double* xvec) {
-    TetCtx c{P.arena, P.vars, P.Tpad, tet, order, P.odim};
+                              const double* xvec, double* cur, int64_t cur_stride) {
+    TetCtx c{P.arena, P.vars, P.Tpad, tet, order, P.odim, cur, cur_stride, P.out_var};
     if (mode == PASS_GRAD) {
         // seed: d(out)/d(out) = I  (symbolic.cpp:219-220)
         double* j = p_jac(c, P.out_var);

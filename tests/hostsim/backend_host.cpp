@@ -34,7 +34,8 @@ public:
     void sync() override {}
 
     void run_pass(const ProgramDev& P, int mode, int order, const double* xvec) override {
-        for (int64_t t = 0; t < P.T; ++t) exec_program_tet(P, mode, order, t, xvec);
+        std::vector<double> cur(P.cur_size + 1);
+        for (int64_t t = 0; t < P.T; ++t) exec_program_tet(P, mode, order, t, xvec, cur.data(), 1);
     }
     void gather_rows(const SparseRowsDev& R, const double* src, double* dst) override {
         for (int64_t i = 0; i < R.nrows; ++i) dst[i] = gather_row(R, src, i);
