@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=12)
@@ -43,7 +43,8 @@ def parse():
     p.add_argument("--profile", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-steps", type=int, default=1)
-    return p.parse_args()
+    p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL on ROCm) or gloo (CPU tests)")
+    return p.parse_args(argv)
 
 
 def cpu_baseline(workload, cpu_steps):
@@ -67,22 +68,49 @@ def cpu_baseline(workload, cpu_steps):
             "profile": {k: round(v, 3) for k, v in solver.profile.items()}}
 
 
-def main():
-    args = parse()
+def make_api(local_rank):
+    """The HIP product library on GPU `local_rank` (tests replace this hook)."""
+    import sanm_amd
+    return sanm_amd.get_api(local_rank)
+
+
+def device_sync():
+    import torch
+    torch.cuda.synchronize()
+
+
+def load_workload(name):
+    """A named BASELINE config, or 'cuboid:nx,ny,nz' (test-sized synthetic cantilever)."""
+    from sanm_amd import fea as dfea
+    if name.startswith("cuboid:"):
+        nx, ny, nz = (int(v) for v in name.split(":")[1].split(","))
+        cfg = {"material": {"young": 3e3, "poisson": 0.45, "density": 1000.0}, "g": [0, -9.81, 0],
+               "boundary_thresh": 0.05, "boundary_proj_dir": [-1, 0, 0],
+               "energy_model": "neohookean_c", "order": 12}
+        return cfg, dfea.make_cuboid(nx, ny, nz, 0.025)
+    return dfea.load_named_config(name)
+
+
+def main(argv=None):
+    args = parse(argv)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    import torch
     dist = None
+    # torch must load its HIP runtime before libsanm_hip.so pulls in the system one
+    # (the other order leaves torch without visible devices)
+    import torch  # noqa: F401
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
 
-    import sanm_amd
     from sanm_amd import fea as dfea
-    api = sanm_amd.get_api(local_rank)
-    cfg, mesh = dfea.load_named_config(args.workload)
+    api = make_api(local_rank)
+    cfg, mesh = load_workload(args.workload)
     run = dfea.GravityRun(api, mesh, cfg, solver_rtol=args.solver_rtol, solver_kind=args.solver_kind,
                           profile=args.profile)
     x0 = run.model.x0()
@@ -90,7 +118,7 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
     # ---- continuation with restarts: exactly W + K completed steps ----------
     state = {"started": False, "solves": 0, "steps_per_solve": []}
@@ -125,10 +153,13 @@ def main():
     dt = time.perf_counter() - t0
     assert run.solver.get_nr_iter() - it0 == args.steps
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        import torch
+        dev = "cuda" if args.dist_backend == "nccl" else "cpu"
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     stats = run.solver.stats()
+    out = None
 
     if rank == 0:
         # ---- roofline of the dominant kernel: the Taylor pass (graph interpreter) ---
@@ -150,14 +181,18 @@ def main():
         S_, C_ = SC.get(cfg["energy_model"], (20, 45))
         bytes_step = 8.0 * T * (S_ * N * (N - 1) / 2 + N * (C_ + S_ + 9))
         launches_step = pass_cnt / max(steps_meas, 1)
-        alg_bytes = bytes_step / launches_step
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        if pass_cnt > 0 and avg_ms > 0:
+            alg_bytes = bytes_step / launches_step
+            achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        else:  # a backend without event timing (the CPU test harness)
+            alg_bytes, achieved = bytes_step / (2 * N + 1.5), 0.0
         out = {
             "metric": "ANM continuation steps/sec (armadillo, Neo-Hookean, order 20)",
             "value": world * args.steps / dt, "unit": "ANM steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "real mesh Armadillo-small.1 (stand-in for the missing Armadillo.1), rest state",
+            "data": ("real mesh Armadillo-small.1 (stand-in for the missing Armadillo.1), rest state"
+                     if args.workload == "armadillo_small" else f"workload {args.workload}, rest state"),
             "config": {"workload": f"config/{args.workload}.json: {cfg['energy_model']}, order "
                                    f"{N}, T={T}, n={n}, nnz={nnz}, pade on, sanity check on",
                        "parallelism": "replicas" if world > 1 else "single",
@@ -175,10 +210,11 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_steps)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":

@@ -368,12 +368,15 @@ void AnmDriver::solve_expansion_coeffs() {
         } else {
             {
                 ScopedTimer t{this, "sparse_solve"};
-                sanm_check(be->count_nonfinite(n, m_bi.p()) == 0,
-                           "non-finite right-hand side at order %d", i);  // sparse_solver.cpp:160-161
                 m_solver->solve(m_bi.p(), m_xbi.p());
             }
             xbi = m_xbi.p();
             ti = be->dot(n, xbi, m_xt_coeffs[1].p()) / (t1 - xgt_dot_x1);
+            // the reference asserts a finite right-hand side before solving
+            // (sparse_solver.cpp:160-161); a non-finite b_i or solution makes this
+            // reduction non-finite, which is checked instead of a separate pass
+            if (!std::isfinite(ti))
+                sanm_throw(SANM_ERR_NUMERICAL, "non-finite right-hand side / solution at order %d", i);
         }
         // x_i = -ti*xgt - xbi ; t_i appended  (anm.cpp:261-264)
         double* xi = m_xt_coeffs[i].p();
@@ -388,9 +391,10 @@ void AnmDriver::solve_expansion_coeffs() {
             ScopedTimer t{this, "anm_sanity_check"};
             be->spmv(m_pattern->csr(), xi, m_tmp0.p());
             be->axpby(n, -ti, grad_t, -1.0, m_bi.p(), m_tmp1.p());
-            double ex = be->allclose_excess(n, m_tmp0.p(), m_tmp1.p(), 1e-4);
+            double red[2];
+            be->sanity_reduce(n, m_tmp0.p(), m_tmp1.p(), 1e-4, n1, m_xt_coeffs[1].p(), xi, red);
+            const double ex = red[0], xdot = red[1];
             sanm_check(ex < 0, "ANM check coeff eqn: order %d: excess %g", i, ex);
-            double xdot = be->dot(n1, m_xt_coeffs[1].p(), xi);
             if (i == 1) sanm_check(std::fabs(xdot - 1) < 1e-4, "xdot=%g", xdot);
             else sanm_check(std::fabs(xdot) < 1e-4, "i=%d: xdot=%g", i, xdot);
         }

@@ -120,6 +120,14 @@ public:
         return -1.0;
     }
 
+    //! the two reductions of the per-order ANM sanity check in one launch / one
+    //! synchronisation: out[0] = allclose_excess(a, b, eps) over n entries,
+    //! out[1] = x . y over n1 entries  (libsanm/anm.cpp:271-285)
+    virtual void sanity_reduce(size_t n, const double* a, const double* b, double eps, size_t n1,
+                               const double* x, const double* y, double out[2]) {
+        out[0] = allclose_excess(n, a, b, eps);
+        out[1] = dot(n1, x, y);
+    }
     //! like allclose_excess for check_t0v_match (anm.cpp:343-360): a + b*t0 vs 0
     virtual double t0v_excess(size_t n, const double* fx, const double* v, double t0, double tol) = 0;
 };

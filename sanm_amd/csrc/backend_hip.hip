@@ -199,6 +199,21 @@ __global__ void __launch_bounds__(256) allclose_kernel(size_t n, const double* a
     block_reduce_commit<true>(m, out);
 }
 
+// fused reductions of the ANM sanity check: out[0] = max allclose excess, out[1] = dot
+__global__ void __launch_bounds__(256) sanity_kernel(size_t n, const double* a, const double* b,
+                                                     double eps, size_t n1, const double* x,
+                                                     const double* y, double* out) {
+    double m = -1e300, s = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1;
+         i += (size_t)gridDim.x * blockDim.x) {
+        if (i < n) m = fmax(m, allclose_excess1(a[i], b[i], eps));
+        s += x[i] * y[i];
+    }
+    block_reduce_commit<true>(m, out);
+    __syncthreads();
+    block_reduce_commit<false>(s, out + 1);
+}
+
 __global__ void __launch_bounds__(256) t0v_kernel(size_t n, const double* fx, const double* v,
                                                   double t0, double tol, double* out) {
     double m = -1e300;
@@ -520,17 +535,30 @@ public:
                 hipLaunchKernelGGL(extend_add_kernel, dim3(nblk(mb * mb, 256), cnt), dim3(256), 0,
                                    m_stream, mf, sch.ea_children + L.ea_rounds[r].first);
             }
-            const int nt = (L.max_m + L.max_k + NB - 1) / NB;  // augmented extent
+            const int nt = (2 * L.max_k + NB - 1) / NB;  // pivot + augmentation block
+            // panel 0's diagonal tile is factored by diag_kernel; every later diagonal
+            // tile by the update kernel of the previous panel (look-ahead)
+            if (L.nr_panel > 0)
+                hipLaunchKernelGGL(diag_kernel, dim3(L.panel_cnt[0]), dim3(256), 0, m_stream, mf,
+                                   L.front_begin, 0);
             for (int p = 0; p < L.nr_panel; ++p) {
                 const int cnt = L.panel_cnt[p];
-                hipLaunchKernelGGL(diag_kernel, dim3(cnt), dim3(256), 0, m_stream, mf, L.front_begin, p);
                 const int rem = nt - p - 1;
-                if (rem > 0) {
-                    hipLaunchKernelGGL(trsm_kernel, dim3(rem, 2, cnt), dim3(256), 0, m_stream, mf,
-                                       L.front_begin, p);
-                    hipLaunchKernelGGL(update_kernel, dim3(rem, rem, cnt), dim3(256), 0, m_stream, mf,
-                                       L.front_begin, p);
-                }
+                if (rem <= 0) continue;
+                hipLaunchKernelGGL(trsm_kernel, dim3(rem, 2, cnt), dim3(256), 0, m_stream, mf,
+                                   L.front_begin, p);
+                hipLaunchKernelGGL(update_kernel, dim3(rem, rem, cnt), dim3(256), 0, m_stream, mf,
+                                   L.front_begin, p);
+            }
+            // Schur complement and the boundary blocks of the solve operators: two GEMM passes
+            if (L.max_b > 0) {
+                const int nfr = L.front_end - L.front_begin;
+                const int tb = (L.max_b + GT - 1) / GT, tk = (L.max_k + GT - 1) / GT;
+                const int tmax = std::max(tb, tk);
+                hipLaunchKernelGGL(gemm1_kernel, dim3(tmax, tmax, 2 * nfr), dim3(256), 0, m_stream, mf,
+                                   L.front_begin);
+                hipLaunchKernelGGL(gemm2_kernel, dim3(tmax, tmax, 3 * nfr), dim3(256), 0, m_stream, mf,
+                                   L.front_begin);
             }
         }
         HIP_CHECK(hipGetLastError());
@@ -687,6 +715,22 @@ public:
                            m_scalar);
         HIP_CHECK(hipGetLastError());
         return fetch_scalar();
+    }
+    void sanity_reduce(size_t n, const double* a, const double* b, double eps, size_t n1,
+                       const double* x, const double* y, double out[2]) override {
+        if (n1 < n) sanm_throw(SANM_ERR_ASSERT, "sanity_reduce: n1 < n");
+        m_scalar_host[0] = -1e300;
+        m_scalar_host[1] = 0.0;
+        HIP_CHECK(hipMemcpyAsync(m_scalar, m_scalar_host, 2 * sizeof(double), hipMemcpyHostToDevice,
+                                 m_stream));
+        hipLaunchKernelGGL(sanity_kernel, dim3(red_grid(n1)), dim3(256), 0, m_stream, n, a, b, eps, n1, x,
+                           y, m_scalar);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(m_scalar_host, m_scalar, 2 * sizeof(double), hipMemcpyDeviceToHost,
+                                 m_stream));
+        HIP_CHECK(hipStreamSynchronize(m_stream));
+        out[0] = m_scalar_host[0];
+        out[1] = m_scalar_host[1];
     }
     double t0v_excess(size_t n, const double* fx, const double* v, double t0,
                       double tol) override {

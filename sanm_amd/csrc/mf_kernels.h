@@ -4,6 +4,14 @@
 // All fronts of one tree level are processed by the same launches; blocks that
 // fall outside a front's extent exit at once.  Tiles are NB x NB (NB = 32),
 // one 256-thread workgroup per tile, operands staged through LDS.
+//
+// Front layout (mf_types.h): rows / columns ordered [P pivot k | A augmentation k |
+// B boundary b], leading dimension ld = 2k + b.  Per level:
+//   1. panel loop on the leading 2k x 2k block (diag / trsm / update kernels):
+//      LU of F[P,P] with the identity blocks turning into L11^-1 and U11^-1;
+//   2. gemm1_kernel:  tmpU = L11^-1 F[P,B],  tmpL = F[B,P] U11^-1          (K = k)
+//   3. gemm2_kernel:  F[B,B] -= tmpL tmpU,  F[B,A] = -tmpL L11^-1,  F[A,B] = -U11^-1 tmpU
+// so the Schur complement is read and written once instead of once per panel.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -21,15 +29,15 @@ __global__ void scatter_kernel(int64_t nnz, const int64_t* __restrict__ a_dst,
     if (p < nnz) store[a_dst[p]] = val[p];
 }
 
-// identity blocks of the augmentation: F[r, m + r] = F[m + r, r] = 1 for r < k
+// identity blocks of the augmentation: F[r, k + r] = F[k + r, r] = 1 for r < k
 __global__ void aug_identity_kernel(MfDev mf) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= mf.n) return;
     const MfFrontDev f = mf.fronts[mf.own_front[i]];
     const int r = i - f.own_start;
     double* F = mf.front_store + f.off;
-    F[(int64_t)r * f.ld + f.m + r] = 1.0;
-    F[(int64_t)(f.m + r) * f.ld + r] = 1.0;
+    F[(int64_t)r * f.ld + f.k + r] = 1.0;
+    F[(int64_t)(f.k + r) * f.ld + r] = 1.0;
 }
 
 // parent[rel[i], rel[j]] += child_schur[i, j]; one child per blockIdx.y
@@ -41,7 +49,7 @@ __global__ void __launch_bounds__(256) extend_add_kernel(MfDev mf, const int32_t
     const int i = idx / nb, j = idx % nb;
     const MfFrontDev p = mf.fronts[c.parent];
     const int32_t* rel = mf.rel + c.rel_off;
-    double v = mf.front_store[c.off + (int64_t)(c.k + i) * c.ld + c.k + j];
+    double v = mf.front_store[c.off + (int64_t)(2 * c.k + i) * c.ld + 2 * c.k + j];
     mf.front_store[p.off + (int64_t)rel[i] * p.ld + rel[j]] += v;
 }
 
@@ -128,20 +136,20 @@ __device__ __forceinline__ void tile_factor(double (*T)[TPAD], double (*LI)[TPAD
 // diagonal tile of panel p of every front of a level
 __global__ void __launch_bounds__(256) diag_kernel(MfDev mf, int level_begin, int p) {
     const MfFrontDev f = mf.fronts[mf.level_fronts[level_begin + blockIdx.x]];
-    const int m = f.ld, r0 = p * NB;  // m: extent and leading dimension of the augmented front
+    const int ld = f.ld, m = 2 * f.k, r0 = p * NB;  // m: extent of the pivot + augmentation block
     const int kb = min(NB, f.k - r0);
     __shared__ double T[NB][TPAD], LI[NB][TPAD], UI[NB][TPAD];
     double* F = mf.front_store + f.off;
     const int tid = threadIdx.x, tc = tid % NB, tr = tid / NB;
     for (int s = 0; s < 4; ++s) {
         int r = tr + 8 * s, gr = r0 + r, gc = r0 + tc;
-        T[r][tc] = (gr < m && gc < m) ? F[(int64_t)gr * m + gc] : (r == tc ? 1.0 : 0.0);
+        T[r][tc] = (gr < m && gc < m) ? F[(int64_t)gr * ld + gc] : (r == tc ? 1.0 : 0.0);
     }
     __syncthreads();
     tile_factor(T, LI, UI, kb, tid, mf.dinv_store + f.dinv_off + (int64_t)p * 2 * NB * NB, mf.status);
     for (int s = 0; s < 4; ++s) {
         int r = tr + 8 * s, gr = r0 + r, gc = r0 + tc;
-        if (gr < m && gc < m) F[(int64_t)gr * m + gc] = T[r][tc];
+        if (gr < m && gc < m) F[(int64_t)gr * ld + gc] = T[r][tc];
     }
 }
 
@@ -149,7 +157,7 @@ __global__ void __launch_bounds__(256) diag_kernel(MfDev mf, int level_begin, in
 //              blockIdx.y == 1: L panel tile (t, p) <- tile * Uinv      (t > p)
 __global__ void __launch_bounds__(256) trsm_kernel(MfDev mf, int level_begin, int p) {
     const MfFrontDev f = mf.fronts[mf.level_fronts[level_begin + blockIdx.z]];
-    const int m = f.ld, nt = (m + NB - 1) / NB;
+    const int ld = f.ld, m = 2 * f.k, nt = (m + NB - 1) / NB;
     const int t = p + 1 + blockIdx.x;
     if (t >= nt) return;
     const bool upanel = blockIdx.y == 0;
@@ -160,7 +168,7 @@ __global__ void __launch_bounds__(256) trsm_kernel(MfDev mf, int level_begin, in
     const int tid = threadIdx.x, tc = tid % NB, tr = tid / NB;
     for (int s = 0; s < 4; ++s) {
         int r = tr + 8 * s, gr = r0 + r, gc = c0 + tc;
-        A[r][tc] = (gr < m && gc < m) ? F[(int64_t)gr * m + gc] : 0.0;
+        A[r][tc] = (gr < m && gc < m) ? F[(int64_t)gr * ld + gc] : 0.0;
         B[r][tc] = D[r * NB + tc];
     }
     __syncthreads();
@@ -174,43 +182,185 @@ __global__ void __launch_bounds__(256) trsm_kernel(MfDev mf, int level_begin, in
 #pragma unroll 8
             for (int q = 0; q < NB; ++q) acc += A[r][q] * B[q][tc];  // tile * Uinv
         }
-        if (gr < m && gc < m) F[(int64_t)gr * m + gc] = acc;
+        if (gr < m && gc < m) F[(int64_t)gr * ld + gc] = acc;
     }
 }
 
 // trailing update: tile(ti,tj) -= L(ti,p)[:, :kb] * U(p,tj)[:kb, :]   (ti, tj > p).
-// (Fusing the next diagonal tile's LU into this kernel was tried: the extra
-// registers of the tile LU cut the occupancy of every update workgroup and made
-// the factorisation slower overall -- profiles/r01_*.)
+// Look-ahead: the workgroup that owns the next diagonal tile (p+1,p+1) factors it
+// right after updating it, so panels p >= 1 need no separate diagonal launch and
+// that short sequential LU hides behind the other tiles of the same launch.
+// (tile_factor keeps its inverse columns in LDS: with them in registers the
+// fused kernel lost occupancy and the factorisation got slower; a second stream
+// for the diagonal tile was tried as well -- the cross-stream events cost as
+// much as they hid.)
 __global__ void __launch_bounds__(256) update_kernel(MfDev mf, int level_begin, int p) {
     const MfFrontDev f = mf.fronts[mf.level_fronts[level_begin + blockIdx.z]];
-    const int m = f.ld, nt = (m + NB - 1) / NB;
+    const int ld = f.ld, m = 2 * f.k, nt = (m + NB - 1) / NB;
     const int ti = p + 1 + blockIdx.y, tj = p + 1 + blockIdx.x;
     if (ti >= nt || tj >= nt) return;
     // the (augmentation x augmentation) corner is never used
-    if (ti * NB >= f.m && tj * NB >= f.m) return;
+    if (ti * NB >= f.k && tj * NB >= f.k) return;
     const int kb = min(NB, f.k - p * NB);
-    __shared__ double L[NB][TPAD], U[NB][TPAD];
+    __shared__ double L[NB][TPAD], U[NB][TPAD], T[NB][TPAD];
     double* F = mf.front_store + f.off;
     const int tid = threadIdx.x, tc = tid % NB, tr = tid / NB;
     for (int s = 0; s < 4; ++s) {
         int r = tr + 8 * s;
         int gr = ti * NB + r, gc = p * NB + tc;
-        L[r][tc] = (gr < m && tc < kb) ? F[(int64_t)gr * m + gc] : 0.0;
+        L[r][tc] = (gr < m && tc < kb) ? F[(int64_t)gr * ld + gc] : 0.0;
         gr = p * NB + r;
         gc = tj * NB + tc;
-        U[r][tc] = (r < kb && gc < m) ? F[(int64_t)gr * m + gc] : 0.0;
+        U[r][tc] = (r < kb && gc < m) ? F[(int64_t)gr * ld + gc] : 0.0;
     }
     __syncthreads();
+    const bool next_diag = (ti == tj) && (ti == p + 1) && ((p + 1) * NB < f.k);  // workgroup-uniform
     for (int s = 0; s < 4; ++s) {
         int r = tr + 8 * s, gr = ti * NB + r, gc = tj * NB + tc;
+        double v = (r == tc) ? 1.0 : 0.0;  // identity padding outside the front
         if (gr < m && gc < m) {
             double acc = 0;
 #pragma unroll 8
             for (int q = 0; q < NB; ++q) acc += L[r][q] * U[q][tc];
-            F[(int64_t)gr * m + gc] -= acc;
+            v = F[(int64_t)gr * ld + gc] - acc;
+            if (!next_diag) F[(int64_t)gr * ld + gc] = v;
+        }
+        if (next_diag) T[r][tc] = v;
+    }
+    if (!next_diag) return;
+    __syncthreads();
+    const int kb1 = min(NB, f.k - (p + 1) * NB);
+    tile_factor(T, L, U, kb1, tid, mf.dinv_store + f.dinv_off + (int64_t)(p + 1) * 2 * NB * NB, mf.status);
+    for (int s = 0; s < 4; ++s) {
+        int r = tr + 8 * s, gr = ti * NB + r, gc = tj * NB + tc;
+        if (gr < m && gc < m) F[(int64_t)gr * ld + gc] = T[r][tc];
+    }
+}
+
+// C tile (64x64) of a product of two strided matrices: 256 threads, each a 4x4
+// register block, K in steps of 16 through LDS.  Element (i,j) of an operand is
+// p[i*ld + j] inside (rows, cols), else 0.  K range [k0, k1) in elements.
+struct MatView {
+    const double* p;
+    int ld, rows, cols;
+};
+constexpr int GT = 64;   // GEMM tile edge
+constexpr int GK = 16;   // GEMM K step
+__device__ __forceinline__ void gemm_tile(const MatView& A, const MatView& B, int ti, int tj, int k0,
+                                          int k1, double (*As)[GT + 1], double (*Bs)[GT + 4],
+                                          double acc[4][4]) {
+    const int tid = threadIdx.x, tx = tid % 16, ty = tid / 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0;
+    for (int kk = k0; kk < k1; kk += GK) {
+        __syncthreads();
+        // A tile 64 x 16 stored transposed As[e][row]; B tile 16 x 64 as Bs[e][col]
+        for (int s = 0; s < 4; ++s) {
+            int idx = tid + 256 * s;       // 0..1023
+            int ar = idx / GK, ae = idx % GK;  // consecutive threads along K: contiguous in a row of A
+            int gr = ti * GT + ar, gc = kk + ae;
+            As[ae][ar] = (gr < A.rows && gc < A.cols && gc < k1) ? A.p[(int64_t)gr * A.ld + gc] : 0.0;
+            int be = idx / GT, bc = idx % GT;  // consecutive threads along the columns of B
+            gr = kk + be;
+            gc = tj * GT + bc;
+            Bs[be][bc] = (gr < B.rows && gr < k1 && gc < B.cols) ? B.p[(int64_t)gr * B.ld + gc] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < GK; ++e) {
+            double a[4], bq[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[e][ty * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bq[j] = Bs[e][tx * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * bq[j];
         }
     }
+}
+
+// step 2:  which = 0: tmpU (k x b) = L11^-1 F[P,B]     (L11^-1 lower: K tiles 0..ti)
+//          which = 1: tmpL (b x k) = F[B,P] U11^-1     (U11^-1 upper: K tiles 0..tj)
+__global__ void __launch_bounds__(256) gemm1_kernel(MfDev mf, int level_begin) {
+    const MfFrontDev f = mf.fronts[mf.level_fronts[level_begin + blockIdx.z / 2]];
+    const int which = blockIdx.z & 1;
+    const int k = f.k, b = f.m - f.k, ld = f.ld;
+    const int rows = which ? b : k, cols = which ? k : b;
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (ti * GT >= rows || tj * GT >= cols) return;
+    __shared__ double As[GK][GT + 1], Bs[GK][GT + 4];
+    const double* F = mf.front_store + f.off;
+    double* tmp = mf.tmp_store + f.tmp_off;
+    MatView A, B;
+    int k1;
+    if (which == 0) {
+        A = {F + k, ld, k, k};                       // F[P,A] = L11^-1 (lower)
+        B = {F + 2 * k, ld, k, b};                   // F[P,B]
+        k1 = min(k, (ti + 1) * GT);
+    } else {
+        A = {F + (int64_t)2 * k * ld, ld, b, k};     // F[B,P]
+        B = {F + (int64_t)k * ld, ld, k, k};         // F[A,P] = U11^-1 (upper)
+        k1 = min(k, (tj + 1) * GT);
+    }
+    double acc[4][4];
+    gemm_tile(A, B, ti, tj, 0, k1, As, Bs, acc);
+    double* C = which ? tmp + (int64_t)k * b : tmp;  // tmpU: ld b ; tmpL: ld k
+    const int cld = which ? k : b;
+    const int tid = threadIdx.x, tx = tid % 16, ty = tid / 16;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            int r = ti * GT + ty * 4 + i, c = tj * GT + tx * 4 + j;
+            if (r < rows && c < cols) C[(int64_t)r * cld + c] = acc[i][j];
+        }
+}
+
+// step 3:  which = 0: F[B,B] -= tmpL tmpU                        (b x b, K = k)
+//          which = 1: F[B,A]  = -tmpL L11^-1   (b x k; L11^-1 lower: K tiles tj..)
+//          which = 2: F[A,B]  = -U11^-1 tmpU   (k x b; U11^-1 upper: K tiles ti..)
+__global__ void __launch_bounds__(256) gemm2_kernel(MfDev mf, int level_begin) {
+    const MfFrontDev f = mf.fronts[mf.level_fronts[level_begin + blockIdx.z / 3]];
+    const int which = blockIdx.z % 3;
+    const int k = f.k, b = f.m - f.k, ld = f.ld;
+    const int rows = which == 2 ? k : b, cols = which == 1 ? k : b;
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (ti * GT >= rows || tj * GT >= cols) return;
+    __shared__ double As[GK][GT + 1], Bs[GK][GT + 4];
+    double* F = mf.front_store + f.off;
+    const double* tmpU = mf.tmp_store + f.tmp_off;
+    const double* tmpL = tmpU + (int64_t)k * b;
+    MatView A, B;
+    int k0 = 0;
+    double* C;
+    if (which == 0) {
+        A = {tmpL, k, b, k};
+        B = {tmpU, b, k, b};
+        C = F + (int64_t)2 * k * ld + 2 * k;
+    } else if (which == 1) {
+        A = {tmpL, k, b, k};
+        B = {F + k, ld, k, k};  // L11^-1 (lower): rows >= column
+        k0 = tj * GT;
+        C = F + (int64_t)2 * k * ld + k;
+    } else {
+        A = {F + (int64_t)k * ld, ld, k, k};  // U11^-1 (upper): columns >= row
+        B = {tmpU, b, k, b};
+        k0 = ti * GT;
+        C = F + (int64_t)k * ld + 2 * k;
+    }
+    double acc[4][4];
+    gemm_tile(A, B, ti, tj, k0, k, As, Bs, acc);
+    const int tid = threadIdx.x, tx = tid % 16, ty = tid / 16;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            int r = ti * GT + ty * 4 + i, c = tj * GT + tx * 4 + j;
+            if (r < rows && c < cols) {
+                double* dst = C + (int64_t)r * ld + c;
+                *dst = (which == 0) ? *dst - acc[i][j] : -acc[i][j];
+            }
+        }
 }
 
 // ---------------------------------------------------------------- solve --
@@ -249,7 +399,9 @@ __global__ void __launch_bounds__(256) fwd_mv_kernel(MfDev mf, int level_begin) 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r = blockIdx.x * 4 + wv;
     if (r >= m) return;
-    const double* row = mf.front_store + f.off + (int64_t)r * f.ld + m;
+    // row r of [L11^-1 ; -L21 L11^-1] = columns A of physical row r (own) or 2k + (r-k)
+    const int pr = r < k ? r : r + k;
+    const double* row = mf.front_store + f.off + (int64_t)pr * f.ld + k;
     const double* t = mf.work + f.own_start;
     const int cend = r < k ? r + 1 : k;  // L11^-1 is lower triangular
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
@@ -281,7 +433,8 @@ __global__ void __launch_bounds__(256) bwd_mv_kernel(MfDev mf, int level_begin) 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r = blockIdx.x * 4 + wv;
     if (r >= k) return;
-    const double* row = mf.front_store + f.off + (int64_t)(m + r) * f.ld;
+    // row r of [U11^-1 , -U11^-1 U12] = physical row k + r: columns P then columns B
+    const double* row = mf.front_store + f.off + (int64_t)(k + r) * f.ld;
     const double* z = mf.work2 + f.own_start;
     const int32_t* bi = mf.bnd_idx + f.bnd_off;
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
@@ -293,14 +446,16 @@ __global__ void __launch_bounds__(256) bwd_mv_kernel(MfDev mf, int level_begin) 
         a3 += row[c + 192] * z[c + 192];
     }
     for (; c < k; c += 64) a0 += row[c] * z[c];
-    c = k + lane;
-    for (; c + 192 < m; c += 256) {
-        a0 += row[c] * mf.work[bi[c - k]];
-        a1 += row[c + 64] * mf.work[bi[c + 64 - k]];
-        a2 += row[c + 128] * mf.work[bi[c + 128 - k]];
-        a3 += row[c + 192] * mf.work[bi[c + 192 - k]];
+    const double* rowb = row + 2 * k;  // boundary columns
+    const int nbnd = m - k;
+    c = lane;
+    for (; c + 192 < nbnd; c += 256) {
+        a0 += rowb[c] * mf.work[bi[c]];
+        a1 += rowb[c + 64] * mf.work[bi[c + 64]];
+        a2 += rowb[c + 128] * mf.work[bi[c + 128]];
+        a3 += rowb[c + 192] * mf.work[bi[c + 192]];
     }
-    for (; c < m; c += 64) a0 += row[c] * mf.work[bi[c - k]];
+    for (; c < nbnd; c += 64) a0 += rowb[c] * mf.work[bi[c]];
     double acc = wave_sum((a0 + a1) + (a2 + a3));
     if (lane == 0) mf.work[f.own_start + r] = acc;
 }

@@ -12,9 +12,11 @@ struct MfFrontDev {
     int64_t off;        // offset of the dense ld*ld augmented front (row-major) in the front storage
     int64_t dinv_off;   // offset of the inverted diagonal blocks: per panel [Linv | Uinv], NB*NB each
     int32_t k, m;       // pivots, front size
-    int32_t ld;         // m + k: the front is augmented by k identity columns / rows, so that
-                        // the elimination leaves  F[0:k, m:]  = L11^-1,  F[k:m, m:] = -L21 L11^-1,
-                        //                         F[m:, 0:k]  = U11^-1,  F[m:, k:m] = -U11^-1 U12
+    int32_t ld;         // m + k.  Row / column order of the dense front: [pivot P (k) | augmentation A (k) |
+                        // boundary B (m-k)].  A starts as identity blocks F[P,A] = F[A,P] = I; the LU of the
+                        // leading 2k x 2k block leaves F[P,A] = L11^-1 and F[A,P] = U11^-1; one GEMM pass then
+                        // writes F[B,B] -= L21 U12 (Schur complement), F[B,A] = -L21 L11^-1, F[A,B] = -U11^-1 U12
+    int64_t tmp_off;    // offset of this front's GEMM workspace (2*k*(m-k) doubles) in tmp_store
     int32_t own_start;  // first own variable (new numbering)
     int32_t bnd_off;    // offset into bnd_idx (m-k entries, new numbering, ascending)
     int32_t parent;     // -1 for roots
@@ -43,6 +45,7 @@ struct MfDev {
     double* upd_store;            // solve workspace: concatenated update vectors
     double* work;                 // n doubles (permuted rhs / solution)
     double* work2;                // n doubles (forward-solved vector z)
+    double* tmp_store;            // per-level workspace: L11^-1 F12 (k x b) and F21 U11^-1 (b x k) per front
     int32_t* status;              // [0]: number of bad pivots
     int64_t front_store_size, dinv_store_size, upd_store_size;
 };

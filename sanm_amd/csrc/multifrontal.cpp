@@ -462,7 +462,7 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
         int32_t nb = fr[f].m - fr[f].k;
         const int32_t* it = std::lower_bound(b, b + nb, x);
         sanm_check(it != b + nb && *it == x, "variable %d is not part of front %d", x, f);
-        return fr[f].k + (it - b);
+        return 2 * fr[f].k + (it - b);  // [pivot | augmentation | boundary]
     };
 
     std::vector<int32_t> rel(bnd_idx.size(), -1);
@@ -478,10 +478,12 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     // gather lists of the solve: which child update entries feed row r of front f
     std::vector<int32_t> gat_ptr(gat, 0), gat_src;
     {
+        // logical row of a physical front position: own rows first, then boundary rows
+        auto logical = [&](int32_t f, int32_t pos) { return pos < fr[f].k ? pos : pos - fr[f].k; };
         for (int32_t f = 0; f < F; ++f)
             for (int32_t c : children[f])
                 for (int32_t j = 0; j < fr[c].m - fr[c].k; ++j)
-                    gat_ptr[fr[f].gat_off + rel[fr[c].rel_off + j] + 1]++;
+                    gat_ptr[fr[f].gat_off + logical(f, rel[fr[c].rel_off + j]) + 1]++;
         int32_t run = 0;
         for (int32_t f = 0; f < F; ++f) {
             // local prefix sums, made global by adding the running total
@@ -497,7 +499,7 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
         for (int32_t f = 0; f < F; ++f)
             for (int32_t c : children[f])
                 for (int32_t j = 0; j < fr[c].m - fr[c].k; ++j)
-                    gat_src[fill[fr[f].gat_off + rel[fr[c].rel_off + j]]++] = fr[c].upd_off + j;
+                    gat_src[fill[fr[f].gat_off + logical(f, rel[fr[c].rel_off + j])]++] = fr[c].upd_off + j;
     }
 
     // owner front of every new index
@@ -521,6 +523,7 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     nr_level = H;
     std::vector<int32_t> level_fronts;
     std::vector<int32_t> ea_children;
+    int64_t tmp_doubles = 1;
     m_sched.levels.resize(H);
     for (int32_t h = 0; h < H; ++h) {
         auto& L = m_sched.levels[h];
@@ -538,6 +541,14 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
             L.max_k = std::max(L.max_k, fr[f].k);
             L.max_b = std::max(L.max_b, fr[f].m - fr[f].k);
             max_children = std::max(max_children, children[f].size());
+        }
+        {
+            int64_t t = 0;
+            for (int32_t f : fs) {
+                fr[f].tmp_off = t;
+                t += 2 * (int64_t)fr[f].k * (fr[f].m - fr[f].k);
+            }
+            tmp_doubles = std::max(tmp_doubles, t);
         }
         L.nr_panel = (L.max_k + MF_NB - 1) / MF_NB;
         L.panel_cnt.assign(L.nr_panel, 0);
@@ -580,6 +591,8 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     m_dev.work = static_cast<double*>(be->alloc(n * sizeof(double)));
     m_dev.work2 = static_cast<double*>(be->alloc(n * sizeof(double)));
     m_bufs.push_back(m_dev.work2);
+    m_dev.tmp_store = static_cast<double*>(be->alloc(tmp_doubles * sizeof(double)));
+    m_bufs.push_back(m_dev.tmp_store);
     m_dev.status = static_cast<int32_t*>(be->alloc(64));
     be->zero(m_dev.status, 64);
     m_bufs.push_back(m_dev.front_store);

@@ -114,21 +114,24 @@ struct HostMf {
                     for (int i = 0; i < nb; ++i)
                         for (int j = 0; j < nb; ++j)
                             mf.front_store[p.off + (int64_t)rel[i] * p.ld + rel[j]] +=
-                                    mf.front_store[c.off + (int64_t)(c.k + i) * c.ld + c.k + j];
+                                    mf.front_store[c.off + (int64_t)(2 * c.k + i) * c.ld + 2 * c.k + j];
                 }
             for (int32_t q = L.front_begin; q < L.front_end; ++q) {
                 const MfFrontDev& f = mf.fronts[mf.level_fronts[q]];
                 double* F = mf.front_store + f.off;
-                const int m = f.m, ld = f.ld;
-                for (int j = 0; j < f.k; ++j) {
-                    double piv = F[(int64_t)j * ld + j];
+                // physical position of logical index i: [pivot | augmentation (unused here) | boundary]
+                const int m = f.m, k = f.k;
+                const int64_t ld = f.ld;
+                auto P = [k](int i) { return i < k ? i : i + k; };
+                for (int j = 0; j < k; ++j) {
+                    double piv = F[P(j) * ld + P(j)];
                     if (!(std::fabs(piv) > 1e-290)) ++bad;
                     double inv = 1.0 / piv;
                     for (int i = j + 1; i < m; ++i) {
-                        double l = F[(int64_t)i * ld + j] * inv;
-                        F[(int64_t)i * ld + j] = l;
+                        double l = F[P(i) * ld + P(j)] * inv;
+                        F[P(i) * ld + P(j)] = l;
                         if (l != 0)
-                            for (int c2 = j + 1; c2 < m; ++c2) F[(int64_t)i * ld + c2] -= l * F[(int64_t)j * ld + c2];
+                            for (int c2 = j + 1; c2 < m; ++c2) F[P(i) * ld + P(c2)] -= l * F[P(j) * ld + P(c2)];
                     }
                 }
             }
@@ -157,7 +160,7 @@ struct HostMf {
                 }
                 for (int r = k; r < m; ++r) {
                     double v = t[r];
-                    for (int c2 = 0; c2 < k; ++c2) v -= F[(int64_t)r * f.ld + c2] * t[c2];
+                    for (int c2 = 0; c2 < k; ++c2) v -= F[(int64_t)(r + k) * f.ld + c2] * t[c2];
                     mf.upd_store[f.upd_off + r - k] = v;
                 }
                 for (int r = 0; r < k; ++r) w[f.own_start + r] = t[r];
@@ -171,7 +174,7 @@ struct HostMf {
                 const int32_t* bi = mf.bnd_idx + f.bnd_off;
                 for (int r = k - 1; r >= 0; --r) {
                     double v = w[f.own_start + r];
-                    for (int c2 = k; c2 < m; ++c2) v -= F[(int64_t)r * f.ld + c2] * w[bi[c2 - k]];
+                    for (int c2 = k; c2 < m; ++c2) v -= F[(int64_t)r * f.ld + c2 + k] * w[bi[c2 - k]];
                     for (int c2 = r + 1; c2 < k; ++c2) v -= F[(int64_t)r * f.ld + c2] * w[f.own_start + c2];
                     w[f.own_start + r] = v / F[(int64_t)r * f.ld + r];
                 }
