@@ -43,6 +43,9 @@ def parse(argv=None):
     p.add_argument("--profile", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-steps", type=int, default=1)
+    p.add_argument("--parallelism", default="replicas", choices=["replicas", "shard"],
+                   help="N>1: independent replicas (weak scaling) or one tet-sharded problem with an "
+                        "RCCL all-reduce of b_k per Taylor order (strong scaling)")
     p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL on ROCm) or gloo (CPU tests)")
     return p.parse_args(argv)
 
@@ -111,8 +114,13 @@ def main(argv=None):
     from sanm_amd import fea as dfea
     api = make_api(local_rank)
     cfg, mesh = load_workload(args.workload)
-    run = dfea.GravityRun(api, mesh, cfg, solver_rtol=args.solver_rtol, solver_kind=args.solver_kind,
-                          profile=args.profile)
+    shard = None
+    if world > 1 and args.parallelism == "shard":
+        from sanm_amd import dist as sdist
+        fn = sdist.make_rccl_allreduce() if args.dist_backend == "nccl" else sdist.make_host_allreduce()
+        shard = (rank, world, fn)
+    run = dfea.GravityRun(api, mesh, cfg, shard=shard, solver_rtol=args.solver_rtol,
+                          solver_kind=args.solver_kind, profile=args.profile)
     x0 = run.model.x0()
 
     def barrier():
@@ -186,16 +194,27 @@ def main(argv=None):
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         else:  # a backend without event timing (the CPU test harness)
             alg_bytes, achieved = bytes_step / (2 * N + 1.5), 0.0
+        # HBM-side bytes per launch of that kernel from the committed PMC profile
+        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, corrected per
+        # MI355X_MICROARCH.md; profiles/r01_pmc_traffic.md) -- not collected live
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pmc.get("workload") == args.workload and pmc.get("order") == N:
+                traffic = pmc["kernels"]["taylor_pass_kernel"]["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "ANM continuation steps/sec (armadillo, Neo-Hookean, order 20)",
-            "value": world * args.steps / dt, "unit": "ANM steps/s", "n_gpus": world,
+            "value": (1 if shard else world) * args.steps / dt, "unit": "ANM steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None,
+            "dtype": "f64",
             "data": ("real mesh Armadillo-small.1 (stand-in for the missing Armadillo.1), rest state"
                      if args.workload == "armadillo_small" else f"workload {args.workload}, rest state"),
             "config": {"workload": f"config/{args.workload}.json: {cfg['energy_model']}, order "
                                    f"{N}, T={T}, n={n}, nnz={nnz}, pade on, sanity check on",
-                       "parallelism": "replicas" if world > 1 else "single",
+                       "parallelism": ("tet-shard + all-reduce(b_k)/order" if shard else "replicas") if world > 1 else "single",
                        "linear_solver": "jacobi-pcg" if args.solver_kind == 0 else "multifrontal-lu",
                        "solver_stats": {k: stats[k] for k in ("factor_nnz", "factor_flops", "nr_front",
                                                               "nr_level", "max_front")},
@@ -203,7 +222,7 @@ def main(argv=None):
                        "steps_per_solve": state["steps_per_solve"]},
             "roofline": {"bound": "hbm", "kernel": "taylor_pass_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "avg_launch_us": avg_ms * 1e3,
+                         "traffic": traffic, "avg_launch_us": avg_ms * 1e3,
                          "launches_per_step": launches_step,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "algorithmic_bytes_per_step": bytes_step},

@@ -129,6 +129,21 @@ void sanm_hyper_param_default(sanm_hyper_param* hp, int eqn_solver);
 int sanm_anm_eqn_solver_create(const sanm_graph* g, int out_var, const sanm_sparse_desc* remap_inp,
                                const sanm_sparse_desc* remap_out, const double* x0, const double* y,
                                int64_t n, const sanm_hyper_param* hp, sanm_anm_solver** s);
+/* Tet-sharded ANMEqnSolver, one process per GPU.  Replaces ParallelTaylorCoeffProp's
+ * worker sharding (libsanm/symbolic.cpp:306-590): rank r owns tets
+ * [r*T/world, (r+1)*T/world) for the Taylor passes and the assembly; the nodal
+ * vectors f(x0), b_k (n doubles, once per order) and the Jacobian values (once per
+ * step) are summed across ranks through `allreduce`, which must perform an in-place
+ * sum of `count` doubles at the DEVICE pointer `buf` on all ranks and return 0
+ * (ncclAllReduce on RCCL; the linear solve is replicated).  Every rank passes the
+ * same graph, remaps, x0 and y. */
+typedef int (*sanm_allreduce_fn)(void* user, double* buf, int64_t count);
+int sanm_anm_eqn_solver_create_sharded(const sanm_graph* g, int out_var,
+                                       const sanm_sparse_desc* remap_inp,
+                                       const sanm_sparse_desc* remap_out, const double* x0,
+                                       const double* y, int64_t n, const sanm_hyper_param* hp, int rank,
+                                       int world, sanm_allreduce_fn allreduce, void* user,
+                                       sanm_anm_solver** s);
 /* ANMSolverVecScale: f(x) + t*v = 0 (anm.cpp:322-341) */
 int sanm_anm_vecscale_solver_create(const sanm_graph* g, int out_var,
                                     const sanm_sparse_desc* remap_inp,

@@ -77,7 +77,8 @@ SYMBOLS = [
     "sanm_taylor_create", "sanm_taylor_destroy", "sanm_taylor_push_xi",
     "sanm_taylor_compute_next_order_bias", "sanm_taylor_get_jacobian", "sanm_taylor_get_var",
     "sanm_taylor_reset",
-    "sanm_hyper_param_default", "sanm_anm_eqn_solver_create", "sanm_anm_vecscale_solver_create",
+    "sanm_hyper_param_default", "sanm_anm_eqn_solver_create", "sanm_anm_eqn_solver_create_sharded",
+    "sanm_anm_vecscale_solver_create",
     "sanm_anm_implicit_solver_create", "sanm_anm_solver_destroy", "sanm_anm_next_iter",
     "sanm_anm_update_approx", "sanm_anm_restart", "sanm_anm_time_kernel", "sanm_anm_pass_timing", "sanm_anm_converged", "sanm_anm_residual_rms", "sanm_anm_get_x",
     "sanm_anm_get_t_upper", "sanm_anm_get_t_max_a", "sanm_anm_solve_a", "sanm_anm_eval",
@@ -533,17 +534,40 @@ class _ANMSolver:
         return sp.csr_matrix((val, col.astype(np.int64), rp.astype(np.int64)), shape=(n.value, n.value))
 
 
-class ANMEqnSolver(_ANMSolver):
-    """libsanm/anm.h:245-283"""
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
 
-    def __init__(self, api, y: SymbolVar, remap_inp, remap_out, x0, f_y, hyper):
+
+class ANMEqnSolver(_ANMSolver):
+    """libsanm/anm.h:245-283.  ``shard=(rank, world, allreduce)`` runs the Taylor
+    passes and the assembly on this rank's tet range; ``allreduce(ptr, count)`` must
+    sum ``count`` doubles in place at device pointer ``ptr`` over all ranks
+    (see sanm_amd/dist.py)."""
+
+    def __init__(self, api, y: SymbolVar, remap_inp, remap_out, x0, f_y, hyper, shard=None):
         super().__init__(api)
         x0, f_y = _f64(x0).ravel(), _f64(f_y).ravel()
         self.n = x0.size
         self._keep = (y.graph, remap_inp, remap_out)
-        api.check(api.lib.sanm_anm_eqn_solver_create(y.graph.h, C.c_int(y.id), remap_inp.h, remap_out.h,
-                                                     _dp(x0), _dp(f_y), C.c_int64(self.n),
-                                                     C.byref(hyper), C.byref(self.h)))
+        if shard is None or shard[1] <= 1:
+            api.check(api.lib.sanm_anm_eqn_solver_create(y.graph.h, C.c_int(y.id), remap_inp.h, remap_out.h,
+                                                         _dp(x0), _dp(f_y), C.c_int64(self.n),
+                                                         C.byref(hyper), C.byref(self.h)))
+            return
+        rank, world, fn = shard
+
+        def _cb(user, ptr, count):
+            try:
+                fn(ptr, count)
+                return 0
+            except Exception as e:  # noqa: BLE001 - reported through the C error path
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._cb = ALLREDUCE_FN(_cb)  # keep the trampoline alive
+        api.check(api.lib.sanm_anm_eqn_solver_create_sharded(
+            y.graph.h, C.c_int(y.id), remap_inp.h, remap_out.h, _dp(x0), _dp(f_y), C.c_int64(self.n),
+            C.byref(hyper), C.c_int(rank), C.c_int(world), self._cb, None, C.byref(self.h)))
 
     def next_iter(self):
         self.api.check(self.api.lib.sanm_anm_next_iter(self.h))

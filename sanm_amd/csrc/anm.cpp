@@ -263,19 +263,31 @@ void PadeApproximation::eval_xt(double a, double* out) const {
 
 // ------------------------------------------------------------ AnmDriver --
 AnmDriver::AnmDriver(Backend* be, const Graph& g, int out_var, const SparseDesc& remap_inp,
-                     const SparseDesc& remap_out, int64_t nr_unknown, const HyperParam& hp)
-        : m_be{be}, m_hp{hp}, m_n{nr_unknown}, m_max_a_bound{poly::stable_x_range(hp.order)} {
+                     const SparseDesc& remap_out, int64_t nr_unknown, const HyperParam& hp,
+                     const ShardInfo& shard)
+        : m_be{be}, m_hp{hp}, m_n{nr_unknown}, m_max_a_bound{poly::stable_x_range(hp.order)},
+          m_shard{shard} {
     sanm_check(hp.order >= 2, "order=%d", hp.order);  // anm.cpp:108-110
     sanm_check(remap_inp.out_size % 9 == 0, "remap_inp must produce a (T,3,3) tensor");
     if (hp.xcoeff_l2_penalty != 0)
         sanm_throw(SANM_ERR_UNSUPPORTED, "xcoeff_l2_penalty (Tikhonov path) is not on the device path");
     const int64_t T = remap_inp.out_size / 9;
-    m_prog = std::make_unique<Program>(be, g, out_var, T, hp.order);
+    // this rank's tets: contiguous ranges like the reference's worker shards
+    // (libsanm/symbolic.cpp:525-536)
+    int64_t tb = 0, te = T;
+    if (m_shard.active()) {
+        sanm_check(m_shard.allreduce && m_shard.rank >= 0 && m_shard.rank < m_shard.world,
+                   "invalid shard description");
+        tb = (int64_t)m_shard.rank * T / m_shard.world;
+        te = (int64_t)(m_shard.rank + 1) * T / m_shard.world;
+        sanm_check(te > tb, "more ranks than tets");
+    }
+    m_prog = std::make_unique<Program>(be, g, out_var, te - tb, hp.order, tb, T);
     m_prog->set_remap_in(remap_inp.in_size, remap_inp.rowptr.data(), remap_inp.idx.data(),
                          remap_inp.coef.data());
-    m_remap_out = std::make_unique<DeviceRows>(be, remap_out, T, m_prog->Tpad());
+    m_remap_out = std::make_unique<DeviceRows>(be, remap_out, te - tb, m_prog->Tpad(), tb, te);
     m_pattern = std::make_unique<JacobianPattern>(be, remap_out, remap_inp, m_n, T, m_prog->Tpad(),
-                                                  m_prog->dev().odim);
+                                                  m_prog->dev().odim, tb, te);
     if (hp.solver_kind == 1) {
         const double* coords = remap_out.out_coords.size() == (size_t)m_n * 3 ? remap_out.out_coords.data() : nullptr;
         m_solver = make_direct_solver(be, *m_pattern, hp, coords);
@@ -298,6 +310,13 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g, int out_var, const SparseDesc&
 }
 
 AnmDriver::~AnmDriver() = default;
+
+void AnmDriver::allreduce(double* buf, int64_t count) {
+    if (!m_shard.active()) return;
+    m_be->sync();  // the collective runs outside this backend's stream
+    int rc = m_shard.allreduce(m_shard.user, buf, count);
+    if (rc != 0) sanm_throw(SANM_ERR_HIP, "all-reduce callback failed with code %d", rc);
+}
 
 void AnmDriver::init_xt0(const double* x_host, double t) {
     std::vector<double> h(m_n + 1);
@@ -326,6 +345,7 @@ void AnmDriver::solve_expansion_coeffs() {
         ScopedTimer t{this, "taylor_order0"};
         be->run_pass(P, PASS_EVAL0, 0, m_xt0.p());
         be->gather_rows(m_remap_out->dev(), m_prog->out_coef0(), m_fx0.p());
+        allreduce(m_fx0.p(), n);
     }
     if (!on_fx0_computed(m_fx0.p())) return;
 
@@ -341,6 +361,8 @@ void AnmDriver::solve_expansion_coeffs() {
             ScopedTimer t{this, "taylor_next_order"};
             be->run_pass(P, PASS_BIAS, i, nullptr);
             be->gather_rows(m_remap_out->dev(), m_prog->out_bias(), m_bi.p());
+            // the one collective per Taylor order: sum of the per-shard nodal bias (n doubles)
+            if (i > 1) allreduce(m_bi.p(), n);
         }
         double ti;
         const double* xbi;
@@ -351,6 +373,8 @@ void AnmDriver::solve_expansion_coeffs() {
                 if (m_pattern->has_t())
                     be->assemble(m_pattern->assembly_grad_t(), m_prog->placeholder_jac(),
                                  m_grad_t_buf.p());
+                allreduce(m_pattern->csr().val, m_pattern->nnz());
+                if (m_pattern->has_t()) allreduce(m_grad_t_buf.p(), n);
                 sanm_check(be->count_nonfinite(m_pattern->nnz(), m_pattern->csr().val) == 0,
                            "non-finite Jacobian coefficient");  // sparse_solver.cpp:288-289
             }
@@ -502,8 +526,8 @@ void AnmDriver::get_xt_coeff(int i, double* dst) const {
 AnmSolverVecScale::AnmSolverVecScale(Backend* be, const Graph& g, int out_var,
                                      const SparseDesc& remap_inp, const SparseDesc& remap_out,
                                      const double* x0, int64_t n, double t0, const double* v,
-                                     const HyperParam& hp, bool defer_solve)
-        : AnmDriver(be, g, out_var, remap_inp, remap_out, n, hp) {
+                                     const HyperParam& hp, bool defer_solve, const ShardInfo& shard)
+        : AnmDriver(be, g, out_var, remap_inp, remap_out, n, hp, shard) {
     // libsanm/anm.cpp:322-341
     sanm_check(remap_inp.in_size == n, "linear map expects %ld inputs, got x0 of %ld",
                (long)remap_inp.in_size, (long)n);
@@ -532,8 +556,8 @@ bool AnmSolverVecScale::on_fx0_computed(const double* fx_dev) {
 // --------------------------------------------------------- AnmEqnSolver --
 AnmEqnSolver::AnmEqnSolver(Backend* be, const Graph& g, int out_var, const SparseDesc& remap_inp,
                            const SparseDesc& remap_out, const double* x0, const double* y,
-                           int64_t n, const HyperParam& hp)
-        : AnmSolverVecScale(be, g, out_var, remap_inp, remap_out, x0, n, 0, nullptr, hp, true),
+                           int64_t n, const HyperParam& hp, const ShardInfo& shard)
+        : AnmSolverVecScale(be, g, out_var, remap_inp, remap_out, x0, n, 0, nullptr, hp, true, shard),
           m_converge_rms{hp.converge_rms} {
     // libsanm/anm.cpp:446-462: f(x) - f(x0) + t*(y + f(x0)) = 0, t from 0
     init_xt0(x0, 0);

@@ -36,6 +36,19 @@ struct HyperParam {  // libsanm/anm.h:100-114, :247-251
     int profile = 0;      // synchronise + time every phase
 };
 
+//! tet-sharded execution over several ranks (one process per GPU).  The reference's
+//! counterpart is ParallelTaylorCoeffProp (libsanm/symbolic.cpp:306-590): worker w
+//! owns tets [w*T/nr, (w+1)*T/nr) and the partial results are gathered; here every
+//! rank owns such a range and the assembled vectors (b_k, f(x0), Jacobian values) are
+//! summed with one all-reduce each -- RCCL over xGMI, supplied by the caller.
+struct ShardInfo {
+    int rank = 0, world = 1;
+    //! in-place sum over all ranks of `count` doubles at device pointer `buf`; 0 = ok
+    int (*allreduce)(void* user, double* buf, int64_t count) = nullptr;
+    void* user = nullptr;
+    bool active() const { return world > 1; }
+};
+
 class DVec {
 public:
     DVec() = default;
@@ -109,7 +122,8 @@ private:
 class AnmDriver {  // ANMDriverHelper, libsanm/anm.h:96-207
 public:
     AnmDriver(Backend* be, const Graph& g, int out_var, const SparseDesc& remap_inp,
-              const SparseDesc& remap_out, int64_t nr_unknown, const HyperParam& hp);
+              const SparseDesc& remap_out, int64_t nr_unknown, const HyperParam& hp,
+              const ShardInfo& shard = {});
     virtual ~AnmDriver();
 
     void update_approx();
@@ -141,6 +155,8 @@ protected:
     const HyperParam m_hp;
     const int64_t m_n;
     const double m_max_a_bound;
+    const ShardInfo m_shard;
+    void allreduce(double* buf, int64_t count);
     std::unique_ptr<Program> m_prog;
     std::unique_ptr<DeviceRows> m_remap_out;
     std::unique_ptr<JacobianPattern> m_pattern;
@@ -174,7 +190,8 @@ class AnmSolverVecScale : public AnmDriver {  // libsanm/anm.h:209-243
 public:
     AnmSolverVecScale(Backend* be, const Graph& g, int out_var, const SparseDesc& remap_inp,
                       const SparseDesc& remap_out, const double* x0, int64_t n, double t0,
-                      const double* v, const HyperParam& hp, bool defer_solve = false);
+                      const double* v, const HyperParam& hp, bool defer_solve = false,
+                      const ShardInfo& shard = {});
 
 protected:
     DVec m_v;
@@ -187,7 +204,7 @@ class AnmEqnSolver final : public AnmSolverVecScale {  // libsanm/anm.h:245-283
 public:
     AnmEqnSolver(Backend* be, const Graph& g, int out_var, const SparseDesc& remap_inp,
                  const SparseDesc& remap_out, const double* x0, const double* y, int64_t n,
-                 const HyperParam& hp);
+                 const HyperParam& hp, const ShardInfo& shard = {});
     double residual_rms() const { return m_residual_rms; }
     bool converged() const { return m_converged; }
     AnmEqnSolver& next_iter();

@@ -355,6 +355,26 @@ int sanm_anm_eqn_solver_create(const sanm_graph* g, int out_var, const sanm_spar
         *s = p.release();
     });
 }
+int sanm_anm_eqn_solver_create_sharded(const sanm_graph* g, int out_var,
+                                       const sanm_sparse_desc* remap_inp,
+                                       const sanm_sparse_desc* remap_out, const double* x0,
+                                       const double* y, int64_t n, const sanm_hyper_param* hp, int rank,
+                                       int world, sanm_allreduce_fn allreduce, void* user,
+                                       sanm_anm_solver** s) {
+    return guard([&] {
+        auto p = std::make_unique<sanm_anm_solver>();
+        ShardInfo sh;
+        sh.rank = rank;
+        sh.world = world;
+        sh.allreduce = allreduce;
+        sh.user = user;
+        auto* e = new AnmEqnSolver(backend(), g->g, out_var, remap_inp->d, remap_out->d, x0, y, n,
+                                   to_hp(hp), sh);
+        p->drv.reset(e);
+        p->eqn = e;
+        *s = p.release();
+    });
+}
 int sanm_anm_vecscale_solver_create(const sanm_graph* g, int out_var,
                                     const sanm_sparse_desc* remap_inp,
                                     const sanm_sparse_desc* remap_out, const double* x0, double t0,

@@ -179,7 +179,10 @@ void Graph::batched_svd_w(int x, bool require_rotation, int out[3]) {
 }
 
 // ---------------------------------------------------------------- Program --
-Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_order) : m_be{be} {
+Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_order,
+                 int64_t tet_begin, int64_t T_global)
+        : m_be{be}, m_tet_begin{tet_begin} {
+    if (T_global < 0) T_global = T;
     sanm_check(out_var >= 0 && out_var < (int)g.vars.size(), "invalid output var");
     sanm_check(T > 0 && max_order >= 1, "invalid T/order");
     const int64_t Tpad = (T + 63) / 64 * 64;
@@ -324,13 +327,13 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
         const GraphOp& op = g.ops[oi];
         if (op.type != OP_CONSTANT) continue;
         const VarDesc& d = m_vars[m_var_map[op.out[0]]];
-        sanm_check(op.batch == T || op.batch == 1,
-                   "ConstantOprMeta shape mismatch: tot_batch=%ld value_shape=%ld", (long)T,
-                   (long)op.batch);
+        sanm_check(op.batch == T_global || op.batch == 1,
+                   "ConstantOprMeta shape mismatch in data parallel: tot_batch=%ld value_shape=%ld",
+                   (long)T_global, (long)op.batch);
         soa.assign((size_t)d.size * Tpad, 0.0);
         for (int64_t e = 0; e < T; ++e)
             for (int c = 0; c < d.size; ++c)
-                soa[c * Tpad + e] = op.value[(op.batch == 1 ? 0 : e) * d.size + c];
+                soa[c * Tpad + e] = op.value[(op.batch == 1 ? 0 : tet_begin + e) * d.size + c];
         // pad lanes replicate tet 0 so that padded lanes stay finite
         for (int64_t e = T; e < Tpad; ++e)
             for (int c = 0; c < d.size; ++c) soa[c * Tpad + e] = soa[c * Tpad];
@@ -362,7 +365,8 @@ void Program::set_remap_in(int64_t n_in, const uint64_t* rowptr, const uint64_t*
                            const double* coef) {
     const int64_t T = m_dev.T, Tpad = m_dev.Tpad;
     int nslot = 0;
-    for (int64_t o = 0; o < T * 9; ++o) {
+    const int64_t o0 = m_tet_begin * 9;
+    for (int64_t o = o0; o < o0 + T * 9; ++o) {
         sanm_check(rowptr[o + 1] >= rowptr[o], "remap_in: rowptr not monotone");
         nslot = std::max<int>(nslot, rowptr[o + 1] - rowptr[o]);
     }
@@ -372,7 +376,7 @@ void Program::set_remap_in(int64_t n_in, const uint64_t* rowptr, const uint64_t*
     std::vector<double> hcoef((size_t)nslot * 9 * Tpad, 0.0);
     for (int64_t e = 0; e < T; ++e)
         for (int c = 0; c < 9; ++c) {
-            int64_t o = e * 9 + c;
+            int64_t o = (m_tet_begin + e) * 9 + c;
             int s = 0;
             for (uint64_t p = rowptr[o]; p < rowptr[o + 1]; ++p, ++s) {
                 sanm_check((int64_t)idx[p] < n_in, "remap_in: index %lu out of range",

@@ -79,14 +79,19 @@ private:
 // device.  Owns the arena.
 class Program {
 public:
-    Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_order);
+    //! T: tets handled by this program.  When the batch is sharded (one rank of a
+    //! tet-sharded run) the program covers tets [tet_begin, tet_begin + T) of
+    //! T_global and batched constants are sliced accordingly (ConstantOprMeta
+    //! under ParallelTaylorCoeffProp, libsanm/oprs/misc.cpp:51-72).
+    Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_order,
+            int64_t tet_begin = 0, int64_t T_global = -1);
     ~Program();
     Program(const Program&) = delete;
 
     //! attach the remap_in table (ELL), converting flattened AoS output
     //! indices e*9+c (fea/mesh_template.h:73-110) to the SoA layout
     void set_remap_in(int64_t n_in, const uint64_t* rowptr, const uint64_t* idx,
-                      const double* coef);
+                      const double* coef);  // rowptr indexed by GLOBAL output element
 
     ProgramDev dev() const { return m_dev; }
     int64_t T() const { return m_dev.T; }
@@ -116,6 +121,7 @@ private:
     int m_placeholder_var = -1;
     int64_t m_arena_doubles = 0, m_jac_begin = 0, m_jac_end = 0;
     int64_t m_n_in = 0;
+    int64_t m_tet_begin = 0;
     void* m_d_ops = nullptr;
     void* m_d_vars = nullptr;
     void* m_d_rin_idx = nullptr;

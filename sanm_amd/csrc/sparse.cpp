@@ -22,22 +22,33 @@ SparseDesc::SparseDesc(int64_t out_size_, int64_t in_size_, const uint64_t* rp, 
                    (unsigned long)idx[p], (long)in_size);
 }
 
-DeviceRows::DeviceRows(Backend* be, const SparseDesc& d, int64_t T, int64_t Tpad) : m_be{be} {
-    sanm_check(d.in_size == T * 9, "remap_out expects a (T,3,3) input, got %ld elements",
+DeviceRows::DeviceRows(Backend* be, const SparseDesc& d, int64_t T, int64_t Tpad, int64_t tet_begin,
+                       int64_t tet_end)
+        : m_be{be} {
+    sanm_check(d.in_size % 9 == 0, "remap_out expects a (T,3,3) input, got %ld elements",
                (long)d.in_size);
+    if (tet_end < 0) tet_end = d.in_size / 9;
+    sanm_check(tet_end - tet_begin == T, "remap_out: shard size mismatch");
     sanm_check(d.idx.size() < std::numeric_limits<uint32_t>::max(), "remap_out too large");
-    std::vector<uint32_t> ptr(d.out_size + 1), idx(d.idx.size());
-    for (int64_t i = 0; i <= d.out_size; ++i) ptr[i] = d.rowptr[i];
-    for (size_t p = 0; p < d.idx.size(); ++p) {
-        uint64_t e = d.idx[p] / 9, c = d.idx[p] % 9;
-        idx[p] = c * Tpad + e;
+    std::vector<uint32_t> ptr(d.out_size + 1, 0), idx;
+    std::vector<double> coef;
+    idx.reserve(d.idx.size());
+    coef.reserve(d.idx.size());
+    for (int64_t i = 0; i < d.out_size; ++i) {
+        for (uint64_t p = d.rowptr[i]; p < d.rowptr[i + 1]; ++p) {
+            int64_t e = d.idx[p] / 9, c = d.idx[p] % 9;
+            if (e < tet_begin || e >= tet_end) continue;
+            idx.push_back(c * Tpad + (e - tet_begin));
+            coef.push_back(d.coef[p]);
+        }
+        ptr[i + 1] = idx.size();
     }
     m_ptr = be->alloc(ptr.size() * 4);
     m_idx = be->alloc(std::max<size_t>(idx.size(), 1) * 4);
     m_coef = be->alloc(std::max<size_t>(idx.size(), 1) * 8);
     be->h2d(m_ptr, ptr.data(), ptr.size() * 4);
     be->h2d(m_idx, idx.data(), idx.size() * 4);
-    be->h2d(m_coef, d.coef.data(), idx.size() * 8);
+    be->h2d(m_coef, coef.data(), idx.size() * 8);
     m_dev = {static_cast<uint32_t*>(m_ptr), static_cast<uint32_t*>(m_idx),
              static_cast<double*>(m_coef), d.out_size};
 }
@@ -57,8 +68,9 @@ T* JacobianPattern::upload(const std::vector<T>& v) {
 }
 
 JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const SparseDesc& ri, int64_t n,
-                                 int64_t T, int64_t Tpad, int odim)
+                                 int64_t T, int64_t Tpad, int odim, int64_t tet_begin, int64_t tet_end)
         : m_be{be} {
+    if (tet_end < 0) tet_end = T;
     const int idim = 9;
     sanm_check(ro.out_size == n, "remap_out must produce %ld unknowns, got %ld", (long)n,
                (long)ro.out_size);
@@ -69,6 +81,7 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
     struct Contrib {
         uint32_t col, jidx;
         double coef;
+        bool mine;  // the tet belongs to this rank's shard
     };
     std::vector<Contrib> row;
     std::vector<uint32_t> rowptr(n + 1, 0), col;
@@ -84,10 +97,11 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
             double c_out = ro.coef[p];
             for (int m = 0; m < idim; ++m) {
                 uint64_t irow = b * idim + m;
-                uint64_t jidx = ((uint64_t)o * idim + m) * Tpad + b;
+                const bool mine = (int64_t)b >= tet_begin && (int64_t)b < tet_end;
+                uint64_t jidx = mine ? ((uint64_t)o * idim + m) * Tpad + (b - tet_begin) : 0;
                 sanm_check(jidx < std::numeric_limits<uint32_t>::max(), "mesh too large for u32 jidx");
                 for (uint64_t q = ri.rowptr[irow]; q < ri.rowptr[irow + 1]; ++q) {
-                    row.push_back({(uint32_t)ri.idx[q], (uint32_t)jidx, c_out * ri.coef[q]});
+                    row.push_back({(uint32_t)ri.idx[q], (uint32_t)jidx, c_out * ri.coef[q], mine});
                 }
             }
         }
@@ -99,6 +113,7 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
             uint32_t c = row[k].col;
             if ((int64_t)c == n) {  // the t column -> grad_t
                 for (; k < row.size() && row[k].col == c; ++k) {
+                    if (!row[k].mine) continue;
                     tjidx.push_back(row[k].jidx);
                     tcoef.push_back(row[k].coef);
                 }
@@ -107,6 +122,7 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
             col.push_back(c);
             any = true;
             for (; k < row.size() && row[k].col == c; ++k) {
+                if (!row[k].mine) continue;
                 ajidx.push_back(row[k].jidx);
                 acoef.push_back(row[k].coef);
             }

@@ -35,7 +35,10 @@ struct SparseDesc {
 //! (T,9) AoS tensor, re-indexed to the SoA layout [c][Tpad]
 class DeviceRows {
 public:
-    DeviceRows(Backend* be, const SparseDesc& d, int64_t T, int64_t Tpad);
+    //! only the entries whose input tet lies in [tet_begin, tet_end) are kept (all of
+    //! them by default); T / Tpad describe the local SoA tensor
+    DeviceRows(Backend* be, const SparseDesc& d, int64_t T, int64_t Tpad, int64_t tet_begin = 0,
+               int64_t tet_end = -1);
     ~DeviceRows();
     SparseRowsDev dev() const { return m_dev; }
 
@@ -49,8 +52,10 @@ class JacobianPattern {
 public:
     //! n = number of unknowns; remap_in may have n or n+1 columns (column n is
     //! the continuation parameter t of ANMImplicitSolver, anm.cpp:575-579)
+    //! T: global number of tets; contributions of tets outside [tet_begin, tet_end)
+    //! are left to the other ranks (the CSR pattern itself is always the global one)
     JacobianPattern(Backend* be, const SparseDesc& remap_out, const SparseDesc& remap_in, int64_t n,
-                    int64_t T, int64_t Tpad, int odim);
+                    int64_t T, int64_t Tpad, int odim, int64_t tet_begin = 0, int64_t tet_end = -1);
     ~JacobianPattern();
 
     CsrDev csr() const { return m_csr; }

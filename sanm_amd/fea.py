@@ -92,7 +92,7 @@ def setup_gravity(api: Api, mesh: Mesh, config):
 class GravityRun:
     """run_and_save (fea/main.cpp:247-433), ANM branch, on the device path."""
 
-    def __init__(self, api: Api, mesh: Mesh, config, inverse=False, **hyper_over):
+    def __init__(self, api: Api, mesh: Mesh, config, inverse=False, shard=None, **hyper_over):
         self.api = api
         self.mesh = mesh
         self.config = config
@@ -105,13 +105,14 @@ class GravityRun:
         self.hyper = hyper_from_config(api, config, **hyper_over)
         self.time_prep = time.perf_counter() - t0
         self.solver = None
+        self.shard = shard
         self.rms = []
         self.time_solve = 0.0
 
     def construct(self):
         t0 = time.perf_counter()
         self.solver = ANMEqnSolver(self.api, self.model.y, self.model.lt_inp, self.model.lt_out,
-                                   self.model.x0(), self.f_sub, self.hyper)
+                                   self.model.x0(), self.f_sub, self.hyper, shard=self.shard)
         self.rms = [self.solver.residual_rms()]
         self.time_solve += time.perf_counter() - t0
         return self
