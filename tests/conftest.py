@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # torch must load its bundled HIP runtime before libsanm_hip.so loads the system one
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
