@@ -341,6 +341,7 @@ class HipBackend final : public Backend {
     double* m_scalar_host = nullptr;  // pinned
     double* m_pcg_w[4] = {nullptr, nullptr, nullptr, nullptr};
     PcgScalars* m_pcg_sc = nullptr;
+    static constexpr int kSolveLdsMax = 150 * 1024;
     PcgScalars* m_pcg_sc_host = nullptr;
     size_t m_pcg_n = 0;
     bool m_time_passes = false;
@@ -568,25 +569,51 @@ public:
         return *hs;
     }
 
+    // Level solve kernels are instantiated for R rows per wave and U preloaded 64-column chunks per row
+    // with R * U == 16: U covers the level's widest row where it can, R takes what is left.
+    template <int R, int U>
+    void launch_level_solve(bool fwd, const MfDev& mf, const MfSchedule::Level& L) {
+        using namespace mfk;
+        const int cnt = L.front_end - L.front_begin;
+        const int rows = fwd ? L.max_m : L.max_k;
+        const size_t lds = (size_t)(fwd ? L.max_k : L.max_m) * sizeof(double);
+        auto kern = fwd ? fwd_level_kernel<R, U> : bwd_level_kernel<R, U>;
+        if (lds > 48 * 1024) {
+            if (lds > (size_t)kSolveLdsMax)
+                sanm_throw(SANM_ERR_UNSUPPORTED,
+                           "front of %d rows exceeds the LDS staging of the solve kernels", L.max_m);
+            HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          kSolveLdsMax));
+        }
+        hipLaunchKernelGGL(kern, dim3((rows + 4 * R - 1) / (4 * R), cnt), dim3(256), lds, m_stream, mf,
+                           L.front_begin);
+    }
+    void level_solve(bool fwd, const MfDev& mf, const MfSchedule::Level& L) {
+        const int width = fwd ? L.max_k : L.max_m;  // longest row
+        const int64_t rows = fwd ? L.sum_m : L.sum_k;
+        int u = 1;
+        while (u < 16 && 64 * u < width) u *= 2;
+        // enough workgroups to fill the chip comes first, then R * U <= 16 row chunks in registers
+        int r = rows >= 16 * 2048 ? 4 : (rows >= 8 * 2048 ? 2 : 1);
+        while (r * u > 16) r /= 2;
+#define SANM_LS(R, U)                         \
+    if (r == R && u == U) {                   \
+        launch_level_solve<R, U>(fwd, mf, L); \
+        return;                               \
+    }
+        SANM_LS(4, 1) SANM_LS(4, 2) SANM_LS(4, 4)
+        SANM_LS(2, 1) SANM_LS(2, 2) SANM_LS(2, 4) SANM_LS(2, 8)
+        SANM_LS(1, 1) SANM_LS(1, 2) SANM_LS(1, 4) SANM_LS(1, 8) SANM_LS(1, 16)
+#undef SANM_LS
+        sanm_throw(SANM_ERR_ASSERT, "no level solve kernel for R=%d U=%d", r, u);
+    }
+
     void mf_solve(const MfDev& mf, const MfSchedule& sch, const double* b, double* x) override {
         using namespace mfk;
         hipLaunchKernelGGL(permute_in_kernel, dim3(nblk(mf.n, 256)), dim3(256), 0, m_stream, mf.n,
                            mf.perm, b, mf.work);
-        for (size_t li = 0; li < sch.levels.size(); ++li) {
-            const auto& L = sch.levels[li];
-            const int cnt = L.front_end - L.front_begin;
-            if (li > 0)  // leaves have no children to gather from
-                hipLaunchKernelGGL(fwd_gather_kernel, dim3((L.max_k + 255) / 256, cnt), dim3(256), 0,
-                                   m_stream, mf, L.front_begin);
-            hipLaunchKernelGGL(fwd_mv_kernel, dim3((L.max_m + 3) / 4, cnt), dim3(256), 0, m_stream, mf,
-                               L.front_begin);
-        }
-        for (int li = (int)sch.levels.size() - 1; li >= 0; --li) {
-            const auto& L = sch.levels[li];
-            const int cnt = L.front_end - L.front_begin;
-            hipLaunchKernelGGL(bwd_mv_kernel, dim3((L.max_k + 3) / 4, cnt), dim3(256), 0, m_stream, mf,
-                               L.front_begin);
-        }
+        for (size_t li = 0; li < sch.levels.size(); ++li) level_solve(true, mf, sch.levels[li]);
+        for (int li = (int)sch.levels.size() - 1; li >= 0; --li) level_solve(false, mf, sch.levels[li]);
         hipLaunchKernelGGL(permute_out_kernel, dim3(nblk(mf.n, 256)), dim3(256), 0, m_stream, mf.n,
                            mf.perm, mf.work, x);
         HIP_CHECK(hipGetLastError());

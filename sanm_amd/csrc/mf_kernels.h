@@ -54,15 +54,29 @@ __global__ void __launch_bounds__(256) extend_add_kernel(MfDev mf, const int32_t
 }
 
 // In-LDS LU of a diagonal tile (kb pivots, no pivoting) by a 256-thread
-// workgroup, followed by the inverses of the extended tile factors
+// workgroup, together with the inverses of the extended tile factors
 //   Lext = [[L11,0],[L21,I]] (unit lower),  Uext = [[U11,U12],[0,I]] (upper)
 // written to D = [Lext^-1 | Uext^-1].  On entry T holds the tile (synchronised);
 // on exit T holds the packed factors (synchronised).
-__device__ __forceinline__ void tile_factor(double (*T)[TPAD], double (*LI)[TPAD], double (*UI)[TPAD],
+//
+// The inverses ride along with the elimination sweep: step j applies the
+// elementary matrix M_j = I - l_j e_j^T to the trailing columns tc > j of T, and
+// the lanes of the columns tc <= j (idle in a plain right-looking LU) apply the
+// same M_j to LI (which therefore ends as M_{kb-1}...M_0 = Lext^-1) and the
+// analogous M'_j built from row j of U to UT (ending as the inverse of the unit
+// lower factor of Uext^T; Uext^-1[a][b] = UT[b][a] / d_b).  Row j of LI / UT is
+// final before step j and only its first j+1 entries are non-zero.
+__device__ __forceinline__ void tile_factor(double (*T)[TPAD], double (*LI)[TPAD], double (*UT)[TPAD],
                                             int kb, int tid, double* D, int32_t* status) {
     const int tc = tid % NB, tr = tid / NB;  // tr in 0..7
-    // right-looking elimination; column j is left unscaled during the sweep (later
-    // steps never read it), so one barrier per step suffices
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int r = tr + 8 * s;
+        LI[r][tc] = UT[r][tc] = (r == tc) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    // column j of T is left unscaled during the sweep (later steps never read it),
+    // so one barrier per step suffices
     for (int j = 0; j < kb; ++j) {
         double piv = T[j][j];
         if (!(fabs(piv) > 1e-290)) {
@@ -74,63 +88,33 @@ __device__ __forceinline__ void tile_factor(double (*T)[TPAD], double (*LI)[TPAD
             const double u = T[j][tc];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                int r = tr + 8 * s;
+                const int r = tr + 8 * s;
                 if (r > j) T[r][tc] -= (T[r][j] * inv) * u;
+            }
+        } else {
+            const double lj = LI[j][tc], uj = UT[j][tc];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int r = tr + 8 * s;
+                if (r > j) {
+                    LI[r][tc] -= (T[r][j] * inv) * lj;
+                    UT[r][tc] -= (T[j][r] * inv) * uj;
+                }
             }
         }
         __syncthreads();
     }
-    // scale the L columns
+    // scale the L columns; emit the inverses
+    const double dc = (tc < kb && fabs(T[tc][tc]) > 1e-290) ? T[tc][tc] : 1.0;
+    const double dinv = 1.0 / dc;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        int r = tr + 8 * s;
-        if (tc < kb && r > tc) {
-            double d = T[tc][tc];
-            T[r][tc] /= (fabs(d) > 1e-290) ? d : 1.0;
-        }
-    }
-    __syncthreads();
-    // column c of each inverse by substitution; the inverse columns live in LDS
-    // (LI / UI), lanes 0..31 of wave 0 build Lext^-1, lanes 0..31 of wave 1 Uext^-1
-    const int c = tid & 63;
-    if (tid < NB) {
-        for (int i = 0; i < NB; ++i) {
-            double v0 = (i == c) ? 1.0 : 0.0, v1 = 0, v2 = 0, v3 = 0;
-            const int lim = min(i, kb);
-            int q = 0;
-            for (; q + 3 < lim; q += 4) {  // four independent LDS load pairs in flight
-                v0 -= T[i][q] * LI[q][c];
-                v1 -= T[i][q + 1] * LI[q + 1][c];
-                v2 -= T[i][q + 2] * LI[q + 2][c];
-                v3 -= T[i][q + 3] * LI[q + 3][c];
-            }
-            for (; q < lim; ++q) v0 -= T[i][q] * LI[q][c];
-            LI[i][c] = (i < c) ? 0.0 : (v0 + v1) + (v2 + v3);
-        }
-    } else if (tid >= 64 && tid < 64 + NB) {
-        for (int i = NB - 1; i >= 0; --i) {
-            double v0 = (i == c) ? 1.0 : 0.0, v1 = 0, v2 = 0, v3 = 0;
-            if (i < kb) {
-                int q = i + 1;
-                for (; q + 3 < NB; q += 4) {
-                    v0 -= T[i][q] * UI[q][c];
-                    v1 -= T[i][q + 1] * UI[q + 1][c];
-                    v2 -= T[i][q + 2] * UI[q + 2][c];
-                    v3 -= T[i][q + 3] * UI[q + 3][c];
-                }
-                for (; q < NB; ++q) v0 -= T[i][q] * UI[q][c];
-                double d = T[i][i];
-                v0 = ((v0 + v1) + (v2 + v3)) / ((fabs(d) > 1e-290) ? d : 1.0);
-            }
-            UI[i][c] = (i > c) ? 0.0 : v0;
-        }
-    }
-    __syncthreads();
-    for (int s = 0; s < 4; ++s) {
-        int r = tr + 8 * s;
+        const int r = tr + 8 * s;
+        if (tc < kb && r > tc) T[r][tc] *= dinv;
         D[r * NB + tc] = LI[r][tc];
-        D[NB * NB + r * NB + tc] = UI[r][tc];
+        D[NB * NB + r * NB + tc] = UT[tc][r] * dinv;
     }
+    __syncthreads();
 }
 
 // diagonal tile of panel p of every front of a level
@@ -380,84 +364,173 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// forward, step 1: t = w_own + (children's update entries mapped to own rows)
-__global__ void __launch_bounds__(256) fwd_gather_kernel(MfDev mf, int level_begin) {
-    const MfFrontDev f = mf.fronts[mf.level_fronts[level_begin + blockIdx.y]];
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= f.k) return;
-    const int32_t* gp = mf.gat_ptr + f.gat_off;
-    double v = mf.work[f.own_start + r];
-    for (int32_t s = gp[r]; s < gp[r + 1]; ++s) v += mf.upd_store[mf.gat_src[s]];
-    mf.work[f.own_start + r] = v;
+// Solve sweeps: one launch per level and direction.  With the augmented fronts a
+// front's forward step is one mat-vec [z; upd] = [L11^-1; -L21 L11^-1] t and its
+// backward step x_own = [U11^-1, -U11^-1 U12] [z; x_bnd].  A workgroup stages the
+// front's input vector in LDS once (adding the children's inbox slots on the
+// way, so no gather list is walked and no separate gather launch is needed) and
+// its 4 waves then take R rows each, one 64-lane dot product per row.
+//
+// These launches last a few microseconds and every dependent memory round trip
+// costs about one, so the kernels are written for a short dependency chain:
+// descriptor -> {row chunks, vector, inbox, destination slots} all in flight
+// together -> barrier -> FMAs -> wave reduction -> store.  The first U 64-column
+// chunks of every row are loaded to registers by unconditional (index-clamped)
+// loads BEFORE the staging barrier; U is chosen per level to cover its widest
+// front, so the loop over further chunks only runs for fronts beyond 64*U pivots.
+
+template <int R, int U>
+struct RowChunks {
+    double a[U][R];
+};
+
+// issue the loads of chunks c0 + 64u (u < U) of R rows; entries outside [cbeg, cend) read as 0
+template <int R, int U>
+__device__ __forceinline__ void rows_preload(RowChunks<R, U>& rc, const double* const (&rowp)[R],
+                                             const int (&cbeg)[R], const int (&cend)[R], int c0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int c = c0 + 64 * u;
+            const bool ok = c >= cbeg[q] && c < cend[q];
+            const double v = rowp[q][ok ? c : 0];
+            rc.a[u][q] = ok ? v : 0.0;
+        }
 }
 
-// forward, step 2: [z; upd] = [L11^-1; -L21 L11^-1] t (+ gathered on boundary rows);
-// one wave per row, rows of all fronts of the level in one launch
-__global__ void __launch_bounds__(256) fwd_mv_kernel(MfDev mf, int level_begin) {
-    const MfFrontDev f = mf.fronts[mf.level_fronts[level_begin + blockIdx.y]];
-    const int m = f.m, k = f.k;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int r = blockIdx.x * 4 + wv;
-    if (r >= m) return;
-    // row r of [L11^-1 ; -L21 L11^-1] = columns A of physical row r (own) or 2k + (r-k)
-    const int pr = r < k ? r : r + k;
-    const double* row = mf.front_store + f.off + (int64_t)pr * f.ld + k;
-    const double* t = mf.work + f.own_start;
-    const int cend = r < k ? r + 1 : k;  // L11^-1 is lower triangular
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    int c = lane;
-    for (; c + 192 < cend; c += 256) {  // 4 independent loads in flight per lane
-        a0 += row[c] * t[c];
-        a1 += row[c + 64] * t[c + 64];
-        a2 += row[c + 128] * t[c + 128];
-        a3 += row[c + 192] * t[c + 192];
+// acc[q] += sum_c row_q[c] * v[c] over c = c0, c0 + 64, ... inside [cbeg[q], cend[q]); v in LDS,
+// v[csafe] is an initialised entry (read, times zero, by lanes outside the range)
+template <int R, int U>
+__device__ __forceinline__ void rows_consume(const RowChunks<R, U>& rc, const double* const (&rowp)[R],
+                                             const int (&cbeg)[R], const int (&cend)[R], int cmax, int c0,
+                                             const double* v, int csafe, double (&acc)[R]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int c = c0 + 64 * u;
+        const double tv = v[c < cmax ? c : csafe];
+#pragma unroll
+        for (int q = 0; q < R; ++q) acc[q] += rc.a[u][q] * tv;
     }
-    for (; c < cend; c += 64) a0 += row[c] * t[c];
-    double acc = wave_sum((a0 + a1) + (a2 + a3));
-    if (lane == 0) {
-        if (r < k) {
-            mf.work2[f.own_start + r] = acc;
-        } else {
-            const int32_t* gp = mf.gat_ptr + f.gat_off;
-            double v = acc;
-            for (int32_t s = gp[r]; s < gp[r + 1]; ++s) v += mf.upd_store[mf.gat_src[s]];
-            mf.upd_store[f.upd_off + r - k] = v;
+    for (int c = c0 + 64 * U; c < cmax; c += 64) {
+        const double tv = v[c];
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+            if (c >= cbeg[q] && c < cend[q]) acc[q] += rowp[q][c] * tv;
+    }
+}
+
+template <int R, int U>
+__global__ void __launch_bounds__(256) fwd_level_kernel(MfDev mf, int level_begin) {
+    const MfFrontDev f = mf.lfronts[level_begin + blockIdx.y];
+    const int m = f.m, k = f.k;
+    const int rb = blockIdx.x * (4 * R);
+    if (rb >= m) return;
+    extern __shared__ double vs[];  // t = w_own + children's contributions (k entries)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double* inbox = mf.inbox_store + f.inbox_off;
+    // rows of this wave; boundary rows also pick up the children's entries and forward the sum to the parent
+    int r[R], cbeg[R], cend[R], dst[R];
+    const double* rowp[R];
+    double pre[R], acc[R];
+    int cmax = 0;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        r[q] = rb + wv * R + q;
+        const bool live = r[q] < m;
+        const int pr = r[q] < k ? r[q] : r[q] + k;  // physical row: columns A hold [L11^-1 ; -L21 L11^-1]
+        rowp[q] = mf.front_store + f.off + (int64_t)(live ? pr : 0) * f.ld + k;
+        cbeg[q] = 0;
+        cend[q] = !live ? 0 : (r[q] < k ? r[q] + 1 : k);  // L11^-1 is lower triangular
+        cmax = max(cmax, cend[q]);
+        acc[q] = 0;
+    }
+    RowChunks<R, U> rc;
+    rows_preload<R, U>(rc, rowp, cbeg, cend, lane);
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        pre[q] = 0;
+        dst[q] = -1;
+        if (r[q] >= k && r[q] < m) {
+            dst[q] = mf.upd_dst[f.bnd_off + r[q] - k];
+            for (int j = 0; j < f.nch; ++j) pre[q] += inbox[(int64_t)j * m + r[q]];
+        }
+    }
+    const int kneed = min(k, rb + 4 * R);  // own rows read t[0..r] only
+    for (int c = tid; c < kneed; c += 256) {
+        double v = mf.work[f.own_start + c];
+        for (int j = 0; j < f.nch; ++j) v += inbox[(int64_t)j * m + c];
+        vs[c] = v;
+    }
+    __syncthreads();
+    rows_consume<R, U>(rc, rowp, cbeg, cend, cmax, lane, vs, 0, acc);
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const double v = wave_sum(acc[q]);
+        if (lane == 0 && r[q] < m) {
+            if (r[q] < k)
+                mf.work2[f.own_start + r[q]] = v;
+            else
+                mf.inbox_store[dst[q]] = v + pre[q];
         }
     }
 }
 
-// backward: x_own = [U11^-1, -U11^-1 U12] [z; x_bnd]; one wave per row
-__global__ void __launch_bounds__(256) bwd_mv_kernel(MfDev mf, int level_begin) {
-    const MfFrontDev f = mf.fronts[mf.level_fronts[level_begin + blockIdx.y]];
+template <int R, int U>
+__global__ void __launch_bounds__(256) bwd_level_kernel(MfDev mf, int level_begin) {
+    const MfFrontDev f = mf.lfronts[level_begin + blockIdx.y];
     const int m = f.m, k = f.k;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int r = blockIdx.x * 4 + wv;
-    if (r >= k) return;
-    // row r of [U11^-1 , -U11^-1 U12] = physical row k + r: columns P then columns B
-    const double* row = mf.front_store + f.off + (int64_t)(k + r) * f.ld;
-    const double* z = mf.work2 + f.own_start;
+    const int rb = blockIdx.x * (4 * R);
+    if (rb >= k) return;
+    extern __shared__ double vs[];  // [z (k) ; x_bnd (m-k)]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // row r of [U11^-1 , -U11^-1 U12] is physical row k + r: columns P (upper triangular: from r on) and,
+    // one augmentation block further right, columns B; addressed as one virtual row over [r, m) whose
+    // entries c >= k sit at physical column c + k, matching the layout of vs.
+    int r[R], cbeg[R], cend[R];
+    const double* rowp[R];
+    double acc[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        r[q] = rb + wv * R + q;
+        const bool live = r[q] < k;
+        rowp[q] = mf.front_store + f.off + (int64_t)(k + (live ? r[q] : 0)) * f.ld;
+        cbeg[q] = r[q];
+        cend[q] = live ? m : 0;
+        acc[q] = 0;
+    }
+    const int c0 = rb + wv * R + lane;
+    double a[U][R];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int c = c0 + 64 * u;
+            const bool ok = c >= cbeg[q] && c < cend[q];
+            const double v = rowp[q][ok ? (c < k ? c : c + k) : 0];
+            a[u][q] = ok ? v : 0.0;
+        }
     const int32_t* bi = mf.bnd_idx + f.bnd_off;
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    int c = r + lane;  // U11^-1 is upper triangular
-    for (; c + 192 < k; c += 256) {
-        a0 += row[c] * z[c];
-        a1 += row[c + 64] * z[c + 64];
-        a2 += row[c + 128] * z[c + 128];
-        a3 += row[c + 192] * z[c + 192];
+    for (int c = rb + tid; c < m; c += 256) vs[c] = c < k ? mf.work2[f.own_start + c] : mf.work[bi[c - k]];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int c = c0 + 64 * u;
+        const double tv = vs[c < m ? c : rb];
+#pragma unroll
+        for (int q = 0; q < R; ++q) acc[q] += a[u][q] * tv;
     }
-    for (; c < k; c += 64) a0 += row[c] * z[c];
-    const double* rowb = row + 2 * k;  // boundary columns
-    const int nbnd = m - k;
-    c = lane;
-    for (; c + 192 < nbnd; c += 256) {
-        a0 += rowb[c] * mf.work[bi[c]];
-        a1 += rowb[c + 64] * mf.work[bi[c + 64]];
-        a2 += rowb[c + 128] * mf.work[bi[c + 128]];
-        a3 += rowb[c + 192] * mf.work[bi[c + 192]];
+    for (int c = c0 + 64 * U; c < m; c += 64) {
+        const double tv = vs[c];
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+            if (c >= cbeg[q] && c < cend[q]) acc[q] += rowp[q][c < k ? c : c + k] * tv;
     }
-    for (; c < nbnd; c += 64) a0 += rowb[c] * mf.work[bi[c]];
-    double acc = wave_sum((a0 + a1) + (a2 + a3));
-    if (lane == 0) mf.work[f.own_start + r] = acc;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const double v = wave_sum(acc[q]);
+        if (lane == 0 && r[q] < k) mf.work[f.own_start + r[q]] = v;
+    }
 }
 
 }  // namespace mfk

@@ -21,8 +21,8 @@ struct MfFrontDev {
     int32_t bnd_off;    // offset into bnd_idx (m-k entries, new numbering, ascending)
     int32_t parent;     // -1 for roots
     int32_t rel_off;    // offset into rel (m-k entries): position of each boundary row in the parent front
-    int32_t upd_off;    // offset of this front's update vector (m-k doubles) in the solve workspace
-    int32_t gat_off;    // offset into gat_ptr (m+1 entries): children's update entries feeding each row
+    int32_t nch;        // number of children
+    int32_t inbox_off;  // offset of this front's inbox (nch x m doubles, [child slot][logical row]) in inbox_store
 };
 
 // Everything the numeric kernels need, resident on the device.
@@ -31,10 +31,12 @@ struct MfDev {
     int32_t nr_front, nr_level;
     const MfFrontDev* fronts;
     const int32_t* level_fronts;  // front ids grouped by level, by decreasing k inside a level
+    const MfFrontDev* lfronts;    // fronts[level_fronts[i]]: the descriptors themselves in level order
+    const int32_t* upd_dst;       // parallel to bnd_idx: inbox_store slot (in the parent's inbox) of each boundary row
+    double* inbox_store;          // solve workspace: children's update entries, one slot per (child, parent row);
+                                  // slots no child writes stay zero forever
     const int32_t* bnd_idx;
     const int32_t* rel;
-    const int32_t* gat_ptr;       // per front row: range of gat_src
-    const int32_t* gat_src;       // indices into the update-vector workspace
     const int32_t* perm;          // original -> new numbering
     const int32_t* own_front;     // new index -> owning front (identity init of the augmentation)
     // scatter of A: front_store[a_dst[p]] = A.val[p]
@@ -42,12 +44,11 @@ struct MfDev {
     // extend-add: child lists per level and round
     double* front_store;          // sum of m*m
     double* dinv_store;
-    double* upd_store;            // solve workspace: concatenated update vectors
     double* work;                 // n doubles (permuted rhs / solution)
     double* work2;                // n doubles (forward-solved vector z)
     double* tmp_store;            // per-level workspace: L11^-1 F12 (k x b) and F21 U11^-1 (b x k) per front
     int32_t* status;              // [0]: number of bad pivots
-    int64_t front_store_size, dinv_store_size, upd_store_size;
+    int64_t front_store_size, dinv_store_size;
 };
 
 // Host-side schedule (what to launch, in which order).  Within a level the
@@ -58,6 +59,7 @@ struct MfSchedule {
         int32_t front_begin, front_end;  // into level_fronts
         int32_t nr_panel;
         int32_t max_m, max_k, max_b;
+        int64_t sum_m, sum_k;            // rows of the level's forward / backward solve
         std::vector<int32_t> panel_cnt;  // number of fronts with k > p*NB
         // extend-add rounds: round r holds the r-th child of every front of the
         // level; [begin,end) into ea_children

@@ -1,6 +1,8 @@
 #include "multifrontal.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <numeric>
@@ -426,7 +428,6 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     std::vector<MfFrontDev> fr(F);
     std::vector<int32_t> bnd_idx;
     int64_t off = 0, doff = 0;
-    int32_t upd = 0, gat = 0;
     for (int32_t f = 0; f < F; ++f) {
         fr[f].bnd_off = bnd_idx.size();
         for (int32_t t : bnd_sv[f])
@@ -442,10 +443,6 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
         fr[f].dinv_off = doff;
         doff += (int64_t)((fr[f].k + MF_NB - 1) / MF_NB) * 2 * MF_NB * MF_NB;
         fr[f].rel_off = fr[f].bnd_off;  // rel is parallel to bnd_idx
-        fr[f].upd_off = upd;
-        upd += b;
-        fr[f].gat_off = gat;
-        gat += fr[f].m + 1;
         max_front = std::max(max_front, fr[f].m);
         if (parent[f] < 0) root_pivots = std::max(root_pivots, fr[f].k);
         double k = fr[f].k, bb = b;
@@ -475,31 +472,25 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
             rel[fr[f].rel_off + j] = pos_in_front(parent[f], bnd_idx[fr[f].bnd_off + j]);
     }
 
-    // gather lists of the solve: which child update entries feed row r of front f
-    std::vector<int32_t> gat_ptr(gat, 0), gat_src;
+    // inboxes of the solve: child c (slot j of its parent p) stores the update entry of its
+    // boundary row i at inbox[p][j][logical row of i in p]; no gather lists are walked at solve time
+    std::vector<int32_t> upd_dst(bnd_idx.size(), -1);
+    int64_t inbox_doubles = 0;
     {
-        // logical row of a physical front position: own rows first, then boundary rows
         auto logical = [&](int32_t f, int32_t pos) { return pos < fr[f].k ? pos : pos - fr[f].k; };
-        for (int32_t f = 0; f < F; ++f)
-            for (int32_t c : children[f])
-                for (int32_t j = 0; j < fr[c].m - fr[c].k; ++j)
-                    gat_ptr[fr[f].gat_off + logical(f, rel[fr[c].rel_off + j]) + 1]++;
-        int32_t run = 0;
         for (int32_t f = 0; f < F; ++f) {
-            // local prefix sums, made global by adding the running total
-            int32_t base = fr[f].gat_off;
-            gat_ptr[base] = run;
-            for (int32_t r = 0; r < fr[f].m; ++r) {
-                run += gat_ptr[base + r + 1];
-                gat_ptr[base + r + 1] = run;
-            }
+            fr[f].nch = children[f].size();
+            fr[f].inbox_off = inbox_doubles;
+            inbox_doubles += (int64_t)fr[f].nch * fr[f].m;
+            sanm_check(inbox_doubles < (int64_t(1) << 31), "solve workspace exceeds 32-bit indexing");
         }
-        gat_src.assign(run, -1);
-        std::vector<int32_t> fill(gat_ptr);
         for (int32_t f = 0; f < F; ++f)
-            for (int32_t c : children[f])
-                for (int32_t j = 0; j < fr[c].m - fr[c].k; ++j)
-                    gat_src[fill[fr[f].gat_off + logical(f, rel[fr[c].rel_off + j])]++] = fr[c].upd_off + j;
+            for (size_t j = 0; j < children[f].size(); ++j) {
+                const int32_t c = children[f][j];
+                for (int32_t i = 0; i < fr[c].m - fr[c].k; ++i)
+                    upd_dst[fr[c].bnd_off + i] =
+                            fr[f].inbox_off + (int32_t)j * fr[f].m + logical(f, rel[fr[c].rel_off + i]);
+            }
     }
 
     // owner front of every new index
@@ -535,11 +526,14 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
         level_fronts.insert(level_fronts.end(), fs.begin(), fs.end());
         L.front_end = level_fronts.size();
         L.max_m = L.max_k = L.max_b = 0;
+        L.sum_m = L.sum_k = 0;
         size_t max_children = 0;
         for (int32_t f : fs) {
             L.max_m = std::max(L.max_m, fr[f].m);
             L.max_k = std::max(L.max_k, fr[f].k);
             L.max_b = std::max(L.max_b, fr[f].m - fr[f].k);
+            L.sum_m += fr[f].m;
+            L.sum_k += fr[f].k;
             max_children = std::max(max_children, children[f].size());
         }
         {
@@ -567,6 +561,20 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
         }
     }
 
+    if (std::getenv("SANM_MF_DEBUG")) {
+        for (int32_t h = 0; h < H; ++h) {
+            const auto& L = m_sched.levels[h];
+            int64_t solve_elems = 0;
+            for (int32_t i = L.front_begin; i < L.front_end; ++i) {
+                const auto& f = fr[level_fronts[i]];
+                solve_elems += (int64_t)(f.m + f.k) * f.k;
+            }
+            std::fprintf(stderr, "mf level %d: fronts=%d max_k=%d max_m=%d max_b=%d panels=%d solve_MB=%.2f\n", h,
+                         L.front_end - L.front_begin, L.max_k, L.max_m, L.max_b, L.nr_panel,
+                         solve_elems * 8 / 1e6);
+        }
+    }
+
     // device copies
     m_dev.n = n;
     m_dev.nnzA = nnzA;
@@ -574,20 +582,25 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     m_dev.nr_level = H;
     m_dev.fronts = upload(fr);
     m_dev.level_fronts = upload(level_fronts);
+    {
+        std::vector<MfFrontDev> lf(level_fronts.size());
+        for (size_t i = 0; i < lf.size(); ++i) lf[i] = fr[level_fronts[i]];
+        m_dev.lfronts = upload(lf);
+    }
+    m_dev.upd_dst = upload(upd_dst);
+    m_dev.inbox_store = static_cast<double*>(be->alloc(std::max<int64_t>(inbox_doubles, 1) * sizeof(double)));
+    be->zero(m_dev.inbox_store, std::max<int64_t>(inbox_doubles, 1) * sizeof(double));
+    m_bufs.push_back(m_dev.inbox_store);
     m_dev.bnd_idx = upload(bnd_idx);
     m_dev.rel = upload(rel);
-    m_dev.gat_ptr = upload(gat_ptr);
-    m_dev.gat_src = upload(gat_src);
     m_dev.perm = upload(perm);
     m_dev.own_front = upload(owner);
     m_dev.a_dst = upload(a_dst);
     m_sched.ea_children = upload(ea_children);
     m_dev.front_store_size = off;
     m_dev.dinv_store_size = doff;
-    m_dev.upd_store_size = std::max(upd, 1);
     m_dev.front_store = static_cast<double*>(be->alloc(off * sizeof(double)));
     m_dev.dinv_store = static_cast<double*>(be->alloc(std::max<int64_t>(doff, 1) * sizeof(double)));
-    m_dev.upd_store = static_cast<double*>(be->alloc(m_dev.upd_store_size * sizeof(double)));
     m_dev.work = static_cast<double*>(be->alloc(n * sizeof(double)));
     m_dev.work2 = static_cast<double*>(be->alloc(n * sizeof(double)));
     m_bufs.push_back(m_dev.work2);
@@ -597,7 +610,6 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     be->zero(m_dev.status, 64);
     m_bufs.push_back(m_dev.front_store);
     m_bufs.push_back(m_dev.dinv_store);
-    m_bufs.push_back(m_dev.upd_store);
     m_bufs.push_back(m_dev.work);
     m_bufs.push_back(m_dev.status);
 }

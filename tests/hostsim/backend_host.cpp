@@ -145,14 +145,14 @@ struct HostMf {
         std::vector<double> t;
         for (const auto& L : sch.levels)  // forward
             for (int32_t q = L.front_begin; q < L.front_end; ++q) {
-                const MfFrontDev& f = mf.fronts[mf.level_fronts[q]];
+                const MfFrontDev& f = mf.lfronts[q];
                 const double* F = mf.front_store + f.off;
                 const int m = f.m, k = f.k;
                 t.assign(m, 0.0);
                 for (int r = 0; r < k; ++r) t[r] = w[f.own_start + r];
-                const int32_t* gp = mf.gat_ptr + f.gat_off;
-                for (int r = 0; r < m; ++r)
-                    for (int32_t s = gp[r]; s < gp[r + 1]; ++s) t[r] += mf.upd_store[mf.gat_src[s]];
+                // children's update entries arrive through the inbox (one slot per child and row)
+                for (int j = 0; j < f.nch; ++j)
+                    for (int r = 0; r < m; ++r) t[r] += mf.inbox_store[f.inbox_off + (int64_t)j * m + r];
                 for (int r = 0; r < k; ++r) {  // unit lower L11
                     double v = t[r];
                     for (int c2 = 0; c2 < r; ++c2) v -= F[(int64_t)r * f.ld + c2] * t[c2];
@@ -161,7 +161,7 @@ struct HostMf {
                 for (int r = k; r < m; ++r) {
                     double v = t[r];
                     for (int c2 = 0; c2 < k; ++c2) v -= F[(int64_t)(r + k) * f.ld + c2] * t[c2];
-                    mf.upd_store[f.upd_off + r - k] = v;
+                    mf.inbox_store[mf.upd_dst[f.bnd_off + r - k]] = v;
                 }
                 for (int r = 0; r < k; ++r) w[f.own_start + r] = t[r];
             }
