@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "backend.h"
@@ -39,11 +40,23 @@ namespace {
 
 // The current-order values travel from operator to operator through LDS
 // (cur_size doubles per lane, lane-interleaved: conflict-free), not through HBM.
-__global__ void __launch_bounds__(64) taylor_pass_kernel(ProgramDev P, int mode, int order,
-                                                         const double* __restrict__ xvec) {
+// blockDim.x / 64 wavefronts share the workgroup's 64 tets (tet_ops.h: convolution
+// split); their exchange buffer follows the scratch.
+// One instantiation per pass so that each carries only its own branch of every operator
+// (register pressure decides how many wavefronts fit a SIMD); W = wavefronts per SIMD the
+// register allocation must leave room for.
+template <int MODE, int W>
+__global__ void __launch_bounds__(256, W) taylor_pass_kernel(ProgramDev P, int order,
+                                                             const double* __restrict__ xvec) {
     extern __shared__ double cur_lds[];
-    int64_t tet = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tet < P.T) exec_program_tet(P, mode, order, tet, xvec, cur_lds + threadIdx.x, 64);
+    const int lane = threadIdx.x & 63;
+    // wave-uniform by construction; tell the compiler so that the slice bounds stay scalar
+    const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nparts = blockDim.x >> 6;
+    int64_t tet = (int64_t)blockIdx.x * 64 + lane;
+    if (tet < P.T)
+        exec_program_tet(P, MODE, order, tet, xvec, cur_lds + lane, 64, part, nparts,
+                         cur_lds + (int64_t)P.cur_size * 64 + lane);
 }
 
 // remap_out: ROW_LANES lanes per output row (~45 gathered entries each), shuffle reduce
@@ -342,10 +355,13 @@ class HipBackend final : public Backend {
     double* m_pcg_w[4] = {nullptr, nullptr, nullptr, nullptr};
     PcgScalars* m_pcg_sc = nullptr;
     static constexpr int kSolveLdsMax = 150 * 1024;
+    int m_conv_parts = std::getenv("SANM_CONV_PARTS") ? std::atoi(std::getenv("SANM_CONV_PARTS")) : 4;
+    int m_conv_split_order = std::getenv("SANM_CONV_SPLIT_ORDER") ? std::atoi(std::getenv("SANM_CONV_SPLIT_ORDER")) : 6;
     PcgScalars* m_pcg_sc_host = nullptr;
     size_t m_pcg_n = 0;
     bool m_time_passes = false;
-    size_t m_pass_lds_limit = 48 * 1024;
+    size_t m_pass_lds_limit[4] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
+    static constexpr int kBiasWaves = 3;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> m_pass_events;
     double* m_pool = nullptr;
     double* m_pool_host = nullptr;
@@ -415,15 +431,25 @@ public:
             HIP_CHECK(hipEventCreate(&e1));
             HIP_CHECK(hipEventRecord(e0, m_stream));
         }
-        const size_t lds = (size_t)P.cur_size * 64 * sizeof(double);
+        // convolutions of an order-k bias have k-1 terms: worth splitting over wavefronts once they
+        // outweigh the two barriers per operator
+        int nparts = (mode == PASS_BIAS && order >= m_conv_split_order) ? m_conv_parts : 1;
+        const size_t lds = (size_t)(P.cur_size + (nparts - 1) * 9) * 64 * sizeof(double);
         if (lds > 160 * 1024) sanm_throw(SANM_ERR_UNSUPPORTED, "graph too large for the LDS scratch");
-        if (lds > m_pass_lds_limit) {
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(taylor_pass_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            m_pass_lds_limit = lds;
+        void (*kern)(ProgramDev, int, const double*) = nullptr;
+        switch (mode) {
+            case PASS_EVAL0: kern = taylor_pass_kernel<PASS_EVAL0, 1>; break;
+            case PASS_GRAD: kern = taylor_pass_kernel<PASS_GRAD, 1>; break;
+            case PASS_BIAS: kern = taylor_pass_kernel<PASS_BIAS, kBiasWaves>; break;
+            case PASS_COEFF: kern = taylor_pass_kernel<PASS_COEFF, 1>; break;
+            default: sanm_throw(SANM_ERR_ASSERT, "unknown pass mode %d", mode);
         }
-        hipLaunchKernelGGL(taylor_pass_kernel, dim3(nblk(P.T, 64)), dim3(64), lds, m_stream, P, mode,
-                           order, xvec);
+        if (lds > m_pass_lds_limit[mode]) {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            m_pass_lds_limit[mode] = lds;
+        }
+        hipLaunchKernelGGL(kern, dim3(nblk(P.T, 64)), dim3(64 * nparts), lds, m_stream, P, order, xvec);
         HIP_CHECK(hipGetLastError());
         if (m_time_passes) {
             HIP_CHECK(hipEventRecord(e1, m_stream));
@@ -593,14 +619,16 @@ public:
         const int64_t rows = fwd ? L.sum_m : L.sum_k;
         int u = 1;
         while (u < 16 && 64 * u < width) u *= 2;
-        // enough workgroups to fill the chip comes first, then R * U <= 16 row chunks in registers
-        int r = rows >= 16 * 2048 ? 4 : (rows >= 8 * 2048 ? 2 : 1);
-        while (r * u > 16) r /= 2;
+        // R * U <= 16 row chunks in registers; short rows are latency-bound, so take as many rows per
+        // wave as still leave about a thousand workgroups
+        int r = 8;
+        while (r > 1 && (r * u > 16 || rows / (4 * r) < 1024)) r /= 2;
 #define SANM_LS(R, U)                         \
     if (r == R && u == U) {                   \
         launch_level_solve<R, U>(fwd, mf, L); \
         return;                               \
     }
+        SANM_LS(8, 1) SANM_LS(8, 2)
         SANM_LS(4, 1) SANM_LS(4, 2) SANM_LS(4, 4)
         SANM_LS(2, 1) SANM_LS(2, 2) SANM_LS(2, 4) SANM_LS(2, 8)
         SANM_LS(1, 1) SANM_LS(1, 2) SANM_LS(1, 4) SANM_LS(1, 8) SANM_LS(1, 16)
@@ -627,8 +655,10 @@ public:
         if (kernel == 2 && !m_pcg_sc) HIP_CHECK(hipMalloc(&m_pcg_sc, sizeof(PcgScalars)));
         auto launch = [&]() {
             if (kernel == 0) {
-                hipLaunchKernelGGL(taylor_pass_kernel, dim3(nblk(P->T, 64)), dim3(64),
-                                   (size_t)P->cur_size * 64 * sizeof(double), m_stream, *P, mode, order, x);
+                const bool timing = m_time_passes;
+                m_time_passes = false;
+                run_pass(*P, mode, order, x);
+                m_time_passes = timing;
             } else if (kernel == 1) {
                 hipLaunchKernelGGL(spmv_kernel, dim3(nblk((size_t)A->n * SPMV_LANES, 256)),
                                    dim3(256), 0, m_stream, *A, x, y);

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 
@@ -244,10 +245,65 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
         d.coef = take((int64_t)(d.is_const ? 1 : N + 1) * d.size * Tpad);
         d.bias = take((int64_t)d.size * Tpad);
     }
+    // Per-lane scratch slots of the current-order values.  A value lives from its producing
+    // operator to its last reader, so slots are handed out by a linear scan over the
+    // topological order and reused once dead: the scratch sits in LDS and its size bounds the
+    // number of resident wavefronts.  An operator's outputs never share a slot with its inputs.
     int32_t cur_size = 0;
-    for (auto& d : m_vars) {
-        d.cur = cur_size;
-        if (!d.is_const) cur_size += d.size;
+    {
+        std::vector<int> last_use(m_vars.size(), -1);
+        for (size_t pos = 0; pos < topo.size(); ++pos) {
+            const GraphOp& op = g.ops[topo[pos]];
+            for (int v : op.in) last_use[m_var_map[v]] = pos;
+            for (int v : op.out) last_use[m_var_map[v]] = std::max(last_use[m_var_map[v]], (int)pos);
+        }
+        last_use[lout] = topo.size();  // the output is read by remap_out
+        std::vector<std::pair<int32_t, int32_t>> free_list;  // (offset, size), sorted by offset
+        auto alloc_slot = [&](int32_t size) {
+            for (size_t i = 0; i < free_list.size(); ++i)
+                if (free_list[i].second >= size) {
+                    int32_t o = free_list[i].first;
+                    free_list[i].first += size;
+                    free_list[i].second -= size;
+                    if (!free_list[i].second) free_list.erase(free_list.begin() + i);
+                    return o;
+                }
+            int32_t o = cur_size;
+            cur_size += size;
+            return o;
+        };
+        auto free_slot = [&](int32_t o, int32_t size) {
+            auto it = std::lower_bound(free_list.begin(), free_list.end(), std::make_pair(o, (int32_t)0));
+            it = free_list.insert(it, {o, size});
+            if (it + 1 != free_list.end() && it->first + it->second == (it + 1)->first) {
+                it->second += (it + 1)->second;
+                free_list.erase(it + 1);
+            }
+            if (it != free_list.begin() && (it - 1)->first + (it - 1)->second == it->first) {
+                (it - 1)->second += it->second;
+                free_list.erase(it);
+            }
+        };
+        for (auto& d : m_vars) d.cur = 0;
+        for (size_t pos = 0; pos < topo.size(); ++pos) {
+            const GraphOp& op = g.ops[topo[pos]];
+            for (int v : op.out) {
+                VarDesc& d = m_vars[m_var_map[v]];
+                if (!d.is_const) d.cur = alloc_slot(d.size);
+            }
+            auto release = [&](int v) {
+                VarDesc& d = m_vars[m_var_map[v]];
+                if (!d.is_const && last_use[m_var_map[v]] == (int)pos) {
+                    free_slot(d.cur, d.size);
+                    last_use[m_var_map[v]] = -2;  // an input listed twice is released once
+                }
+            };
+            for (int v : op.in) release(v);
+            for (int v : op.out) release(v);  // outputs nobody reads (U, S of SVD-W)
+        }
+        if (std::getenv("SANM_DEBUG"))
+            std::fprintf(stderr, "program: %zu ops, %zu vars, %d scratch doubles per tet\n", topo.size(),
+                         m_vars.size(), cur_size);
     }
     m_jac_begin = off;
     for (auto& d : m_vars)

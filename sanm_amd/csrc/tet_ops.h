@@ -1,8 +1,13 @@
 // Per-tet bodies of every graph operator, for all four passes.
 //
 // One lane handles one tet; every operator is tet-local, so a lane only ever
-// re-reads values it wrote itself and a whole pass needs no inter-lane
-// synchronisation.  The functions are __host__ __device__ so that the
+// re-reads values it wrote itself.  A batch of a few 10^4 tets gives the chip
+// less than one wavefront per SIMD, and the order-k bias of the bilinear
+// operators is a convolution over k-1 earlier orders whose loads then sit on
+// the critical path one round trip after the other.  At higher orders a
+// workgroup therefore runs `nparts` wavefronts over the SAME 64 tets: each takes
+// a contiguous slice of every convolution, the partial sums meet in LDS
+// (conv_reduce) and wavefront 0 alone finishes the operator.  The functions are __host__ __device__ so that the
 // GPU-less authoring container can run the very same bodies in a test-only
 // host harness (tests/hostsim); the product path is the HIP kernel in
 // backend_hip.hip.
@@ -40,7 +45,34 @@ struct TetCtx {
     double* cur;
     int64_t cur_stride;
     int32_t out_var;
+    // convolution split (device, BIAS pass): this wavefront's part, the number of parts and the
+    // LDS exchange buffer of this lane ([part-1][element][64 lanes])
+    int32_t part = 0, nparts = 1;
+    double* red = nullptr;
 };
+
+// slice [lo, hi) of the convolution index range 1 .. order-1 taken by this part
+SANM_HD void conv_range(const TetCtx& c, int& lo, int& hi) {
+    const int n = c.order - 1;
+    lo = 1 + n * c.part / c.nparts;
+    hi = 1 + n * (c.part + 1) / c.nparts;
+}
+
+// sum the n partial values of all parts into part 0 (no-op when the pass runs unsplit)
+SANM_HD void conv_reduce(const TetCtx& c, double* v, int n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (c.nparts == 1) return;
+    __syncthreads();  // part 0 is done reading the previous exchange
+    if (c.part)
+        for (int e = 0; e < n; ++e) c.red[((c.part - 1) * 9 + e) * 64] = v[e];
+    __syncthreads();
+    if (!c.part)
+        for (int p = 1; p < c.nparts; ++p)
+            for (int e = 0; e < n; ++e) v[e] += c.red[((p - 1) * 9 + e) * 64];
+#else
+    (void)c; (void)v; (void)n;
+#endif
+}
 
 // ---------------------------------------------------------------- access --
 SANM_HD double* p_coef(const TetCtx& c, int v, int k) {
@@ -380,8 +412,9 @@ SANM_HD void op_multiply(const TetCtx& c, const OpDesc& o, int mode) {
         double sb2[9];
         for (int e = 0; e < osz; ++e) sb[e] = sb2[e] = 0;
         if (!c.vars[a].is_const && !c.vars[b].is_const) {
-            int i = 1;
-            for (; i + 1 < c.order; i += 2) {  // two independent terms in flight
+            int i, hi;
+            conv_range(c, i, hi);
+            for (; i + 1 < hi; i += 2) {  // two independent terms in flight
                 const double *pa = p_coef(c, a, i), *pb = p_coef(c, b, c.order - i);
                 const double *pa2 = p_coef(c, a, i + 1), *pb2 = p_coef(c, b, c.order - i - 1);
                 for (int e = 0; e < osz; ++e) {
@@ -389,12 +422,14 @@ SANM_HD void op_multiply(const TetCtx& c, const OpDesc& o, int mode) {
                     sb2[e] += bval(pa2, s, asz, e) * bval(pb2, s, bsz, e);
                 }
             }
-            for (; i < c.order; ++i) {
+            for (; i < hi; ++i) {
                 const double *pa = p_coef(c, a, i), *pb = p_coef(c, b, c.order - i);
                 for (int e = 0; e < osz; ++e) sb[e] += bval(pa, s, asz, e) * bval(pb, s, bsz, e);
             }
             for (int e = 0; e < osz; ++e) sb[e] += sb2[e];
+            conv_reduce(c, sb, osz);
         }
+        if (c.part) return;
         st(psb, s, osz, sb);
     } else {
         ld(psb, s, osz, sb);
@@ -447,7 +482,9 @@ SANM_HD void op_unary(const TetCtx& c, const OpDesc& o, int mode) {
         for (int e = 0; e < sz; ++e) sb[e] = 0;
         if (!c.vars[x].is_const) {
             const bool int2 = (!is_log && pw == 2.0);
-            for (int i = 1; i < k; ++i) {
+            int lo, hi;
+            conv_range(c, lo, hi);
+            for (int i = lo; i < hi; ++i) {
                 // log: x[k-i]*f[i]*(-i/k); pow: f[k-i]*x[i]*((i/k)(p+1)-1); pow 2: x[i]*x[k-i]
                 const double* p1 = int2 ? p_coef(c, x, i) : (is_log ? p_coef(c, x, k - i) : p_coef(c, ov, k - i));
                 const double* p2 = int2 ? p_coef(c, x, k - i) : (is_log ? p_coef(c, ov, i) : p_coef(c, x, i));
@@ -455,11 +492,14 @@ SANM_HD void op_unary(const TetCtx& c, const OpDesc& o, int mode) {
                                                 : (double)i / (double)k * (pw + 1.0) - 1.0);
                 for (int e = 0; e < sz; ++e) sb[e] += p1[e * s] * p2[e * s] * w;
             }
+            conv_reduce(c, sb, sz);
+            if (c.part) return;
             if (!int2) {
                 const double* x0 = p_coef(c, x, 0);
                 for (int e = 0; e < sz; ++e) sb[e] /= x0[e * s];
             }
         }
+        if (c.part) return;
         st(psb, s, sz, sb);
     } else {
         ld(psb, s, sz, sb);
@@ -528,8 +568,9 @@ SANM_HD void op_matmul(const TetCtx& c, const OpDesc& o, int mode) {
         double R2[9], A2[9], B2[9];
         for (int e = 0; e < 9; ++e) R[e] = R2[e] = 0;
         if (!c.vars[a].is_const && !c.vars[b].is_const) {
-            int i = 1;
-            for (; i + 1 < c.order; i += 2) {
+            int i, hi;
+            conv_range(c, i, hi);
+            for (; i + 1 < hi; i += 2) {
                 ld9(p_coef(c, a, i), s, A);
                 ld9(p_coef(c, b, c.order - i), s, B);
                 ld9(p_coef(c, a, i + 1), s, A2);
@@ -537,13 +578,15 @@ SANM_HD void op_matmul(const TetCtx& c, const OpDesc& o, int mode) {
                 mm3<false, false, true>(R, A, B);
                 mm3<false, false, true>(R2, A2, B2);
             }
-            for (; i < c.order; ++i) {
+            for (; i < hi; ++i) {
                 ld9(p_coef(c, a, i), s, A);
                 ld9(p_coef(c, b, c.order - i), s, B);
                 mm3<false, false, true>(R, A, B);
             }
             for (int e = 0; e < 9; ++e) R[e] += R2[e];
+            conv_reduce(c, R, 9);
         }
+        if (c.part) return;
         st9(psb, s, R);
     } else {
         ld9(psb, s, R);
@@ -612,8 +655,9 @@ SANM_HD void op_matinvmul(const TetCtx& c, const OpDesc& o, int mode) {
         for (int e = 0; e < 9; ++e) R[e] = R2[e] = 0;
         if (!c.vars[x].is_const) {
             // sum_{i=1}^{k-1} Y_i X_{k-i} (left) or X_i Y_{k-i}; two terms in flight
-            int i = 1;
-            for (; i + 1 < c.order; i += 2) {
+            int i, hi;
+            conv_range(c, i, hi);
+            for (; i + 1 < hi; i += 2) {
                 if (is_left) {
                     ld9(p_coef(c, ov, i), s, Y);
                     ld9(p_coef(c, x, c.order - i), s, X);
@@ -630,7 +674,7 @@ SANM_HD void op_matinvmul(const TetCtx& c, const OpDesc& o, int mode) {
                     mm3<false, false, true>(R2, X2, Y2);
                 }
             }
-            for (; i < c.order; ++i) {
+            for (; i < hi; ++i) {
                 if (is_left) {
                     ld9(p_coef(c, ov, i), s, Y);
                     ld9(p_coef(c, x, c.order - i), s, X);
@@ -643,6 +687,8 @@ SANM_HD void op_matinvmul(const TetCtx& c, const OpDesc& o, int mode) {
             }
         }
         for (int e = 0; e < 9; ++e) R[e] = -(R[e] + R2[e]);
+        if (!c.vars[x].is_const) conv_reduce(c, R, 9);
+        if (c.part) return;
         st9(psb, s, R);
     } else {
         ld9(psb, s, R);
@@ -706,28 +752,35 @@ SANM_HD void op_det(const TetCtx& c, const OpDesc& o, int mode) {
     const int k = c.order;
     double sb = 0;
     if (c.vars[x].is_const) {
+        if (c.part) return;
         st_cur(c, ov, 1, &sb, in_coeff);
         return;
     }
     if (!in_coeff) {
-        double ck[3] = {0, 0, 0}, t[3];
-        for (int j = 1; j < k; ++j) {
+        int lo, hi;
+        conv_range(c, lo, hi);
+        double ck[4] = {0, 0, 0, 0}, t[3];  // ck[3]: this part's share of sum_i r0_i . c_{k-i}
+        for (int j = lo; j < hi; ++j) {
             double r1[3], r2[3];
             ld(p_coef(c, x, j) + 3 * s, s, 3, r1);
             ld(p_coef(c, x, k - j) + 6 * s, s, 3, r2);
             cross3(r1, r2, t);
             ck[0] += t[0]; ck[1] += t[1]; ck[2] += t[2];
         }
-        st(pck, s, 3, ck);
-        double r0[3];
-        ld(p_coef(c, x, 0), s, 3, r0);
-        sb = r0[0] * ck[0] + r0[1] * ck[1] + r0[2] * ck[2];
-        for (int i = 1; i < k; ++i) {
+        double r0[3], x0[3];
+        ld(p_coef(c, x, 0), s, 3, x0);
+        // unsplit, the running sum starts from r0_0 . c_k^partial like the plain loop it replaces
+        if (c.nparts == 1) ck[3] = x0[0] * ck[0] + x0[1] * ck[1] + x0[2] * ck[2];
+        for (int i = lo; i < hi; ++i) {
             double cm[3];
             ld(p_coef(c, x, i), s, 3, r0);
             ld(pcs + (int64_t)(k - i) * 3 * s, s, 3, cm);
-            sb += r0[0] * cm[0] + r0[1] * cm[1] + r0[2] * cm[2];
+            ck[3] += r0[0] * cm[0] + r0[1] * cm[1] + r0[2] * cm[2];
         }
+        conv_reduce(c, ck, 4);
+        if (c.part) return;
+        st(pck, s, 3, ck);
+        sb = c.nparts == 1 ? ck[3] : x0[0] * ck[0] + x0[1] * ck[1] + x0[2] * ck[2] + ck[3];
         *psb = sb;
     } else {
         sb = *psb;
@@ -832,7 +885,9 @@ SANM_HD void op_svdw(const TetCtx& c, const OpDesc& o, int mode) {
     double Bm[9], Bp[9], Bpw[9], A[9], B[9];
     if (!in_coeff) {
         for (int e = 0; e < 9; ++e) Bm[e] = Bp[e] = Bpw[e] = 0;
-        for (int i = 1; i < k; ++i) {
+        int lo, hi;
+        conv_range(c, lo, hi);
+        for (int i = lo; i < hi; ++i) {
             ld9(p_coef(c, x, i), s, A);
             ld9(p_coef(c, x, k - i), s, B);
             mm3<false, true, true>(Bm, A, B);  // M_i M_{k-i}'
@@ -842,6 +897,10 @@ SANM_HD void op_svdw(const TetCtx& c, const OpDesc& o, int mode) {
             ld9(p_coef(c, wv, k - i), s, B);
             mm3<false, false, true>(Bpw, A, B);  // P_i W_{k-i}
         }
+        conv_reduce(c, Bm, 9);
+        conv_reduce(c, Bp, 9);
+        conv_reduce(c, Bpw, 9);
+        if (c.part) return;
         st9(p_aux(c, o.aux[1]), s, Bm);
         st9(p_aux(c, o.aux[2]), s, Bp);
         st9(p_aux(c, o.aux[3]), s, Bpw);
@@ -887,6 +946,14 @@ SANM_HD void exec_op(const TetCtx& c, const OpDesc& o, int mode, const RemapInDe
     // operators fed by constants only are evaluated once (order 0); their
     // higher-order terms are identically zero, never stored and never read
     if (mode != PASS_EVAL0 && c.vars[o.out[0]].is_const) return;
+    if (c.part) {
+        // helper wavefronts of a split BIAS pass only join the convolutions
+        switch (o.type) {
+            case OP_MULTIPLY: case OP_LOG: case OP_POW: case OP_MATMUL: case OP_MATINVMUL: case OP_DET:
+            case OP_SVDW: break;
+            default: return;
+        }
+    }
     switch (o.type) {
         case OP_PLACEHOLDER: op_placeholder(c, o, mode, rin, xvec); break;
         case OP_CONSTANT: break;  // uploaded at compile time
@@ -909,8 +976,9 @@ SANM_HD void exec_op(const TetCtx& c, const OpDesc& o, int mode, const RemapInDe
 // placeholder gathers from (EVAL0 / COEFF passes); `cur` the per-lane scratch
 // for the current-order values (P.cur_size doubles at stride cur_stride).
 SANM_HD void exec_program_tet(const ProgramDev& P, int mode, int order, int64_t tet,
-                              const double* xvec, double* cur, int64_t cur_stride) {
-    TetCtx c{P.arena, P.vars, P.Tpad, tet, order, P.odim, cur, cur_stride, P.out_var};
+                              const double* xvec, double* cur, int64_t cur_stride, int part = 0,
+                              int nparts = 1, double* red = nullptr) {
+    TetCtx c{P.arena, P.vars, P.Tpad, tet, order, P.odim, cur, cur_stride, P.out_var, part, nparts, red};
     if (mode == PASS_GRAD) {
         // seed: d(out)/d(out) = I  (symbolic.cpp:219-220)
         double* j = p_jac(c, P.out_var);
