@@ -131,10 +131,46 @@ PadeApproximation::PadeApproximation(Backend* be, const std::vector<DVec>& xs,
     std::vector<DVec> orth(nx);
     std::vector<const double*> ptrs(nx);
     std::vector<double> coefs(nx), dots(nx);
-    for (int i = 1; i <= n; ++i) {
+    // Classical Gram-Schmidt (the projections use xs[i], not the running uii).  The sweep is queued
+    // without waiting for the device: projections and squared norms stay in device memory for the
+    // update / scaling kernels that consume them and come back in one copy at the end.  The one case
+    // that needs a host decision mid-sweep (a basis vector that underflows, aii < eps) re-runs the sweep
+    // step by step.
+    bool redo_on_host = false;
+    {
+        DVec acoef{be, (size_t)nx * nx};
+        for (int i = 1; i <= n; ++i) {
+            DVec uii{be, m_len};
+            for (int j = 1; j < i; ++j) ptrs[j - 1] = orth[j].p();
+            double* row = acoef.p() + (size_t)i * nx;
+            be->multi_dot_async(m_len, xs[i].p(), i - 1, ptrs.data(), row + 1);
+            // under the ANM condition the projection on the first basis vector is dropped (checked below)
+            be->gs_update_async(m_len, xs[i].p(), i - 1, ptrs.data(), row + 1, anm_cond ? 1 : 0, uii.p());
+            be->dot_async(m_len, uii.p(), uii.p(), row + i);
+            be->scale_rsqrt_async(m_len, uii.p(), row + i, eps);
+            orth[i] = std::move(uii);
+        }
+        std::vector<double> h((size_t)nx * nx);
+        be->d2h(h.data(), acoef.p(), h.size() * 8);
+        for (int i = 1; i <= n && !redo_on_host; ++i) {
+            for (int j = 1; j < i; ++j) {
+                A(i, j) = h[(size_t)i * nx + j];
+                if (anm_cond && j == 1) {
+                    sanm_check(std::fabs(A(i, j)) < 1e-4, "pade: anm condition violated: %g", A(i, j));
+                    A(i, j) = 0;
+                }
+            }
+            const double aii = std::sqrt(h[(size_t)i * nx + i]);
+            if (aii == 0) {
+                m_d.clear();
+                return;
+            }
+            A(i, i) = aii;
+            if (aii < eps) redo_on_host = true;
+        }
+    }
+    for (int i = 1; redo_on_host && i <= n; ++i) {
         DVec uii{be, m_len};
-        // classical Gram-Schmidt (the projections use xs[i], not the running uii):
-        // all i-1 projections in one reduction kernel, the update in one fused kernel
         for (int j = 1; j < i; ++j) ptrs[j - 1] = orth[j].p();
         be->multi_dot(m_len, xs[i].p(), i - 1, ptrs.data(), dots.data());
         int nv = 0;
@@ -187,17 +223,21 @@ PadeApproximation::PadeApproximation(Backend* be, const std::vector<DVec>& xs,
     }
 }
 
-void PadeApproximation::eval_nume(double a, const double* d, int n, double* out) const {
-    // libsanm/pade.cpp:181-189: sum_{i=1}^{n} a^(i-1) * poly(d[0..n-i], a) * xs[i],
-    // evaluated as one fused linear combination instead of a Horner chain of axpys
-    std::vector<const double*> ptrs(n);
-    std::vector<double> coefs(n);
+void PadeApproximation::nume_coefs(double a, const double* d, int n, double* coefs) const {
+    // libsanm/pade.cpp:181-189: the numerator is sum_{i=1}^{n} a^(i-1) * poly(d[0..n-i], a) * xs[i]
     double ap = 1.0;
     for (int i = 1; i <= n; ++i) {
-        ptrs[i - 1] = m_xs[i].p();
         coefs[i - 1] = ap * poly::eval(d, n - i + 1, a);
         ap *= a;
     }
+}
+
+void PadeApproximation::eval_nume(double a, const double* d, int n, double* out) const {
+    // evaluated as one fused linear combination instead of a Horner chain of axpys
+    std::vector<const double*> ptrs(n);
+    std::vector<double> coefs(n);
+    for (int i = 1; i <= n; ++i) ptrs[i - 1] = m_xs[i].p();
+    nume_coefs(a, d, n, coefs.data());
     m_be->lincomb(m_len, n, ptrs.data(), coefs.data(), out);
 }
 
@@ -219,13 +259,19 @@ bool PadeApproximation::estimate_valid_range(double start, double eps, double li
 
     const int n = (int)m_xs.size() - 2;
     const double eps2 = eps * eps;
-    DVec pn{m_be, m_len}, pn_lo{m_be, m_len};
+    std::vector<const double*> ptrs(n);
+    std::vector<double> c_n(n), c_lo(n);
+    for (int i = 1; i <= n; ++i) ptrs[i - 1] = m_xs[i].p();
     auto check = [&](double a) {
+        // |P_n(a)/D_n(a) - P_{n-1}(a)/D_{n-1}(a)| <= eps |P_n(a)/D_n(a)| on the numerators, one pass
+        // over the series and one synchronisation per probe
         double denom_n = poly::eval(m_d, a), denom_lo = poly::eval(m_d_lo, a);
-        eval_nume(a, m_d.data(), n, pn.p());
-        eval_nume(a, m_d_lo.data(), n - 1, pn_lo.p());
-        m_be->axpby(m_len, denom_n / denom_lo, pn_lo.p(), -1.0, pn.p(), pn_lo.p());
-        return m_be->dot(m_len, pn_lo.p(), pn_lo.p()) <= m_be->dot(m_len, pn.p(), pn.p()) * eps2;
+        nume_coefs(a, m_d.data(), n, c_n.data());
+        nume_coefs(a, m_d_lo.data(), n - 1, c_lo.data());
+        c_lo[n - 1] = 0;
+        double r[2];
+        m_be->lincomb2_diff_norms(m_len, n, ptrs.data(), c_n.data(), c_lo.data(), denom_n / denom_lo, r);
+        return r[0] <= r[1] * eps2;
     };
     double left = start * 1.001, right = start + (pole - start) * 0.99;
     if (!check(left)) return false;
@@ -305,11 +351,15 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g, int out_var, const SparseDesc&
     m_grad_t_buf = DVec{be, (size_t)m_n};
     m_tmp0 = DVec{be, n1};
     m_tmp1 = DVec{be, n1};
+    m_dev_scalars = DVec{be, (size_t)hp.order + 2};
+    m_host_scalars = be->alloc_host(3 * ((size_t)hp.order + 2));
     m_xt_coeffs.resize(hp.order + 1);
     for (auto& v : m_xt_coeffs) v = DVec{be, n1};
 }
 
-AnmDriver::~AnmDriver() = default;
+AnmDriver::~AnmDriver() {
+    if (m_host_scalars) m_be->free_host(m_host_scalars);
+}
 
 void AnmDriver::allreduce(double* buf, int64_t count) {
     if (!m_shard.active()) return;
@@ -364,8 +414,13 @@ void AnmDriver::solve_expansion_coeffs() {
             // the one collective per Taylor order: sum of the per-shard nodal bias (n doubles)
             if (i > 1) allreduce(m_bi.p(), n);
         }
-        double ti;
+        // Orders >= 2 queue their kernels without ever waiting for the device: t_i is formed on the
+        // device from the reduction's result (next_coeff_async), lands in x_i[n] for the kernels that need
+        // it and in pinned host memory for the checks below the loop.  (Order 1 needs t_1 on the host for
+        // the scale factors; the sharded mode synchronises at its all-reduce anyway.)
+        double ti = 0;
         const double* xbi;
+        double* xi = m_xt_coeffs[i].p();
         if (i == 1) {
             {
                 ScopedTimer t{this, "build_sparse_coeff"};
@@ -389,47 +444,52 @@ void AnmDriver::solve_expansion_coeffs() {
             }
             xbi = m_bi.p();  // zero at first order (anm.cpp:235)
             t1 = ti = 1.0 / std::sqrt(be->dot(n, m_xgt.p(), m_xgt.p()) + 1.0);
+            // x_1 = -t1*xgt - xbi ; t_1 appended  (anm.cpp:261-264)
+            be->axpby_tail(n, -ti, m_xgt.p(), -1.0, xbi, xi, ti);
+            m_host_scalars[3 * i] = ti;
+            xgt_dot_x1 = be->dot(n, xi, m_xgt.p());
         } else {
             {
                 ScopedTimer t{this, "sparse_solve"};
                 m_solver->solve(m_bi.p(), m_xbi.p());
             }
             xbi = m_xbi.p();
-            ti = be->dot(n, xbi, m_xt_coeffs[1].p()) / (t1 - xgt_dot_x1);
-            // the reference asserts a finite right-hand side before solving
-            // (sparse_solver.cpp:160-161); a non-finite b_i or solution makes this
-            // reduction non-finite, which is checked instead of a separate pass
-            if (!std::isfinite(ti))
-                sanm_throw(SANM_ERR_NUMERICAL, "non-finite right-hand side / solution at order %d", i);
+            // t_i = (xb_i . x_1) / (t1 - xgt . x_1);  x_i = -t_i*xgt - xb_i  (anm.cpp:246-264)
+            be->dot_async(n, xbi, m_xt_coeffs[1].p(), m_dev_scalars.p() + i);
+            be->next_coeff_async(n, m_dev_scalars.p() + i, 1.0 / (t1 - xgt_dot_x1), m_xgt.p(), xbi, xi,
+                                 m_host_scalars + 3 * i);
         }
-        // x_i = -ti*xgt - xbi ; t_i appended  (anm.cpp:261-264)
-        double* xi = m_xt_coeffs[i].p();
-        be->axpby(n, -ti, m_xgt.p(), -1.0, xbi, xi);
-        be->h2d(xi + n, &ti, 8);
-        m_t_coeffs.push_back(ti);
         m_nr_valid_coeffs = i + 1;
-        if (i == 1) xgt_dot_x1 = be->dot(n, xi, m_xgt.p());
 
         if (m_hp.sanity_check) {
-            // anm.cpp:271-285
+            // anm.cpp:271-285; results are examined after the loop
             ScopedTimer t{this, "anm_sanity_check"};
-            be->spmv(m_pattern->csr(), xi, m_tmp0.p());
-            be->axpby(n, -ti, grad_t, -1.0, m_bi.p(), m_tmp1.p());
-            double red[2];
-            be->sanity_reduce(n, m_tmp0.p(), m_tmp1.p(), 1e-4, n1, m_xt_coeffs[1].p(), xi, red);
-            const double ex = red[0], xdot = red[1];
-            sanm_check(ex < 0, "ANM check coeff eqn: order %d: excess %g", i, ex);
-            if (i == 1) sanm_check(std::fabs(xdot - 1) < 1e-4, "xdot=%g", xdot);
-            else sanm_check(std::fabs(xdot) < 1e-4, "i=%d: xdot=%g", i, xdot);
+            be->sanity_check_async(m_pattern->csr(), xi, grad_t, m_bi.p(), 1e-4, n1, m_xt_coeffs[1].p(),
+                                   m_tmp0.p(), m_tmp1.p(), m_host_scalars + 3 * i + 1);
         }
         if (m_hp.profile) {
             trace_b_norm.push_back(std::sqrt(be->dot(n, m_bi.p(), m_bi.p())));
             trace_x_norm.push_back(std::sqrt(be->dot(n1, xi, xi)));
-            trace_t.push_back(ti);
+            trace_t.push_back(m_host_scalars[3 * i]);  // valid: the dot above synchronised
         }
         if (i < N) {
             ScopedTimer t{this, "taylor_push"};
             be->run_pass(P, PASS_COEFF, i, xi);
+        }
+    }
+    be->sync();
+    for (int i = 1; i <= N; ++i) {
+        const double ti = m_host_scalars[3 * i];
+        // the reference asserts a finite right-hand side before solving (sparse_solver.cpp:160-161);
+        // a non-finite b_i or solution makes t_i non-finite, which is checked instead of a separate pass
+        if (!std::isfinite(ti))
+            sanm_throw(SANM_ERR_NUMERICAL, "non-finite right-hand side / solution at order %d", i);
+        m_t_coeffs.push_back(ti);
+        if (m_hp.sanity_check) {
+            const double ex = m_host_scalars[3 * i + 1], xdot = m_host_scalars[3 * i + 2];
+            sanm_check(ex < 0, "ANM check coeff eqn: order %d: excess %g", i, ex);
+            if (i == 1) sanm_check(std::fabs(xdot - 1) < 1e-4, "xdot=%g", xdot);
+            else sanm_check(std::fabs(xdot) < 1e-4, "i=%d: xdot=%g", i, xdot);
         }
     }
     {

@@ -117,6 +117,7 @@ private:
     std::vector<double> m_d, m_d_lo, m_t_nume;
     double m_t0 = 0, m_t_max = 0, m_t_max_a = 0;
     void eval_nume(double a, const double* d, int n, double* out) const;
+    void nume_coefs(double a, const double* d, int n, double* coefs) const;
 };
 
 class AnmDriver {  // ANMDriverHelper, libsanm/anm.h:96-207
@@ -170,6 +171,8 @@ protected:
     double m_t_max = 0, m_t_max_a = 0;
     std::unique_ptr<PadeApproximation> m_pade;
     DVec m_fx0, m_bi, m_xbi, m_xgt, m_grad_t_buf, m_tmp0, m_tmp1;
+    DVec m_dev_scalars;                // per order: xb_i . x_1 (consumed on the device)
+    double* m_host_scalars = nullptr;  // pinned, per order: t_i, sanity excess, sanity x-dot
     std::map<std::string, double> m_profile;
 
     void init_xt0(const double* x_host, double t);

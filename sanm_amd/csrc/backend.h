@@ -50,6 +50,10 @@ public:
     virtual void d2d(void* dst, const void* src, size_t bytes) = 0;
     virtual void zero(void* dst, size_t bytes) = 0;
     virtual void sync() = 0;
+    //! host memory the device can write (pinned); results of the *_async reductions land here and are
+    //! valid after the next sync()
+    virtual double* alloc_host(size_t n_doubles) = 0;
+    virtual void free_host(double* p) = 0;
 
     //! one whole graph pass over all tets (tet_ops.h: exec_program_tet)
     virtual void run_pass(const ProgramDev& P, int mode, int order, const double* xvec) = 0;
@@ -65,6 +69,9 @@ public:
     //! out = a*x + b*y  (y may be null iff b == 0; out may alias x or y)
     virtual void axpby(size_t n, double a, const double* x, double b, const double* y,
                        double* out) = 0;
+    //! axpby over n entries, then out[n] = tail (the t component appended to an x coefficient)
+    virtual void axpby_tail(size_t n, double a, const double* x, double b, const double* y, double* out,
+                            double tail) = 0;
     //! out = sum_j coefs[j] * ptrs[j]  (nvec <= 24; out may alias one of the inputs
     //! only if that input has index 0)
     virtual void lincomb(size_t n, int nvec, const double* const* ptrs, const double* coefs,
@@ -72,6 +79,10 @@ public:
     //! out_host[j] = x . ys[j]  for j < nvec (nvec <= 24), one synchronisation
     virtual void multi_dot(size_t n, const double* x, int nvec, const double* const* ys,
                            double* out_host);
+    //! u = sum_j c1[j]*ptrs[j], w = sum_j c2[j]*ptrs[j], d = scale*w - u:  out_host = {d.d, u.u}.
+    //! The Pade range test (pade.cpp:143-165) on two numerators without materialising them.
+    virtual void lincomb2_diff_norms(size_t n, int nvec, const double* const* ptrs, const double* c1,
+                                     const double* c2, double scale, double out_host[2]);
     //! out = x .* y
     virtual void vmul(size_t n, const double* x, const double* y, double* out) = 0;
     //! d[i] = 1 / A[i,i]  (scaled by `scale`)
@@ -128,6 +139,34 @@ public:
         out[0] = allclose_excess(n, a, b, eps);
         out[1] = dot(n1, x, y);
     }
+    //! the whole per-order sanity check (libsanm/anm.cpp:271-285) in one pass over the matrix:
+    //! out[0] = allclose_excess(A xi, -ti*grad_t - bi, eps) over the n rows, out[1] = x1 . xi over n1
+    //! entries.  `tmp0` / `tmp1` (n doubles each) are scratch for backends that take the unfused route.
+    virtual void sanity_check(const CsrDev& A, const double* xi, double ti, const double* grad_t,
+                              const double* bi, double eps, size_t n1, const double* x1, double* tmp0,
+                              double* tmp1, double out[2]) {
+        spmv(A, xi, tmp0);
+        axpby(A.n, -ti, grad_t, -1.0, bi, tmp1);
+        sanity_reduce(A.n, tmp0, tmp1, eps, n1, x1, xi, out);
+    }
+    // Queue-only forms used inside the order loop (no host synchronisation): scalars flow from kernel to
+    // kernel through device-visible memory and the host reads them once, after the last order.
+    //! *out = x . y  (out: device or pinned host memory)
+    virtual void dot_async(size_t n, const double* x, const double* y, double* out) = 0;
+    //! t = *num * scale;  out[0..n) = -t * x - y;  out[n] = t;  *t_out = t   (anm.cpp:258-264)
+    virtual void next_coeff_async(size_t n, const double* num, double scale, const double* x, const double* y,
+                                  double* out, double* t_out) = 0;
+    //! out[j] = x . ys[j]  (out: device memory)
+    virtual void multi_dot_async(size_t n, const double* x, int nvec, const double* const* ys, double* out) = 0;
+    //! out = x - sum_{j >= first} coefs[j] * qs[j]   (coefs: device memory; classical Gram-Schmidt update)
+    virtual void gs_update_async(size_t n, const double* x, int nvec, const double* const* qs,
+                                 const double* coefs, int first, double* out) = 0;
+    //! v *= 1 / max(sqrt(*norm2), eps)   (norm2: device memory)
+    virtual void scale_rsqrt_async(size_t n, double* v, const double* norm2, double eps) = 0;
+    //! sanity_check with t_i read from xi[n]; out2 as in sanity_check
+    virtual void sanity_check_async(const CsrDev& A, const double* xi, const double* grad_t, const double* bi,
+                                    double eps, size_t n1, const double* x1, double* tmp0, double* tmp1,
+                                    double* out2) = 0;
     //! like allclose_excess for check_t0v_match (anm.cpp:343-360): a + b*t0 vs 0
     virtual double t0v_excess(size_t n, const double* fx, const double* v, double t0, double tol) = 0;
 };

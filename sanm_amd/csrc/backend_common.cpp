@@ -19,6 +19,19 @@ void Backend::multi_dot(size_t n, const double* x, int nvec, const double* const
     for (int j = 0; j < nvec; ++j) out_host[j] = dot(n, x, ys[j]);
 }
 
+void Backend::lincomb2_diff_norms(size_t n, int nvec, const double* const* ptrs, const double* c1,
+                                  const double* c2, double scale, double out_host[2]) {
+    double* u = static_cast<double*>(alloc(n * 8));
+    double* w = static_cast<double*>(alloc(n * 8));
+    lincomb(n, nvec, ptrs, c1, u);
+    lincomb(n, nvec, ptrs, c2, w);
+    axpby(n, scale, w, -1.0, u, w);
+    out_host[0] = dot(n, w, w);
+    out_host[1] = dot(n, u, u);
+    free(u);
+    free(w);
+}
+
 void Backend::pcg(const CsrDev& A, double sign, const double* dinv, const double* b, double* x,
                   double rtol, int maxit, int* iters, double* relres) {
     const size_t n = A.n;

@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <unordered_map>
 #include <vector>
 
 #include "backend.h"
@@ -139,19 +140,87 @@ __device__ __forceinline__ void block_reduce_commit(double v, double* out) {
     }
 }
 
+// Grid-wide reduction of nv values whose result the HOST reads: every workgroup stores its partials,
+// the last one to arrive (device-scope ticket) combines them in workgroup order -- deterministic, unlike
+// an atomic accumulation -- and writes straight into pinned host memory, so a reduction costs one launch
+// and one stream synchronisation (no accumulator memset, no read-back copy kernel).
+constexpr unsigned RED_MAX_GRID = 256;
+struct GridRed {
+    double* partials;  // [MAX_RED][RED_MAX_GRID]
+    unsigned* ticket;
+    double* host;      // pinned, device-accessible
+};
+template <int NV>
+__device__ __forceinline__ void grid_commit(const double (&v)[NV], int nv, unsigned maxmask, GridRed g) {
+    __shared__ double sh[NV][4];
+    __shared__ bool last;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+        if (j < nv) {
+            const double r = ((maxmask >> j) & 1) ? wave_reduce_max(v[j]) : wave_reduce_sum(v[j]);
+            if (lane == 0) sh[j][w] = r;
+        }
+    __syncthreads();
+    if ((int)threadIdx.x < nv) {
+        const int j = threadIdx.x;
+        const bool mx = (maxmask >> j) & 1;
+        double r = sh[j][0];
+        for (int i = 1; i < 4; ++i) r = mx ? fmax(r, sh[j][i]) : r + sh[j][i];
+        g.partials[j * RED_MAX_GRID + blockIdx.x] = r;
+        __threadfence();  // release the partial before the ticket
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(g.ticket, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();  // acquire the other workgroups' partials
+    for (int j = w; j < nv; j += 4) {  // one wavefront per value
+        const bool mx = (maxmask >> j) & 1;
+        double r = mx ? -1e300 : 0.0;
+        for (unsigned b = lane; b < gridDim.x; b += 64) {
+            const double pv = g.partials[j * RED_MAX_GRID + b];
+            r = mx ? fmax(r, pv) : r + pv;
+        }
+        r = mx ? wave_reduce_max(r) : wave_reduce_sum(r);
+        if (lane == 0) g.host[j] = r;
+    }
+    if (threadIdx.x == 0) *g.ticket = 0;  // launches on the stream are serialised
+}
+
 __global__ void __launch_bounds__(256) dot_kernel(size_t n, const double* __restrict__ x,
-                                                  const double* __restrict__ y, double* out) {
-    double s = 0;
+                                                  const double* __restrict__ y, GridRed g) {
+    double s[1] = {0};
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (size_t)gridDim.x * blockDim.x)
-        s += x[i] * y[i];
-    block_reduce_commit<false>(s, out);
+        s[0] += x[i] * y[i];
+    grid_commit<1>(s, 1, 0u, g);
 }
 
 __global__ void axpby_kernel(size_t n, double a, const double* x, double b, const double* y,
                              double* out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = b == 0.0 ? a * x[i] : a * x[i] + b * y[i];
+}
+
+__global__ void axpby_tail_kernel(size_t n, double a, const double* x, double b, const double* y,
+                                  double* out, double tail) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a * x[i] + b * y[i];
+    else if (i == n) out[i] = tail;
+}
+
+// x_i of the order loop with t_i taken from the device: t = *num * scale
+__global__ void next_coeff_kernel(size_t n, const double* __restrict__ num, double scale,
+                                  const double* __restrict__ x, const double* __restrict__ y, double* out,
+                                  double* t_out) {
+    const double t = *num * scale;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = -t * x[i] - y[i];
+    else if (i == n) {
+        out[i] = t;
+        *t_out = t;
+    }
 }
 
 constexpr int MAX_VEC = 24;
@@ -167,9 +236,42 @@ __global__ void lincomb_kernel(size_t n, VecList v, double* out) {
     for (int j = 0; j < v.n; ++j) acc += v.c[j] * v.p[j][i];
     out[i] = acc;
 }
-// out[j] += x . ys[j]; x is read once per element
+// classical Gram-Schmidt update with the projections read from device memory
+__global__ void gs_update_kernel(size_t n, const double* __restrict__ x, VecList q, const double* __restrict__ coefs,
+                                 int first, double* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double acc = x[i];
+    for (int j = first; j < q.n; ++j) acc += -coefs[j] * q.p[j][i];
+    out[i] = acc;
+}
+__global__ void scale_rsqrt_kernel(size_t n, double* v, const double* __restrict__ norm2, double eps) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] *= 1.0 / fmax(sqrt(*norm2), eps);
+}
+
+// Pade range test: two linear combinations of the same vectors, their scaled difference and both norms
+__global__ void __launch_bounds__(256) lincomb2_diff_norms_kernel(size_t n, VecList v, VecList v2, double scale,
+                                                                  GridRed g) {
+    double r[2] = {0, 0};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        double u = 0, w = 0;
+        for (int j = 0; j < v.n; ++j) {
+            const double x = v.p[j][i];
+            u += v.c[j] * x;
+            w += v2.c[j] * x;
+        }
+        const double d = scale * w - u;
+        r[0] += d * d;
+        r[1] += u * u;
+    }
+    grid_commit<2>(r, 2, 0u, g);
+}
+
+// out[j] = x . ys[j]; x is read once per element
 __global__ void __launch_bounds__(256) multi_dot_kernel(size_t n, const double* __restrict__ x, VecList v,
-                                                        double* out) {
+                                                        GridRed g) {
     double acc[MAX_VEC];
     for (int j = 0; j < MAX_VEC; ++j) acc[j] = 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -179,10 +281,7 @@ __global__ void __launch_bounds__(256) multi_dot_kernel(size_t n, const double* 
         for (int j = 0; j < MAX_VEC; ++j)
             if (j < v.n) acc[j] += xi * v.p[j][i];
     }
-    for (int j = 0; j < v.n; ++j) {
-        block_reduce_commit<false>(acc[j], out + j);
-        __syncthreads();
-    }
+    grid_commit<MAX_VEC>(acc, v.n, 0u, g);
 }
 
 __global__ void vmul_kernel(size_t n, const double* x, const double* y, double* out) {
@@ -195,40 +294,61 @@ __global__ void inv_diag_kernel(CsrDev A, double scale, double* d) {
     if (i < A.n) d[i] = 1.0 / (scale * csr_diag(A, i));
 }
 
-__global__ void __launch_bounds__(256) nonfinite_kernel(size_t n, const double* x, double* out) {
-    double s = 0;
+__global__ void __launch_bounds__(256) nonfinite_kernel(size_t n, const double* x, GridRed g) {
+    double s[1] = {0};
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (size_t)gridDim.x * blockDim.x)
-        s += isfinite(x[i]) ? 0.0 : 1.0;
-    block_reduce_commit<false>(s, out);
+        s[0] += isfinite(x[i]) ? 0.0 : 1.0;
+    grid_commit<1>(s, 1, 0u, g);
 }
 
 __global__ void __launch_bounds__(256) allclose_kernel(size_t n, const double* a, const double* b,
-                                                       double eps, double* out) {
-    double m = -1e300;
+                                                       double eps, GridRed g) {
+    double m[1] = {-1e300};
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (size_t)gridDim.x * blockDim.x)
-        m = fmax(m, allclose_excess1(a[i], b[i], eps));
-    block_reduce_commit<true>(m, out);
+        m[0] = fmax(m[0], allclose_excess1(a[i], b[i], eps));
+    grid_commit<1>(m, 1, 1u, g);
 }
 
 // fused reductions of the ANM sanity check: out[0] = max allclose excess, out[1] = dot
 __global__ void __launch_bounds__(256) sanity_kernel(size_t n, const double* a, const double* b,
                                                      double eps, size_t n1, const double* x,
-                                                     const double* y, double* out) {
-    double m = -1e300, s = 0;
+                                                     const double* y, GridRed g) {
+    double v[2] = {-1e300, 0};
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1;
          i += (size_t)gridDim.x * blockDim.x) {
-        if (i < n) m = fmax(m, allclose_excess1(a[i], b[i], eps));
-        s += x[i] * y[i];
+        if (i < n) v[0] = fmax(v[0], allclose_excess1(a[i], b[i], eps));
+        v[1] += x[i] * y[i];
     }
-    block_reduce_commit<true>(m, out);
-    __syncthreads();
-    block_reduce_commit<false>(s, out + 1);
+    grid_commit<2>(v, 2, 1u, g);
+}
+
+// the per-order sanity check without materialising A*xi or the right-hand side: SPMV_LANES lanes per row
+__global__ void __launch_bounds__(256) sanity_check_kernel(CsrDev A, const double* __restrict__ xi,
+                                                           const double* ti_ptr, double ti_val,
+                                                           const double* __restrict__ grad_t,
+                                                           const double* __restrict__ bi, double eps, size_t n1,
+                                                           const double* __restrict__ x1, GridRed g) {
+    double v[2] = {-1e300, 0};
+    const double ti = ti_ptr ? *ti_ptr : ti_val;
+    const int sub = threadIdx.x % SPMV_LANES;
+    for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < (int64_t)A.n * SPMV_LANES;
+         gid += (int64_t)gridDim.x * blockDim.x) {  // A.n * SPMV_LANES is a multiple of the group size
+        const int64_t row = gid / SPMV_LANES;
+        double s = 0;
+        for (uint32_t p = A.rowptr[row] + sub, e = A.rowptr[row + 1]; p < e; p += SPMV_LANES)
+            s += A.val[p] * xi[A.col[p]];
+        for (int off = SPMV_LANES / 2; off > 0; off >>= 1) s += __shfl_down(s, off, SPMV_LANES);
+        if (sub == 0) v[0] = fmax(v[0], allclose_excess1(s, -ti * grad_t[row] - bi[row], eps));
+        if ((size_t)gid < n1) v[1] += x1[gid] * xi[gid];
+    }
+    grid_commit<2>(v, 2, 1u, g);
 }
 
 __global__ void __launch_bounds__(256) t0v_kernel(size_t n, const double* fx, const double* v,
-                                                  double t0, double tol, double* out) {
+                                                  double t0, double tol, GridRed g) {
+    double mm[1];
     double m = -1e300;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (size_t)gridDim.x * blockDim.x) {
@@ -238,7 +358,8 @@ __global__ void __launch_bounds__(256) t0v_kernel(size_t n, const double* fx, co
         double d = fabs(a + b);
         m = fmax(m, (d == d) ? d - me : 1e300);
     }
-    block_reduce_commit<true>(m, out);
+    mm[0] = m;
+    grid_commit<1>(mm, 1, 1u, g);
 }
 
 
@@ -345,11 +466,16 @@ constexpr int PCG_CHECK_EVERY = 64;
 inline unsigned nblk(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 inline unsigned red_grid(size_t n) {
     size_t g = (n + 255) / 256;
-    return (unsigned)(g < 1 ? 1 : (g > 1024 ? 1024 : g));
+    return (unsigned)(g < 1 ? 1 : (g > RED_MAX_GRID ? RED_MAX_GRID : g));
 }
 
 class HipBackend final : public Backend {
     hipStream_t m_stream = nullptr;
+    GridRed m_red{nullptr, nullptr, nullptr};
+    static constexpr size_t kPoolBlockMax = size_t(64) << 20, kPoolTotalMax = size_t(4) << 30;
+    std::unordered_map<void*, size_t> m_live;
+    std::unordered_map<size_t, std::vector<void*>> m_pool_free;
+    size_t m_pool_cached = 0;
     double* m_scalar = nullptr;  // device scratch for reductions
     double* m_scalar_host = nullptr;  // pinned
     double* m_pcg_w[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -363,9 +489,6 @@ class HipBackend final : public Backend {
     size_t m_pass_lds_limit[4] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
     static constexpr int kBiasWaves = 3;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> m_pass_events;
-    double* m_pool = nullptr;
-    double* m_pool_host = nullptr;
-    int m_pool_next = 0;
 
 public:
     explicit HipBackend(int device) {
@@ -384,8 +507,11 @@ public:
     }
     ~HipBackend() override {
         (void)hipFree(m_scalar);
-        if (m_pool) (void)hipFree(m_pool);
-        if (m_pool_host) (void)hipHostFree(m_pool_host);
+        for (auto& kv : m_pool_free)
+            for (void* p : kv.second) (void)hipFree(p);
+        if (m_red.partials) (void)hipFree(m_red.partials);
+        if (m_red.ticket) (void)hipFree(m_red.ticket);
+        if (m_red.host) (void)hipHostFree(m_red.host);
         for (double* w : m_pcg_w)
             if (w) (void)hipFree(w);
         if (m_pcg_sc) (void)hipFree(m_pcg_sc);
@@ -395,13 +521,36 @@ public:
     }
     const char* name() const override { return "hip"; }
 
+    // Work vectors come and go every continuation step (Pade basis, range checks); hipMalloc / hipFree
+    // cost tens of microseconds each and hipFree synchronises the device, so freed blocks of up to
+    // kPoolBlockMax bytes are kept and handed out again by exact size.  Everything runs on one stream, so a
+    // recycled block is never written before its previous readers have finished.
     void* alloc(size_t bytes) override {
+        if (!bytes) bytes = 8;
+        auto it = m_pool_free.find(bytes);
+        if (it != m_pool_free.end() && !it->second.empty()) {
+            void* p = it->second.back();
+            it->second.pop_back();
+            m_pool_cached -= bytes;
+            m_live[p] = bytes;
+            return p;
+        }
         void* p = nullptr;
-        HIP_CHECK(hipMalloc(&p, bytes ? bytes : 8));
+        HIP_CHECK(hipMalloc(&p, bytes));
+        m_live[p] = bytes;
         return p;
     }
     void free(void* p) override {
-        if (p) (void)hipFree(p);
+        if (!p) return;
+        auto it = m_live.find(p);
+        const size_t bytes = it == m_live.end() ? 0 : it->second;
+        if (it != m_live.end()) m_live.erase(it);
+        if (bytes && bytes <= kPoolBlockMax && m_pool_cached + bytes <= kPoolTotalMax) {
+            m_pool_free[bytes].push_back(p);
+            m_pool_cached += bytes;
+        } else {
+            (void)hipFree(p);
+        }
     }
     void h2d(void* dst, const void* src, size_t bytes) override {
         if (!bytes) return;
@@ -680,47 +829,40 @@ public:
         return (double)ms / reps;
     }
 
-    double fetch_scalar() {
-        HIP_CHECK(hipMemcpyAsync(m_scalar_host, m_scalar, sizeof(double), hipMemcpyDeviceToHost,
-                                 m_stream));
+    // reductions read by the host: see grid_commit
+    GridRed red() {
+        if (!m_red.partials) {
+            HIP_CHECK(hipMalloc(&m_red.partials, MAX_VEC * RED_MAX_GRID * sizeof(double)));
+            HIP_CHECK(hipMalloc(&m_red.ticket, sizeof(unsigned)));
+            HIP_CHECK(hipMemset(m_red.ticket, 0, sizeof(unsigned)));
+            HIP_CHECK(hipHostMalloc(&m_red.host, MAX_VEC * sizeof(double)));
+        }
+        return m_red;
+    }
+    GridRed red_to(double* out) {  // same partials / ticket, result to `out` (device or pinned memory)
+        GridRed g = red();
+        g.host = out;
+        return g;
+    }
+    const double* red_result() {
+        HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(m_stream));
-        return *m_scalar_host;
-    }
-    void set_scalar(double v) {
-        *m_scalar_host = v;
-        HIP_CHECK(hipMemcpyAsync(m_scalar, m_scalar_host, sizeof(double), hipMemcpyHostToDevice,
-                                 m_stream));
-    }
-
-    // pre-zeroed accumulator slots: one memset per POOL_SLOTS reductions instead of
-    // one per reduction
-    static constexpr int POOL_SLOTS = 4096;
-    double* take_slots(int cnt) {
-        if (!m_pool) {
-            HIP_CHECK(hipMalloc(&m_pool, POOL_SLOTS * sizeof(double)));
-            HIP_CHECK(hipHostMalloc(&m_pool_host, 64 * sizeof(double)));
-            m_pool_next = POOL_SLOTS;
-        }
-        if (m_pool_next + cnt > POOL_SLOTS) {
-            HIP_CHECK(hipMemsetAsync(m_pool, 0, POOL_SLOTS * sizeof(double), m_stream));
-            m_pool_next = 0;
-        }
-        double* r = m_pool + m_pool_next;
-        m_pool_next += cnt;
-        return r;
+        return m_red.host;
     }
     double dot(size_t n, const double* x, const double* y) override {
-        double* slot = take_slots(1);
-        hipLaunchKernelGGL(dot_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, y, slot);
-        HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipMemcpyAsync(m_pool_host, slot, sizeof(double), hipMemcpyDeviceToHost, m_stream));
-        HIP_CHECK(hipStreamSynchronize(m_stream));
-        return *m_pool_host;
+        hipLaunchKernelGGL(dot_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, y, red());
+        return red_result()[0];
     }
     void axpby(size_t n, double a, const double* x, double b, const double* y,
                double* out) override {
         hipLaunchKernelGGL(axpby_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, a, x, b, y,
                            out);
+        HIP_CHECK(hipGetLastError());
+    }
+    void axpby_tail(size_t n, double a, const double* x, double b, const double* y, double* out,
+                    double tail) override {
+        hipLaunchKernelGGL(axpby_tail_kernel, dim3(nblk(n + 1, 256)), dim3(256), 0, m_stream, n, a, x, b, y,
+                           out, tail);
         HIP_CHECK(hipGetLastError());
     }
     void lincomb(size_t n, int nvec, const double* const* ptrs, const double* coefs,
@@ -735,6 +877,22 @@ public:
         hipLaunchKernelGGL(lincomb_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, v, out);
         HIP_CHECK(hipGetLastError());
     }
+    void lincomb2_diff_norms(size_t n, int nvec, const double* const* ptrs, const double* c1,
+                             const double* c2, double scale, double out_host[2]) override {
+        if (nvec > MAX_VEC) sanm_throw(SANM_ERR_ASSERT, "lincomb2_diff_norms: too many vectors");
+        VecList v{}, v2{};
+        v.n = v2.n = nvec;
+        for (int j = 0; j < nvec; ++j) {
+            v.p[j] = ptrs[j];
+            v.c[j] = c1[j];
+            v2.c[j] = c2[j];
+        }
+        hipLaunchKernelGGL(lincomb2_diff_norms_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, v, v2,
+                           scale, red());
+        const double* r = red_result();
+        out_host[0] = r[0];
+        out_host[1] = r[1];
+    }
     void multi_dot(size_t n, const double* x, int nvec, const double* const* ys,
                    double* out_host) override {
         if (nvec > MAX_VEC) sanm_throw(SANM_ERR_ASSERT, "multi_dot: too many vectors");
@@ -742,13 +900,9 @@ public:
         VecList v{};
         v.n = nvec;
         for (int j = 0; j < nvec; ++j) v.p[j] = ys[j];
-        double* slots = take_slots(nvec);
-        hipLaunchKernelGGL(multi_dot_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, slots);
-        HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipMemcpyAsync(m_pool_host, slots, nvec * sizeof(double), hipMemcpyDeviceToHost,
-                                 m_stream));
-        HIP_CHECK(hipStreamSynchronize(m_stream));
-        for (int j = 0; j < nvec; ++j) out_host[j] = m_pool_host[j];
+        hipLaunchKernelGGL(multi_dot_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, red());
+        const double* r = red_result();
+        for (int j = 0; j < nvec; ++j) out_host[j] = r[j];
     }
     void vmul(size_t n, const double* x, const double* y, double* out) override {
         hipLaunchKernelGGL(vmul_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, x, y, out);
@@ -760,42 +914,85 @@ public:
         HIP_CHECK(hipGetLastError());
     }
     int64_t count_nonfinite(size_t n, const double* x) override {
-        HIP_CHECK(hipMemsetAsync(m_scalar, 0, sizeof(double), m_stream));
-        hipLaunchKernelGGL(nonfinite_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x,
-                           m_scalar);
-        HIP_CHECK(hipGetLastError());
-        return (int64_t)fetch_scalar();
+        hipLaunchKernelGGL(nonfinite_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, red());
+        return (int64_t)red_result()[0];
     }
     double allclose_excess(size_t n, const double* a, const double* b, double eps) override {
-        set_scalar(-1e300);
         hipLaunchKernelGGL(allclose_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, a, b, eps,
-                           m_scalar);
-        HIP_CHECK(hipGetLastError());
-        return fetch_scalar();
+                           red());
+        return red_result()[0];
     }
     void sanity_reduce(size_t n, const double* a, const double* b, double eps, size_t n1,
                        const double* x, const double* y, double out[2]) override {
         if (n1 < n) sanm_throw(SANM_ERR_ASSERT, "sanity_reduce: n1 < n");
-        m_scalar_host[0] = -1e300;
-        m_scalar_host[1] = 0.0;
-        HIP_CHECK(hipMemcpyAsync(m_scalar, m_scalar_host, 2 * sizeof(double), hipMemcpyHostToDevice,
-                                 m_stream));
         hipLaunchKernelGGL(sanity_kernel, dim3(red_grid(n1)), dim3(256), 0, m_stream, n, a, b, eps, n1, x,
-                           y, m_scalar);
+                           y, red());
+        const double* r = red_result();
+        out[0] = r[0];
+        out[1] = r[1];
+    }
+    void sanity_check(const CsrDev& A, const double* xi, double ti, const double* grad_t, const double* bi,
+                      double eps, size_t n1, const double* x1, double*, double*, double out[2]) override {
+        if (n1 > (size_t)A.n * SPMV_LANES) sanm_throw(SANM_ERR_ASSERT, "sanity_check: n1 too large");
+        hipLaunchKernelGGL(sanity_check_kernel, dim3(red_grid((size_t)A.n * SPMV_LANES)), dim3(256), 0,
+                           m_stream, A, xi, (const double*)nullptr, ti, grad_t, bi, eps, n1, x1, red());
+        const double* r = red_result();
+        out[0] = r[0];
+        out[1] = r[1];
+    }
+    void sanity_check_async(const CsrDev& A, const double* xi, const double* grad_t, const double* bi,
+                            double eps, size_t n1, const double* x1, double*, double*, double* out2) override {
+        if (n1 > (size_t)A.n * SPMV_LANES) sanm_throw(SANM_ERR_ASSERT, "sanity_check: n1 too large");
+        hipLaunchKernelGGL(sanity_check_kernel, dim3(red_grid((size_t)A.n * SPMV_LANES)), dim3(256), 0,
+                           m_stream, A, xi, xi + A.n, 0.0, grad_t, bi, eps, n1, x1, red_to(out2));
         HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipMemcpyAsync(m_scalar_host, m_scalar, 2 * sizeof(double), hipMemcpyDeviceToHost,
-                                 m_stream));
-        HIP_CHECK(hipStreamSynchronize(m_stream));
-        out[0] = m_scalar_host[0];
-        out[1] = m_scalar_host[1];
+    }
+    void multi_dot_async(size_t n, const double* x, int nvec, const double* const* ys, double* out) override {
+        if (nvec > MAX_VEC) sanm_throw(SANM_ERR_ASSERT, "multi_dot: too many vectors");
+        if (nvec == 0) return;
+        VecList v{};
+        v.n = nvec;
+        for (int j = 0; j < nvec; ++j) v.p[j] = ys[j];
+        hipLaunchKernelGGL(multi_dot_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, red_to(out));
+        HIP_CHECK(hipGetLastError());
+    }
+    void gs_update_async(size_t n, const double* x, int nvec, const double* const* qs, const double* coefs,
+                         int first, double* out) override {
+        if (nvec > MAX_VEC) sanm_throw(SANM_ERR_ASSERT, "gs_update: too many vectors");
+        VecList v{};
+        v.n = nvec;
+        for (int j = 0; j < nvec; ++j) v.p[j] = qs[j];
+        hipLaunchKernelGGL(gs_update_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, x, v, coefs, first,
+                           out);
+        HIP_CHECK(hipGetLastError());
+    }
+    void scale_rsqrt_async(size_t n, double* v, const double* norm2, double eps) override {
+        hipLaunchKernelGGL(scale_rsqrt_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, v, norm2, eps);
+        HIP_CHECK(hipGetLastError());
+    }
+    void dot_async(size_t n, const double* x, const double* y, double* out) override {
+        hipLaunchKernelGGL(dot_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, y, red_to(out));
+        HIP_CHECK(hipGetLastError());
+    }
+    void next_coeff_async(size_t n, const double* num, double scale, const double* x, const double* y,
+                          double* out, double* t_out) override {
+        hipLaunchKernelGGL(next_coeff_kernel, dim3(nblk(n + 1, 256)), dim3(256), 0, m_stream, n, num, scale, x,
+                           y, out, t_out);
+        HIP_CHECK(hipGetLastError());
+    }
+    double* alloc_host(size_t n) override {
+        double* p = nullptr;
+        HIP_CHECK(hipHostMalloc(&p, (n ? n : 1) * sizeof(double)));
+        return p;
+    }
+    void free_host(double* p) override {
+        if (p) (void)hipHostFree(p);
     }
     double t0v_excess(size_t n, const double* fx, const double* v, double t0,
                       double tol) override {
-        set_scalar(-1e300);
         hipLaunchKernelGGL(t0v_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, fx, v, t0, tol,
-                           m_scalar);
-        HIP_CHECK(hipGetLastError());
-        return fetch_scalar();
+                           red());
+        return red_result()[0];
     }
 };
 

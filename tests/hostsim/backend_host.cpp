@@ -55,6 +55,40 @@ public:
                double* out) override {
         for (size_t i = 0; i < n; ++i) out[i] = b == 0.0 ? a * x[i] : a * x[i] + b * y[i];
     }
+    double* alloc_host(size_t n) override { return static_cast<double*>(std::malloc(std::max<size_t>(n, 1) * 8)); }
+    void free_host(double* p) override { std::free(p); }
+    void dot_async(size_t n, const double* x, const double* y, double* out) override { *out = dot(n, x, y); }
+    void multi_dot_async(size_t n, const double* x, int nvec, const double* const* ys, double* out) override {
+        multi_dot(n, x, nvec, ys, out);
+    }
+    void gs_update_async(size_t n, const double* x, int nvec, const double* const* qs, const double* coefs,
+                         int first, double* out) override {
+        for (size_t i = 0; i < n; ++i) {
+            double acc = x[i];
+            for (int j = first; j < nvec; ++j) acc += -coefs[j] * qs[j][i];
+            out[i] = acc;
+        }
+    }
+    void scale_rsqrt_async(size_t n, double* v, const double* norm2, double eps) override {
+        const double s = 1.0 / std::max(std::sqrt(*norm2), eps);
+        for (size_t i = 0; i < n; ++i) v[i] *= s;
+    }
+    void next_coeff_async(size_t n, const double* num, double scale, const double* x, const double* y,
+                          double* out, double* t_out) override {
+        const double t = *num * scale;
+        axpby_tail(n, -t, x, -1.0, y, out, t);
+        *t_out = t;
+    }
+    void sanity_check_async(const CsrDev& A, const double* xi, const double* grad_t, const double* bi,
+                            double eps, size_t n1, const double* x1, double* tmp0, double* tmp1,
+                            double* out2) override {
+        sanity_check(A, xi, xi[A.n], grad_t, bi, eps, n1, x1, tmp0, tmp1, out2);
+    }
+    void axpby_tail(size_t n, double a, const double* x, double b, const double* y, double* out,
+                    double tail) override {
+        axpby(n, a, x, b, y, out);
+        out[n] = tail;
+    }
     void vmul(size_t n, const double* x, const double* y, double* out) override {
         for (size_t i = 0; i < n; ++i) out[i] = x[i] * y[i];
     }
