@@ -130,15 +130,12 @@ PadeApproximation::PadeApproximation(Backend* be, const std::vector<DVec>& xs,
     const double eps = std::numeric_limits<double>::epsilon();
     std::vector<DVec> orth(nx);
     std::vector<const double*> ptrs(nx);
-    std::vector<double> coefs(nx), dots(nx);
     // Classical Gram-Schmidt (the projections use xs[i], not the running uii).  The sweep is queued
     // without waiting for the device: projections and squared norms stay in device memory for the
-    // update / scaling kernels that consume them and come back in one copy at the end.  The one case
-    // that needs a host decision mid-sweep (a basis vector that underflows, aii < eps) re-runs the sweep
-    // step by step.
-    bool redo_on_host = false;
+    // update / scaling kernels that consume them and come back in one copy at the end.
     {
-        DVec acoef{be, (size_t)nx * nx};
+        DVec acoef{be, (size_t)nx * nx + 1};
+        double* scratch = acoef.p() + (size_t)nx * nx;
         for (int i = 1; i <= n; ++i) {
             DVec uii{be, m_len};
             for (int j = 1; j < i; ++j) ptrs[j - 1] = orth[j].p();
@@ -147,12 +144,12 @@ PadeApproximation::PadeApproximation(Backend* be, const std::vector<DVec>& xs,
             // under the ANM condition the projection on the first basis vector is dropped (checked below)
             be->gs_update_async(m_len, xs[i].p(), i - 1, ptrs.data(), row + 1, anm_cond ? 1 : 0, uii.p());
             be->dot_async(m_len, uii.p(), uii.p(), row + i);
-            be->scale_rsqrt_async(m_len, uii.p(), row + i, eps);
+            be->scale_rsqrt_async(m_len, uii.p(), row + i, eps, scratch);
             orth[i] = std::move(uii);
         }
         std::vector<double> h((size_t)nx * nx);
         be->d2h(h.data(), acoef.p(), h.size() * 8);
-        for (int i = 1; i <= n && !redo_on_host; ++i) {
+        for (int i = 1; i <= n; ++i) {
             for (int j = 1; j < i; ++j) {
                 A(i, j) = h[(size_t)i * nx + j];
                 if (anm_cond && j == 1) {
@@ -166,39 +163,7 @@ PadeApproximation::PadeApproximation(Backend* be, const std::vector<DVec>& xs,
                 return;
             }
             A(i, i) = aii;
-            if (aii < eps) redo_on_host = true;
         }
-    }
-    for (int i = 1; redo_on_host && i <= n; ++i) {
-        DVec uii{be, m_len};
-        for (int j = 1; j < i; ++j) ptrs[j - 1] = orth[j].p();
-        be->multi_dot(m_len, xs[i].p(), i - 1, ptrs.data(), dots.data());
-        int nv = 0;
-        ptrs[nv] = xs[i].p();
-        coefs[nv++] = 1.0;
-        for (int j = 1; j < i; ++j) {
-            A(i, j) = dots[j - 1];
-            if (anm_cond && j == 1) {
-                sanm_check(std::fabs(A(i, j)) < 1e-4, "pade: anm condition violated: %g", A(i, j));
-                A(i, j) = 0;
-            } else {
-                ptrs[nv] = orth[j].p();
-                coefs[nv++] = -A(i, j);
-            }
-        }
-        be->lincomb(m_len, nv, ptrs.data(), coefs.data(), uii.p());
-        double aii = std::sqrt(be->dot(m_len, uii.p(), uii.p()));
-        if (aii == 0) {
-            m_d.clear();
-            return;
-        }
-        A(i, i) = aii;
-        be->axpby(m_len, 1.0 / std::max(aii, eps), uii.p(), 0, nullptr, uii.p());
-        if (aii < eps) {
-            double nn = std::sqrt(be->dot(m_len, uii.p(), uii.p()));
-            be->axpby(m_len, 1.0 / nn, uii.p(), 0, nullptr, uii.p());
-        }
-        orth[i] = std::move(uii);
     }
     auto solve_d = [&](std::vector<double>& d, int nn) {
         d.assign(nn, 0.0);

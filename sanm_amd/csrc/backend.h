@@ -161,8 +161,9 @@ public:
     //! out = x - sum_{j >= first} coefs[j] * qs[j]   (coefs: device memory; classical Gram-Schmidt update)
     virtual void gs_update_async(size_t n, const double* x, int nvec, const double* const* qs,
                                  const double* coefs, int first, double* out) = 0;
-    //! v *= 1 / max(sqrt(*norm2), eps)   (norm2: device memory)
-    virtual void scale_rsqrt_async(size_t n, double* v, const double* norm2, double eps) = 0;
+    //! v *= 1 / max(sqrt(*norm2), eps); if sqrt(*norm2) < eps the result is normalised once more by its own
+    //! norm (pade.cpp:60-66).  norm2: device memory; scratch: one double of device memory
+    virtual void scale_rsqrt_async(size_t n, double* v, const double* norm2, double eps, double* scratch) = 0;
     //! sanity_check with t_i read from xi[n]; out2 as in sanity_check
     virtual void sanity_check_async(const CsrDev& A, const double* xi, const double* grad_t, const double* bi,
                                     double eps, size_t n1, const double* x1, double* tmp0, double* tmp1,

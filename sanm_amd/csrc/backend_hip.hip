@@ -144,7 +144,7 @@ __device__ __forceinline__ void block_reduce_commit(double v, double* out) {
 // the last one to arrive (device-scope ticket) combines them in workgroup order -- deterministic, unlike
 // an atomic accumulation -- and writes straight into pinned host memory, so a reduction costs one launch
 // and one stream synchronisation (no accumulator memset, no read-back copy kernel).
-constexpr unsigned RED_MAX_GRID = 256;
+constexpr unsigned RED_MAX_GRID = 2048;
 struct GridRed {
     double* partials;  // [MAX_RED][RED_MAX_GRID]
     unsigned* ticket;
@@ -248,6 +248,23 @@ __global__ void gs_update_kernel(size_t n, const double* __restrict__ x, VecList
 __global__ void scale_rsqrt_kernel(size_t n, double* v, const double* __restrict__ norm2, double eps) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) v[i] *= 1.0 / fmax(sqrt(*norm2), eps);
+}
+
+// second normalisation of an underflowed Gram-Schmidt direction; both kernels leave at once otherwise
+__global__ void __launch_bounds__(256) renorm_dot_kernel(size_t n, const double* __restrict__ v,
+                                                         const double* __restrict__ norm2, double eps, GridRed g) {
+    if (sqrt(*norm2) >= eps) return;
+    double s[1] = {0};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x)
+        s[0] += v[i] * v[i];
+    grid_commit<1>(s, 1, 0u, g);
+}
+__global__ void renorm_scale_kernel(size_t n, double* v, const double* __restrict__ norm2, double eps,
+                                    const double* __restrict__ nn2) {
+    if (sqrt(*norm2) >= eps) return;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] *= 1.0 / sqrt(*nn2);
 }
 
 // Pade range test: two linear combinations of the same vectors, their scaled difference and both norms
@@ -966,8 +983,12 @@ public:
                            out);
         HIP_CHECK(hipGetLastError());
     }
-    void scale_rsqrt_async(size_t n, double* v, const double* norm2, double eps) override {
+    void scale_rsqrt_async(size_t n, double* v, const double* norm2, double eps, double* scratch) override {
         hipLaunchKernelGGL(scale_rsqrt_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, v, norm2, eps);
+        hipLaunchKernelGGL(renorm_dot_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, v, norm2, eps,
+                           red_to(scratch));
+        hipLaunchKernelGGL(renorm_scale_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, v, norm2, eps,
+                           scratch);
         HIP_CHECK(hipGetLastError());
     }
     void dot_async(size_t n, const double* x, const double* y, double* out) override {

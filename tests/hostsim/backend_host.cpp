@@ -69,9 +69,13 @@ public:
             out[i] = acc;
         }
     }
-    void scale_rsqrt_async(size_t n, double* v, const double* norm2, double eps) override {
+    void scale_rsqrt_async(size_t n, double* v, const double* norm2, double eps, double*) override {
         const double s = 1.0 / std::max(std::sqrt(*norm2), eps);
         for (size_t i = 0; i < n; ++i) v[i] *= s;
+        if (std::sqrt(*norm2) < eps) {
+            const double nn = std::sqrt(dot(n, v, v));
+            for (size_t i = 0; i < n; ++i) v[i] *= 1.0 / nn;
+        }
     }
     void next_coeff_async(size_t n, const double* num, double scale, const double* x, const double* y,
                           double* out, double* t_out) override {
