@@ -144,7 +144,7 @@ __device__ __forceinline__ void block_reduce_commit(double v, double* out) {
 // the last one to arrive (device-scope ticket) combines them in workgroup order -- deterministic, unlike
 // an atomic accumulation -- and writes straight into pinned host memory, so a reduction costs one launch
 // and one stream synchronisation (no accumulator memset, no read-back copy kernel).
-constexpr unsigned RED_MAX_GRID = 2048;
+constexpr unsigned RED_MAX_GRID = 512;  // one same-address atomic per workgroup (~12 ns each) bounds the useful grid
 struct GridRed {
     double* partials;  // [MAX_RED][RED_MAX_GRID]
     unsigned* ticket;
@@ -162,24 +162,30 @@ __device__ __forceinline__ void grid_commit(const double (&v)[NV], int nv, unsig
             if (lane == 0) sh[j][w] = r;
         }
     __syncthreads();
+    // Hand-off without cache-wide fences (MI355X_MICROARCH.md, inter-workgroup visibility): the partials are
+    // written through (agent-scope atomic stores), the storing wavefront drains them, one lane signals with
+    // an agent-scope add behind the workgroup barrier, and the workgroup whose add came last reads them
+    // with agent-scope loads.
     if ((int)threadIdx.x < nv) {
         const int j = threadIdx.x;
         const bool mx = (maxmask >> j) & 1;
         double r = sh[j][0];
         for (int i = 1; i < 4; ++i) r = mx ? fmax(r, sh[j][i]) : r + sh[j][i];
-        g.partials[j * RED_MAX_GRID + blockIdx.x] = r;
-        __threadfence();  // release the partial before the ticket
+        __hip_atomic_store(&g.partials[j * RED_MAX_GRID + blockIdx.x], r, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(g.ticket, 1u) == gridDim.x - 1;
+    if (threadIdx.x == 0)
+        last = __hip_atomic_fetch_add(g.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     __syncthreads();
     if (!last) return;
-    __threadfence();  // acquire the other workgroups' partials
     for (int j = w; j < nv; j += 4) {  // one wavefront per value
         const bool mx = (maxmask >> j) & 1;
         double r = mx ? -1e300 : 0.0;
         for (unsigned b = lane; b < gridDim.x; b += 64) {
-            const double pv = g.partials[j * RED_MAX_GRID + b];
+            const double pv = __hip_atomic_load(&g.partials[j * RED_MAX_GRID + b], __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
             r = mx ? fmax(r, pv) : r + pv;
         }
         r = mx ? wave_reduce_max(r) : wave_reduce_sum(r);
@@ -785,16 +791,15 @@ public:
         const int64_t rows = fwd ? L.sum_m : L.sum_k;
         int u = 1;
         while (u < 16 && 64 * u < width) u *= 2;
-        // R * U <= 16 row chunks in registers; short rows are latency-bound, so take as many rows per
-        // wave as still leave about a thousand workgroups
-        int r = 8;
-        while (r > 1 && (r * u > 16 || rows / (4 * r) < 1024)) r /= 2;
+        // R * U <= 16 row chunks in registers, and enough workgroups to fill the chip (measured: more than
+        // 4 rows per wavefront never paid, even on the leaf level)
+        int r = rows >= 16 * 2048 ? 4 : (rows >= 8 * 2048 ? 2 : 1);
+        while (r * u > 16) r /= 2;
 #define SANM_LS(R, U)                         \
     if (r == R && u == U) {                   \
         launch_level_solve<R, U>(fwd, mf, L); \
         return;                               \
     }
-        SANM_LS(8, 1) SANM_LS(8, 2)
         SANM_LS(4, 1) SANM_LS(4, 2) SANM_LS(4, 4)
         SANM_LS(2, 1) SANM_LS(2, 2) SANM_LS(2, 4) SANM_LS(2, 8)
         SANM_LS(1, 1) SANM_LS(1, 2) SANM_LS(1, 4) SANM_LS(1, 8) SANM_LS(1, 16)

@@ -54,29 +54,62 @@ __global__ void __launch_bounds__(256) extend_add_kernel(MfDev mf, const int32_t
 }
 
 // In-LDS LU of a diagonal tile (kb pivots, no pivoting) by a 256-thread
-// workgroup, together with the inverses of the extended tile factors
+// workgroup, followed by the inverses of the extended tile factors
 //   Lext = [[L11,0],[L21,I]] (unit lower),  Uext = [[U11,U12],[0,I]] (upper)
 // written to D = [Lext^-1 | Uext^-1].  On entry T holds the tile (synchronised);
-// on exit T holds the packed factors (synchronised).
+// on exit T holds the packed factors (synchronised).  W is scratch.
 //
-// The inverses ride along with the elimination sweep: step j applies the
-// elementary matrix M_j = I - l_j e_j^T to the trailing columns tc > j of T, and
-// the lanes of the columns tc <= j (idle in a plain right-looking LU) apply the
-// same M_j to LI (which therefore ends as M_{kb-1}...M_0 = Lext^-1) and the
-// analogous M'_j built from row j of U to UT (ending as the inverse of the unit
-// lower factor of Uext^T; Uext^-1[a][b] = UT[b][a] / d_b).  Row j of LI / UT is
-// final before step j and only its first j+1 entries are non-zero.
-__device__ __forceinline__ void tile_factor(double (*T)[TPAD], double (*LI)[TPAD], double (*UT)[TPAD],
-                                            int kb, int tid, double* D, int32_t* status) {
-    const int tc = tid % NB, tr = tid / NB;  // tr in 0..7
+// The elimination is a chain of kb barrier-separated rank-1 updates; the two
+// triangular inverses are NOT built by another 32-step substitution but by
+// recursive blocking: the four 8x8 diagonal blocks by substitution (one lane per
+// column, 8 short steps), then two merge levels
+//   [[A,0],[C,B]]^-1 = [[A^-1,0],[-B^-1 C A^-1, B^-1]]   (and its transpose form for U)
+// as small matrix products over all 256 threads -- five barriers instead of 32.
+__device__ __forceinline__ double tf_l(const double (*T)[TPAD], int kb, int r, int c) {
+    return (c < r && c < kb) ? T[r][c] : (r == c ? 1.0 : 0.0);
+}
+__device__ __forceinline__ double tf_u(const double (*T)[TPAD], int kb, int r, int c) {
+    if (r >= kb) return r == c ? 1.0 : 0.0;
+    if (c < r) return 0.0;
+    const double v = T[r][c];
+    return (c == r && !(fabs(v) > 1e-290)) ? 1.0 : v;
+}
+// one merge level: blocks of size H at offsets (o, o+H) of problem `prob` (0: L, 1: U), output (i, j)
+template <int H>
+__device__ __forceinline__ void tf_merge_mid(const double (*T)[TPAD], const double (*LI)[TPAD],
+                                             const double (*UI)[TPAD], double (*W)[TPAD], int kb, int prob,
+                                             int o, int i, int j) {
+    double acc = 0;
+    if (prob == 0) {  // W = C * A^-1,  C = L[o+H.., o..]
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int r = tr + 8 * s;
-        LI[r][tc] = UT[r][tc] = (r == tc) ? 1.0 : 0.0;
+        for (int q = 0; q < H; ++q) acc += tf_l(T, kb, o + H + i, o + q) * LI[o + q][o + j];
+        W[o + H + i][o + j] = acc;
+    } else {  // W = A^-1 * C,  C = U[o.., o+H..]
+#pragma unroll
+        for (int q = 0; q < H; ++q) acc += UI[o + i][o + q] * tf_u(T, kb, o + q, o + H + j);
+        W[o + i][o + H + j] = acc;
     }
-    __syncthreads();
-    // column j of T is left unscaled during the sweep (later steps never read it),
-    // so one barrier per step suffices
+}
+template <int H>
+__device__ __forceinline__ void tf_merge_fin(double (*LI)[TPAD], double (*UI)[TPAD], const double (*W)[TPAD],
+                                             int prob, int o, int i, int j) {
+    double acc = 0;
+    if (prob == 0) {  // X21 = -B^-1 * W
+#pragma unroll
+        for (int q = 0; q < H; ++q) acc += LI[o + H + i][o + H + q] * W[o + H + q][o + j];
+        LI[o + H + i][o + j] = -acc;
+    } else {  // X12 = -W * B^-1
+#pragma unroll
+        for (int q = 0; q < H; ++q) acc += W[o + i][o + H + q] * UI[o + H + q][o + H + j];
+        UI[o + i][o + H + j] = -acc;
+    }
+}
+
+__device__ __forceinline__ void tile_factor(double (*T)[TPAD], double (*LI)[TPAD], double (*UI)[TPAD],
+                                            double (*W)[TPAD], int kb, int tid, double* D, int32_t* status) {
+    const int tc = tid % NB, tr = tid / NB;  // tr in 0..7
+    // right-looking elimination; column j is left unscaled during the sweep (later
+    // steps never read it), so one barrier per step suffices
     for (int j = 0; j < kb; ++j) {
         double piv = T[j][j];
         if (!(fabs(piv) > 1e-290)) {
@@ -91,30 +124,71 @@ __device__ __forceinline__ void tile_factor(double (*T)[TPAD], double (*LI)[TPAD
                 const int r = tr + 8 * s;
                 if (r > j) T[r][tc] -= (T[r][j] * inv) * u;
             }
-        } else {
-            const double lj = LI[j][tc], uj = UT[j][tc];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int r = tr + 8 * s;
-                if (r > j) {
-                    LI[r][tc] -= (T[r][j] * inv) * lj;
-                    UT[r][tc] -= (T[j][r] * inv) * uj;
-                }
-            }
         }
         __syncthreads();
     }
-    // scale the L columns; emit the inverses
-    const double dc = (tc < kb && fabs(T[tc][tc]) > 1e-290) ? T[tc][tc] : 1.0;
-    const double dinv = 1.0 / dc;
+    // scale the L columns; clear the inverses
+    {
+        const double d = (tc < kb) ? T[tc][tc] : 1.0;
+        const double dinv = 1.0 / ((fabs(d) > 1e-290) ? d : 1.0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int r = tr + 8 * s;
+            if (tc < kb && r > tc) T[r][tc] *= dinv;
+            LI[r][tc] = 0.0;
+            UI[r][tc] = 0.0;
+        }
+    }
+    __syncthreads();
+    // 8x8 diagonal blocks: lanes 0..31 one column of Lext^-1 each, lanes 32..63 one of Uext^-1
+    if (tid < 64) {
+        const int o = ((tid & 31) / 8) * 8, c = tid & 7;
+        double x[8];
+        if (tid < 32) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                double v = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (q >= c && q < r) v -= tf_l(T, kb, o + r, o + q) * x[q];
+                x[r] = (r < c) ? 0.0 : v;
+                LI[o + r][o + c] = x[r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 7; r >= 0; --r) {
+                double v = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+                for (int q = 7; q >= 0; --q)
+                    if (q > r && q <= c) v -= tf_u(T, kb, o + r, o + q) * x[q];
+                x[r] = (r > c) ? 0.0 : v / tf_u(T, kb, o + r, o + r);
+                UI[o + r][o + c] = x[r];
+            }
+        }
+    }
+    __syncthreads();
+    {  // 8 -> 16: four problems (L / U) x (pair 0 / 1), 64 outputs each
+        const int prob = (tid >> 6) & 1, o = (tid >> 7) * 16, i = (tid & 63) >> 3, j = tid & 7;
+        tf_merge_mid<8>(T, LI, UI, W, kb, prob, o, i, j);
+        __syncthreads();
+        tf_merge_fin<8>(LI, UI, W, prob, o, i, j);
+        __syncthreads();
+    }
+    {  // 16 -> 32: two problems, 256 outputs each: every thread one output of both
+        const int i = tid >> 4, j = tid & 15;
+        tf_merge_mid<16>(T, LI, UI, W, kb, 0, 0, i, j);
+        tf_merge_mid<16>(T, LI, UI, W, kb, 1, 0, i, j);
+        __syncthreads();
+        tf_merge_fin<16>(LI, UI, W, 0, 0, i, j);
+        tf_merge_fin<16>(LI, UI, W, 1, 0, i, j);
+        __syncthreads();
+    }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int r = tr + 8 * s;
-        if (tc < kb && r > tc) T[r][tc] *= dinv;
         D[r * NB + tc] = LI[r][tc];
-        D[NB * NB + r * NB + tc] = UT[tc][r] * dinv;
+        D[NB * NB + r * NB + tc] = UI[r][tc];
     }
-    __syncthreads();
 }
 
 // diagonal tile of panel p of every front of a level
@@ -122,7 +196,7 @@ __global__ void __launch_bounds__(256) diag_kernel(MfDev mf, int level_begin, in
     const MfFrontDev f = mf.fronts[mf.level_fronts[level_begin + blockIdx.x]];
     const int ld = f.ld, m = 2 * f.k, r0 = p * NB;  // m: extent of the pivot + augmentation block
     const int kb = min(NB, f.k - r0);
-    __shared__ double T[NB][TPAD], LI[NB][TPAD], UI[NB][TPAD];
+    __shared__ double T[NB][TPAD], LI[NB][TPAD], UI[NB][TPAD], W[NB][TPAD];
     double* F = mf.front_store + f.off;
     const int tid = threadIdx.x, tc = tid % NB, tr = tid / NB;
     for (int s = 0; s < 4; ++s) {
@@ -130,7 +204,7 @@ __global__ void __launch_bounds__(256) diag_kernel(MfDev mf, int level_begin, in
         T[r][tc] = (gr < m && gc < m) ? F[(int64_t)gr * ld + gc] : (r == tc ? 1.0 : 0.0);
     }
     __syncthreads();
-    tile_factor(T, LI, UI, kb, tid, mf.dinv_store + f.dinv_off + (int64_t)p * 2 * NB * NB, mf.status);
+    tile_factor(T, LI, UI, W, kb, tid, mf.dinv_store + f.dinv_off + (int64_t)p * 2 * NB * NB, mf.status);
     for (int s = 0; s < 4; ++s) {
         int r = tr + 8 * s, gr = r0 + r, gc = r0 + tc;
         if (gr < m && gc < m) F[(int64_t)gr * ld + gc] = T[r][tc];
@@ -186,7 +260,7 @@ __global__ void __launch_bounds__(256) update_kernel(MfDev mf, int level_begin, 
     // the (augmentation x augmentation) corner is never used
     if (ti * NB >= f.k && tj * NB >= f.k) return;
     const int kb = min(NB, f.k - p * NB);
-    __shared__ double L[NB][TPAD], U[NB][TPAD], T[NB][TPAD];
+    __shared__ double L[NB][TPAD], U[NB][TPAD], T[NB][TPAD], W[NB][TPAD];
     double* F = mf.front_store + f.off;
     const int tid = threadIdx.x, tc = tid % NB, tr = tid / NB;
     for (int s = 0; s < 4; ++s) {
@@ -214,7 +288,7 @@ __global__ void __launch_bounds__(256) update_kernel(MfDev mf, int level_begin, 
     if (!next_diag) return;
     __syncthreads();
     const int kb1 = min(NB, f.k - (p + 1) * NB);
-    tile_factor(T, L, U, kb1, tid, mf.dinv_store + f.dinv_off + (int64_t)(p + 1) * 2 * NB * NB, mf.status);
+    tile_factor(T, L, U, W, kb1, tid, mf.dinv_store + f.dinv_off + (int64_t)(p + 1) * 2 * NB * NB, mf.status);
     for (int s = 0; s < 4; ++s) {
         int r = tr + 8 * s, gr = ti * NB + r, gc = tj * NB + tc;
         if (gr < m && gc < m) F[(int64_t)gr * ld + gc] = T[r][tc];
