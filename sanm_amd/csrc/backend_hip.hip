@@ -744,8 +744,8 @@ public:
                 const int cnt = L.panel_cnt[p];
                 const int rem = nt - p - 1;
                 if (rem <= 0) continue;
-                hipLaunchKernelGGL(trsm_kernel, dim3(rem, 2, cnt), dim3(256), 0, m_stream, mf,
-                                   L.front_begin, p);
+                hipLaunchKernelGGL(trsm_kernel, dim3((rem + TRSM_TILES - 1) / TRSM_TILES, 2, cnt), dim3(256), 0,
+                                   m_stream, mf, L.front_begin, p);
                 hipLaunchKernelGGL(update_kernel, dim3(rem, rem, cnt), dim3(256), 0, m_stream, mf,
                                    L.front_begin, p);
             }

@@ -13,6 +13,7 @@
 //   3. gemm2_kernel:  F[B,B] -= tmpL tmpU,  F[B,A] = -tmpL L11^-1,  F[A,B] = -U11^-1 tmpU
 // so the Schur complement is read and written once instead of once per panel.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include "mf_types.h"
@@ -53,60 +54,11 @@ __global__ void __launch_bounds__(256) extend_add_kernel(MfDev mf, const int32_t
     mf.front_store[p.off + (int64_t)rel[i] * p.ld + rel[j]] += v;
 }
 
-// In-LDS LU of a diagonal tile (kb pivots, no pivoting) by a 256-thread
-// workgroup, followed by the inverses of the extended tile factors
-//   Lext = [[L11,0],[L21,I]] (unit lower),  Uext = [[U11,U12],[0,I]] (upper)
-// written to D = [Lext^-1 | Uext^-1].  On entry T holds the tile (synchronised);
-// on exit T holds the packed factors (synchronised).  W is scratch.
-//
-// The elimination is a chain of kb barrier-separated rank-1 updates; the two
-// triangular inverses are NOT built by another 32-step substitution but by
-// recursive blocking: the four 8x8 diagonal blocks by substitution (one lane per
-// column, 8 short steps), then two merge levels
-//   [[A,0],[C,B]]^-1 = [[A^-1,0],[-B^-1 C A^-1, B^-1]]   (and its transpose form for U)
-// as small matrix products over all 256 threads -- five barriers instead of 32.
-__device__ __forceinline__ double tf_l(const double (*T)[TPAD], int kb, int r, int c) {
-    return (c < r && c < kb) ? T[r][c] : (r == c ? 1.0 : 0.0);
-}
-__device__ __forceinline__ double tf_u(const double (*T)[TPAD], int kb, int r, int c) {
-    if (r >= kb) return r == c ? 1.0 : 0.0;
-    if (c < r) return 0.0;
-    const double v = T[r][c];
-    return (c == r && !(fabs(v) > 1e-290)) ? 1.0 : v;
-}
-// one merge level: blocks of size H at offsets (o, o+H) of problem `prob` (0: L, 1: U), output (i, j)
-template <int H>
-__device__ __forceinline__ void tf_merge_mid(const double (*T)[TPAD], const double (*LI)[TPAD],
-                                             const double (*UI)[TPAD], double (*W)[TPAD], int kb, int prob,
-                                             int o, int i, int j) {
-    double acc = 0;
-    if (prob == 0) {  // W = C * A^-1,  C = L[o+H.., o..]
-#pragma unroll
-        for (int q = 0; q < H; ++q) acc += tf_l(T, kb, o + H + i, o + q) * LI[o + q][o + j];
-        W[o + H + i][o + j] = acc;
-    } else {  // W = A^-1 * C,  C = U[o.., o+H..]
-#pragma unroll
-        for (int q = 0; q < H; ++q) acc += UI[o + i][o + q] * tf_u(T, kb, o + q, o + H + j);
-        W[o + i][o + H + j] = acc;
-    }
-}
-template <int H>
-__device__ __forceinline__ void tf_merge_fin(double (*LI)[TPAD], double (*UI)[TPAD], const double (*W)[TPAD],
-                                             int prob, int o, int i, int j) {
-    double acc = 0;
-    if (prob == 0) {  // X21 = -B^-1 * W
-#pragma unroll
-        for (int q = 0; q < H; ++q) acc += LI[o + H + i][o + H + q] * W[o + H + q][o + j];
-        LI[o + H + i][o + j] = -acc;
-    } else {  // X12 = -W * B^-1
-#pragma unroll
-        for (int q = 0; q < H; ++q) acc += W[o + i][o + H + q] * UI[o + H + q][o + H + j];
-        UI[o + i][o + H + j] = -acc;
-    }
-}
-
-__device__ __forceinline__ void tile_factor(double (*T)[TPAD], double (*LI)[TPAD], double (*UI)[TPAD],
-                                            double (*W)[TPAD], int kb, int tid, double* D, int32_t* status) {
+// In-LDS LU of a diagonal tile (kb pivots, no pivoting) by a 256-thread workgroup.  On entry T holds
+// the tile (synchronised); on exit the packed factors: multipliers below the diagonal, U on and above it
+// (synchronised).  A partial last panel (kb < NB) leaves rows / columns kb.. of the tile updated by all kb
+// pivots, i.e. holding the part of the trailing matrix that lives in this tile.
+__device__ __forceinline__ void tile_factor(double (*T)[TPAD], int kb, int tid, int32_t* status) {
     const int tc = tid % NB, tr = tid / NB;  // tr in 0..7
     // right-looking elimination; column j is left unscaled during the sweep (later
     // steps never read it), so one barrier per step suffices
@@ -127,68 +79,15 @@ __device__ __forceinline__ void tile_factor(double (*T)[TPAD], double (*LI)[TPAD
         }
         __syncthreads();
     }
-    // scale the L columns; clear the inverses
-    {
-        const double d = (tc < kb) ? T[tc][tc] : 1.0;
-        const double dinv = 1.0 / ((fabs(d) > 1e-290) ? d : 1.0);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int r = tr + 8 * s;
-            if (tc < kb && r > tc) T[r][tc] *= dinv;
-            LI[r][tc] = 0.0;
-            UI[r][tc] = 0.0;
-        }
-    }
-    __syncthreads();
-    // 8x8 diagonal blocks: lanes 0..31 one column of Lext^-1 each, lanes 32..63 one of Uext^-1
-    if (tid < 64) {
-        const int o = ((tid & 31) / 8) * 8, c = tid & 7;
-        double x[8];
-        if (tid < 32) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                double v = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (q >= c && q < r) v -= tf_l(T, kb, o + r, o + q) * x[q];
-                x[r] = (r < c) ? 0.0 : v;
-                LI[o + r][o + c] = x[r];
-            }
-        } else {
-#pragma unroll
-            for (int r = 7; r >= 0; --r) {
-                double v = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-                for (int q = 7; q >= 0; --q)
-                    if (q > r && q <= c) v -= tf_u(T, kb, o + r, o + q) * x[q];
-                x[r] = (r > c) ? 0.0 : v / tf_u(T, kb, o + r, o + r);
-                UI[o + r][o + c] = x[r];
-            }
-        }
-    }
-    __syncthreads();
-    {  // 8 -> 16: four problems (L / U) x (pair 0 / 1), 64 outputs each
-        const int prob = (tid >> 6) & 1, o = (tid >> 7) * 16, i = (tid & 63) >> 3, j = tid & 7;
-        tf_merge_mid<8>(T, LI, UI, W, kb, prob, o, i, j);
-        __syncthreads();
-        tf_merge_fin<8>(LI, UI, W, prob, o, i, j);
-        __syncthreads();
-    }
-    {  // 16 -> 32: two problems, 256 outputs each: every thread one output of both
-        const int i = tid >> 4, j = tid & 15;
-        tf_merge_mid<16>(T, LI, UI, W, kb, 0, 0, i, j);
-        tf_merge_mid<16>(T, LI, UI, W, kb, 1, 0, i, j);
-        __syncthreads();
-        tf_merge_fin<16>(LI, UI, W, 0, 0, i, j);
-        tf_merge_fin<16>(LI, UI, W, 1, 0, i, j);
-        __syncthreads();
-    }
+    // scale the L columns
+    const double d = (tc < kb) ? T[tc][tc] : 1.0;
+    const double dinv = 1.0 / ((fabs(d) > 1e-290) ? d : 1.0);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int r = tr + 8 * s;
-        D[r * NB + tc] = LI[r][tc];
-        D[NB * NB + r * NB + tc] = UI[r][tc];
+        if (tc < kb && r > tc) T[r][tc] *= dinv;
     }
+    __syncthreads();
 }
 
 // diagonal tile of panel p of every front of a level
@@ -196,7 +95,7 @@ __global__ void __launch_bounds__(256) diag_kernel(MfDev mf, int level_begin, in
     const MfFrontDev f = mf.fronts[mf.level_fronts[level_begin + blockIdx.x]];
     const int ld = f.ld, m = 2 * f.k, r0 = p * NB;  // m: extent of the pivot + augmentation block
     const int kb = min(NB, f.k - r0);
-    __shared__ double T[NB][TPAD], LI[NB][TPAD], UI[NB][TPAD], W[NB][TPAD];
+    __shared__ double T[NB][TPAD];
     double* F = mf.front_store + f.off;
     const int tid = threadIdx.x, tc = tid % NB, tr = tid / NB;
     for (int s = 0; s < 4; ++s) {
@@ -204,43 +103,103 @@ __global__ void __launch_bounds__(256) diag_kernel(MfDev mf, int level_begin, in
         T[r][tc] = (gr < m && gc < m) ? F[(int64_t)gr * ld + gc] : (r == tc ? 1.0 : 0.0);
     }
     __syncthreads();
-    tile_factor(T, LI, UI, W, kb, tid, mf.dinv_store + f.dinv_off + (int64_t)p * 2 * NB * NB, mf.status);
+    tile_factor(T, kb, tid, mf.status);
     for (int s = 0; s < 4; ++s) {
         int r = tr + 8 * s, gr = r0 + r, gc = r0 + tc;
         if (gr < m && gc < m) F[(int64_t)gr * ld + gc] = T[r][tc];
     }
 }
 
-// panel tiles: blockIdx.y == 0: U panel tile (p, t) <- Linv * tile
-//              blockIdx.y == 1: L panel tile (t, p) <- tile * Uinv      (t > p)
+// panel tiles by substitution with the factored diagonal tile, 8 tiles per workgroup:
+//   blockIdx.y == 0: U panel tile (p, t): one lane per COLUMN, x_r = b_r - sum_{j<r} l_rj x_j;
+//   blockIdx.y == 1: L panel tile (t, p): one lane per ROW,    x_c = (b_c - sum_{j<c} x_j u_jc) / u_cc   (t > p)
+// The workgroup first lays the factor out in LDS as S[i][j] (j < i) = l_ij resp. u_ji, zero for pivots
+// j >= kb, with 1/u_ii beside it (1 for i >= kb): row i is then one contiguous broadcast read, the
+// substitution is branch-free straight-line code over a register array, and the rows / columns kb.. of a
+// partial panel receive their trailing update by the same formula.
+// (Earlier versions multiplied by explicit inverses of the tile factors; building those inverses cost the
+// look-ahead tile LU as much again as the elimination itself, on the critical path of every panel.)
+constexpr int TRSM_TILES = 8;
+constexpr int SPAD = NB + 2;  // even row stride: 16-byte aligned rows
+template <bool SCALE>
+__device__ __forceinline__ void trsm_sweep(const double (*S)[SPAD], const double* Dv, double (&x)[NB]) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        // keep this row's LDS reads in this step: hoisted to the top they would all have to be spilled
+        // asm volatile("" ::: "memory");
+        double a0 = x[i], a1 = 0;
+#pragma unroll
+        for (int j = 0; j + 1 < i; j += 2) {
+            const double2 l = *reinterpret_cast<const double2*>(&S[i][j]);
+            a0 -= l.x * x[j];
+            a1 -= l.y * x[j + 1];
+        }
+        if (i & 1) a0 -= S[i][i - 1] * x[i - 1];
+        a0 += a1;
+        x[i] = SCALE ? a0 * Dv[i] : a0;
+    }
+}
+
 __global__ void __launch_bounds__(256) trsm_kernel(MfDev mf, int level_begin, int p) {
     const MfFrontDev f = mf.fronts[mf.level_fronts[level_begin + blockIdx.z]];
     const int ld = f.ld, m = 2 * f.k, nt = (m + NB - 1) / NB;
-    const int t = p + 1 + blockIdx.x;
-    if (t >= nt) return;
+    if (p + 1 + (int)blockIdx.x * TRSM_TILES >= nt) return;
     const bool upanel = blockIdx.y == 0;
-    __shared__ double A[NB][TPAD], B[NB][TPAD];
+    const int kb = min(NB, f.k - p * NB);
+    __shared__ __attribute__((aligned(16))) double S[NB][SPAD];
+    __shared__ double Dv[NB];
     double* F = mf.front_store + f.off;
-    const double* D = mf.dinv_store + f.dinv_off + (int64_t)p * 2 * NB * NB + (upanel ? 0 : NB * NB);
-    const int r0 = (upanel ? p : t) * NB, c0 = (upanel ? t : p) * NB;
-    const int tid = threadIdx.x, tc = tid % NB, tr = tid / NB;
+    const int tid = threadIdx.x;
     for (int s = 0; s < 4; ++s) {
-        int r = tr + 8 * s, gr = r0 + r, gc = c0 + tc;
-        A[r][tc] = (gr < m && gc < m) ? F[(int64_t)gr * ld + gc] : 0.0;
-        B[r][tc] = D[r * NB + tc];
+        // (a, c) of the diagonal tile; the L panel wants U transposed: S[c][a] = u_ac
+        const int a = tid / NB + 8 * s, c = tid % NB, ga = p * NB + a, gc = p * NB + c;
+        const double v = (ga < m && gc < m) ? F[(int64_t)ga * ld + gc] : 0.0;
+        if (upanel) {
+            S[a][c] = (c < a && c < kb) ? v : 0.0;
+        } else {
+            S[c][a] = (a < c && a < kb) ? v : 0.0;
+            if (a == c) Dv[a] = (a < kb && fabs(v) > 1e-290) ? 1.0 / v : 1.0;
+        }
     }
     __syncthreads();
-    for (int s = 0; s < 4; ++s) {
-        int r = tr + 8 * s, gr = r0 + r, gc = c0 + tc;
-        double acc = 0;
-        if (upanel) {
-#pragma unroll 8
-            for (int q = 0; q < NB; ++q) acc += B[r][q] * A[q][tc];  // Linv * tile
+    const int t = p + 1 + blockIdx.x * TRSM_TILES + tid / NB, q = tid % NB;
+    if (t >= nt) return;
+    // rows (U panel) / columns (L panel) of the panel that lie inside the 2k x 2k block: all NB of them
+    // except for fronts of fewer than NB - 1 pivots.  Loads clamp their index (a duplicate read is harmless,
+    // per-element predicates cost the register allocation of the whole kernel dearly); stores of a partial
+    // panel take the predicated path.
+    const int vmax = min(NB, m - p * NB) - 1;
+    double x[NB];
+    if (upanel) {
+        const int gc = t * NB + q;
+        if (gc >= m) return;
+        double* col = F + (int64_t)p * NB * ld + gc;
+#pragma unroll
+        for (int r = 0; r < NB; ++r) x[r] = col[(int64_t)min(r, vmax) * ld];
+        trsm_sweep<false>(S, nullptr, x);
+        if (vmax == NB - 1) {
+#pragma unroll
+            for (int r = 0; r < NB; ++r) col[(int64_t)r * ld] = x[r];
         } else {
-#pragma unroll 8
-            for (int q = 0; q < NB; ++q) acc += A[r][q] * B[q][tc];  // tile * Uinv
+#pragma unroll
+            for (int r = 0; r < NB; ++r)
+                if (r <= vmax) col[(int64_t)r * ld] = x[r];
         }
-        if (gr < m && gc < m) F[(int64_t)gr * ld + gc] = acc;
+    } else {
+        const int gr = t * NB + q;
+        if (gr >= m) return;
+        double* row = F + (int64_t)gr * ld + p * NB;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) x[c] = row[min(c, vmax)];
+        trsm_sweep<true>(S, Dv, x);
+        if (vmax == NB - 1) {
+#pragma unroll
+            for (int c = 0; c < NB; ++c) row[c] = x[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+                if (c <= vmax) row[c] = x[c];
+        }
     }
 }
 
@@ -248,10 +207,8 @@ __global__ void __launch_bounds__(256) trsm_kernel(MfDev mf, int level_begin, in
 // Look-ahead: the workgroup that owns the next diagonal tile (p+1,p+1) factors it
 // right after updating it, so panels p >= 1 need no separate diagonal launch and
 // that short sequential LU hides behind the other tiles of the same launch.
-// (tile_factor keeps its inverse columns in LDS: with them in registers the
-// fused kernel lost occupancy and the factorisation got slower; a second stream
-// for the diagonal tile was tried as well -- the cross-stream events cost as
-// much as they hid.)
+// (A second stream for the diagonal tile was tried as well: the cross-stream
+// events cost as much as they hid.)
 __global__ void __launch_bounds__(256) update_kernel(MfDev mf, int level_begin, int p) {
     const MfFrontDev f = mf.fronts[mf.level_fronts[level_begin + blockIdx.z]];
     const int ld = f.ld, m = 2 * f.k, nt = (m + NB - 1) / NB;
@@ -260,7 +217,7 @@ __global__ void __launch_bounds__(256) update_kernel(MfDev mf, int level_begin, 
     // the (augmentation x augmentation) corner is never used
     if (ti * NB >= f.k && tj * NB >= f.k) return;
     const int kb = min(NB, f.k - p * NB);
-    __shared__ double L[NB][TPAD], U[NB][TPAD], T[NB][TPAD], W[NB][TPAD];
+    __shared__ double L[NB][TPAD], U[NB][TPAD], T[NB][TPAD];
     double* F = mf.front_store + f.off;
     const int tid = threadIdx.x, tc = tid % NB, tr = tid / NB;
     for (int s = 0; s < 4; ++s) {
@@ -288,57 +245,95 @@ __global__ void __launch_bounds__(256) update_kernel(MfDev mf, int level_begin, 
     if (!next_diag) return;
     __syncthreads();
     const int kb1 = min(NB, f.k - (p + 1) * NB);
-    tile_factor(T, L, U, W, kb1, tid, mf.dinv_store + f.dinv_off + (int64_t)(p + 1) * 2 * NB * NB, mf.status);
+    tile_factor(T, kb1, tid, mf.status);
     for (int s = 0; s < 4; ++s) {
         int r = tr + 8 * s, gr = ti * NB + r, gc = tj * NB + tc;
         if (gr < m && gc < m) F[(int64_t)gr * ld + gc] = T[r][tc];
     }
 }
 
-// C tile (64x64) of a product of two strided matrices: 256 threads, each a 4x4
-// register block, K in steps of 16 through LDS.  Element (i,j) of an operand is
-// p[i*ld + j] inside (rows, cols), else 0.  K range [k0, k1) in elements.
+// C tile (64x64) of a product of two strided matrices on the fp64 matrix cores: 4 wavefronts, each a
+// 32x32 quadrant = 2x2 tiles of v_mfma_f64_16x16x4_f64 (A: lane l holds A[l&15][l>>4], B: B[l>>4][l&15],
+// C/D: register g of lane l is C[(l>>4) + 4g][l&15]).  K advances in steps of 16 through LDS; the next
+// step's global loads are issued before the current step's MFMAs (register prefetch).  Element (i,j) of
+// an operand is p[i*ld + j] inside (rows, cols), else 0.  K range [k0, k1) in elements.
 struct MatView {
     const double* p;
     int ld, rows, cols;
 };
 constexpr int GT = 64;   // GEMM tile edge
 constexpr int GK = 16;   // GEMM K step
+typedef double mfma_f64x4 __attribute__((ext_vector_type(4)));
+
+struct GemmStage {
+    double a[4], b[4];
+};
+__device__ __forceinline__ void gemm_stage_load(GemmStage& st, const MatView& A, const MatView& B, int ti,
+                                                int tj, int kk, int k1) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int idx = tid + 256 * s;             // 0..1023
+        const int ar = idx / GK, ae = idx % GK;    // consecutive threads along K: contiguous in a row of A
+        int gr = ti * GT + ar, gc = kk + ae;
+        st.a[s] = (gr < A.rows && gc < A.cols && gc < k1) ? A.p[(int64_t)gr * A.ld + gc] : 0.0;
+        const int be = idx / GT, bc = idx % GT;    // consecutive threads along the columns of B
+        gr = kk + be;
+        gc = tj * GT + bc;
+        st.b[s] = (gr < B.rows && gr < k1 && gc < B.cols) ? B.p[(int64_t)gr * B.ld + gc] : 0.0;
+    }
+}
+__device__ __forceinline__ void gemm_stage_store(const GemmStage& st, double (*As)[GT + 1],
+                                                 double (*Bs)[GT + 4]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int idx = tid + 256 * s;
+        As[idx % GK][idx / GK] = st.a[s];  // A tile 64 x 16 stored transposed As[e][row]
+        Bs[idx / GT][idx % GT] = st.b[s];  // B tile 16 x 64 as Bs[e][col]
+    }
+}
+
+// acc[mi][ni]: the 16x16 tile at rows 32*(wave>>1) + 16*mi, columns 32*(wave&1) + 16*ni of the 64x64 tile
 __device__ __forceinline__ void gemm_tile(const MatView& A, const MatView& B, int ti, int tj, int k0,
                                           int k1, double (*As)[GT + 1], double (*Bs)[GT + 4],
-                                          double acc[4][4]) {
-    const int tid = threadIdx.x, tx = tid % 16, ty = tid / 16;
+                                          mfma_f64x4 acc[2][2]) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r0 = 32 * (wv >> 1) + (lane & 15), c0 = 32 * (wv & 1) + (lane & 15), kq = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0;
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_f64x4{0, 0, 0, 0};
+    GemmStage st;
+    if (k0 < k1) gemm_stage_load(st, A, B, ti, tj, k0, k1);
     for (int kk = k0; kk < k1; kk += GK) {
+        __syncthreads();  // the previous step's fragments have been read
+        gemm_stage_store(st, As, Bs);
         __syncthreads();
-        // A tile 64 x 16 stored transposed As[e][row]; B tile 16 x 64 as Bs[e][col]
-        for (int s = 0; s < 4; ++s) {
-            int idx = tid + 256 * s;       // 0..1023
-            int ar = idx / GK, ae = idx % GK;  // consecutive threads along K: contiguous in a row of A
-            int gr = ti * GT + ar, gc = kk + ae;
-            As[ae][ar] = (gr < A.rows && gc < A.cols && gc < k1) ? A.p[(int64_t)gr * A.ld + gc] : 0.0;
-            int be = idx / GT, bc = idx % GT;  // consecutive threads along the columns of B
-            gr = kk + be;
-            gc = tj * GT + bc;
-            Bs[be][bc] = (gr < B.rows && gr < k1 && gc < B.cols) ? B.p[(int64_t)gr * B.ld + gc] : 0.0;
-        }
-        __syncthreads();
+        if (kk + GK < k1) gemm_stage_load(st, A, B, ti, tj, kk + GK, k1);
 #pragma unroll
-        for (int e = 0; e < GK; ++e) {
-            double a[4], bq[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = As[e][ty * 4 + i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bq[j] = Bs[e][tx * 4 + j];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * bq[j];
+        for (int e = 0; e < GK; e += 4) {
+            const double a0 = As[e + kq][r0], a1 = As[e + kq][r0 + 16];
+            const double b0 = Bs[e + kq][c0], b1 = Bs[e + kq][c0 + 16];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
         }
     }
+}
+// visit every element of the accumulators: f(row in tile, column in tile, value)
+template <class F>
+__device__ __forceinline__ void gemm_tile_foreach(const mfma_f64x4 acc[2][2], F&& f) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                f(32 * (wv >> 1) + 16 * mi + (lane >> 4) + 4 * g, 32 * (wv & 1) + 16 * ni + (lane & 15),
+                  acc[mi][ni][g]);
 }
 
 // step 2:  which = 0: tmpU (k x b) = L11^-1 F[P,B]     (L11^-1 lower: K tiles 0..ti)
@@ -364,16 +359,14 @@ __global__ void __launch_bounds__(256) gemm1_kernel(MfDev mf, int level_begin) {
         B = {F + (int64_t)k * ld, ld, k, k};         // F[A,P] = U11^-1 (upper)
         k1 = min(k, (tj + 1) * GT);
     }
-    double acc[4][4];
+    mfma_f64x4 acc[2][2];
     gemm_tile(A, B, ti, tj, 0, k1, As, Bs, acc);
     double* C = which ? tmp + (int64_t)k * b : tmp;  // tmpU: ld b ; tmpL: ld k
     const int cld = which ? k : b;
-    const int tid = threadIdx.x, tx = tid % 16, ty = tid / 16;
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) {
-            int r = ti * GT + ty * 4 + i, c = tj * GT + tx * 4 + j;
-            if (r < rows && c < cols) C[(int64_t)r * cld + c] = acc[i][j];
-        }
+    gemm_tile_foreach(acc, [&](int i, int j, double v) {
+        const int r = ti * GT + i, c = tj * GT + j;
+        if (r < rows && c < cols) C[(int64_t)r * cld + c] = v;
+    });
 }
 
 // step 3:  which = 0: F[B,B] -= tmpL tmpU                        (b x b, K = k)
@@ -408,17 +401,15 @@ __global__ void __launch_bounds__(256) gemm2_kernel(MfDev mf, int level_begin) {
         k0 = ti * GT;
         C = F + (int64_t)k * ld + 2 * k;
     }
-    double acc[4][4];
+    mfma_f64x4 acc[2][2];
     gemm_tile(A, B, ti, tj, k0, k, As, Bs, acc);
-    const int tid = threadIdx.x, tx = tid % 16, ty = tid / 16;
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) {
-            int r = ti * GT + ty * 4 + i, c = tj * GT + tx * 4 + j;
-            if (r < rows && c < cols) {
-                double* dst = C + (int64_t)r * ld + c;
-                *dst = (which == 0) ? *dst - acc[i][j] : -acc[i][j];
-            }
+    gemm_tile_foreach(acc, [&](int i, int j, double v) {
+        const int r = ti * GT + i, c = tj * GT + j;
+        if (r < rows && c < cols) {
+            double* dst = C + (int64_t)r * ld + c;
+            *dst = (which == 0) ? *dst - v : -v;
         }
+    });
 }
 
 // ---------------------------------------------------------------- solve --

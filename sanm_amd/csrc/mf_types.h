@@ -10,7 +10,6 @@ constexpr int MF_NB = 32;  // panel / tile width
 
 struct MfFrontDev {
     int64_t off;        // offset of the dense ld*ld augmented front (row-major) in the front storage
-    int64_t dinv_off;   // offset of the inverted diagonal blocks: per panel [Linv | Uinv], NB*NB each
     int32_t k, m;       // pivots, front size
     int32_t ld;         // m + k.  Row / column order of the dense front: [pivot P (k) | augmentation A (k) |
                         // boundary B (m-k)].  A starts as identity blocks F[P,A] = F[A,P] = I; the LU of the
@@ -43,12 +42,11 @@ struct MfDev {
     const int64_t* a_dst;
     // extend-add: child lists per level and round
     double* front_store;          // sum of m*m
-    double* dinv_store;
     double* work;                 // n doubles (permuted rhs / solution)
     double* work2;                // n doubles (forward-solved vector z)
     double* tmp_store;            // per-level workspace: L11^-1 F12 (k x b) and F21 U11^-1 (b x k) per front
     int32_t* status;              // [0]: number of bad pivots
-    int64_t front_store_size, dinv_store_size;
+    int64_t front_store_size;
 };
 
 // Host-side schedule (what to launch, in which order).  Within a level the

@@ -427,7 +427,7 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
 
     std::vector<MfFrontDev> fr(F);
     std::vector<int32_t> bnd_idx;
-    int64_t off = 0, doff = 0;
+    int64_t off = 0;
     for (int32_t f = 0; f < F; ++f) {
         fr[f].bnd_off = bnd_idx.size();
         for (int32_t t : bnd_sv[f])
@@ -440,8 +440,6 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
         fr[f].parent = parent[f];
         fr[f].off = off;
         off += (int64_t)fr[f].ld * fr[f].ld;
-        fr[f].dinv_off = doff;
-        doff += (int64_t)((fr[f].k + MF_NB - 1) / MF_NB) * 2 * MF_NB * MF_NB;
         fr[f].rel_off = fr[f].bnd_off;  // rel is parallel to bnd_idx
         max_front = std::max(max_front, fr[f].m);
         if (parent[f] < 0) root_pivots = std::max(root_pivots, fr[f].k);
@@ -598,9 +596,7 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     m_dev.a_dst = upload(a_dst);
     m_sched.ea_children = upload(ea_children);
     m_dev.front_store_size = off;
-    m_dev.dinv_store_size = doff;
     m_dev.front_store = static_cast<double*>(be->alloc(off * sizeof(double)));
-    m_dev.dinv_store = static_cast<double*>(be->alloc(std::max<int64_t>(doff, 1) * sizeof(double)));
     m_dev.work = static_cast<double*>(be->alloc(n * sizeof(double)));
     m_dev.work2 = static_cast<double*>(be->alloc(n * sizeof(double)));
     m_bufs.push_back(m_dev.work2);
@@ -609,7 +605,6 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     m_dev.status = static_cast<int32_t*>(be->alloc(64));
     be->zero(m_dev.status, 64);
     m_bufs.push_back(m_dev.front_store);
-    m_bufs.push_back(m_dev.dinv_store);
     m_bufs.push_back(m_dev.work);
     m_bufs.push_back(m_dev.status);
 }

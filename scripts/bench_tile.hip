@@ -8,13 +8,13 @@ using namespace sanm_hip::mfk;
 
 template <int VARIANT>
 __global__ void __launch_bounds__(256) k(double* F, double* D, int32_t* status, int nfront) {
-    __shared__ double T[NB][TPAD], LI[NB][TPAD], UI[NB][TPAD], W[NB][TPAD];
+    __shared__ double T[NB][TPAD];
     const int tid = threadIdx.x, tc = tid % NB, tr = tid / NB;
     double* Ff = F + (size_t)blockIdx.x * NB * NB;
     for (int s = 0; s < 4; ++s) T[tr + 8 * s][tc] = Ff[(tr + 8 * s) * NB + tc];
     __syncthreads();
     if (VARIANT == 0) {
-        tile_factor(T, LI, UI, W, NB, tid, D + (size_t)blockIdx.x * 2 * NB * NB, status);
+        tile_factor(T, NB, tid, status);
     } else if (VARIANT == 1) {  // elimination only
         for (int j = 0; j < NB; ++j) {
             double piv = T[j][j];
@@ -62,7 +62,7 @@ int main() {
         hipEventElapsedTime(&ms, e0, e1);
         printf("%-28s %.2f us per launch\n", name, ms * 1e3 / reps);
     };
-    run(k<0>, "tile_factor (LU + inverses)");
+    run(k<0>, "tile_factor (in-LDS LU)");
     run(k<1>, "elimination only");
     run(k<2>, "load/store only");
     return 0;
