@@ -273,15 +273,129 @@ void PadeApproximation::eval_xt(double a, double* out) const {
 }
 
 // ------------------------------------------------------------ AnmDriver --
-AnmDriver::AnmDriver(Backend* be, const Graph& g, int out_var, const SparseDesc& remap_inp,
-                     const SparseDesc& remap_out, int64_t nr_unknown, const HyperParam& hp,
+// ---- spatial tet order ------------------------------------------------------
+// The Taylor passes stream the per-tet state and do not care about the order of the tets, but remap_out
+// and the Jacobian assembly GATHER single doubles from per-tet arrays: a 64-byte line holds 8 consecutive
+// tets, and it only serves more than one of the ~10^7 gathered entries if consecutive tets are neighbours
+// in the mesh.  Mesh generators do not number them that way, so when the caller supplied the positions of
+// the unknowns (sanm_sparse_desc_set_out_coords) the tets are renumbered along a Morton curve through
+// their centroids.  The renumbering is internal to the driver: everything it exposes lives in the space
+// of the unknowns.
+namespace {
+std::vector<int64_t> spatial_tet_order(const SparseDesc& remap_inp, const std::vector<double>& coords,
+                                       int64_t n) {
+    const int64_t T = remap_inp.out_size / 9;
+    std::vector<double> cen((size_t)T * 3, 0.0);
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int64_t e = 0; e < T; ++e) {
+        double acc[3] = {0, 0, 0};
+        int64_t cnt = 0;
+        for (uint64_t q = remap_inp.rowptr[e * 9]; q < remap_inp.rowptr[e * 9 + 9]; ++q) {
+            const int64_t u = remap_inp.idx[q];
+            if (u >= n) continue;  // the t column of the implicit solver
+            for (int d = 0; d < 3; ++d) acc[d] += coords[u * 3 + d];
+            ++cnt;
+        }
+        for (int d = 0; d < 3; ++d) {
+            cen[e * 3 + d] = cnt ? acc[d] / cnt : 0.0;
+            lo[d] = std::min(lo[d], cen[e * 3 + d]);
+            hi[d] = std::max(hi[d], cen[e * 3 + d]);
+        }
+    }
+    auto spread = [](uint64_t v) {  // 21 bits -> every third bit
+        v &= 0x1fffff;
+        v = (v | v << 32) & 0x1f00000000ffffULL;
+        v = (v | v << 16) & 0x1f0000ff0000ffULL;
+        v = (v | v << 8) & 0x100f00f00f00f00fULL;
+        v = (v | v << 4) & 0x10c30c30c30c30c3ULL;
+        v = (v | v << 2) & 0x1249249249249249ULL;
+        return v;
+    };
+    std::vector<std::pair<uint64_t, int64_t>> key(T);
+    for (int64_t e = 0; e < T; ++e) {
+        uint64_t k = 0;
+        for (int d = 0; d < 3; ++d) {
+            const double ext = hi[d] - lo[d];
+            const double f = ext > 0 ? (cen[e * 3 + d] - lo[d]) / ext : 0.0;
+            k |= spread((uint64_t)(f * 2097151.0)) << d;
+        }
+        key[e] = {k, e};
+    }
+    std::sort(key.begin(), key.end());
+    std::vector<int64_t> order(T);
+    for (int64_t e = 0; e < T; ++e) order[e] = key[e].second;  // new tet e = old tet order[e]
+    return order;
+}
+
+//! remap_inp with its (tet, component) rows permuted
+SparseDesc permute_rows_by_tet(const SparseDesc& d, const std::vector<int64_t>& order) {
+    SparseDesc r;
+    r.out_size = d.out_size;
+    r.in_size = d.in_size;
+    r.out_coords = d.out_coords;
+    r.rowptr.assign(d.out_size + 1, 0);
+    r.idx.reserve(d.idx.size());
+    r.coef.reserve(d.coef.size());
+    for (int64_t e = 0; e < (int64_t)order.size(); ++e)
+        for (int c = 0; c < 9; ++c) {
+            const int64_t src = order[e] * 9 + c;
+            for (uint64_t q = d.rowptr[src]; q < d.rowptr[src + 1]; ++q) {
+                r.idx.push_back(d.idx[q]);
+                r.coef.push_back(d.coef[q]);
+            }
+            r.rowptr[e * 9 + c + 1] = r.idx.size();
+        }
+    return r;
+}
+
+//! remap_out with its (tet, component) input indices renumbered
+SparseDesc permute_inputs_by_tet(const SparseDesc& d, const std::vector<int64_t>& order) {
+    std::vector<int64_t> inv(order.size());
+    for (size_t e = 0; e < order.size(); ++e) inv[order[e]] = e;
+    SparseDesc r = d;
+    for (auto& i : r.idx) i = (uint64_t)(inv[i / 9] * 9 + i % 9);
+    return r;
+}
+
+//! the graph with its per-tet constants permuted
+Graph permute_constants_by_tet(const Graph& g, const std::vector<int64_t>& order) {
+    Graph r = g;
+    const int64_t T = order.size();
+    for (auto& op : r.ops) {
+        if (op.type != OP_CONSTANT || op.batch != T) continue;
+        const size_t sz = op.value.size() / T;
+        std::vector<double> v(op.value.size());
+        for (int64_t e = 0; e < T; ++e)
+            std::copy(op.value.begin() + order[e] * sz, op.value.begin() + (order[e] + 1) * sz,
+                      v.begin() + e * sz);
+        op.value.swap(v);
+    }
+    return r;
+}
+}  // namespace
+
+AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDesc& remap_inp_in,
+                     const SparseDesc& remap_out_in, int64_t nr_unknown, const HyperParam& hp,
                      const ShardInfo& shard)
         : m_be{be}, m_hp{hp}, m_n{nr_unknown}, m_max_a_bound{poly::stable_x_range(hp.order)},
           m_shard{shard} {
     sanm_check(hp.order >= 2, "order=%d", hp.order);  // anm.cpp:108-110
-    sanm_check(remap_inp.out_size % 9 == 0, "remap_inp must produce a (T,3,3) tensor");
+    sanm_check(remap_inp_in.out_size % 9 == 0, "remap_inp must produce a (T,3,3) tensor");
     if (hp.xcoeff_l2_penalty != 0)
         sanm_throw(SANM_ERR_UNSUPPORTED, "xcoeff_l2_penalty (Tikhonov path) is not on the device path");
+    Graph g_perm;
+    SparseDesc inp_perm, out_perm;
+    const bool reorder = remap_out_in.out_coords.size() == (size_t)m_n * 3 &&
+                         remap_out_in.in_size == remap_inp_in.out_size && !std::getenv("SANM_NO_TET_ORDER");
+    if (reorder) {
+        const std::vector<int64_t> order = spatial_tet_order(remap_inp_in, remap_out_in.out_coords, m_n);
+        g_perm = permute_constants_by_tet(g_in, order);
+        inp_perm = permute_rows_by_tet(remap_inp_in, order);
+        out_perm = permute_inputs_by_tet(remap_out_in, order);
+    }
+    const Graph& g = reorder ? g_perm : g_in;
+    const SparseDesc& remap_inp = reorder ? inp_perm : remap_inp_in;
+    const SparseDesc& remap_out = reorder ? out_perm : remap_out_in;
     const int64_t T = remap_inp.out_size / 9;
     // this rank's tets: contiguous ranges like the reference's worker shards
     // (libsanm/symbolic.cpp:525-536)

@@ -60,18 +60,29 @@ __global__ void __launch_bounds__(256, W) taylor_pass_kernel(ProgramDev P, int o
                          cur_lds + (int64_t)P.cur_size * 64 + lane);
 }
 
-// remap_out: ROW_LANES lanes per output row (~45 gathered entries each), shuffle reduce
+// remap_out: GATHER_LANES lanes per output row (~45 gathered entries each), shuffle reduce.  The index ->
+// value loads of an entry are dependent, so each lane keeps the entries of two strides in flight.
 constexpr int ROW_LANES = 8;
+constexpr int GATHER_LANES = 16;
 __global__ void __launch_bounds__(256) gather_rows_kernel(SparseRowsDev R, const double* __restrict__ src,
                                                           double* __restrict__ dst) {
     int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t i = gid / ROW_LANES;
-    int sub = gid % ROW_LANES;
-    double s = 0;
-    if (i < R.nrows)
-        for (uint32_t p = R.ptr[i] + sub, e = R.ptr[i + 1]; p < e; p += ROW_LANES)
-            s += R.coef[p] * src[R.idx[p]];
-    for (int off = ROW_LANES / 2; off > 0; off >>= 1) s += __shfl_down(s, off, ROW_LANES);
+    int64_t i = gid / GATHER_LANES;
+    int sub = gid % GATHER_LANES;
+    double s = 0, s2 = 0;
+    if (i < R.nrows) {
+        const uint32_t e = R.ptr[i + 1];
+        uint32_t p = R.ptr[i] + sub;
+        for (; p + GATHER_LANES < e; p += 2 * GATHER_LANES) {
+            const uint32_t i0 = R.idx[p], i1 = R.idx[p + GATHER_LANES];
+            const double c0 = R.coef[p], c1 = R.coef[p + GATHER_LANES];
+            s += c0 * src[i0];
+            s2 += c1 * src[i1];
+        }
+        if (p < e) s += R.coef[p] * src[R.idx[p]];
+    }
+    s += s2;
+    for (int off = GATHER_LANES / 2; off > 0; off >>= 1) s += __shfl_down(s, off, GATHER_LANES);
     if (i < R.nrows && sub == 0) dst[i] = s;
 }
 
@@ -82,11 +93,20 @@ __global__ void __launch_bounds__(256) assemble_kernel(AssemblyDev A, const doub
     int64_t s = gid / ROW_LANES;
     int sub = gid % ROW_LANES;
     double v = 0;
-    if (s < A.nslots)
-        for (uint32_t p = A.ptr[s] + sub, e = A.ptr[s + 1]; p < e; p += ROW_LANES) {
-            double c = A.coef[p] * jac[A.jidx[p]];
-            if (fabs(c) >= 1e-9) v += c;  // libsanm/sparse_solver.cpp:291-293
+    if (s < A.nslots) {
+        const uint32_t e = A.ptr[s + 1];
+        uint32_t p = A.ptr[s] + sub;
+        for (; p + ROW_LANES < e; p += 2 * ROW_LANES) {  // two dependent index -> value chains in flight
+            const uint32_t j0 = A.jidx[p], j1 = A.jidx[p + ROW_LANES];
+            const double c0 = A.coef[p] * jac[j0], c1 = A.coef[p + ROW_LANES] * jac[j1];
+            if (fabs(c0) >= 1e-9) v += c0;  // libsanm/sparse_solver.cpp:291-293
+            if (fabs(c1) >= 1e-9) v += c1;
         }
+        if (p < e) {
+            const double c = A.coef[p] * jac[A.jidx[p]];
+            if (fabs(c) >= 1e-9) v += c;
+        }
+    }
     for (int off = ROW_LANES / 2; off > 0; off >>= 1) v += __shfl_down(v, off, ROW_LANES);
     if (s < A.nslots && sub == 0) val[s] = v;
 }
@@ -359,9 +379,16 @@ __global__ void __launch_bounds__(256) sanity_check_kernel(CsrDev A, const doubl
     for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < (int64_t)A.n * SPMV_LANES;
          gid += (int64_t)gridDim.x * blockDim.x) {  // A.n * SPMV_LANES is a multiple of the group size
         const int64_t row = gid / SPMV_LANES;
-        double s = 0;
-        for (uint32_t p = A.rowptr[row] + sub, e = A.rowptr[row + 1]; p < e; p += SPMV_LANES)
-            s += A.val[p] * xi[A.col[p]];
+        double s = 0, s2 = 0;
+        const uint32_t e = A.rowptr[row + 1];
+        uint32_t p = A.rowptr[row] + sub;
+        for (; p + SPMV_LANES < e; p += 2 * SPMV_LANES) {
+            const uint32_t c0 = A.col[p], c1 = A.col[p + SPMV_LANES];
+            s += A.val[p] * xi[c0];
+            s2 += A.val[p + SPMV_LANES] * xi[c1];
+        }
+        if (p < e) s += A.val[p] * xi[A.col[p]];
+        s += s2;
         for (int off = SPMV_LANES / 2; off > 0; off >>= 1) s += __shfl_down(s, off, SPMV_LANES);
         if (sub == 0) v[0] = fmax(v[0], allclose_excess1(s, -ti * grad_t[row] - bi[row], eps));
         if ((size_t)gid < n1) v[1] += x1[gid] * xi[gid];
@@ -648,7 +675,7 @@ public:
         *count = m_pass_events.size();
     }
     void gather_rows(const SparseRowsDev& R, const double* src, double* dst) override {
-        hipLaunchKernelGGL(gather_rows_kernel, dim3(nblk((size_t)R.nrows * ROW_LANES, 256)), dim3(256), 0,
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(nblk((size_t)R.nrows * GATHER_LANES, 256)), dim3(256), 0,
                            m_stream, R, src, dst);
         HIP_CHECK(hipGetLastError());
     }
