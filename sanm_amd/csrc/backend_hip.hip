@@ -771,10 +771,16 @@ public:
                 const int cnt = L.panel_cnt[p];
                 const int rem = nt - p - 1;
                 if (rem <= 0) continue;
-                hipLaunchKernelGGL(trsm_kernel, dim3((rem + TRSM_TILES - 1) / TRSM_TILES, 2, cnt), dim3(256), 0,
-                                   m_stream, mf, L.front_begin, p);
                 hipLaunchKernelGGL(update_kernel, dim3(rem, rem, cnt), dim3(256), 0, m_stream, mf,
                                    L.front_begin, p);
+            }
+            if (L.nr_panel > 0) {
+                // augmentation tiles of every panel: at most ceil(k / NB) + 1 tiles per panel and side
+                const int atiles = (L.max_k + NB - 1) / NB + 1;
+                hipLaunchKernelGGL(panel_finalize_kernel,
+                                   dim3((atiles + FIN_TILES - 1) / FIN_TILES, 2,
+                                        (L.front_end - L.front_begin) * L.nr_panel),
+                                   dim3(256), 0, m_stream, mf, L.front_begin, L.nr_panel);
             }
             // Schur complement and the boundary blocks of the solve operators: two GEMM passes
             if (L.max_b > 0) {

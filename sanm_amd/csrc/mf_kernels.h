@@ -110,16 +110,15 @@ __global__ void __launch_bounds__(256) diag_kernel(MfDev mf, int level_begin, in
     }
 }
 
-// panel tiles by substitution with the factored diagonal tile, 8 tiles per workgroup:
-//   blockIdx.y == 0: U panel tile (p, t): one lane per COLUMN, x_r = b_r - sum_{j<r} l_rj x_j;
-//   blockIdx.y == 1: L panel tile (t, p): one lane per ROW,    x_c = (b_c - sum_{j<c} x_j u_jc) / u_cc   (t > p)
-// The workgroup first lays the factor out in LDS as S[i][j] (j < i) = l_ij resp. u_ji, zero for pivots
-// j >= kb, with 1/u_ii beside it (1 for i >= kb): row i is then one contiguous broadcast read, the
-// substitution is branch-free straight-line code over a register array, and the rows / columns kb.. of a
-// partial panel receive their trailing update by the same formula.
+// Panel tiles by substitution with the factored diagonal tile:
+//   U panel tile (p, t): one lane per COLUMN, x_r = b_r - sum_{j<r} l_rj x_j;
+//   L panel tile (t, p): one lane per ROW,    x_c = (b_c - sum_{j<c} x_j u_jc) / u_cc          (t > p)
+// The factor is laid out in LDS as S[i][j] (j < i) = l_ij resp. u_ji, zero for pivots j >= kb, with
+// 1/u_ii beside it (1 for i >= kb): row i is then one contiguous broadcast read, the substitution is
+// branch-free straight-line code over a register array, and the rows / columns kb.. of a partial panel
+// receive their trailing update by the same formula.
 // (Earlier versions multiplied by explicit inverses of the tile factors; building those inverses cost the
 // look-ahead tile LU as much again as the elimination itself, on the critical path of every panel.)
-constexpr int TRSM_TILES = 8;
 constexpr int SPAD = NB + 2;  // even row stride: 16-byte aligned rows
 template <bool SCALE>
 __device__ __forceinline__ void trsm_sweep(const double (*S)[SPAD], const double* Dv, double (&x)[NB]) {
@@ -140,10 +139,95 @@ __device__ __forceinline__ void trsm_sweep(const double (*S)[SPAD], const double
     }
 }
 
-__global__ void __launch_bounds__(256) trsm_kernel(MfDev mf, int level_begin, int p) {
+// One launch per panel p: tile(ti,tj) -= L(ti,p)[:, :kb] * U(p,tj)[:kb, :]   (ti, tj > p), where every
+// workgroup first SOLVES its two panel tiles itself (wavefront 0 the L tile, wavefront 1 the U tile, 32
+// lanes each, in registers) instead of reading them from a separate panel-solve launch: the redundant
+// substitutions cost a few microseconds of an otherwise idle chip, the kernel boundary they replace cost
+// twelve on the critical path of each of the ~80 panels.  The panel tiles themselves stay as they are (other
+// workgroups of the launch read them); the ones that are results -- the augmentation blocks, which become
+// L11^-1 and U11^-1 -- are solved in place by panel_finalize_kernel after the last panel.  Look-ahead: the workgroup that owns the next diagonal tile (p+1,p+1)
+// factors it right after updating it, so panels p >= 1 need no separate diagonal launch.
+// (A second stream for the diagonal tile was tried as well: the cross-stream events cost as much as they
+// hid.)
+__global__ void __launch_bounds__(256) update_kernel(MfDev mf, int level_begin, int p) {
     const MfFrontDev f = mf.fronts[mf.level_fronts[level_begin + blockIdx.z]];
     const int ld = f.ld, m = 2 * f.k, nt = (m + NB - 1) / NB;
-    if (p + 1 + (int)blockIdx.x * TRSM_TILES >= nt) return;
+    const int ti = p + 1 + blockIdx.y, tj = p + 1 + blockIdx.x;
+    if (ti >= nt || tj >= nt) return;
+    // the (augmentation x augmentation) corner is never used
+    if (ti * NB >= f.k && tj * NB >= f.k) return;
+    const int kb = min(NB, f.k - p * NB);
+    __shared__ double L[NB][TPAD], U[NB][TPAD], T[NB][TPAD];
+    __shared__ __attribute__((aligned(16))) double SL[NB][SPAD], SU[NB][SPAD];
+    __shared__ double Dv[NB];
+    double* F = mf.front_store + f.off;
+    const int tid = threadIdx.x, tc = tid % NB, tr = tid / NB;
+    for (int s = 0; s < 4; ++s) {
+        const int r = tr + 8 * s;
+        int gr = ti * NB + r, gc = p * NB + tc;
+        L[r][tc] = (gr < m && gc < m) ? F[(int64_t)gr * ld + gc] : 0.0;
+        gr = p * NB + r;
+        gc = tj * NB + tc;
+        U[r][tc] = (gr < m && gc < m) ? F[(int64_t)gr * ld + gc] : 0.0;
+        // diagonal tile entry (r, tc): multipliers row-wise for the U panel, U transposed for the L panel
+        gc = p * NB + tc;
+        const double v = (gr < m && gc < m) ? F[(int64_t)gr * ld + gc] : 0.0;
+        SL[r][tc] = (tc < r && tc < kb) ? v : 0.0;
+        SU[tc][r] = (r < tc && r < kb) ? v : 0.0;
+        if (r == tc) Dv[r] = (r < kb && fabs(v) > 1e-290) ? 1.0 / v : 1.0;
+    }
+    __syncthreads();
+    if (tid < 32) {  // row tid of the L tile
+        double x[NB];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) x[c] = L[tid][c];
+        trsm_sweep<true>(SU, Dv, x);
+#pragma unroll
+        for (int c = 0; c < NB; ++c) L[tid][c] = x[c];
+    } else if (tid >= 64 && tid < 96) {  // column tid - 64 of the U tile
+        const int q = tid - 64;
+        double x[NB];
+#pragma unroll
+        for (int r = 0; r < NB; ++r) x[r] = U[r][q];
+        trsm_sweep<false>(SL, nullptr, x);
+#pragma unroll
+        for (int r = 0; r < NB; ++r) U[r][q] = x[r];
+    }
+    __syncthreads();
+    const bool next_diag = (ti == tj) && (ti == p + 1) && ((p + 1) * NB < f.k);  // workgroup-uniform
+    for (int s = 0; s < 4; ++s) {
+        int r = tr + 8 * s, gr = ti * NB + r, gc = tj * NB + tc;
+        double v = (r == tc) ? 1.0 : 0.0;  // identity padding outside the front
+        if (gr < m && gc < m) {
+            double acc = 0;
+#pragma unroll 8
+            for (int q = 0; q < kb; ++q) acc += L[r][q] * U[q][tc];  // pivot columns / rows only
+            v = F[(int64_t)gr * ld + gc] - acc;
+            if (!next_diag) F[(int64_t)gr * ld + gc] = v;
+        }
+        if (next_diag) T[r][tc] = v;
+    }
+    if (!next_diag) return;
+    __syncthreads();
+    const int kb1 = min(NB, f.k - (p + 1) * NB);
+    tile_factor(T, kb1, tid, mf.status);
+    for (int s = 0; s < 4; ++s) {
+        int r = tr + 8 * s, gr = ti * NB + r, gc = tj * NB + tc;
+        if (gr < m && gc < m) F[(int64_t)gr * ld + gc] = T[r][tc];
+    }
+}
+
+// After the panel loop of a level: solve, in place, the panel tiles that hold results -- U panel tiles
+// (p, t) and L panel tiles (t, p) with t in the augmentation block (they become L11^-1 resp. U11^-1).  All
+// (front, panel, tile) triples are independent: one launch, 8 tiles per workgroup, one lane per column / row.
+constexpr int FIN_TILES = 8;
+__global__ void __launch_bounds__(256) panel_finalize_kernel(MfDev mf, int level_begin, int nr_panel) {
+    const MfFrontDev f = mf.fronts[mf.level_fronts[level_begin + blockIdx.z / nr_panel]];
+    const int p = blockIdx.z % nr_panel;
+    if (p * NB >= f.k) return;
+    const int ld = f.ld, m = 2 * f.k, nt = (m + NB - 1) / NB;
+    const int t0 = max(p + 1, f.k / NB);  // first tile with augmentation columns / rows
+    if (t0 + (int)blockIdx.x * FIN_TILES >= nt) return;
     const bool upanel = blockIdx.y == 0;
     const int kb = min(NB, f.k - p * NB);
     __shared__ __attribute__((aligned(16))) double S[NB][SPAD];
@@ -162,7 +246,7 @@ __global__ void __launch_bounds__(256) trsm_kernel(MfDev mf, int level_begin, in
         }
     }
     __syncthreads();
-    const int t = p + 1 + blockIdx.x * TRSM_TILES + tid / NB, q = tid % NB;
+    const int t = t0 + blockIdx.x * FIN_TILES + tid / NB, q = tid % NB;
     if (t >= nt) return;
     // rows (U panel) / columns (L panel) of the panel that lie inside the 2k x 2k block: all NB of them
     // except for fronts of fewer than NB - 1 pivots.  Loads clamp their index (a duplicate read is harmless,
@@ -200,55 +284,6 @@ __global__ void __launch_bounds__(256) trsm_kernel(MfDev mf, int level_begin, in
             for (int c = 0; c < NB; ++c)
                 if (c <= vmax) row[c] = x[c];
         }
-    }
-}
-
-// trailing update: tile(ti,tj) -= L(ti,p)[:, :kb] * U(p,tj)[:kb, :]   (ti, tj > p).
-// Look-ahead: the workgroup that owns the next diagonal tile (p+1,p+1) factors it
-// right after updating it, so panels p >= 1 need no separate diagonal launch and
-// that short sequential LU hides behind the other tiles of the same launch.
-// (A second stream for the diagonal tile was tried as well: the cross-stream
-// events cost as much as they hid.)
-__global__ void __launch_bounds__(256) update_kernel(MfDev mf, int level_begin, int p) {
-    const MfFrontDev f = mf.fronts[mf.level_fronts[level_begin + blockIdx.z]];
-    const int ld = f.ld, m = 2 * f.k, nt = (m + NB - 1) / NB;
-    const int ti = p + 1 + blockIdx.y, tj = p + 1 + blockIdx.x;
-    if (ti >= nt || tj >= nt) return;
-    // the (augmentation x augmentation) corner is never used
-    if (ti * NB >= f.k && tj * NB >= f.k) return;
-    const int kb = min(NB, f.k - p * NB);
-    __shared__ double L[NB][TPAD], U[NB][TPAD], T[NB][TPAD];
-    double* F = mf.front_store + f.off;
-    const int tid = threadIdx.x, tc = tid % NB, tr = tid / NB;
-    for (int s = 0; s < 4; ++s) {
-        int r = tr + 8 * s;
-        int gr = ti * NB + r, gc = p * NB + tc;
-        L[r][tc] = (gr < m && tc < kb) ? F[(int64_t)gr * ld + gc] : 0.0;
-        gr = p * NB + r;
-        gc = tj * NB + tc;
-        U[r][tc] = (r < kb && gc < m) ? F[(int64_t)gr * ld + gc] : 0.0;
-    }
-    __syncthreads();
-    const bool next_diag = (ti == tj) && (ti == p + 1) && ((p + 1) * NB < f.k);  // workgroup-uniform
-    for (int s = 0; s < 4; ++s) {
-        int r = tr + 8 * s, gr = ti * NB + r, gc = tj * NB + tc;
-        double v = (r == tc) ? 1.0 : 0.0;  // identity padding outside the front
-        if (gr < m && gc < m) {
-            double acc = 0;
-#pragma unroll 8
-            for (int q = 0; q < NB; ++q) acc += L[r][q] * U[q][tc];
-            v = F[(int64_t)gr * ld + gc] - acc;
-            if (!next_diag) F[(int64_t)gr * ld + gc] = v;
-        }
-        if (next_diag) T[r][tc] = v;
-    }
-    if (!next_diag) return;
-    __syncthreads();
-    const int kb1 = min(NB, f.k - (p + 1) * NB);
-    tile_factor(T, kb1, tid, mf.status);
-    for (int s = 0; s < 4; ++s) {
-        int r = tr + 8 * s, gr = ti * NB + r, gc = tj * NB + tc;
-        if (gr < m && gc < m) F[(int64_t)gr * ld + gc] = T[r][tc];
     }
 }
 
