@@ -118,7 +118,7 @@ std::unique_ptr<LinearSolver> make_pcg_solver(Backend* be, const JacobianPattern
 
 // ----------------------------------------------------------------- Pade --
 PadeApproximation::PadeApproximation(Backend* be, const std::vector<DVec>& xs,
-                                     const std::vector<double>& t_coeffs, bool anm_cond)
+                                     const std::vector<double>& t_coeffs, bool anm_cond, PadeWorkspace* ws)
         : m_be{be}, m_xs{xs}, m_len{xs[0].size()} {
     // libsanm/pade.cpp:13-105
     const int nx = xs.size();
@@ -128,27 +128,44 @@ PadeApproximation::PadeApproximation(Backend* be, const std::vector<DVec>& xs,
     std::vector<double> a((size_t)nx * nx, 0.0);
     auto A = [&](int i, int j) -> double& { return a[(size_t)i * nx + j]; };
     const double eps = std::numeric_limits<double>::epsilon();
-    std::vector<DVec> orth(nx);
-    std::vector<const double*> ptrs(nx);
     // Classical Gram-Schmidt (the projections use xs[i], not the running uii).  The sweep is queued
     // without waiting for the device: projections and squared norms stay in device memory for the
-    // update / scaling kernels that consume them and come back in one copy at the end.
-    {
-        DVec acoef{be, (size_t)nx * nx + 1};
-        double* scratch = acoef.p() + (size_t)nx * nx;
+    // update / scaling kernels that consume them and come back in one copy at the end.  With a workspace
+    // from the driver the whole sweep is recorded once and replayed as a graph.
+    PadeWorkspace local;
+    if (!ws) ws = &local;
+    if (ws->orth.empty()) {
+        ws->be = be;
+        ws->orth.resize(nx);
+        for (int i = 1; i <= n; ++i) ws->orth[i] = DVec{be, m_len};
+        ws->acoef = DVec{be, (size_t)nx * nx + 1};
+    }
+    sanm_check((int)ws->orth.size() == nx && ws->orth[1].size() == m_len, "pade workspace mismatch");
+    auto sweep = [&]() {
+        std::vector<const double*> ptrs(nx);
+        double* scratch = ws->acoef.p() + (size_t)nx * nx;
         for (int i = 1; i <= n; ++i) {
-            DVec uii{be, m_len};
-            for (int j = 1; j < i; ++j) ptrs[j - 1] = orth[j].p();
-            double* row = acoef.p() + (size_t)i * nx;
+            for (int j = 1; j < i; ++j) ptrs[j - 1] = ws->orth[j].p();
+            double* row = ws->acoef.p() + (size_t)i * nx;
+            double* uii = ws->orth[i].p();
             be->multi_dot_async(m_len, xs[i].p(), i - 1, ptrs.data(), row + 1);
             // under the ANM condition the projection on the first basis vector is dropped (checked below)
-            be->gs_update_async(m_len, xs[i].p(), i - 1, ptrs.data(), row + 1, anm_cond ? 1 : 0, uii.p());
-            be->dot_async(m_len, uii.p(), uii.p(), row + i);
-            be->scale_rsqrt_async(m_len, uii.p(), row + i, eps, scratch);
-            orth[i] = std::move(uii);
+            be->gs_update_async(m_len, xs[i].p(), i - 1, ptrs.data(), row + 1, anm_cond ? 1 : 0, uii, row + i);
+            be->scale_rsqrt_async(m_len, uii, row + i, eps, scratch);
         }
+    };
+    if (ws->graph) {
+        be->graph_launch(ws->graph);
+    } else if (ws != &local && be->graph_capture_begin()) {
+        sweep();
+        ws->graph = be->graph_capture_end();
+        be->graph_launch(ws->graph);
+    } else {
+        sweep();
+    }
+    {
         std::vector<double> h((size_t)nx * nx);
-        be->d2h(h.data(), acoef.p(), h.size() * 8);
+        be->d2h(h.data(), ws->acoef.p(), h.size() * 8);
         for (int i = 1; i <= n; ++i) {
             for (int j = 1; j < i; ++j) {
                 A(i, j) = h[(size_t)i * nx + j];
@@ -596,7 +613,7 @@ void AnmDriver::estimate_valid_range() {
     static const bool env_pade = getenv("SANM_PADE") != nullptr;
     if ((m_hp.use_pade || env_pade) && a_bound < m_max_a_bound) {
         auto pade = std::make_unique<PadeApproximation>(m_be, m_xt_coeffs, m_t_coeffs,
-                                                        !m_hp.xcoeff_l2_penalty);
+                                                        !m_hp.xcoeff_l2_penalty, &m_pade_ws);
         if (pade->estimate_valid_range(a_bound, m_hp.maxr, m_max_a_bound)) {
             m_t_max_a = pade->get_t_max_a();
             m_t_max = pade->get_t_max();

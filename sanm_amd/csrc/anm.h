@@ -97,11 +97,23 @@ std::unique_ptr<LinearSolver> make_direct_solver(Backend* be, const JacobianPatt
                                                  const HyperParam& hp, const double* coords);
 
 //! libsanm/pade.h on device vectors
+//! buffers of the Pade basis sweep that live as long as the driver, so that the sweep (a launch-bound
+//! sequence of ~80 small kernels with the same arguments every continuation step) can be replayed as a graph
+struct PadeWorkspace {
+    Backend* be = nullptr;
+    std::vector<DVec> orth;
+    DVec acoef;
+    void* graph = nullptr;
+    ~PadeWorkspace() {
+        if (graph) be->graph_destroy(graph);
+    }
+};
+
 class PadeApproximation {
 public:
     //! t_coeffs: host copy of the last element of every xs[i]
     PadeApproximation(Backend* be, const std::vector<DVec>& xs, const std::vector<double>& t_coeffs,
-                      bool anm_cond);
+                      bool anm_cond, PadeWorkspace* ws = nullptr);
     bool estimate_valid_range(double start, double eps, double limit);
     double get_t_max() const { return m_t_max; }
     double get_t_max_a() const { return m_t_max_a; }
@@ -171,6 +183,7 @@ protected:
     double m_t_max = 0, m_t_max_a = 0;
     std::unique_ptr<PadeApproximation> m_pade;
     DVec m_fx0, m_bi, m_xbi, m_xgt, m_grad_t_buf, m_tmp0, m_tmp1;
+    PadeWorkspace m_pade_ws;
     DVec m_dev_scalars;                // per order: xb_i . x_1 (consumed on the device)
     double* m_host_scalars = nullptr;  // pinned, per order: t_i, sanity excess, sanity x-dot
     std::map<std::string, double> m_profile;

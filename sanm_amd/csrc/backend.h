@@ -50,6 +50,14 @@ public:
     virtual void d2d(void* dst, const void* src, size_t bytes) = 0;
     virtual void zero(void* dst, size_t bytes) = 0;
     virtual void sync() = 0;
+    //! Record the launches queued between begin and end instead of running them, for replay with
+    //! graph_launch (a launch-bound sequence of small kernels whose arguments do not change from one
+    //! continuation step to the next).  begin returns false if the backend has no graphs: the caller then
+    //! simply runs the sequence.
+    virtual bool graph_capture_begin() { return false; }
+    virtual void* graph_capture_end() { return nullptr; }
+    virtual void graph_launch(void*) {}
+    virtual void graph_destroy(void*) {}
     //! host memory the device can write (pinned); results of the *_async reductions land here and are
     //! valid after the next sync()
     virtual double* alloc_host(size_t n_doubles) = 0;
@@ -158,9 +166,10 @@ public:
                                   double* out, double* t_out) = 0;
     //! out[j] = x . ys[j]  (out: device memory)
     virtual void multi_dot_async(size_t n, const double* x, int nvec, const double* const* ys, double* out) = 0;
-    //! out = x - sum_{j >= first} coefs[j] * qs[j]   (coefs: device memory; classical Gram-Schmidt update)
+    //! out = x - sum_{j >= first} coefs[j] * qs[j];  *norm2 = out . out   (coefs, norm2: device memory;
+    //! classical Gram-Schmidt update)
     virtual void gs_update_async(size_t n, const double* x, int nvec, const double* const* qs,
-                                 const double* coefs, int first, double* out) = 0;
+                                 const double* coefs, int first, double* out, double* norm2) = 0;
     //! v *= 1 / max(sqrt(*norm2), eps); if sqrt(*norm2) < eps the result is normalised once more by its own
     //! norm (pade.cpp:60-66).  norm2: device memory; scratch: one double of device memory
     virtual void scale_rsqrt_async(size_t n, double* v, const double* norm2, double eps, double* scratch) = 0;

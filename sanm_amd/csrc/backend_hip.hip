@@ -262,30 +262,36 @@ __global__ void lincomb_kernel(size_t n, VecList v, double* out) {
     for (int j = 0; j < v.n; ++j) acc += v.c[j] * v.p[j][i];
     out[i] = acc;
 }
-// classical Gram-Schmidt update with the projections read from device memory
-__global__ void gs_update_kernel(size_t n, const double* __restrict__ x, VecList q, const double* __restrict__ coefs,
-                                 int first, double* out) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double acc = x[i];
-    for (int j = first; j < q.n; ++j) acc += -coefs[j] * q.p[j][i];
-    out[i] = acc;
-}
-__global__ void scale_rsqrt_kernel(size_t n, double* v, const double* __restrict__ norm2, double eps) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) v[i] *= 1.0 / fmax(sqrt(*norm2), eps);
-}
-
-// second normalisation of an underflowed Gram-Schmidt direction; both kernels leave at once otherwise
-__global__ void __launch_bounds__(256) renorm_dot_kernel(size_t n, const double* __restrict__ v,
-                                                         const double* __restrict__ norm2, double eps, GridRed g) {
-    if (sqrt(*norm2) >= eps) return;
+// classical Gram-Schmidt update with the projections read from device memory, and the squared norm of
+// the result
+__global__ void __launch_bounds__(256) gs_update_kernel(size_t n, const double* __restrict__ x, VecList q,
+                                                        const double* __restrict__ coefs, int first, double* out,
+                                                        GridRed g) {
     double s[1] = {0};
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (size_t)gridDim.x * blockDim.x)
-        s[0] += v[i] * v[i];
+         i += (size_t)gridDim.x * blockDim.x) {
+        double acc = x[i];
+        for (int j = first; j < q.n; ++j) acc += -coefs[j] * q.p[j][i];
+        out[i] = acc;
+        s[0] += acc * acc;
+    }
     grid_commit<1>(s, 1, 0u, g);
 }
+// v *= 1 / max(sqrt(*norm2), eps), and the squared norm of the result for the (rare) second normalisation
+__global__ void __launch_bounds__(256) scale_rsqrt_kernel(size_t n, double* v, const double* __restrict__ norm2,
+                                                          double eps, GridRed g) {
+    const double f = 1.0 / fmax(sqrt(*norm2), eps);
+    double s[1] = {0};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const double w = v[i] * f;
+        v[i] = w;
+        s[0] += w * w;
+    }
+    grid_commit<1>(s, 1, 0u, g);
+}
+
+// second normalisation of an underflowed Gram-Schmidt direction; leaves at once otherwise
 __global__ void renorm_scale_kernel(size_t n, double* v, const double* __restrict__ norm2, double eps,
                                     const double* __restrict__ nn2) {
     if (sqrt(*norm2) >= eps) return;
@@ -1012,22 +1018,38 @@ public:
         HIP_CHECK(hipGetLastError());
     }
     void gs_update_async(size_t n, const double* x, int nvec, const double* const* qs, const double* coefs,
-                         int first, double* out) override {
+                         int first, double* out, double* norm2) override {
         if (nvec > MAX_VEC) sanm_throw(SANM_ERR_ASSERT, "gs_update: too many vectors");
         VecList v{};
         v.n = nvec;
         for (int j = 0; j < nvec; ++j) v.p[j] = qs[j];
-        hipLaunchKernelGGL(gs_update_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, x, v, coefs, first,
-                           out);
+        hipLaunchKernelGGL(gs_update_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, coefs, first, out,
+                           red_to(norm2));
         HIP_CHECK(hipGetLastError());
     }
     void scale_rsqrt_async(size_t n, double* v, const double* norm2, double eps, double* scratch) override {
-        hipLaunchKernelGGL(scale_rsqrt_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, v, norm2, eps);
-        hipLaunchKernelGGL(renorm_dot_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, v, norm2, eps,
+        hipLaunchKernelGGL(scale_rsqrt_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, v, norm2, eps,
                            red_to(scratch));
         hipLaunchKernelGGL(renorm_scale_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, v, norm2, eps,
                            scratch);
         HIP_CHECK(hipGetLastError());
+    }
+    bool graph_capture_begin() override {
+        red();  // no allocation while capturing
+        HIP_CHECK(hipStreamBeginCapture(m_stream, hipStreamCaptureModeThreadLocal));
+        return true;
+    }
+    void* graph_capture_end() override {
+        hipGraph_t graph = nullptr;
+        HIP_CHECK(hipStreamEndCapture(m_stream, &graph));
+        hipGraphExec_t exec = nullptr;
+        HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        HIP_CHECK(hipGraphDestroy(graph));
+        return exec;
+    }
+    void graph_launch(void* g) override { HIP_CHECK(hipGraphLaunch(static_cast<hipGraphExec_t>(g), m_stream)); }
+    void graph_destroy(void* g) override {
+        if (g) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(g));
     }
     void dot_async(size_t n, const double* x, const double* y, double* out) override {
         hipLaunchKernelGGL(dot_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, y, red_to(out));

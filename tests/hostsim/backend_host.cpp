@@ -62,12 +62,13 @@ public:
         multi_dot(n, x, nvec, ys, out);
     }
     void gs_update_async(size_t n, const double* x, int nvec, const double* const* qs, const double* coefs,
-                         int first, double* out) override {
+                         int first, double* out, double* norm2) override {
         for (size_t i = 0; i < n; ++i) {
             double acc = x[i];
             for (int j = first; j < nvec; ++j) acc += -coefs[j] * qs[j][i];
             out[i] = acc;
         }
+        *norm2 = dot(n, out, out);
     }
     void scale_rsqrt_async(size_t n, double* v, const double* norm2, double eps, double*) override {
         const double s = 1.0 / std::max(std::sqrt(*norm2), eps);
