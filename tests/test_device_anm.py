@@ -159,3 +159,19 @@ def test_error_paths(api):
         A.ANMEqnSolver(api, m.y, m.lt_inp, m.lt_out, m.x0(), v, api.default_hyper(order=1))
     with pytest.raises(A.SanmUnsupportedError):
         A.ANMEqnSolver(api, m.y, m.lt_inp, m.lt_out, m.x0(), v, api.default_hyper(order=4, xcoeff_l2_penalty=0.1))
+
+
+def test_tet_renumbering_is_transparent(api, monkeypatch):
+    """the driver renumbers the tets along a Morton curve when it knows the positions of the
+    unknowns (gather locality); nothing it returns may depend on that: same step count and the
+    same solution with the renumbering switched off."""
+    gold = json.load(open(os.path.join(GOLD, "anm_cuboid_nc.json")))
+    run = _run_device(api, gold["dims"], gold["spacing"], gold["config"])
+    monkeypatch.setenv("SANM_NO_TET_ORDER", "1")
+    ref = _run_device(api, gold["dims"], gold["spacing"], gold["config"])
+    assert run.solver.get_nr_iter() == ref.solver.get_nr_iter() == gold["iter"]
+    x, xr = run.solver.get_x(), ref.solver.get_x()
+    assert np.abs(x - xr).max() <= 1e-9 * np.abs(xr).max()
+    # the Jacobian handed out in CSR form lives in the space of the unknowns as well
+    J, Jr = run.solver.jacobian_csr(), ref.solver.jacobian_csr()
+    assert np.array_equal(J.indices, Jr.indices) and np.allclose(J.data, Jr.data, rtol=1e-9, atol=1e-9)

@@ -90,3 +90,23 @@ def test_singular_matrix_reports_bad_pivot(api):
     A = sp.csr_matrix(np.array([[1.0, 2.0, 0], [2.0, 4.0, 0], [0, 0, 1.0]]))
     ds = DirectSolver(api, A)
     assert ds.factor(A) >= 1
+
+
+def test_grid3d_wide_separators(api):
+    """3-D 7-point stencil with unsymmetric values and the coordinate hint: the top
+    separators have 200+ pivots, i.e. many 32-wide panels per front, partial last
+    panels and workgroups that read panel tiles other workgroups of the same launch
+    are busy with (a data race there only shows on fronts this wide)."""
+    k = 15
+    rng = np.random.default_rng(7)
+    I, T = sp.identity(k), sp.diags([-1.0, -1.0], [-1, 1], shape=(k, k))
+    P = sp.kron(sp.kron(T, I), I) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(I, I), T)
+    P = sp.csr_matrix(P)
+    A = P.copy()
+    A.data = P.data * (1 + 0.3 * rng.standard_normal(P.nnz))
+    A = sp.csr_matrix(A + sp.diags(np.full(k ** 3, 7.0)))
+    g = np.arange(k, dtype=float)
+    coords = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    ds = _check(api, A, coords=coords, nrhs=2)
+    st = ds.stats()
+    assert st["max_front"] >= 200 and st["nr_level"] >= 4
