@@ -51,10 +51,12 @@ def parse(argv=None):
 
 
 def cpu_baseline(workload, cpu_steps):
-    """The oracle (numpy port of the reference algorithm, SuperLU direct solve)
-    timed on the host for `cpu_steps` ANM steps of the same workload."""
+    """The oracle (numpy port of the reference algorithm; MKL PARDISO on one thread for the direct
+    solve when the image has MKL, SuperLU otherwise) timed on the host for `cpu_steps` ANM steps of
+    the same workload."""
     import numpy as np  # noqa: F401
     from oracle import fea as ofea
+    from oracle import pardiso
     from sanm_amd import fea as dfea
     cfg, mesh = dfea.load_named_config(workload)
     omesh = ofea.TetMesh(mesh.V, mesh.tets, mesh.surface_vtx)
@@ -67,7 +69,8 @@ def cpu_baseline(workload, cpu_steps):
     dt = time.perf_counter() - t0
     return {"value": steps / dt, "unit": "ANM steps/s", "cores": 1, "kind": "port",
             "sample": f"{steps} ANM step(s) of {workload} (order {cfg.get('order', 20)}) from the rest state, "
-                      f"numpy oracle + SuperLU, {dt:.1f} s incl. graph/remap setup",
+                      f"numpy oracle + {'MKL PARDISO (1 thread)' if pardiso.available() else 'SuperLU'}, "
+                      f"{dt:.1f} s incl. graph/remap setup",
             "profile": {k: round(v, 3) for k, v in solver.profile.items()}}
 
 

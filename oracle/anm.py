@@ -8,8 +8,9 @@ anm.cpp:193-312, estimate_valid_range :117-154, eval/solve_a :156-191),
 ``ANMImplicitSolver`` (:494-615).  The sparse system follows
 libsanm/sparse_solver.cpp: contributions with |c| < 1e-9 are dropped *before*
 duplicates are merged (:286-305), the factorisation is an unsymmetric sparse
-LU (reference: MKL PARDISO mtype 11, :107-127; here: SuperLU through scipy --
-a different direct solver of the same system).
+LU (reference: MKL PARDISO mtype 11, :107-127; here: the same MKL PARDISO with the
+same settings through ctypes when the image has MKL -- oracle/pardiso.py --, SuperLU
+through scipy otherwise).
 
 Remaps (``SparseLinearDesc``, anm.h:24-73) are held as scipy CSR matrices of
 shape (out_size, in_size): ``apply`` (anm.cpp:55-75) is a mat-vec.
@@ -23,6 +24,7 @@ import numpy as np
 import scipy.sparse as sp
 import scipy.sparse.linalg as spla
 
+from . import pardiso
 from . import unary_polynomial as up
 from .pade import PadeApproximation
 from .symbolic import SANMNumericalError, TaylorCoeffProp
@@ -114,7 +116,8 @@ def build_jacobian_csr(remap_out, jac, remap_in, nr_unknown, drop=1e-9, chunk_ro
 
 
 class SparseSolver:
-    """libsanm/sparse_solver.{h,cpp}: factor once, solve many, SpMV."""
+    """libsanm/sparse_solver.{h,cpp}: factor once, solve many, SpMV.  The factorisation is MKL PARDISO with
+    the reference's settings when the image provides MKL (oracle/pardiso.py), SuperLU otherwise."""
 
     def __init__(self, A):
         self.A = A.tocsr()
@@ -122,7 +125,10 @@ class SparseSolver:
 
     def prepare(self, l2=0.0):
         assert l2 == 0.0, "Tikhonov path (sparse_solver.cpp:366-395) is outside the hot path"
-        self.lu = spla.splu(self.A.tocsc(), permc_spec="MMD_AT_PLUS_A")
+        if pardiso.available():
+            self.lu = pardiso.Pardiso(self.A)
+        else:
+            self.lu = spla.splu(self.A.tocsc(), permc_spec="MMD_AT_PLUS_A")
 
     def solve(self, b):
         assert np.all(np.isfinite(b))

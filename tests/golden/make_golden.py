@@ -13,7 +13,9 @@ Two kinds of vectors:
 2. ``anm_*.json`` -- results of the oracle (pinned by 1. and by the invariant
    tests) on small end-to-end cases: per-step residual RMS, step counts,
    a_bound / t_max per step and final vertices.  The GPU tests compare the HIP
-   path against these and against the live oracle.
+   path against these and against the live oracle.  The oracle's linear solves
+   were MKL PARDISO (oracle/pardiso.py: the reference's solver and settings) when
+   these were generated.
 """
 import json
 import os
