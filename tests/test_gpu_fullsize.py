@@ -49,12 +49,11 @@ def test_named_config_against_oracle(hip_api, name):
     Vo = omodel.lt_inp.full_vertices(xo)
     print(f"{name}: device steps={steps} rms={run.rms} | oracle steps={osolver.get_nr_iter()} rms={orms}")
     if name == "human_arap16":
-        # The first step of this configuration sits on the Pade accept threshold: with
-        # series coefficients that agree to 3e-11 .. 3e-9 (scripts/diag_compare.py) the
-        # oracle rejects the approximant (a = 0.295) and the device path accepts it
-        # (a = 0.327); from there the two continuations take different but equally valid
-        # step sequences (7..8 device steps against the oracle's 9, depending on the
-        # summation order of the reductions) to the same equilibrium.  DESIGN.md section 5.
+        # This configuration sits on the Pade accept threshold: with series coefficients that
+        # agree to 1e-11 .. 6e-9 (scripts/diag_compare.py) the device path and the oracle accept
+        # the approximant at different steps and then take different but equally valid step
+        # sequences to the same equilibrium.  Observed over the builds of this round and both
+        # oracle solvers (PARDISO / SuperLU): 7..8 device steps against 8..9.  DESIGN.md section 5.
         assert abs(steps - osolver.get_nr_iter()) <= 2
     else:
         assert steps == osolver.get_nr_iter()
