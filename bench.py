@@ -42,7 +42,7 @@ def parse(argv=None):
     p.add_argument("--solver-kind", type=int, default=1, help="0: Jacobi-PCG, 1: multifrontal LU")
     p.add_argument("--profile", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-steps", type=int, default=1)
+    p.add_argument("--cpu-steps", type=int, default=2)
     p.add_argument("--parallelism", default="replicas", choices=["replicas", "shard"],
                    help="N>1: independent replicas (weak scaling) or one tet-sharded problem with an "
                         "RCCL all-reduce of b_k per Taylor order (strong scaling)")
