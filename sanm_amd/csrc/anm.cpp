@@ -500,7 +500,6 @@ void AnmDriver::solve_expansion_coeffs() {
     for (int i = 1; i <= N; ++i) {
         if (i == 1) {
             ScopedTimer t{this, "jacobian"};
-            m_prog->zero_jacobians();
             be->run_pass(P, PASS_GRAD, 0, nullptr);
         }
         {

@@ -55,9 +55,10 @@ __global__ void __launch_bounds__(256, W) taylor_pass_kernel(ProgramDev P, int o
     const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nparts = blockDim.x >> 6;
     int64_t tet = (int64_t)blockIdx.x * 64 + lane;
+    // the GRAD pass runs one (tet, Jacobian row) pair per lane: the row is blockIdx.y
     if (tet < P.T)
-        exec_program_tet(P, MODE, order, tet, xvec, cur_lds + lane, 64, part, nparts,
-                         cur_lds + (int64_t)P.cur_size * 64 + lane);
+        exec_program_tet(P, MODE, MODE == PASS_GRAD ? (int)blockIdx.y : order, tet, xvec, cur_lds + lane, 64, part,
+                         nparts, cur_lds + (int64_t)P.cur_size * 64 + lane);
 }
 
 // remap_out: GATHER_LANES lanes per output row (~45 gathered entries each), shuffle reduce.  The index ->
@@ -654,7 +655,8 @@ public:
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             m_pass_lds_limit[mode] = lds;
         }
-        hipLaunchKernelGGL(kern, dim3(nblk(P.T, 64)), dim3(64 * nparts), lds, m_stream, P, order, xvec);
+        hipLaunchKernelGGL(kern, dim3(nblk(P.T, 64), mode == PASS_GRAD ? P.odim : 1), dim3(64 * nparts), lds,
+                           m_stream, P, order, xvec);
         HIP_CHECK(hipGetLastError());
         if (m_time_passes) {
             HIP_CHECK(hipEventRecord(e1, m_stream));

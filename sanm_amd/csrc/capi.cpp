@@ -80,7 +80,6 @@ struct sanm_taylor_prop {
     void ensure_jacobian() {
         if (jacobian_done) return;
         sanm_check(order == 0, "jacobian must be taken at order 0");
-        prog->zero_jacobians();
         backend()->run_pass(prog->dev(), PASS_GRAD, 0, nullptr);
         jacobian_done = true;
     }

@@ -305,12 +305,19 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
             std::fprintf(stderr, "program: %zu ops, %zu vars, %d scratch doubles per tet\n", topo.size(),
                          m_vars.size(), cur_size);
     }
+    // only the placeholder's Jacobian d(out)/d(placeholder) lives in HBM (the assembly gathers from it);
+    // the reverse sweep keeps the gradients of the intermediate variables in the LDS slots (tet_ops.h)
     m_jac_begin = off;
-    for (auto& d : m_vars)
-        if (!d.is_const) d.jac = take((int64_t)odim * d.size * Tpad);
+    m_vars[m_placeholder_var].jac = take((int64_t)odim * m_vars[m_placeholder_var].size * Tpad);
     m_jac_end = off;
 
-    for (int oi : topo) {
+    // last reader of every variable: in the reverse sweep of the GRAD pass it is the first operator to
+    // accumulate into the variable's gradient slot and clears it first
+    std::vector<int> last_reader(m_vars.size(), -1);
+    for (size_t pos = 0; pos < topo.size(); ++pos)
+        for (int v : g.ops[topo[pos]].in) last_reader[m_var_map[v]] = pos;
+    for (size_t pos = 0; pos < topo.size(); ++pos) {
+        const int oi = topo[pos];
         const GraphOp& op = g.ops[oi];
         OpDesc o{};
         o.type = op.type;
@@ -319,6 +326,14 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
         o.nout = op.out.size();
         for (int i = 0; i < o.nin; ++i) o.in[i] = m_var_map[op.in[i]];
         for (int i = 0; i < o.nout; ++i) o.out[i] = m_var_map[op.out[i]];
+        o.grad_zero = 0;
+        for (int i = 0; i < o.nin; ++i) {
+            bool first = true;  // an input listed twice is cleared once
+            for (int j = 0; j < i; ++j) first = first && o.in[j] != o.in[i];
+            // (the graph output's slot holds the seed and is never cleared)
+            if (first && last_reader[o.in[i]] == (int)pos && o.in[i] != lout && !m_vars[o.in[i]].is_const)
+                o.grad_zero |= 1 << i;
+        }
         for (int i = 0; i < 4; ++i) o.aux[i] = -1;
         const int osz = m_vars[o.out[0]].size;
         switch (op.type) {
@@ -450,10 +465,6 @@ void Program::set_remap_in(int64_t n_in, const uint64_t* rowptr, const uint64_t*
     m_dev.rin = {static_cast<const uint32_t*>(m_d_rin_idx),
                  static_cast<const double*>(m_d_rin_coef), nslot};
     m_n_in = n_in;
-}
-
-void Program::zero_jacobians() {
-    m_be->zero(m_dev.arena + m_jac_begin, (m_jac_end - m_jac_begin) * sizeof(double));
 }
 
 void Program::download_var(int graph_var, int order, double* dst) const {

@@ -102,7 +102,6 @@ public:
     const std::vector<VarDesc>& vars() const { return m_vars; }
     int64_t n_in() const { return m_n_in; }
 
-    void zero_jacobians();
     //! device pointer of the output's order-0 value / bias, SoA [9][Tpad]
     const double* out_coef0() const { return m_dev.arena + m_vars[m_dev.out_var].coef; }
     const double* out_bias() const { return m_dev.arena + m_vars[m_dev.out_var].bias; }

@@ -45,7 +45,7 @@ constexpr int MAX_OP_IN = 4;
 struct VarDesc {
     int64_t coef;  // arena offset of coefficient 0; order k at coef + k*size*Tpad
     int64_t bias;  // arena offset of cur_order_bias
-    int64_t jac;   // arena offset of the Jacobian [odim][size][Tpad]; -1 if none
+    int64_t jac;   // arena offset of the Jacobian [odim][size][Tpad]: the placeholder only; -1 otherwise
     int32_t size;  // 1 (batched scalar), 3 (singular values) or 9 (3x3)
     int32_t is_const;  // coefficients of order >= 1 are identically zero
     int32_t cur;       // offset (in doubles) of the current-order value in the per-lane scratch
@@ -56,7 +56,8 @@ struct OpDesc {
     int32_t type, nin, nout, flags;
     int32_t in[MAX_OP_IN];
     int32_t out[3];
-    int32_t pad_;
+    int32_t grad_zero;  // GRAD pass: bit i set = this operator is the first (in reverse order) to accumulate
+                        // into the gradient slot of input i and clears it first
     double p[MAX_OP_IN + 2];  // LINCOMB: coeffs then bias at p[MAX_OP_IN]; POW: p[0]=exponent
     int64_t aux[4];           // arena offsets of per-operator scratch (see tet_ops.h)
 };

@@ -49,6 +49,11 @@ struct TetCtx {
     // LDS exchange buffer of this lane ([part-1][element][64 lanes])
     int32_t part = 0, nparts = 1;
     double* red = nullptr;
+    // GRAD pass: the row of the Jacobian d(out)/d(.) this lane propagates.  Rows are independent, so a
+    // (tet, row) pair per lane gives 9x the wavefronts, and the gradients of the intermediate variables (one
+    // size-vector per variable and row) fit the same LDS slots the forward passes use for current values
+    // instead of 9 x size doubles per variable in HBM.
+    int32_t grow = 0;
 };
 
 // slice [lo, hi) of the convolution index range 1 .. order-1 taken by this part
@@ -326,12 +331,12 @@ SANM_HD void st_cur(const TetCtx& c, int v, int n, const double* m, bool in_coef
 }
 
 // jac accumulate:  in.jac[r][ci] += v
-SANM_HD void jadd(const TetCtx& c, int v, int r, int ci, double val) {
-    double* p = p_jac(c, v) + ((int64_t)r * c.vars[v].size + ci) * c.Tpad;
-    *p += val;
+// gradient slot of variable v for this lane's row (r is that row: c.grow)
+SANM_HD void jadd(const TetCtx& c, int v, int, int ci, double val) {
+    c.cur[(int64_t)(c.vars[v].cur + ci) * c.cur_stride] += val;
 }
-SANM_HD double jget(const TetCtx& c, int v, int r, int ci) {
-    return p_jac(c, v)[((int64_t)r * c.vars[v].size + ci) * c.Tpad];
+SANM_HD double jget(const TetCtx& c, int v, int, int ci) {
+    return c.cur[(int64_t)(c.vars[v].cur + ci) * c.cur_stride];
 }
 
 // ---- LINCOMB: elem_arith.cpp:42-124
@@ -343,7 +348,7 @@ SANM_HD void op_lincomb(const TetCtx& c, const OpDesc& o, int mode) {
             int iv = o.in[k], isz = c.vars[iv].size;
             if (c.vars[iv].is_const) continue;
             double ck = o.p[k];
-            for (int r = 0; r < c.odim; ++r) {
+            for (int r = c.grow; r <= c.grow; ++r) {
                 if (isz == osz) {
                     for (int e = 0; e < osz; ++e) jadd(c, iv, r, e, ck * jget(c, ov, r, e));
                 } else {
@@ -392,7 +397,7 @@ SANM_HD void op_multiply(const TetCtx& c, const OpDesc& o, int mode) {
             if (c.vars[iv].is_const) continue;
             int isz = c.vars[iv].size, otsz = c.vars[other].size;
             const double* po = p_coef(c, other, 0);
-            for (int r = 0; r < c.odim; ++r) {
+            for (int r = c.grow; r <= c.grow; ++r) {
                 if (isz == osz) {
                     for (int e = 0; e < osz; ++e)
                         jadd(c, iv, r, e, jget(c, ov, r, e) * bval(po, s, otsz, e));
@@ -471,7 +476,7 @@ SANM_HD void op_unary(const TetCtx& c, const OpDesc& o, int mode) {
     }
     if (mode == PASS_GRAD) {
         if (c.vars[x].is_const) return;
-        for (int r = 0; r < c.odim; ++r)
+        for (int r = c.grow; r <= c.grow; ++r)
             for (int e = 0; e < sz; ++e) jadd(c, x, r, e, jget(c, ov, r, e) * pk[e * s]);
         return;
     }
@@ -515,7 +520,7 @@ SANM_HD void op_reduce(const TetCtx& c, const OpDesc& o, int mode) {
     const int x = o.in[0], ov = o.out[0], isz = c.vars[x].size;
     if (mode == PASS_GRAD) {
         if (c.vars[x].is_const) return;
-        for (int r = 0; r < c.odim; ++r) {
+        for (int r = c.grow; r <= c.grow; ++r) {
             double g = jget(c, ov, r, 0);
             for (int e = 0; e < isz; ++e) jadd(c, x, r, e, g);
         }
@@ -548,7 +553,7 @@ SANM_HD void op_matmul(const TetCtx& c, const OpDesc& o, int mode) {
     if (mode == PASS_GRAD) {
         ld9(p_coef(c, a, 0), s, A);
         ld9(p_coef(c, b, 0), s, B);
-        for (int r = 0; r < c.odim; ++r) {
+        for (int r = c.grow; r <= c.grow; ++r) {
             double G[9];
             for (int e = 0; e < 9; ++e) G[e] = jget(c, ov, r, e);
             if (!c.vars[a].is_const) {  // ga[m,k] = sum_n g[m,n] b[k,n]
@@ -632,7 +637,7 @@ SANM_HD void op_matinvmul(const TetCtx& c, const OpDesc& o, int mode) {
         ld9(p_coef(c, ov, 0), s, Y0);
         for (int e = 0; e < 9; ++e) Y0[e] = -Y0[e];
         const double *m0 = is_left ? Y0 : XI, *m1 = is_left ? XI : Y0;
-        for (int r = 0; r < c.odim; ++r) {
+        for (int r = c.grow; r <= c.grow; ++r) {
             double G[9];
             for (int e = 0; e < 9; ++e) G[e] = jget(c, ov, r, e);
             if (!c.vars[x].is_const) {
@@ -742,7 +747,7 @@ SANM_HD void op_det(const TetCtx& c, const OpDesc& o, int mode) {
     if (mode == PASS_GRAD) {
         if (c.vars[x].is_const) return;
         ld9(pcof, s, C);
-        for (int r = 0; r < c.odim; ++r) {
+        for (int r = c.grow; r <= c.grow; ++r) {
             double g = jget(c, ov, r, 0);
             for (int e = 0; e < 9; ++e) jadd(c, x, r, e, g * C[e]);
         }
@@ -810,7 +815,7 @@ SANM_HD void op_transpose(const TetCtx& c, const OpDesc& o, int mode) {
     const int x = o.in[0], ov = o.out[0];
     if (mode == PASS_GRAD) {
         if (c.vars[x].is_const) return;
-        for (int r = 0; r < c.odim; ++r)
+        for (int r = c.grow; r <= c.grow; ++r)
             for (int i = 0; i < 3; ++i)
                 for (int j = 0; j < 3; ++j) jadd(c, x, r, i * 3 + j, jget(c, ov, r, j * 3 + i));
         return;
@@ -830,7 +835,7 @@ SANM_HD void op_muleye(const TetCtx& c, const OpDesc& o, int mode) {
     const int x = o.in[0], ov = o.out[0];
     if (mode == PASS_GRAD) {
         if (c.vars[x].is_const) return;
-        for (int r = 0; r < c.odim; ++r)
+        for (int r = c.grow; r <= c.grow; ++r)
             jadd(c, x, r, 0, jget(c, ov, r, 0) + jget(c, ov, r, 4) + jget(c, ov, r, 8));
         return;
     }
@@ -866,7 +871,7 @@ SANM_HD void op_svdw(const TetCtx& c, const OpDesc& o, int mode) {
         if (c.vars[x].is_const) return;
         double V[9], G[9], Tm[9], Z[9];
         mm3<true, false, false>(V, W, U);
-        for (int r = 0; r < c.odim; ++r) {
+        for (int r = c.grow; r <= c.grow; ++r) {
             for (int e = 0; e < 9; ++e) G[e] = jget(c, wv, r, e);
             mm3<true, false, false>(Tm, U, G);
             mm3<false, false, false>(G, Tm, V);
@@ -922,7 +927,12 @@ SANM_HD void op_placeholder(const TetCtx& c, const OpDesc& o, int mode, const Re
                             const double* xvec) {
     const int64_t s = c.Tpad;
     const int ov = o.out[0];
-    if (mode == PASS_GRAD) return;
+    if (mode == PASS_GRAD) {
+        // the end of the reverse sweep: row grow of d(out)/d(placeholder), what the assembly gathers
+        double* j = p_jac(c, ov) + (int64_t)c.grow * 9 * s;
+        for (int e = 0; e < 9; ++e) j[e * s] = jget(c, ov, c.grow, e);
+        return;
+    }
     double X[9];
     if (mode == PASS_BIAS) {
         for (int e = 0; e < 9; ++e) X[e] = 0.0;
@@ -946,6 +956,12 @@ SANM_HD void exec_op(const TetCtx& c, const OpDesc& o, int mode, const RemapInDe
     // operators fed by constants only are evaluated once (order 0); their
     // higher-order terms are identically zero, never stored and never read
     if (mode != PASS_EVAL0 && c.vars[o.out[0]].is_const) return;
+    if (mode == PASS_GRAD)
+        for (int i = 0; i < o.nin; ++i)
+            if ((o.grad_zero >> i) & 1) {
+                const VarDesc& d = c.vars[o.in[i]];
+                for (int e = 0; e < d.size; ++e) c.cur[(int64_t)(d.cur + e) * c.cur_stride] = 0.0;
+            }
     if (c.part) {
         // helper wavefronts of a split BIAS pass only join the convolutions
         switch (o.type) {
@@ -980,10 +996,10 @@ SANM_HD void exec_program_tet(const ProgramDev& P, int mode, int order, int64_t 
                               int nparts = 1, double* red = nullptr) {
     TetCtx c{P.arena, P.vars, P.Tpad, tet, order, P.odim, cur, cur_stride, P.out_var, part, nparts, red};
     if (mode == PASS_GRAD) {
-        // seed: d(out)/d(out) = I  (symbolic.cpp:219-220)
-        double* j = p_jac(c, P.out_var);
-        for (int r = 0; r < P.odim; ++r)
-            for (int e = 0; e < P.odim; ++e) j[((int64_t)r * P.odim + e) * P.Tpad] = (r == e) ? 1.0 : 0.0;
+        // seed: row `order` of d(out)/d(out) = I  (symbolic.cpp:219-220); the launch passes the row in `order`
+        c.grow = order;
+        const VarDesc& d = P.vars[P.out_var];
+        for (int e = 0; e < P.odim; ++e) cur[(int64_t)(d.cur + e) * cur_stride] = (e == order) ? 1.0 : 0.0;
         for (int i = P.nops - 1; i >= 0; --i) exec_op(c, P.ops[i], mode, P.rin, xvec);
     } else {
         for (int i = 0; i < P.nops; ++i) exec_op(c, P.ops[i], mode, P.rin, xvec);

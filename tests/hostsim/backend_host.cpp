@@ -35,6 +35,11 @@ public:
 
     void run_pass(const ProgramDev& P, int mode, int order, const double* xvec) override {
         std::vector<double> cur(P.cur_size + 1);
+        if (mode == PASS_GRAD) {  // one reverse sweep per row of the Jacobian (the row travels in `order`)
+            for (int64_t t = 0; t < P.T; ++t)
+                for (int r = 0; r < P.odim; ++r) exec_program_tet(P, mode, r, t, xvec, cur.data(), 1);
+            return;
+        }
         for (int64_t t = 0; t < P.T; ++t) exec_program_tet(P, mode, order, t, xvec, cur.data(), 1);
     }
     void gather_rows(const SparseRowsDev& R, const double* src, double* dst) override {
