@@ -264,7 +264,8 @@ private:
     //     key) at a few positions around the median -- and the one with the lightest boundary is kept;
     //  2. the vertex separator is a MINIMUM VERTEX COVER of the cut edges (Koenig: from a maximum matching of
     //     the bipartite boundary graph), not one whole boundary layer;
-    //  3. separator vertices left without a neighbour on one side are handed to the other side.
+    //  3. separator vertices left without a neighbour on one side are handed to the other side, and a few
+    //     Fiduccia-Mattheyses passes (refine_separator) move the rest where that lightens the separator.
     void bisect(const std::vector<int32_t>& set, std::vector<int32_t>& sep, std::vector<int32_t>& pa,
                 std::vector<int32_t>& pb) {
         const int32_t mark = in_set[set[0]];
@@ -462,10 +463,96 @@ private:
                 if (!hasB) in_set[u] = markA;
                 else if (!hasA) in_set[u] = markB;
             }
+        refine_separator(set, markA, markB, markS);
         for (int32_t u : set) {
             if (in_set[u] == markA) pa.push_back(u);
             else if (in_set[u] == markB) pb.push_back(u);
             else sep.push_back(u);
+        }
+    }
+
+    // Fiduccia-Mattheyses passes on the vertex separator.  A move takes a separator vertex v into side X; its
+    // neighbours on the other side Y then have to enter the separator, so the move changes the separator
+    // weight by w(N(v) & Y) - w(v).  A pass applies the best admissible move again and again -- also when it
+    // makes things worse, each vertex at most once -- and finally returns to the lightest separator it has
+    // seen; that is how the search leaves the local optimum the vertex cover ends in.  Sides may not exceed
+    // 58 % of the set: an unbalanced cut deepens the tree, and a tree level costs more than a few pivots.
+    void refine_separator(const std::vector<int32_t>& set, int32_t markA, int32_t markB, int32_t markS) {
+        int64_t w[3] = {0, 0, 0};  // A, B, S
+        auto side_of = [&](int32_t u) { return in_set[u] == markA ? 0 : (in_set[u] == markB ? 1 : (in_set[u] == markS ? 2 : 3)); };
+        for (int32_t u : set) w[side_of(u)] += g.size(u);
+        const int64_t wTot = w[0] + w[1] + w[2];
+        const int64_t wMax = std::max<int64_t>((int64_t)(0.58 * wTot), std::max(w[0], w[1]));
+        std::vector<int32_t> sepv, best_state(set.size());
+        std::vector<int32_t>& locked = stamp;  // stamp[v] == cur_stamp: moved in this pass
+        for (int pass = 0; pass < 6; ++pass) {
+            ++cur_stamp;
+            int64_t best_w = w[2], cur_w = w[2];
+            int64_t best_imb = std::llabs(w[0] - w[1]);
+            for (size_t i = 0; i < set.size(); ++i) best_state[i] = in_set[set[i]];
+            int64_t wa = w[0], wb = w[1];
+            int since_best = 0;
+            for (int step = 0; step < (int)set.size() && since_best < 60; ++step) {
+                // best admissible move
+                int32_t bv = -1, bside = 0;
+                int64_t bgain = INT64_MIN;
+                sepv.clear();
+                for (int32_t u : set)
+                    if (in_set[u] == markS && locked[u] != cur_stamp) sepv.push_back(u);
+                for (int32_t v : sepv) {
+                    int64_t nA = 0, nB = 0;
+                    for (int32_t q = g.adj_ptr[v]; q < g.adj_ptr[v + 1]; ++q) {
+                        const int32_t u = g.adj[q];
+                        if (in_set[u] == markA) nA += g.size(u);
+                        else if (in_set[u] == markB) nB += g.size(u);
+                    }
+                    const int64_t wv = g.size(v);
+                    // to A: B-neighbours enter the separator (B shrinks, A grows by w(v))
+                    if (wa + wv <= wMax) {
+                        const int64_t gain = wv - nB;
+                        if (gain > bgain || (gain == bgain && wa < wb)) {
+                            bgain = gain;
+                            bv = v;
+                            bside = 0;
+                        }
+                    }
+                    if (wb + wv <= wMax) {
+                        const int64_t gain = wv - nA;
+                        if (gain > bgain || (gain == bgain && bside == 0 && wb < wa)) {
+                            bgain = gain;
+                            bv = v;
+                            bside = 1;
+                        }
+                    }
+                }
+                if (bv < 0) break;
+                const int32_t to = bside == 0 ? markA : markB, from = bside == 0 ? markB : markA;
+                for (int32_t q = g.adj_ptr[bv]; q < g.adj_ptr[bv + 1]; ++q) {
+                    const int32_t u = g.adj[q];
+                    if (in_set[u] == from) {
+                        in_set[u] = markS;
+                        (bside == 0 ? wb : wa) -= g.size(u);
+                    }
+                }
+                in_set[bv] = to;
+                locked[bv] = cur_stamp;
+                (bside == 0 ? wa : wb) += g.size(bv);
+                cur_w -= bgain;
+                const int64_t imb = std::llabs(wa - wb);
+                if (cur_w < best_w || (cur_w == best_w && imb < best_imb)) {
+                    best_w = cur_w;
+                    best_imb = imb;
+                    for (size_t i = 0; i < set.size(); ++i) best_state[i] = in_set[set[i]];
+                    since_best = 0;
+                } else {
+                    ++since_best;
+                }
+            }
+            for (size_t i = 0; i < set.size(); ++i) in_set[set[i]] = best_state[i];
+            const int64_t before = w[2];
+            w[0] = w[1] = w[2] = 0;
+            for (int32_t u : set) w[side_of(u)] += g.size(u);
+            if (w[2] >= before) break;
         }
     }
 };
