@@ -244,30 +244,59 @@ bool PadeApproximation::estimate_valid_range(double start, double eps, double li
     std::vector<const double*> ptrs(n);
     std::vector<double> c_n(n), c_lo(n);
     for (int i = 1; i <= n; ++i) ptrs[i - 1] = m_xs[i].p();
-    auto check = [&](double a) {
-        // |P_n(a)/D_n(a) - P_{n-1}(a)/D_{n-1}(a)| <= eps |P_n(a)/D_n(a)| on the numerators, one pass
-        // over the series and one synchronisation per probe
-        double denom_n = poly::eval(m_d, a), denom_lo = poly::eval(m_d_lo, a);
-        nume_coefs(a, m_d.data(), n, c_n.data());
-        nume_coefs(a, m_d_lo.data(), n - 1, c_lo.data());
-        c_lo[n - 1] = 0;
-        double r[2];
-        m_be->lincomb2_diff_norms(m_len, n, ptrs.data(), c_n.data(), c_lo.data(), denom_n / denom_lo, r);
-        return r[0] <= r[1] * eps2;
+    // check(a): |P_n(a)/D_n(a) - P_{n-1}(a)/D_{n-1}(a)| <= eps |P_n(a)/D_n(a)| on the numerators.  Several
+    // points are probed in one pass over the series and one synchronisation; each point's arithmetic is the
+    // same as if it were probed alone.
+    auto check_many = [&](const std::vector<double>& as) {
+        const int nc = as.size();
+        std::vector<double> c1((size_t)nc * n), c2((size_t)nc * n, 0.0), scale(nc), r(2 * nc);
+        for (int c = 0; c < nc; ++c) {
+            nume_coefs(as[c], m_d.data(), n, c1.data() + (size_t)c * n);
+            nume_coefs(as[c], m_d_lo.data(), n - 1, c2.data() + (size_t)c * n);
+            scale[c] = poly::eval(m_d, as[c]) / poly::eval(m_d_lo, as[c]);
+        }
+        m_be->lincomb2_diff_norms_multi(m_len, n, ptrs.data(), nc, c1.data(), c2.data(), scale.data(), r.data());
+        std::vector<char> ok(nc);
+        for (int c = 0; c < nc; ++c) ok[c] = r[2 * c] <= r[2 * c + 1] * eps2;
+        return ok;
     };
     double left = start * 1.001, right = start + (pole - start) * 0.99;
-    if (!check(left)) return false;
     if (limit && right > limit) right = limit;
-    if (right > start * 2) {
-        if (check(start * 2)) left = start * 2;
-        else right = start * 2;
+    {
+        // the two opening probes (pade.cpp:143-156) do not depend on each other
+        std::vector<double> as{left};
+        const bool dbl = right > start * 2;
+        if (dbl) as.push_back(start * 2);
+        const std::vector<char> ok = check_many(as);
+        if (!ok[0]) return false;
+        if (dbl) {
+            if (ok[1]) left = start * 2;
+            else right = start * 2;
+        }
     }
+    // bisection (pade.cpp:157-165), three levels per pass: the 7 midpoints the next three decisions can
+    // ask for are probed together and the decisions then walk down that tree
     int iter = 0;
     while (iter < 8 && right - left > 1e-3) {
-        double mid = (left + right) / 2;
-        if (check(mid)) left = mid;
-        else right = mid;
-        ++iter;
+        const int depth = std::min(3, 8 - iter), nn = (1 << depth) - 1;
+        std::vector<double> lo(nn + 1), hi(nn + 1), mid(nn + 1);
+        lo[1] = left;
+        hi[1] = right;
+        for (int v = 1; v <= nn; ++v) {
+            mid[v] = (lo[v] + hi[v]) / 2;
+            if (2 * v + 1 <= nn) {
+                lo[2 * v] = lo[v];  // probe failed: right = mid
+                hi[2 * v] = mid[v];
+                lo[2 * v + 1] = mid[v];  // probe passed: left = mid
+                hi[2 * v + 1] = hi[v];
+            }
+        }
+        const std::vector<char> ok = check_many(std::vector<double>(mid.begin() + 1, mid.end()));
+        for (int v = 1; v <= nn && iter < 8 && right - left > 1e-3; ++iter) {
+            if (ok[v - 1]) left = mid[v];
+            else right = mid[v];
+            v = 2 * v + (ok[v - 1] ? 1 : 0);
+        }
     }
     m_t_max_a = left;
     m_t_max = eval_t(left);

@@ -91,6 +91,11 @@ public:
     //! The Pade range test (pade.cpp:143-165) on two numerators without materialising them.
     virtual void lincomb2_diff_norms(size_t n, int nvec, const double* const* ptrs, const double* c1,
                                      const double* c2, double scale, double out_host[2]);
+    //! the same for `ncand` (<= 7) coefficient sets at once (row c of c1 / c2 has nvec entries): the vectors
+    //! are read once and there is one synchronisation for all of them; out_host = {d.d, u.u} per candidate
+    virtual void lincomb2_diff_norms_multi(size_t n, int nvec, const double* const* ptrs, int ncand,
+                                           const double* c1, const double* c2, const double* scale,
+                                           double* out_host);
     //! out = x .* y
     virtual void vmul(size_t n, const double* x, const double* y, double* out) = 0;
     //! d[i] = 1 / A[i,i]  (scaled by `scale`)

@@ -32,6 +32,13 @@ void Backend::lincomb2_diff_norms(size_t n, int nvec, const double* const* ptrs,
     free(w);
 }
 
+void Backend::lincomb2_diff_norms_multi(size_t n, int nvec, const double* const* ptrs, int ncand,
+                                        const double* c1, const double* c2, const double* scale,
+                                        double* out_host) {
+    for (int c = 0; c < ncand; ++c)
+        lincomb2_diff_norms(n, nvec, ptrs, c1 + (size_t)c * nvec, c2 + (size_t)c * nvec, scale[c], out_host + 2 * c);
+}
+
 void Backend::pcg(const CsrDev& A, double sign, const double* dinv, const double* b, double* x,
                   double rtol, int maxit, int* iters, double* relres) {
     const size_t n = A.n;

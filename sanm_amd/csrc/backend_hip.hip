@@ -319,6 +319,40 @@ __global__ void __launch_bounds__(256) lincomb2_diff_norms_kernel(size_t n, VecL
     grid_commit<2>(r, 2, 0u, g);
 }
 
+// ... for up to PROBE_MAX coefficient sets in one pass over the vectors (speculative bisection of the range)
+constexpr int PROBE_MAX = 7;
+struct ProbeArgs {
+    const double* p[MAX_VEC];
+    double c1[PROBE_MAX][MAX_VEC], c2[PROBE_MAX][MAX_VEC];
+    double scale[PROBE_MAX];
+    int nvec, ncand;
+};
+__global__ void __launch_bounds__(256) lincomb2_diff_norms_multi_kernel(size_t n, ProbeArgs a, GridRed g) {
+    double r[2 * PROBE_MAX];
+    for (int c = 0; c < 2 * PROBE_MAX; ++c) r[c] = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        double u[PROBE_MAX], w[PROBE_MAX];
+#pragma unroll
+        for (int c = 0; c < PROBE_MAX; ++c) u[c] = w[c] = 0;
+        for (int j = 0; j < a.nvec; ++j) {
+            const double x = a.p[j][i];
+#pragma unroll
+            for (int c = 0; c < PROBE_MAX; ++c) {  // same accumulation order per candidate as the single probe
+                u[c] += a.c1[c][j] * x;
+                w[c] += a.c2[c][j] * x;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < PROBE_MAX; ++c) {
+            const double d = a.scale[c] * w[c] - u[c];
+            r[2 * c] += d * d;
+            r[2 * c + 1] += u[c] * u[c];
+        }
+    }
+    grid_commit<2 * PROBE_MAX>(r, 2 * a.ncand, 0u, g);
+}
+
 // out[j] = x . ys[j]; x is read once per element
 __global__ void __launch_bounds__(256) multi_dot_kernel(size_t n, const double* __restrict__ x, VecList v,
                                                         GridRed g) {
@@ -955,6 +989,26 @@ public:
         const double* r = red_result();
         out_host[0] = r[0];
         out_host[1] = r[1];
+    }
+    void lincomb2_diff_norms_multi(size_t n, int nvec, const double* const* ptrs, int ncand, const double* c1,
+                                   const double* c2, const double* scale, double* out_host) override {
+        if (nvec > MAX_VEC || ncand > PROBE_MAX || ncand < 1)
+            sanm_throw(SANM_ERR_ASSERT, "lincomb2_diff_norms_multi: %d vectors, %d candidates", nvec, ncand);
+        ProbeArgs a{};
+        a.nvec = nvec;
+        a.ncand = ncand;
+        for (int j = 0; j < nvec; ++j) a.p[j] = ptrs[j];
+        for (int c = 0; c < ncand; ++c) {
+            a.scale[c] = scale[c];
+            for (int j = 0; j < nvec; ++j) {
+                a.c1[c][j] = c1[(size_t)c * nvec + j];
+                a.c2[c][j] = c2[(size_t)c * nvec + j];
+            }
+        }
+        hipLaunchKernelGGL(lincomb2_diff_norms_multi_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, a,
+                           red());
+        const double* r = red_result();
+        for (int c = 0; c < 2 * ncand; ++c) out_host[c] = r[c];
     }
     void multi_dot(size_t n, const double* x, int nvec, const double* const* ys,
                    double* out_host) override {
