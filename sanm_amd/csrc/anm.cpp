@@ -138,21 +138,24 @@ PadeApproximation::PadeApproximation(Backend* be, const std::vector<DVec>& xs,
         ws->be = be;
         ws->orth.resize(nx);
         for (int i = 1; i <= n; ++i) ws->orth[i] = DVec{be, m_len};
-        ws->acoef = DVec{be, (size_t)nx * nx + 1};
+        ws->acoef = DVec{be, (size_t)nx * nx + nx};
     }
     sanm_check((int)ws->orth.size() == nx && ws->orth[1].size() == m_len, "pade workspace mismatch");
     auto sweep = [&]() {
-        std::vector<const double*> ptrs(nx);
-        double* scratch = ws->acoef.p() + (size_t)nx * nx;
+        std::vector<double*> ptrs(nx);
+        double* nn2 = ws->acoef.p() + (size_t)nx * nx;  // per vector: squared norm after the first scaling
         for (int i = 1; i <= n; ++i) {
             for (int j = 1; j < i; ++j) ptrs[j - 1] = ws->orth[j].p();
             double* row = ws->acoef.p() + (size_t)i * nx;
             double* uii = ws->orth[i].p();
-            be->multi_dot_async(m_len, xs[i].p(), i - 1, ptrs.data(), row + 1);
+            // the projection kernel also completes the normalisation of the previous basis vector
+            const double* prev_norm2 = i >= 2 ? ws->acoef.p() + (size_t)(i - 1) * nx + (i - 1) : nullptr;
+            be->multi_dot_async(m_len, xs[i].p(), i - 1, ptrs.data(), row + 1, prev_norm2, nn2 + (i - 1), eps);
             // under the ANM condition the projection on the first basis vector is dropped (checked below)
             be->gs_update_async(m_len, xs[i].p(), i - 1, ptrs.data(), row + 1, anm_cond ? 1 : 0, uii, row + i);
-            be->scale_rsqrt_async(m_len, uii, row + i, eps, scratch);
+            be->scale_rsqrt_async(m_len, uii, row + i, eps, nn2 + i);
         }
+        be->gs_renorm_async(m_len, ws->orth[n].p(), ws->acoef.p() + (size_t)n * nx + n, nn2 + n, eps);
     };
     if (ws->graph) {
         be->graph_launch(ws->graph);

@@ -169,15 +169,20 @@ public:
     //! t = *num * scale;  out[0..n) = -t * x - y;  out[n] = t;  *t_out = t   (anm.cpp:258-264)
     virtual void next_coeff_async(size_t n, const double* num, double scale, const double* x, const double* y,
                                   double* out, double* t_out) = 0;
-    //! out[j] = x . ys[j]  (out: device memory)
-    virtual void multi_dot_async(size_t n, const double* x, int nvec, const double* const* ys, double* out) = 0;
-    //! out = x - sum_{j >= first} coefs[j] * qs[j];  *norm2 = out . out   (coefs, norm2: device memory;
-    //! classical Gram-Schmidt update)
+    // One classical Gram-Schmidt step of the Pade basis (pade.cpp:36-70) is three queued kernels; scalars stay
+    // in device memory.  A vector whose norm underflows (sqrt(norm2) < eps) is normalised a second time by
+    // its own norm: that rare fix-up is applied by the NEXT step's projection kernel, which reads the vector
+    // anyway (gs_renorm_async for the last one).
+    //! out[j] = x . ys[j].  First, if last_norm2 != null and sqrt(*last_norm2) < eps: ys[nvec-1] *= 1/sqrt(*last_nn2)
+    virtual void multi_dot_async(size_t n, const double* x, int nvec, double* const* ys, double* out,
+                                 const double* last_norm2, const double* last_nn2, double eps) = 0;
+    //! out = x - sum_{j >= first} coefs[j] * qs[j];  *norm2 = out . out   (coefs, norm2: device memory)
     virtual void gs_update_async(size_t n, const double* x, int nvec, const double* const* qs,
                                  const double* coefs, int first, double* out, double* norm2) = 0;
-    //! v *= 1 / max(sqrt(*norm2), eps); if sqrt(*norm2) < eps the result is normalised once more by its own
-    //! norm (pade.cpp:60-66).  norm2: device memory; scratch: one double of device memory
-    virtual void scale_rsqrt_async(size_t n, double* v, const double* norm2, double eps, double* scratch) = 0;
+    //! v *= 1 / max(sqrt(*norm2), eps);  *nn2 = v . v  (of the scaled vector)
+    virtual void scale_rsqrt_async(size_t n, double* v, const double* norm2, double eps, double* nn2) = 0;
+    //! if sqrt(*norm2) < eps: v *= 1/sqrt(*nn2)
+    virtual void gs_renorm_async(size_t n, double* v, const double* norm2, const double* nn2, double eps) = 0;
     //! sanity_check with t_i read from xi[n]; out2 as in sanity_check
     virtual void sanity_check_async(const CsrDev& A, const double* xi, const double* grad_t, const double* bi,
                                     double eps, size_t n1, const double* x1, double* tmp0, double* tmp1,

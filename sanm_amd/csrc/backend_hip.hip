@@ -353,14 +353,21 @@ __global__ void __launch_bounds__(256) lincomb2_diff_norms_multi_kernel(size_t n
     grid_commit<2 * PROBE_MAX>(r, 2 * a.ncand, 0u, g);
 }
 
-// out[j] = x . ys[j]; x is read once per element
+// out[j] = x . ys[j]; x is read once per element.  The newest vector ys[v.n-1] may still await the second
+// normalisation of an underflowed Gram-Schmidt direction (last_norm2 != null and sqrt(*last_norm2) < eps):
+// every element is read here anyway, so it is rescaled in place on the way.
 __global__ void __launch_bounds__(256) multi_dot_kernel(size_t n, const double* __restrict__ x, VecList v,
-                                                        GridRed g) {
+                                                        const double* last_norm2, const double* last_nn2,
+                                                        double eps, GridRed g) {
     double acc[MAX_VEC];
     for (int j = 0; j < MAX_VEC; ++j) acc[j] = 0;
+    const bool fix = last_norm2 && v.n > 0 && sqrt(*last_norm2) < eps;
+    const double f = fix ? 1.0 / sqrt(*last_nn2) : 1.0;
+    double* last = fix ? const_cast<double*>(v.p[v.n - 1]) : nullptr;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (size_t)gridDim.x * blockDim.x) {
         double xi = x[i];
+        if (fix) last[i] *= f;
 #pragma unroll
         for (int j = 0; j < MAX_VEC; ++j)
             if (j < v.n) acc[j] += xi * v.p[j][i];
@@ -1017,7 +1024,8 @@ public:
         VecList v{};
         v.n = nvec;
         for (int j = 0; j < nvec; ++j) v.p[j] = ys[j];
-        hipLaunchKernelGGL(multi_dot_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, red());
+        hipLaunchKernelGGL(multi_dot_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v,
+                           (const double*)nullptr, (const double*)nullptr, 0.0, red());
         const double* r = red_result();
         for (int j = 0; j < nvec; ++j) out_host[j] = r[j];
     }
@@ -1064,13 +1072,15 @@ public:
                            m_stream, A, xi, xi + A.n, 0.0, grad_t, bi, eps, n1, x1, red_to(out2));
         HIP_CHECK(hipGetLastError());
     }
-    void multi_dot_async(size_t n, const double* x, int nvec, const double* const* ys, double* out) override {
+    void multi_dot_async(size_t n, const double* x, int nvec, double* const* ys, double* out,
+                         const double* last_norm2, const double* last_nn2, double eps) override {
         if (nvec > MAX_VEC) sanm_throw(SANM_ERR_ASSERT, "multi_dot: too many vectors");
         if (nvec == 0) return;
         VecList v{};
         v.n = nvec;
         for (int j = 0; j < nvec; ++j) v.p[j] = ys[j];
-        hipLaunchKernelGGL(multi_dot_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, red_to(out));
+        hipLaunchKernelGGL(multi_dot_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, last_norm2,
+                           last_nn2, eps, red_to(out));
         HIP_CHECK(hipGetLastError());
     }
     void gs_update_async(size_t n, const double* x, int nvec, const double* const* qs, const double* coefs,
@@ -1083,11 +1093,13 @@ public:
                            red_to(norm2));
         HIP_CHECK(hipGetLastError());
     }
-    void scale_rsqrt_async(size_t n, double* v, const double* norm2, double eps, double* scratch) override {
+    void scale_rsqrt_async(size_t n, double* v, const double* norm2, double eps, double* nn2) override {
         hipLaunchKernelGGL(scale_rsqrt_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, v, norm2, eps,
-                           red_to(scratch));
-        hipLaunchKernelGGL(renorm_scale_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, v, norm2, eps,
-                           scratch);
+                           red_to(nn2));
+        HIP_CHECK(hipGetLastError());
+    }
+    void gs_renorm_async(size_t n, double* v, const double* norm2, const double* nn2, double eps) override {
+        hipLaunchKernelGGL(renorm_scale_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, v, norm2, eps, nn2);
         HIP_CHECK(hipGetLastError());
     }
     bool graph_capture_begin() override {

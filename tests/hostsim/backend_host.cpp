@@ -63,7 +63,9 @@ public:
     double* alloc_host(size_t n) override { return static_cast<double*>(std::malloc(std::max<size_t>(n, 1) * 8)); }
     void free_host(double* p) override { std::free(p); }
     void dot_async(size_t n, const double* x, const double* y, double* out) override { *out = dot(n, x, y); }
-    void multi_dot_async(size_t n, const double* x, int nvec, const double* const* ys, double* out) override {
+    void multi_dot_async(size_t n, const double* x, int nvec, double* const* ys, double* out,
+                         const double* last_norm2, const double* last_nn2, double eps) override {
+        if (last_norm2 && nvec > 0) gs_renorm_async(n, ys[nvec - 1], last_norm2, last_nn2, eps);
         multi_dot(n, x, nvec, ys, out);
     }
     void gs_update_async(size_t n, const double* x, int nvec, const double* const* qs, const double* coefs,
@@ -75,13 +77,15 @@ public:
         }
         *norm2 = dot(n, out, out);
     }
-    void scale_rsqrt_async(size_t n, double* v, const double* norm2, double eps, double*) override {
+    void scale_rsqrt_async(size_t n, double* v, const double* norm2, double eps, double* nn2) override {
         const double s = 1.0 / std::max(std::sqrt(*norm2), eps);
         for (size_t i = 0; i < n; ++i) v[i] *= s;
-        if (std::sqrt(*norm2) < eps) {
-            const double nn = std::sqrt(dot(n, v, v));
-            for (size_t i = 0; i < n; ++i) v[i] *= 1.0 / nn;
-        }
+        *nn2 = dot(n, v, v);
+    }
+    void gs_renorm_async(size_t n, double* v, const double* norm2, const double* nn2, double eps) override {
+        if (std::sqrt(*norm2) >= eps) return;
+        const double s = 1.0 / std::sqrt(*nn2);
+        for (size_t i = 0; i < n; ++i) v[i] *= s;
     }
     void next_coeff_async(size_t n, const double* num, double scale, const double* x, const double* y,
                           double* out, double* t_out) override {
