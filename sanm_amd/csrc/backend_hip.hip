@@ -579,6 +579,10 @@ class HipBackend final : public Backend {
     double* m_pcg_w[4] = {nullptr, nullptr, nullptr, nullptr};
     PcgScalars* m_pcg_sc = nullptr;
     static constexpr int kSolveLdsMax = 150 * 1024;
+    // fronts from this many pivots on are factored with two blocking levels (outer blocks of kOuterPanels
+    // 32-wide panels); SANM_MF_OUTER_MIN_K overrides it (tests force the path on small fronts)
+    static constexpr int kOuterPanels = 4;
+    static constexpr int kOuterMinK = 1024;
     int m_conv_parts = std::getenv("SANM_CONV_PARTS") ? std::atoi(std::getenv("SANM_CONV_PARTS")) : 4;
     int m_conv_split_order = std::getenv("SANM_CONV_SPLIT_ORDER") ? std::atoi(std::getenv("SANM_CONV_SPLIT_ORDER")) : 6;
     PcgScalars* m_pcg_sc_host = nullptr;
@@ -802,6 +806,8 @@ public:
         hipLaunchKernelGGL(scatter_kernel, dim3(nblk(mf.nnzA, 256)), dim3(256), 0, m_stream, mf.nnzA,
                            mf.a_dst, A.val, mf.front_store);
         hipLaunchKernelGGL(aug_identity_kernel, dim3(nblk(mf.n, 256)), dim3(256), 0, m_stream, mf);
+        const char* env_min_k = std::getenv("SANM_MF_OUTER_MIN_K");
+        const int outer_min_k = env_min_k ? std::atoi(env_min_k) : kOuterMinK;
         for (const auto& L : sch.levels) {
             for (size_t r = 0; r < L.ea_rounds.size(); ++r) {
                 int cnt = L.ea_rounds[r].second - L.ea_rounds[r].first;
@@ -811,25 +817,47 @@ public:
                                    m_stream, mf, sch.ea_children + L.ea_rounds[r].first);
             }
             const int nt = (2 * L.max_k + NB - 1) / NB;  // pivot + augmentation block
-            // panel 0's diagonal tile is factored by diag_kernel; every later diagonal
-            // tile by the update kernel of the previous panel (look-ahead)
-            if (L.nr_panel > 0)
-                hipLaunchKernelGGL(diag_kernel, dim3(L.panel_cnt[0]), dim3(256), 0, m_stream, mf,
-                                   L.front_begin, 0);
-            for (int p = 0; p < L.nr_panel; ++p) {
-                const int cnt = L.panel_cnt[p];
-                const int rem = nt - p - 1;
-                if (rem <= 0) continue;
-                hipLaunchKernelGGL(update_kernel, dim3(rem, rem, cnt), dim3(256), 0, m_stream, mf,
-                                   L.front_begin, p);
-            }
-            if (L.nr_panel > 0) {
-                // augmentation tiles of every panel: at most ceil(k / NB) + 1 tiles per panel and side
-                const int atiles = (L.max_k + NB - 1) / NB + 1;
-                hipLaunchKernelGGL(panel_finalize_kernel,
-                                   dim3((atiles + FIN_TILES - 1) / FIN_TILES, 2,
-                                        (L.front_end - L.front_begin) * L.nr_panel),
-                                   dim3(256), 0, m_stream, mf, L.front_begin, L.nr_panel);
+            const int nfront = L.front_end - L.front_begin;
+            // augmentation tiles of a panel: at most ceil(k / NB) + 1 per side
+            const int atiles = (L.max_k + NB - 1) / NB + 1;
+            if (L.max_k < outer_min_k) {
+                // one blocking level.  Panel 0's diagonal tile is factored by diag_kernel; every later
+                // diagonal tile by the update kernel of the previous panel (look-ahead)
+                if (L.nr_panel > 0)
+                    hipLaunchKernelGGL(diag_kernel, dim3(L.panel_cnt[0]), dim3(256), 0, m_stream, mf,
+                                       L.front_begin, 0);
+                for (int p = 0; p < L.nr_panel; ++p) {
+                    const int rem = nt - p - 1;
+                    if (rem <= 0) continue;
+                    hipLaunchKernelGGL(update_kernel, dim3(rem, rem, L.panel_cnt[p]), dim3(256), 0, m_stream, mf,
+                                       L.front_begin, p, nt);
+                }
+                if (L.nr_panel > 0)
+                    hipLaunchKernelGGL(panel_finalize_kernel,
+                                       dim3((atiles + FIN_TILES - 1) / FIN_TILES, 2, nfront * L.nr_panel),
+                                       dim3(256), 0, m_stream, mf, L.front_begin, 0, L.nr_panel, -1);
+            } else {
+                // two blocking levels (mf_kernels.h, update_kernel): outer blocks of kOuterPanels panels
+                for (int p0 = 0; p0 < L.nr_panel; p0 += kOuterPanels) {
+                    const int p1 = std::min(p0 + kOuterPanels, L.nr_panel), cnt0 = L.panel_cnt[p0];
+                    hipLaunchKernelGGL(diag_kernel, dim3(cnt0), dim3(256), 0, m_stream, mf, L.front_begin, p0);
+                    for (int p = p0; p < p1; ++p) {
+                        const int w = p1 - p - 1, rem = nt - p - 1, rem2 = nt - p1;
+                        if (w <= 0 || rem <= 0) continue;
+                        hipLaunchKernelGGL(update_kernel, dim3(w, rem + std::max(rem2, 0), L.panel_cnt[p]),
+                                           dim3(256), 0, m_stream, mf, L.front_begin, p, p1);
+                    }
+                    const int tiles = nt - p1;  // trailing extent beyond the block
+                    // (a smaller front of the level may start its augmentation tiles before p1)
+                    hipLaunchKernelGGL(panel_finalize_kernel,
+                                       dim3((std::max(tiles, atiles) + FIN_TILES - 1) / FIN_TILES, 2,
+                                            cnt0 * (p1 - p0)),
+                                       dim3(256), 0, m_stream, mf, L.front_begin, p0, p1 - p0, p1);
+                    if (tiles <= 0) continue;
+                    const int gt = (tiles * NB + GT - 1) / GT;
+                    hipLaunchKernelGGL(block_gemm_kernel, dim3(gt, gt, cnt0), dim3(256), 0, m_stream, mf,
+                                       L.front_begin, p0, p1);
+                }
             }
             // Schur complement and the boundary blocks of the solve operators: two GEMM passes
             if (L.max_b > 0) {

@@ -149,10 +149,26 @@ __device__ __forceinline__ void trsm_sweep(const double (*S)[SPAD], const double
 // factors it right after updating it, so panels p >= 1 need no separate diagonal launch.
 // (A second stream for the diagonal tile was tried as well: the cross-stream events cost as much as they
 // hid.)
-__global__ void __launch_bounds__(256) update_kernel(MfDev mf, int level_begin, int p) {
+//
+// Two blocking levels (large fronts): with t_end < nt only the tiles of block rows / columns p+1 .. t_end-1
+// are updated now -- the L-shaped region the remaining panels of the current OUTER block need -- and the
+// rest of the trailing matrix waits for one rank-(32 * outer block) update by block_gemm_kernel: rank-32 tile
+// updates move 2 flop per byte and are bandwidth-bound on fronts of thousands of pivots.  The grid is the
+// L shape: blockIdx.x = position inside the outer block, blockIdx.y < rem: the column part (all rows),
+// blockIdx.y >= rem: the row part beyond t_end.  t_end >= nt gives the plain square.
+__global__ void __launch_bounds__(256) update_kernel(MfDev mf, int level_begin, int p, int t_end) {
     const MfFrontDev f = mf.fronts[mf.level_fronts[level_begin + blockIdx.z]];
     const int ld = f.ld, m = 2 * f.k, nt = (m + NB - 1) / NB;
-    const int ti = p + 1 + blockIdx.y, tj = p + 1 + blockIdx.x;
+    const int te = min(t_end, nt), rem = nt - p - 1;
+    if ((int)blockIdx.x >= te - p - 1) return;
+    int ti, tj;
+    if ((int)blockIdx.y < rem) {
+        ti = p + 1 + blockIdx.y;
+        tj = p + 1 + blockIdx.x;
+    } else {
+        ti = p + 1 + blockIdx.x;
+        tj = te + ((int)blockIdx.y - rem);
+    }
     if (ti >= nt || tj >= nt) return;
     // the (augmentation x augmentation) corner is never used
     if (ti * NB >= f.k && tj * NB >= f.k) return;
@@ -221,12 +237,18 @@ __global__ void __launch_bounds__(256) update_kernel(MfDev mf, int level_begin, 
 // (p, t) and L panel tiles (t, p) with t in the augmentation block (they become L11^-1 resp. U11^-1).  All
 // (front, panel, tile) triples are independent: one launch, 8 tiles per workgroup, one lane per column / row.
 constexpr int FIN_TILES = 8;
-__global__ void __launch_bounds__(256) panel_finalize_kernel(MfDev mf, int level_begin, int nr_panel) {
+// (Two blocking levels: called per outer block [p_begin, p_begin + nr_panel) with t_min = its end: the tiles
+// from t_min on are exactly what block_gemm_kernel multiplies, and they include the augmentation tiles.)
+__global__ void __launch_bounds__(256) panel_finalize_kernel(MfDev mf, int level_begin, int p_begin, int nr_panel,
+                                                             int t_min) {
     const MfFrontDev f = mf.fronts[mf.level_fronts[level_begin + blockIdx.z / nr_panel]];
-    const int p = blockIdx.z % nr_panel;
+    const int p = p_begin + blockIdx.z % nr_panel;
     if (p * NB >= f.k) return;
     const int ld = f.ld, m = 2 * f.k, nt = (m + NB - 1) / NB;
-    const int t0 = max(p + 1, f.k / NB);  // first tile with augmentation columns / rows
+    // first tile to solve: the first one with augmentation columns / rows (they hold results), or t_min
+    // if that comes earlier (the tiles block_gemm_kernel multiplies)
+    const int ta = f.k / NB;
+    const int t0 = max(p + 1, t_min >= 0 ? min(t_min, ta) : ta);
     if (t0 + (int)blockIdx.x * FIN_TILES >= nt) return;
     const bool upanel = blockIdx.y == 0;
     const int kb = min(NB, f.k - p * NB);
@@ -444,6 +466,30 @@ __global__ void __launch_bounds__(256) gemm2_kernel(MfDev mf, int level_begin) {
             double* dst = C + (int64_t)r * ld + c;
             *dst = (which == 0) ? *dst - v : -v;
         }
+    });
+}
+
+// Two blocking levels: after the panels [p0, p1) of an outer block the trailing matrix beyond it,
+//   F[r, c] -= sum_{q in pivots of the block} L[r, q] U[q, c],   r, c >= p1 * NB,
+// as one rank-(p1 - p0) * NB product of the solved panel tiles (panel_finalize_kernel) on the matrix cores.
+// Tiles inside the (augmentation x augmentation) corner are never used and skipped.
+__global__ void __launch_bounds__(256) block_gemm_kernel(MfDev mf, int level_begin, int p0, int p1) {
+    const MfFrontDev f = mf.fronts[mf.level_fronts[level_begin + blockIdx.z]];
+    const int k = f.k, ld = f.ld, m = 2 * k, r0 = p1 * NB;
+    if (p0 * NB >= k || r0 >= m) return;
+    const int ti = blockIdx.y, tj = blockIdx.x, ext = m - r0;
+    if (ti * GT >= ext || tj * GT >= ext) return;
+    if (r0 + ti * GT >= k && r0 + tj * GT >= k) return;
+    __shared__ double As[GK][GT + 1], Bs[GK][GT + 4];
+    double* F = mf.front_store + f.off;
+    const MatView A{F + (int64_t)r0 * ld, ld, ext, m};  // rows r0.., K = absolute column
+    const MatView B{F + r0, ld, m, ext};                 // K = absolute row, columns r0..
+    mfma_f64x4 acc[2][2];
+    gemm_tile(A, B, ti, tj, p0 * NB, min(p1 * NB, k), As, Bs, acc);
+    double* C = F + (int64_t)r0 * ld + r0;
+    gemm_tile_foreach(acc, [&](int i, int j, double v) {
+        const int r = ti * GT + i, c = tj * GT + j;
+        if (r < ext && c < ext) C[(int64_t)r * ld + c] -= v;
     });
 }
 

@@ -110,3 +110,16 @@ def test_grid3d_wide_separators(api):
     ds = _check(api, A, coords=coords, nrhs=2)
     st = ds.stats()
     assert st["max_front"] >= 200 and st["nr_level"] >= 4
+
+
+@pytest.mark.parametrize("min_k", ["32", "96"])
+def test_two_level_blocking_forced(api, monkeypatch, min_k):
+    """fronts of 1000+ pivots are factored with two blocking levels (outer blocks of 4 panels, the rest of
+    the trailing matrix updated by one MFMA GEMM per outer block); SANM_MF_OUTER_MIN_K forces that path on
+    the fronts of the small test systems, partial panels and fronts narrower than an outer block included.
+    (The host test harness has its own serial factorisation and ignores the switch.)"""
+    monkeypatch.setenv("SANM_MF_OUTER_MIN_K", min_k)
+    test_grid3d_wide_separators(api)
+    test_random_block_unsymmetric(api)
+    test_scalar_pattern_no_blocks(api)
+    test_tiny_and_diagonal(api)
