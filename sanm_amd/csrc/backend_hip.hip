@@ -579,10 +579,10 @@ class HipBackend final : public Backend {
     double* m_pcg_w[4] = {nullptr, nullptr, nullptr, nullptr};
     PcgScalars* m_pcg_sc = nullptr;
     static constexpr int kSolveLdsMax = 150 * 1024;
-    // fronts from this many pivots on are factored with two blocking levels (outer blocks of kOuterPanels
+    // fronts from this many pivots on are factored with two blocking levels (measured: pays from ~400) (outer blocks of kOuterPanels
     // 32-wide panels); SANM_MF_OUTER_MIN_K overrides it (tests force the path on small fronts)
     static constexpr int kOuterPanels = 4;
-    static constexpr int kOuterMinK = 1024;
+    static constexpr int kOuterMinK = 512;
     int m_conv_parts = std::getenv("SANM_CONV_PARTS") ? std::atoi(std::getenv("SANM_CONV_PARTS")) : 4;
     int m_conv_split_order = std::getenv("SANM_CONV_SPLIT_ORDER") ? std::atoi(std::getenv("SANM_CONV_SPLIT_ORDER")) : 6;
     PcgScalars* m_pcg_sc_host = nullptr;

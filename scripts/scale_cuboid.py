@@ -7,7 +7,7 @@ import time
 
 import torch  # noqa: F401  (before the HIP library)
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import sanm_amd
 from sanm_amd import fea
 

@@ -1,7 +1,7 @@
 """Per-(mode, order) steady-state time of the Taylor pass kernel: python scripts/time_passes.py [workload]"""
 import sys
 import torch  # noqa: F401  (before the HIP library)
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import sanm_amd
 from sanm_amd import fea
 
