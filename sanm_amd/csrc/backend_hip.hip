@@ -1,17 +1,21 @@
-// HIP backend: the product execution path (gfx950 / MI355X).
+// HIP backend: the product execution path (gfx950 / MI355X).  One in-order stream; DESIGN.md has the
+// measurements behind every choice below.
 //
-// Kernels here are HBM/L2-bandwidth bound fp64 streaming kernels (no dense
-// contraction, MFMA unused):
-//  * taylor_pass_kernel   one lane per tet, SoA state => every load/store of
-//                         a wavefront is one contiguous 512-byte segment;
-//                         64-thread workgroups so that even the small meshes
-//                         (42k tets = 661 wavefronts) spread over all 256 CUs.
-//  * gather_rows_kernel   remap_out: one lane per unknown, ~45 gathered
-//                         entries from a 9*Tpad*8-byte (L2 resident) tensor.
-//  * assemble_kernel      one lane per CSR non-zero over a fixed gather list.
-//  * spmv_kernel          CSR, 8 lanes per row + DPP-free shuffle reduction.
-//  * BLAS-1               grid-stride, wavefront shuffle + LDS block reduce,
-//                         one double atomic per block.
+//  * taylor_pass_kernel<MODE, W>  the graph interpreter, one lane per tet on SoA state (every load / store of a
+//                         wavefront is one contiguous 512-byte segment); one instantiation per pass; BIAS passes
+//                         of higher orders run 4 wavefronts per 64 tets (convolution split, tet_ops.h); the GRAD
+//                         pass one (tet, Jacobian row) pair per lane.
+//  * gather_rows_kernel   remap_out: 16 lanes per unknown, ~45 gathered entries, two index -> value chains in
+//                         flight per lane.
+//  * assemble_kernel      8 lanes per CSR non-zero over a fixed gather list (incl. the 1e-9 drop rule).
+//  * sanity_check_kernel  the per-order check A x_i = -(t_i g_t + b_i) and x_1 . x_i fused with its reductions.
+//  * reductions           grid_commit: per-workgroup partials written through, agent-scope ticket, the last
+//                         workgroup combines them in a fixed order and writes to pinned host memory (or to device
+//                         memory for the kernels of the order loop / Pade sweep that consume scalars on the device).
+//  * mf_factor / mf_solve the multifrontal LU (mf_kernels.h): one launch per 32-wide panel (panel solves, tile
+//                         update and look-ahead tile LU), fp64-MFMA GEMMs for the boundary blocks and for the
+//                         second blocking level of large fronts; solves = one mat-vec launch per level and direction.
+//  * graphs               the Pade basis sweep is captured once and replayed (graph_capture_*).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
