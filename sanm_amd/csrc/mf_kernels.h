@@ -7,8 +7,11 @@
 //
 // Front layout (mf_types.h): rows / columns ordered [P pivot k | A augmentation k |
 // B boundary b], leading dimension ld = 2k + b.  Per level:
-//   1. panel loop on the leading 2k x 2k block (diag / trsm / update kernels):
-//      LU of F[P,P] with the identity blocks turning into L11^-1 and U11^-1;
+//   1. panel loop on the leading 2k x 2k block: diag_kernel for the first diagonal tile, then one
+//      update_kernel launch per 32-wide panel (panel solves by substitution, tile update, look-ahead LU
+//      of the next diagonal tile) and panel_finalize_kernel for the result tiles; fronts of 500+ pivots
+//      defer most of the trailing matrix to block_gemm_kernel (second blocking level).  This is the LU
+//      of F[P,P] with the identity blocks turning into L11^-1 and U11^-1;
 //   2. gemm1_kernel:  tmpU = L11^-1 F[P,B],  tmpL = F[B,P] U11^-1          (K = k)
 //   3. gemm2_kernel:  F[B,B] -= tmpL tmpU,  F[B,A] = -tmpL L11^-1,  F[A,B] = -U11^-1 tmpU
 // so the Schur complement is read and written once instead of once per panel.

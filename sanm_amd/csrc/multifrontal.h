@@ -8,16 +8,18 @@
 //
 // Method (classic multifrontal, structurally symmetric pattern, no pivoting):
 //   * indistinguishable rows are merged into supervariables (the 3 dofs of a
-//     vertex), the compressed graph is ordered by nested dissection --
-//     principal-axis median cuts when coordinates of the unknowns are known,
-//     two-source graph-distance cuts otherwise;
+//     vertex), the compressed graph is ordered by nested dissection: cuts
+//     along the principal directions of the unknowns' coordinates when they
+//     are known (a two-source graph-distance key otherwise), the separator a
+//     minimum vertex cover of the cut edges refined by Fiduccia-Mattheyses
+//     passes (multifrontal.cpp: NestedDissection::bisect);
 //   * every dissection-tree node is a front: a dense m x m matrix whose first
 //     k rows/cols are its own (pivot) variables and the rest its boundary in
 //     the ancestors.  Fronts of equal height are independent and are
 //     processed by the same kernel launches;
 //   * factor: scatter A, extend-add the children's Schur complements, blocked
-//     right-looking LU of the leading k columns (NB x NB diagonal blocks are
-//     inverted so panel solves become small GEMMs).  Each front carries k
+//     right-looking LU of the leading k columns (32-wide panels, one launch
+//     each; large fronts with a second blocking level).  Each front carries k
 //     extra identity columns and rows; the same row/column operations turn
 //     them into L11^-1, -L21 L11^-1, U11^-1 and -U11^-1 U12;
 //   * solve: with those blocks every level of the forward (resp. backward)
