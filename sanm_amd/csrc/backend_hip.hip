@@ -901,6 +901,23 @@ public:
                            L.front_begin);
     }
     void level_solve(bool fwd, const MfDev& mf, const MfSchedule::Level& L) {
+        using namespace mfk;
+        const char* env_lds = std::getenv("SANM_MF_LDS_MAX");  // tests force the large-front path
+        const size_t lds_max = env_lds ? (size_t)std::atol(env_lds) : (size_t)kSolveLdsMax;
+        if ((size_t)(fwd ? L.max_k : L.max_m) * sizeof(double) > lds_max) {
+            // vectors beyond the LDS: plain mat-vec kernels on operands in HBM (bandwidth-bound levels)
+            const int cnt = L.front_end - L.front_begin;
+            if (fwd) {
+                hipLaunchKernelGGL(fwd_prep_kernel, dim3((L.max_k + 255) / 256, cnt), dim3(256), 0, m_stream, mf,
+                                   L.front_begin);
+                hipLaunchKernelGGL(fwd_big_kernel, dim3((L.max_m + 3) / 4, cnt), dim3(256), 0, m_stream, mf,
+                                   L.front_begin);
+            } else {
+                hipLaunchKernelGGL(bwd_big_kernel, dim3((L.max_k + 3) / 4, cnt), dim3(256), 0, m_stream, mf,
+                                   L.front_begin);
+            }
+            return;
+        }
         const int width = fwd ? L.max_k : L.max_m;  // longest row
         const int64_t rows = fwd ? L.sum_m : L.sum_k;
         int u = 1;

@@ -682,5 +682,66 @@ __global__ void __launch_bounds__(256) bwd_level_kernel(MfDev mf, int level_begi
     }
 }
 
+// ---- level kernels for fronts whose vectors do not fit the LDS (tens of thousands of rows) ---------
+// Such levels are bandwidth-bound, not latency-bound: plain wave-per-row mat-vecs on operands in HBM, with a
+// small pre-pass that folds the children's inbox slots into the front's own part of the work vector.
+__global__ void __launch_bounds__(256) fwd_prep_kernel(MfDev mf, int level_begin) {
+    const MfFrontDev f = mf.lfronts[level_begin + blockIdx.y];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= f.k) return;
+    double v = mf.work[f.own_start + c];
+    for (int j = 0; j < f.nch; ++j) v += mf.inbox_store[f.inbox_off + (int64_t)j * f.m + c];
+    mf.work[f.own_start + c] = v;
+}
+__device__ __forceinline__ double wave_dot_global(const double* __restrict__ row, const double* __restrict__ v,
+                                                  int cbeg, int cend, int lane) {
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int c = cbeg + lane;
+    for (; c + 192 < cend; c += 256) {
+        a0 += row[c] * v[c];
+        a1 += row[c + 64] * v[c + 64];
+        a2 += row[c + 128] * v[c + 128];
+        a3 += row[c + 192] * v[c + 192];
+    }
+    for (; c < cend; c += 64) a0 += row[c] * v[c];
+    return wave_sum((a0 + a1) + (a2 + a3));
+}
+__global__ void __launch_bounds__(256) fwd_big_kernel(MfDev mf, int level_begin) {
+    const MfFrontDev f = mf.lfronts[level_begin + blockIdx.y];
+    const int m = f.m, k = f.k, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= m) return;
+    const int pr = r < k ? r : r + k;
+    const double* row = mf.front_store + f.off + (int64_t)pr * f.ld + k;
+    double acc = wave_dot_global(row, mf.work + f.own_start, 0, r < k ? r + 1 : k, lane);
+    if (lane == 0) {
+        if (r < k) {
+            mf.work2[f.own_start + r] = acc;
+        } else {
+            for (int j = 0; j < f.nch; ++j) acc += mf.inbox_store[f.inbox_off + (int64_t)j * m + r];
+            mf.inbox_store[mf.upd_dst[f.bnd_off + r - k]] = acc;
+        }
+    }
+}
+__global__ void __launch_bounds__(256) bwd_big_kernel(MfDev mf, int level_begin) {
+    const MfFrontDev f = mf.lfronts[level_begin + blockIdx.y];
+    const int m = f.m, k = f.k, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= k) return;
+    const double* row = mf.front_store + f.off + (int64_t)(k + r) * f.ld;
+    double acc = wave_dot_global(row, mf.work2 + f.own_start, r, k, lane);
+    const double* rowb = row + 2 * k;
+    const int32_t* bi = mf.bnd_idx + f.bnd_off;
+    double a0 = 0, a1 = 0;
+    int c = lane;
+    for (; c + 64 < m - k; c += 128) {
+        a0 += rowb[c] * mf.work[bi[c]];
+        a1 += rowb[c + 64] * mf.work[bi[c + 64]];
+    }
+    if (c < m - k) a0 += rowb[c] * mf.work[bi[c]];
+    acc += wave_sum(a0 + a1);
+    if (lane == 0) mf.work[f.own_start + r] = acc;
+}
+
 }  // namespace mfk
 }  // namespace sanm_hip

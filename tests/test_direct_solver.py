@@ -123,3 +123,12 @@ def test_two_level_blocking_forced(api, monkeypatch, min_k):
     test_random_block_unsymmetric(api)
     test_scalar_pattern_no_blocks(api)
     test_tiny_and_diagonal(api)
+
+
+def test_solve_kernels_for_vectors_beyond_lds(api, monkeypatch):
+    """fronts whose solve vectors do not fit the LDS (20,000+ rows, million-tet meshes) take plain mat-vec level
+    kernels; SANM_MF_LDS_MAX forces them on the small test systems.  (Ignored by the host test harness.)"""
+    monkeypatch.setenv("SANM_MF_LDS_MAX", "64")
+    test_grid3d_wide_separators(api)
+    test_random_block_unsymmetric(api)
+    test_tiny_and_diagonal(api)
