@@ -54,7 +54,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             if verbose and err:
                 print(err)
     if jobs or not os.path.exists(OUT):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", OUT] + objs)
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-Wl,-Bsymbolic", "-o", OUT] + objs)
     return OUT
 
 

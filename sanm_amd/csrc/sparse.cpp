@@ -3,6 +3,8 @@
 #include <algorithm>
 #include <cstring>
 #include <limits>
+#include <string>
+#include <thread>
 
 namespace sanm_hip {
 
@@ -78,60 +80,133 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
     sanm_check(ri.in_size == n || ri.in_size == n + 1, "remap_in must take n or n+1 inputs");
     m_has_t = ri.in_size == n + 1;
 
+    // Row i of remap_out . blockdiag(J_e) . remap_in: every (output entry, Jacobian entry, input entry)
+    // triple is one contribution to CSR entry (i, col); contributions of one entry keep the order in which
+    // the triples are enumerated (that fixes the summation order of the assembly kernel).  ~1500
+    // contributions per row and n rows: the rows are independent, so they are built by several host threads
+    // (this is the largest part of the setup of a large mesh) and grouped by a stable counting sort over the
+    // ~100 distinct columns of a row instead of a comparison sort.
     struct Contrib {
         uint32_t col, jidx;
         double coef;
         bool mine;  // the tet belongs to this rank's shard
     };
-    std::vector<Contrib> row;
+    struct Part {
+        std::vector<uint32_t> row_nnz, col, acnt, ajidx, tcnt, tjidx;  // acnt: contributions per CSR entry
+        std::vector<double> acoef, tcoef;
+        std::string error;
+    };
+    const int nthread = (int)std::max<int64_t>(
+            1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 16, n / 4096 + 1}));
+    std::vector<Part> parts(nthread);
+    auto build = [&](int t) {
+        Part& P = parts[t];
+        const int64_t r0 = n * t / nthread, r1 = n * (t + 1) / nthread;
+        std::vector<Contrib> row, sorted;
+        std::vector<uint32_t> ucol, rank, start;
+        try {
+            for (int64_t i = r0; i < r1; ++i) {
+                row.clear();
+                for (uint64_t p = ro.rowptr[i]; p < ro.rowptr[i + 1]; ++p) {
+                    uint64_t b = ro.idx[p] / odim, o = ro.idx[p] % odim;
+                    double c_out = ro.coef[p];
+                    for (int m = 0; m < idim; ++m) {
+                        uint64_t irow = b * idim + m;
+                        const bool mine = (int64_t)b >= tet_begin && (int64_t)b < tet_end;
+                        uint64_t jidx = mine ? ((uint64_t)o * idim + m) * Tpad + (b - tet_begin) : 0;
+                        sanm_check(jidx < std::numeric_limits<uint32_t>::max(), "mesh too large for u32 jidx");
+                        for (uint64_t q = ri.rowptr[irow]; q < ri.rowptr[irow + 1]; ++q)
+                            row.push_back({(uint32_t)ri.idx[q], (uint32_t)jidx, c_out * ri.coef[q], mine});
+                    }
+                }
+                // distinct columns, ascending; stable counting sort of the contributions by column
+                ucol.clear();
+                for (const Contrib& c : row) ucol.push_back(c.col);
+                std::sort(ucol.begin(), ucol.end());
+                ucol.erase(std::unique(ucol.begin(), ucol.end()), ucol.end());
+                rank.resize(row.size());
+                start.assign(ucol.size() + 1, 0);
+                for (size_t k = 0; k < row.size(); ++k) {
+                    rank[k] = std::lower_bound(ucol.begin(), ucol.end(), row[k].col) - ucol.begin();
+                    start[rank[k] + 1]++;
+                }
+                for (size_t u = 0; u < ucol.size(); ++u) start[u + 1] += start[u];
+                sorted.resize(row.size());
+                {
+                    std::vector<uint32_t>& fill = rank;  // reuse: position counters per column
+                    std::vector<uint32_t> pos(start.begin(), start.end() - 1);
+                    for (size_t k = 0; k < row.size(); ++k) sorted[pos[fill[k]]++] = row[k];
+                }
+                uint32_t nnz_row = 0, tcount = 0;
+                for (size_t u = 0; u < ucol.size(); ++u) {
+                    const uint32_t c = ucol[u];
+                    if ((int64_t)c == n) {  // the t column -> grad_t
+                        for (uint32_t k = start[u]; k < start[u + 1]; ++k) {
+                            if (!sorted[k].mine) continue;
+                            P.tjidx.push_back(sorted[k].jidx);
+                            P.tcoef.push_back(sorted[k].coef);
+                            ++tcount;
+                        }
+                        continue;
+                    }
+                    P.col.push_back(c);
+                    ++nnz_row;
+                    uint32_t cnt = 0;
+                    for (uint32_t k = start[u]; k < start[u + 1]; ++k) {
+                        if (!sorted[k].mine) continue;
+                        P.ajidx.push_back(sorted[k].jidx);
+                        P.acoef.push_back(sorted[k].coef);
+                        ++cnt;
+                    }
+                    P.acnt.push_back(cnt);
+                }
+                sanm_check(nnz_row > 0, "empty row %ld", (long)i);  // sparse_solver.cpp:251-252
+                P.row_nnz.push_back(nnz_row);
+                P.tcnt.push_back(tcount);
+            }
+        } catch (const SanmError& e) {
+            P.error = e.msg;
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nthread; ++t) th.emplace_back(build, t);
+        build(0);
+        for (auto& x : th) x.join();
+    }
+    for (const Part& P : parts) sanm_check(P.error.empty(), "%s", P.error.c_str());
     std::vector<uint32_t> rowptr(n + 1, 0), col;
     std::vector<uint32_t> aptr{0}, ajidx;
     std::vector<double> acoef;
     std::vector<uint32_t> tptr(n + 1, 0), tjidx;
     std::vector<double> tcoef;
-
-    for (int64_t i = 0; i < n; ++i) {
-        row.clear();
-        for (uint64_t p = ro.rowptr[i]; p < ro.rowptr[i + 1]; ++p) {
-            uint64_t b = ro.idx[p] / odim, o = ro.idx[p] % odim;
-            double c_out = ro.coef[p];
-            for (int m = 0; m < idim; ++m) {
-                uint64_t irow = b * idim + m;
-                const bool mine = (int64_t)b >= tet_begin && (int64_t)b < tet_end;
-                uint64_t jidx = mine ? ((uint64_t)o * idim + m) * Tpad + (b - tet_begin) : 0;
-                sanm_check(jidx < std::numeric_limits<uint32_t>::max(), "mesh too large for u32 jidx");
-                for (uint64_t q = ri.rowptr[irow]; q < ri.rowptr[irow + 1]; ++q) {
-                    row.push_back({(uint32_t)ri.idx[q], (uint32_t)jidx, c_out * ri.coef[q], mine});
-                }
-            }
+    {
+        size_t ncol = 0, ncon = 0, nt = 0;
+        for (const Part& P : parts) {
+            ncol += P.col.size();
+            ncon += P.ajidx.size();
+            nt += P.tjidx.size();
         }
-        std::stable_sort(row.begin(), row.end(),
-                         [](const Contrib& a, const Contrib& b) { return a.col < b.col; });
-        size_t k = 0;
-        bool any = false;
-        while (k < row.size()) {
-            uint32_t c = row[k].col;
-            if ((int64_t)c == n) {  // the t column -> grad_t
-                for (; k < row.size() && row[k].col == c; ++k) {
-                    if (!row[k].mine) continue;
-                    tjidx.push_back(row[k].jidx);
-                    tcoef.push_back(row[k].coef);
-                }
-                continue;
+        sanm_check(ncon < std::numeric_limits<uint32_t>::max(), "assembly list too large");
+        col.reserve(ncol);
+        aptr.reserve(ncol + 1);
+        ajidx.reserve(ncon);
+        acoef.reserve(ncon);
+        tjidx.reserve(nt);
+        tcoef.reserve(nt);
+        int64_t i = 0;
+        for (const Part& P : parts) {
+            for (size_t r = 0; r < P.row_nnz.size(); ++r, ++i) {
+                rowptr[i + 1] = rowptr[i] + P.row_nnz[r];
+                tptr[i + 1] = tptr[i] + P.tcnt[r];
             }
-            col.push_back(c);
-            any = true;
-            for (; k < row.size() && row[k].col == c; ++k) {
-                if (!row[k].mine) continue;
-                ajidx.push_back(row[k].jidx);
-                acoef.push_back(row[k].coef);
-            }
-            sanm_check(ajidx.size() < std::numeric_limits<uint32_t>::max(), "assembly list too large");
-            aptr.push_back(ajidx.size());
+            col.insert(col.end(), P.col.begin(), P.col.end());
+            for (uint32_t c : P.acnt) aptr.push_back(aptr.back() + c);
+            ajidx.insert(ajidx.end(), P.ajidx.begin(), P.ajidx.end());
+            acoef.insert(acoef.end(), P.acoef.begin(), P.acoef.end());
+            tjidx.insert(tjidx.end(), P.tjidx.begin(), P.tjidx.end());
+            tcoef.insert(tcoef.end(), P.tcoef.begin(), P.tcoef.end());
         }
-        sanm_check(any, "empty row %ld", (long)i);  // sparse_solver.cpp:251-252
-        rowptr[i + 1] = col.size();
-        tptr[i + 1] = tjidx.size();
     }
     m_nr_contrib = ajidx.size();
     m_h_rowptr = rowptr;
