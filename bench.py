@@ -86,8 +86,17 @@ def device_sync():
 
 
 def load_workload(name):
-    """A named BASELINE config, or 'cuboid:nx,ny,nz' (test-sized synthetic cantilever)."""
+    """A named BASELINE config, 'cuboid:nx,ny,nz' (test-sized synthetic cantilever) or 'block:N' (the
+    armadillo material / load / boundary rule on an N^3-vertex block of 5 (N-1)^3 tets: the scaling stand-in
+    SURVEY 8d names for the missing full Armadillo mesh; block:60 = 1.03 M tets)."""
     from sanm_amd import fea as dfea
+    if name.startswith("block:"):
+        nx = int(name.split(":")[1])
+        cfg, _ = dfea.load_named_config("armadillo_small")
+        cfg = dict(cfg)
+        cfg.pop("scale", None)
+        cfg["material"] = dict(cfg["material"], young=2.0e4)  # soft enough to need several steps
+        return cfg, dfea.make_cuboid(nx, nx, nx, 0.2 / nx)
     if name.startswith("cuboid:"):
         nx, ny, nz = (int(v) for v in name.split(":")[1].split(","))
         cfg = {"material": {"young": 3e3, "poisson": 0.45, "density": 1000.0}, "g": [0, -9.81, 0],
@@ -215,7 +224,9 @@ def main(argv=None):
             "dtype": "f64",
             "data": ("real mesh Armadillo-small.1 (stand-in for the missing Armadillo.1), rest state"
                      if args.workload == "armadillo_small" else f"workload {args.workload}, rest state"),
-            "config": {"workload": f"config/{args.workload}.json: {cfg['energy_model']}, order "
+            "config": {"workload": (f"config/{args.workload}.json" if ":" not in args.workload
+                                    else f"synthetic {args.workload} (armadillo material, load and boundary rule)")
+                                   + f": {cfg['energy_model']}, order "
                                    f"{N}, T={T}, n={n}, nnz={nnz}, pade on, sanity check on",
                        "parallelism": ("tet-shard + all-reduce(b_k)/order" if shard else "replicas") if world > 1 else "single",
                        "linear_solver": "jacobi-pcg" if args.solver_kind == 0 else "multifrontal-lu",
@@ -230,7 +241,7 @@ def main(argv=None):
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "algorithmic_bytes_per_step": bytes_step},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not args.workload.startswith("block:"):
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_steps)
         print(json.dumps(out), flush=True)
     if dist is not None:
