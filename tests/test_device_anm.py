@@ -175,3 +175,22 @@ def test_tet_renumbering_is_transparent(api, monkeypatch):
     # the Jacobian handed out in CSR form lives in the space of the unknowns as well
     J, Jr = run.solver.jacobian_csr(), ref.solver.jacobian_csr()
     assert np.array_equal(J.indices, Jr.indices) and np.allclose(J.data, Jr.data, rtol=1e-9, atol=1e-9)
+
+
+def test_jacobian_of_a_mesh_built_by_several_host_threads(api):
+    """the Jacobian pattern / gather lists of more than 4096 unknowns are built by several host threads and
+    merged; the assembled matrix must still be the oracle's, entry by entry."""
+    cfg = {"material": {"young": 3e4, "poisson": 0.45, "density": 900.0}, "g": [0, -9.81, 0],
+           "boundary_thresh": 0.05, "boundary_proj_dir": [-1, 0, 0], "energy_model": "neohookean_c", "order": 6}
+    dims, sp = (13, 13, 13), 0.01
+    omesh = ofea.make_cuboid(*dims, sp)
+    omodel, osolver, _ = ofea.make_gravity_solver(omesh, cfg)
+    assert omodel.lt_inp.n > 4096  # two builder threads
+    run = dfea.GravityRun(api, dfea.make_cuboid(*dims, sp), dict(cfg)).construct()
+    prop = S.TaylorCoeffProp(omodel.y)
+    prop.push_xi([(omodel.lt_inp.mat @ omodel.lt_inp.x0).reshape(-1, 3, 3)])
+    Ao, _ = build_jacobian_csr(omodel.lt_out, prop.get_jacobian(), omodel.lt_inp.mat, omodel.lt_inp.n)
+    Ad = run.solver.jacobian_csr()
+    assert Ad.shape == Ao.shape and abs(Ad - Ao).max() <= 1e-10 * abs(Ao).max()
+    assert run.solver.get_nr_iter() == osolver.get_nr_iter() == 1
+    assert run.rms[-1] == pytest.approx(osolver.residual_rms, rel=1e-6, abs=1e-14)
