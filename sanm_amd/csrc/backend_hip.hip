@@ -51,8 +51,15 @@ namespace {
 // (register pressure decides how many wavefronts fit a SIMD); W = wavefronts per SIMD the
 // register allocation must leave room for.
 template <int MODE, int W>
-__global__ void __launch_bounds__(256, W) taylor_pass_kernel(ProgramDev P, int order,
+__global__ void __launch_bounds__(256, W) taylor_pass_kernel(ProgramDev P0, const OpDesc* __restrict__ ops,
+                                                             const VarDesc* __restrict__ vars, int order,
                                                              const double* __restrict__ xvec) {
+    // the operator / variable records arrive as separate read-only parameters: known not to alias the arena
+    // stores, their (wave-uniform) loads go through the scalar cache instead of three dependent vector-memory
+    // round trips per operator
+    ProgramDev P = P0;
+    P.ops = ops;
+    P.vars = vars;
     extern __shared__ double cur_lds[];
     const int lane = threadIdx.x & 63;
     // wave-uniform by construction; tell the compiler so that the slice bounds stay scalar
@@ -691,7 +698,7 @@ public:
         int nparts = (mode == PASS_BIAS && order >= m_conv_split_order) ? m_conv_parts : 1;
         const size_t lds = (size_t)(P.cur_size + (nparts - 1) * 9) * 64 * sizeof(double);
         if (lds > 160 * 1024) sanm_throw(SANM_ERR_UNSUPPORTED, "graph too large for the LDS scratch");
-        void (*kern)(ProgramDev, int, const double*) = nullptr;
+        void (*kern)(ProgramDev, const OpDesc*, const VarDesc*, int, const double*) = nullptr;
         switch (mode) {
             case PASS_EVAL0: kern = taylor_pass_kernel<PASS_EVAL0, 1>; break;
             case PASS_GRAD: kern = taylor_pass_kernel<PASS_GRAD, 1>; break;
@@ -705,7 +712,7 @@ public:
             m_pass_lds_limit[mode] = lds;
         }
         hipLaunchKernelGGL(kern, dim3(nblk(P.T, 64), mode == PASS_GRAD ? P.odim : 1), dim3(64 * nparts), lds,
-                           m_stream, P, order, xvec);
+                           m_stream, P, P.ops, P.vars, order, xvec);
         HIP_CHECK(hipGetLastError());
         if (m_time_passes) {
             HIP_CHECK(hipEventRecord(e1, m_stream));
