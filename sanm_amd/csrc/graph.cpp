@@ -387,9 +387,14 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
     // device buffers
     double* arena = static_cast<double*>(be->alloc(off * sizeof(double)));
     be->zero(arena, off * sizeof(double));
-    m_d_ops = be->alloc(m_ops.size() * sizeof(OpDesc));
+    // operator and variable records share one block, padded to whole groups of 8 cache lines: the pass kernel
+    // pulls the block into the scalar cache with one batch of loads before it walks the operators
+    const size_t ops_bytes = (m_ops.size() * sizeof(OpDesc) + 63) / 64 * 64;
+    const size_t desc_bytes = (ops_bytes + m_vars.size() * sizeof(VarDesc) + 511) / 512 * 512;
+    m_d_ops = be->alloc(desc_bytes);
+    be->zero(m_d_ops, desc_bytes);
+    m_d_vars = static_cast<char*>(m_d_ops) + ops_bytes;
     be->h2d(m_d_ops, m_ops.data(), m_ops.size() * sizeof(OpDesc));
-    m_d_vars = be->alloc(m_vars.size() * sizeof(VarDesc));
     be->h2d(m_d_vars, m_vars.data(), m_vars.size() * sizeof(VarDesc));
 
     // constants: AoS (T,size) or (1,size) -> SoA coefficient 0
@@ -415,6 +420,7 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
     m_dev.vars = static_cast<const VarDesc*>(m_d_vars);
     m_dev.arena = arena;
     m_dev.nops = m_ops.size();
+    m_dev.desc_lines = desc_bytes / 64;
     m_dev.out_var = lout;
     m_dev.odim = odim;
     m_dev.max_order = N;
@@ -426,8 +432,7 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
 
 Program::~Program() {
     m_be->free(m_dev.arena);
-    m_be->free(m_d_ops);
-    m_be->free(m_d_vars);
+    m_be->free(m_d_ops);  // the variable records live in the same block
     if (m_d_rin_idx) m_be->free(m_d_rin_idx);
     if (m_d_rin_coef) m_be->free(m_d_rin_coef);
 }

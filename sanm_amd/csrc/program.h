@@ -79,6 +79,7 @@ struct ProgramDev {
     int32_t odim;      // size of the output var (9)
     int32_t max_order;
     int32_t cur_size;  // doubles of per-lane scratch (sum of the sizes of the non-constant vars)
+    int32_t desc_lines;  // 64-byte lines of the block holding ops and vars (a multiple of 8)
     int64_t T, Tpad;
     RemapInDev rin;
 };

@@ -340,9 +340,13 @@ SANM_HD double jget(const TetCtx& c, int v, int, int ci) {
 }
 
 // ---- LINCOMB: elem_arith.cpp:42-124
-SANM_HD void op_lincomb(const TetCtx& c, const OpDesc& o, int mode) {
+// (The element loops of the elementwise operators must have compile-time bounds: with a run-time size they stay
+// rolled, and every element's load -> use becomes a memory round trip of its own -- 9 per term instead of one.
+// Hence the *_t templates on the operand sizes, 0 = not known at compile time.)
+template <int OSZ>
+SANM_HD void op_lincomb_t(const TetCtx& c, const OpDesc& o, int mode) {
     const int64_t s = c.Tpad;
-    const int ov = o.out[0], osz = c.vars[ov].size;
+    const int ov = o.out[0], osz = OSZ ? OSZ : c.vars[ov].size;
     if (mode == PASS_GRAD) {
         for (int k = 0; k < o.nin; ++k) {
             int iv = o.in[k], isz = c.vars[iv].size;
@@ -380,11 +384,20 @@ SANM_HD void op_lincomb(const TetCtx& c, const OpDesc& o, int mode) {
     st_cur(c, ov, osz, acc, mode == PASS_COEFF);
 }
 
+SANM_HD void op_lincomb(const TetCtx& c, const OpDesc& o, int mode) {
+    const int osz = c.vars[o.out[0]].size;
+    if (osz == 9) op_lincomb_t<9>(c, o, mode);
+    else if (osz == 1) op_lincomb_t<1>(c, o, mode);
+    else op_lincomb_t<0>(c, o, mode);
+}
+
 // ---- MULTIPLY: elem_arith.cpp:128-217   aux0 = self_bias[osz]
-SANM_HD void op_multiply(const TetCtx& c, const OpDesc& o, int mode) {
+template <int ASZ, int BSZ>
+SANM_HD void op_multiply_t(const TetCtx& c, const OpDesc& o, int mode) {
     const int64_t s = c.Tpad;
     const int a = o.in[0], b = o.in[1], ov = o.out[0];
-    const int asz = c.vars[a].size, bsz = c.vars[b].size, osz = c.vars[ov].size;
+    const int asz = ASZ ? ASZ : c.vars[a].size, bsz = BSZ ? BSZ : c.vars[b].size;
+    const int osz = ASZ ? (ASZ > BSZ ? ASZ : BSZ) : c.vars[ov].size;
     if (mode == PASS_EVAL0) {
         const double *pa = p_coef(c, a, 0), *pb = p_coef(c, b, 0);
         double* po = p_coef(c, ov, 0);
@@ -447,11 +460,21 @@ SANM_HD void op_multiply(const TetCtx& c, const OpDesc& o, int mode) {
     st_cur(c, ov, osz, sb, in_coeff);
 }
 
+SANM_HD void op_multiply(const TetCtx& c, const OpDesc& o, int mode) {
+    const int asz = c.vars[o.in[0]].size, bsz = c.vars[o.in[1]].size;
+    if (asz == 9 && bsz == 9) op_multiply_t<9, 9>(c, o, mode);
+    else if (asz == 1 && bsz == 9) op_multiply_t<1, 9>(c, o, mode);
+    else if (asz == 9 && bsz == 1) op_multiply_t<9, 1>(c, o, mode);
+    else if (asz == 1 && bsz == 1) op_multiply_t<1, 1>(c, o, mode);
+    else op_multiply_t<0, 0>(c, o, mode);
+}
+
 // ---- LOG / POW: oprs/analytic_unary.cpp:113-158, analytic_unary.cpp:13-139
 //      aux0 = k = f'(x0) [sz], aux1 = self_bias [sz]
-SANM_HD void op_unary(const TetCtx& c, const OpDesc& o, int mode) {
+template <int SZ>
+SANM_HD void op_unary_t(const TetCtx& c, const OpDesc& o, int mode) {
     const int64_t s = c.Tpad;
-    const int x = o.in[0], ov = o.out[0], sz = c.vars[ov].size;
+    const int x = o.in[0], ov = o.out[0], sz = SZ ? SZ : c.vars[ov].size;
     const bool is_log = o.type == OP_LOG;
     const double pw = o.p[0];
     double* pk = p_aux(c, o.aux[0]);
@@ -514,10 +537,18 @@ SANM_HD void op_unary(const TetCtx& c, const OpDesc& o, int mode) {
     st_cur(c, ov, sz, sb, in_coeff);
 }
 
+SANM_HD void op_unary(const TetCtx& c, const OpDesc& o, int mode) {
+    const int sz = c.vars[o.out[0]].size;
+    if (sz == 1) op_unary_t<1>(c, o, mode);
+    else if (sz == 9) op_unary_t<9>(c, o, mode);
+    else op_unary_t<0>(c, o, mode);
+}
+
 // ---- REDUCE_SUM axis=-1: oprs/reduce.cpp:11-102
-SANM_HD void op_reduce(const TetCtx& c, const OpDesc& o, int mode) {
+template <int ISZ>
+SANM_HD void op_reduce_t(const TetCtx& c, const OpDesc& o, int mode) {
     const int64_t s = c.Tpad;
-    const int x = o.in[0], ov = o.out[0], isz = c.vars[x].size;
+    const int x = o.in[0], ov = o.out[0], isz = ISZ ? ISZ : c.vars[x].size;
     if (mode == PASS_GRAD) {
         if (c.vars[x].is_const) return;
         for (int r = c.grow; r <= c.grow; ++r) {
@@ -536,6 +567,11 @@ SANM_HD void op_reduce(const TetCtx& c, const OpDesc& o, int mode) {
     if (!c.vars[x].is_const)
         for (int e = 0; e < isz; ++e) sum += cur_bval(c, x, isz, e);
     st_cur(c, ov, 1, &sum, mode == PASS_COEFF);
+}
+
+SANM_HD void op_reduce(const TetCtx& c, const OpDesc& o, int mode) {
+    if (c.vars[o.in[0]].size == 9) op_reduce_t<9>(c, o, mode);
+    else op_reduce_t<0>(c, o, mode);
 }
 
 // ---- MATMUL: oprs/linalg.cpp:339-418   aux0 = self_bias[9]
