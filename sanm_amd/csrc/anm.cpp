@@ -456,7 +456,7 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
         te = (int64_t)(m_shard.rank + 1) * T / m_shard.world;
         sanm_check(te > tb, "more ranks than tets");
     }
-    m_prog = std::make_unique<Program>(be, g, out_var, te - tb, hp.order, tb, T);
+    m_prog = std::make_unique<Program>(be, g, out_var, te - tb, hp.order, tb, T, /*full_history=*/false);
     m_prog->set_remap_in(remap_inp.in_size, remap_inp.rowptr.data(), remap_inp.idx.data(),
                          remap_inp.coef.data());
     m_remap_out = std::make_unique<DeviceRows>(be, remap_out, te - tb, m_prog->Tpad(), tb, te);

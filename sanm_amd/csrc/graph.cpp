@@ -181,7 +181,7 @@ void Graph::batched_svd_w(int x, bool require_rotation, int out[3]) {
 
 // ---------------------------------------------------------------- Program --
 Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_order,
-                 int64_t tet_begin, int64_t T_global)
+                 int64_t tet_begin, int64_t T_global, bool full_history)
         : m_be{be}, m_tet_begin{tet_begin} {
     if (T_global < 0) T_global = T;
     sanm_check(out_var >= 0 && out_var < (int)g.vars.size(), "invalid output var");
@@ -241,9 +241,38 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
         off += n;
         return r;
     };
-    for (auto& d : m_vars) {
-        d.coef = take((int64_t)(d.is_const ? 1 : N + 1) * d.size * Tpad);
-        d.bias = take((int64_t)d.size * Tpad);
+    // Which series are history: an order-k coefficient goes back to HBM only if a convolution of a later order
+    // reads it (both factors of a product, the argument and the result of log / pow / inverse, the argument of
+    // det, M and W of the polar decomposition).  Everything else -- the placeholder, linear combinations,
+    // transposes read by linear operators only, the output -- lives in the LDS scratch of its pass and dies
+    // there: for the Neo-Hookean graph 29 of 65 doubles per tet and order are stored.
+    for (auto& d : m_vars) d.hist = full_history && !d.is_const;
+    for (int oi : topo) {
+        const GraphOp& op = g.ops[oi];
+        auto lv = [&](int i) -> VarDesc& { return m_vars[m_var_map[op.in[i]]]; };
+        VarDesc& ov = m_vars[m_var_map[op.out[0]]];
+        if (ov.is_const) continue;
+        switch (op.type) {
+            case OP_MULTIPLY: case OP_MATMUL:
+                if (!lv(0).is_const && !lv(1).is_const) lv(0).hist = lv(1).hist = 1;
+                break;
+            case OP_LOG: case OP_POW: case OP_MATINVMUL:
+                if (!lv(0).is_const) lv(0).hist = ov.hist = 1;
+                break;
+            case OP_DET:
+                if (!lv(0).is_const) lv(0).hist = 1;
+                break;
+            case OP_SVDW:
+                if (!lv(0).is_const) lv(0).hist = m_vars[m_var_map[op.out[2]]].hist = 1;
+                break;
+            default:
+                break;
+        }
+    }
+    for (size_t i = 0; i < m_vars.size(); ++i) {
+        VarDesc& d = m_vars[i];
+        d.coef = take((int64_t)(d.hist ? N + 1 : 1) * d.size * Tpad);
+        d.bias = (full_history || (int)i == lout) ? take((int64_t)d.size * Tpad) : -1;
     }
     // Per-lane scratch slots of the current-order values.  A value lives from its producing
     // operator to its last reader, so slots are handed out by a linear scan over the
@@ -336,6 +365,14 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
         }
         for (int i = 0; i < 4; ++i) o.aux[i] = -1;
         const int osz = m_vars[o.out[0]].size;
+        if (op.type == OP_LINCOMB || op.type == OP_MULTIPLY || op.type == OP_LOG || op.type == OP_POW ||
+            op.type == OP_REDUCE_SUM) {
+            // the device bodies of the elementwise operators exist for these sizes only (tet_ops.h)
+            bool ok = osz == 1 || osz == 9;
+            for (int i = 0; i < o.nin; ++i) ok = ok && (m_vars[o.in[i]].size == 1 || m_vars[o.in[i]].size == 9);
+            if (!ok)
+                sanm_throw(SANM_ERR_UNSUPPORTED, "elementwise operators take 3x3 matrices and batched scalars only");
+        }
         switch (op.type) {
             case OP_LINCOMB:
                 for (int i = 0; i < o.nin; ++i) o.p[i] = op.coeffs[i];
@@ -483,6 +520,8 @@ void Program::download_var(int graph_var, int order, double* dst) const {
         return;
     }
     sanm_check(order <= m_dev.max_order, "order %d out of range", order);
+    sanm_check(order < 1 || d.hist, "the series of var %d is not kept by this program", graph_var);
+    sanm_check(order >= 0 || d.bias >= 0, "the bias of var %d is not kept by this program", graph_var);
     int64_t off = order < 0 ? d.bias : d.coef + (int64_t)order * d.size * Tpad;
     m_be->d2h(soa.data(), m_dev.arena + off, soa.size() * sizeof(double));
     for (int64_t e = 0; e < T; ++e)

@@ -83,8 +83,10 @@ public:
     //! tet-sharded run) the program covers tets [tet_begin, tet_begin + T) of
     //! T_global and batched constants are sliced accordingly (ConstantOprMeta
     //! under ParallelTaylorCoeffProp, libsanm/oprs/misc.cpp:51-72).
+    //! full_history: keep the series of every variable (what sanm_taylor_get_var exposes, like
+    //! VarNodeExeCtx::coeffs of the reference); otherwise only the series some convolution reads back
     Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_order,
-            int64_t tet_begin = 0, int64_t T_global = -1);
+            int64_t tet_begin = 0, int64_t T_global = -1, bool full_history = true);
     ~Program();
     Program(const Program&) = delete;
 

@@ -49,7 +49,8 @@ struct VarDesc {
     int32_t size;  // 1 (batched scalar), 3 (singular values) or 9 (3x3)
     int32_t is_const;  // coefficients of order >= 1 are identically zero
     int32_t cur;       // offset (in doubles) of the current-order value in the per-lane scratch
-    int32_t pad_;
+    int32_t hist;      // coefficients of order >= 1 are kept in the arena: some convolution reads them back
+                       // (or the program keeps every series for the operator-level API)
 };
 
 struct OpDesc {

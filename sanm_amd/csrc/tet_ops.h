@@ -326,7 +326,9 @@ SANM_HD double cur_bval(const TetCtx& c, int v, int sz, int e) {
 // orders (COEFF pass) or the graph output read by the remap_out kernel (BIAS pass)
 SANM_HD void st_cur(const TetCtx& c, int v, int n, const double* m, bool in_coeff) {
     st(p_curv(c, v), c.cur_stride, n, m);
-    if (in_coeff) st(p_coef(c, v, c.order), c.Tpad, n, m);
+    if (in_coeff) {
+        if (c.vars[v].hist) st(p_coef(c, v, c.order), c.Tpad, n, m);
+    }
     else if (v == c.out_var) st(p_bias(c, v), c.Tpad, n, m);
 }
 
@@ -342,11 +344,12 @@ SANM_HD double jget(const TetCtx& c, int v, int, int ci) {
 // ---- LINCOMB: elem_arith.cpp:42-124
 // (The element loops of the elementwise operators must have compile-time bounds: with a run-time size they stay
 // rolled, and every element's load -> use becomes a memory round trip of its own -- 9 per term instead of one.
-// Hence the *_t templates on the operand sizes, 0 = not known at compile time.)
+// Hence the *_t templates on the operand sizes; the program compiler (graph.cpp) admits elementwise operators on
+// 3x3 matrices and batched scalars only.)
 template <int OSZ>
 SANM_HD void op_lincomb_t(const TetCtx& c, const OpDesc& o, int mode) {
     const int64_t s = c.Tpad;
-    const int ov = o.out[0], osz = OSZ ? OSZ : c.vars[ov].size;
+    const int ov = o.out[0], osz = OSZ;
     if (mode == PASS_GRAD) {
         for (int k = 0; k < o.nin; ++k) {
             int iv = o.in[k], isz = c.vars[iv].size;
@@ -387,8 +390,7 @@ SANM_HD void op_lincomb_t(const TetCtx& c, const OpDesc& o, int mode) {
 SANM_HD void op_lincomb(const TetCtx& c, const OpDesc& o, int mode) {
     const int osz = c.vars[o.out[0]].size;
     if (osz == 9) op_lincomb_t<9>(c, o, mode);
-    else if (osz == 1) op_lincomb_t<1>(c, o, mode);
-    else op_lincomb_t<0>(c, o, mode);
+    else op_lincomb_t<1>(c, o, mode);  // graph.cpp admits sizes 1 and 9 only
 }
 
 // ---- MULTIPLY: elem_arith.cpp:128-217   aux0 = self_bias[osz]
@@ -396,8 +398,7 @@ template <int ASZ, int BSZ>
 SANM_HD void op_multiply_t(const TetCtx& c, const OpDesc& o, int mode) {
     const int64_t s = c.Tpad;
     const int a = o.in[0], b = o.in[1], ov = o.out[0];
-    const int asz = ASZ ? ASZ : c.vars[a].size, bsz = BSZ ? BSZ : c.vars[b].size;
-    const int osz = ASZ ? (ASZ > BSZ ? ASZ : BSZ) : c.vars[ov].size;
+    constexpr int asz = ASZ, bsz = BSZ, osz = ASZ > BSZ ? ASZ : BSZ;
     if (mode == PASS_EVAL0) {
         const double *pa = p_coef(c, a, 0), *pb = p_coef(c, b, 0);
         double* po = p_coef(c, ov, 0);
@@ -449,14 +450,18 @@ SANM_HD void op_multiply_t(const TetCtx& c, const OpDesc& o, int mode) {
         }
         if (c.part) return;
         st(psb, s, osz, sb);
-    } else {
-        ld(psb, s, osz, sb);
     }
     const double *a0 = p_coef(c, a, 0), *b0 = p_coef(c, b, 0);
+    double A0[9], B0[9];  // one batch of loads
+    for (int e = 0; e < osz; ++e) {
+        A0[e] = bval(a0, s, asz, e);
+        B0[e] = bval(b0, s, bsz, e);
+        if (in_coeff) sb[e] = psb[e * s];
+    }
     if (!c.vars[b].is_const)
-        for (int e = 0; e < osz; ++e) sb[e] += bval(a0, s, asz, e) * cur_bval(c, b, bsz, e);
+        for (int e = 0; e < osz; ++e) sb[e] += A0[e] * cur_bval(c, b, bsz, e);
     if (!c.vars[a].is_const)
-        for (int e = 0; e < osz; ++e) sb[e] += cur_bval(c, a, asz, e) * bval(b0, s, bsz, e);
+        for (int e = 0; e < osz; ++e) sb[e] += cur_bval(c, a, asz, e) * B0[e];
     st_cur(c, ov, osz, sb, in_coeff);
 }
 
@@ -465,8 +470,7 @@ SANM_HD void op_multiply(const TetCtx& c, const OpDesc& o, int mode) {
     if (asz == 9 && bsz == 9) op_multiply_t<9, 9>(c, o, mode);
     else if (asz == 1 && bsz == 9) op_multiply_t<1, 9>(c, o, mode);
     else if (asz == 9 && bsz == 1) op_multiply_t<9, 1>(c, o, mode);
-    else if (asz == 1 && bsz == 1) op_multiply_t<1, 1>(c, o, mode);
-    else op_multiply_t<0, 0>(c, o, mode);
+    else op_multiply_t<1, 1>(c, o, mode);
 }
 
 // ---- LOG / POW: oprs/analytic_unary.cpp:113-158, analytic_unary.cpp:13-139
@@ -474,7 +478,7 @@ SANM_HD void op_multiply(const TetCtx& c, const OpDesc& o, int mode) {
 template <int SZ>
 SANM_HD void op_unary_t(const TetCtx& c, const OpDesc& o, int mode) {
     const int64_t s = c.Tpad;
-    const int x = o.in[0], ov = o.out[0], sz = SZ ? SZ : c.vars[ov].size;
+    const int x = o.in[0], ov = o.out[0], sz = SZ;
     const bool is_log = o.type == OP_LOG;
     const double pw = o.p[0];
     double* pk = p_aux(c, o.aux[0]);
@@ -529,26 +533,28 @@ SANM_HD void op_unary_t(const TetCtx& c, const OpDesc& o, int mode) {
         }
         if (c.part) return;
         st(psb, s, sz, sb);
-    } else {
-        ld(psb, s, sz, sb);
+    }
+    double K[9];
+    for (int e = 0; e < sz; ++e) {  // one batch of loads
+        K[e] = pk[e * s];
+        if (in_coeff) sb[e] = psb[e * s];
     }
     if (!c.vars[x].is_const)
-        for (int e = 0; e < sz; ++e) sb[e] += pk[e * s] * cur_bval(c, x, sz, e);
+        for (int e = 0; e < sz; ++e) sb[e] += K[e] * cur_bval(c, x, sz, e);
     st_cur(c, ov, sz, sb, in_coeff);
 }
 
 SANM_HD void op_unary(const TetCtx& c, const OpDesc& o, int mode) {
     const int sz = c.vars[o.out[0]].size;
     if (sz == 1) op_unary_t<1>(c, o, mode);
-    else if (sz == 9) op_unary_t<9>(c, o, mode);
-    else op_unary_t<0>(c, o, mode);
+    else op_unary_t<9>(c, o, mode);
 }
 
 // ---- REDUCE_SUM axis=-1: oprs/reduce.cpp:11-102
 template <int ISZ>
 SANM_HD void op_reduce_t(const TetCtx& c, const OpDesc& o, int mode) {
     const int64_t s = c.Tpad;
-    const int x = o.in[0], ov = o.out[0], isz = ISZ ? ISZ : c.vars[x].size;
+    const int x = o.in[0], ov = o.out[0], isz = ISZ;
     if (mode == PASS_GRAD) {
         if (c.vars[x].is_const) return;
         for (int r = c.grow; r <= c.grow; ++r) {
@@ -571,7 +577,7 @@ SANM_HD void op_reduce_t(const TetCtx& c, const OpDesc& o, int mode) {
 
 SANM_HD void op_reduce(const TetCtx& c, const OpDesc& o, int mode) {
     if (c.vars[o.in[0]].size == 9) op_reduce_t<9>(c, o, mode);
-    else op_reduce_t<0>(c, o, mode);
+    else op_reduce_t<1>(c, o, mode);
 }
 
 // ---- MATMUL: oprs/linalg.cpp:339-418   aux0 = self_bias[9]
@@ -629,18 +635,18 @@ SANM_HD void op_matmul(const TetCtx& c, const OpDesc& o, int mode) {
         }
         if (c.part) return;
         st9(psb, s, R);
-    } else {
-        ld9(psb, s, R);
     }
+    double A0[9], B0[9];  // one batch of loads
+    ld9(p_coef(c, a, 0), s, A0);
+    ld9(p_coef(c, b, 0), s, B0);
+    if (in_coeff) ld9(psb, s, R);
     if (!c.vars[a].is_const) {
         ld_cur(c, a, 9, A);
-        ld9(p_coef(c, b, 0), s, B);
-        mm3<false, false, true>(R, A, B);
+        mm3<false, false, true>(R, A, B0);
     }
     if (!c.vars[b].is_const) {
-        ld9(p_coef(c, a, 0), s, A);
         ld_cur(c, b, 9, B);
-        mm3<false, false, true>(R, A, B);
+        mm3<false, false, true>(R, A0, B);
     }
     st_cur(c, ov, 9, R, in_coeff);
 }
@@ -731,23 +737,24 @@ SANM_HD void op_matinvmul(const TetCtx& c, const OpDesc& o, int mode) {
         if (!c.vars[x].is_const) conv_reduce(c, R, 9);
         if (c.part) return;
         st9(psb, s, R);
-    } else {
-        ld9(psb, s, R);
     }
+    // one batch of loads (a memory round trip for the operator, not one per conditional block below)
+    double XI[9];
+    ld9(p_coef(c, ov, 0), s, Y);
+    ld9(pxinv, s, XI);
+    if (in_coeff) ld9(psb, s, R);
     if (!ident && !c.vars[av].is_const) {
         ld_cur(c, av, 9, X);
         for (int e = 0; e < 9; ++e) R[e] += X[e];
     }
     if (!c.vars[x].is_const) {
-        ld9(p_coef(c, ov, 0), s, Y);
         ld_cur(c, x, 9, X);
         if (is_left) mm3<false, false, false>(Tm, Y, X);
         else mm3<false, false, false>(Tm, X, Y);
         for (int e = 0; e < 9; ++e) R[e] -= Tm[e];
     }
-    ld9(pxinv, s, X);
-    if (is_left) mm3<false, false, false>(Tm, R, X);
-    else mm3<false, false, false>(Tm, X, R);
+    if (is_left) mm3<false, false, false>(Tm, R, XI);
+    else mm3<false, false, false>(Tm, XI, R);
     st_cur(c, ov, 9, Tm, in_coeff);
 }
 
@@ -801,41 +808,38 @@ SANM_HD void op_det(const TetCtx& c, const OpDesc& o, int mode) {
         int lo, hi;
         conv_range(c, lo, hi);
         double ck[4] = {0, 0, 0, 0}, t[3];  // ck[3]: this part's share of sum_i r0_i . c_{k-i}
-        for (int j = lo; j < hi; ++j) {
-            double r1[3], r2[3];
+        for (int j = lo; j < hi; ++j) {  // both sums in one sweep: their loads share a memory round trip
+            double r0[3], r1[3], r2[3], cm[3];
+            ld(p_coef(c, x, j), s, 3, r0);
             ld(p_coef(c, x, j) + 3 * s, s, 3, r1);
             ld(p_coef(c, x, k - j) + 6 * s, s, 3, r2);
+            ld(pcs + (int64_t)(k - j) * 3 * s, s, 3, cm);
             cross3(r1, r2, t);
             ck[0] += t[0]; ck[1] += t[1]; ck[2] += t[2];
-        }
-        double r0[3], x0[3];
-        ld(p_coef(c, x, 0), s, 3, x0);
-        // unsplit, the running sum starts from r0_0 . c_k^partial like the plain loop it replaces
-        if (c.nparts == 1) ck[3] = x0[0] * ck[0] + x0[1] * ck[1] + x0[2] * ck[2];
-        for (int i = lo; i < hi; ++i) {
-            double cm[3];
-            ld(p_coef(c, x, i), s, 3, r0);
-            ld(pcs + (int64_t)(k - i) * 3 * s, s, 3, cm);
             ck[3] += r0[0] * cm[0] + r0[1] * cm[1] + r0[2] * cm[2];
         }
+        double x0[3];
+        ld(p_coef(c, x, 0), s, 3, x0);
         conv_reduce(c, ck, 4);
         if (c.part) return;
         st(pck, s, 3, ck);
-        sb = c.nparts == 1 ? ck[3] : x0[0] * ck[0] + x0[1] * ck[1] + x0[2] * ck[2] + ck[3];
+        sb = x0[0] * ck[0] + x0[1] * ck[1] + x0[2] * ck[2] + ck[3];
         *psb = sb;
-    } else {
-        sb = *psb;
     }
-    ld9(pcof, s, C);
+    ld9(pcof, s, C);  // one batch of loads
+    double ck[3] = {0, 0, 0}, r1[3] = {0, 0, 0}, r2[3] = {0, 0, 0};
+    if (in_coeff) {
+        sb = *psb;
+        ld(pck, s, 3, ck);
+        ld(p_coef(c, x, 0) + 3 * s, s, 3, r1);
+        ld(p_coef(c, x, 0) + 6 * s, s, 3, r2);
+    }
     ld_cur(c, x, 9, X);
     if (in_coeff) {
         // finish c_k now that x_k is known
-        double ck[3], r1[3], r2[3], t[3];
-        ld(pck, s, 3, ck);
-        ld(p_coef(c, x, 0) + 3 * s, s, 3, r1);
+        double t[3];
         cross3(r1, X + 6, t);
         ck[0] += t[0]; ck[1] += t[1]; ck[2] += t[2];
-        ld(p_coef(c, x, 0) + 6 * s, s, 3, r2);
         cross3(X + 3, r2, t);
         ck[0] += t[0]; ck[1] += t[1]; ck[2] += t[2];
         st(pcs + (int64_t)k * 3 * s, s, 3, ck);
