@@ -963,6 +963,32 @@ SANM_HD void op_svdw(const TetCtx& c, const OpDesc& o, int mode) {
 
 // ---- PLACEHOLDER: oprs/misc.cpp:13-44 fused with remap_in
 //      (SparseLinearDesc::apply, anm.cpp:55-75): coef[k] = gather of x_k.
+template <int NSLOT>
+SANM_HD void gather_remap_in(const TetCtx& c, const RemapInDev& rin, const double* xvec, double* X) {
+    const int64_t s = c.Tpad;
+    if constexpr (NSLOT > 0) {
+        uint32_t idx[9 * NSLOT];
+        double coef[9 * NSLOT];
+        for (int i = 0; i < 9 * NSLOT; ++i) {  // slot sl of element e at i = sl * 9 + e
+            idx[i] = rin.idx[(int64_t)i * s + c.tet];
+            coef[i] = rin.coef[(int64_t)i * s + c.tet];
+        }
+        for (int e = 0; e < 9; ++e) {
+            double acc = 0;
+            for (int sl = 0; sl < NSLOT; ++sl) acc += coef[sl * 9 + e] * xvec[idx[sl * 9 + e]];
+            X[e] = acc;
+        }
+    } else {
+        for (int e = 0; e < 9; ++e) {
+            double acc = 0;
+            for (int sl = 0; sl < rin.nslot; ++sl) {
+                int64_t off = ((int64_t)sl * 9 + e) * s + c.tet;
+                acc += rin.coef[off] * xvec[rin.idx[off]];
+            }
+            X[e] = acc;
+        }
+    }
+}
 SANM_HD void op_placeholder(const TetCtx& c, const OpDesc& o, int mode, const RemapInDev& rin,
                             const double* xvec) {
     const int64_t s = c.Tpad;
@@ -979,14 +1005,12 @@ SANM_HD void op_placeholder(const TetCtx& c, const OpDesc& o, int mode, const Re
         st_cur(c, ov, 9, X, false);
         return;
     }
-    for (int e = 0; e < 9; ++e) {
-        double acc = 0;
-        for (int sl = 0; sl < rin.nslot; ++sl) {
-            int64_t off = ((int64_t)sl * 9 + e) * s + c.tet;
-            acc += rin.coef[off] * xvec[rin.idx[off]];
-        }
-        X[e] = acc;
-    }
+    // index -> value is a dependent pair of loads; with the slot count known at compile time all 9 x NSLOT
+    // index / coefficient loads go out together and all gathers after them (two round trips instead of 18 x NSLOT)
+    if (rin.nslot == 2) gather_remap_in<2>(c, rin, xvec, X);
+    else if (rin.nslot == 3) gather_remap_in<3>(c, rin, xvec, X);
+    else if (rin.nslot == 1) gather_remap_in<1>(c, rin, xvec, X);
+    else gather_remap_in<0>(c, rin, xvec, X);
     if (mode == PASS_EVAL0) st9(p_coef(c, ov, 0), s, X);
     else st_cur(c, ov, 9, X, true);
 }
