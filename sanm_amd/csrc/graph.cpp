@@ -274,6 +274,7 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
         d.coef = take((int64_t)(d.hist ? N + 1 : 1) * d.size * Tpad);
         d.bias = (full_history || (int)i == lout) ? take((int64_t)d.size * Tpad) : -1;
     }
+    const int64_t out_aos = take(9 * Tpad);
     // Per-lane scratch slots of the current-order values.  A value lives from its producing
     // operator to its last reader, so slots are handed out by a linear scan over the
     // topological order and reused once dead: the scratch sits in LDS and its size bounds the
@@ -464,6 +465,7 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
     m_dev.cur_size = cur_size;
     m_dev.T = T;
     m_dev.Tpad = Tpad;
+    m_dev.out_aos = out_aos;
     m_dev.rin = {nullptr, nullptr, 0};
 }
 

@@ -104,9 +104,9 @@ public:
     const std::vector<VarDesc>& vars() const { return m_vars; }
     int64_t n_in() const { return m_n_in; }
 
-    //! device pointer of the output's order-0 value / bias, SoA [9][Tpad]
-    const double* out_coef0() const { return m_dev.arena + m_vars[m_dev.out_var].coef; }
-    const double* out_bias() const { return m_dev.arena + m_vars[m_dev.out_var].bias; }
+    //! device pointer of the output's order-0 value (after EVAL0) / order-k bias (after BIAS(k)), tet-major [T][9]
+    const double* out_coef0() const { return m_dev.arena + m_dev.out_aos; }
+    const double* out_bias() const { return m_dev.arena + m_dev.out_aos; }
     const double* placeholder_jac() const { return m_dev.arena + m_vars[m_placeholder_var].jac; }
     //! copy a coefficient (or bias when order < 0) of a graph var to host, AoS (T,size)
     void download_var(int graph_var, int order, double* dst) const;

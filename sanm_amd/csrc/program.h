@@ -82,6 +82,10 @@ struct ProgramDev {
     int32_t cur_size;  // doubles of per-lane scratch (sum of the sizes of the non-constant vars)
     int32_t desc_lines;  // 64-byte lines of the block holding ops and vars (a multiple of 8)
     int64_t T, Tpad;
+    // the graph output as remap_out gathers it: tet-major [T][9] (order-0 value after EVAL0, order-k bias after
+    // BIAS(k)).  A row of remap_out takes 3 entries of each adjacent tet and the 3 rows of a vertex the same tets:
+    // tet-major they share cache lines, component-major every entry sits in a line of its own.
+    int64_t out_aos;
     RemapInDev rin;
 };
 

@@ -40,7 +40,7 @@ DeviceRows::DeviceRows(Backend* be, const SparseDesc& d, int64_t T, int64_t Tpad
         for (uint64_t p = d.rowptr[i]; p < d.rowptr[i + 1]; ++p) {
             int64_t e = d.idx[p] / 9, c = d.idx[p] % 9;
             if (e < tet_begin || e >= tet_end) continue;
-            idx.push_back(c * Tpad + (e - tet_begin));
+            idx.push_back((e - tet_begin) * 9 + c);
             coef.push_back(d.coef[p]);
         }
         ptr[i + 1] = idx.size();

@@ -32,7 +32,7 @@ struct SparseDesc {
 };
 
 //! device copy of the rows of a SparseDesc whose *inputs* are a flattened
-//! (T,9) AoS tensor, re-indexed to the SoA layout [c][Tpad]
+//! (T,9) AoS tensor (tet-major, like the output buffer of the program: ProgramDev::out_aos)
 class DeviceRows {
 public:
     //! only the entries whose input tet lies in [tet_begin, tet_end) are kept (all of

@@ -54,6 +54,7 @@ struct TetCtx {
     // size-vector per variable and row) fit the same LDS slots the forward passes use for current values
     // instead of 9 x size doubles per variable in HBM.
     int32_t grow = 0;
+    double* out = nullptr;  // arena + ProgramDev::out_aos
 };
 
 // slice [lo, hi) of the convolution index range 1 .. order-1 taken by this part
@@ -322,6 +323,11 @@ SANM_HD void ld_cur(const TetCtx& c, int v, int n, double* m) { ld(p_curv(c, v),
 SANM_HD double cur_bval(const TetCtx& c, int v, int sz, int e) {
     return bval(p_curv(c, v), c.cur_stride, sz, e);
 }
+// the graph output where remap_out gathers it (ProgramDev::out_aos)
+SANM_HD void st_out(const TetCtx& c, int n, const double* m) {
+    double* p = c.out + c.tet * 9;
+    for (int e = 0; e < n; ++e) p[e] = m[e];
+}
 // publish the current value of v: scratch always; HBM when it is history for later
 // orders (COEFF pass) or the graph output read by the remap_out kernel (BIAS pass)
 SANM_HD void st_cur(const TetCtx& c, int v, int n, const double* m, bool in_coeff) {
@@ -329,7 +335,10 @@ SANM_HD void st_cur(const TetCtx& c, int v, int n, const double* m, bool in_coef
     if (in_coeff) {
         if (c.vars[v].hist) st(p_coef(c, v, c.order), c.Tpad, n, m);
     }
-    else if (v == c.out_var) st(p_bias(c, v), c.Tpad, n, m);
+    else if (v == c.out_var) {
+        st_out(c, n, m);
+        if (c.vars[v].bias >= 0) st(p_bias(c, v), c.Tpad, n, m);  // kept for the operator-level API only
+    }
 }
 
 // jac accumulate:  in.jac[r][ci] += v
@@ -1059,6 +1068,7 @@ SANM_HD void exec_program_tet(const ProgramDev& P, int mode, int order, int64_t 
                               const double* xvec, double* cur, int64_t cur_stride, int part = 0,
                               int nparts = 1, double* red = nullptr) {
     TetCtx c{P.arena, P.vars, P.Tpad, tet, order, P.odim, cur, cur_stride, P.out_var, part, nparts, red};
+    c.out = P.arena + P.out_aos;
     if (mode == PASS_GRAD) {
         // seed: row `order` of d(out)/d(out) = I  (symbolic.cpp:219-220); the launch passes the row in `order`
         c.grow = order;
@@ -1067,6 +1077,11 @@ SANM_HD void exec_program_tet(const ProgramDev& P, int mode, int order, int64_t 
         for (int i = P.nops - 1; i >= 0; --i) exec_op(c, P.ops[i], mode, P.rin, xvec);
     } else {
         for (int i = 0; i < P.nops; ++i) exec_op(c, P.ops[i], mode, P.rin, xvec);
+        if (mode == PASS_EVAL0) {  // f(x0) for remap_out
+            double Y[9];
+            ld9(p_coef(c, P.out_var, 0), P.Tpad, Y);
+            st_out(c, 9, Y);
+        }
     }
 }
 
