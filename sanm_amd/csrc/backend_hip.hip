@@ -87,24 +87,38 @@ __global__ void __launch_bounds__(256, W) taylor_pass_kernel(ProgramDev P0, cons
 // value loads of an entry are dependent, so each lane keeps the entries of two strides in flight.
 constexpr int ROW_LANES = 8;
 constexpr int GATHER_LANES = 16;
+// This lane's share of sum_p coef[p] * src[idx[p]] over [p0, e), LANES lanes per row: index -> value is a dependent
+// pair of loads, so 4 entries per lane go out together (clamped, unconditional loads: nothing for the compiler to
+// serialise) -- a row of up to 4 * LANES entries costs two memory round trips.
+template <int LANES, typename I>
+__device__ __forceinline__ double row_dot(const I* __restrict__ idx, const double* __restrict__ coef,
+                                          const double* __restrict__ src, uint32_t p0, uint32_t e, int sub) {
+    double s0 = 0, s1 = 0;
+    for (uint32_t base = p0; base < e; base += 4 * LANES) {
+        I i[4];
+        double c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t q = base + sub + u * LANES;
+            const uint32_t qq = q < e ? q : p0;
+            i[u] = idx[qq];
+            const double cv = coef[qq];
+            c[u] = q < e ? cv : 0.0;
+        }
+        s0 += c[0] * src[i[0]];
+        s1 += c[1] * src[i[1]];
+        s0 += c[2] * src[i[2]];
+        s1 += c[3] * src[i[3]];
+    }
+    return s0 + s1;
+}
 __global__ void __launch_bounds__(256) gather_rows_kernel(SparseRowsDev R, const double* __restrict__ src,
                                                           double* __restrict__ dst) {
     int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t i = gid / GATHER_LANES;
     int sub = gid % GATHER_LANES;
-    double s = 0, s2 = 0;
-    if (i < R.nrows) {
-        const uint32_t e = R.ptr[i + 1];
-        uint32_t p = R.ptr[i] + sub;
-        for (; p + GATHER_LANES < e; p += 2 * GATHER_LANES) {
-            const uint32_t i0 = R.idx[p], i1 = R.idx[p + GATHER_LANES];
-            const double c0 = R.coef[p], c1 = R.coef[p + GATHER_LANES];
-            s += c0 * src[i0];
-            s2 += c1 * src[i1];
-        }
-        if (p < e) s += R.coef[p] * src[R.idx[p]];
-    }
-    s += s2;
+    double s = 0;
+    if (i < R.nrows) s = row_dot<GATHER_LANES>(R.idx, R.coef, src, R.ptr[i], R.ptr[i + 1], sub);
     for (int off = GATHER_LANES / 2; off > 0; off >>= 1) s += __shfl_down(s, off, GATHER_LANES);
     if (i < R.nrows && sub == 0) dst[i] = s;
 }
@@ -117,17 +131,23 @@ __global__ void __launch_bounds__(256) assemble_kernel(AssemblyDev A, const doub
     int sub = gid % ROW_LANES;
     double v = 0;
     if (s < A.nslots) {
-        const uint32_t e = A.ptr[s + 1];
-        uint32_t p = A.ptr[s] + sub;
-        for (; p + ROW_LANES < e; p += 2 * ROW_LANES) {  // two dependent index -> value chains in flight
-            const uint32_t j0 = A.jidx[p], j1 = A.jidx[p + ROW_LANES];
-            const double c0 = A.coef[p] * jac[j0], c1 = A.coef[p + ROW_LANES] * jac[j1];
-            if (fabs(c0) >= 1e-9) v += c0;  // libsanm/sparse_solver.cpp:291-293
-            if (fabs(c1) >= 1e-9) v += c1;
-        }
-        if (p < e) {
-            const double c = A.coef[p] * jac[A.jidx[p]];
-            if (fabs(c) >= 1e-9) v += c;
+        const uint32_t p0 = A.ptr[s], e = A.ptr[s + 1];
+        for (uint32_t base = p0; base < e; base += 4 * ROW_LANES) {  // 4 index -> value chains in flight
+            uint32_t j[4];
+            double c[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t q = base + sub + u * ROW_LANES;
+                const uint32_t qq = q < e ? q : p0;
+                j[u] = A.jidx[qq];
+                const double cv = A.coef[qq];
+                c[u] = q < e ? cv : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double t = c[u] * jac[j[u]];
+                if (fabs(t) >= 1e-9) v += t;  // libsanm/sparse_solver.cpp:291-293
+            }
         }
     }
     for (int off = ROW_LANES / 2; off > 0; off >>= 1) v += __shfl_down(v, off, ROW_LANES);
@@ -438,6 +458,8 @@ __global__ void __launch_bounds__(256) sanity_kernel(size_t n, const double* a, 
 }
 
 // the per-order sanity check without materialising A*xi or the right-hand side: SPMV_LANES lanes per row
+// (in the order loop the matrix comes from HBM every time -- 300 MB of Taylor state and factor pass through the
+// caches between two checks -- so the kernel runs at 19 us where the same product on a cached matrix takes 8)
 __global__ void __launch_bounds__(256) sanity_check_kernel(CsrDev A, const double* __restrict__ xi,
                                                            const double* ti_ptr, double ti_val,
                                                            const double* __restrict__ grad_t,
@@ -449,19 +471,12 @@ __global__ void __launch_bounds__(256) sanity_check_kernel(CsrDev A, const doubl
     for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < (int64_t)A.n * SPMV_LANES;
          gid += (int64_t)gridDim.x * blockDim.x) {  // A.n * SPMV_LANES is a multiple of the group size
         const int64_t row = gid / SPMV_LANES;
-        double s = 0, s2 = 0;
-        const uint32_t e = A.rowptr[row + 1];
-        uint32_t p = A.rowptr[row] + sub;
-        for (; p + SPMV_LANES < e; p += 2 * SPMV_LANES) {
-            const uint32_t c0 = A.col[p], c1 = A.col[p + SPMV_LANES];
-            s += A.val[p] * xi[c0];
-            s2 += A.val[p + SPMV_LANES] * xi[c1];
-        }
-        if (p < e) s += A.val[p] * xi[A.col[p]];
-        s += s2;
-        for (int off = SPMV_LANES / 2; off > 0; off >>= 1) s += __shfl_down(s, off, SPMV_LANES);
-        if (sub == 0) v[0] = fmax(v[0], allclose_excess1(s, -ti * grad_t[row] - bi[row], eps));
+        // right-hand side and the x_1 . x_i term: same round trip as the row pointers
+        const double rhs = -ti * grad_t[row] - bi[row];
         if ((size_t)gid < n1) v[1] += x1[gid] * xi[gid];
+        double s = row_dot<SPMV_LANES>(A.col, A.val, xi, A.rowptr[row], A.rowptr[row + 1], sub);
+        for (int off = SPMV_LANES / 2; off > 0; off >>= 1) s += __shfl_down(s, off, SPMV_LANES);
+        if (sub == 0) v[0] = fmax(v[0], allclose_excess1(s, rhs, eps));
     }
     grid_commit<2>(v, 2, 1u, g);
 }
@@ -940,6 +955,23 @@ public:
         }
         const int width = fwd ? L.max_k : L.max_m;  // longest row
         const int64_t rows = fwd ? L.sum_m : L.sum_k;
+        static const bool no_sub = std::getenv("SANM_MF_NO_SUB") != nullptr;
+        if (fwd && width <= 128 && !no_sub) {  // short rows: several rows per wavefront (mf_kernels.h)
+            const int cnt = L.front_end - L.front_begin;
+            const size_t lds = (size_t)L.max_k * sizeof(double);
+            // 2 rows per lane group once the level has enough rows to fill the chip several times over
+            // (leaf level of the armadillo mesh: 13.4 / 11.5 / 17.5 us with 1 / 2 / 4 rows)
+            const int rr = L.sum_m >= 16 * 2048 ? 2 : 1;
+            const int g = width <= 32 ? 8 : (width <= 64 ? 16 : 32);
+#define SANM_FS(G, R)                                                                                          \
+    if (g == G && rr == R) {                                                                                   \
+        hipLaunchKernelGGL((fwd_level_sub_kernel<G, R>), dim3((L.max_m + 256 / G * R - 1) / (256 / G * R), cnt), \
+                           dim3(256), lds, m_stream, mf, L.front_begin);                                       \
+        return;                                                                                                \
+    }
+            SANM_FS(8, 1) SANM_FS(8, 2) SANM_FS(16, 1) SANM_FS(16, 2) SANM_FS(32, 1) SANM_FS(32, 2)
+#undef SANM_FS
+        }
         int u = 1;
         while (u < 16 && 64 * u < width) u *= 2;
         // R * U <= 16 row chunks in registers, and enough workgroups to fill the chip (measured: more than

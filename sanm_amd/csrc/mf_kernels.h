@@ -630,6 +630,66 @@ __global__ void __launch_bounds__(256) fwd_level_kernel(MfDev mf, int level_begi
     }
 }
 
+// Forward level kernel for levels whose rows are short (k <= 4 G): G lanes per row, 64 / G rows per wavefront,
+// instead of a whole wavefront on a row of a few dozen entries.  The lower levels of the tree have hundreds of
+// fronts with a few dozen pivots and a boundary several times that: with one row per wavefront they are
+// thousands of workgroups of mostly idle lanes and the launch is bound by dispatch.
+template <int G, int R>
+__global__ void __launch_bounds__(256) fwd_level_sub_kernel(MfDev mf, int level_begin) {
+    const MfFrontDev f = mf.lfronts[level_begin + blockIdx.y];
+    const int m = f.m, k = f.k;
+    constexpr int RPB = 256 / G * R;  // rows per workgroup: R per lane group
+    const int rb = blockIdx.x * RPB;
+    if (rb >= m) return;
+    extern __shared__ double vs[];
+    const int tid = threadIdx.x, sub = tid % G, r0 = rb + tid / G * R;
+    const double* inbox = mf.inbox_store + f.inbox_off;
+    const double* rowp[R];
+    int cend[R], dst[R];
+    double a[R][4], pre[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {  // unconditional clamped loads, in flight across the staging below
+        const int r = r0 + q;
+        const bool live = r < m;
+        const int pr = r < k ? r : r + k;
+        rowp[q] = mf.front_store + f.off + (int64_t)(live ? pr : 0) * f.ld + k;
+        cend[q] = !live ? 0 : (r < k ? r + 1 : k);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = sub + G * u;
+            const double v = rowp[q][min(c, k - 1)];
+            a[q][u] = c < cend[q] ? v : 0.0;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const int r = r0 + q;
+        pre[q] = 0;
+        dst[q] = -1;
+        if (r >= k && r < m) {
+            dst[q] = mf.upd_dst[f.bnd_off + r - k];
+            pre[q] = inbox_sum(inbox, f.nch, m, r);
+        }
+    }
+    const int kneed = min(k, rb + RPB);
+    for (int c = tid; c < kneed; c += 256) vs[c] = mf.work[f.own_start + c] + inbox_sum(inbox, f.nch, m, c);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        double acc = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += a[q][u] * vs[min(sub + G * u, k - 1)];
+        for (int c = sub + 4 * G; c < cend[q]; c += G) acc += rowp[q][c] * vs[c];
+#pragma unroll
+        for (int off = G / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, G);
+        const int r = r0 + q;
+        if (sub == 0 && r < m) {
+            if (r < k) mf.work2[f.own_start + r] = acc;
+            else mf.inbox_store[dst[q]] = acc + pre[q];
+        }
+    }
+}
+
 template <int R, int U>
 __global__ void __launch_bounds__(256) bwd_level_kernel(MfDev mf, int level_begin) {
     const MfFrontDev f = mf.lfronts[level_begin + blockIdx.y];

@@ -17,7 +17,7 @@ for r in rows[:int(sys.argv[3]) if len(sys.argv) > 3 else 18]:
           f"avg_us={float(r['AverageNs']) / 1e3:8.2f} pct={float(r['Percentage']):.1f}")
 rows = list(csv.DictReader(open(trace)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-for name in ["fwd_level_kernel", "bwd_level_kernel"]:
+for name in ["fwd_level", "bwd_level"]:
     by = collections.OrderedDict()
     for r in rows:
         if name in r["Kernel_Name"]:
