@@ -17,7 +17,7 @@ SOURCES = ["graph.cpp", "sparse.cpp", "backend_common.cpp", "poly.cpp", "anm.cpp
            "capi.cpp", "backend_hip.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-fno-gpu-rdc"]
+         "-fno-gpu-rdc"] + os.environ.get("SANM_EXTRA_CXXFLAGS", "").split()
 
 
 def _newer(src_list, target):

@@ -913,6 +913,15 @@ public:
         int32_t* hs = reinterpret_cast<int32_t*>(m_scalar_host);
         HIP_CHECK(hipMemcpyAsync(hs, mf.status, sizeof(int32_t), hipMemcpyDeviceToHost, m_stream));
         HIP_CHECK(hipStreamSynchronize(m_stream));
+#ifdef SANM_MF_PHASES
+        {
+            unsigned long long ph[8];
+            HIP_CHECK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(mfk::g_phase), sizeof(ph)));
+            std::fprintf(stderr, "update_kernel, diagonal workgroup, 10 ns ticks: load %.0f  panel solves %.0f  tile update %.0f  "
+                         "tile LU %.0f  store %.0f  (%llu launches)\n", (double)ph[0] / ph[7], (double)ph[1] / ph[7],
+                         (double)ph[2] / ph[7], (double)ph[3] / ph[7], (double)ph[4] / ph[7], ph[7]);
+        }
+#endif
         return *hs;
     }
 

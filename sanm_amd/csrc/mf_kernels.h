@@ -26,6 +26,7 @@ namespace mfk {
 
 constexpr int NB = MF_NB;
 constexpr int TPAD = NB + 1;  // LDS row stride (odd: no bank conflicts on column access)
+typedef double mfma_f64x4 __attribute__((ext_vector_type(4)));
 
 __global__ void scatter_kernel(int64_t nnz, const int64_t* __restrict__ a_dst,
                                const double* __restrict__ val, double* __restrict__ store) {
@@ -57,45 +58,67 @@ __global__ void __launch_bounds__(256) extend_add_kernel(MfDev mf, const int32_t
     mf.front_store[p.off + (int64_t)rel[i] * p.ld + rel[j]] += v;
 }
 
-// In-LDS LU of a diagonal tile (kb pivots, no pivoting) by a 256-thread workgroup.  On entry T holds
-// the tile (synchronised); on exit the packed factors: multipliers below the diagonal, U on and above it
-// (synchronised).  A partial last panel (kb < NB) leaves rows / columns kb.. of the tile updated by all kb
-// pivots, i.e. holding the part of the trailing matrix that lives in this tile.
+// LU of a diagonal tile (kb pivots, no pivoting) by ONE wavefront, in registers: lane r < 32 holds row r, the
+// pivot row travels by v_readlane (the step index is a compile-time constant after unrolling), so a step is
+// ~(2 readlanes + 1 fma) per remaining column and no LDS round trip or barrier -- 3.3 us per tile where the
+// 256-thread version (elimination in LDS, one barrier per step) took 9.7 us, all of it on the critical path of
+// the panel chain.  On entry T holds the tile (synchronised); on exit the packed factors: multipliers below the
+// diagonal, U on and above it; the caller synchronises.  A partial last panel (kb < NB) leaves rows / columns
+// kb.. of the tile updated by all kb pivots, i.e. holding the part of the trailing matrix that lives in this tile.
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+// (a recursive template rather than a loop over the steps: the step index has to be a compile-time constant for
+// the row to stay in registers, and the compiler does not fully unroll the 496-iteration loop nest on its own.
+// The body is branch-free -- rows above the pivot take a zero multiplier, bad pivots are counted, not branched on
+// -- so that the whole LU is one basic block, and the reciprocal of the NEXT pivot (v_rcp_f64 + two Newton steps,
+// a chain of dependent instructions) is started as soon as its column is updated and overlaps with the
+// remaining column updates of the current step.)
+__device__ __forceinline__ double pivot_reciprocal(double piv, int& nbad, bool used) {
+    const bool bad = !(fabs(piv) > 1e-290);
+    nbad += bad && used;
+    piv = bad ? 1.0 : piv;
+    double r = __builtin_amdgcn_rcp(piv);
+    r = __builtin_fma(__builtin_fma(-piv, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-piv, r, 1.0), r, r);
+    return r;
+}
+template <int J>
+__device__ __forceinline__ void tile_lu_step(double (&a)[NB], int r, int kb, double inv, int& nbad) {
+    // (J < kb is wave-uniform; a partial panel stops here)
+    if (J >= kb) return;
+    const double l = (r > J) ? a[J] * inv : 0.0;
+    a[J] = (r > J) ? l : a[J];
+    double inv_next = 1.0;
+    if constexpr (J + 1 < NB) {
+        a[J + 1] -= l * readlane_f64(a[J + 1], J);
+        inv_next = pivot_reciprocal(readlane_f64(a[J + 1], J + 1), nbad, J + 1 < kb);
+    }
+#pragma unroll
+    for (int c = J + 2; c < NB; ++c) a[c] -= l * readlane_f64(a[c], J);
+    if constexpr (J + 1 < NB) tile_lu_step<J + 1>(a, r, kb, inv_next, nbad);
+}
 __device__ __forceinline__ void tile_factor(double (*T)[TPAD], int kb, int tid, int32_t* status) {
-    const int tc = tid % NB, tr = tid / NB;  // tr in 0..7
-    // right-looking elimination; column j is left unscaled during the sweep (later
-    // steps never read it), so one barrier per step suffices
-    for (int j = 0; j < kb; ++j) {
-        double piv = T[j][j];
-        if (!(fabs(piv) > 1e-290)) {
-            if (tid == 0) atomicAdd(status, 1);
-            piv = 1.0;
-        }
-        const double inv = 1.0 / piv;
-        if (tc > j) {
-            const double u = T[j][tc];
+    if (tid >= 64) return;
+    const int r = tid & (NB - 1);  // lanes 32..63 shadow lanes 0..31 and store nothing
+    double a[NB];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int r = tr + 8 * s;
-                if (r > j) T[r][tc] -= (T[r][j] * inv) * u;
-            }
-        }
-        __syncthreads();
-    }
-    // scale the L columns
-    const double d = (tc < kb) ? T[tc][tc] : 1.0;
-    const double dinv = 1.0 / ((fabs(d) > 1e-290) ? d : 1.0);
+    for (int c = 0; c < NB; ++c) a[c] = T[r][c];
+    int nbad = 0;
+    const double inv0 = pivot_reciprocal(readlane_f64(a[0], 0), nbad, kb > 0);
+    tile_lu_step<0>(a, r, kb, inv0, nbad);
+    if (tid == 0 && nbad) atomicAdd(status, nbad);
+    if (tid < NB) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int r = tr + 8 * s;
-        if (tc < kb && r > tc) T[r][tc] *= dinv;
+        for (int c = 0; c < NB; ++c) T[r][c] = a[c];
     }
-    __syncthreads();
 }
 
 // diagonal tile of panel p of every front of a level
 __global__ void __launch_bounds__(256) diag_kernel(MfDev mf, int level_begin, int p) {
-    const MfFrontDev f = mf.fronts[mf.level_fronts[level_begin + blockIdx.x]];
+    const MfFrontDev f = mf.lfronts[level_begin + blockIdx.x];
     const int ld = f.ld, m = 2 * f.k, r0 = p * NB;  // m: extent of the pivot + augmentation block
     const int kb = min(NB, f.k - r0);
     __shared__ double T[NB][TPAD];
@@ -107,6 +130,7 @@ __global__ void __launch_bounds__(256) diag_kernel(MfDev mf, int level_begin, in
     }
     __syncthreads();
     tile_factor(T, kb, tid, mf.status);
+    __syncthreads();
     for (int s = 0; s < 4; ++s) {
         int r = tr + 8 * s, gr = r0 + r, gc = r0 + tc;
         if (gr < m && gc < m) F[(int64_t)gr * ld + gc] = T[r][tc];
@@ -116,30 +140,43 @@ __global__ void __launch_bounds__(256) diag_kernel(MfDev mf, int level_begin, in
 // Panel tiles by substitution with the factored diagonal tile:
 //   U panel tile (p, t): one lane per COLUMN, x_r = b_r - sum_{j<r} l_rj x_j;
 //   L panel tile (t, p): one lane per ROW,    x_c = (b_c - sum_{j<c} x_j u_jc) / u_cc          (t > p)
-// The factor is laid out in LDS as S[i][j] (j < i) = l_ij resp. u_ji, zero for pivots j >= kb, with
-// 1/u_ii beside it (1 for i >= kb): row i is then one contiguous broadcast read, the substitution is
-// branch-free straight-line code over a register array, and the rows / columns kb.. of a partial panel
-// receive their trailing update by the same formula.
+// in the right-looking order: as soon as x_j is final every later entry takes its term, x_i -= s_ji x_j.  The 31-j
+// updates of a step are independent of each other, so the only chain through the sweep is one multiply-add per
+// step (the left-looking form -- a dot product per entry -- chained i/2 dependent multiply-adds at step i and took
+// 3.6 us per tile).  The factor is laid out in LDS as S[j][i] (i > j) = l_ij resp. u_ji, zero elsewhere and for
+// pivots j >= kb, with 1/u_jj beside it (1 for j >= kb): row j is one contiguous broadcast read that does not
+// depend on x, the substitution is branch-free straight-line code over a register array, and the rows / columns
+// kb.. of a partial panel receive their trailing update by the same formula.
 // (Earlier versions multiplied by explicit inverses of the tile factors; building those inverses cost the
 // look-ahead tile LU as much again as the elimination itself, on the critical path of every panel.)
 constexpr int SPAD = NB + 2;  // even row stride: 16-byte aligned rows
+template <int J>
+__device__ __forceinline__ void trsm_row_load(const double (*S)[SPAD], double2 (&buf)[NB / 2]) {
+    // entries J+1 .. NB-1 of row J in aligned pairs; a pair that starts at J itself holds a zero there
+#pragma unroll
+    for (int i = (J + 1) & ~1; i < NB; i += 2) buf[i / 2] = *reinterpret_cast<const double2*>(&S[J][i]);
+}
+template <bool SCALE, int J>
+__device__ __forceinline__ void trsm_step(const double (*S)[SPAD], const double* Dv, double (&x)[NB],
+                                          const double2 (&cur)[NB / 2]) {
+    // row J + 1 is requested before row J is consumed: the reads do not depend on x, and an LDS round trip per
+    // pair of multiply-adds is what the compiler's own schedule exposes
+    double2 nxt[NB / 2];
+    if constexpr (J + 1 < NB) trsm_row_load<J + 1>(S, nxt);
+    if (SCALE) x[J] *= Dv[J];
+    const double xj = x[J];
+#pragma unroll
+    for (int i = (J + 1) & ~1; i < NB; i += 2) {
+        if (i > J) x[i] -= cur[i / 2].x * xj;
+        x[i + 1] -= cur[i / 2].y * xj;
+    }
+    if constexpr (J + 1 < NB) trsm_step<SCALE, J + 1>(S, Dv, x, nxt);
+}
 template <bool SCALE>
 __device__ __forceinline__ void trsm_sweep(const double (*S)[SPAD], const double* Dv, double (&x)[NB]) {
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        // keep this row's LDS reads in this step: hoisted to the top they would all have to be spilled
-        // asm volatile("" ::: "memory");
-        double a0 = x[i], a1 = 0;
-#pragma unroll
-        for (int j = 0; j + 1 < i; j += 2) {
-            const double2 l = *reinterpret_cast<const double2*>(&S[i][j]);
-            a0 -= l.x * x[j];
-            a1 -= l.y * x[j + 1];
-        }
-        if (i & 1) a0 -= S[i][i - 1] * x[i - 1];
-        a0 += a1;
-        x[i] = SCALE ? a0 * Dv[i] : a0;
-    }
+    double2 row0[NB / 2];
+    trsm_row_load<0>(S, row0);
+    trsm_step<SCALE, 0>(S, Dv, x, row0);
 }
 
 // One launch per panel p: tile(ti,tj) -= L(ti,p)[:, :kb] * U(p,tj)[:kb, :]   (ti, tj > p), where every
@@ -159,8 +196,17 @@ __device__ __forceinline__ void trsm_sweep(const double (*S)[SPAD], const double
 // updates move 2 flop per byte and are bandwidth-bound on fronts of thousands of pivots.  The grid is the
 // L shape: blockIdx.x = position inside the outer block, blockIdx.y < rem: the column part (all rows),
 // blockIdx.y >= rem: the row part beyond t_end.  t_end >= nt gives the plain square.
+// (-DSANM_MF_PHASES: the workgroup that factors the next diagonal tile -- the critical path of the panel chain --
+// accumulates wall-clock ticks per phase; backend_hip.hip prints them after a factorisation.)
+#ifdef SANM_MF_PHASES
+__device__ unsigned long long g_phase[8];
+#define SANM_PHASE_MARK(name) const unsigned long long name = wall_clock64()
+#else
+#define SANM_PHASE_MARK(name)
+#endif
 __global__ void __launch_bounds__(256) update_kernel(MfDev mf, int level_begin, int p, int t_end) {
-    const MfFrontDev f = mf.fronts[mf.level_fronts[level_begin + blockIdx.z]];
+    SANM_PHASE_MARK(c0);
+    const MfFrontDev f = mf.lfronts[level_begin + blockIdx.z];
     const int ld = f.ld, m = 2 * f.k, nt = (m + NB - 1) / NB;
     const int te = min(t_end, nt), rem = nt - p - 1;
     if ((int)blockIdx.x >= te - p - 1) return;
@@ -188,14 +234,24 @@ __global__ void __launch_bounds__(256) update_kernel(MfDev mf, int level_begin, 
         gr = p * NB + r;
         gc = tj * NB + tc;
         U[r][tc] = (gr < m && gc < m) ? F[(int64_t)gr * ld + gc] : 0.0;
-        // diagonal tile entry (r, tc): multipliers row-wise for the U panel, U transposed for the L panel
+        // diagonal tile entry (r, tc): multipliers by pivot column for the U panel, U by pivot row for the L panel
         gc = p * NB + tc;
         const double v = (gr < m && gc < m) ? F[(int64_t)gr * ld + gc] : 0.0;
-        SL[r][tc] = (tc < r && tc < kb) ? v : 0.0;
-        SU[tc][r] = (r < tc && r < kb) ? v : 0.0;
+        SL[tc][r] = (tc < r && tc < kb) ? v : 0.0;  // SL[j][i] = l_ij
+        SU[r][tc] = (r < tc && r < kb) ? v : 0.0;   // SU[j][i] = u_ji
         if (r == tc) Dv[r] = (r < kb && fabs(v) > 1e-290) ? 1.0 / v : 1.0;
     }
+    // this thread's four entries of the tile to update (matrix-core C layout, see below): requested now, they
+    // arrive while the panel tiles are solved
+    const int lane = tid & 63, qi = (tid >> 6) >> 1, qj = (tid >> 6) & 1;
+    double cpre[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int gr = ti * NB + 16 * qi + (lane >> 4) + 4 * g, gc = tj * NB + 16 * qj + (lane & 15);
+        cpre[g] = (gr < m && gc < m) ? F[(int64_t)gr * ld + gc] : 0.0;
+    }
     __syncthreads();
+    SANM_PHASE_MARK(c1);
     if (tid < 32) {  // row tid of the L tile
         double x[NB];
 #pragma unroll
@@ -213,27 +269,54 @@ __global__ void __launch_bounds__(256) update_kernel(MfDev mf, int level_begin, 
         for (int r = 0; r < NB; ++r) U[r][q] = x[r];
     }
     __syncthreads();
+    SANM_PHASE_MARK(c2);
     const bool next_diag = (ti == tj) && (ti == p + 1) && ((p + 1) * NB < f.k);  // workgroup-uniform
-    for (int s = 0; s < 4; ++s) {
-        int r = tr + 8 * s, gr = ti * NB + r, gc = tj * NB + tc;
-        double v = (r == tc) ? 1.0 : 0.0;  // identity padding outside the front
-        if (gr < m && gc < m) {
-            double acc = 0;
-#pragma unroll 8
-            for (int q = 0; q < kb; ++q) acc += L[r][q] * U[q][tc];  // pivot columns / rows only
-            v = F[(int64_t)gr * ld + gc] - acc;
-            if (!next_diag) F[(int64_t)gr * ld + gc] = v;
+    {
+        // rank-kb update of the 32x32 tile on the fp64 matrix cores: wavefront w owns the 16x16 quadrant
+        // (w >> 1, w & 1), 8 steps of v_mfma_f64_16x16x4_f64 (operand layout: see gemm_tile below) -- the vector
+        // version read two LDS operands per multiply-add and took 3.8 us of the 22 us of a panel step
+        static_assert(NB == 32, "the tile update is written for 32x32 tiles");
+        mfma_f64x4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < NB / 4; ++ks) {
+            const int kk = 4 * ks + (lane >> 4);  // pivot columns / rows only
+            const double a = kk < kb ? L[16 * qi + (lane & 15)][kk] : 0.0;
+            const double b = kk < kb ? U[kk][16 * qj + (lane & 15)] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
         }
-        if (next_diag) T[r][tc] = v;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int r = 16 * qi + (lane >> 4) + 4 * g, c = 16 * qj + (lane & 15);
+            const int gr = ti * NB + r, gc = tj * NB + c;
+            double v = (r == c) ? 1.0 : 0.0;  // identity padding outside the front
+            if (gr < m && gc < m) {
+                v = cpre[g] - acc[g];
+                if (!next_diag) F[(int64_t)gr * ld + gc] = v;
+            }
+            if (next_diag) T[r][c] = v;
+        }
     }
     if (!next_diag) return;
     __syncthreads();
+    SANM_PHASE_MARK(c3);
     const int kb1 = min(NB, f.k - (p + 1) * NB);
     tile_factor(T, kb1, tid, mf.status);
+    __syncthreads();
+    SANM_PHASE_MARK(c4);
     for (int s = 0; s < 4; ++s) {
         int r = tr + 8 * s, gr = ti * NB + r, gc = tj * NB + tc;
         if (gr < m && gc < m) F[(int64_t)gr * ld + gc] = T[r][tc];
     }
+#ifdef SANM_MF_PHASES
+    if (tid == 0 && blockIdx.z == 0) {
+        atomicAdd(&g_phase[0], c1 - c0);
+        atomicAdd(&g_phase[1], c2 - c1);
+        atomicAdd(&g_phase[2], c3 - c2);
+        atomicAdd(&g_phase[3], c4 - c3);
+        atomicAdd(&g_phase[4], wall_clock64() - c4);
+        atomicAdd(&g_phase[7], 1ull);
+    }
+#endif
 }
 
 // After the panel loop of a level: solve, in place, the panel tiles that hold results -- U panel tiles
@@ -244,7 +327,7 @@ constexpr int FIN_TILES = 8;
 // from t_min on are exactly what block_gemm_kernel multiplies, and they include the augmentation tiles.)
 __global__ void __launch_bounds__(256) panel_finalize_kernel(MfDev mf, int level_begin, int p_begin, int nr_panel,
                                                              int t_min) {
-    const MfFrontDev f = mf.fronts[mf.level_fronts[level_begin + blockIdx.z / nr_panel]];
+    const MfFrontDev f = mf.lfronts[level_begin + blockIdx.z / nr_panel];
     const int p = p_begin + blockIdx.z % nr_panel;
     if (p * NB >= f.k) return;
     const int ld = f.ld, m = 2 * f.k, nt = (m + NB - 1) / NB;
@@ -260,13 +343,13 @@ __global__ void __launch_bounds__(256) panel_finalize_kernel(MfDev mf, int level
     double* F = mf.front_store + f.off;
     const int tid = threadIdx.x;
     for (int s = 0; s < 4; ++s) {
-        // (a, c) of the diagonal tile; the L panel wants U transposed: S[c][a] = u_ac
+        // (a, c) of the diagonal tile
         const int a = tid / NB + 8 * s, c = tid % NB, ga = p * NB + a, gc = p * NB + c;
         const double v = (ga < m && gc < m) ? F[(int64_t)ga * ld + gc] : 0.0;
         if (upanel) {
-            S[a][c] = (c < a && c < kb) ? v : 0.0;
+            S[c][a] = (c < a && c < kb) ? v : 0.0;  // S[j][i] = l_ij
         } else {
-            S[c][a] = (a < c && a < kb) ? v : 0.0;
+            S[a][c] = (a < c && a < kb) ? v : 0.0;  // S[j][i] = u_ji
             if (a == c) Dv[a] = (a < kb && fabs(v) > 1e-290) ? 1.0 / v : 1.0;
         }
     }
@@ -323,7 +406,6 @@ struct MatView {
 };
 constexpr int GT = 64;   // GEMM tile edge
 constexpr int GK = 16;   // GEMM K step
-typedef double mfma_f64x4 __attribute__((ext_vector_type(4)));
 
 struct GemmStage {
     double a[4], b[4];
@@ -399,7 +481,7 @@ __device__ __forceinline__ void gemm_tile_foreach(const mfma_f64x4 acc[2][2], F&
 // step 2:  which = 0: tmpU (k x b) = L11^-1 F[P,B]     (L11^-1 lower: K tiles 0..ti)
 //          which = 1: tmpL (b x k) = F[B,P] U11^-1     (U11^-1 upper: K tiles 0..tj)
 __global__ void __launch_bounds__(256) gemm1_kernel(MfDev mf, int level_begin) {
-    const MfFrontDev f = mf.fronts[mf.level_fronts[level_begin + blockIdx.z / 2]];
+    const MfFrontDev f = mf.lfronts[level_begin + blockIdx.z / 2];
     const int which = blockIdx.z & 1;
     const int k = f.k, b = f.m - f.k, ld = f.ld;
     const int rows = which ? b : k, cols = which ? k : b;
@@ -433,7 +515,7 @@ __global__ void __launch_bounds__(256) gemm1_kernel(MfDev mf, int level_begin) {
 //          which = 1: F[B,A]  = -tmpL L11^-1   (b x k; L11^-1 lower: K tiles tj..)
 //          which = 2: F[A,B]  = -U11^-1 tmpU   (k x b; U11^-1 upper: K tiles ti..)
 __global__ void __launch_bounds__(256) gemm2_kernel(MfDev mf, int level_begin) {
-    const MfFrontDev f = mf.fronts[mf.level_fronts[level_begin + blockIdx.z / 3]];
+    const MfFrontDev f = mf.lfronts[level_begin + blockIdx.z / 3];
     const int which = blockIdx.z % 3;
     const int k = f.k, b = f.m - f.k, ld = f.ld;
     const int rows = which == 2 ? k : b, cols = which == 1 ? k : b;
@@ -477,7 +559,7 @@ __global__ void __launch_bounds__(256) gemm2_kernel(MfDev mf, int level_begin) {
 // as one rank-(p1 - p0) * NB product of the solved panel tiles (panel_finalize_kernel) on the matrix cores.
 // Tiles inside the (augmentation x augmentation) corner are never used and skipped.
 __global__ void __launch_bounds__(256) block_gemm_kernel(MfDev mf, int level_begin, int p0, int p1) {
-    const MfFrontDev f = mf.fronts[mf.level_fronts[level_begin + blockIdx.z]];
+    const MfFrontDev f = mf.lfronts[level_begin + blockIdx.z];
     const int k = f.k, ld = f.ld, m = 2 * k, r0 = p1 * NB;
     if (p0 * NB >= k || r0 >= m) return;
     const int ti = blockIdx.y, tj = blockIdx.x, ext = m - r0;
