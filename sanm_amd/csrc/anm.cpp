@@ -103,6 +103,12 @@ public:
         m_be->mf_solve(m_mf.dev(), m_mf.schedule(), b, x);
         ++nr_solve;
     }
+    const int32_t* rhs_perm() const override { return m_mf.dev().perm; }
+    double* rhs_work() const override { return m_mf.dev().work; }
+    void solve_fused(const double* b, double* x, const double* dot_y, double* dot_out) override {
+        m_be->mf_solve_fused(m_mf.dev(), m_mf.schedule(), b, x, dot_y, dot_out);
+        ++nr_solve;
+    }
 };
 }  // namespace
 
@@ -529,6 +535,7 @@ void AnmDriver::solve_expansion_coeffs() {
 
     double t1 = 0, xgt_dot_x1 = 0;
     const double* grad_t = nullptr;
+    const int32_t* rhs_perm = nullptr;
     for (int i = 1; i <= N; ++i) {
         if (i == 1) {
             ScopedTimer t{this, "jacobian"};
@@ -537,7 +544,10 @@ void AnmDriver::solve_expansion_coeffs() {
         {
             ScopedTimer t{this, "taylor_next_order"};
             be->run_pass(P, PASS_BIAS, i, nullptr);
-            be->gather_rows(m_remap_out->dev(), m_prog->out_bias(), m_bi.p());
+            // (orders >= 2, single rank: remap_out drops b_i where the direct solver reads its right-hand side)
+            rhs_perm = (i > 1 && !m_shard.active()) ? m_solver->rhs_perm() : nullptr;
+            be->gather_rows(m_remap_out->dev(), m_prog->out_bias(), m_bi.p(), rhs_perm,
+                            rhs_perm ? m_solver->rhs_work() : nullptr);
             // the one collective per Taylor order: sum of the per-shard nodal bias (n doubles)
             if (i > 1) allreduce(m_bi.p(), n);
         }
@@ -576,13 +586,17 @@ void AnmDriver::solve_expansion_coeffs() {
             m_host_scalars[3 * i] = ti;
             xgt_dot_x1 = be->dot(n, xi, m_xgt.p());
         } else {
+            // t_i = (xb_i . x_1) / (t1 - xgt . x_1);  x_i = -t_i*xgt - xb_i  (anm.cpp:246-264)
             {
                 ScopedTimer t{this, "sparse_solve"};
-                m_solver->solve(m_bi.p(), m_xbi.p());
+                if (rhs_perm) {  // ... and the solver's last kernel forms xb_i . x_1 on the way out
+                    m_solver->solve_fused(nullptr, m_xbi.p(), m_xt_coeffs[1].p(), m_dev_scalars.p() + i);
+                } else {
+                    m_solver->solve(m_bi.p(), m_xbi.p());
+                    be->dot_async(n, m_xbi.p(), m_xt_coeffs[1].p(), m_dev_scalars.p() + i);
+                }
             }
             xbi = m_xbi.p();
-            // t_i = (xb_i . x_1) / (t1 - xgt . x_1);  x_i = -t_i*xgt - xb_i  (anm.cpp:246-264)
-            be->dot_async(n, xbi, m_xt_coeffs[1].p(), m_dev_scalars.p() + i);
             be->next_coeff_async(n, m_dev_scalars.p() + i, 1.0 / (t1 - xgt_dot_x1), m_xgt.p(), xbi, xi,
                                  m_host_scalars + 3 * i);
         }

@@ -84,6 +84,14 @@ public:
     virtual ~LinearSolver() = default;
     virtual void prepare() = 0;                       // after new values were assembled
     virtual void solve(const double* b, double* x) = 0;
+    //! Where the solver wants its right-hand side, if the caller can put it there while producing it: entry i
+    //! at rhs_work()[rhs_perm()[i]] (null: no such place).  solve_fused(nullptr, ...) then solves for that
+    //! right-hand side; with dot_y it also leaves x . dot_y in *dot_out (device memory).
+    virtual const int32_t* rhs_perm() const { return nullptr; }
+    virtual double* rhs_work() const { return nullptr; }
+    virtual void solve_fused(const double*, double*, const double*, double*) {
+        sanm_throw(SANM_ERR_ASSERT, "solve_fused: not offered by this solver (rhs_perm() is null)");
+    }
     int64_t nr_solve = 0, tot_iters = 0, last_iters = 0;
     double last_relres = 0;
     // direct solver analysis (0 for iterative solvers)

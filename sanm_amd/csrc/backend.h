@@ -66,7 +66,10 @@ public:
     //! one whole graph pass over all tets (tet_ops.h: exec_program_tet)
     virtual void run_pass(const ProgramDev& P, int mode, int order, const double* xvec) = 0;
     //! remap_out apply (SparseLinearDesc::apply, libsanm/anm.cpp:55-75)
-    virtual void gather_rows(const SparseRowsDev& R, const double* src, double* dst) = 0;
+    //! dst = R * src; with `perm`, additionally dst2[perm[i]] = dst[i] (the right-hand side where the direct
+    //! solver wants it: saves the solver's own permutation launch)
+    virtual void gather_rows(const SparseRowsDev& R, const double* src, double* dst, const int32_t* perm = nullptr,
+                             double* dst2 = nullptr) = 0;
     //! Jacobian values into a fixed CSR pattern (anm.cpp:362-438 + sparse_solver.cpp:250-305)
     virtual void assemble(const AssemblyDev& A, const double* jac, double* val) = 0;
     //! y = A x  (SparseSolver::apply, sparse_solver.cpp:202-215)
@@ -125,6 +128,11 @@ public:
     virtual int mf_factor(const MfDev& mf, const MfSchedule& sch, const CsrDev& A) = 0;
     //! x = A^-1 b with the factors of the last mf_factor (b, x: n doubles, may alias)
     virtual void mf_solve(const MfDev& mf, const MfSchedule& sch, const double* b, double* x) = 0;
+    //! the same with the two ends of the solve fused into its neighbours in the order loop: b == nullptr means the
+    //! permuted right-hand side already sits in mf.work (gather_rows with perm); with dot_y the kernel that writes
+    //! x also forms x . dot_y into *dot_out (device memory, like dot_async)
+    virtual void mf_solve_fused(const MfDev& mf, const MfSchedule& sch, const double* b, double* x,
+                                const double* dot_y, double* dot_out);  // default: backend_common.cpp
 
     //! bracket every run_pass launch with device events (measurement runs only);
     //! pass_timing() returns the summed duration in ms and the launch count since

@@ -1,8 +1,16 @@
 #include <cmath>
 
 #include "backend.h"
+#include "graph.h"
 
 namespace sanm_hip {
+
+void Backend::mf_solve_fused(const MfDev& mf, const MfSchedule& sch, const double* b, double* x, const double* dot_y,
+                             double* dot_out) {
+    if (!b) sanm_throw(SANM_ERR_ASSERT, "mf_solve_fused: this backend needs the right-hand side");
+    mf_solve(mf, sch, b, x);
+    if (dot_y) dot_async(mf.n, x, dot_y, dot_out);
+}
 
 void Backend::lincomb(size_t n, int nvec, const double* const* ptrs, const double* coefs,
                       double* out) {

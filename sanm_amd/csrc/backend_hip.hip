@@ -113,14 +113,19 @@ __device__ __forceinline__ double row_dot(const I* __restrict__ idx, const doubl
     return s0 + s1;
 }
 __global__ void __launch_bounds__(256) gather_rows_kernel(SparseRowsDev R, const double* __restrict__ src,
-                                                          double* __restrict__ dst) {
+                                                          double* __restrict__ dst,
+                                                          const int32_t* __restrict__ perm,
+                                                          double* __restrict__ dst2) {
     int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t i = gid / GATHER_LANES;
     int sub = gid % GATHER_LANES;
     double s = 0;
     if (i < R.nrows) s = row_dot<GATHER_LANES>(R.idx, R.coef, src, R.ptr[i], R.ptr[i + 1], sub);
     for (int off = GATHER_LANES / 2; off > 0; off >>= 1) s += __shfl_down(s, off, GATHER_LANES);
-    if (i < R.nrows && sub == 0) dst[i] = s;
+    if (i < R.nrows && sub == 0) {
+        dst[i] = s;
+        if (perm) dst2[perm[i]] = s;
+    }
 }
 
 // CSR assembly: ROW_LANES lanes per non-zero (~25 contributions each)
@@ -255,6 +260,19 @@ __device__ __forceinline__ void grid_commit(const double (&v)[NV], int nv, unsig
         if (lane == 0) g.host[j] = r;
     }
     if (threadIdx.x == 0) *g.ticket = 0;  // launches on the stream are serialised
+}
+
+// the last kernel of a solve (x[i] = w[perm[i]]) fused with the dot product the order loop takes of its result
+__global__ void __launch_bounds__(256) permute_out_dot_kernel(int64_t n, const int32_t* __restrict__ perm,
+                                                              const double* __restrict__ w, double* __restrict__ x,
+                                                              const double* __restrict__ y, GridRed g) {
+    double s[1] = {0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = w[perm[i]];
+        x[i] = v;
+        s[0] += v * y[i];
+    }
+    grid_commit<1>(s, 1, 0u, g);
 }
 
 __global__ void __launch_bounds__(256) dot_kernel(size_t n, const double* __restrict__ x,
@@ -766,9 +784,10 @@ public:
         *total_ms = tot;
         *count = m_pass_events.size();
     }
-    void gather_rows(const SparseRowsDev& R, const double* src, double* dst) override {
+    void gather_rows(const SparseRowsDev& R, const double* src, double* dst, const int32_t* perm,
+                     double* dst2) override {
         hipLaunchKernelGGL(gather_rows_kernel, dim3(nblk((size_t)R.nrows * GATHER_LANES, 256)), dim3(256), 0,
-                           m_stream, R, src, dst);
+                           m_stream, R, src, dst, perm, dst2);
         HIP_CHECK(hipGetLastError());
     }
     void assemble(const AssemblyDev& A, const double* jac, double* val) override {
@@ -1000,13 +1019,22 @@ public:
     }
 
     void mf_solve(const MfDev& mf, const MfSchedule& sch, const double* b, double* x) override {
+        mf_solve_fused(mf, sch, b, x, nullptr, nullptr);
+    }
+    void mf_solve_fused(const MfDev& mf, const MfSchedule& sch, const double* b, double* x, const double* dot_y,
+                        double* dot_out) override {
         using namespace mfk;
-        hipLaunchKernelGGL(permute_in_kernel, dim3(nblk(mf.n, 256)), dim3(256), 0, m_stream, mf.n,
-                           mf.perm, b, mf.work);
+        if (b)
+            hipLaunchKernelGGL(permute_in_kernel, dim3(nblk(mf.n, 256)), dim3(256), 0, m_stream, mf.n,
+                               mf.perm, b, mf.work);
         for (size_t li = 0; li < sch.levels.size(); ++li) level_solve(true, mf, sch.levels[li]);
         for (int li = (int)sch.levels.size() - 1; li >= 0; --li) level_solve(false, mf, sch.levels[li]);
-        hipLaunchKernelGGL(permute_out_kernel, dim3(nblk(mf.n, 256)), dim3(256), 0, m_stream, mf.n,
-                           mf.perm, mf.work, x);
+        if (dot_y)
+            hipLaunchKernelGGL(permute_out_dot_kernel, dim3(red_grid(mf.n)), dim3(256), 0, m_stream, mf.n, mf.perm,
+                               mf.work, x, dot_y, red_to(dot_out));
+        else
+            hipLaunchKernelGGL(permute_out_kernel, dim3(nblk(mf.n, 256)), dim3(256), 0, m_stream, mf.n,
+                               mf.perm, mf.work, x);
         HIP_CHECK(hipGetLastError());
     }
 

@@ -42,8 +42,12 @@ public:
         }
         for (int64_t t = 0; t < P.T; ++t) exec_program_tet(P, mode, order, t, xvec, cur.data(), 1);
     }
-    void gather_rows(const SparseRowsDev& R, const double* src, double* dst) override {
-        for (int64_t i = 0; i < R.nrows; ++i) dst[i] = gather_row(R, src, i);
+    void gather_rows(const SparseRowsDev& R, const double* src, double* dst, const int32_t* perm,
+                     double* dst2) override {
+        for (int64_t i = 0; i < R.nrows; ++i) {
+            dst[i] = gather_row(R, src, i);
+            if (perm) dst2[perm[i]] = dst[i];
+        }
     }
     void assemble(const AssemblyDev& A, const double* jac, double* val) override {
         for (int64_t s = 0; s < A.nslots; ++s) val[s] = assemble_slot(A, jac, s);
@@ -122,6 +126,11 @@ public:
     int mf_factor(const MfDev& mf, const MfSchedule& sch, const CsrDev& A) override {
         return hostsim_mf_factor(mf, sch, A);
     }
+    void mf_solve_fused(const MfDev& mf, const MfSchedule& sch, const double* b, double* x, const double* dot_y,
+                        double* dot_out) override {
+        hostsim_mf_solve(mf, sch, b, x);
+        if (dot_y) *dot_out = dot(mf.n, x, dot_y);
+    }
     void mf_solve(const MfDev& mf, const MfSchedule& sch, const double* b, double* x) override {
         hostsim_mf_solve(mf, sch, b, x);
     }
@@ -189,7 +198,8 @@ struct HostMf {
 
     static void solve(const MfDev& mf, const MfSchedule& sch, const double* b, double* x) {
         double* w = mf.work;
-        for (int64_t i = 0; i < mf.n; ++i) w[mf.perm[i]] = b[i];
+        if (b)  // (nullptr: the caller already put the permuted right-hand side into mf.work)
+            for (int64_t i = 0; i < mf.n; ++i) w[mf.perm[i]] = b[i];
         std::vector<double> t;
         for (const auto& L : sch.levels)  // forward
             for (int32_t q = L.front_begin; q < L.front_end; ++q) {
