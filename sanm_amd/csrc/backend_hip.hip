@@ -220,15 +220,37 @@ struct GridRed {
 };
 template <int NV>
 __device__ __forceinline__ void grid_commit(const double (&v)[NV], int nv, unsigned maxmask, GridRed g) {
+    // A wavefront reduction is 6 cross-lane steps of ~100 cycles; with many values per thread (the Gram-Schmidt
+    // projections: up to 24) they are spread over the 4 wavefronts through LDS instead of every wavefront
+    // reducing every value (multi_dot_kernel: 17.6 -> see DESIGN.md for 20 vectors).
+    constexpr bool kViaLds = NV > 4;
     __shared__ double sh[NV][4];
+    __shared__ double stage[kViaLds ? NV : 1][kViaLds ? 256 : 1];
     __shared__ bool last;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if constexpr (kViaLds) {
 #pragma unroll
-    for (int j = 0; j < NV; ++j)
-        if (j < nv) {
-            const double r = ((maxmask >> j) & 1) ? wave_reduce_max(v[j]) : wave_reduce_sum(v[j]);
-            if (lane == 0) sh[j][w] = r;
+        for (int j = 0; j < NV; ++j)
+            if (j < nv) stage[j][threadIdx.x] = v[j];
+        __syncthreads();
+        for (int j = w; j < nv; j += 4) {
+            const bool mx = (maxmask >> j) & 1;
+            const double a = stage[j][lane], b = stage[j][lane + 64], c = stage[j][lane + 128],
+                         d = stage[j][lane + 192];
+            const double r = mx ? wave_reduce_max(fmax(fmax(a, b), fmax(c, d))) : wave_reduce_sum((a + b) + (c + d));
+            if (lane == 0) {
+                sh[j][0] = r;
+                sh[j][1] = sh[j][2] = sh[j][3] = mx ? -1e300 : 0.0;
+            }
         }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            if (j < nv) {
+                const double r = ((maxmask >> j) & 1) ? wave_reduce_max(v[j]) : wave_reduce_sum(v[j]);
+                if (lane == 0) sh[j][w] = r;
+            }
+    }
     __syncthreads();
     // Hand-off without cache-wide fences (MI355X_MICROARCH.md, inter-workgroup visibility): the partials are
     // written through (agent-scope atomic stores), the storing wavefront drains them, one lane signals with
@@ -248,16 +270,31 @@ __device__ __forceinline__ void grid_commit(const double (&v)[NV], int nv, unsig
         last = __hip_atomic_fetch_add(g.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     __syncthreads();
     if (!last) return;
-    for (int j = w; j < nv; j += 4) {  // one wavefront per value
-        const bool mx = (maxmask >> j) & 1;
-        double r = mx ? -1e300 : 0.0;
-        for (unsigned b = lane; b < gridDim.x; b += 64) {
-            const double pv = __hip_atomic_load(&g.partials[j * RED_MAX_GRID + b], __ATOMIC_RELAXED,
-                                                __HIP_MEMORY_SCOPE_AGENT);
-            r = mx ? fmax(r, pv) : r + pv;
+    // one wavefront per value; the (up to KV) values of a wavefront are read in lock step, so that their
+    // partials -- agent-scope loads that go all the way to memory -- share the round trips
+    constexpr int KV = (NV + 3) / 4;
+    double r[KV];
+#pragma unroll
+    for (int q = 0; q < KV; ++q) r[q] = ((maxmask >> (w + 4 * q)) & 1) ? -1e300 : 0.0;
+    for (unsigned b0 = 0; b0 < gridDim.x; b0 += 64) {
+        const unsigned b = b0 + lane;
+#pragma unroll
+        for (int q = 0; q < KV; ++q) {
+            const int j = w + 4 * q;
+            if (j < nv && b < gridDim.x) {
+                const double pv = __hip_atomic_load(&g.partials[j * RED_MAX_GRID + b], __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+                r[q] = ((maxmask >> j) & 1) ? fmax(r[q], pv) : r[q] + pv;
+            }
         }
-        r = mx ? wave_reduce_max(r) : wave_reduce_sum(r);
-        if (lane == 0) g.host[j] = r;
+    }
+#pragma unroll
+    for (int q = 0; q < KV; ++q) {
+        const int j = w + 4 * q;
+        if (j < nv) {
+            const double t = ((maxmask >> j) & 1) ? wave_reduce_max(r[q]) : wave_reduce_sum(r[q]);
+            if (lane == 0) g.host[j] = t;
+        }
     }
     if (threadIdx.x == 0) *g.ticket = 0;  // launches on the stream are serialised
 }
@@ -325,14 +362,21 @@ __global__ void lincomb_kernel(size_t n, VecList v, double* out) {
 }
 // classical Gram-Schmidt update with the projections read from device memory, and the squared norm of
 // the result
+template <int NVT>
 __global__ void __launch_bounds__(256) gs_update_kernel(size_t n, const double* __restrict__ x, VecList q,
                                                         const double* __restrict__ coefs, int first, double* out,
                                                         GridRed g) {
     double s[1] = {0};
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (size_t)gridDim.x * blockDim.x) {
-        double acc = x[i];
-        for (int j = first; j < q.n; ++j) acc += -coefs[j] * q.p[j][i];
+        double acc = x[i], qv[NVT];
+        if (q.n > 0) {
+#pragma unroll
+            for (int j = 0; j < NVT; ++j) qv[j] = q.p[j < q.n ? j : q.n - 1][i];  // one batch of loads
+#pragma unroll
+            for (int j = 0; j < NVT; ++j)
+                if (j >= first && j < q.n) acc += -coefs[j] * qv[j];
+        }
         out[i] = acc;
         s[0] += acc * acc;
     }
@@ -416,23 +460,34 @@ __global__ void __launch_bounds__(256) lincomb2_diff_norms_multi_kernel(size_t n
 // out[j] = x . ys[j]; x is read once per element.  The newest vector ys[v.n-1] may still await the second
 // normalisation of an underflowed Gram-Schmidt direction (last_norm2 != null and sqrt(*last_norm2) < eps):
 // every element is read here anyway, so it is rescaled in place on the way.
+// (NVT = vector count rounded up to a multiple of 4, a template parameter: the loop over the vectors has to be
+// unrolled with unconditional loads -- slots beyond the count re-read the last vector -- or every vector's load
+// becomes a memory round trip of its own)
+template <int NVT>
 __global__ void __launch_bounds__(256) multi_dot_kernel(size_t n, const double* __restrict__ x, VecList v,
                                                         const double* last_norm2, const double* last_nn2,
                                                         double eps, GridRed g) {
-    double acc[MAX_VEC];
-    for (int j = 0; j < MAX_VEC; ++j) acc[j] = 0;
+    double acc[NVT];
+#pragma unroll
+    for (int j = 0; j < NVT; ++j) acc[j] = 0;
     const bool fix = last_norm2 && v.n > 0 && sqrt(*last_norm2) < eps;
     const double f = fix ? 1.0 / sqrt(*last_nn2) : 1.0;
     double* last = fix ? const_cast<double*>(v.p[v.n - 1]) : nullptr;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (size_t)gridDim.x * blockDim.x) {
-        double xi = x[i];
-        if (fix) last[i] *= f;
+        const double xi = x[i];
+        double y[NVT];
 #pragma unroll
-        for (int j = 0; j < MAX_VEC; ++j)
-            if (j < v.n) acc[j] += xi * v.p[j][i];
+        for (int j = 0; j < NVT; ++j) y[j] = v.p[j < v.n ? j : v.n - 1][i];
+#pragma unroll
+        for (int j = 0; j < NVT; ++j)
+            if (j < v.n) {
+                double yj = y[j];
+                if (fix && j == v.n - 1) last[i] = yj = yj * f;
+                acc[j] += xi * yj;
+            }
     }
-    grid_commit<MAX_VEC>(acc, v.n, 0u, g);
+    grid_commit<NVT>(acc, v.n, 0u, g);
 }
 
 __global__ void vmul_kernel(size_t n, const double* x, const double* y, double* out) {
@@ -1162,8 +1217,7 @@ public:
         VecList v{};
         v.n = nvec;
         for (int j = 0; j < nvec; ++j) v.p[j] = ys[j];
-        hipLaunchKernelGGL(multi_dot_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v,
-                           (const double*)nullptr, (const double*)nullptr, 0.0, red());
+        launch_multi_dot(n, x, v, nullptr, nullptr, 0.0, red());
         const double* r = red_result();
         for (int j = 0; j < nvec; ++j) out_host[j] = r[j];
     }
@@ -1210,6 +1264,17 @@ public:
                            m_stream, A, xi, xi + A.n, 0.0, grad_t, bi, eps, n1, x1, red_to(out2));
         HIP_CHECK(hipGetLastError());
     }
+    void launch_multi_dot(size_t n, const double* x, const VecList& v, const double* last_norm2,
+                          const double* last_nn2, double eps, GridRed g) {
+        switch ((v.n + 3) / 4) {
+            case 1: hipLaunchKernelGGL(multi_dot_kernel<4>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, last_norm2, last_nn2, eps, g); break;
+            case 2: hipLaunchKernelGGL(multi_dot_kernel<8>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, last_norm2, last_nn2, eps, g); break;
+            case 3: hipLaunchKernelGGL(multi_dot_kernel<12>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, last_norm2, last_nn2, eps, g); break;
+            case 4: hipLaunchKernelGGL(multi_dot_kernel<16>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, last_norm2, last_nn2, eps, g); break;
+            case 5: hipLaunchKernelGGL(multi_dot_kernel<20>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, last_norm2, last_nn2, eps, g); break;
+            default: hipLaunchKernelGGL(multi_dot_kernel<24>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, last_norm2, last_nn2, eps, g); break;
+        }
+    }
     void multi_dot_async(size_t n, const double* x, int nvec, double* const* ys, double* out,
                          const double* last_norm2, const double* last_nn2, double eps) override {
         if (nvec > MAX_VEC) sanm_throw(SANM_ERR_ASSERT, "multi_dot: too many vectors");
@@ -1217,8 +1282,7 @@ public:
         VecList v{};
         v.n = nvec;
         for (int j = 0; j < nvec; ++j) v.p[j] = ys[j];
-        hipLaunchKernelGGL(multi_dot_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, last_norm2,
-                           last_nn2, eps, red_to(out));
+        launch_multi_dot(n, x, v, last_norm2, last_nn2, eps, red_to(out));
         HIP_CHECK(hipGetLastError());
     }
     void gs_update_async(size_t n, const double* x, int nvec, const double* const* qs, const double* coefs,
@@ -1227,8 +1291,14 @@ public:
         VecList v{};
         v.n = nvec;
         for (int j = 0; j < nvec; ++j) v.p[j] = qs[j];
-        hipLaunchKernelGGL(gs_update_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, coefs, first, out,
-                           red_to(norm2));
+        switch ((nvec + 3) / 4) {
+            case 0: case 1: hipLaunchKernelGGL(gs_update_kernel<4>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, coefs, first, out, red_to(norm2)); break;
+            case 2: hipLaunchKernelGGL(gs_update_kernel<8>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, coefs, first, out, red_to(norm2)); break;
+            case 3: hipLaunchKernelGGL(gs_update_kernel<12>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, coefs, first, out, red_to(norm2)); break;
+            case 4: hipLaunchKernelGGL(gs_update_kernel<16>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, coefs, first, out, red_to(norm2)); break;
+            case 5: hipLaunchKernelGGL(gs_update_kernel<20>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, coefs, first, out, red_to(norm2)); break;
+            default: hipLaunchKernelGGL(gs_update_kernel<24>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, coefs, first, out, red_to(norm2)); break;
+        }
         HIP_CHECK(hipGetLastError());
     }
     void scale_rsqrt_async(size_t n, double* v, const double* norm2, double eps, double* nn2) override {
