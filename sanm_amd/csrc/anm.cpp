@@ -165,7 +165,7 @@ PadeApproximation::PadeApproximation(Backend* be, const std::vector<DVec>& xs,
     };
     if (ws->graph) {
         be->graph_launch(ws->graph);
-    } else if (ws != &local && be->graph_capture_begin()) {
+    } else if (ws != &local && !std::getenv("SANM_NO_PADE_GRAPH") && be->graph_capture_begin()) {
         sweep();
         ws->graph = be->graph_capture_end();
         be->graph_launch(ws->graph);
