@@ -170,6 +170,13 @@ int sanm_anm_restart(sanm_anm_solver* s, const double* x0);
  * call sanm_anm_restart() afterwards. */
 int sanm_anm_time_kernel(sanm_anm_solver* s, int kernel, int reps, int mode, int order,
                          double* avg_ms);
+/* The HIP source of the pass kernels specialised for the solver's compiled graph (what the library compiles at run
+ * time for batches of SANM_JIT_MIN_T tets or more).  Returns the length of the source;
+ * copies at most cap-1 characters and a terminator into buf if it is not NULL. */
+int64_t sanm_anm_spec_source(sanm_anm_solver* s, char* buf, int64_t cap);
+/* test hook, needs no device: 0 if `source` (which may include "program.h" / "tet_ops.h") compiles for gfx950
+ * with the run-time compiler; the compiler's log goes to `log`, the size of the code object to *code_size. */
+int sanm_rtc_compile_check(const char* source, char* log, size_t log_cap, size_t* code_size);
 /* measurement hook for bench.py: when enabled, every launch of the Taylor pass
  * kernel (the graph interpreter) is bracketed by HIP events on the solver's
  * stream.  Each call first returns the summed duration / launch count gathered

@@ -80,7 +80,7 @@ SYMBOLS = [
     "sanm_hyper_param_default", "sanm_anm_eqn_solver_create", "sanm_anm_eqn_solver_create_sharded",
     "sanm_anm_vecscale_solver_create",
     "sanm_anm_implicit_solver_create", "sanm_anm_solver_destroy", "sanm_anm_next_iter",
-    "sanm_anm_update_approx", "sanm_anm_restart", "sanm_anm_time_kernel", "sanm_anm_pass_timing", "sanm_anm_converged", "sanm_anm_residual_rms", "sanm_anm_get_x",
+    "sanm_anm_update_approx", "sanm_anm_restart", "sanm_anm_spec_source", "sanm_rtc_compile_check", "sanm_anm_time_kernel", "sanm_anm_pass_timing", "sanm_anm_converged", "sanm_anm_residual_rms", "sanm_anm_get_x",
     "sanm_anm_get_t_upper", "sanm_anm_get_t_max_a", "sanm_anm_solve_a", "sanm_anm_eval",
     "sanm_anm_nr_iter", "sanm_anm_nr_xt_coeffs", "sanm_anm_xt_coeff", "sanm_anm_has_pade",
     "sanm_anm_get_stats", "sanm_anm_profile", "sanm_anm_trace", "sanm_anm_jacobian_csr",
@@ -508,6 +508,14 @@ class _ANMSolver:
         b, x, t = np.zeros(max(n, 1)), np.zeros(max(n, 1)), np.zeros(max(n, 1))
         n = self.api.lib.sanm_anm_trace(self.h, C.c_int(n), _dp(b), _dp(x), _dp(t))
         return {"b_norm": b[:n].tolist(), "x_norm": x[:n].tolist(), "t": t[:n].tolist()}
+
+    def spec_source(self):
+        """HIP source of the pass kernels specialised for this solver's graph (sanm_anm_spec_source)."""
+        self.api.lib.sanm_anm_spec_source.restype = C.c_int64
+        n = self.api.lib.sanm_anm_spec_source(self.h, None, C.c_int64(0))
+        buf = C.create_string_buffer(n + 1)
+        self.api.lib.sanm_anm_spec_source(self.h, buf, C.c_int64(n + 1))
+        return buf.value.decode()
 
     def time_kernel(self, kernel, reps, mode=2, order=1):
         out = C.c_double()

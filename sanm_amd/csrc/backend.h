@@ -65,6 +65,11 @@ public:
 
     //! one whole graph pass over all tets (tet_ops.h: exec_program_tet)
     virtual void run_pass(const ProgramDev& P, int mode, int order, const double* xvec) = 0;
+    //! Compile pass kernels for one program from generated source (graph.cpp: Program::spec_source) and return a
+    //! handle for ProgramDev::spec_id; -1 if the backend does not compile at run time or the compilation failed
+    //! (the generic interpreter kernels then run the program).
+    virtual int specialize(const char* source) { (void)source; return -1; }
+    virtual void release_specialized(int id) { (void)id; }
     //! remap_out apply (SparseLinearDesc::apply, libsanm/anm.cpp:55-75)
     //! dst = R * src; with `perm`, additionally dst2[perm[i]] = dst[i] (the right-hand side where the direct
     //! solver wants it: saves the solver's own permutation launch)

@@ -29,6 +29,7 @@
 #include "graph.h"
 #include "mf_kernels.h"
 #include "row_ops.h"
+#include "rtc.h"
 #include "tet_ops.h"
 
 namespace sanm_hip {
@@ -679,6 +680,12 @@ inline unsigned red_grid(size_t n) {
 
 class HipBackend final : public Backend {
     hipStream_t m_stream = nullptr;
+    // pass kernels compiled at run time for one program each (specialize)
+    struct SpecKernels {
+        hipModule_t mod = nullptr;
+        hipFunction_t pass[4] = {nullptr, nullptr, nullptr, nullptr};
+    };
+    std::vector<SpecKernels> m_spec;
     GridRed m_red{nullptr, nullptr, nullptr};
     static constexpr size_t kPoolBlockMax = size_t(64) << 20, kPoolTotalMax = size_t(4) << 30;
     std::unordered_map<void*, size_t> m_live;
@@ -785,6 +792,40 @@ public:
     void sync() override { HIP_CHECK(hipStreamSynchronize(m_stream)); }
     hipStream_t stream() const { return m_stream; }
 
+    int specialize(const char* source) override {
+        std::vector<char> code;
+        std::string log;
+        if (!rtc_compile(source, code, log)) {
+            std::fprintf(stderr, "sanm_hip: run-time compilation of the pass kernels failed, using the interpreter kernels\n%s\n",
+                         log.c_str());
+            return -1;
+        }
+        SpecKernels k;
+        if (hipModuleLoadData(&k.mod, code.data()) != hipSuccess) {
+            std::fprintf(stderr, "sanm_hip: could not load the compiled pass kernels, using the interpreter kernels\n");
+            return -1;
+        }
+        for (int m = 0; m < 4; ++m) {
+            const std::string name = "spec_pass" + std::to_string(m);
+            if (hipModuleGetFunction(&k.pass[m], k.mod, name.c_str()) != hipSuccess) {
+                (void)hipModuleUnload(k.mod);
+                return -1;
+            }
+        }
+        for (size_t i = 0; i < m_spec.size(); ++i)
+            if (!m_spec[i].mod) {
+                m_spec[i] = k;
+                return (int)i;
+            }
+        m_spec.push_back(k);
+        return (int)m_spec.size() - 1;
+    }
+    void release_specialized(int id) override {
+        if (id < 0 || id >= (int)m_spec.size() || !m_spec[id].mod) return;
+        (void)hipStreamSynchronize(m_stream);
+        (void)hipModuleUnload(m_spec[id].mod);
+        m_spec[id] = SpecKernels{};
+    }
     void run_pass(const ProgramDev& P, int mode, int order, const double* xvec) override {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (m_time_passes) {
@@ -804,6 +845,24 @@ public:
             case PASS_BIAS: kern = taylor_pass_kernel<PASS_BIAS, kBiasWaves>; break;
             case PASS_COEFF: kern = taylor_pass_kernel<PASS_COEFF, 1>; break;
             default: sanm_throw(SANM_ERR_ASSERT, "unknown pass mode %d", mode);
+        }
+        if (P.spec_id >= 0 && lds <= 48 * 1024) {
+            // this program's own kernels (same grid, same LDS layout as the interpreter's)
+            struct {
+                ProgramDev P;
+                int order;
+                const double* xvec;
+            } args{P, order, xvec};
+            size_t arg_size = sizeof(args);
+            void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_size,
+                              HIP_LAUNCH_PARAM_END};
+            HIP_CHECK(hipModuleLaunchKernel(m_spec[P.spec_id].pass[mode], nblk(P.T, 64), mode == PASS_GRAD ? P.odim : 1,
+                                            1, 64 * nparts, 1, 1, (unsigned)lds, m_stream, nullptr, config));
+            if (m_time_passes) {
+                HIP_CHECK(hipEventRecord(e1, m_stream));
+                m_pass_events.emplace_back(e0, e1);
+            }
+            return;
         }
         if (lds > m_pass_lds_limit[mode]) {
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

@@ -411,6 +411,19 @@ int sanm_anm_restart(sanm_anm_solver* s, const double* x0) {
         s->eqn->restart(x0);
     });
 }
+int64_t sanm_anm_spec_source(sanm_anm_solver* s, char* buf, int64_t cap) {
+    int64_t len = -1;
+    guard([&] {
+        const std::string src = s->drv->program().spec_source();
+        len = src.size();
+        if (buf && cap > 0) {
+            const int64_t n = std::min<int64_t>(len, cap - 1);
+            std::memcpy(buf, src.data(), n);
+            buf[n] = 0;
+        }
+    });
+    return len;
+}
 int sanm_anm_time_kernel(sanm_anm_solver* s, int kernel, int reps, int mode, int order,
                          double* avg_ms) {
     return guard([&] {

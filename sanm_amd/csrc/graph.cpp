@@ -467,9 +467,87 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
     m_dev.Tpad = Tpad;
     m_dev.out_aos = out_aos;
     m_dev.rin = {nullptr, nullptr, 0};
+    m_dev.spec_id = -1;
+    // Run-time specialisation: with the records as compile-time constants every branch on them folds, the element
+    // loops unroll, the LDS scratch turns into registers and each pass becomes a few basic blocks whose loads the
+    // compiler hoists.  It costs a compilation (seconds), so small batches -- the tests --
+    // stay on the interpreter kernels.
+    const char* env_min = std::getenv("SANM_JIT_MIN_T");
+    const int64_t jit_min_t = env_min ? std::atoll(env_min) : 8192;
+    if (!std::getenv("SANM_NO_JIT") && T >= jit_min_t) m_dev.spec_id = be->specialize(spec_source().c_str());
+}
+
+std::string Program::spec_source() const {
+    std::string src;
+    char buf[512];
+    auto add = [&](const char* fmt, auto... a) {
+        std::snprintf(buf, sizeof(buf), fmt, a...);
+        src += buf;
+    };
+    src += "#include \"tet_ops.h\"\nusing namespace sanm_hip;\nnamespace {\n";
+    add("constexpr int kNops = %zu, kCurSize = %d, kOutVar = %d;\nconstexpr long long kTpad = %lld, kOutAos = %lld;\n",
+        m_ops.size(), (int)m_dev.cur_size, (int)m_dev.out_var, (long long)m_dev.Tpad, (long long)m_dev.out_aos);
+    src += "#define SPEC_OPS { \\\n";
+    for (const OpDesc& o : m_ops) {
+        add("  {%d, %d, %d, %d, {%d, %d, %d, %d}, {%d, %d, %d}, %d, {", o.type, o.nin, o.nout, o.flags, o.in[0], o.in[1],
+            o.in[2], o.in[3], o.out[0], o.out[1], o.out[2], o.grad_zero);
+        for (int i = 0; i < MAX_OP_IN + 2; ++i) add("%a%s", o.p[i], i + 1 < MAX_OP_IN + 2 ? ", " : "}, {");
+        add("%lldLL, %lldLL, %lldLL, %lldLL}}, \\\n", (long long)o.aux[0], (long long)o.aux[1], (long long)o.aux[2],
+            (long long)o.aux[3]);
+    }
+    src += "}\n#define SPEC_VARS { \\\n";
+    for (const VarDesc& d : m_vars)
+        add("  {%lldLL, %lldLL, %lldLL, %d, %d, %d, %d}, \\\n", (long long)d.coef, (long long)d.bias, (long long)d.jac,
+            d.size, d.is_const, d.cur, d.hist);
+    src += "}\n";
+    src += R"SRC(
+template <int MODE>
+__device__ __forceinline__ void spec_body(const ProgramDev& P, int order, const double* __restrict__ xvec) {
+    extern __shared__ double cur_lds[];
+    static constexpr OpDesc kOps[] = SPEC_OPS;
+    static constexpr VarDesc kVars[] = SPEC_VARS;
+    const int lane = threadIdx.x & 63;
+    const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nparts = blockDim.x >> 6;
+    const int64_t tet = (int64_t)blockIdx.x * 64 + lane;
+    if (tet >= P.T) return;
+    double* cur = cur_lds + lane;
+    TetCtx c{P.arena, kVars, kTpad, tet, MODE == PASS_GRAD ? (int)blockIdx.y : order, 9, cur, 64, kOutVar, part, nparts,
+             cur_lds + (int64_t)kCurSize * 64 + lane};
+    c.out = P.arena + kOutAos;
+    if (MODE == PASS_GRAD) {
+        c.grow = blockIdx.y;
+        for (int e = 0; e < 9; ++e) cur[(int64_t)(kVars[kOutVar].cur + e) * 64] = (e == c.grow) ? 1.0 : 0.0;
+)SRC";
+    for (int i = (int)m_ops.size() - 1; i >= 0; --i) add("        exec_op(c, kOps[%d], MODE, P.rin, xvec);\n", i);
+    src += "    } else {\n";
+    for (size_t i = 0; i < m_ops.size(); ++i) add("        exec_op(c, kOps[%zu], MODE, P.rin, xvec);\n", i);
+    src += R"SRC(        if (MODE == PASS_EVAL0) {
+            double Y[9];
+            ld9(p_coef(c, kOutVar, 0), kTpad, Y);
+            st_out(c, 9, Y);
+        }
+    }
+}
+}  // namespace
+extern "C" __global__ void __launch_bounds__(256, 1) spec_pass0(ProgramDev P, int order, const double* xvec) {
+    spec_body<PASS_EVAL0>(P, order, xvec);
+}
+extern "C" __global__ void __launch_bounds__(256, 1) spec_pass1(ProgramDev P, int order, const double* xvec) {
+    spec_body<PASS_GRAD>(P, order, xvec);
+}
+extern "C" __global__ void __launch_bounds__(256, 3) spec_pass2(ProgramDev P, int order, const double* xvec) {
+    spec_body<PASS_BIAS>(P, order, xvec);
+}
+extern "C" __global__ void __launch_bounds__(256, 1) spec_pass3(ProgramDev P, int order, const double* xvec) {
+    spec_body<PASS_COEFF>(P, order, xvec);
+}
+)SRC";
+    return src;
 }
 
 Program::~Program() {
+    if (m_dev.spec_id >= 0) m_be->release_specialized(m_dev.spec_id);
     m_be->free(m_dev.arena);
     m_be->free(m_d_ops);  // the variable records live in the same block
     if (m_d_rin_idx) m_be->free(m_d_rin_idx);

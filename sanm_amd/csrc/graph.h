@@ -96,6 +96,8 @@ public:
                       const double* coef);  // rowptr indexed by GLOBAL output element
 
     ProgramDev dev() const { return m_dev; }
+    //! HIP source of the four pass kernels with this program's records as compile-time constants
+    std::string spec_source() const;
     int64_t T() const { return m_dev.T; }
     int64_t Tpad() const { return m_dev.Tpad; }
     int max_order() const { return m_dev.max_order; }

@@ -10,7 +10,14 @@
 // SoA: element c of tet e of a tensor at arena offset `off` lives at
 // off + c*Tpad + e, so the 64 lanes of a wavefront read 512 contiguous bytes.
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <cstdint>
+#else  // run-time compilation has no standard headers; its built-ins cover what is used
+using __hip_internal::int32_t;
+using __hip_internal::int64_t;
+using __hip_internal::uint32_t;
+using __hip_internal::uint64_t;
+#endif
 
 namespace sanm_hip {
 
@@ -87,6 +94,8 @@ struct ProgramDev {
     // tet-major they share cache lines, component-major every entry sits in a line of its own.
     int64_t out_aos;
     RemapInDev rin;
+    // host side only: handle of the kernels compiled for this very program (Backend::specialize), -1 = none
+    int32_t spec_id;
 };
 
 }  // namespace sanm_hip

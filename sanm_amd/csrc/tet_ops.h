@@ -15,12 +15,19 @@
 // Math follows the reference operator by operator (file:line on each block);
 // the 3x3 kernels are closed forms instead of Eigen calls.
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <cmath>
+#endif
+#if !defined(__HIPCC_RTC__)  // (run-time compilation has no standard headers; its built-ins cover what is used)
 #include <cstdint>
+#endif
 
 #include "program.h"
 
-#if defined(__HIPCC__)
+#if defined(__HIPCC_RTC__)
+#define SANM_HD __device__ __forceinline__
+#define SANM_HD_NOINLINE __device__ inline
+#elif defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define SANM_HD __host__ __device__ __forceinline__
 #define SANM_HD_NOINLINE __host__ __device__ inline

@@ -245,3 +245,6 @@ struct HostMf {
 int hostsim_mf_factor(const MfDev& mf, const MfSchedule& sch, const CsrDev& A) { return HostMf::factor(mf, sch, A); }
 void hostsim_mf_solve(const MfDev& mf, const MfSchedule& sch, const double* b, double* x) { HostMf::solve(mf, sch, b, x); }
 }  // namespace sanm_hip
+
+// the run-time compiler belongs to the product library only (sanm_amd/csrc/rtc.cpp)
+extern "C" int sanm_rtc_compile_check(const char*, char*, size_t, size_t*) { return 2; }

@@ -177,6 +177,22 @@ def test_tet_renumbering_is_transparent(api, monkeypatch):
     assert np.array_equal(J.indices, Jr.indices) and np.allclose(J.data, Jr.data, rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize("gold_name", ["anm_cuboid_nc.json", "anm_cuboid_ni.json", "anm_cuboid_arap.json"])
+def test_specialised_pass_kernels_agree_with_the_interpreter(api, monkeypatch, gold_name):
+    """batches of SANM_JIT_MIN_T tets or more run pass kernels compiled at run time for their graph (the operator
+    records as compile-time constants); forced on a small model here, they must reproduce the interpreter kernels'
+    continuation: same step count, same solution.  (On the host harness both runs take the shared bodies.)"""
+    gold = json.load(open(os.path.join(GOLD, gold_name)))
+    monkeypatch.setenv("SANM_NO_JIT", "1")
+    ref = _run_device(api, gold["dims"], gold["spacing"], gold["config"])
+    monkeypatch.delenv("SANM_NO_JIT")
+    monkeypatch.setenv("SANM_JIT_MIN_T", "1")
+    run = _run_device(api, gold["dims"], gold["spacing"], gold["config"])
+    assert run.solver.get_nr_iter() == ref.solver.get_nr_iter() == gold["iter"]
+    x, xr = run.solver.get_x(), ref.solver.get_x()
+    assert np.abs(x - xr).max() <= 1e-9 * np.abs(xr).max()
+
+
 def test_jacobian_of_a_mesh_built_by_several_host_threads(api):
     """the Jacobian pattern / gather lists of more than 4096 unknowns are built by several host threads and
     merged; the assembled matrix must still be the oracle's, entry by entry."""
