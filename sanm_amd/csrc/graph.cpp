@@ -470,10 +470,10 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
     m_dev.spec_id = -1;
     // Run-time specialisation: with the records as compile-time constants every branch on them folds, the element
     // loops unroll, the LDS scratch turns into registers and each pass becomes a few basic blocks whose loads the
-    // compiler hoists.  It costs a compilation (seconds), so small batches -- the tests --
-    // stay on the interpreter kernels.
+    // compiler hoists.  It costs a compilation (about a second), so small batches -- the
+    // tests -- stay on the interpreter kernels.
     const char* env_min = std::getenv("SANM_JIT_MIN_T");
-    const int64_t jit_min_t = env_min ? std::atoll(env_min) : 8192;
+    const int64_t jit_min_t = env_min ? std::atoll(env_min) : 2048;
     if (!std::getenv("SANM_NO_JIT") && T >= jit_min_t) m_dev.spec_id = be->specialize(spec_source().c_str());
 }
 

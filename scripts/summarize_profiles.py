@@ -22,6 +22,8 @@ dst = os.path.join(ROOT, "profiles")
 def short(name):
     """kernel family: namespaces and template arguments stripped"""
     name = re.sub(r"^void ", "", name)
+    if name.startswith("spec_pass"):  # the pass kernels compiled at run time for one graph (graph.cpp: spec_source)
+        return "taylor_pass_kernel"
     name = name.replace("sanm_hip::(anonymous namespace)::", "").replace("sanm_hip::", "")
     name = re.sub(r"[<(].*", "", name)
     return name
