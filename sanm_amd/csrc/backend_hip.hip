@@ -701,7 +701,7 @@ class HipBackend final : public Backend {
     static constexpr int kOuterPanels = 4;
     static constexpr int kOuterMinK = 512;
     int m_conv_parts = std::getenv("SANM_CONV_PARTS") ? std::atoi(std::getenv("SANM_CONV_PARTS")) : 4;
-    int m_conv_split_order = std::getenv("SANM_CONV_SPLIT_ORDER") ? std::atoi(std::getenv("SANM_CONV_SPLIT_ORDER")) : 6;
+    int m_conv_split_order = std::getenv("SANM_CONV_SPLIT_ORDER") ? std::atoi(std::getenv("SANM_CONV_SPLIT_ORDER")) : 4;
     PcgScalars* m_pcg_sc_host = nullptr;
     size_t m_pcg_n = 0;
     bool m_time_passes = false;
