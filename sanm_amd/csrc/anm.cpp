@@ -536,6 +536,9 @@ void AnmDriver::solve_expansion_coeffs() {
     double t1 = 0, xgt_dot_x1 = 0;
     const double* grad_t = nullptr;
     const int32_t* rhs_perm = nullptr;
+    // COEFF(i) and BIAS(i+1) are back to back: one launch among the kernels compiled for this graph
+    const bool fuse_passes = P.spec_id >= 0 && !std::getenv("SANM_NO_FUSED_PASS");
+    bool bias_done = false;
     for (int i = 1; i <= N; ++i) {
         if (i == 1) {
             ScopedTimer t{this, "jacobian"};
@@ -543,7 +546,7 @@ void AnmDriver::solve_expansion_coeffs() {
         }
         {
             ScopedTimer t{this, "taylor_next_order"};
-            be->run_pass(P, PASS_BIAS, i, nullptr);
+            if (!bias_done) be->run_pass(P, PASS_BIAS, i, nullptr);
             // (orders >= 2, single rank: remap_out drops b_i where the direct solver reads its right-hand side)
             rhs_perm = (i > 1 && !m_shard.active()) ? m_solver->rhs_perm() : nullptr;
             be->gather_rows(m_remap_out->dev(), m_prog->out_bias(), m_bi.p(), rhs_perm,
@@ -615,7 +618,8 @@ void AnmDriver::solve_expansion_coeffs() {
         }
         if (i < N) {
             ScopedTimer t{this, "taylor_push"};
-            be->run_pass(P, PASS_COEFF, i, xi);
+            be->run_pass(P, fuse_passes ? PASS_COEFF_BIAS : PASS_COEFF, i, xi);
+            bias_done = fuse_passes;
         }
     }
     be->sync();

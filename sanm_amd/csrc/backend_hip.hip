@@ -683,7 +683,7 @@ class HipBackend final : public Backend {
     // pass kernels compiled at run time for one program each (specialize)
     struct SpecKernels {
         hipModule_t mod = nullptr;
-        hipFunction_t pass[4] = {nullptr, nullptr, nullptr, nullptr};
+        hipFunction_t pass[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     };
     std::vector<SpecKernels> m_spec;
     GridRed m_red{nullptr, nullptr, nullptr};
@@ -805,7 +805,7 @@ public:
             std::fprintf(stderr, "sanm_hip: could not load the compiled pass kernels, using the interpreter kernels\n");
             return -1;
         }
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < 5; ++m) {
             const std::string name = "spec_pass" + std::to_string(m);
             if (hipModuleGetFunction(&k.pass[m], k.mod, name.c_str()) != hipSuccess) {
                 (void)hipModuleUnload(k.mod);
@@ -835,16 +835,22 @@ public:
         }
         // convolutions of an order-k bias have k-1 terms: worth splitting over wavefronts once they
         // outweigh the two barriers per operator
-        int nparts = (mode == PASS_BIAS && order >= m_conv_split_order) ? m_conv_parts : 1;
+        // (the fused pass runs BIAS(order + 1))
+        int nparts = ((mode == PASS_BIAS && order >= m_conv_split_order) ||
+                      (mode == PASS_COEFF_BIAS && order + 1 >= m_conv_split_order))
+                             ? m_conv_parts
+                             : 1;
         const size_t lds = (size_t)(P.cur_size + (nparts - 1) * 9) * 64 * sizeof(double);
         if (lds > 160 * 1024) sanm_throw(SANM_ERR_UNSUPPORTED, "graph too large for the LDS scratch");
-        void (*kern)(ProgramDev, const OpDesc*, const VarDesc*, int, const double*) = nullptr;
-        switch (mode) {
-            case PASS_EVAL0: kern = taylor_pass_kernel<PASS_EVAL0, 1>; break;
-            case PASS_GRAD: kern = taylor_pass_kernel<PASS_GRAD, 1>; break;
-            case PASS_BIAS: kern = taylor_pass_kernel<PASS_BIAS, kBiasWaves>; break;
-            case PASS_COEFF: kern = taylor_pass_kernel<PASS_COEFF, 1>; break;
-            default: sanm_throw(SANM_ERR_ASSERT, "unknown pass mode %d", mode);
+        if (mode == PASS_COEFF_BIAS && (P.spec_id < 0 || lds > 48 * 1024)) {
+            // the fused pass exists among the kernels compiled per graph only: two launches otherwise
+            if (m_time_passes) {
+                (void)hipEventDestroy(e0);
+                (void)hipEventDestroy(e1);
+            }
+            run_pass(P, PASS_COEFF, order, xvec);
+            run_pass(P, PASS_BIAS, order + 1, nullptr);
+            return;
         }
         if (P.spec_id >= 0 && lds <= 48 * 1024) {
             // this program's own kernels (same grid, same LDS layout as the interpreter's)
@@ -863,6 +869,14 @@ public:
                 m_pass_events.emplace_back(e0, e1);
             }
             return;
+        }
+        void (*kern)(ProgramDev, const OpDesc*, const VarDesc*, int, const double*) = nullptr;
+        switch (mode) {
+            case PASS_EVAL0: kern = taylor_pass_kernel<PASS_EVAL0, 1>; break;
+            case PASS_GRAD: kern = taylor_pass_kernel<PASS_GRAD, 1>; break;
+            case PASS_BIAS: kern = taylor_pass_kernel<PASS_BIAS, kBiasWaves>; break;
+            case PASS_COEFF: kern = taylor_pass_kernel<PASS_COEFF, 1>; break;
+            default: sanm_throw(SANM_ERR_ASSERT, "unknown pass mode %d", mode);
         }
         if (lds > m_pass_lds_limit[mode]) {
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

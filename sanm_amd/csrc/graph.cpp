@@ -539,6 +539,14 @@ extern "C" __global__ void __launch_bounds__(256, 1) spec_pass1(ProgramDev P, in
 extern "C" __global__ void __launch_bounds__(256, 3) spec_pass2(ProgramDev P, int order, const double* xvec) {
     spec_body<PASS_BIAS>(P, order, xvec);
 }
+// COEFF(order) by wavefront 0 of every workgroup, then BIAS(order + 1) by all of them (PASS_COEFF_BIAS)
+extern "C" __global__ void __launch_bounds__(256, 3) spec_pass4(ProgramDev P, int order, const double* xvec) {
+    if ((threadIdx.x >> 6) == 0) spec_body<PASS_COEFF>(P, order, xvec);
+    // the coefficients just stored are history for the other wavefronts' slices of the convolutions
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    spec_body<PASS_BIAS>(P, order + 1, xvec);
+}
 extern "C" __global__ void __launch_bounds__(256, 1) spec_pass3(ProgramDev P, int order, const double* xvec) {
     spec_body<PASS_COEFF>(P, order, xvec);
 }

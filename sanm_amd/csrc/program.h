@@ -42,6 +42,9 @@ enum PassMode : int32_t {
     PASS_GRAD = 1,   // ensure_jacobian reverse sweep, symbolic.cpp:206-247
     PASS_BIAS = 2,   // compute_next_order_bias, symbolic.cpp:249-289
     PASS_COEFF = 3,  // push_xi at order >= 1, symbolic.cpp:177-178
+    // COEFF(k) then BIAS(k+1) in one launch: the two are back to back in the order loop.  Only among the kernels
+    // compiled per graph (ProgramDev::spec_id >= 0).
+    PASS_COEFF_BIAS = 4,
 };
 
 constexpr int OP_FLAG_IS_LEFT = 1;         // MATINVMUL: Y X = A

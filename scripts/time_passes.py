@@ -14,3 +14,7 @@ names = {0: "EVAL0", 1: "GRAD", 2: "BIAS", 3: "COEFF"}
 print("EVAL0 %.1f us  GRAD %.1f us" % (s.time_kernel(0, 50, 0, 0) * 1e3, s.time_kernel(0, 50, 1, 0) * 1e3))
 for mode in (2, 3):
     print(names[mode], " ".join("%.0f" % (s.time_kernel(0, 50, mode, k) * 1e3) for k in range(1, 21 if mode == 2 else 20)))
+try:
+    print("COEFF(k)+BIAS(k+1) fused", " ".join("%.0f" % (s.time_kernel(0, 50, 4, k) * 1e3) for k in range(1, 20)))
+except Exception as e:  # interpreter kernels only: no fused pass
+    print("fused pass:", e)
