@@ -620,12 +620,8 @@ void Program::download_jacobian(double* dst) const {
     const VarDesc& d = m_vars[m_placeholder_var];
     const int64_t T = m_dev.T, Tpad = m_dev.Tpad;
     const int odim = m_dev.odim;
-    std::vector<double> soa((size_t)odim * d.size * Tpad);
-    m_be->d2h(soa.data(), m_dev.arena + d.jac, soa.size() * sizeof(double));
-    for (int64_t e = 0; e < T; ++e)
-        for (int r = 0; r < odim; ++r)
-            for (int c = 0; c < d.size; ++c)
-                dst[(e * odim + r) * d.size + c] = soa[((size_t)r * d.size + c) * Tpad + e];
+    (void)Tpad;
+    m_be->d2h(dst, m_dev.arena + d.jac, (size_t)T * odim * d.size * sizeof(double));  // tet-major already
 }
 
 }  // namespace sanm_hip

@@ -55,7 +55,7 @@ constexpr int MAX_OP_IN = 4;
 struct VarDesc {
     int64_t coef;  // arena offset of coefficient 0; order k at coef + k*size*Tpad
     int64_t bias;  // arena offset of cur_order_bias
-    int64_t jac;   // arena offset of the Jacobian [odim][size][Tpad]: the placeholder only; -1 otherwise
+    int64_t jac;   // arena offset of the Jacobian, tet-major [Tpad][odim][size]: the placeholder only; -1 otherwise
     int32_t size;  // 1 (batched scalar), 3 (singular values) or 9 (3x3)
     int32_t is_const;  // coefficients of order >= 1 are identically zero
     int32_t cur;       // offset (in doubles) of the current-order value in the per-lane scratch

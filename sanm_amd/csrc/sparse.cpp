@@ -113,7 +113,8 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
                     for (int m = 0; m < idim; ++m) {
                         uint64_t irow = b * idim + m;
                         const bool mine = (int64_t)b >= tet_begin && (int64_t)b < tet_end;
-                        uint64_t jidx = mine ? ((uint64_t)o * idim + m) * Tpad + (b - tet_begin) : 0;
+                        // (index into the placeholder's Jacobian, tet-major [T][odim][idim])
+                        uint64_t jidx = mine ? (uint64_t)(b - tet_begin) * odim * idim + o * idim + m : 0;
                         sanm_check(jidx < std::numeric_limits<uint32_t>::max(), "mesh too large for u32 jidx");
                         for (uint64_t q = ri.rowptr[irow]; q < ri.rowptr[irow + 1]; ++q)
                             row.push_back({(uint32_t)ri.idx[q], (uint32_t)jidx, c_out * ri.coef[q], mine});

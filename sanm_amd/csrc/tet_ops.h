@@ -93,7 +93,6 @@ SANM_HD double* p_coef(const TetCtx& c, int v, int k) {
     return c.arena + d.coef + (int64_t)k * d.size * c.Tpad + c.tet;
 }
 SANM_HD double* p_bias(const TetCtx& c, int v) { return c.arena + c.vars[v].bias + c.tet; }
-SANM_HD double* p_jac(const TetCtx& c, int v) { return c.arena + c.vars[v].jac + c.tet; }
 SANM_HD double* p_aux(const TetCtx& c, int64_t off) { return c.arena + off + c.tet; }
 // value pointer of the "current" term: bias buffer (BIAS pass) or coef[k]
 SANM_HD double* p_cur(const TetCtx& c, int v, bool in_coeff) {
@@ -1011,8 +1010,10 @@ SANM_HD void op_placeholder(const TetCtx& c, const OpDesc& o, int mode, const Re
     const int ov = o.out[0];
     if (mode == PASS_GRAD) {
         // the end of the reverse sweep: row grow of d(out)/d(placeholder), what the assembly gathers
-        double* j = p_jac(c, ov) + (int64_t)c.grow * 9 * s;
-        for (int e = 0; e < 9; ++e) j[e * s] = jget(c, ov, c.grow, e);
+        // (tet-major [T][9][9]: the contributions to one Jacobian entry come from a few tets and from up to 9
+        // entries of each; tet-major those share cache lines)
+        double* j = c.arena + c.vars[ov].jac + c.tet * 81 + c.grow * 9;
+        for (int e = 0; e < 9; ++e) j[e] = jget(c, ov, c.grow, e);
         return;
     }
     double X[9];
