@@ -486,7 +486,12 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
     m_tmp0 = DVec{be, n1};
     m_tmp1 = DVec{be, n1};
     m_dev_scalars = DVec{be, (size_t)hp.order + 2};
-    m_host_scalars = be->alloc_host(3 * ((size_t)hp.order + 2));
+    // per order: t_i, then (after all of them) the two results of its sanity check
+    m_host_scalars = be->alloc_host(5 * ((size_t)hp.order + 2));
+    if (hp.sanity_check) {
+        m_bi_all.resize(hp.order + 1);
+        for (int i = 1; i <= hp.order; ++i) m_bi_all[i] = DVec{be, (size_t)m_n};
+    }
     m_xt_coeffs.resize(hp.order + 1);
     for (auto& v : m_xt_coeffs) v = DVec{be, n1};
 }
@@ -539,7 +544,10 @@ void AnmDriver::solve_expansion_coeffs() {
     // COEFF(i) and BIAS(i+1) are back to back: one launch among the kernels compiled for this graph
     const bool fuse_passes = P.spec_id >= 0 && !std::getenv("SANM_NO_FUSED_PASS");
     bool bias_done = false;
+    double* const host_sanity = m_host_scalars + 3 * ((size_t)N + 2);  // [2 (i-1)], [2 (i-1) + 1]
     for (int i = 1; i <= N; ++i) {
+        // (with the checks on, every order keeps its b_i: they are all verified in one pass after the loop)
+        double* const bi = m_hp.sanity_check ? m_bi_all[i].p() : m_bi.p();
         if (i == 1) {
             ScopedTimer t{this, "jacobian"};
             be->run_pass(P, PASS_GRAD, 0, nullptr);
@@ -549,10 +557,10 @@ void AnmDriver::solve_expansion_coeffs() {
             if (!bias_done) be->run_pass(P, PASS_BIAS, i, nullptr);
             // (orders >= 2, single rank: remap_out drops b_i where the direct solver reads its right-hand side)
             rhs_perm = (i > 1 && !m_shard.active()) ? m_solver->rhs_perm() : nullptr;
-            be->gather_rows(m_remap_out->dev(), m_prog->out_bias(), m_bi.p(), rhs_perm,
+            be->gather_rows(m_remap_out->dev(), m_prog->out_bias(), bi, rhs_perm,
                             rhs_perm ? m_solver->rhs_work() : nullptr);
             // the one collective per Taylor order: sum of the per-shard nodal bias (n doubles)
-            if (i > 1) allreduce(m_bi.p(), n);
+            if (i > 1) allreduce(bi, n);
         }
         // Orders >= 2 queue their kernels without ever waiting for the device: t_i is formed on the
         // device from the reduction's result (next_coeff_async), lands in x_i[n] for the kernels that need
@@ -582,7 +590,7 @@ void AnmDriver::solve_expansion_coeffs() {
                 ScopedTimer t{this, "sparse_solve"};
                 m_solver->solve(grad_t, m_xgt.p());
             }
-            xbi = m_bi.p();  // zero at first order (anm.cpp:235)
+            xbi = bi;  // zero at first order (anm.cpp:235)
             t1 = ti = 1.0 / std::sqrt(be->dot(n, m_xgt.p(), m_xgt.p()) + 1.0);
             // x_1 = -t1*xgt - xbi ; t_1 appended  (anm.cpp:261-264)
             be->axpby_tail(n, -ti, m_xgt.p(), -1.0, xbi, xi, ti);
@@ -595,7 +603,7 @@ void AnmDriver::solve_expansion_coeffs() {
                 if (rhs_perm) {  // ... and the solver's last kernel forms xb_i . x_1 on the way out
                     m_solver->solve_fused(nullptr, m_xbi.p(), m_xt_coeffs[1].p(), m_dev_scalars.p() + i);
                 } else {
-                    m_solver->solve(m_bi.p(), m_xbi.p());
+                    m_solver->solve(bi, m_xbi.p());
                     be->dot_async(n, m_xbi.p(), m_xt_coeffs[1].p(), m_dev_scalars.p() + i);
                 }
             }
@@ -605,14 +613,8 @@ void AnmDriver::solve_expansion_coeffs() {
         }
         m_nr_valid_coeffs = i + 1;
 
-        if (m_hp.sanity_check) {
-            // anm.cpp:271-285; results are examined after the loop
-            ScopedTimer t{this, "anm_sanity_check"};
-            be->sanity_check_async(m_pattern->csr(), xi, grad_t, m_bi.p(), 1e-4, n1, m_xt_coeffs[1].p(),
-                                   m_tmp0.p(), m_tmp1.p(), m_host_scalars + 3 * i + 1);
-        }
         if (m_hp.profile) {
-            trace_b_norm.push_back(std::sqrt(be->dot(n, m_bi.p(), m_bi.p())));
+            trace_b_norm.push_back(std::sqrt(be->dot(n, bi, bi)));
             trace_x_norm.push_back(std::sqrt(be->dot(n1, xi, xi)));
             trace_t.push_back(m_host_scalars[3 * i]);  // valid: the dot above synchronised
         }
@@ -621,6 +623,18 @@ void AnmDriver::solve_expansion_coeffs() {
             be->run_pass(P, fuse_passes ? PASS_COEFF_BIAS : PASS_COEFF, i, xi);
             bias_done = fuse_passes;
         }
+    }
+    if (m_hp.sanity_check) {
+        // anm.cpp:271-285: A x_i = -(t_i g_t + b_i) and x_1 . x_i = delta_1i for every order, in one pass over the
+        // matrix per 8 orders (the reference checks each order as it goes; a failure surfaces after the loop here)
+        ScopedTimer t{this, "anm_sanity_check"};
+        std::vector<const double*> xs(N), bs(N);
+        for (int i = 1; i <= N; ++i) {
+            xs[i - 1] = m_xt_coeffs[i].p();
+            bs[i - 1] = m_bi_all[i].p();
+        }
+        be->sanity_check_batch_async(m_pattern->csr(), N, xs.data(), grad_t, bs.data(), 1e-4, n1, m_xt_coeffs[1].p(),
+                                     m_tmp0.p(), m_tmp1.p(), host_sanity);
     }
     be->sync();
     for (int i = 1; i <= N; ++i) {
@@ -631,7 +645,7 @@ void AnmDriver::solve_expansion_coeffs() {
             sanm_throw(SANM_ERR_NUMERICAL, "non-finite right-hand side / solution at order %d", i);
         m_t_coeffs.push_back(ti);
         if (m_hp.sanity_check) {
-            const double ex = m_host_scalars[3 * i + 1], xdot = m_host_scalars[3 * i + 2];
+            const double ex = host_sanity[2 * (i - 1)], xdot = host_sanity[2 * (i - 1) + 1];
             sanm_check(ex < 0, "ANM check coeff eqn: order %d: excess %g", i, ex);
             if (i == 1) sanm_check(std::fabs(xdot - 1) < 1e-4, "xdot=%g", xdot);
             else sanm_check(std::fabs(xdot) < 1e-4, "i=%d: xdot=%g", i, xdot);

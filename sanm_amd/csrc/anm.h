@@ -191,6 +191,7 @@ protected:
     double m_t_max = 0, m_t_max_a = 0;
     std::unique_ptr<PadeApproximation> m_pade;
     DVec m_fx0, m_bi, m_xbi, m_xgt, m_grad_t_buf, m_tmp0, m_tmp1;
+    std::vector<DVec> m_bi_all;  // b_i of every order, kept for the checks after the order loop (sanity_check)
     PadeWorkspace m_pade_ws;
     DVec m_dev_scalars;                // per order: xb_i . x_1 (consumed on the device)
     double* m_host_scalars = nullptr;  // pinned, per order: t_i, sanity excess, sanity x-dot

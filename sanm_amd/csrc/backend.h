@@ -200,6 +200,15 @@ public:
     virtual void sanity_check_async(const CsrDev& A, const double* xi, const double* grad_t, const double* bi,
                                     double eps, size_t n1, const double* x1, double* tmp0, double* tmp1,
                                     double* out2) = 0;
+    //! The checks of `nvec` orders at once: out[2q], out[2q+1] as sanity_check_async for (xs[q], bs[q]).  The
+    //! matrix is read once for all of them instead of once per order (the order loop examines the results after
+    //! its last order anyway).  `out` as in sanity_check_async (memory the host can read after a sync).
+    virtual void sanity_check_batch_async(const CsrDev& A, int nvec, const double* const* xs, const double* grad_t,
+                                          const double* const* bs, double eps, size_t n1, const double* x1,
+                                          double* tmp0, double* tmp1, double* out) {
+        for (int q = 0; q < nvec; ++q)
+            sanity_check_async(A, xs[q], grad_t, bs[q], eps, n1, x1, tmp0, tmp1, out + 2 * q);
+    }
     //! like allclose_excess for check_t0v_match (anm.cpp:343-360): a + b*t0 vs 0
     virtual double t0v_excess(size_t n, const double* fx, const double* v, double t0, double tol) = 0;
 };
