@@ -626,7 +626,7 @@ void AnmDriver::solve_expansion_coeffs() {
     }
     if (m_hp.sanity_check) {
         // anm.cpp:271-285: A x_i = -(t_i g_t + b_i) and x_1 . x_i = delta_1i for every order, in one pass over the
-        // matrix per 8 orders (the reference checks each order as it goes; a failure surfaces after the loop here)
+        // matrix per 10 orders (the reference checks each order as it goes; a failure surfaces after the loop here)
         ScopedTimer t{this, "anm_sanity_check"};
         std::vector<const double*> xs(N), bs(N);
         for (int i = 1; i <= N; ++i) {

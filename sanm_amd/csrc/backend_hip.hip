@@ -557,7 +557,7 @@ __global__ void __launch_bounds__(256) sanity_check_kernel(CsrDev A, const doubl
 
 // ... for up to SANITY_ORDERS orders in one pass over the matrix: the order loop examines the checks after its last
 // order, and a pass over the matrix per order re-reads 15 MB from HBM every time (18 us each, 20 per step)
-constexpr int SANITY_ORDERS = 8;
+constexpr int SANITY_ORDERS = 10;
 struct SanityBatch {
     const double* x[SANITY_ORDERS];
     const double* b[SANITY_ORDERS];
