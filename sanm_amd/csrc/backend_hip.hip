@@ -936,7 +936,8 @@ public:
             m_pass_lds_limit[mode] = lds;
         }
         ProgramDev Pd = P;
-        if (getenv("SANM_DBG_NOPS")) Pd.nops = std::min(P.nops, atoi(getenv("SANM_DBG_NOPS")));
+        // measurement hook (scripts/time_nops.py): the pass truncated after n operators, interpreter kernels only
+        if (const char* e = std::getenv("SANM_DBG_NOPS")) Pd.nops = std::min(P.nops, std::atoi(e));
         hipLaunchKernelGGL(kern, dim3(nblk(P.T, 64), mode == PASS_GRAD ? P.odim : 1), dim3(64 * nparts), lds,
                            m_stream, Pd, P.ops, P.vars, order, xvec);
         HIP_CHECK(hipGetLastError());

@@ -1,4 +1,5 @@
 import sys, os
+os.environ["SANM_NO_JIT"] = "1"  # the truncation hook lives in the interpreter kernels
 import torch
 sys.path.insert(0, "/root/repo")
 import sanm_amd
