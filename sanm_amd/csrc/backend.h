@@ -20,6 +20,13 @@ struct SparseRowsDev {
     const uint32_t* idx;
     const double* coef;
     int64_t nrows;
+    // Rows in triples: when rows 3u, 3u+1, 3u+2 have the same coefficients and index lists that differ by the
+    // constant offsets 0, 3, 6 (the nodal force f_c = sum_tets sum_j P[c][j] N_j: the normal does not depend on c),
+    // one list per triple does: a third of the bytes.  bptr[u] .. bptr[u+1] into bidx / bcoef (the list of row 3u);
+    // nullptr if the matrix does not have that structure.
+    const uint32_t* bptr;
+    const uint32_t* bidx;
+    const double* bcoef;
 };
 
 struct CsrDev {

@@ -129,6 +129,53 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(SparseRowsDev R, const
     }
 }
 
+// remap_out with its rows in triples (SparseRowsDev::bptr): GATHER_LANES lanes per vertex, one list entry feeds the
+// three components (their values sit 3 doubles apart in the tet's block of the tet-major output buffer)
+__global__ void __launch_bounds__(256) gather_rows3_kernel(SparseRowsDev R, const double* __restrict__ src,
+                                                           double* __restrict__ dst,
+                                                           const int32_t* __restrict__ perm,
+                                                           double* __restrict__ dst2) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t u = gid / GATHER_LANES;
+    const int sub = gid % GATHER_LANES;
+    double s[3] = {0, 0, 0};
+    int pm[3] = {0, 0, 0};
+    if (u < R.nrows / 3) {
+        const uint32_t p0 = R.bptr[u], e = R.bptr[u + 1];
+        if (perm && sub == 0) {  // requested with the list, not after the sums
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pm[c] = perm[3 * u + c];
+        }
+        for (uint32_t base = p0; base < e; base += 4 * GATHER_LANES) {  // 4 index -> value chains in flight
+            uint32_t i[4];
+            double c[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t q = base + sub + k * GATHER_LANES, qq = q < e ? q : p0;
+                i[k] = R.bidx[qq];
+                const double cv = R.bcoef[qq];
+                c[k] = q < e ? cv : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s[0] += c[k] * src[i[k]];
+                s[1] += c[k] * src[i[k] + 3];
+                s[2] += c[k] * src[i[k] + 6];
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        for (int off = GATHER_LANES / 2; off > 0; off >>= 1) s[c] += __shfl_down(s[c], off, GATHER_LANES);
+    if (u < R.nrows / 3 && sub == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            dst[3 * u + c] = s[c];
+            if (perm) dst2[pm[c]] = s[c];
+        }
+    }
+}
+
 // CSR assembly: ROW_LANES lanes per non-zero (~25 contributions each)
 __global__ void __launch_bounds__(256) assemble_kernel(AssemblyDev A, const double* __restrict__ jac,
                                                        double* __restrict__ val) {
@@ -967,8 +1014,12 @@ public:
     }
     void gather_rows(const SparseRowsDev& R, const double* src, double* dst, const int32_t* perm,
                      double* dst2) override {
-        hipLaunchKernelGGL(gather_rows_kernel, dim3(nblk((size_t)R.nrows * GATHER_LANES, 256)), dim3(256), 0,
-                           m_stream, R, src, dst, perm, dst2);
+        if (R.bptr)
+            hipLaunchKernelGGL(gather_rows3_kernel, dim3(nblk((size_t)R.nrows / 3 * GATHER_LANES, 256)), dim3(256), 0,
+                               m_stream, R, src, dst, perm, dst2);
+        else
+            hipLaunchKernelGGL(gather_rows_kernel, dim3(nblk((size_t)R.nrows * GATHER_LANES, 256)), dim3(256), 0,
+                               m_stream, R, src, dst, perm, dst2);
         HIP_CHECK(hipGetLastError());
     }
     void assemble(const AssemblyDev& A, const double* jac, double* val) override {

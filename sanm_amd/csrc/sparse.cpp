@@ -1,5 +1,8 @@
 #include "sparse.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 #include <algorithm>
 #include <cstring>
 #include <limits>
@@ -52,13 +55,50 @@ DeviceRows::DeviceRows(Backend* be, const SparseDesc& d, int64_t T, int64_t Tpad
     be->h2d(m_idx, idx.data(), idx.size() * 4);
     be->h2d(m_coef, coef.data(), idx.size() * 8);
     m_dev = {static_cast<uint32_t*>(m_ptr), static_cast<uint32_t*>(m_idx),
-             static_cast<double*>(m_coef), d.out_size};
+             static_cast<double*>(m_coef), d.out_size, nullptr, nullptr, nullptr};
+    // rows in triples?  (SparseRowsDev: same coefficients, indices shifted by 0 / 3 / 6 inside one tet's block)
+    const int64_t nr = d.out_size;
+    bool triples = nr > 0 && nr % 3 == 0;
+    for (int64_t u = 0; triples && u < nr / 3; ++u) {
+        const uint32_t p0 = ptr[3 * u], len = ptr[3 * u + 1] - p0;
+        for (int c = 1; triples && c < 3; ++c) {
+            const uint32_t pc = ptr[3 * u + c];
+            triples = ptr[3 * u + c + 1] - pc == len;
+            for (uint32_t q = 0; triples && q < len; ++q)
+                triples = idx[pc + q] == idx[p0 + q] + 3u * c && coef[pc + q] == coef[p0 + q] && idx[p0 + q] % 9 < 3;
+        }
+    }
+    if (std::getenv("SANM_DEBUG"))
+        std::fprintf(stderr, "remap_out: %ld rows, %zu entries, rows in triples: %s\n", (long)nr, idx.size(), triples ? "yes" : "no");
+    if (triples) {
+        std::vector<uint32_t> bptr(nr / 3 + 1, 0), bidx;
+        std::vector<double> bcoef;
+        for (int64_t u = 0; u < nr / 3; ++u) {
+            bidx.insert(bidx.end(), idx.begin() + ptr[3 * u], idx.begin() + ptr[3 * u + 1]);
+            bcoef.insert(bcoef.end(), coef.begin() + ptr[3 * u], coef.begin() + ptr[3 * u + 1]);
+            bptr[u + 1] = bidx.size();
+        }
+        m_bptr = be->alloc(bptr.size() * 4);
+        m_bidx = be->alloc(std::max<size_t>(bidx.size(), 1) * 4);
+        m_bcoef = be->alloc(std::max<size_t>(bidx.size(), 1) * 8);
+        be->h2d(m_bptr, bptr.data(), bptr.size() * 4);
+        be->h2d(m_bidx, bidx.data(), bidx.size() * 4);
+        be->h2d(m_bcoef, bcoef.data(), bidx.size() * 8);
+        m_dev.bptr = static_cast<uint32_t*>(m_bptr);
+        m_dev.bidx = static_cast<uint32_t*>(m_bidx);
+        m_dev.bcoef = static_cast<double*>(m_bcoef);
+    }
 }
 
 DeviceRows::~DeviceRows() {
     m_be->free(m_ptr);
     m_be->free(m_idx);
     m_be->free(m_coef);
+    if (m_bptr) {
+        m_be->free(m_bptr);
+        m_be->free(m_bidx);
+        m_be->free(m_bcoef);
+    }
 }
 
 template <class T>

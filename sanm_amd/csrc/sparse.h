@@ -46,6 +46,7 @@ private:
     Backend* m_be;
     SparseRowsDev m_dev{};
     void *m_ptr = nullptr, *m_idx = nullptr, *m_coef = nullptr;
+    void *m_bptr = nullptr, *m_bidx = nullptr, *m_bcoef = nullptr;  // rows in triples (SparseRowsDev)
 };
 
 class JacobianPattern {
