@@ -99,6 +99,13 @@ public:
         if (bad)
             sanm_throw(SANM_ERR_NUMERICAL, "multifrontal LU: %d zero pivot(s); the Jacobian is singular", bad);
     }
+    void prepare_async(double* status) override {
+        m_be->mf_factor_async(m_mf.dev(), m_mf.schedule(), m_pat.csr(), status);
+    }
+    void check_prepared(const double* status) override {
+        if (*status != 0)
+            sanm_throw(SANM_ERR_NUMERICAL, "multifrontal LU: %d zero pivot(s); the Jacobian is singular", (int)*status);
+    }
     void solve(const double* b, double* x) override {
         m_be->mf_solve(m_mf.dev(), m_mf.schedule(), b, x);
         ++nr_solve;
@@ -487,7 +494,7 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
     m_tmp1 = DVec{be, n1};
     m_dev_scalars = DVec{be, (size_t)hp.order + 2};
     // per order: t_i, then (after all of them) the two results of its sanity check
-    m_host_scalars = be->alloc_host(5 * ((size_t)hp.order + 2));
+    m_host_scalars = be->alloc_host(5 * ((size_t)hp.order + 2) + 8);
     if (hp.sanity_check) {
         m_bi_all.resize(hp.order + 1);
         for (int i = 1; i <= hp.order; ++i) m_bi_all[i] = DVec{be, (size_t)m_n};
@@ -545,6 +552,9 @@ void AnmDriver::solve_expansion_coeffs() {
     const bool fuse_passes = P.spec_id >= 0 && !std::getenv("SANM_NO_FUSED_PASS");
     bool bias_done = false;
     double* const host_sanity = m_host_scalars + 3 * ((size_t)N + 2);  // [2 (i-1)], [2 (i-1) + 1]
+    // asynchronous results examined after the loop: non-finite Jacobian entries, rejected pivots, |x_1|^2, |x_N|^2
+    double* const host_checks = m_host_scalars + 5 * ((size_t)N + 2);
+    host_checks[0] = host_checks[1] = 0;
     for (int i = 1; i <= N; ++i) {
         // (with the checks on, every order keeps its b_i: they are all verified in one pass after the loop)
         double* const bi = m_hp.sanity_check ? m_bi_all[i].p() : m_bi.p();
@@ -578,13 +588,13 @@ void AnmDriver::solve_expansion_coeffs() {
                                  m_grad_t_buf.p());
                 allreduce(m_pattern->csr().val, m_pattern->nnz());
                 if (m_pattern->has_t()) allreduce(m_grad_t_buf.p(), n);
-                sanm_check(be->count_nonfinite(m_pattern->nnz(), m_pattern->csr().val) == 0,
-                           "non-finite Jacobian coefficient");  // sparse_solver.cpp:288-289
+                // sparse_solver.cpp:288-289: the coefficients must be finite (examined after the loop)
+                be->count_nonfinite_async(m_pattern->nnz(), m_pattern->csr().val, host_checks);
             }
             grad_t = get_grad_t();
             {
                 ScopedTimer t{this, "sparse_prep"};
-                m_solver->prepare();
+                m_solver->prepare_async(host_checks + 1);
             }
             {
                 ScopedTimer t{this, "sparse_solve"};
@@ -636,7 +646,12 @@ void AnmDriver::solve_expansion_coeffs() {
         be->sanity_check_batch_async(m_pattern->csr(), N, xs.data(), grad_t, bs.data(), 1e-4, n1, m_xt_coeffs[1].p(),
                                      m_tmp0.p(), m_tmp1.p(), host_sanity);
     }
+    // the two norms of estimate_valid_range travel with the rest
+    be->dot_async(n1, m_xt_coeffs[1].p(), m_xt_coeffs[1].p(), host_checks + 2);
+    be->dot_async(n1, m_xt_coeffs[N].p(), m_xt_coeffs[N].p(), host_checks + 3);
     be->sync();
+    sanm_check(host_checks[0] == 0, "non-finite Jacobian coefficient");
+    m_solver->check_prepared(host_checks + 1);
     for (int i = 1; i <= N; ++i) {
         const double ti = m_host_scalars[3 * i];
         // the reference asserts a finite right-hand side before solving (sparse_solver.cpp:160-161);
@@ -662,8 +677,11 @@ void AnmDriver::estimate_valid_range() {
     // libsanm/anm.cpp:117-154
     const size_t n1 = m_n + 1;
     const int N = m_hp.order;
-    double x1 = std::sqrt(m_be->dot(n1, m_xt_coeffs[1].p(), m_xt_coeffs[1].p()));
-    double xback = std::max(std::sqrt(m_be->dot(n1, m_xt_coeffs[N].p(), m_xt_coeffs[N].p())), 1e-15);
+    // |x_1|, |x_N|: queued at the end of the order loop (solve_expansion_coeffs), here after its synchronisation
+    const double* norms2 = m_host_scalars + 5 * ((size_t)N + 2) + 2;
+    (void)n1;
+    double x1 = std::sqrt(norms2[0]);
+    double xback = std::max(std::sqrt(norms2[1]), 1e-15);
     double a_bound = std::pow(m_hp.maxr / xback * x1, 1.0 / double(N - 1));
     a_bound = std::min(a_bound, m_max_a_bound);
     sanm_check((int)m_t_coeffs.size() == N + 1, "t coefficients incomplete");

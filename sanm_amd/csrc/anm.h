@@ -83,6 +83,13 @@ class LinearSolver {
 public:
     virtual ~LinearSolver() = default;
     virtual void prepare() = 0;                       // after new values were assembled
+    //! the same without waiting for the device: a failure (singular matrix) is reported by check_prepared(),
+    //! to be called after the next synchronisation; `status`: a double the host can read then
+    virtual void prepare_async(double* status) {
+        (void)status;
+        prepare();
+    }
+    virtual void check_prepared(const double* status) { (void)status; }
     virtual void solve(const double* b, double* x) = 0;
     //! Where the solver wants its right-hand side, if the caller can put it there while producing it: entry i
     //! at rhs_work()[rhs_perm()[i]] (null: no such place).  solve_fused(nullptr, ...) then solves for that

@@ -117,6 +117,8 @@ public:
     virtual void csr_inv_diag(const CsrDev& A, double scale, double* d) = 0;
     //! number of non-finite entries
     virtual int64_t count_nonfinite(size_t n, const double* x) = 0;
+    //! the same without waiting: the count lands in *out (memory the host can read after a sync)
+    virtual void count_nonfinite_async(size_t n, const double* x, double* out) { *out = (double)count_nonfinite(n, x); }
     //! max_i ( |a_i - b_i| - eps*max(1, min(|a_i|,|b_i|)) ) ; <0 means allclose
     //! (TensorND::assert_allclose, libsanm/tensor.cpp:670-684)
     virtual double allclose_excess(size_t n, const double* a, const double* b, double eps) = 0;
@@ -138,6 +140,10 @@ public:
     //! scatter + extend-add + blocked partial LU of every front, level by level.
     //! Returns the number of (near-)zero pivots met.
     virtual int mf_factor(const MfDev& mf, const MfSchedule& sch, const CsrDev& A) = 0;
+    //! the same without waiting: the number of rejected pivots lands in *status (as above) once the stream gets there
+    virtual void mf_factor_async(const MfDev& mf, const MfSchedule& sch, const CsrDev& A, double* status) {
+        *status = mf_factor(mf, sch, A);
+    }
     //! x = A^-1 b with the factors of the last mf_factor (b, x: n doubles, may alias)
     virtual void mf_solve(const MfDev& mf, const MfSchedule& sch, const double* b, double* x) = 0;
     //! the same with the two ends of the solve fused into its neighbours in the order loop: b == nullptr means the

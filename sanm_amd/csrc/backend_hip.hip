@@ -548,6 +548,9 @@ __global__ void inv_diag_kernel(CsrDev A, double scale, double* d) {
     if (i < A.n) d[i] = 1.0 / (scale * csr_diag(A, i));
 }
 
+// the pivot counter of a factorisation as a double where the host reads its asynchronous results
+__global__ void status_to_double_kernel(const int32_t* status, double* out) { *out = (double)*status; }
+
 __global__ void __launch_bounds__(256) nonfinite_kernel(size_t n, const double* x, GridRed g) {
     double s[1] = {0};
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -1090,6 +1093,30 @@ public:
 
     // ---- multifrontal LU (mf_kernels.h) ---------------------------------------
     int mf_factor(const MfDev& mf, const MfSchedule& sch, const CsrDev& A) override {
+        mf_factor_launch(mf, sch, A);
+        int32_t* hs = reinterpret_cast<int32_t*>(m_scalar_host);
+        HIP_CHECK(hipMemcpyAsync(hs, mf.status, sizeof(int32_t), hipMemcpyDeviceToHost, m_stream));
+        HIP_CHECK(hipStreamSynchronize(m_stream));
+#ifdef SANM_MF_PHASES
+        mf_print_phases();
+#endif
+        return *hs;
+    }
+    void mf_factor_async(const MfDev& mf, const MfSchedule& sch, const CsrDev& A, double* status) override {
+        mf_factor_launch(mf, sch, A);
+        hipLaunchKernelGGL(status_to_double_kernel, dim3(1), dim3(1), 0, m_stream, mf.status, status);
+        HIP_CHECK(hipGetLastError());
+    }
+#ifdef SANM_MF_PHASES
+    void mf_print_phases() {
+        unsigned long long ph[8];
+        HIP_CHECK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(mfk::g_phase), sizeof(ph)));
+        std::fprintf(stderr, "update_kernel, diagonal workgroup, 10 ns ticks: load %.0f  panel solves %.0f  tile update %.0f  "
+                     "tile LU %.0f  store %.0f  (%llu launches)\n", (double)ph[0] / ph[7], (double)ph[1] / ph[7],
+                     (double)ph[2] / ph[7], (double)ph[3] / ph[7], (double)ph[4] / ph[7], ph[7]);
+    }
+#endif
+    void mf_factor_launch(const MfDev& mf, const MfSchedule& sch, const CsrDev& A) {
         using namespace mfk;
         HIP_CHECK(hipMemsetAsync(mf.front_store, 0, mf.front_store_size * sizeof(double), m_stream));
         HIP_CHECK(hipMemsetAsync(mf.status, 0, sizeof(int32_t), m_stream));
@@ -1161,19 +1188,6 @@ public:
             }
         }
         HIP_CHECK(hipGetLastError());
-        int32_t* hs = reinterpret_cast<int32_t*>(m_scalar_host);
-        HIP_CHECK(hipMemcpyAsync(hs, mf.status, sizeof(int32_t), hipMemcpyDeviceToHost, m_stream));
-        HIP_CHECK(hipStreamSynchronize(m_stream));
-#ifdef SANM_MF_PHASES
-        {
-            unsigned long long ph[8];
-            HIP_CHECK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(mfk::g_phase), sizeof(ph)));
-            std::fprintf(stderr, "update_kernel, diagonal workgroup, 10 ns ticks: load %.0f  panel solves %.0f  tile update %.0f  "
-                         "tile LU %.0f  store %.0f  (%llu launches)\n", (double)ph[0] / ph[7], (double)ph[1] / ph[7],
-                         (double)ph[2] / ph[7], (double)ph[3] / ph[7], (double)ph[4] / ph[7], ph[7]);
-        }
-#endif
-        return *hs;
     }
 
     // Level solve kernels are instantiated for R rows per wave and U preloaded 64-column chunks per row
@@ -1405,6 +1419,10 @@ public:
     void csr_inv_diag(const CsrDev& A, double scale, double* d) override {
         hipLaunchKernelGGL(inv_diag_kernel, dim3(nblk(A.n, 256)), dim3(256), 0, m_stream, A, scale,
                            d);
+        HIP_CHECK(hipGetLastError());
+    }
+    void count_nonfinite_async(size_t n, const double* x, double* out) override {
+        hipLaunchKernelGGL(nonfinite_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, red_to(out));
         HIP_CHECK(hipGetLastError());
     }
     int64_t count_nonfinite(size_t n, const double* x) override {
