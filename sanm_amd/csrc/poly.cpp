@@ -96,7 +96,9 @@ bool real_roots(const std::vector<double>& f, std::vector<double>& roots) {
     // monic, long double for a little headroom.  Complex arithmetic is spelt out on the components: the
     // library's std::complex<long double> operators go through the overflow / NaN recovery paths of
     // __mulxc3 / __divxc3 and made this loop 4x slower (0.53 -> 0.13 ms at degree 19) -- the GPU waits for it once per continuation step.
-    using ld = long double;
+    // (double, not long double: x87 arithmetic made the iteration 3x slower, and the caller -- the pole bound of the
+    // Pade range -- needs the real roots to a few digits)
+    using ld = double;
     struct cd {
         ld re, im;
     };
@@ -110,21 +112,21 @@ bool real_roots(const std::vector<double>& f, std::vector<double>& roots) {
     for (int i = 0; i <= n; ++i) a[i] = (ld)c[i] / (ld)c[n];
     // Cauchy bound based start radius
     ld radius = 0;
-    for (int i = 0; i < n; ++i) radius = std::max(radius, std::pow(std::fabs(a[i]), 1.0L / (n - i)));
+    for (int i = 0; i < n; ++i) radius = std::max(radius, std::pow(std::fabs(a[i]), 1.0 / (n - i)));
     if (radius == 0) {
         for (int i = 0; i < n; ++i) roots.push_back(0.0);
         return true;
     }
     std::vector<cd> z(n);
     for (int i = 0; i < n; ++i) {
-        ld ang = 2.0L * 3.14159265358979323846264338327950288L * i / n + 0.4L;
+        ld ang = 2.0 * 3.14159265358979323846264338327950288 * i / n + 0.4;
         z[i] = cd{radius * std::cos(ang), radius * std::sin(ang)};
     }
     bool converged = false;
-    for (int it = 0; it < 2000 && !converged; ++it) {
+    for (int it = 0; it < 500 && !converged; ++it) {
         ld maxstep = 0;
         for (int i = 0; i < n; ++i) {
-            cd p{1.0L, 0.0L}, dp{0.0L, 0.0L};  // Horner for p and p'
+            cd p{1.0, 0.0}, dp{0.0, 0.0};  // Horner for p and p'
             for (int k = n - 1; k >= 0; --k) {
                 dp = mul(dp, z[i]);
                 dp.re += p.re;
@@ -134,7 +136,7 @@ bool real_roots(const std::vector<double>& f, std::vector<double>& roots) {
             }
             if (p.re == 0 && p.im == 0) continue;
             const cd ratio = mul(p, inv(dp));
-            cd sum{0.0L, 0.0L};
+            cd sum{0.0, 0.0};
             for (int j = 0; j < n; ++j)
                 if (j != i) {
                     const cd t = inv(cd{z[i].re - z[j].re, z[i].im - z[j].im});
@@ -142,30 +144,30 @@ bool real_roots(const std::vector<double>& f, std::vector<double>& roots) {
                     sum.im += t.im;
                 }
             const cd rs = mul(ratio, sum);
-            const cd step = mul(ratio, inv(cd{1.0L - rs.re, -rs.im}));
+            const cd step = mul(ratio, inv(cd{1.0 - rs.re, -rs.im}));
             z[i].re -= step.re;
             z[i].im -= step.im;
-            maxstep = std::max(maxstep, cabs(step) / std::max<ld>(cabs(z[i]), 1e-300L));
+            maxstep = std::max(maxstep, cabs(step) / std::max<ld>(cabs(z[i]), 1e-300));
         }
-        if (maxstep < 1e-17L) converged = true;
+        if (maxstep < 1e-14) converged = true;
     }
     if (!converged) {
         // accept if every root has a tiny residual anyway
         for (int i = 0; i < n; ++i) {
-            cd p{1.0L, 0.0L};
-            ld scale = 1.0L;
+            cd p{1.0, 0.0};
+            ld scale = 1.0;
             const ld az = cabs(z[i]);
             for (int k = n - 1; k >= 0; --k) {
                 p = mul(p, z[i]);
                 p.re += a[k];
                 scale = scale * az + std::fabs(a[k]);
             }
-            if (cabs(p) > 1e-10L * scale) return false;
+            if (cabs(p) > 1e-10 * scale) return false;
         }
     }
     for (int i = 0; i < n; ++i) {
-        long double re = z[i].re, im = z[i].im;
-        if (std::fabs(im) <= 1e-8L * std::max<long double>(1.0L, std::fabs(re)))
+        const double re = z[i].re, im = z[i].im;
+        if (std::fabs(im) <= 1e-8 * std::max(1.0, std::fabs(re)))
             roots.push_back((double)re);
     }
     std::sort(roots.begin(), roots.end());
