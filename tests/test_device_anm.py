@@ -193,6 +193,30 @@ def test_specialised_pass_kernels_agree_with_the_interpreter(api, monkeypatch, g
     assert np.abs(x - xr).max() <= 1e-9 * np.abs(xr).max()
 
 
+def test_remap_out_without_the_triple_structure(api):
+    """the FEA builder's remap_out has its rows in triples (equal coefficients for the three force components of a
+    vertex), which the device path exploits with one list per vertex; any other sparse map takes the row-by-row
+    gather.  Scaling the rows of one component (and the load with them) keeps the solution and the continuation
+    but breaks the structure -- and makes the Jacobian unsymmetric: same step count, same solution."""
+    import scipy.sparse as sp
+    gold = json.load(open(os.path.join(GOLD, "anm_cuboid_nc.json")))
+    ref = _run_device(api, gold["dims"], gold["spacing"], gold["config"])
+    run = dfea.GravityRun(api, dfea.make_cuboid(*gold["dims"], gold["spacing"]), dict(gold["config"]),
+                          solver_rtol=1e-15)
+    R = run.model.lt_out.to_scipy()
+    scale = np.ones(R.shape[0])
+    scale[1::3] = 2.0
+    lt_out = A.SparseLinearDesc(api, sp.diags(scale) @ R)
+    run.solver = A.ANMEqnSolver(api, run.model.y, run.model.lt_inp, lt_out, run.model.x0(), run.f_sub * scale,
+                                run.hyper)
+    run.rms = [run.solver.residual_rms()]
+    run.run()
+    assert run.solver.converged()
+    assert run.solver.get_nr_iter() == ref.solver.get_nr_iter() == gold["iter"]
+    x, xr = run.solver.get_x(), ref.solver.get_x()
+    assert np.abs(x - xr).max() <= 1e-8 * np.abs(xr).max()
+
+
 def test_jacobian_of_a_mesh_built_by_several_host_threads(api):
     """the Jacobian pattern / gather lists of more than 4096 unknowns are built by several host threads and
     merged; the assembled matrix must still be the oracle's, entry by entry."""
