@@ -15,8 +15,10 @@ checks on).  The full Armadillo mesh is missing from the reference snapshot
 The continuation runs from the rest state exactly as `fea` does; when a solve
 converges before W+K steps are done, the next solve starts again from the rest
 state on the same solver (sanm_anm_restart), so exactly K completed steps are
-timed.  For N > 1 every rank runs the whole problem on its own GPU (replicas:
-see DESIGN.md "Multi-GPU"), value = N*K / max-over-ranks time.
+timed.  For N > 1 the default is ONE problem whose tets are sharded over the
+ranks (BASELINE config 4: strong scaling, one all-reduce of b_k per Taylor order,
+value = K / max-over-ranks time); `--parallelism replicas` runs N independent
+copies instead (weak scaling, value = N*K / time).  See DESIGN.md "Multi-GPU".
 """
 from __future__ import annotations
 
@@ -42,36 +44,57 @@ def parse(argv=None):
     p.add_argument("--solver-kind", type=int, default=1, help="0: Jacobi-PCG, 1: multifrontal LU")
     p.add_argument("--profile", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-steps", type=int, default=2)
-    p.add_argument("--parallelism", default="replicas", choices=["replicas", "shard"],
-                   help="N>1: independent replicas (weak scaling) or one tet-sharded problem with an "
-                        "RCCL all-reduce of b_k per Taylor order (strong scaling)")
+    p.add_argument("--cpu-seconds", type=float, default=20.0, help="stepping time of the CPU baseline sample")
+    p.add_argument("--parallelism", default="shard", choices=["replicas", "shard"],
+                   help="N>1: one tet-sharded problem with an RCCL all-reduce of b_k per Taylor order (strong "
+                        "scaling, the default: BASELINE config 4) or independent replicas (weak scaling)")
     p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL on ROCm) or gloo (CPU tests)")
+    p.add_argument("--callback-allreduce", action="store_true",
+                   help="shard mode: all-reduce through the C ABI's callback (torch.distributed) instead of the "
+                        "library's own RCCL communicator")
     return p.parse_args(argv)
 
 
-def cpu_baseline(workload, cpu_steps):
-    """The oracle (numpy port of the reference algorithm; MKL PARDISO on one thread for the direct
-    solve when the image has MKL, SuperLU otherwise) timed on the host for `cpu_steps` ANM steps of
-    the same workload."""
-    import numpy as np  # noqa: F401
-    from oracle import fea as ofea
-    from oracle import pardiso
+def cpu_baseline(workload, budget_s=20.0):
+    """The build's own CPU path, timed on this box's host cores: the same C++ host code as the
+    product linked with the CPU backend of tests/hostsim -- tet-sharded worker threads for the Taylor passes and
+    the assembly (libsanm/symbolic.cpp:525-536), serial remaps and BLAS-1 on the main thread, and the reference's
+    own direct solver, MKL PARDISO, bound with dlopen and set up as libsanm/sparse_solver.cpp:107-127 does
+    (mtype 11, iparm[34] = 1, iparm[1] = 3 when threaded, phase 12 at every step, phase 33 per solve).  All host
+    cores the process may use.  Sample: whole solves from the rest state until `budget_s` seconds of stepping
+    are spent; the per-tag breakdown mirrors the reference's ScopedProfiler tags."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    os.environ["SANM_CPU_THREADS"] = str(cores)
+    os.environ.setdefault("MKL_THREADING_LAYER", "GNU")  # libgomp is what this process has loaded already
+    from tests.hostsim import get_hostsim_api
     from sanm_amd import fea as dfea
-    cfg, mesh = dfea.load_named_config(workload)
-    omesh = ofea.TetMesh(mesh.V, mesh.tets, mesh.surface_vtx)
+    capi = get_hostsim_api()
+    cfg, mesh = load_workload(workload)
+    run = dfea.GravityRun(capi, mesh, cfg, solver_kind=2, profile=1)
     t0 = time.perf_counter()
-    model, solver, _ = ofea.make_gravity_solver(omesh, cfg)  # ctor = first step
-    steps = 1
-    while steps < cpu_steps and not solver.converged:
-        solver.next_iter()
-        steps += 1
-    dt = time.perf_counter() - t0
-    return {"value": steps / dt, "unit": "ANM steps/s", "cores": 1, "kind": "port",
-            "sample": f"{steps} ANM step(s) of {workload} (order {cfg.get('order', 20)}) from the rest state, "
-                      f"numpy oracle + {'MKL PARDISO (1 thread)' if pardiso.available() else 'SuperLU'}, "
-                      f"{dt:.1f} s incl. graph/remap setup",
-            "profile": {k: round(v, 3) for k, v in solver.profile.items()}}
+    run.construct()  # builds the tables that depend on the mesh only (untimed) and takes the first step
+    setup_s = time.perf_counter() - t0
+    s = run.solver
+    x0 = run.model.x0()
+    s.set_profile(1)  # clears what the constructor accumulated
+    steps, t_step = 0, 0.0
+    while t_step < budget_s:
+        t0 = time.perf_counter()
+        it0 = s.get_nr_iter()
+        s.restart(x0)
+        while not s.converged() and time.perf_counter() - t0 < 4 * budget_s:
+            s.next_iter()
+        steps += s.get_nr_iter() - it0
+        t_step += time.perf_counter() - t0
+    prof = s.profile()
+    tags = ("taylor_order0", "jacobian", "taylor_next_order", "taylor_push", "remap_out", "build_sparse_coeff",
+            "sparse_prep", "sparse_solve", "anm_sanity_check", "estimate_valid_range", "solve_expansion_coeffs")
+    return {"value": steps / t_step, "unit": "ANM steps/s", "cores": cores, "kind": "port",
+            "impl": "C++ host path of this build (tests/hostsim: worker threads over tet ranges) + MKL PARDISO "
+                    "(dlopen, reference settings)",
+            "sample": f"{steps} ANM steps ({workload}, order {cfg.get('order', 20)}: whole solves from the rest "
+                      f"state) in {t_step:.1f} s on {cores} threads; mesh-only setup {setup_s:.1f} s not counted",
+            "seconds_per_step": {k: round(prof.get(k, 0.0) / max(steps, 1), 4) for k in tags}}
 
 
 def make_api(local_rank):
@@ -106,6 +129,91 @@ def load_workload(name):
     return dfea.load_named_config(name)
 
 
+def metric_name(workload, cfg):
+    """BASELINE.json's metric, with the workload that was actually run"""
+    energy = {"neohookean_c": "Neo-Hookean", "neohookean_i": "Neo-Hookean incompressible",
+              "arap": "ARAP"}.get(cfg["energy_model"], cfg["energy_model"])
+    mesh = {"armadillo_small": "armadillo"}.get(workload, workload)
+    return f"ANM continuation steps/sec ({mesh}, {energy}, order {int(cfg.get('order', 20))})"
+
+
+# kernels of each family (names as rocprofv3 reports them; profiles/*_kernel_stats.md)
+FAMILY_KERNELS = {
+    "solve": "mfk::fwd_level_sub_kernel + mfk::fwd_level_kernel + mfk::bwd_level_kernel + permute_out_dot_kernel",
+    "factor": "mfk::update_kernel + gemm1/gemm2 + extend_add + panel_finalize + diag + scatter",
+    "taylor": "spec_pass* (taylor_pass_kernel: EVAL0, GRAD, COEFF+BIAS per order)",
+    "io": "gather_rows3_kernel (remap_out; remap_in is fused into the Taylor passes)",
+    "asm": "assemble_kernel + nonfinite_kernel",
+    "tail": "sanity_check_multi + Pade (multi_dot, gs_update, scale_rsqrt, lincomb2_diff_norms_multi) + "
+            "next_coeff / dot / lincomb + host root finder",
+}
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: dense fp64 matrix peak
+
+
+def measure_families(run, one_step, cfg, stats, args, nsteps=2):
+    """Two more ANM steps with device events around the phases of solve_expansion_coeffs (profile mode 2:
+    no synchronisation is added).  Returns per-family time, launches, SURVEY 8(d)'s algorithmic bytes and
+    the achieved rate."""
+    s = run.solver
+    n, nnz, T = stats["nr_unknown"], stats["jacobian_nnz"], stats["nr_tet"]
+    N = int(cfg.get("order", 20))
+    s.set_profile(2)
+    s.pass_timing(True, fetch=False)
+    it0 = s.get_nr_iter()
+    t0 = time.perf_counter()
+    while s.get_nr_iter() - it0 < nsteps:
+        one_step()
+    prof = s.profile()  # waits for the device
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    cnt = s.profile_counts()
+    pass_ms, pass_cnt = s.pass_timing(False)
+    s.set_profile(0)
+    k = s.get_nr_iter() - it0
+    g = lambda tag: prof.get(tag, 0.0) * 1e3 / k  # ms per step
+    c = lambda tag: cnt.get(tag, 0.0) / k
+    whole = g("solve_expansion_coeffs")
+    t = {"taylor": g("taylor_order0") + g("jacobian") + g("taylor_next_order") + g("taylor_push") - g("remap_out"),
+         "io": g("remap_out"), "asm": g("build_sparse_coeff"), "factor": g("sparse_prep"),
+         "solve": g("sparse_solve")}
+    t["tail"] = max(whole - sum(t.values()), 0.0)
+    # SURVEY.md 8(d), per ANM step
+    SC = {"neohookean_c": (20, 45), "neohookean_i": (22, 45), "arap": (27, 39)}
+    S_, C_ = SC.get(cfg["energy_model"], (20, 45))
+    fnnz = stats["factor_nnz"]
+    B = {"taylor": 8.0 * T * (S_ * N * (N - 1) / 2 + N * (C_ + S_ + 9)),
+         "io": N * 432.0 * T,
+         "asm": T * (81 + 144 * 2) * 8.0 + nnz * 12.0,
+         "factor": fnnz * 8.0,          # the "1" of nnz(L+U)*8*(1+N)
+         "solve": fnnz * 8.0 * N,       # N solves per step
+         "tail": (2 + 3 * N) * 8.0 * (n + 1) + (2.5 * N * N + 44 * N) * 8.0 * (n + 1) + N * (12.0 * nnz + 16.0 * n)}
+    nlev = stats["nr_level"]
+    launches = {"taylor": pass_cnt / max(k, 1), "io": c("remap_out"), "asm": 2.0,
+                "solve": c("sparse_solve") * (2 * nlev + 1), "factor": None, "tail": None}
+    fam = {}
+    for name in ("solve", "factor", "taylor", "io", "asm", "tail"):
+        ms = t[name]
+        e = {"ms_per_step": ms, "share_of_step": ms / whole if whole > 0 else 0.0, "bound": "hbm",
+             "algorithmic_per_step": B[name], "kernels": FAMILY_KERNELS[name],
+             "achieved": B[name] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+        e["frac"] = e["achieved"] / HBM_PEAK_GBS
+        L = launches[name]
+        e["launches_per_step"] = L
+        e["avg_launch_us"] = ms * 1e3 / L if L else None
+        e["algorithmic_bytes_per_launch"] = B[name] / L if L else None
+        fam[name] = e
+    # the factorisation is dense arithmetic on the fp64 matrix cores: priced in flops
+    f = fam["factor"]
+    f["bound"] = "mfma"
+    f["flops_per_step"] = stats["factor_flops"]
+    f["achieved_tflops"] = stats["factor_flops"] / (f["ms_per_step"] * 1e-3) / 1e12 if f["ms_per_step"] > 0 else 0.0
+    f["peak_tflops"] = FP64_MFMA_PEAK_TFLOPS
+    f["frac_mfma"] = f["achieved_tflops"] / FP64_MFMA_PEAK_TFLOPS
+    if pass_cnt:
+        fam["taylor"]["avg_launch_us_events"] = pass_ms / pass_cnt * 1e3
+    return {"families": fam, "bytes_step": sum(B.values()), "ms_step_measured": whole,
+            "ms_step_wall_measured": wall_ms / max(k, 1)}
+
+
 def main(argv=None):
     args = parse(argv)
     rank = int(os.environ.get("RANK", "0"))
@@ -129,7 +237,12 @@ def main(argv=None):
     shard = None
     if world > 1 and args.parallelism == "shard":
         from sanm_amd import dist as sdist
-        fn = sdist.make_rccl_allreduce() if args.dist_backend == "nccl" else sdist.make_host_allreduce()
+        if args.dist_backend == "nccl" and not args.callback_allreduce:
+            # the library's own RCCL communicator: ncclAllReduce queued on the solver's stream
+            sdist.init_native_comm(api, rank, world)
+            fn = None
+        else:
+            fn = sdist.make_rccl_allreduce() if args.dist_backend == "nccl" else sdist.make_host_allreduce()
         shard = (rank, world, fn)
     run = dfea.GravityRun(api, mesh, cfg, shard=shard, solver_rtol=args.solver_rtol,
                           solver_kind=args.solver_kind, profile=args.profile)
@@ -181,46 +294,34 @@ def main(argv=None):
     stats = run.solver.stats()
     out = None
 
+    # ---- where the step goes: device-event brackets around the phases of two more steps ----------------
+    # Every rank runs them (the sharded solver's collectives need all ranks); rank 0 reports.
+    meas = measure_families(run, one_step, cfg, stats, args)
     if rank == 0:
-        # ---- roofline of the dominant kernel: the Taylor pass (graph interpreter) ---
-        # Measured live with HIP events on the solver's stream over two extra ANM
-        # steps (same launch mix as the timed region: eval0 + grad + N bias + N-1
-        # coefficient passes per step).
         n, nnz, T = stats["nr_unknown"], stats["jacobian_nnz"], stats["nr_tet"]
         N = int(cfg.get("order", 20))
-        run.solver.pass_timing(True, fetch=False)
-        it_before = run.solver.get_nr_iter()
-        while run.solver.get_nr_iter() - it_before < 2:
-            one_step()
-        pass_ms, pass_cnt = run.solver.pass_timing(False)
-        steps_meas = run.solver.get_nr_iter() - it_before
-        avg_ms = pass_ms / max(pass_cnt, 1)
-        # algorithmic bytes (state-streaming model): per tet and step
-        #   8 * [S*N(N-1)/2 + N*(C+S+9)],  S/C = per-order state / per-tet constants
-        SC = {"neohookean_c": (20, 45), "neohookean_i": (22, 45), "arap": (27, 39)}
-        S_, C_ = SC.get(cfg["energy_model"], (20, 45))
-        bytes_step = 8.0 * T * (S_ * N * (N - 1) / 2 + N * (C_ + S_ + 9))
-        launches_step = pass_cnt / max(steps_meas, 1)
-        if pass_cnt > 0 and avg_ms > 0:
-            alg_bytes = bytes_step / launches_step
-            achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        else:  # a backend without event timing (the CPU test harness)
-            alg_bytes, achieved = bytes_step / (2 * N + 1.5), 0.0
-        # HBM-side bytes per launch of that kernel from the committed PMC profile
-        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, corrected per
-        # MI355X_MICROARCH.md; profiles/r01_pmc_traffic.md) -- not collected live
+        ms_per_step = dt / args.steps * 1e3
+        fam = meas["families"]
+        dom = max((k for k in fam if fam[k]["bound"] == "hbm"), key=lambda k: fam[k]["ms_per_step"])
+        d = fam[dom]
+        # HBM-side bytes per launch of the dominant family's kernels from the committed PMC profile
+        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, corrected per MI355X_MICROARCH.md) --
+        # not collected live
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if pmc.get("workload") == args.workload and pmc.get("order") == N:
-                traffic = pmc["kernels"]["taylor_pass_kernel"]["traffic_bytes_per_launch"]
+                traffic = pmc["families"][dom]["traffic_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
+        whole = {"algorithmic_bytes_per_step": meas["bytes_step"],
+                 "achieved": meas["bytes_step"] / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
+                 "frac": meas["bytes_step"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
         out = {
-            "metric": "ANM continuation steps/sec (armadillo, Neo-Hookean, order 20)",
+            "metric": metric_name(args.workload, cfg),
             "value": (1 if shard else world) * args.steps / dt, "unit": "ANM steps/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong" if (shard or world == 1) else "weak", "vs_baseline": None,
             "dtype": "f64",
             "data": ("real mesh Armadillo-small.1 (stand-in for the missing Armadillo.1), rest state"
                      if args.workload == "armadillo_small" else f"workload {args.workload}, rest state"),
@@ -232,17 +333,23 @@ def main(argv=None):
                        "linear_solver": "jacobi-pcg" if args.solver_kind == 0 else "multifrontal-lu",
                        "solver_stats": {k: stats[k] for k in ("factor_nnz", "factor_flops", "nr_front",
                                                               "nr_level", "max_front")},
-                       "profile": run.solver.profile(),
                        "steps_per_solve": state["steps_per_solve"]},
-            "roofline": {"bound": "hbm", "kernel": "taylor_pass_kernel", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "avg_launch_us": avg_ms * 1e3,
-                         "launches_per_step": launches_step,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "algorithmic_bytes_per_step": bytes_step},
+            # the family of kernels the step spends most of its time in (HBM-bound families only; the
+            # factorisation is priced against the fp64 matrix-core peak in roofline_families)
+            "roofline": {"bound": "hbm", "kernel": d["kernels"], "family": dom, "achieved": d["achieved"],
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["achieved"] / HBM_PEAK_GBS,
+                         "traffic": traffic, "avg_launch_us": d["avg_launch_us"],
+                         "launches_per_step": d["launches_per_step"],
+                         "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
+                         "algorithmic_bytes_per_step": d["algorithmic_per_step"],
+                         "share_of_step": d["ms_per_step"] / max(meas["ms_step_measured"], 1e-9)},
+            "roofline_families": fam,
+            "roofline_whole_step": whole,
         }
         if not args.no_cpu_baseline and world == 1 and not args.workload.startswith("block:"):
-            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
+            cb = out["cpu_baseline"]
+            cb["gpu_over_cpu"] = out["value"] / cb["value"] if cb["value"] > 0 else None
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

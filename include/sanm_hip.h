@@ -121,7 +121,8 @@ typedef struct sanm_hyper_param { /* ANMDriverHelper::HyperParam, anm.h:100-114,
     double solver_rtol; /* device linear solver: relative residual target */
     int solver_maxit;
     int solver_kind;    /* 0 = Jacobi-PCG, 1 = multifrontal LU (default) */
-    int profile;        /* sync + time each phase (ScopedProfiler tags, utils.h:225-249) */
+    int profile;        /* 1: sync + host clock around each phase (ScopedProfiler tags, utils.h:225-249);
+                           2: device events around each phase, no synchronisation (bench.py) */
 } sanm_hyper_param;
 void sanm_hyper_param_default(sanm_hyper_param* hp, int eqn_solver);
 
@@ -136,8 +137,18 @@ int sanm_anm_eqn_solver_create(const sanm_graph* g, int out_var, const sanm_spar
  * step) are summed across ranks through `allreduce`, which must perform an in-place
  * sum of `count` doubles at the DEVICE pointer `buf` on all ranks and return 0
  * (ncclAllReduce on RCCL; the linear solve is replicated).  Every rank passes the
- * same graph, remaps, x0 and y. */
+ * same graph, remaps, x0 and y.
+ * With allreduce == NULL the library's own communicator is used (sanm_hip_comm_init below): ncclAllReduce is
+ * queued on the solver's stream and the order loop never waits for the host.  rank/world must then equal the
+ * communicator's.  world == 1 is allowed (the sharded code path on one rank). */
 typedef int (*sanm_allreduce_fn)(void* user, double* buf, int64_t count);
+/* RCCL communicator of this process's device context (one process per GPU; RCCL is loaded with dlopen on first
+ * use).  Rank 0 calls sanm_hip_comm_unique_id (128 bytes = ncclUniqueId) and hands the bytes to every rank by any
+ * out-of-band means; then every rank calls sanm_hip_comm_init, a collective.  Replaces the worker-thread pool of
+ * ParallelTaylorCoeffProp (libsanm/symbolic.cpp:306-590) as the means by which shards exchange results. */
+int sanm_hip_comm_unique_id(void* id, size_t cap);
+int sanm_hip_comm_init(int rank, int world, const void* id, size_t id_bytes);
+int sanm_hip_comm_destroy(void);
 int sanm_anm_eqn_solver_create_sharded(const sanm_graph* g, int out_var,
                                        const sanm_sparse_desc* remap_inp,
                                        const sanm_sparse_desc* remap_out, const double* x0,
@@ -206,6 +217,11 @@ typedef struct sanm_anm_stats {
 int sanm_anm_get_stats(const sanm_anm_solver* s, sanm_anm_stats* st);
 /* profile tags: returns the number of tags; names/seconds may be NULL */
 int sanm_anm_profile(const sanm_anm_solver* s, int max_tags, const char** names, double* seconds);
+/* how many times each tag was entered, in the order of sanm_anm_profile (call that first) */
+int sanm_anm_profile_counts(const sanm_anm_solver* s, int max_tags, double* counts);
+/* switch the phase profile of a live solver (modes as sanm_hyper_param.profile); clear != 0 drops
+ * what was accumulated so far */
+int sanm_anm_set_profile(sanm_anm_solver* s, int mode, int clear);
 /* per-order trace of the last expansion (needs hp.profile): |b_k|, |x_k|, t_k; returns count */
 int sanm_anm_trace(const sanm_anm_solver* s, int max_n, double* b_norm, double* x_norm, double* t);
 /* Jacobian CSR of the current step (SparseSolver contents, sparse_solver.cpp:327-421);

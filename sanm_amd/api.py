@@ -66,6 +66,7 @@ ENERGY = {"neohookean_i": 0, "neohookean_c": 1, "arap": 2, "stvk_stretch": 3}
 # every symbol include/sanm_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "sanm_hip_init", "sanm_hip_last_error", "sanm_hip_backend_name",
+    "sanm_hip_comm_unique_id", "sanm_hip_comm_init", "sanm_hip_comm_destroy",
     "sanm_graph_create", "sanm_graph_destroy", "sanm_graph_placeholder", "sanm_graph_constant",
     "sanm_graph_linear_combine", "sanm_graph_multiply", "sanm_graph_pow", "sanm_graph_log",
     "sanm_graph_reduce_sum", "sanm_graph_batched_matmul", "sanm_graph_batched_mat_inv_mul",
@@ -83,7 +84,7 @@ SYMBOLS = [
     "sanm_anm_update_approx", "sanm_anm_restart", "sanm_anm_spec_source", "sanm_rtc_compile_check", "sanm_anm_time_kernel", "sanm_anm_pass_timing", "sanm_anm_converged", "sanm_anm_residual_rms", "sanm_anm_get_x",
     "sanm_anm_get_t_upper", "sanm_anm_get_t_max_a", "sanm_anm_solve_a", "sanm_anm_eval",
     "sanm_anm_nr_iter", "sanm_anm_nr_xt_coeffs", "sanm_anm_xt_coeff", "sanm_anm_has_pade",
-    "sanm_anm_get_stats", "sanm_anm_profile", "sanm_anm_trace", "sanm_anm_jacobian_csr",
+    "sanm_anm_get_stats", "sanm_anm_profile", "sanm_anm_profile_counts", "sanm_anm_set_profile", "sanm_anm_trace", "sanm_anm_jacobian_csr",
     "sanm_fea_model_create", "sanm_fea_model_destroy", "sanm_fea_model_nr_unknown",
     "sanm_fea_model_graph", "sanm_fea_model_output_var", "sanm_fea_model_F_var",
     "sanm_fea_model_remap_inp", "sanm_fea_model_remap_out", "sanm_fea_model_x0",
@@ -125,6 +126,19 @@ class Api:
         self.check(self.lib.sanm_hip_init(C.c_int(device)))
         self._initialised = True
         return self
+
+    def comm_unique_id(self):
+        """ncclUniqueId (128 bytes) of a new communicator; rank 0 calls this and hands the bytes to all ranks"""
+        buf = C.create_string_buffer(128)
+        self.check(self.lib.sanm_hip_comm_unique_id(buf, C.c_size_t(128)))
+        return buf.raw
+
+    def comm_init(self, rank, world, uid: bytes):
+        """join the library's RCCL communicator (collective over all ranks)"""
+        self.check(self.lib.sanm_hip_comm_init(C.c_int(rank), C.c_int(world), C.c_char_p(uid), C.c_size_t(len(uid))))
+
+    def comm_destroy(self):
+        self.check(self.lib.sanm_hip_comm_destroy())
 
     def backend_name(self):
         return self.lib.sanm_hip_backend_name().decode()
@@ -503,6 +517,17 @@ class _ANMSolver:
         n = self.api.lib.sanm_anm_profile(self.h, C.c_int(n), names, secs)
         return {names[i].decode(): secs[i] for i in range(n)}
 
+    def profile_counts(self):
+        """how often each profile tag was entered (same keys as profile())"""
+        keys = list(self.profile().keys())
+        cnt = (C.c_double * max(len(keys), 1))()
+        n = self.api.lib.sanm_anm_profile_counts(self.h, C.c_int(len(keys)), cnt)
+        return {keys[i]: cnt[i] for i in range(min(n, len(keys)))}
+
+    def set_profile(self, mode, clear=True):
+        """0: off, 1: host clock around synchronised phases, 2: device events (no synchronisation)"""
+        self.api.check(self.api.lib.sanm_anm_set_profile(self.h, C.c_int(mode), C.c_int(1 if clear else 0)))
+
     def trace(self):
         n = self.api.lib.sanm_anm_trace(self.h, C.c_int(0), None, None, None)
         b, x, t = np.zeros(max(n, 1)), np.zeros(max(n, 1)), np.zeros(max(n, 1))
@@ -556,12 +581,18 @@ class ANMEqnSolver(_ANMSolver):
         x0, f_y = _f64(x0).ravel(), _f64(f_y).ravel()
         self.n = x0.size
         self._keep = (y.graph, remap_inp, remap_out)
-        if shard is None or shard[1] <= 1:
+        if shard is None:
             api.check(api.lib.sanm_anm_eqn_solver_create(y.graph.h, C.c_int(y.id), remap_inp.h, remap_out.h,
                                                          _dp(x0), _dp(f_y), C.c_int64(self.n),
                                                          C.byref(hyper), C.byref(self.h)))
             return
         rank, world, fn = shard
+        if fn is None:  # the library's own RCCL communicator (Api.comm_init), all-reduce on the solver's stream
+            self._cb = None
+            api.check(api.lib.sanm_anm_eqn_solver_create_sharded(
+                y.graph.h, C.c_int(y.id), remap_inp.h, remap_out.h, _dp(x0), _dp(f_y), C.c_int64(self.n),
+                C.byref(hyper), C.c_int(rank), C.c_int(world), C.cast(None, ALLREDUCE_FN), None, C.byref(self.h)))
+            return
 
         def _cb(user, ptr, count):
             try:

@@ -17,17 +17,24 @@ class AnmDriver::ScopedTimer {
     std::chrono::steady_clock::time_point m_t0;
 
 public:
+    // mode 1: host clock around a synchronised region (the ScopedProfiler of the reference, utils.h:225-249);
+    // mode 2: device events, no synchronisation (the launch mix of the timed run is undisturbed)
     ScopedTimer(AnmDriver* d, const char* tag) : m_d{d}, m_tag{tag} {
-        if (m_d->m_hp.profile) {
+        if (m_d->m_profile_mode == 1) {
             m_d->m_be->sync();
             m_t0 = std::chrono::steady_clock::now();
+        } else if (m_d->m_profile_mode == 2) {
+            m_d->m_be->phase_begin(tag);
         }
     }
     ~ScopedTimer() {
-        if (m_d->m_hp.profile) {
+        if (m_d->m_profile_mode == 1) {
             m_d->m_be->sync();
             m_d->m_profile[m_tag] +=
                     std::chrono::duration<double>(std::chrono::steady_clock::now() - m_t0).count();
+            m_d->m_profile_cnt[m_tag] += 1;
+        } else if (m_d->m_profile_mode == 2) {
+            m_d->m_be->phase_end();
         }
     }
 };
@@ -440,7 +447,7 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
                      const SparseDesc& remap_out_in, int64_t nr_unknown, const HyperParam& hp,
                      const ShardInfo& shard)
         : m_be{be}, m_hp{hp}, m_n{nr_unknown}, m_max_a_bound{poly::stable_x_range(hp.order)},
-          m_shard{shard} {
+          m_shard{shard}, m_profile_mode{hp.profile} {
     sanm_check(hp.order >= 2, "order=%d", hp.order);  // anm.cpp:108-110
     sanm_check(remap_inp_in.out_size % 9 == 0, "remap_inp must produce a (T,3,3) tensor");
     if (hp.xcoeff_l2_penalty != 0)
@@ -463,8 +470,13 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
     // (libsanm/symbolic.cpp:525-536)
     int64_t tb = 0, te = T;
     if (m_shard.active()) {
-        sanm_check(m_shard.allreduce && m_shard.rank >= 0 && m_shard.rank < m_shard.world,
+        sanm_check(m_shard.world >= 1 && m_shard.rank >= 0 && m_shard.rank < m_shard.world,
                    "invalid shard description");
+        if (!m_shard.allreduce)
+            sanm_check(be->comm_world() == m_shard.world && be->comm_rank() == m_shard.rank,
+                       "sharded solver without a callback: the backend's communicator (sanm_hip_comm_init) has rank "
+                       "%d of %d, the solver was given rank %d of %d",
+                       be->comm_rank(), be->comm_world(), m_shard.rank, m_shard.world);
         tb = (int64_t)m_shard.rank * T / m_shard.world;
         te = (int64_t)(m_shard.rank + 1) * T / m_shard.world;
         sanm_check(te > tb, "more ranks than tets");
@@ -480,6 +492,10 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
         m_solver = make_direct_solver(be, *m_pattern, hp, coords);
     } else if (hp.solver_kind == 0) {
         m_solver = make_pcg_solver(be, *m_pattern, hp);
+    } else if (hp.solver_kind == 2) {
+        m_solver.reset(be->make_external_solver(*m_pattern, hp));
+        if (!m_solver)
+            sanm_throw(SANM_ERR_UNSUPPORTED, "solver_kind 2 (host MKL PARDISO) exists in the CPU baseline harness only");
     } else {
         sanm_throw(SANM_ERR_ASSERT, "unknown solver_kind %d", hp.solver_kind);
     }
@@ -503,13 +519,23 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
     for (auto& v : m_xt_coeffs) v = DVec{be, n1};
 }
 
+const std::map<std::string, double>& AnmDriver::profile() {
+    if (m_profile_mode == 2) m_be->phase_collect(m_profile, &m_profile_cnt);
+    return m_profile;
+}
+
 AnmDriver::~AnmDriver() {
     if (m_host_scalars) m_be->free_host(m_host_scalars);
 }
 
 void AnmDriver::allreduce(double* buf, int64_t count) {
     if (!m_shard.active()) return;
-    m_be->sync();  // the collective runs outside this backend's stream
+    ScopedTimer t{this, "allreduce"};
+    if (!m_shard.allreduce) {
+        m_be->allreduce_sum(buf, count);  // queued on the backend's stream
+        return;
+    }
+    m_be->sync();  // the callback's collective runs outside this backend's stream
     int rc = m_shard.allreduce(m_shard.user, buf, count);
     if (rc != 0) sanm_throw(SANM_ERR_HIP, "all-reduce callback failed with code %d", rc);
 }
@@ -540,7 +566,10 @@ void AnmDriver::solve_expansion_coeffs() {
     {
         ScopedTimer t{this, "taylor_order0"};
         be->run_pass(P, PASS_EVAL0, 0, m_xt0.p());
-        be->gather_rows(m_remap_out->dev(), m_prog->out_coef0(), m_fx0.p());
+        {
+            ScopedTimer t2{this, "remap_out"};
+            be->gather_rows(m_remap_out->dev(), m_prog->out_coef0(), m_fx0.p());
+        }
         allreduce(m_fx0.p(), n);
     }
     if (!on_fx0_computed(m_fx0.p())) return;
@@ -567,8 +596,11 @@ void AnmDriver::solve_expansion_coeffs() {
             if (!bias_done) be->run_pass(P, PASS_BIAS, i, nullptr);
             // (orders >= 2, single rank: remap_out drops b_i where the direct solver reads its right-hand side)
             rhs_perm = (i > 1 && !m_shard.active()) ? m_solver->rhs_perm() : nullptr;
-            be->gather_rows(m_remap_out->dev(), m_prog->out_bias(), bi, rhs_perm,
-                            rhs_perm ? m_solver->rhs_work() : nullptr);
+            {
+                ScopedTimer t2{this, "remap_out"};
+                be->gather_rows(m_remap_out->dev(), m_prog->out_bias(), bi, rhs_perm,
+                                rhs_perm ? m_solver->rhs_work() : nullptr);
+            }
             // the one collective per Taylor order: sum of the per-shard nodal bias (n doubles)
             if (i > 1) allreduce(bi, n);
         }
@@ -623,7 +655,7 @@ void AnmDriver::solve_expansion_coeffs() {
         }
         m_nr_valid_coeffs = i + 1;
 
-        if (m_hp.profile) {
+        if (m_profile_mode == 1) {
             trace_b_norm.push_back(std::sqrt(be->dot(n, bi, bi)));
             trace_x_norm.push_back(std::sqrt(be->dot(n1, xi, xi)));
             trace_t.push_back(m_host_scalars[3 * i]);  // valid: the dot above synchronised

@@ -43,10 +43,13 @@ struct HyperParam {  // libsanm/anm.h:100-114, :247-251
 //! summed with one all-reduce each -- RCCL over xGMI, supplied by the caller.
 struct ShardInfo {
     int rank = 0, world = 1;
-    //! in-place sum over all ranks of `count` doubles at device pointer `buf`; 0 = ok
+    //! in-place sum over all ranks of `count` doubles at device pointer `buf`; 0 = ok.  nullptr: the backend's
+    //! own collective (RCCL on the solver's stream, Backend::allreduce_sum; no host synchronisation)
     int (*allreduce)(void* user, double* buf, int64_t count) = nullptr;
     void* user = nullptr;
-    bool active() const { return world > 1; }
+    //! set by the sharded constructors: the sharded code path runs also with world == 1 (tests)
+    bool enabled = false;
+    bool active() const { return enabled; }
 };
 
 class DVec {
@@ -168,7 +171,15 @@ public:
     int nr_valid_xt_coeffs() const { return m_nr_valid_coeffs; }
     bool has_pade() const { return (bool)m_pade; }
 
-    const std::map<std::string, double>& profile() const { return m_profile; }
+    //! seconds per tag (HyperParam::profile != 0); with event timing this waits for the device first
+    const std::map<std::string, double>& profile();
+    const std::map<std::string, double>& profile_counts() const { return m_profile_cnt; }
+    //! 0: off, 1: host clock around synchronised phases, 2: device events (no synchronisation)
+    void set_profile_mode(int mode) { m_profile_mode = mode; }
+    void clear_profile() {
+        m_profile.clear();
+        m_profile_cnt.clear();
+    }
     const LinearSolver& linear_solver() const { return *m_solver; }
     const JacobianPattern& pattern() const { return *m_pattern; }
     Program& program() { return *m_prog; }
@@ -184,6 +195,7 @@ protected:
     const int64_t m_n;
     const double m_max_a_bound;
     const ShardInfo m_shard;
+    int m_profile_mode = 0;
     void allreduce(double* buf, int64_t count);
     std::unique_ptr<Program> m_prog;
     std::unique_ptr<DeviceRows> m_remap_out;
@@ -202,7 +214,7 @@ protected:
     PadeWorkspace m_pade_ws;
     DVec m_dev_scalars;                // per order: xb_i . x_1 (consumed on the device)
     double* m_host_scalars = nullptr;  // pinned, per order: t_i, sanity excess, sanity x-dot
-    std::map<std::string, double> m_profile;
+    std::map<std::string, double> m_profile, m_profile_cnt;
 
     void init_xt0(const double* x_host, double t);
     void solve_expansion_coeffs();

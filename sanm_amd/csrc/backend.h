@@ -8,11 +8,17 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <map>
+#include <string>
 
 #include "mf_types.h"
 #include "program.h"
 
 namespace sanm_hip {
+
+class LinearSolver;
+class JacobianPattern;
+struct HyperParam;
 
 // rows of a sparse gather: dst[i] = sum_{p in [ptr[i], ptr[i+1])} coef[p] * src[idx[p]]
 struct SparseRowsDev {
@@ -159,6 +165,36 @@ public:
     virtual void pass_timing(double* total_ms, int64_t* count) {
         *total_ms = 0;
         *count = 0;
+    }
+
+    // ---- collective of the tet-sharded mode (one process per GPU; RCCL over xGMI in the HIP backend) ----------
+    //! 128-byte identifier of a new communicator (rank 0 creates it, the caller hands it to every rank).
+    //! The defaults (backend_common.cpp) report UNSUPPORTED.
+    virtual void comm_unique_id(void* id128);
+    //! join the communicator; collective over all `world` ranks
+    virtual void comm_init(int rank, int world, const void* id128);
+    virtual void comm_destroy() {}
+    virtual int comm_world() const { return 0; }  // 0: no communicator
+    virtual int comm_rank() const { return 0; }
+    //! in-place sum of `count` doubles over all ranks, queued on the backend's stream (no host synchronisation)
+    virtual void allreduce_sum(double* buf, int64_t count);
+
+    //! HyperParam::solver_kind == 2: a linear solver supplied by the backend itself.  The HIP backend has none
+    //! (nullptr: the driver rejects the setting); the CPU baseline harness (tests/hostsim) returns MKL PARDISO,
+    //! the reference's own solver (libsanm/sparse_solver.cpp:107-127).
+    virtual LinearSolver* make_external_solver(const JacobianPattern& pat, const HyperParam& hp) {
+        (void)pat; (void)hp;
+        return nullptr;
+    }
+
+    //! Phase timing without host synchronisation (measurement runs: HyperParam::profile == 2): the launches queued
+    //! between phase_begin(tag) and the matching phase_end() are bracketed by device events on the backend's
+    //! stream; phase_collect() waits for the stream and adds the elapsed seconds of every closed bracket to
+    //! acc[tag] / the number of brackets to cnt[tag].  Brackets nest.  Backends without events do nothing.
+    virtual void phase_begin(const char* tag) { (void)tag; }
+    virtual void phase_end() {}
+    virtual void phase_collect(std::map<std::string, double>& acc, std::map<std::string, double>* cnt) {
+        (void)acc; (void)cnt;
     }
 
     //! average duration in ms of `reps` back-to-back launches of one kernel,

@@ -5,6 +5,14 @@
 
 namespace sanm_hip {
 
+void Backend::comm_unique_id(void*) { sanm_throw(SANM_ERR_UNSUPPORTED, "backend %s has no native collective", name()); }
+void Backend::comm_init(int, int, const void*) {
+    sanm_throw(SANM_ERR_UNSUPPORTED, "backend %s has no native collective", name());
+}
+void Backend::allreduce_sum(double*, int64_t) {
+    sanm_throw(SANM_ERR_UNSUPPORTED, "backend %s has no native collective (pass an all-reduce callback)", name());
+}
+
 void Backend::mf_solve_fused(const MfDev& mf, const MfSchedule& sch, const double* b, double* x, const double* dot_y,
                              double* dot_out) {
     if (!b) sanm_throw(SANM_ERR_ASSERT, "mf_solve_fused: this backend needs the right-hand side");

@@ -17,11 +17,13 @@
 //                         second blocking level of large fronts; solves = one mat-vec launch per level and direction.
 //  * graphs               the Pade basis sweep is captured once and replayed (graph_capture_*).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <unordered_map>
 #include <vector>
 
@@ -780,8 +782,53 @@ inline unsigned red_grid(size_t n) {
     return (unsigned)(g < 1 ? 1 : (g > RED_MAX_GRID ? RED_MAX_GRID : g));
 }
 
+// ---- RCCL, bound at run time ------------------------------------------------------------------------------
+// The tet-sharded mode sums nodal vectors over the ranks with ncclAllReduce on the backend's own stream, so the
+// order loop stays free of host synchronisation (the callback form of the C ABI has to synchronise on both sides
+// of the call).  RCCL is looked up with dlopen: a process that already holds it (torch.distributed's nccl backend
+// loads its copy under the same soname) shares that copy, and single-GPU users never load it.  The four
+// prototypes are RCCL's public C interface (rccl.h: ncclGetUniqueId, ncclCommInitRank, ncclAllReduce,
+// ncclCommDestroy; ncclUniqueId is 128 opaque bytes, ncclFloat64 = 8, ncclSum = 0).
+struct Rccl {
+    struct UniqueId {
+        char internal[128];
+    };
+    using Comm = void*;
+    int (*GetUniqueId)(UniqueId*) = nullptr;
+    int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+    int (*CommDestroy)(Comm) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    static const Rccl& get() {
+        static Rccl r = [] {
+            Rccl x;
+            const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+            for (const char* nm : names) {
+                void* h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+                if (!h) continue;
+                x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+                x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+                x.AllReduce = reinterpret_cast<decltype(x.AllReduce)>(dlsym(h, "ncclAllReduce"));
+                x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+                x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+                if (x.GetUniqueId && x.CommInitRank && x.AllReduce && x.CommDestroy) break;
+                x = Rccl{};
+            }
+            return x;
+        }();
+        if (!r.AllReduce) sanm_throw(SANM_ERR_HIP, "RCCL (librccl.so.1) could not be loaded: %s", dlerror());
+        return r;
+    }
+    void check(int rc, const char* what) const {
+        if (rc != 0)
+            sanm_throw(SANM_ERR_HIP, "RCCL %s failed: %s", what, GetErrorString ? GetErrorString(rc) : "error");
+    }
+};
+
 class HipBackend final : public Backend {
     hipStream_t m_stream = nullptr;
+    Rccl::Comm m_comm = nullptr;
+    int m_comm_rank = 0, m_comm_world = 0;
     // pass kernels compiled at run time for one program each (specialize)
     struct SpecKernels {
         hipModule_t mod = nullptr;
@@ -810,6 +857,23 @@ class HipBackend final : public Backend {
     size_t m_pass_lds_limit[4] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
     static constexpr int kBiasWaves = 3;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> m_pass_events;
+    // phase brackets (phase_begin / phase_end): closed ones wait in m_phase_done for phase_collect
+    struct PhaseBracket {
+        std::string tag;
+        hipEvent_t e0, e1;
+    };
+    std::vector<PhaseBracket> m_phase_open, m_phase_done;
+    std::vector<hipEvent_t> m_event_pool;
+    hipEvent_t pooled_event() {
+        if (!m_event_pool.empty()) {
+            hipEvent_t e = m_event_pool.back();
+            m_event_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreate(&e));
+        return e;
+    }
 
 public:
     explicit HipBackend(int device) {
@@ -827,6 +891,7 @@ public:
         HIP_CHECK(hipHostMalloc(&m_scalar_host, 64));
     }
     ~HipBackend() override {
+        comm_destroy();
         (void)hipFree(m_scalar);
         for (auto& kv : m_pool_free)
             for (void* p : kv.second) (void)hipFree(p);
@@ -838,9 +903,40 @@ public:
         if (m_pcg_sc) (void)hipFree(m_pcg_sc);
         if (m_pcg_sc_host) (void)hipHostFree(m_pcg_sc_host);
         (void)hipHostFree(m_scalar_host);
+        for (hipEvent_t e : m_event_pool) (void)hipEventDestroy(e);
         (void)hipStreamDestroy(m_stream);
     }
     const char* name() const override { return "hip"; }
+
+    void comm_unique_id(void* id128) override {
+        const Rccl& r = Rccl::get();
+        Rccl::UniqueId id;
+        r.check(r.GetUniqueId(&id), "ncclGetUniqueId");
+        std::memcpy(id128, id.internal, 128);
+    }
+    void comm_init(int rank, int world, const void* id128) override {
+        const Rccl& r = Rccl::get();
+        comm_destroy();
+        Rccl::UniqueId id;
+        std::memcpy(id.internal, id128, 128);
+        r.check(r.CommInitRank(&m_comm, world, id, rank), "ncclCommInitRank");
+        m_comm_rank = rank;
+        m_comm_world = world;
+    }
+    void comm_destroy() override {
+        if (!m_comm) return;
+        (void)hipStreamSynchronize(m_stream);
+        (void)Rccl::get().CommDestroy(m_comm);
+        m_comm = nullptr;
+        m_comm_world = 0;
+    }
+    int comm_world() const override { return m_comm_world; }
+    int comm_rank() const override { return m_comm_rank; }
+    void allreduce_sum(double* buf, int64_t count) override {
+        if (!m_comm) sanm_throw(SANM_ERR_ASSERT, "all-reduce without a communicator (sanm_hip_comm_init first)");
+        const Rccl& r = Rccl::get();
+        r.check(r.AllReduce(buf, buf, (size_t)count, /*ncclFloat64*/ 8, /*ncclSum*/ 0, m_comm, m_stream), "ncclAllReduce");
+    }
 
     // Work vectors come and go every continuation step (Pade basis, range checks); hipMalloc / hipFree
     // cost tens of microseconds each and hipFree synchronises the device, so freed blocks of up to
@@ -995,6 +1091,29 @@ public:
             HIP_CHECK(hipEventRecord(e1, m_stream));
             m_pass_events.emplace_back(e0, e1);
         }
+    }
+    void phase_begin(const char* tag) override {
+        PhaseBracket b{tag, pooled_event(), pooled_event()};
+        HIP_CHECK(hipEventRecord(b.e0, m_stream));
+        m_phase_open.push_back(std::move(b));
+    }
+    void phase_end() override {
+        if (m_phase_open.empty()) return;
+        HIP_CHECK(hipEventRecord(m_phase_open.back().e1, m_stream));
+        m_phase_done.push_back(std::move(m_phase_open.back()));
+        m_phase_open.pop_back();
+    }
+    void phase_collect(std::map<std::string, double>& acc, std::map<std::string, double>* cnt) override {
+        HIP_CHECK(hipStreamSynchronize(m_stream));
+        for (auto& b : m_phase_done) {
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, b.e0, b.e1));
+            acc[b.tag] += ms * 1e-3;
+            if (cnt) (*cnt)[b.tag] += 1;
+            m_event_pool.push_back(b.e0);
+            m_event_pool.push_back(b.e1);
+        }
+        m_phase_done.clear();
     }
     void enable_pass_timing(bool on) override {
         for (auto& ev : m_pass_events) {

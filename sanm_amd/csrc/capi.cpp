@@ -367,11 +367,29 @@ int sanm_anm_eqn_solver_create_sharded(const sanm_graph* g, int out_var,
         sh.world = world;
         sh.allreduce = allreduce;
         sh.user = user;
+        sh.enabled = true;
         auto* e = new AnmEqnSolver(backend(), g->g, out_var, remap_inp->d, remap_out->d, x0, y, n,
                                    to_hp(hp), sh);
         p->drv.reset(e);
         p->eqn = e;
         *s = p.release();
+    });
+}
+int sanm_hip_comm_unique_id(void* id, size_t cap) {
+    return guard([&] {
+        sanm_check(cap >= 128, "the identifier needs 128 bytes");
+        backend()->comm_unique_id(id);
+    });
+}
+int sanm_hip_comm_init(int rank, int world, const void* id, size_t id_bytes) {
+    return guard([&] {
+        sanm_check(id_bytes >= 128 && world >= 1 && rank >= 0 && rank < world, "bad communicator arguments");
+        backend()->comm_init(rank, world, id);
+    });
+}
+int sanm_hip_comm_destroy(void) {
+    return guard([&] {
+        if (g_backend) g_backend->comm_destroy();
     });
 }
 int sanm_anm_vecscale_solver_create(const sanm_graph* g, int out_var,
@@ -506,11 +524,29 @@ int sanm_anm_get_stats(const sanm_anm_solver* s, sanm_anm_stats* st) {
         st->max_front = d.linear_solver().max_front;
     });
 }
+int sanm_anm_set_profile(sanm_anm_solver* s, int mode, int clear) {
+    return guard([&] {
+        sanm_check(mode >= 0 && mode <= 2, "profile mode %d", mode);
+        if (clear) {
+            (void)s->drv->profile();  // drains pending event brackets
+            s->drv->clear_profile();
+        }
+        s->drv->set_profile_mode(mode);
+    });
+}
+int sanm_anm_profile_counts(const sanm_anm_solver* s, int max_tags, double* counts) {
+    int k = 0;
+    for (auto& kv : s->drv->profile_counts()) {
+        if (k < max_tags && counts) counts[k] = kv.second;
+        ++k;
+    }
+    return k;
+}
 int sanm_anm_profile(const sanm_anm_solver* s, int max_tags, const char** names, double* seconds) {
     auto* ms = const_cast<sanm_anm_solver*>(s);
     ms->tag_storage.clear();
     int k = 0;
-    for (auto& kv : s->drv->profile()) {
+    for (auto& kv : ms->drv->profile()) {
         ms->tag_storage.push_back(kv.first);
         if (k < max_tags && seconds) seconds[k] = kv.second;
         ++k;

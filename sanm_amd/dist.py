@@ -11,6 +11,17 @@ from __future__ import annotations
 import ctypes
 
 
+def init_native_comm(api, rank, world):
+    """The library's own RCCL communicator (sanm_hip_comm_init): ncclAllReduce is queued on the solver's stream,
+    so the sharded order loop runs without host synchronisation.  The 128-byte identifier travels from rank 0
+    to the others through torch.distributed's default group (any out-of-band channel would do)."""
+    uid = [api.comm_unique_id() if rank == 0 else None]
+    if world > 1:
+        import torch.distributed as dist
+        dist.broadcast_object_list(uid, src=0)
+    api.comm_init(rank, world, uid[0])
+
+
 class _DevicePtr:
     def __init__(self, ptr, count):
         self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8",

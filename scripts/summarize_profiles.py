@@ -81,5 +81,19 @@ with open(os.path.join(dst, f"{tag}_pmc_traffic.md"), "w") as fo:
         traffic = (2 * f_avg + w_avg) * 1024
         out["kernels"][k] = {"fetch_kib": f_avg, "write_kib": w_avg, "traffic_bytes_per_launch": traffic}
         fo.write(f"| {k} | {c} | {f_avg:.1f} | {w_avg:.1f} | {traffic / 1e6:.2f} |\n")
+# kernel families as bench.py reports them (roofline_families); traffic per launch = dispatch-weighted mean
+FAMILY_OF = {"mfk::fwd_level_sub_kernel": "solve", "mfk::fwd_level_kernel": "solve", "mfk::bwd_level_kernel": "solve",
+             "mfk::fwd_top_kernel": "solve", "mfk::bwd_top_kernel": "solve", "mfk::root_solve_kernel": "solve",
+             "mfk::fwd_big_kernel": "solve", "mfk::bwd_big_kernel": "solve", "mfk::fwd_prep_kernel": "solve",
+             "permute_out_dot_kernel": "solve", "mfk::permute_out_kernel": "solve", "mfk::permute_in_kernel": "solve",
+             "taylor_pass_kernel": "taylor", "gather_rows3_kernel": "io", "gather_rows_kernel": "io",
+             "assemble_kernel": "asm", "nonfinite_kernel": "asm"}
+famacc = collections.OrderedDict()
+for k, (c, v) in fetch.items():
+    name = FAMILY_OF.get(k, "factor" if k.startswith("mfk::") else "tail")
+    a = famacc.setdefault(name, [0, 0.0])
+    a[0] += c
+    a[1] += out["kernels"][k]["traffic_bytes_per_launch"] * c
+out["families"] = {k: {"dispatches": c, "traffic_bytes_per_launch": v / c} for k, (c, v) in famacc.items()}
 json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 print(open(os.path.join(dst, f"{tag}_pmc_traffic.md")).read())

@@ -8,9 +8,14 @@
 // tests/hostsim/libsanm_hostsim.so by tests/hostsim/build.py; libsanm_hip.so
 // never contains it and sanm_amd never loads it.  GPU parity is proven by the
 // `-m gpu` tests, not by this harness.
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "backend.h"
@@ -21,10 +26,99 @@
 namespace sanm_hip {
 int hostsim_mf_factor(const MfDev& mf, const MfSchedule& sch, const CsrDev& A);
 void hostsim_mf_solve(const MfDev& mf, const MfSchedule& sch, const double* b, double* x);
+LinearSolver* hostsim_make_pardiso(const JacobianPattern& pat, int threads);  // pardiso_solver.cpp
 namespace {
+// Worker threads over contiguous ranges, like the reference's ParallelTaylorCoeffProp
+// (libsanm/symbolic.cpp:525-536: worker w owns [w*T/nr, (w+1)*T/nr)); SANM_CPU_THREADS sets the count
+// (default 1: the tests stay serial and deterministic).  Used by the CPU-baseline leg of bench.py.
+class RangePool {
+    std::vector<std::thread> m_threads;
+    std::mutex m_mtx;
+    std::condition_variable m_cv_job, m_cv_done;
+    std::function<void(int64_t, int64_t)> m_fn;
+    int64_t m_n = 0;
+    uint64_t m_gen = 0;
+    int m_pending = 0;
+    bool m_stop = false;
+    const int m_nr;
+
+    void worker(int id) {
+        uint64_t seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk{m_mtx};
+            m_cv_job.wait(lk, [&] { return m_stop || m_gen != seen; });
+            if (m_stop) return;
+            seen = m_gen;
+            const int64_t b = id * m_n / m_nr, e = (id + 1) * m_n / m_nr;
+            lk.unlock();
+            if (e > b) m_fn(b, e);
+            lk.lock();
+            if (--m_pending == 0) m_cv_done.notify_one();
+        }
+    }
+
+public:
+    explicit RangePool(int nr) : m_nr{nr} {
+        for (int i = 1; i < nr; ++i) m_threads.emplace_back([this, i] { worker(i); });
+    }
+    ~RangePool() {
+        {
+            std::lock_guard<std::mutex> lk{m_mtx};
+            m_stop = true;
+        }
+        m_cv_job.notify_all();
+        for (auto& t : m_threads) t.join();
+    }
+    int size() const { return m_nr; }
+    void run(int64_t n, std::function<void(int64_t, int64_t)> fn) {
+        if (m_nr == 1 || n < 2 * m_nr) {
+            fn(0, n);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk{m_mtx};
+            m_fn = std::move(fn);
+            m_n = n;
+            m_pending = m_nr - 1;
+            ++m_gen;
+        }
+        m_cv_job.notify_all();
+        m_fn(0, n / m_nr);  // the calling thread is worker 0
+        std::unique_lock<std::mutex> lk{m_mtx};
+        m_cv_done.wait(lk, [&] { return m_pending == 0; });
+    }
+};
+
 class HostSimBackend final : public Backend {
+    RangePool m_pool{std::max(1, std::getenv("SANM_CPU_THREADS") ? std::atoi(std::getenv("SANM_CPU_THREADS")) : 1)};
+    struct Bracket {
+        std::string tag;
+        std::chrono::steady_clock::time_point t0;
+    };
+    std::vector<Bracket> m_open;
+    std::map<std::string, double> m_acc, m_cnt;
+
 public:
     const char* name() const override { return "hostsim"; }
+    LinearSolver* make_external_solver(const JacobianPattern& pat, const HyperParam&) override {
+        return hostsim_make_pardiso(pat, m_pool.size());
+    }
+    // everything runs synchronously here: the brackets are host clocks
+    void phase_begin(const char* tag) override { m_open.push_back({tag, std::chrono::steady_clock::now()}); }
+    void phase_end() override {
+        if (m_open.empty()) return;
+        m_acc[m_open.back().tag] +=
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - m_open.back().t0).count();
+        m_cnt[m_open.back().tag] += 1;
+        m_open.pop_back();
+    }
+    void phase_collect(std::map<std::string, double>& acc, std::map<std::string, double>* cnt) override {
+        for (auto& kv : m_acc) acc[kv.first] += kv.second;
+        if (cnt)
+            for (auto& kv : m_cnt) (*cnt)[kv.first] += kv.second;
+        m_acc.clear();
+        m_cnt.clear();
+    }
     void* alloc(size_t bytes) override { return std::malloc(bytes ? bytes : 8); }
     void free(void* p) override { std::free(p); }
     void h2d(void* d, const void* s, size_t b) override { if (b) std::memcpy(d, s, b); }
@@ -34,13 +128,15 @@ public:
     void sync() override {}
 
     void run_pass(const ProgramDev& P, int mode, int order, const double* xvec) override {
-        std::vector<double> cur(P.cur_size + 1);
-        if (mode == PASS_GRAD) {  // one reverse sweep per row of the Jacobian (the row travels in `order`)
-            for (int64_t t = 0; t < P.T; ++t)
-                for (int r = 0; r < P.odim; ++r) exec_program_tet(P, mode, r, t, xvec, cur.data(), 1);
-            return;
-        }
-        for (int64_t t = 0; t < P.T; ++t) exec_program_tet(P, mode, order, t, xvec, cur.data(), 1);
+        m_pool.run(P.T, [&](int64_t tb, int64_t te) {
+            std::vector<double> cur(P.cur_size + 1);
+            if (mode == PASS_GRAD) {  // one reverse sweep per row of the Jacobian (the row travels in `order`)
+                for (int64_t t = tb; t < te; ++t)
+                    for (int r = 0; r < P.odim; ++r) exec_program_tet(P, mode, r, t, xvec, cur.data(), 1);
+                return;
+            }
+            for (int64_t t = tb; t < te; ++t) exec_program_tet(P, mode, order, t, xvec, cur.data(), 1);
+        });
     }
     void gather_rows(const SparseRowsDev& R, const double* src, double* dst, const int32_t* perm,
                      double* dst2) override {
@@ -50,7 +146,10 @@ public:
         }
     }
     void assemble(const AssemblyDev& A, const double* jac, double* val) override {
-        for (int64_t s = 0; s < A.nslots; ++s) val[s] = assemble_slot(A, jac, s);
+        // worker-parallel by rows in the reference (anm.cpp:384-390)
+        m_pool.run(A.nslots, [&](int64_t sb, int64_t se) {
+            for (int64_t s = sb; s < se; ++s) val[s] = assemble_slot(A, jac, s);
+        });
     }
     void spmv(const CsrDev& A, const double* x, double* y) override {
         for (int64_t i = 0; i < A.n; ++i) y[i] = spmv_row(A, x, i);

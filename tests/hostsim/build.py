@@ -18,12 +18,13 @@ SOURCES = ["graph.cpp", "sparse.cpp", "backend_common.cpp", "poly.cpp", "anm.cpp
 
 
 def build(force=False):
-    srcs = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "backend_host.cpp")]
+    srcs = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "backend_host.cpp"),
+                                                         os.path.join(HERE, "pardiso_solver.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
         return OUT
     cmd = ["g++", "-O2", "-std=c++20", "-fPIC", "-shared", "-pthread", "-Wl,-Bsymbolic", "-Wall",
-           "-Wno-unused-function", "-I", CSRC, "-o", OUT] + srcs
+           "-Wno-unused-function", "-I", CSRC, "-o", OUT] + srcs + ["-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hostsim build failed:\n" + r.stderr)

@@ -17,7 +17,7 @@ from tests.hostsim import get_hostsim_api
 bench.make_api = lambda local_rank: get_hostsim_api()
 bench.device_sync = lambda: None
 out = bench.main(["--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "cuboid:5,3,3",
-                  "--no-cpu-baseline", "--dist-backend", "gloo"])
+                  "--no-cpu-baseline", "--dist-backend", "gloo"] + {extra!r})
 if os.environ["RANK"] == "0":
     assert out is not None
 else:
@@ -33,23 +33,52 @@ def _free_port():
     return p
 
 
-def test_two_rank_replicas_gloo():
+def _run_two_ranks(extra):
     port = _free_port()
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, "-c", WORKER.format(root=ROOT)], env=env, cwd=ROOT,
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER.format(root=ROOT, extra=extra)], env=env, cwd=ROOT,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    outs = [p.communicate(timeout=600) for p in procs]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=300))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se[-2000:]
     lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
     assert len(lines) == 1, outs[0][0]
-    d = json.loads(lines[0])
     assert not [l for l in outs[1][0].splitlines() if l.startswith("{")], "only rank 0 prints"
+    return json.loads(lines[0])
+
+
+def _check_common(d):
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1
+    fam = d["roofline_families"]
+    assert set(fam) == {"solve", "factor", "taylor", "io", "asm", "tail"}
+    assert d["roofline"]["family"] in fam and d["roofline"]["bound"] == "hbm"
+    assert abs(sum(f["share_of_step"] for f in fam.values()) - 1) < 1e-6
+    assert d["roofline_whole_step"]["algorithmic_bytes_per_step"] > 0
+
+
+def test_two_rank_replicas_gloo():
+    d = _run_two_ranks(["--parallelism", "replicas"])
+    _check_common(d)
     assert d["scaling"] == "weak" and d["config"]["parallelism"] == "replicas"
     # whole-job value = N * K / max-over-ranks time
     assert abs(d["value"] - 2 * 3 / (d["ms_per_step"] * 3 / 1e3)) < 1e-6 * d["value"]
-    assert d["roofline"]["kernel"] == "taylor_pass_kernel"
+
+
+def test_two_rank_shard_is_the_default_and_terminates():
+    """N > 1 defaults to ONE tet-sharded problem (BASELINE config 4); the measurement steps after the timed
+    region issue collectives too, so every rank has to run them (they once ran on rank 0 only: a deadlock)."""
+    d = _run_two_ranks([])
+    _check_common(d)
+    assert d["scaling"] == "strong" and d["config"]["parallelism"].startswith("tet-shard")
+    # one problem: value = K / max-over-ranks time
+    assert abs(d["value"] - 3 / (d["ms_per_step"] * 3 / 1e3)) < 1e-6 * d["value"]

@@ -76,3 +76,26 @@ def test_two_rank_tet_shard_matches_single_rank():
             steps, order = r["steps"], 12
             assert r["ncall"] == steps * (1 + 1 + (order - 1)) + 1
         assert res[0]["steps"] == res[1]["steps"]
+
+
+def test_single_rank_shard_runs_the_sharded_code_path():
+    """world == 1 is a valid shard description: the sharded path (tet range = all tets, collectives of one rank)
+    must give exactly the unsharded solve.  The GPU twin of this test is tests/test_gpu_dist.py."""
+    import numpy as np
+    from tests.hostsim import get_hostsim_api
+    from sanm_amd import fea as dfea
+    api = get_hostsim_api()
+    cfg = {"material": {"young": 3e3, "poisson": 0.45, "density": 1000.0}, "g": [0, -9.81, 0],
+           "boundary_thresh": 0.05, "boundary_proj_dir": [-1, 0, 0], "energy_model": "neohookean_c", "order": 12}
+    ncall = [0]
+
+    def identity(ptr, count):
+        ncall[0] += 1
+
+    run = dfea.GravityRun(api, dfea.make_cuboid(6, 3, 3, 0.025), dict(cfg), shard=(0, 1, identity),
+                          solver_rtol=1e-15).run()
+    ref = dfea.GravityRun(api, dfea.make_cuboid(6, 3, 3, 0.025), dict(cfg), solver_rtol=1e-15).run()
+    steps = run.solver.get_nr_iter()
+    assert steps == ref.solver.get_nr_iter()
+    assert np.array_equal(run.vertices(), ref.vertices())
+    assert ncall[0] == steps * (1 + 1 + (12 - 1)) + 1
