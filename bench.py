@@ -44,6 +44,7 @@ def parse(argv=None):
     p.add_argument("--solver-kind", type=int, default=1, help="0: Jacobi-PCG, 1: multifrontal LU")
     p.add_argument("--profile", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-threads", type=int, default=None, help="CPU baseline threads (default min(32, cores))")
     p.add_argument("--cpu-seconds", type=float, default=20.0, help="stepping time of the CPU baseline sample")
     p.add_argument("--parallelism", default="shard", choices=["replicas", "shard"],
                    help="N>1: one tet-sharded problem with an RCCL all-reduce of b_k per Taylor order (strong "
@@ -55,7 +56,7 @@ def parse(argv=None):
     return p.parse_args(argv)
 
 
-def cpu_baseline(workload, budget_s=20.0):
+def cpu_baseline(workload, budget_s=20.0, threads=None):
     """The build's own CPU path, timed on this box's host cores: the same C++ host code as the
     product linked with the CPU backend of tests/hostsim -- tet-sharded worker threads for the Taylor passes and
     the assembly (libsanm/symbolic.cpp:525-536), serial remaps and BLAS-1 on the main thread, and the reference's
@@ -63,7 +64,9 @@ def cpu_baseline(workload, budget_s=20.0):
     (mtype 11, iparm[34] = 1, iparm[1] = 3 when threaded, phase 12 at every step, phase 33 per solve).  All host
     cores the process may use.  Sample: whole solves from the rest state until `budget_s` seconds of stepping
     are spent; the per-tag breakdown mirrors the reference's ScopedProfiler tags."""
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # the reference's multi-threaded configuration is 32 threads (config/sys-mt32.json:3); fewer if the box has fewer
+    cores = min(32, avail) if threads is None else threads
     os.environ["SANM_CPU_THREADS"] = str(cores)
     os.environ.setdefault("MKL_THREADING_LAYER", "GNU")  # libgomp is what this process has loaded already
     from tests.hostsim import get_hostsim_api
@@ -93,7 +96,8 @@ def cpu_baseline(workload, budget_s=20.0):
             "impl": "C++ host path of this build (tests/hostsim: worker threads over tet ranges) + MKL PARDISO "
                     "(dlopen, reference settings)",
             "sample": f"{steps} ANM steps ({workload}, order {cfg.get('order', 20)}: whole solves from the rest "
-                      f"state) in {t_step:.1f} s on {cores} threads; mesh-only setup {setup_s:.1f} s not counted",
+                      f"state) in {t_step:.1f} s on {cores} threads of {avail} available (32 = the reference's "
+                      f"sys-mt32 configuration); mesh-only setup {setup_s:.1f} s not counted",
             "seconds_per_step": {k: round(prof.get(k, 0.0) / max(steps, 1), 4) for k in tags}}
 
 
@@ -347,7 +351,7 @@ def main(argv=None):
             "roofline_whole_step": whole,
         }
         if not args.no_cpu_baseline and world == 1 and not args.workload.startswith("block:"):
-            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds, args.cpu_threads)
             cb = out["cpu_baseline"]
             cb["gpu_over_cpu"] = out["value"] / cb["value"] if cb["value"] > 0 else None
         print(json.dumps(out), flush=True)

@@ -112,7 +112,7 @@ class Api:
             getattr(lib, name).restype = C.c_void_p
         for name in SYMBOLS:
             fn = getattr(lib, name)
-            if fn.restype is C.c_int and name.endswith("_destroy"):
+            if fn.restype is C.c_int and name.endswith("_destroy") and name != "sanm_hip_comm_destroy":
                 fn.restype = None
         self._initialised = False
 
