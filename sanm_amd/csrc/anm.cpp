@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <limits>
 
 #include "multifrontal.h"
@@ -137,6 +138,65 @@ std::unique_ptr<LinearSolver> make_pcg_solver(Backend* be, const JacobianPattern
 }
 
 // ----------------------------------------------------------------- Pade --
+void PadeWorkspace::ensure(Backend* be_, int nx, size_t len) {
+    if (!orth.empty()) {
+        sanm_check((int)orth.size() == nx && orth[1].size() == len, "pade workspace mismatch");
+        return;
+    }
+    be = be_;
+    orth.resize(nx);
+    for (int i = 1; i < nx; ++i) orth[i] = DVec{be, len};
+    acoef = DVec{be, (size_t)nx * nx + nx};
+}
+
+void PadeWorkspace::step(const std::vector<DVec>& xs, int i, bool anm_cond) {
+    for (int k = 1; k <= 3; ++k) phase(xs, i, k, anm_cond, false);
+}
+
+void PadeWorkspace::phase(const std::vector<DVec>& xs, int i, int k, bool anm_cond, bool defer) {
+    // Classical Gram-Schmidt (the projections use xs[i], not the running uii).  Nothing here waits for the
+    // device: projections and squared norms stay in device memory for the update / scaling kernels that
+    // consume them and come back in one copy when the basis is complete.
+    const int nx = orth.size(), n = nx - 1;
+    sanm_check(i >= 1 && i <= n && ((k == 1 && i == done + 1) || (k > 1 && i == done + 1)), "pade basis: step %d after %d", i,
+               done);
+    double* nn2 = acoef.p() + (size_t)nx * nx;  // per vector: squared norm after the first scaling
+    double* row = acoef.p() + (size_t)i * nx;
+    GsPhase ph;
+    ph.kind = k;
+    ph.n = orth[1].size();
+    ph.x = xs[i].p();
+    ph.nvec = i - 1;
+    for (int j = 1; j < i; ++j) ph.vecs[j - 1] = orth[j].p();
+    ph.eps = std::numeric_limits<double>::epsilon();
+    if (k == 1) {
+        // the projection kernel also completes the normalisation of the previous basis vector
+        ph.norm2 = i >= 2 ? acoef.p() + (size_t)(i - 1) * nx + (i - 1) : nullptr;
+        ph.nn2 = nn2 + (i - 1);
+        ph.red_out = row + 1;
+    } else if (k == 2) {
+        // under the ANM condition the projection on the first basis vector is dropped (checked by the reader)
+        ph.coefs = row + 1;
+        ph.first = anm_cond ? 1 : 0;
+        ph.out = orth[i].p();
+        ph.red_out = row + i;
+    } else {
+        ph.out = orth[i].p();
+        ph.norm2 = row + i;
+        ph.red_out = nn2 + i;
+    }
+    if (defer) be->defer_gs_phase(ph);
+    else be->run_gs_phase(ph);
+    if (k == 3) {
+        if (i == n) {
+            be->flush_deferred();
+            be->gs_renorm_async(ph.n, orth[n].p(), acoef.p() + (size_t)n * nx + n, nn2 + n, ph.eps);
+        }
+        done = i;
+        done_anm_cond = anm_cond;
+    }
+}
+
 PadeApproximation::PadeApproximation(Backend* be, const std::vector<DVec>& xs,
                                      const std::vector<double>& t_coeffs, bool anm_cond, PadeWorkspace* ws)
         : m_be{be}, m_xs{xs}, m_len{xs[0].size()} {
@@ -147,45 +207,29 @@ PadeApproximation::PadeApproximation(Backend* be, const std::vector<DVec>& xs,
     const int n = nx - 1;
     std::vector<double> a((size_t)nx * nx, 0.0);
     auto A = [&](int i, int j) -> double& { return a[(size_t)i * nx + j]; };
-    const double eps = std::numeric_limits<double>::epsilon();
-    // Classical Gram-Schmidt (the projections use xs[i], not the running uii).  The sweep is queued
-    // without waiting for the device: projections and squared norms stay in device memory for the
-    // update / scaling kernels that consume them and come back in one copy at the end.  With a workspace
-    // from the driver the whole sweep is recorded once and replayed as a graph.
+    // The basis (PadeWorkspace::step).  With a workspace from the driver most or all of its steps are already
+    // queued beside the order loop.
     PadeWorkspace local;
     if (!ws) ws = &local;
-    if (ws->orth.empty()) {
-        ws->be = be;
-        ws->orth.resize(nx);
-        for (int i = 1; i <= n; ++i) ws->orth[i] = DVec{be, m_len};
-        ws->acoef = DVec{be, (size_t)nx * nx + nx};
-    }
-    sanm_check((int)ws->orth.size() == nx && ws->orth[1].size() == m_len, "pade workspace mismatch");
-    auto sweep = [&]() {
-        std::vector<double*> ptrs(nx);
-        double* nn2 = ws->acoef.p() + (size_t)nx * nx;  // per vector: squared norm after the first scaling
-        for (int i = 1; i <= n; ++i) {
-            for (int j = 1; j < i; ++j) ptrs[j - 1] = ws->orth[j].p();
-            double* row = ws->acoef.p() + (size_t)i * nx;
-            double* uii = ws->orth[i].p();
-            // the projection kernel also completes the normalisation of the previous basis vector
-            const double* prev_norm2 = i >= 2 ? ws->acoef.p() + (size_t)(i - 1) * nx + (i - 1) : nullptr;
-            be->multi_dot_async(m_len, xs[i].p(), i - 1, ptrs.data(), row + 1, prev_norm2, nn2 + (i - 1), eps);
-            // under the ANM condition the projection on the first basis vector is dropped (checked below)
-            be->gs_update_async(m_len, xs[i].p(), i - 1, ptrs.data(), row + 1, anm_cond ? 1 : 0, uii, row + i);
-            be->scale_rsqrt_async(m_len, uii, row + i, eps, nn2 + i);
+    ws->ensure(be, nx, m_len);
+    if (ws->done > 0 && ws->done_anm_cond != anm_cond) ws->done = 0;
+    if (ws->done == 0 && ws != &local && !std::getenv("SANM_NO_PADE_GRAPH") && std::getenv("SANM_PADE_GRAPH")) {
+        // (the whole sweep as one graph replay: kept as an experiment switch; the steps queued by the driver
+        // beside the order loop made it redundant)
+        if (!ws->graph && be->graph_capture_begin()) {
+            for (int i = 1; i <= n; ++i) ws->step(xs, i, anm_cond);
+            ws->graph = be->graph_capture_end();
+            ws->done = 0;
         }
-        be->gs_renorm_async(m_len, ws->orth[n].p(), ws->acoef.p() + (size_t)n * nx + n, nn2 + n, eps);
-    };
-    if (ws->graph) {
-        be->graph_launch(ws->graph);
-    } else if (ws != &local && !std::getenv("SANM_NO_PADE_GRAPH") && be->graph_capture_begin()) {
-        sweep();
-        ws->graph = be->graph_capture_end();
-        be->graph_launch(ws->graph);
-    } else {
-        sweep();
+        if (ws->graph) {
+            be->graph_launch(ws->graph);
+            ws->done = n;
+        }
     }
+    // the steps the driver has not queued yet (all of them for a stand-alone PadeApproximation)
+    for (int i = ws->done + 1; i <= n; ++i) ws->step(xs, i, anm_cond);
+    be->side_join();
+    ws->done = 0;  // consumed: the next series starts over
     {
         std::vector<double> h((size_t)nx * nx);
         be->d2h(h.data(), ws->acoef.p(), h.size() * 8);
@@ -584,6 +628,38 @@ void AnmDriver::solve_expansion_coeffs() {
     // asynchronous results examined after the loop: non-finite Jacobian entries, rejected pivots, |x_1|^2, |x_N|^2
     double* const host_checks = m_host_scalars + 5 * ((size_t)N + 2);
     host_checks[0] = host_checks[1] = 0;
+    // The Pade basis (pade.cpp:36-70) grows by one Gram-Schmidt step per order instead of being built after the
+    // loop -- speculatively: estimate_valid_range decides later whether it is used.  The step for x_{i-1} is
+    // handed to the backend in its three phases at the points of order i where the kernels that can carry them
+    // are launched (remap_out gather, last kernel of the solve, next_coeff: Backend::defer_gs_phase); a backend
+    // that cannot carry them runs them as launches of their own at those points, which is the same arithmetic.
+    // SANM_GS_MODE: "tail" = the whole basis after the loop, "side" = steps on a second queue beside the loop
+    // (measured: the cross-queue traffic slows the solve's latency-bound launches by more than it hides),
+    // default = riders.
+    static const bool env_pade = getenv("SANM_PADE") != nullptr;
+    static const int gs_mode = [] {
+        const char* e = getenv("SANM_GS_MODE");
+        return !e ? 2 : (!strcmp(e, "tail") ? 0 : (!strcmp(e, "side") ? 1 : 2));
+    }();
+    const bool anm_cond = !m_hp.xcoeff_l2_penalty;
+    const bool pade_steps = (m_hp.use_pade || env_pade) && gs_mode != 0 && n1 >= 2 * ((size_t)N + 1) && N + 1 > 4;
+    const bool pade_riders = pade_steps && gs_mode == 2, pade_side = pade_steps && gs_mode == 1;
+    m_pade_ws.done = 0;
+    if (pade_steps) m_pade_ws.ensure(be, N + 1, n1);
+    int sanity_done = 0;  // orders 1 .. sanity_done are queued
+    auto queue_sanity = [&](int upto, const double* grad_t_dev) {
+        // anm.cpp:271-285: A x_i = -(t_i g_t + b_i) and x_1 . x_i = delta_1i, in one pass over the matrix per 10
+        // orders (the reference checks each order as it goes; a failure surfaces after the loop here)
+        ScopedTimer t{this, "anm_sanity_check"};
+        std::vector<const double*> xs, bs;
+        for (int q = sanity_done + 1; q <= upto; ++q) {
+            xs.push_back(m_xt_coeffs[q].p());
+            bs.push_back(m_bi_all[q].p());
+        }
+        be->sanity_check_batch_async(m_pattern->csr(), (int)xs.size(), xs.data(), grad_t_dev, bs.data(), 1e-4, n1,
+                                     m_xt_coeffs[1].p(), m_tmp0.p(), m_tmp1.p(), host_sanity + 2 * sanity_done);
+        sanity_done = upto;
+    };
     for (int i = 1; i <= N; ++i) {
         // (with the checks on, every order keeps its b_i: they are all verified in one pass after the loop)
         double* const bi = m_hp.sanity_check ? m_bi_all[i].p() : m_bi.p();
@@ -596,6 +672,7 @@ void AnmDriver::solve_expansion_coeffs() {
             if (!bias_done) be->run_pass(P, PASS_BIAS, i, nullptr);
             // (orders >= 2, single rank: remap_out drops b_i where the direct solver reads its right-hand side)
             rhs_perm = (i > 1 && !m_shard.active()) ? m_solver->rhs_perm() : nullptr;
+            if (pade_riders && i >= 2) m_pade_ws.phase(m_xt_coeffs, i - 1, 1, anm_cond, true);
             {
                 ScopedTimer t2{this, "remap_out"};
                 be->gather_rows(m_remap_out->dev(), m_prog->out_bias(), bi, rhs_perm,
@@ -640,6 +717,7 @@ void AnmDriver::solve_expansion_coeffs() {
             xgt_dot_x1 = be->dot(n, xi, m_xgt.p());
         } else {
             // t_i = (xb_i . x_1) / (t1 - xgt . x_1);  x_i = -t_i*xgt - xb_i  (anm.cpp:246-264)
+            if (pade_riders) m_pade_ws.phase(m_xt_coeffs, i - 1, 2, anm_cond, true);
             {
                 ScopedTimer t{this, "sparse_solve"};
                 if (rhs_perm) {  // ... and the solver's last kernel forms xb_i . x_1 on the way out
@@ -650,10 +728,16 @@ void AnmDriver::solve_expansion_coeffs() {
                 }
             }
             xbi = m_xbi.p();
+            if (pade_riders) m_pade_ws.phase(m_xt_coeffs, i - 1, 3, anm_cond, true);
             be->next_coeff_async(n, m_dev_scalars.p() + i, 1.0 / (t1 - xgt_dot_x1), m_xgt.p(), xbi, xi,
                                  m_host_scalars + 3 * i);
         }
         m_nr_valid_coeffs = i + 1;
+        if (pade_side) {
+            be->side_fork();
+            m_pade_ws.step(m_xt_coeffs, i, anm_cond);
+            be->side_end();
+        }
 
         if (m_profile_mode == 1) {
             trace_b_norm.push_back(std::sqrt(be->dot(n, bi, bi)));
@@ -666,18 +750,7 @@ void AnmDriver::solve_expansion_coeffs() {
             bias_done = fuse_passes;
         }
     }
-    if (m_hp.sanity_check) {
-        // anm.cpp:271-285: A x_i = -(t_i g_t + b_i) and x_1 . x_i = delta_1i for every order, in one pass over the
-        // matrix per 10 orders (the reference checks each order as it goes; a failure surfaces after the loop here)
-        ScopedTimer t{this, "anm_sanity_check"};
-        std::vector<const double*> xs(N), bs(N);
-        for (int i = 1; i <= N; ++i) {
-            xs[i - 1] = m_xt_coeffs[i].p();
-            bs[i - 1] = m_bi_all[i].p();
-        }
-        be->sanity_check_batch_async(m_pattern->csr(), N, xs.data(), grad_t, bs.data(), 1e-4, n1, m_xt_coeffs[1].p(),
-                                     m_tmp0.p(), m_tmp1.p(), host_sanity);
-    }
+    if (m_hp.sanity_check) queue_sanity(N, grad_t);  // the orders not checked beside the loop
     // the two norms of estimate_valid_range travel with the rest
     be->dot_async(n1, m_xt_coeffs[1].p(), m_xt_coeffs[1].p(), host_checks + 2);
     be->dot_async(n1, m_xt_coeffs[N].p(), m_xt_coeffs[N].p(), host_checks + 3);
@@ -724,6 +797,7 @@ void AnmDriver::estimate_valid_range() {
                m_t_coeffs[0], m_t_max, a_bound);
     m_pade.reset();
     static const bool env_pade = getenv("SANM_PADE") != nullptr;
+    m_be->side_join();
     if ((m_hp.use_pade || env_pade) && a_bound < m_max_a_bound) {
         auto pade = std::make_unique<PadeApproximation>(m_be, m_xt_coeffs, m_t_coeffs,
                                                         !m_hp.xcoeff_l2_penalty, &m_pade_ws);

@@ -122,9 +122,20 @@ struct PadeWorkspace {
     std::vector<DVec> orth;
     DVec acoef;
     void* graph = nullptr;
+    //! Gram-Schmidt steps 1 .. done of the current series are queued (the driver queues step i on the side
+    //! queue as soon as x_i exists: PadeApproximation then finds the basis ready); -1: steps not in use
+    int done = 0;
+    bool done_anm_cond = false;
     ~PadeWorkspace() {
         if (graph) be->graph_destroy(graph);
     }
+    void ensure(Backend* be_, int nx, size_t len);
+    //! one classical Gram-Schmidt step (pade.cpp:36-70) for xs[i], i = done + 1; the last step also completes
+    //! the normalisation of its own vector
+    void step(const std::vector<DVec>& xs, int i, bool anm_cond);
+    //! the same in its three phases (1 projections, 2 update, 3 scaling): step(i) == phase(i, 1..3, false);
+    //! with `defer` the backend may run the phase inside one of its next launches (Backend::defer_gs_phase)
+    void phase(const std::vector<DVec>& xs, int i, int k, bool anm_cond, bool defer);
 };
 
 class PadeApproximation {

@@ -51,6 +51,26 @@ struct AssemblyDev {
     int64_t nslots;
 };
 
+// One phase of a classical Gram-Schmidt step of the Pade basis (pade.cpp:36-70), as a value the backend may run at
+// once or carry along with one of its next launches (Backend::defer_gs_phase):
+//   kind 1: red_out[j] = x . vecs[j], j < nvec  (after completing the normalisation of vecs[nvec-1], see
+//           multi_dot_async);   kind 2: out = x - sum_{j >= first} coefs[j] vecs[j], *red_out = out . out;
+//   kind 3: out *= 1 / max(sqrt(*norm2), eps), *red_out = out . out
+struct GsPhase {
+    int kind = 0;
+    size_t n = 0;
+    const double* x = nullptr;
+    int nvec = 0;
+    double* vecs[24] = {};
+    const double* coefs = nullptr;
+    int first = 0;
+    double* out = nullptr;
+    const double* norm2 = nullptr;  // kind 3: of `out`; kind 1: of vecs[nvec-1] (may be null)
+    const double* nn2 = nullptr;    // kind 1: squared norm of vecs[nvec-1] after its first scaling
+    double eps = 0;
+    double* red_out = nullptr;      // device memory
+};
+
 class Backend {
 public:
     virtual ~Backend() = default;
@@ -71,6 +91,23 @@ public:
     virtual void* graph_capture_end() { return nullptr; }
     virtual void graph_launch(void*) {}
     virtual void graph_destroy(void*) {}
+    //! run one Gram-Schmidt phase now (through the *_async primitives below)
+    void run_gs_phase(const GsPhase& ph);
+    //! The same, but the backend may hold the phase back and run it inside one of its next launches on the same
+    //! queue (extra workgroups of a kernel that is launched anyway: the order loop is a chain of short launches
+    //! that leave most of the chip idle, and a launch of its own costs the chain its full latency).  A held phase
+    //! is run at the latest by the next defer_gs_phase, flush_deferred, sync or copy to the host.
+    virtual void defer_gs_phase(const GsPhase& ph) { run_gs_phase(ph); }
+    virtual void flush_deferred() {}
+    //! A second in-order queue beside the main one, for work that depends on the main queue only at the moment it
+    //! is forked off (the Pade basis grows by one vector per Taylor order while the main queue is busy with the
+    //! next order's solve, a chain of short latency-bound launches that leaves most of the chip idle).
+    //! side_fork(): everything queued so far on the main queue happens before what follows; launches go to the
+    //! side queue until side_end().  side_join(): what was queued on the side queue happens before what the main
+    //! queue gets from now on.  sync() waits for both.  Backends without queues run everything in order.
+    virtual void side_fork() {}
+    virtual void side_end() {}
+    virtual void side_join() {}
     //! host memory the device can write (pinned); results of the *_async reductions land here and are
     //! valid after the next sync()
     virtual double* alloc_host(size_t n_doubles) = 0;

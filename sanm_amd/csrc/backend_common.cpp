@@ -13,6 +13,22 @@ void Backend::allreduce_sum(double*, int64_t) {
     sanm_throw(SANM_ERR_UNSUPPORTED, "backend %s has no native collective (pass an all-reduce callback)", name());
 }
 
+void Backend::run_gs_phase(const GsPhase& ph) {
+    switch (ph.kind) {
+        case 1:
+            multi_dot_async(ph.n, ph.x, ph.nvec, ph.vecs, ph.red_out, ph.norm2, ph.nn2, ph.eps);
+            break;
+        case 2:
+            gs_update_async(ph.n, ph.x, ph.nvec, ph.vecs, ph.coefs, ph.first, ph.out, ph.red_out);
+            break;
+        case 3:
+            scale_rsqrt_async(ph.n, ph.out, ph.norm2, ph.eps, ph.red_out);
+            break;
+        default:
+            sanm_throw(SANM_ERR_ASSERT, "bad Gram-Schmidt phase %d", ph.kind);
+    }
+}
+
 void Backend::mf_solve_fused(const MfDev& mf, const MfSchedule& sch, const double* b, double* x, const double* dot_y,
                              double* dot_out) {
     if (!b) sanm_throw(SANM_ERR_ASSERT, "mf_solve_fused: this backend needs the right-hand side");

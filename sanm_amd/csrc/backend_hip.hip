@@ -131,53 +131,6 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(SparseRowsDev R, const
     }
 }
 
-// remap_out with its rows in triples (SparseRowsDev::bptr): GATHER_LANES lanes per vertex, one list entry feeds the
-// three components (their values sit 3 doubles apart in the tet's block of the tet-major output buffer)
-__global__ void __launch_bounds__(256) gather_rows3_kernel(SparseRowsDev R, const double* __restrict__ src,
-                                                           double* __restrict__ dst,
-                                                           const int32_t* __restrict__ perm,
-                                                           double* __restrict__ dst2) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t u = gid / GATHER_LANES;
-    const int sub = gid % GATHER_LANES;
-    double s[3] = {0, 0, 0};
-    int pm[3] = {0, 0, 0};
-    if (u < R.nrows / 3) {
-        const uint32_t p0 = R.bptr[u], e = R.bptr[u + 1];
-        if (perm && sub == 0) {  // requested with the list, not after the sums
-#pragma unroll
-            for (int c = 0; c < 3; ++c) pm[c] = perm[3 * u + c];
-        }
-        for (uint32_t base = p0; base < e; base += 4 * GATHER_LANES) {  // 4 index -> value chains in flight
-            uint32_t i[4];
-            double c[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t q = base + sub + k * GATHER_LANES, qq = q < e ? q : p0;
-                i[k] = R.bidx[qq];
-                const double cv = R.bcoef[qq];
-                c[k] = q < e ? cv : 0.0;
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                s[0] += c[k] * src[i[k]];
-                s[1] += c[k] * src[i[k] + 3];
-                s[2] += c[k] * src[i[k] + 6];
-            }
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-        for (int off = GATHER_LANES / 2; off > 0; off >>= 1) s[c] += __shfl_down(s[c], off, GATHER_LANES);
-    if (u < R.nrows / 3 && sub == 0) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            dst[3 * u + c] = s[c];
-            if (perm) dst2[pm[c]] = s[c];
-        }
-    }
-}
-
 // CSR assembly: ROW_LANES lanes per non-zero (~25 contributions each)
 __global__ void __launch_bounds__(256) assemble_kernel(AssemblyDev A, const double* __restrict__ jac,
                                                        double* __restrict__ val) {
@@ -268,8 +221,11 @@ struct GridRed {
     unsigned* ticket;
     double* host;      // pinned, device-accessible
 };
+// (bid of nb: the workgroup's place among the workgroups that take part -- all of a launch, or the extra ones a
+// launch carries for a deferred Gram-Schmidt phase, see GsRider)
 template <int NV>
-__device__ __forceinline__ void grid_commit(const double (&v)[NV], int nv, unsigned maxmask, GridRed g) {
+__device__ __forceinline__ void grid_commit_at(const double (&v)[NV], int nv, unsigned maxmask, GridRed g,
+                                               unsigned bid, unsigned nb) {
     // A wavefront reduction is 6 cross-lane steps of ~100 cycles; with many values per thread (the Gram-Schmidt
     // projections: up to 24) they are spread over the 4 wavefronts through LDS instead of every wavefront
     // reducing every value (multi_dot_kernel: 17.6 -> see DESIGN.md for 20 vectors).
@@ -311,13 +267,12 @@ __device__ __forceinline__ void grid_commit(const double (&v)[NV], int nv, unsig
         const bool mx = (maxmask >> j) & 1;
         double r = sh[j][0];
         for (int i = 1; i < 4; ++i) r = mx ? fmax(r, sh[j][i]) : r + sh[j][i];
-        __hip_atomic_store(&g.partials[j * RED_MAX_GRID + blockIdx.x], r, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&g.partials[j * RED_MAX_GRID + bid], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0)
-        last = __hip_atomic_fetch_add(g.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+        last = __hip_atomic_fetch_add(g.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nb - 1;
     __syncthreads();
     if (!last) return;
     // one wavefront per value; the (up to KV) values of a wavefront are read in lock step, so that their
@@ -326,12 +281,12 @@ __device__ __forceinline__ void grid_commit(const double (&v)[NV], int nv, unsig
     double r[KV];
 #pragma unroll
     for (int q = 0; q < KV; ++q) r[q] = ((maxmask >> (w + 4 * q)) & 1) ? -1e300 : 0.0;
-    for (unsigned b0 = 0; b0 < gridDim.x; b0 += 64) {
+    for (unsigned b0 = 0; b0 < nb; b0 += 64) {
         const unsigned b = b0 + lane;
 #pragma unroll
         for (int q = 0; q < KV; ++q) {
             const int j = w + 4 * q;
-            if (j < nv && b < gridDim.x) {
+            if (j < nv && b < nb) {
                 const double pv = __hip_atomic_load(&g.partials[j * RED_MAX_GRID + b], __ATOMIC_RELAXED,
                                                     __HIP_MEMORY_SCOPE_AGENT);
                 r[q] = ((maxmask >> j) & 1) ? fmax(r[q], pv) : r[q] + pv;
@@ -348,18 +303,9 @@ __device__ __forceinline__ void grid_commit(const double (&v)[NV], int nv, unsig
     }
     if (threadIdx.x == 0) *g.ticket = 0;  // launches on the stream are serialised
 }
-
-// the last kernel of a solve (x[i] = w[perm[i]]) fused with the dot product the order loop takes of its result
-__global__ void __launch_bounds__(256) permute_out_dot_kernel(int64_t n, const int32_t* __restrict__ perm,
-                                                              const double* __restrict__ w, double* __restrict__ x,
-                                                              const double* __restrict__ y, GridRed g) {
-    double s[1] = {0};
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const double v = w[perm[i]];
-        x[i] = v;
-        s[0] += v * y[i];
-    }
-    grid_commit<1>(s, 1, 0u, g);
+template <int NV>
+__device__ __forceinline__ void grid_commit(const double (&v)[NV], int nv, unsigned maxmask, GridRed g) {
+    grid_commit_at<NV>(v, nv, maxmask, g, blockIdx.x, gridDim.x);
 }
 
 __global__ void __launch_bounds__(256) dot_kernel(size_t n, const double* __restrict__ x,
@@ -384,19 +330,6 @@ __global__ void axpby_tail_kernel(size_t n, double a, const double* x, double b,
     else if (i == n) out[i] = tail;
 }
 
-// x_i of the order loop with t_i taken from the device: t = *num * scale
-__global__ void next_coeff_kernel(size_t n, const double* __restrict__ num, double scale,
-                                  const double* __restrict__ x, const double* __restrict__ y, double* out,
-                                  double* t_out) {
-    const double t = *num * scale;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = -t * x[i] - y[i];
-    else if (i == n) {
-        out[i] = t;
-        *t_out = t;
-    }
-}
-
 constexpr int MAX_VEC = 24;
 struct VecList {
     const double* p[MAX_VEC];
@@ -410,15 +343,18 @@ __global__ void lincomb_kernel(size_t n, VecList v, double* out) {
     for (int j = 0; j < v.n; ++j) acc += v.c[j] * v.p[j][i];
     out[i] = acc;
 }
+// ---- Gram-Schmidt phases of the Pade basis (pade.cpp:36-70), as bodies over (workgroup bid of nb) -------------
+// They run either as kernels of their own or as EXTRA WORKGROUPS of a kernel the order loop launches anyway
+// (GsRider below): a phase is ~6 us of pure launch latency on a chip the host kernel leaves mostly idle.
+//
 // classical Gram-Schmidt update with the projections read from device memory, and the squared norm of
 // the result
 template <int NVT>
-__global__ void __launch_bounds__(256) gs_update_kernel(size_t n, const double* __restrict__ x, VecList q,
-                                                        const double* __restrict__ coefs, int first, double* out,
-                                                        GridRed g) {
+__device__ __forceinline__ void gs_update_body(size_t n, const double* __restrict__ x, const VecList& q,
+                                               const double* __restrict__ coefs, int first, double* out, GridRed g,
+                                               unsigned bid, unsigned nb) {
     double s[1] = {0};
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = (size_t)bid * blockDim.x + threadIdx.x; i < n; i += (size_t)nb * blockDim.x) {
         double acc = x[i], qv[NVT];
         if (q.n > 0) {
 #pragma unroll
@@ -430,20 +366,29 @@ __global__ void __launch_bounds__(256) gs_update_kernel(size_t n, const double* 
         out[i] = acc;
         s[0] += acc * acc;
     }
-    grid_commit<1>(s, 1, 0u, g);
+    grid_commit_at<1>(s, 1, 0u, g, bid, nb);
+}
+template <int NVT>
+__global__ void __launch_bounds__(256) gs_update_kernel(size_t n, const double* __restrict__ x, VecList q,
+                                                        const double* __restrict__ coefs, int first, double* out,
+                                                        GridRed g) {
+    gs_update_body<NVT>(n, x, q, coefs, first, out, g, blockIdx.x, gridDim.x);
 }
 // v *= 1 / max(sqrt(*norm2), eps), and the squared norm of the result for the (rare) second normalisation
-__global__ void __launch_bounds__(256) scale_rsqrt_kernel(size_t n, double* v, const double* __restrict__ norm2,
-                                                          double eps, GridRed g) {
+__device__ __forceinline__ void scale_rsqrt_body(size_t n, double* v, const double* __restrict__ norm2, double eps,
+                                                 GridRed g, unsigned bid, unsigned nb) {
     const double f = 1.0 / fmax(sqrt(*norm2), eps);
     double s[1] = {0};
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = (size_t)bid * blockDim.x + threadIdx.x; i < n; i += (size_t)nb * blockDim.x) {
         const double w = v[i] * f;
         v[i] = w;
         s[0] += w * w;
     }
-    grid_commit<1>(s, 1, 0u, g);
+    grid_commit_at<1>(s, 1, 0u, g, bid, nb);
+}
+__global__ void __launch_bounds__(256) scale_rsqrt_kernel(size_t n, double* v, const double* __restrict__ norm2,
+                                                          double eps, GridRed g) {
+    scale_rsqrt_body(n, v, norm2, eps, g, blockIdx.x, gridDim.x);
 }
 
 // second normalisation of an underflowed Gram-Schmidt direction; leaves at once otherwise
@@ -514,17 +459,16 @@ __global__ void __launch_bounds__(256) lincomb2_diff_norms_multi_kernel(size_t n
 // unrolled with unconditional loads -- slots beyond the count re-read the last vector -- or every vector's load
 // becomes a memory round trip of its own)
 template <int NVT>
-__global__ void __launch_bounds__(256) multi_dot_kernel(size_t n, const double* __restrict__ x, VecList v,
-                                                        const double* last_norm2, const double* last_nn2,
-                                                        double eps, GridRed g) {
+__device__ __forceinline__ void multi_dot_body(size_t n, const double* __restrict__ x, const VecList& v,
+                                               const double* last_norm2, const double* last_nn2, double eps,
+                                               GridRed g, unsigned bid, unsigned nb) {
     double acc[NVT];
 #pragma unroll
     for (int j = 0; j < NVT; ++j) acc[j] = 0;
     const bool fix = last_norm2 && v.n > 0 && sqrt(*last_norm2) < eps;
     const double f = fix ? 1.0 / sqrt(*last_nn2) : 1.0;
     double* last = fix ? const_cast<double*>(v.p[v.n - 1]) : nullptr;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = (size_t)bid * blockDim.x + threadIdx.x; i < n; i += (size_t)nb * blockDim.x) {
         const double xi = x[i];
         double y[NVT];
 #pragma unroll
@@ -537,7 +481,127 @@ __global__ void __launch_bounds__(256) multi_dot_kernel(size_t n, const double* 
                 acc[j] += xi * yj;
             }
     }
-    grid_commit<NVT>(acc, v.n, 0u, g);
+    grid_commit_at<NVT>(acc, v.n, 0u, g, bid, nb);
+}
+template <int NVT>
+__global__ void __launch_bounds__(256) multi_dot_kernel(size_t n, const double* __restrict__ x, VecList v,
+                                                        const double* last_norm2, const double* last_nn2,
+                                                        double eps, GridRed g) {
+    multi_dot_body<NVT>(n, x, v, last_norm2, last_nn2, eps, g, blockIdx.x, gridDim.x);
+}
+
+// ---- a deferred Gram-Schmidt phase riding on another launch ------------------------------------------------
+// (Backend::defer_gs_phase).  The host kernel is launched with `nblk` extra workgroups behind its own `own`; those
+// run the phase.  Which kernel carries which phase is fixed (template parameter of the carrier): the remap_out
+// gather carries the projections (kind 1, NVT = vector count rounded up to 4), the last kernel of a solve the
+// update (kind 2), next_coeff the scaling (kind 3); the order loop launches the three in that order once per order.
+struct GsRider {
+    size_t n;
+    const double* x;
+    VecList q;
+    const double* coefs;
+    int first;
+    double* out;
+    const double* norm2;
+    const double* nn2;
+    double eps;
+    unsigned nblk;
+    GridRed g;
+};
+
+// remap_out with its rows in triples (SparseRowsDev::bptr): GATHER_LANES lanes per vertex, one list entry feeds the
+// three components (their values sit 3 doubles apart in the tet's block of the tet-major output buffer)
+template <int RIDE_NVT>
+__global__ void __launch_bounds__(256) gather_rows3_kernel(SparseRowsDev R, const double* __restrict__ src,
+                                                           double* __restrict__ dst,
+                                                           const int32_t* __restrict__ perm,
+                                                           double* __restrict__ dst2, unsigned own, GsRider rd) {
+    if constexpr (RIDE_NVT > 0) {
+        if (blockIdx.x >= own) {
+            multi_dot_body<RIDE_NVT>(rd.n, rd.x, rd.q, rd.norm2, rd.nn2, rd.eps, rd.g, blockIdx.x - own, rd.nblk);
+            return;
+        }
+    }
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t u = gid / GATHER_LANES;
+    const int sub = gid % GATHER_LANES;
+    double s[3] = {0, 0, 0};
+    int pm[3] = {0, 0, 0};
+    if (u < R.nrows / 3) {
+        const uint32_t p0 = R.bptr[u], e = R.bptr[u + 1];
+        if (perm && sub == 0) {  // requested with the list, not after the sums
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pm[c] = perm[3 * u + c];
+        }
+        for (uint32_t base = p0; base < e; base += 4 * GATHER_LANES) {  // 4 index -> value chains in flight
+            uint32_t i[4];
+            double c[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t q = base + sub + k * GATHER_LANES, qq = q < e ? q : p0;
+                i[k] = R.bidx[qq];
+                const double cv = R.bcoef[qq];
+                c[k] = q < e ? cv : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s[0] += c[k] * src[i[k]];
+                s[1] += c[k] * src[i[k] + 3];
+                s[2] += c[k] * src[i[k] + 6];
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        for (int off = GATHER_LANES / 2; off > 0; off >>= 1) s[c] += __shfl_down(s[c], off, GATHER_LANES);
+    if (u < R.nrows / 3 && sub == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            dst[3 * u + c] = s[c];
+            if (perm) dst2[pm[c]] = s[c];
+        }
+    }
+}
+
+// the last kernel of a solve (x[i] = w[perm[i]]) fused with the dot product the order loop takes of its result
+template <int RIDE_NVT>
+__global__ void __launch_bounds__(256) permute_out_dot_kernel(int64_t n, const int32_t* __restrict__ perm,
+                                                              const double* __restrict__ w, double* __restrict__ x,
+                                                              const double* __restrict__ y, GridRed g, unsigned own,
+                                                              GsRider rd) {
+    if constexpr (RIDE_NVT > 0) {
+        if (blockIdx.x >= own) {
+            gs_update_body<RIDE_NVT>(rd.n, rd.x, rd.q, rd.coefs, rd.first, rd.out, rd.g, blockIdx.x - own, rd.nblk);
+            return;
+        }
+    }
+    double s[1] = {0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)own * blockDim.x) {
+        const double v = w[perm[i]];
+        x[i] = v;
+        s[0] += v * y[i];
+    }
+    grid_commit_at<1>(s, 1, 0u, g, blockIdx.x, own);
+}
+
+// x_i of the order loop with t_i taken from the device: t = *num * scale
+template <bool RIDE>
+__global__ void __launch_bounds__(256) next_coeff_kernel(size_t n, const double* __restrict__ num, double scale,
+                                                         const double* __restrict__ x, const double* __restrict__ y,
+                                                         double* out, double* t_out, unsigned own, GsRider rd) {
+    if constexpr (RIDE) {
+        if (blockIdx.x >= own) {
+            scale_rsqrt_body(rd.n, rd.out, rd.norm2, rd.eps, rd.g, blockIdx.x - own, rd.nblk);
+            return;
+        }
+    }
+    const double t = *num * scale;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = -t * x[i] - y[i];
+    else if (i == n) {
+        out[i] = t;
+        *t_out = t;
+    }
 }
 
 __global__ void vmul_kernel(size_t n, const double* x, const double* y, double* out) {
@@ -826,7 +890,12 @@ struct Rccl {
 };
 
 class HipBackend final : public Backend {
-    hipStream_t m_stream = nullptr;
+    hipStream_t m_stream = nullptr;  // the queue launches currently go to: m_main, or m_side between side_fork / side_end
+    hipStream_t m_main = nullptr, m_side = nullptr;
+    bool m_side_dirty = false;  // the side queue got work since the last join / sync
+    static constexpr int kForkEvents = 64;
+    hipEvent_t m_fork_ev[kForkEvents] = {};
+    int m_fork_next = 0;
     Rccl::Comm m_comm = nullptr;
     int m_comm_rank = 0, m_comm_world = 0;
     // pass kernels compiled at run time for one program each (specialize)
@@ -835,7 +904,7 @@ class HipBackend final : public Backend {
         hipFunction_t pass[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     };
     std::vector<SpecKernels> m_spec;
-    GridRed m_red{nullptr, nullptr, nullptr};
+    GridRed m_red{nullptr, nullptr, nullptr}, m_red_side{nullptr, nullptr, nullptr};
     static constexpr size_t kPoolBlockMax = size_t(64) << 20, kPoolTotalMax = size_t(4) << 30;
     std::unordered_map<void*, size_t> m_live;
     std::unordered_map<size_t, std::vector<void*>> m_pool_free;
@@ -886,7 +955,8 @@ public:
                        e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
         }
         HIP_CHECK(hipSetDevice(device));
-        HIP_CHECK(hipStreamCreate(&m_stream));
+        HIP_CHECK(hipStreamCreate(&m_main));
+        m_stream = m_main;
         HIP_CHECK(hipMalloc(&m_scalar, 64));
         HIP_CHECK(hipHostMalloc(&m_scalar_host, 64));
     }
@@ -904,7 +974,16 @@ public:
         if (m_pcg_sc_host) (void)hipHostFree(m_pcg_sc_host);
         (void)hipHostFree(m_scalar_host);
         for (hipEvent_t e : m_event_pool) (void)hipEventDestroy(e);
-        (void)hipStreamDestroy(m_stream);
+        for (hipEvent_t e : m_fork_ev)
+            if (e) (void)hipEventDestroy(e);
+        if (m_red_rider.partials) (void)hipFree(m_red_rider.partials);
+        if (m_red_rider.ticket) (void)hipFree(m_red_rider.ticket);
+        if (m_red_rider.host) (void)hipHostFree(m_red_rider.host);
+        if (m_red_side.partials) (void)hipFree(m_red_side.partials);
+        if (m_red_side.ticket) (void)hipFree(m_red_side.ticket);
+        if (m_red_side.host) (void)hipHostFree(m_red_side.host);
+        if (m_side) (void)hipStreamDestroy(m_side);
+        (void)hipStreamDestroy(m_main);
     }
     const char* name() const override { return "hip"; }
 
@@ -976,6 +1055,11 @@ public:
     }
     void d2h(void* dst, const void* src, size_t bytes) override {
         if (!bytes) return;
+        flush_deferred();
+        if (m_stream == m_main && m_side_dirty) {  // what the host reads may come from the side queue
+            HIP_CHECK(hipStreamSynchronize(m_side));
+            m_side_dirty = false;
+        }
         HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, m_stream));
         HIP_CHECK(hipStreamSynchronize(m_stream));
     }
@@ -987,7 +1071,39 @@ public:
         if (!bytes) return;
         HIP_CHECK(hipMemsetAsync(dst, 0, bytes, m_stream));
     }
-    void sync() override { HIP_CHECK(hipStreamSynchronize(m_stream)); }
+    void sync() override {
+        flush_deferred();
+        HIP_CHECK(hipStreamSynchronize(m_main));
+        if (m_side_dirty) {
+            HIP_CHECK(hipStreamSynchronize(m_side));
+            m_side_dirty = false;
+        }
+    }
+    hipEvent_t next_fork_event() {
+        hipEvent_t& e = m_fork_ev[m_fork_next];
+        m_fork_next = (m_fork_next + 1) % kForkEvents;
+        if (!e) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        return e;
+    }
+    void side_fork() override {
+        if (m_stream != m_main) sanm_throw(SANM_ERR_ASSERT, "side_fork inside a fork");
+        if (!m_side) HIP_CHECK(hipStreamCreateWithFlags(&m_side, hipStreamNonBlocking));
+        red_for(m_red_side);  // (allocated outside any launch sequence)
+        hipEvent_t e = next_fork_event();
+        HIP_CHECK(hipEventRecord(e, m_main));
+        HIP_CHECK(hipStreamWaitEvent(m_side, e, 0));
+        m_stream = m_side;
+        m_side_dirty = true;
+    }
+    void side_end() override { m_stream = m_main; }
+    void side_join() override {
+        if (m_stream != m_main) sanm_throw(SANM_ERR_ASSERT, "side_join inside a fork");
+        if (!m_side_dirty) return;
+        hipEvent_t e = next_fork_event();
+        HIP_CHECK(hipEventRecord(e, m_side));
+        HIP_CHECK(hipStreamWaitEvent(m_main, e, 0));
+        m_side_dirty = false;
+    }
     hipStream_t stream() const { return m_stream; }
 
     int specialize(const char* source) override {
@@ -1134,12 +1250,69 @@ public:
         *total_ms = tot;
         *count = m_pass_events.size();
     }
+    // ---- deferred Gram-Schmidt phases (Backend::defer_gs_phase; GsRider above) ------------------------------
+    GsPhase m_pending{};  // kind 0: none
+    GridRed m_red_rider{nullptr, nullptr, nullptr};
+    const bool m_no_riders = std::getenv("SANM_NO_RIDERS") != nullptr;
+    void defer_gs_phase(const GsPhase& ph) override {
+        flush_deferred();
+        if (m_no_riders || m_stream != m_main || (ph.kind == 1 && ph.nvec == 0) || ph.nvec > MAX_VEC) {
+            run_gs_phase(ph);
+            return;
+        }
+        red_for(m_red_rider);
+        m_pending = ph;
+    }
+    void flush_deferred() override {
+        if (!m_pending.kind) return;
+        const GsPhase ph = m_pending;
+        m_pending.kind = 0;
+        run_gs_phase(ph);
+    }
+    //! the pending phase as the extra workgroups of a carrier launch; clears it
+    GsRider take_rider() {
+        const GsPhase& ph = m_pending;
+        GsRider r{};
+        r.n = ph.n;
+        r.x = ph.x;
+        r.q.n = ph.nvec;
+        for (int j = 0; j < ph.nvec; ++j) r.q.p[j] = ph.vecs[j];
+        r.coefs = ph.coefs;
+        r.first = ph.first;
+        r.out = ph.out;
+        r.norm2 = ph.norm2;
+        r.nn2 = ph.nn2;
+        r.eps = ph.eps;
+        r.nblk = red_grid(ph.n);
+        r.g = m_red_rider;
+        r.g.host = ph.red_out;
+        m_pending.kind = 0;
+        return r;
+    }
+    static int nvt_group(int nvec) { return nvec <= 4 ? 4 : (nvec + 3) / 4 * 4; }
+
     void gather_rows(const SparseRowsDev& R, const double* src, double* dst, const int32_t* perm,
                      double* dst2) override {
-        if (R.bptr)
-            hipLaunchKernelGGL(gather_rows3_kernel, dim3(nblk((size_t)R.nrows / 3 * GATHER_LANES, 256)), dim3(256), 0,
-                               m_stream, R, src, dst, perm, dst2);
-        else
+        if (R.bptr) {
+            const unsigned own = nblk((size_t)R.nrows / 3 * GATHER_LANES, 256);
+            if (m_pending.kind == 1 && m_stream == m_main) {  // the projections of a Gram-Schmidt step ride along
+                const int nvt = nvt_group(m_pending.nvec);
+                const GsRider rd = take_rider();
+#define SANM_G3(NVT)                                                                                                \
+    case NVT:                                                                                                       \
+        hipLaunchKernelGGL(gather_rows3_kernel<NVT>, dim3(own + rd.nblk), dim3(256), 0, m_stream, R, src, dst, perm, \
+                           dst2, own, rd);                                                                          \
+        break;
+                switch (nvt) {
+                    SANM_G3(4) SANM_G3(8) SANM_G3(12) SANM_G3(16) SANM_G3(20) SANM_G3(24)
+                    default: sanm_throw(SANM_ERR_ASSERT, "rider: %d vectors", nvt);
+                }
+#undef SANM_G3
+            } else {
+                hipLaunchKernelGGL(gather_rows3_kernel<0>, dim3(own), dim3(256), 0, m_stream, R, src, dst, perm, dst2, own,
+                                   GsRider{});
+            }
+        } else
             hipLaunchKernelGGL(gather_rows_kernel, dim3(nblk((size_t)R.nrows * GATHER_LANES, 256)), dim3(256), 0,
                                m_stream, R, src, dst, perm, dst2);
         HIP_CHECK(hipGetLastError());
@@ -1394,10 +1567,26 @@ public:
                                mf.perm, b, mf.work);
         for (size_t li = 0; li < sch.levels.size(); ++li) level_solve(true, mf, sch.levels[li]);
         for (int li = (int)sch.levels.size() - 1; li >= 0; --li) level_solve(false, mf, sch.levels[li]);
-        if (dot_y)
-            hipLaunchKernelGGL(permute_out_dot_kernel, dim3(red_grid(mf.n)), dim3(256), 0, m_stream, mf.n, mf.perm,
-                               mf.work, x, dot_y, red_to(dot_out));
-        else
+        if (dot_y) {
+            const unsigned own = red_grid(mf.n);
+            if (m_pending.kind == 2 && m_stream == m_main) {  // the update of a Gram-Schmidt step rides along
+                const int nvt = nvt_group(m_pending.nvec);
+                const GsRider rd = take_rider();
+#define SANM_POD(NVT)                                                                                              \
+    case NVT:                                                                                                      \
+        hipLaunchKernelGGL(permute_out_dot_kernel<NVT>, dim3(own + rd.nblk), dim3(256), 0, m_stream, mf.n, mf.perm, \
+                           mf.work, x, dot_y, red_to(dot_out), own, rd);                                           \
+        break;
+                switch (nvt) {
+                    SANM_POD(4) SANM_POD(8) SANM_POD(12) SANM_POD(16) SANM_POD(20) SANM_POD(24)
+                    default: sanm_throw(SANM_ERR_ASSERT, "rider: %d vectors", nvt);
+                }
+#undef SANM_POD
+            } else {
+                hipLaunchKernelGGL(permute_out_dot_kernel<0>, dim3(own), dim3(256), 0, m_stream, mf.n, mf.perm, mf.work, x,
+                                   dot_y, red_to(dot_out), own, GsRider{});
+            }
+        } else
             hipLaunchKernelGGL(permute_out_kernel, dim3(nblk(mf.n, 256)), dim3(256), 0, m_stream, mf.n,
                                mf.perm, mf.work, x);
         HIP_CHECK(hipGetLastError());
@@ -1437,15 +1626,17 @@ public:
     }
 
     // reductions read by the host: see grid_commit
-    GridRed red() {
-        if (!m_red.partials) {
-            HIP_CHECK(hipMalloc(&m_red.partials, MAX_VEC * RED_MAX_GRID * sizeof(double)));
-            HIP_CHECK(hipMalloc(&m_red.ticket, sizeof(unsigned)));
-            HIP_CHECK(hipMemset(m_red.ticket, 0, sizeof(unsigned)));
-            HIP_CHECK(hipHostMalloc(&m_red.host, MAX_VEC * sizeof(double)));
+    // (each queue has its own partials and ticket: kernels of the two queues run side by side)
+    GridRed& red_for(GridRed& r) {
+        if (!r.partials) {
+            HIP_CHECK(hipMalloc(&r.partials, MAX_VEC * RED_MAX_GRID * sizeof(double)));
+            HIP_CHECK(hipMalloc(&r.ticket, sizeof(unsigned)));
+            HIP_CHECK(hipMemset(r.ticket, 0, sizeof(unsigned)));
+            HIP_CHECK(hipHostMalloc(&r.host, MAX_VEC * sizeof(double)));
         }
-        return m_red;
+        return r;
     }
+    GridRed red() { return red_for(m_stream == m_side && m_side ? m_red_side : m_red); }
     GridRed red_to(double* out) {  // same partials / ticket, result to `out` (device or pinned memory)
         GridRed g = red();
         g.host = out;
@@ -1454,7 +1645,7 @@ public:
     const double* red_result() {
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(m_stream));
-        return m_red.host;
+        return (m_stream == m_side && m_side ? m_red_side : m_red).host;
     }
     double dot(size_t n, const double* x, const double* y) override {
         hipLaunchKernelGGL(dot_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, y, red());
@@ -1641,6 +1832,7 @@ public:
         HIP_CHECK(hipGetLastError());
     }
     bool graph_capture_begin() override {
+        flush_deferred();
         red();  // no allocation while capturing
         HIP_CHECK(hipStreamBeginCapture(m_stream, hipStreamCaptureModeThreadLocal));
         return true;
@@ -1663,8 +1855,15 @@ public:
     }
     void next_coeff_async(size_t n, const double* num, double scale, const double* x, const double* y,
                           double* out, double* t_out) override {
-        hipLaunchKernelGGL(next_coeff_kernel, dim3(nblk(n + 1, 256)), dim3(256), 0, m_stream, n, num, scale, x,
-                           y, out, t_out);
+        const unsigned own = nblk(n + 1, 256);
+        if (m_pending.kind == 3 && m_stream == m_main) {  // the scaling of a Gram-Schmidt step rides along
+            const GsRider rd = take_rider();
+            hipLaunchKernelGGL(next_coeff_kernel<true>, dim3(own + rd.nblk), dim3(256), 0, m_stream, n, num, scale, x, y,
+                               out, t_out, own, rd);
+        } else {
+            hipLaunchKernelGGL(next_coeff_kernel<false>, dim3(own), dim3(256), 0, m_stream, n, num, scale, x, y, out,
+                               t_out, own, GsRider{});
+        }
         HIP_CHECK(hipGetLastError());
     }
     double* alloc_host(size_t n) override {

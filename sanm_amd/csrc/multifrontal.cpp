@@ -557,6 +557,82 @@ private:
     }
 };
 
+// ---------------------------------------------------------------------------
+// Amalgamation of tree levels.  Every level of the dissection tree costs the solve two launches per right-hand
+// side (an ANM step solves `order` of them, one after the other) and the factorisation its fixed launches
+// (extend-add rounds, first diagonal tile, panel finalisation, two GEMM passes), while the fronts of the lower
+// levels are so small that their kernels are pure launch latency.  Merging the fronts of a level into their
+// parents removes that level: the parent's pivot block takes the children's variables in front of its own (same
+// elimination order as before), the grandchildren become its children, its boundary stays what it was.  The
+// price is dense storage of the (zero) coupling between the merged children and of their rows over the whole
+// parent boundary instead of their own -- a few per cent of the factor for the two merges below on a 3D mesh,
+// against 1/5 of the solve launches.  SANM_MF_MERGE="h1,h2,..." overrides the heights whose fronts are merged
+// into their parents ("" or "none": no merging); the default merges heights 1 and 3 when the tree is tall enough
+// that those are small separator levels (measured on the BASELINE meshes: DESIGN.md section 5).
+void amalgamate_levels(std::vector<NdNode>& nodes, const SvGraph& g) {
+    const int32_t F = nodes.size();
+    std::vector<int32_t> height(F, 0);
+    // children appear after their parents in `nodes` (the dissection pushes a node before its parts)
+    for (int32_t u = F - 1; u >= 0; --u)
+        if (nodes[u].parent >= 0) height[nodes[u].parent] = std::max(height[nodes[u].parent], height[u] + 1);
+    int32_t H = 0;
+    for (int32_t u = 0; u < F; ++u) H = std::max(H, height[u] + 1);
+    std::vector<int> merge;
+    if (const char* e = std::getenv("SANM_MF_MERGE")) {
+        for (const char* p = e; *p;) {
+            if (*p >= '0' && *p <= '9') {
+                merge.push_back(std::atoi(p));
+                while (*p >= '0' && *p <= '9') ++p;
+            } else {
+                ++p;
+            }
+        }
+    } else if (H >= 8) {
+        merge = {1, 3};
+    }
+    if (merge.empty()) return;
+    std::vector<char> at(H + 1, 0);
+    for (int h : merge)
+        if (h >= 1 && h < H - 1) at[h] = 1;  // never the leaves (they hold the bulk of the factor) nor the roots
+    (void)g;
+    std::vector<char> dead(F, 0);
+    // top-down over the nodes (parents first): a merged node hands its variables and children up
+    for (int32_t u = 0; u < F; ++u) {
+        const int32_t p = nodes[u].parent;
+        if (p < 0 || !at[height[u]] || height[p] != height[u] + 1) continue;
+        dead[u] = 1;
+    }
+    for (int32_t u = F - 1; u >= 0; --u) {  // children before parents: a dead node is complete when it is merged
+        if (!dead[u]) continue;
+        NdNode& c = nodes[u];
+        int32_t p = c.parent;
+        while (dead[p]) p = nodes[p].parent;  // (adjacent heights are never both merged below; kept general)
+        NdNode& P = nodes[p];
+        std::vector<int32_t> vars = std::move(c.vars);
+        vars.insert(vars.end(), P.vars.begin(), P.vars.end());
+        P.vars = std::move(vars);
+        for (int32_t gc : c.children) {
+            nodes[gc].parent = p;
+            P.children.push_back(gc);
+        }
+        P.children.erase(std::remove(P.children.begin(), P.children.end(), u), P.children.end());
+        c.children.clear();
+    }
+    // compact
+    std::vector<int32_t> newid(F, -1);
+    std::vector<NdNode> out;
+    for (int32_t u = 0; u < F; ++u)
+        if (!dead[u]) {
+            newid[u] = out.size();
+            out.push_back(std::move(nodes[u]));
+        }
+    for (auto& nd : out) {
+        if (nd.parent >= 0) nd.parent = newid[nd.parent];
+        for (auto& ch : nd.children) ch = newid[ch];
+    }
+    nodes.swap(out);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -582,6 +658,7 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     used_coords = coords != nullptr;
     NestedDissection nd{g};
     nd.run();
+    amalgamate_levels(nd.nodes, g);
     const int32_t F = nd.nodes.size();
     nr_front = F;
 
@@ -630,8 +707,9 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
         int32_t next = 0;
         for (int32_t f = 0; f < F; ++f) {
             own_start[f] = next;
-            auto vars = nd.nodes[post[f]].vars;
-            std::sort(vars.begin(), vars.end());
+            // (elimination order inside a front: as the dissection left it -- an amalgamated front lists the
+            // variables of its former children first, i.e. keeps the order of the tree it came from)
+            const auto& vars = nd.nodes[post[f]].vars;
             for (int32_t s : vars) {
                 sanm_check(sv_front[s] < 0, "supervariable assigned twice");
                 sv_front[s] = f;
