@@ -123,6 +123,9 @@ typedef struct sanm_hyper_param { /* ANMDriverHelper::HyperParam, anm.h:100-114,
     int solver_kind;    /* 0 = Jacobi-PCG, 1 = multifrontal LU (default) */
     int profile;        /* 1: sync + host clock around each phase (ScopedProfiler tags, utils.h:225-249);
                            2: device events around each phase, no synchronisation (bench.py) */
+    int solver_refine;  /* direct solver: steps of iterative refinement per solve (residual in double-double).
+                           0 = only after a factorisation that had to perturb pivots (2 steps then), which is
+                           what PARDISO does with the reference's settings (sparse_solver.cpp:107-127) */
 } sanm_hyper_param;
 void sanm_hyper_param_default(sanm_hyper_param* hp, int eqn_solver);
 
@@ -215,6 +218,12 @@ typedef struct sanm_anm_stats {
     double factor_flops;
 } sanm_anm_stats;
 int sanm_anm_get_stats(const sanm_anm_solver* s, sanm_anm_stats* st);
+/* test hook (fault injection): during the next expansion, corrupt one entry -- kind 1: coefficient x_order[index],
+ * 2: right-hand side b_order[index] before its solve, 3: Jacobian values [index, index + max(order, 1)) after the
+ * assembly; the entry is multiplied by `value` if scale != 0, else replaced by it (NaN allowed).  The checks the reference makes per
+ * order (libsanm/anm.cpp:271-285, sparse_solver.cpp:160-161, :288-289) are batched after the order loop here;
+ * tests/test_fault_injection.py uses this hook to show that each of them fires. */
+int sanm_anm_debug_inject(sanm_anm_solver* s, int kind, int order, int64_t index, double value, int scale);
 /* profile tags: returns the number of tags; names/seconds may be NULL */
 int sanm_anm_profile(const sanm_anm_solver* s, int max_tags, const char** names, double* seconds);
 /* how many times each tag was entered, in the order of sanm_anm_profile (call that first) */

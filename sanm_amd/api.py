@@ -49,7 +49,7 @@ class HyperParamC(C.Structure):
                 ("maxr", C.c_double), ("solution_check_tol", C.c_double),
                 ("xcoeff_l2_penalty", C.c_double), ("converge_rms", C.c_double),
                 ("solver_rtol", C.c_double), ("solver_maxit", C.c_int), ("solver_kind", C.c_int),
-                ("profile", C.c_int)]
+                ("profile", C.c_int), ("solver_refine", C.c_int)]
 
 
 class StatsC(C.Structure):
@@ -84,7 +84,7 @@ SYMBOLS = [
     "sanm_anm_update_approx", "sanm_anm_restart", "sanm_anm_spec_source", "sanm_rtc_compile_check", "sanm_anm_time_kernel", "sanm_anm_pass_timing", "sanm_anm_converged", "sanm_anm_residual_rms", "sanm_anm_get_x",
     "sanm_anm_get_t_upper", "sanm_anm_get_t_max_a", "sanm_anm_solve_a", "sanm_anm_eval",
     "sanm_anm_nr_iter", "sanm_anm_nr_xt_coeffs", "sanm_anm_xt_coeff", "sanm_anm_has_pade",
-    "sanm_anm_get_stats", "sanm_anm_profile", "sanm_anm_profile_counts", "sanm_anm_set_profile", "sanm_anm_trace", "sanm_anm_jacobian_csr",
+    "sanm_anm_get_stats", "sanm_anm_profile", "sanm_anm_profile_counts", "sanm_anm_set_profile", "sanm_anm_debug_inject", "sanm_anm_trace", "sanm_anm_jacobian_csr",
     "sanm_fea_model_create", "sanm_fea_model_destroy", "sanm_fea_model_nr_unknown",
     "sanm_fea_model_graph", "sanm_fea_model_output_var", "sanm_fea_model_F_var",
     "sanm_fea_model_remap_inp", "sanm_fea_model_remap_out", "sanm_fea_model_x0",
@@ -523,6 +523,11 @@ class _ANMSolver:
         cnt = (C.c_double * max(len(keys), 1))()
         n = self.api.lib.sanm_anm_profile_counts(self.h, C.c_int(len(keys)), cnt)
         return {keys[i]: cnt[i] for i in range(min(n, len(keys)))}
+
+    def debug_inject(self, kind, order, index, value, scale=False):
+        """test hook, see sanm_anm_debug_inject"""
+        self.api.check(self.api.lib.sanm_anm_debug_inject(self.h, C.c_int(kind), C.c_int(order), C.c_int64(index),
+                                                          C.c_double(value), C.c_int(1 if scale else 0)))
 
     def set_profile(self, mode, clear=True):
         """0: off, 1: host clock around synchronised phases, 2: device events (no synchronisation)"""

@@ -92,35 +92,87 @@ class DirectSolver final : public LinearSolver {
     Backend* m_be;
     const JacobianPattern& m_pat;
     Multifrontal m_mf;
+    // Iterative refinement (x += A^-1 (b - A x), residual in double-double): `m_refine_always` steps per solve on
+    // request (HyperParam::solver_refine / SANM_SOLVER_REFINE: brings the solution within ~1e-14 of the exact one
+    // where the plain LU of an elasticity Jacobian of condition 5e8 is off by 4e-11 and PARDISO by 4e-13), and
+    // 2 steps after a factorisation that had to perturb pivots -- what PARDISO does with the reference's
+    // settings (pardisoinit defaults for mtype 11: iparm[9] = 13, iparm[7] = 0; sparse_solver.cpp:107-127).
+    const int m_refine_always;
+    int m_refine = 0;
+    bool m_residual_checked = true;
+    DVec m_r, m_d;
+
+    void refine(const double* b, double* x) {
+        const size_t n = m_pat.n();
+        if (m_r.empty()) {
+            m_r = DVec{m_be, n};
+            m_d = DVec{m_be, n};
+        }
+        for (int s = 0; s < m_refine; ++s) {
+            m_be->residual(m_pat.csr(), b, x, m_r.p());
+            m_be->mf_solve(m_mf.dev(), m_mf.schedule(), m_r.p(), m_d.p());
+            m_be->axpby(n, 1.0, x, 1.0, m_d.p(), x);
+        }
+        if (!m_residual_checked) {
+            // the first solve after perturbed pivots: the refined solution must actually solve the system
+            m_residual_checked = true;
+            m_be->residual(m_pat.csr(), b, x, m_r.p());
+            const double rr = m_be->dot(n, m_r.p(), m_r.p()), bb = m_be->dot(n, b, b);
+            if (!(rr <= 1e-16 * bb))  // relative residual 1e-8
+                sanm_throw(SANM_ERR_NUMERICAL,
+                           "multifrontal LU: pivots were perturbed and iterative refinement stalls at a relative "
+                           "residual of %g; the Jacobian is numerically singular", std::sqrt(rr / std::max(bb, 1e-300)));
+        }
+    }
 
 public:
-    DirectSolver(Backend* be, const JacobianPattern& pat, const double* coords)
-            : m_be{be}, m_pat{pat}, m_mf{be, pat.n(), pat.h_rowptr(), pat.h_col(), coords} {
+    DirectSolver(Backend* be, const JacobianPattern& pat, const HyperParam& hp, const double* coords)
+            : m_be{be}, m_pat{pat}, m_mf{be, pat.n(), pat.h_rowptr(), pat.h_col(), coords},
+              m_refine_always{std::getenv("SANM_SOLVER_REFINE") ? std::atoi(std::getenv("SANM_SOLVER_REFINE"))
+                                                                : hp.solver_refine} {
         nnz_factors = m_mf.nnz_factors;
         nr_front = m_mf.nr_front;
         nr_level = m_mf.nr_level;
         max_front = m_mf.max_front;
         factor_flops = m_mf.factor_flops;
+        m_refine = m_refine_always;
     }
     void prepare() override {
         int bad = m_be->mf_factor(m_mf.dev(), m_mf.schedule(), m_pat.csr());
-        if (bad)
-            sanm_throw(SANM_ERR_NUMERICAL, "multifrontal LU: %d zero pivot(s); the Jacobian is singular", bad);
+        double st = bad;
+        (void)check_prepared(&st);
     }
     void prepare_async(double* status) override {
+        m_refine = m_refine_always;
         m_be->mf_factor_async(m_mf.dev(), m_mf.schedule(), m_pat.csr(), status);
     }
-    void check_prepared(const double* status) override {
-        if (*status != 0)
-            sanm_throw(SANM_ERR_NUMERICAL, "multifrontal LU: %d zero pivot(s); the Jacobian is singular", (int)*status);
+    bool check_prepared(const double* status) override {
+        nr_perturbed_pivots = (int64_t)*status;
+        if (*status != *status) sanm_throw(SANM_ERR_NUMERICAL, "multifrontal LU: the factorisation status is not a number");
+        if (*status == 0) {
+            m_refine = m_refine_always;
+            return false;
+        }
+        if (m_refine >= 2) return false;  // already refining: the solves so far stand
+        m_refine = 2;
+        m_residual_checked = false;
+        return true;
     }
     void solve(const double* b, double* x) override {
         m_be->mf_solve(m_mf.dev(), m_mf.schedule(), b, x);
+        if (m_refine > 0) refine(b, x);
         ++nr_solve;
     }
-    const int32_t* rhs_perm() const override { return m_mf.dev().perm; }
+    // (with refinement the right-hand side is needed again after the solve: no fused ends then)
+    const int32_t* rhs_perm() const override { return m_refine > 0 ? nullptr : m_mf.dev().perm; }
     double* rhs_work() const override { return m_mf.dev().work; }
     void solve_fused(const double* b, double* x, const double* dot_y, double* dot_out) override {
+        sanm_check(m_refine == 0 || b, "solve_fused without a right-hand side while refining");
+        if (m_refine > 0) {
+            solve(b, x);
+            if (dot_y) m_be->dot_async(m_pat.n(), x, dot_y, dot_out);
+            return;
+        }
         m_be->mf_solve_fused(m_mf.dev(), m_mf.schedule(), b, x, dot_y, dot_out);
         ++nr_solve;
     }
@@ -128,8 +180,8 @@ public:
 }  // namespace
 
 std::unique_ptr<LinearSolver> make_direct_solver(Backend* be, const JacobianPattern& pat,
-                                                 const HyperParam&, const double* coords) {
-    return std::make_unique<DirectSolver>(be, pat, coords);
+                                                 const HyperParam& hp, const double* coords) {
+    return std::make_unique<DirectSolver>(be, pat, hp, coords);
 }
 
 std::unique_ptr<LinearSolver> make_pcg_solver(Backend* be, const JacobianPattern& pat,
@@ -572,6 +624,17 @@ AnmDriver::~AnmDriver() {
     if (m_host_scalars) m_be->free_host(m_host_scalars);
 }
 
+void AnmDriver::apply_injection(double* vec, int64_t len) {
+    // test hook (sanm_anm_debug_inject): overwrite or scale one entry of a device vector, once
+    const int64_t cnt = m_inject.kind == 3 ? std::max(m_inject.order, 1) : 1;  // kind 3: `order` entries in a row
+    sanm_check(m_inject.index >= 0 && m_inject.index + cnt <= len, "injection index out of range");
+    std::vector<double> v(cnt);
+    m_be->d2h(v.data(), vec + m_inject.index, 8 * cnt);
+    for (double& e : v) e = m_inject.scale ? e * m_inject.value : m_inject.value;
+    m_be->h2d(vec + m_inject.index, v.data(), 8 * cnt);
+    m_inject.kind = 0;
+}
+
 void AnmDriver::allreduce(double* buf, int64_t count) {
     if (!m_shard.active()) return;
     ScopedTimer t{this, "allreduce"};
@@ -680,6 +743,10 @@ void AnmDriver::solve_expansion_coeffs() {
             }
             // the one collective per Taylor order: sum of the per-shard nodal bias (n doubles)
             if (i > 1) allreduce(bi, n);
+            if (m_inject.kind == 2 && m_inject.order == i) {
+                apply_injection(bi, n);
+                rhs_perm = nullptr;  // the solver takes the corrupted vector, not the copy the gather left it
+            }
         }
         // Orders >= 2 queue their kernels without ever waiting for the device: t_i is formed on the
         // device from the reduction's result (next_coeff_async), lands in x_i[n] for the kernels that need
@@ -697,7 +764,8 @@ void AnmDriver::solve_expansion_coeffs() {
                                  m_grad_t_buf.p());
                 allreduce(m_pattern->csr().val, m_pattern->nnz());
                 if (m_pattern->has_t()) allreduce(m_grad_t_buf.p(), n);
-                // sparse_solver.cpp:288-289: the coefficients must be finite (examined after the loop)
+                if (m_inject.kind == 3) apply_injection(m_pattern->csr().val, m_pattern->nnz());
+                // sparse_solver.cpp:288-289: the coefficients must be finite (examined at the first synchronisation)
                 be->count_nonfinite_async(m_pattern->nnz(), m_pattern->csr().val, host_checks);
             }
             grad_t = get_grad_t();
@@ -705,12 +773,22 @@ void AnmDriver::solve_expansion_coeffs() {
                 ScopedTimer t{this, "sparse_prep"};
                 m_solver->prepare_async(host_checks + 1);
             }
+            double xgt2 = 0;
             {
                 ScopedTimer t{this, "sparse_solve"};
                 m_solver->solve(grad_t, m_xgt.p());
+                xgt2 = be->dot(n, m_xgt.p(), m_xgt.p());  // (waits for the device: the factor's status is in)
+                // sparse_solver.cpp:288-289: the coefficients must be finite
+                sanm_check(host_checks[0] == 0, "non-finite Jacobian coefficient");
+                if (m_solver->check_prepared(host_checks + 1)) {
+                    // perturbed pivots: the solver refines from now on (sparse_solver.cpp:107-127: PARDISO's
+                    // behaviour); this first solution is computed again
+                    m_solver->solve(grad_t, m_xgt.p());
+                    xgt2 = be->dot(n, m_xgt.p(), m_xgt.p());
+                }
             }
             xbi = bi;  // zero at first order (anm.cpp:235)
-            t1 = ti = 1.0 / std::sqrt(be->dot(n, m_xgt.p(), m_xgt.p()) + 1.0);
+            t1 = ti = 1.0 / std::sqrt(xgt2 + 1.0);
             // x_1 = -t1*xgt - xbi ; t_1 appended  (anm.cpp:261-264)
             be->axpby_tail(n, -ti, m_xgt.p(), -1.0, xbi, xi, ti);
             m_host_scalars[3 * i] = ti;
@@ -733,6 +811,7 @@ void AnmDriver::solve_expansion_coeffs() {
                                  m_host_scalars + 3 * i);
         }
         m_nr_valid_coeffs = i + 1;
+        if (m_inject.kind == 1 && m_inject.order == i) apply_injection(xi, n1);
         if (pade_side) {
             be->side_fork();
             m_pade_ws.step(m_xt_coeffs, i, anm_cond);
@@ -756,7 +835,6 @@ void AnmDriver::solve_expansion_coeffs() {
     be->dot_async(n1, m_xt_coeffs[N].p(), m_xt_coeffs[N].p(), host_checks + 3);
     be->sync();
     sanm_check(host_checks[0] == 0, "non-finite Jacobian coefficient");
-    m_solver->check_prepared(host_checks + 1);
     for (int i = 1; i <= N; ++i) {
         const double ti = m_host_scalars[3 * i];
         // the reference asserts a finite right-hand side before solving (sparse_solver.cpp:160-161);

@@ -34,6 +34,7 @@ struct HyperParam {  // libsanm/anm.h:100-114, :247-251
     int solver_maxit = 100000;
     int solver_kind = 1;  // 0: Jacobi-PCG, 1: multifrontal LU (direct)
     int profile = 0;      // synchronise + time every phase
+    int solver_refine = 0;  // direct solver: refinement steps per solve (0: only after perturbed pivots)
 };
 
 //! tet-sharded execution over several ranks (one process per GPU).  The reference's
@@ -92,7 +93,12 @@ public:
         (void)status;
         prepare();
     }
-    virtual void check_prepared(const double* status) { (void)status; }
+    //! true: the factorisation needed help (perturbed pivots) and the solver has switched to iterative
+    //! refinement -- solutions obtained since prepare_async are to be computed again
+    virtual bool check_prepared(const double* status) {
+        (void)status;
+        return false;
+    }
     virtual void solve(const double* b, double* x) = 0;
     //! Where the solver wants its right-hand side, if the caller can put it there while producing it: entry i
     //! at rhs_work()[rhs_perm()[i]] (null: no such place).  solve_fused(nullptr, ...) then solves for that
@@ -102,7 +108,7 @@ public:
     virtual void solve_fused(const double*, double*, const double*, double*) {
         sanm_throw(SANM_ERR_ASSERT, "solve_fused: not offered by this solver (rhs_perm() is null)");
     }
-    int64_t nr_solve = 0, tot_iters = 0, last_iters = 0;
+    int64_t nr_solve = 0, tot_iters = 0, last_iters = 0, nr_perturbed_pivots = 0;
     double last_relres = 0;
     // direct solver analysis (0 for iterative solvers)
     int64_t nnz_factors = 0, nr_front = 0, nr_level = 0, max_front = 0;
@@ -197,6 +203,16 @@ public:
     Backend* backend() const { return m_be; }
     const double* last_xt_coeff_dev(int i) const { return m_xt_coeffs[i].p(); }
     double* scratch_dev(int i) const { return i == 0 ? m_tmp0.p() : m_tmp1.p(); }
+    //! Test hook: corrupt one entry during the next solve_expansion_coeffs so that the deferred checks can be seen
+    //! to fire.  kind 1: x_order[index], 2: b_order[index] (before its solve), 3: Jacobian value [index] (after
+    //! the assembly); the entry is multiplied by `value` if `scale`, else replaced by it.
+    struct Injection {
+        int kind = 0, order = 0;
+        int64_t index = 0;
+        double value = 0;
+        bool scale = false;
+    };
+    void set_injection(const Injection& inj) { m_inject = inj; }
     //! per-order records of the last solve_expansion_coeffs (|b_k|, |x_k|, t_k)
     std::vector<double> trace_b_norm, trace_x_norm, trace_t;
 
@@ -207,6 +223,8 @@ protected:
     const double m_max_a_bound;
     const ShardInfo m_shard;
     int m_profile_mode = 0;
+    Injection m_inject;
+    void apply_injection(double* vec, int64_t len);
     void allreduce(double* buf, int64_t count);
     std::unique_ptr<Program> m_prog;
     std::unique_ptr<DeviceRows> m_remap_out;

@@ -130,6 +130,10 @@ public:
     //! y = A x  (SparseSolver::apply, sparse_solver.cpp:202-215)
     virtual void spmv(const CsrDev& A, const double* x, double* y) = 0;
 
+    //! r = b - A x for iterative refinement, accumulated in twice the working precision (the default, in
+    //! backend_common.cpp, is the plain fp64 form); r may alias b
+    virtual void residual(const CsrDev& A, const double* b, const double* x, double* r);
+
     // BLAS-1 on device vectors (libsanm/tensor.cpp:644-668, tensor_elemwise.cpp)
     virtual double dot(size_t n, const double* x, const double* y) = 0;
     //! out = a*x + b*y  (y may be null iff b == 0; out may alias x or y)

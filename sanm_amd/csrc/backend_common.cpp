@@ -13,6 +13,13 @@ void Backend::allreduce_sum(double*, int64_t) {
     sanm_throw(SANM_ERR_UNSUPPORTED, "backend %s has no native collective (pass an all-reduce callback)", name());
 }
 
+void Backend::residual(const CsrDev& A, const double* b, const double* x, double* r) {
+    double* ax = static_cast<double*>(alloc(A.n * 8));
+    spmv(A, x, ax);
+    axpby(A.n, 1.0, b, -1.0, ax, r);
+    free(ax);
+}
+
 void Backend::run_gs_phase(const GsPhase& ph) {
     switch (ph.kind) {
         case 1:

@@ -176,6 +176,38 @@ __global__ void spmv_kernel(CsrDev A, const double* __restrict__ x, double* __re
     if (row < A.n && sub == 0) y[row] = s;
 }
 
+// r = b - A x in double-double arithmetic (error-free products by fma, two-sum accumulation): the residual of
+// iterative refinement has to be known to more digits than the solution it corrects
+struct DD {
+    double hi, lo;
+};
+__device__ __forceinline__ void dd_add(DD& s, double v, double v_lo) {  // s += v (+ v_lo)
+    const double t = s.hi + v, z = t - s.hi;
+    const double err = (s.hi - (t - z)) + (v - z);
+    s.hi = t;
+    s.lo += err + v_lo;
+}
+__global__ void residual_dd_kernel(CsrDev A, const double* __restrict__ b, const double* __restrict__ x,
+                                   double* __restrict__ r) {
+    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t row = gid / SPMV_LANES;
+    int sub = gid % SPMV_LANES;
+    DD s{0, 0};
+    if (row < A.n) {
+        if (sub == 0) s.hi = b[row];
+        for (uint32_t p = A.rowptr[row] + sub, e = A.rowptr[row + 1]; p < e; p += SPMV_LANES) {
+            const double a = A.val[p], xv = x[A.col[p]];
+            const double pr = a * xv, pe = __builtin_fma(a, xv, -pr);  // pr + pe = a * xv exactly
+            dd_add(s, -pr, -pe);
+        }
+    }
+    for (int off = SPMV_LANES / 2; off > 0; off >>= 1) {
+        const double ohi = __shfl_down(s.hi, off, SPMV_LANES), olo = __shfl_down(s.lo, off, SPMV_LANES);
+        dd_add(s, ohi, olo);
+    }
+    if (row < A.n && sub == 0) r[row] = s.hi + s.lo;
+}
+
 __device__ __forceinline__ double wave_reduce_sum(double v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
@@ -616,6 +648,14 @@ __global__ void inv_diag_kernel(CsrDev A, double scale, double* d) {
 
 // the pivot counter of a factorisation as a double where the host reads its asynchronous results
 __global__ void status_to_double_kernel(const int32_t* status, double* out) { *out = (double)*status; }
+
+// max |x_i| (the scale the factorisation's pivot threshold refers to)
+__global__ void __launch_bounds__(256) absmax_kernel(size_t n, const double* x, GridRed g) {
+    double m[1] = {0};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        m[0] = fmax(m[0], fabs(x[i]));
+    grid_commit<1>(m, 1, 1u, g);
+}
 
 __global__ void __launch_bounds__(256) nonfinite_kernel(size_t n, const double* x, GridRed g) {
     double s[1] = {0};
@@ -1322,6 +1362,11 @@ public:
                            m_stream, A, jac, val);
         HIP_CHECK(hipGetLastError());
     }
+    void residual(const CsrDev& A, const double* b, const double* x, double* r) override {
+        hipLaunchKernelGGL(residual_dd_kernel, dim3(nblk((size_t)A.n * SPMV_LANES, 256)), dim3(256), 0, m_stream, A, b, x,
+                           r);
+        HIP_CHECK(hipGetLastError());
+    }
     void spmv(const CsrDev& A, const double* x, double* y) override {
         hipLaunchKernelGGL(spmv_kernel, dim3(nblk((size_t)A.n * SPMV_LANES, 256)), dim3(256), 0,
                            m_stream, A, x, y);
@@ -1412,6 +1457,8 @@ public:
         using namespace mfk;
         HIP_CHECK(hipMemsetAsync(mf.front_store, 0, mf.front_store_size * sizeof(double), m_stream));
         HIP_CHECK(hipMemsetAsync(mf.status, 0, sizeof(int32_t), m_stream));
+        hipLaunchKernelGGL(absmax_kernel, dim3(red_grid(mf.nnzA)), dim3(256), 0, m_stream, (size_t)mf.nnzA, A.val,
+                           red_to(mf.piv_amax));
         hipLaunchKernelGGL(scatter_kernel, dim3(nblk(mf.nnzA, 256)), dim3(256), 0, m_stream, mf.nnzA,
                            mf.a_dst, A.val, mf.front_store);
         hipLaunchKernelGGL(aug_identity_kernel, dim3(nblk(mf.n, 256)), dim3(256), 0, m_stream, mf);

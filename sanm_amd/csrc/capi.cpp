@@ -65,6 +65,7 @@ HyperParam to_hp(const sanm_hyper_param* h) {
     r.solver_maxit = h->solver_maxit;
     r.solver_kind = h->solver_kind;
     r.profile = h->profile;
+    r.solver_refine = h->solver_refine;
     return r;
 }
 }  // namespace
@@ -339,6 +340,7 @@ void sanm_hyper_param_default(sanm_hyper_param* hp, int eqn_solver) {
     hp->solver_maxit = d.solver_maxit;
     hp->solver_kind = d.solver_kind;
     hp->profile = d.profile;
+    hp->solver_refine = d.solver_refine;
     (void)eqn_solver;
 }
 
@@ -522,6 +524,18 @@ int sanm_anm_get_stats(const sanm_anm_solver* s, sanm_anm_stats* st) {
         st->nr_front = d.linear_solver().nr_front;
         st->nr_level = d.linear_solver().nr_level;
         st->max_front = d.linear_solver().max_front;
+    });
+}
+int sanm_anm_debug_inject(sanm_anm_solver* s, int kind, int order, int64_t index, double value, int scale) {
+    return guard([&] {
+        sanm_check(kind >= 0 && kind <= 3, "injection kind %d", kind);
+        AnmDriver::Injection inj;
+        inj.kind = kind;
+        inj.order = order;
+        inj.index = index;
+        inj.value = value;
+        inj.scale = scale != 0;
+        s->drv->set_injection(inj);
     });
 }
 int sanm_anm_set_profile(sanm_anm_solver* s, int mode, int clear) {

@@ -76,39 +76,45 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // -- so that the whole LU is one basic block, and the reciprocal of the NEXT pivot (v_rcp_f64 + two Newton steps,
 // a chain of dependent instructions) is started as soon as its column is updated and overlaps with the
 // remaining column updates of the current step.)
-__device__ __forceinline__ double pivot_reciprocal(double piv, int& nbad, bool used) {
-    const bool bad = !(fabs(piv) > 1e-290);
+// (thr = MF_PIVOT_EPS * max|a_ij| > 0 normally; a pivot below it -- or not a number -- is replaced by +-thr and
+// counted; an all-zero matrix has thr = 0 and takes 1.  The replaced value is handed back: it becomes the
+// diagonal entry of U, where the substitutions read it.)
+__device__ __forceinline__ double pivot_reciprocal(double& piv, int& nbad, bool used, double thr) {
+    const bool bad = !(fabs(piv) > thr);
     nbad += bad && used;
-    piv = bad ? 1.0 : piv;
+    piv = bad ? (thr > 0 ? copysign(thr, piv) : 1.0) : piv;
     double r = __builtin_amdgcn_rcp(piv);
     r = __builtin_fma(__builtin_fma(-piv, r, 1.0), r, r);
     r = __builtin_fma(__builtin_fma(-piv, r, 1.0), r, r);
     return r;
 }
 template <int J>
-__device__ __forceinline__ void tile_lu_step(double (&a)[NB], int r, int kb, double inv, int& nbad) {
+__device__ __forceinline__ void tile_lu_step(double (&a)[NB], int r, int kb, double inv, double piv, int& nbad,
+                                             double thr) {
     // (J < kb is wave-uniform; a partial panel stops here)
     if (J >= kb) return;
     const double l = (r > J) ? a[J] * inv : 0.0;
-    a[J] = (r > J) ? l : a[J];
-    double inv_next = 1.0;
+    a[J] = (r > J) ? l : (r == J ? piv : a[J]);  // row J keeps the pivot actually used
+    double inv_next = 1.0, piv_next = 1.0;
     if constexpr (J + 1 < NB) {
         a[J + 1] -= l * readlane_f64(a[J + 1], J);
-        inv_next = pivot_reciprocal(readlane_f64(a[J + 1], J + 1), nbad, J + 1 < kb);
+        piv_next = readlane_f64(a[J + 1], J + 1);
+        inv_next = pivot_reciprocal(piv_next, nbad, J + 1 < kb, thr);
     }
 #pragma unroll
     for (int c = J + 2; c < NB; ++c) a[c] -= l * readlane_f64(a[c], J);
-    if constexpr (J + 1 < NB) tile_lu_step<J + 1>(a, r, kb, inv_next, nbad);
+    if constexpr (J + 1 < NB) tile_lu_step<J + 1>(a, r, kb, inv_next, piv_next, nbad, thr);
 }
-__device__ __forceinline__ void tile_factor(double (*T)[TPAD], int kb, int tid, int32_t* status) {
+__device__ __forceinline__ void tile_factor(double (*T)[TPAD], int kb, int tid, int32_t* status, double thr) {
     if (tid >= 64) return;
     const int r = tid & (NB - 1);  // lanes 32..63 shadow lanes 0..31 and store nothing
     double a[NB];
 #pragma unroll
     for (int c = 0; c < NB; ++c) a[c] = T[r][c];
     int nbad = 0;
-    const double inv0 = pivot_reciprocal(readlane_f64(a[0], 0), nbad, kb > 0);
-    tile_lu_step<0>(a, r, kb, inv0, nbad);
+    double piv0 = readlane_f64(a[0], 0);
+    const double inv0 = pivot_reciprocal(piv0, nbad, kb > 0, thr);
+    tile_lu_step<0>(a, r, kb, inv0, piv0, nbad, thr);
     if (tid == 0 && nbad) atomicAdd(status, nbad);
     if (tid < NB) {
 #pragma unroll
@@ -123,13 +129,14 @@ __global__ void __launch_bounds__(256) diag_kernel(MfDev mf, int level_begin, in
     const int kb = min(NB, f.k - r0);
     __shared__ double T[NB][TPAD];
     double* F = mf.front_store + f.off;
+    const double thr = MF_PIVOT_EPS * *mf.piv_amax;
     const int tid = threadIdx.x, tc = tid % NB, tr = tid / NB;
     for (int s = 0; s < 4; ++s) {
         int r = tr + 8 * s, gr = r0 + r, gc = r0 + tc;
         T[r][tc] = (gr < m && gc < m) ? F[(int64_t)gr * ld + gc] : (r == tc ? 1.0 : 0.0);
     }
     __syncthreads();
-    tile_factor(T, kb, tid, mf.status);
+    tile_factor(T, kb, tid, mf.status, thr);
     __syncthreads();
     for (int s = 0; s < 4; ++s) {
         int r = tr + 8 * s, gr = r0 + r, gc = r0 + tc;
@@ -222,6 +229,7 @@ __global__ void __launch_bounds__(256) update_kernel(MfDev mf, int level_begin, 
     // the (augmentation x augmentation) corner is never used
     if (ti * NB >= f.k && tj * NB >= f.k) return;
     const int kb = min(NB, f.k - p * NB);
+    const double thr = MF_PIVOT_EPS * *mf.piv_amax;  // (requested with the tiles; used by the look-ahead tile LU)
     __shared__ double L[NB][TPAD], U[NB][TPAD], T[NB][TPAD];
     __shared__ __attribute__((aligned(16))) double SL[NB][SPAD], SU[NB][SPAD];
     __shared__ double Dv[NB];
@@ -300,7 +308,7 @@ __global__ void __launch_bounds__(256) update_kernel(MfDev mf, int level_begin, 
     __syncthreads();
     SANM_PHASE_MARK(c3);
     const int kb1 = min(NB, f.k - (p + 1) * NB);
-    tile_factor(T, kb1, tid, mf.status);
+    tile_factor(T, kb1, tid, mf.status, thr);
     __syncthreads();
     SANM_PHASE_MARK(c4);
     for (int s = 0; s < 4; ++s) {
@@ -760,7 +768,9 @@ __global__ void __launch_bounds__(256) fwd_level_sub_kernel(MfDev mf, int level_
     for (int q = 0; q < R; ++q) {
         double acc = 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc += a[q][u] * vs[min(sub + G * u, k - 1)];
+        // (entries beyond the row's extent carry a zero factor, but the vector entry they meet must still be an
+        // initialised one: whatever an earlier kernel left in the LDS may be a NaN, and 0 * NaN is not 0)
+        for (int u = 0; u < 4; ++u) acc += a[q][u] * vs[min(sub + G * u, kneed - 1)];
         for (int c = sub + 4 * G; c < cend[q]; c += G) acc += rowp[q][c] * vs[c];
 #pragma unroll
         for (int off = G / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, G);

@@ -7,6 +7,11 @@
 namespace sanm_hip {
 
 constexpr int MF_NB = 32;  // panel / tile width
+// Static pivot perturbation, as PARDISO does for unsymmetric matrices (iparm[9] = 13, the setting the reference's
+// pardisoinit leaves in place, libsanm/sparse_solver.cpp:107-127): a pivot smaller in magnitude than
+// MF_PIVOT_EPS * max|a_ij| is replaced by that value with the pivot's sign and counted; a factorisation with
+// perturbed pivots is followed by iterative refinement in every solve (anm.cpp: DirectSolver).
+constexpr double MF_PIVOT_EPS = 1e-13;
 
 struct MfFrontDev {
     int64_t off;        // offset of the dense ld*ld augmented front (row-major) in the front storage
@@ -45,7 +50,9 @@ struct MfDev {
     double* work;                 // n doubles (permuted rhs / solution)
     double* work2;                // n doubles (forward-solved vector z)
     double* tmp_store;            // per-level workspace: L11^-1 F12 (k x b) and F21 U11^-1 (b x k) per front
-    int32_t* status;              // [0]: number of bad pivots
+    int32_t* status;              // [0]: number of perturbed pivots
+    double* piv_amax;             // max |a_ij| of the matrix being factored: pivots below 1e-13 times that are
+                                  // perturbed (MF_PIVOT_EPS)
     int64_t front_store_size;
 };
 

@@ -919,6 +919,7 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     m_bufs.push_back(m_dev.tmp_store);
     m_dev.status = static_cast<int32_t*>(be->alloc(64));
     be->zero(m_dev.status, 64);
+    m_dev.piv_amax = reinterpret_cast<double*>(m_dev.status) + 1;
     m_bufs.push_back(m_dev.front_store);
     m_bufs.push_back(m_dev.work);
     m_bufs.push_back(m_dev.status);

@@ -151,6 +151,13 @@ public:
             for (int64_t s = sb; s < se; ++s) val[s] = assemble_slot(A, jac, s);
         });
     }
+    void residual(const CsrDev& A, const double* b, const double* x, double* r) override {
+        for (int64_t i = 0; i < A.n; ++i) {  // in extended precision, like the device's double-double kernel
+            long double s = b[i];
+            for (uint32_t p = A.rowptr[i], e = A.rowptr[i + 1]; p < e; ++p) s -= (long double)A.val[p] * x[A.col[p]];
+            r[i] = (double)s;
+        }
+    }
     void spmv(const CsrDev& A, const double* x, double* y) override {
         for (int64_t i = 0; i < A.n; ++i) y[i] = spmv_row(A, x, i);
     }
@@ -259,6 +266,10 @@ struct HostMf {
         std::memset(mf.front_store, 0, mf.front_store_size * sizeof(double));
         for (int64_t p = 0; p < mf.nnzA; ++p) mf.front_store[mf.a_dst[p]] += A.val[p];
         int bad = 0;
+        double amax = 0;
+        for (int64_t p = 0; p < mf.nnzA; ++p) amax = std::fmax(amax, std::fabs(A.val[p]));
+        *mf.piv_amax = amax;
+        const double thr = MF_PIVOT_EPS * amax;  // static pivot perturbation, as in the HIP kernels (mf_kernels.h)
         for (const auto& L : sch.levels) {
             // extend-add the children of this level's fronts
             for (auto [b, e] : L.ea_rounds)
@@ -281,7 +292,11 @@ struct HostMf {
                 auto P = [k](int i) { return i < k ? i : i + k; };
                 for (int j = 0; j < k; ++j) {
                     double piv = F[P(j) * ld + P(j)];
-                    if (!(std::fabs(piv) > 1e-290)) ++bad;
+                    if (!(std::fabs(piv) > thr)) {
+                        ++bad;
+                        piv = thr > 0 ? std::copysign(thr, piv) : 1.0;
+                        F[P(j) * ld + P(j)] = piv;
+                    }
                     double inv = 1.0 / piv;
                     for (int i = j + 1; i < m; ++i) {
                         double l = F[P(i) * ld + P(j)] * inv;

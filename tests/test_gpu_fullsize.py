@@ -10,6 +10,9 @@ merged with their overrides, meshes converted from config/model/*):
   * step count and final vertices match the CPU oracle run on the same inputs
     (north_star: identical continuation-step count, 1e-6 relative vertex tolerance).
 """
+import json
+import os
+
 import numpy as np
 import pytest
 
@@ -18,6 +21,7 @@ from sanm_amd import api as A
 from sanm_amd import fea as dfea
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
 @pytest.fixture(scope="module")
@@ -26,11 +30,32 @@ def hip_api():
     return sanm_amd.get_api()
 
 
+def _device_sequence(api, name, **hyper):
+    cfg, mesh = dfea.load_named_config(name)
+    run = dfea.GravityRun(api, mesh, dict(cfg), **hyper).construct()
+    s = run.solver
+    seq = [(s.residual_rms(), s.get_t_max_a(), bool(s.has_pade()))]
+    while not s.converged():
+        run.step()
+        seq.append((s.residual_rms(), s.get_t_max_a(), bool(s.has_pade())))
+    return run, mesh, seq
+
+
+def _oracle_sequence(name):
+    cfg2, mesh2 = dfea.load_named_config(name)
+    omesh = ofea.TetMesh(mesh2.V, mesh2.tets, mesh2.surface_vtx)
+    omodel, o, _ = ofea.make_gravity_solver(omesh, cfg2)
+    seq = [(o.residual_rms, o.t_max_a, o.pade is not None)]
+    while not o.converged:
+        o.next_iter()
+        seq.append((o.residual_rms, o.t_max_a, o.pade is not None))
+    return omodel, o, seq
+
+
 @pytest.mark.parametrize("name", ["armadillo_small", "bob", "human_arap16"])
 def test_named_config_against_oracle(hip_api, name):
     api = hip_api
-    cfg, mesh = dfea.load_named_config(name)
-    run = dfea.GravityRun(api, mesh, dict(cfg)).run()
+    run, mesh, dseq = _device_sequence(api, name)
     assert run.solver.converged() and run.rms[-1] < 1e-10
     steps = run.solver.get_nr_iter()
     V = run.vertices()
@@ -41,20 +66,51 @@ def test_named_config_against_oracle(hip_api, name):
     resid = f_int + run.f_sub
     tol = 1e-5 * np.maximum(1.0, np.minimum(np.abs(f_int), np.abs(run.f_sub)))
     assert np.all(np.abs(resid) < tol)
-    # oracle on the same inputs
-    cfg2, mesh2 = dfea.load_named_config(name)
-    omesh = ofea.TetMesh(mesh2.V, mesh2.tets, mesh2.surface_vtx)
-    omodel, osolver, _ = ofea.make_gravity_solver(omesh, cfg2)
-    xo, orms = ofea.run_anm(osolver)
-    Vo = omodel.lt_inp.full_vertices(xo)
-    print(f"{name}: device steps={steps} rms={run.rms} | oracle steps={osolver.get_nr_iter()} rms={orms}")
+    # oracle on the same inputs: the whole continuation, step by step
+    omodel, osolver, oseq = _oracle_sequence(name)
+    Vo = omodel.lt_inp.full_vertices(osolver.xt0[:-1])
+    osteps = osolver.get_nr_iter()
+    # first step at which the two continuations part: the discrete Pade decision or the step length
+    split = next((k for k in range(min(len(dseq), len(oseq)))
+                  if dseq[k][2] != oseq[k][2] or abs(dseq[k][1] - oseq[k][1]) > 1e-6 * abs(oseq[k][1])), None)
+    rec = {"config": name, "device_steps": int(steps), "oracle_steps": int(osteps), "first_divergence": split,
+           "device": [list(map(float, t)) for t in dseq], "oracle": [list(map(float, t)) for t in oseq],
+           "vertex_rel_err": float(np.abs(V - Vo).max() / np.abs(Vo).max())}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(rec, open(os.path.join(ROOT, "gpurun_out", f"parity_steps_{name}.json"), "w"), indent=1)
+    print(json.dumps({k: rec[k] for k in ("config", "device_steps", "oracle_steps", "first_divergence", "vertex_rel_err")}))
+    assert rec["vertex_rel_err"] <= 1e-6
     if name == "human_arap16":
-        # This configuration sits on the Pade accept threshold: with series coefficients that
-        # agree to 1e-11 .. 6e-9 (scripts/diag_compare.py) the device path and the oracle accept
-        # the approximant at different steps and then take different but equally valid step
-        # sequences to the same equilibrium.  Observed over the builds of this round and both
-        # oracle solvers (PARDISO / SuperLU): 7..8 device steps against 8..9.  DESIGN.md section 5.
-        assert abs(steps - osolver.get_nr_iter()) <= 2
+        # Knife-edge configuration: the Jacobian of this mesh has condition ~5e8, so two
+        # assemblies that differ in the last bit give series coefficients that differ by 1e-11 .. 1e-9 whatever
+        # the linear solver (three LU codes agree to 4e-11 on the SAME matrix, to 7e-15 after one refinement
+        # step, and refining the device's solves does not move the device-oracle gap), and the Pade accept test
+        # of step 1 sits within that distance of its threshold.  What can be asserted: every step BEFORE the
+        # first discrete divergence agrees to 1e-6, the divergence IS a Pade accept decision, both continuations
+        # reach the same equilibrium, and the counts stay within 2.
+        assert split is None or split >= 1
+        for k in range(split if split is not None else len(oseq)):
+            assert abs(dseq[k][0] - oseq[k][0]) <= 1e-6 * oseq[k][0] and abs(dseq[k][1] - oseq[k][1]) <= 1e-6 * oseq[k][1]
+        if split is not None:
+            assert dseq[split][2] != oseq[split][2], "the continuations part at something other than a Pade decision"
+        assert abs(steps - osteps) <= 2
     else:
-        assert steps == osolver.get_nr_iter()
-    assert np.abs(V - Vo).max() <= 1e-6 * np.abs(Vo).max()
+        assert steps == osteps
+        # (same Pade decisions at every step; the accepted range itself comes out of a bisection and may differ by
+        # one of its cells)
+        assert [t[2] for t in dseq] == [t[2] for t in oseq]
+
+
+def test_refined_solves_do_not_move_the_device_oracle_gap(hip_api):
+    """Iterative refinement (double-double residual) puts the device's linear solves within 1e-14 of the exact
+    solution of the device's matrix; the first-order coefficients still differ from the oracle's by ~1e-11:
+    the gap comes from the last bits of the assembled Jacobian times its condition number, not from the LU."""
+    name = "armadillo_small"
+    out = {}
+    for refine in (0, 1):
+        cfg, mesh = dfea.load_named_config(name)
+        run = dfea.GravityRun(hip_api, mesh, dict(cfg), solver_refine=refine).construct()
+        out[refine] = run.solver.xt_coeffs()
+    d = np.abs(out[1][1] - out[0][1]).max() / np.abs(out[0][1]).max()
+    print("x_1 moved by refinement:", d)
+    assert d < 1e-9  # the refinement changes x_1 by about the plain LU's error (~4e-11)
