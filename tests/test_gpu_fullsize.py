@@ -85,10 +85,12 @@ def test_named_config_against_oracle(hip_api, name):
         # assemblies that differ in the last bit give series coefficients that differ by 1e-11 .. 1e-9 whatever
         # the linear solver (three LU codes agree to 4e-11 on the SAME matrix, to 7e-15 after one refinement
         # step, and refining the device's solves does not move the device-oracle gap), and the Pade accept test
-        # of step 1 sits within that distance of its threshold.  What can be asserted: every step BEFORE the
-        # first discrete divergence agrees to 1e-6, the divergence IS a Pade accept decision, both continuations
-        # reach the same equilibrium, and the counts stay within 2.
-        assert split is None or split >= 1
+        # of the first steps sits within that distance of its threshold: the decision at step 0 even flips with the
+        # version of the run-time compiler that builds the pass kernels (hiprtc 7.0 from the torch wheel, loaded
+        # first under pytest, accepts the approximant; hiprtc 7.2 from /opt/rocm, as loaded by a plain script,
+        # does not -- scripts/determinism.py: bit-identical results from run to run with either).  What can be
+        # asserted: every step BEFORE the first discrete divergence agrees to 1e-6, the divergence IS a Pade
+        # accept decision, both continuations reach the same equilibrium, and the counts stay within 2.
         for k in range(split if split is not None else len(oseq)):
             assert abs(dseq[k][0] - oseq[k][0]) <= 1e-6 * oseq[k][0] and abs(dseq[k][1] - oseq[k][1]) <= 1e-6 * oseq[k][1]
         if split is not None:
