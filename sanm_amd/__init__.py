@@ -34,5 +34,9 @@ def get_api(device: int = 0) -> Api:
     if _API is None:
         a = Api(load_library())
         a.init(device)
+        a.device = device
         _API = a
+    elif getattr(_API, "device", device) != device:
+        raise RuntimeError(f"the library is bound to device {_API.device} (one process per GPU); "
+                           f"device {device} was requested")
     return _API

@@ -94,9 +94,16 @@ struct sanm_anm_solver {
 
 extern "C" {
 
+static int g_device = -1;
 int sanm_hip_init(int device) {
     return guard([&] {
-        if (!g_backend) g_backend.reset(make_backend(device));
+        if (!g_backend) {
+            g_backend.reset(make_backend(device));
+            g_device = device;
+        } else if (device != g_device) {
+            sanm_throw(SANM_ERR_ASSERT, "sanm_hip_init(%d): this process is bound to device %d (one process per GPU)",
+                       device, g_device);
+        }
     });
 }
 const char* sanm_hip_last_error(void) { return g_last_error.c_str(); }

@@ -72,19 +72,29 @@ def hyper_from_config(api: Api, config, **over):
     return api.default_hyper(**kw)
 
 
-def setup_gravity(api: Api, mesh: Mesh, config):
-    """gravity(), fea/main.cpp:984-1046, up to run_and_save.  Scales the mesh
-    in place.  Returns (fixed_mask (nv,3) bool, f_load (nv,3))."""
-    mc = config["material"]
+def boundary_by_config(api: Api, mesh: Mesh, config):
+    """setup_boundary_by_config (fea/main.cpp:921-982) with gravity()'s default projection direction -g"""
     g = np.asarray(config["g"], dtype=np.float64)
-    if "scale" in config:
-        mesh.V = mesh.V * float(config["scale"])
     proj = np.asarray(config.get("boundary_proj_dir", -g), dtype=np.float64)
     flt = config.get("boundary_filter")
-    fixed = api.boundary_by_threshold(
+    return api.boundary_by_threshold(
         mesh.V, mesh.surface_vtx, proj, float(config["boundary_thresh"]),
         None if flt is None else flt["dir"], 0.0 if flt is None else float(flt["min"]),
         0.0 if flt is None else float(flt["max"]))
+
+
+def setup_gravity(api: Api, mesh: Mesh, config, boundary=True):
+    """gravity(), fea/main.cpp:984-1046, up to run_and_save.  Scales the mesh
+    in place (once).  Returns (fixed_mask (nv,3) bool or None, f_load (nv,3)); boundary=False leaves the
+    fixed set to the caller (the `.bou` file of the mesh, sanm_amd/cli.py)."""
+    mc = config["material"]
+    g = np.asarray(config["g"], dtype=np.float64)
+    if "scale" in config and not getattr(mesh, "_scaled", False):
+        # mesh->resize_inplace (fea/main.cpp:995-997); marked so that a second run on the same Mesh object does
+        # not scale it again
+        mesh.V = mesh.V * float(config["scale"])
+        mesh._scaled = True
+    fixed = boundary_by_config(api, mesh, config) if boundary else None
     f_load = api.gravity_load(mesh.V, mesh.tets, float(mc["density"]), g)
     return fixed, f_load
 
@@ -92,12 +102,19 @@ def setup_gravity(api: Api, mesh: Mesh, config):
 class GravityRun:
     """run_and_save (fea/main.cpp:247-433), ANM branch, on the device path."""
 
-    def __init__(self, api: Api, mesh: Mesh, config, inverse=False, shard=None, **hyper_over):
+    @classmethod
+    def from_parts(cls, api: Api, mesh: Mesh, config, fixed, f_load, inverse=False, **hyper_over):
+        """a static solve with the fixed set and the nodal load given by the caller (the test_* tasks, `.bou`
+        files)"""
+        return cls(api, mesh, config, inverse=inverse, _parts=(np.asarray(fixed, dtype=bool), np.asarray(f_load)),
+                   **hyper_over)
+
+    def __init__(self, api: Api, mesh: Mesh, config, inverse=False, shard=None, _parts=None, **hyper_over):
         self.api = api
         self.mesh = mesh
         self.config = config
         t0 = time.perf_counter()
-        self.fixed, self.f_load = setup_gravity(api, mesh, config)
+        self.fixed, self.f_load = _parts if _parts is not None else setup_gravity(api, mesh, config)
         mc = config["material"]
         self.model = api.fea_model(mesh.V, mesh.tets, self.fixed, config["energy_model"],
                                    float(mc["young"]), float(mc["poisson"]), inverse=inverse)
@@ -113,6 +130,7 @@ class GravityRun:
         t0 = time.perf_counter()
         self.solver = ANMEqnSolver(self.api, self.model.y, self.model.lt_inp, self.model.lt_out,
                                    self.model.x0(), self.f_sub, self.hyper, shard=self.shard)
+        self.solver._keep = self.solver._keep + (self.model,)  # the graph / remap views belong to the model
         self.rms = [self.solver.residual_rms()]
         self.time_solve += time.perf_counter() - t0
         return self
@@ -176,8 +194,9 @@ def _force_rms(api: Api, mesh: Mesh, fixed, energy, mat_cfg, vtx_coord):
     return float(np.sqrt(np.mean(f ** 2)))
 
 
-def run_with_vtx_delta(api: Api, mesh: Mesh, fixed, config, vtx_delta, vtx_coord, require_refine):
-    """run_with_vtx_delta, fea/main.cpp:436-580 (ANM branch)."""
+def run_with_vtx_delta(api: Api, mesh: Mesh, fixed, config, vtx_delta, vtx_coord, require_refine, refine_f_load=None):
+    """run_with_vtx_delta, fea/main.cpp:436-580 (ANM branch).  refine_f_load: (nv,3) nodal load of the refinement
+    pass (mesh_twist with add_gravity), zero otherwise."""
     from .api import ANMImplicitSolver
     energy, mc = config["energy_model"], config["material"]
     stat = {}
@@ -197,7 +216,8 @@ def run_with_vtx_delta(api: Api, mesh: Mesh, fixed, config, vtx_delta, vtx_coord
         m2 = api.fea_model(mesh.V, mesh.tets, fixed, energy, float(mc["young"]), float(mc["poisson"]),
                            init_vtx_coord=vtx_coord)
         hp2 = hyper_from_config(api, config, converge_rms=1e-5, solution_check_tol=1e-4, order=6)
-        s2 = ANMEqnSolver(api, m2.y, m2.lt_inp, m2.lt_out, m2.x0(), np.zeros(m2.n), hp2)
+        f_sub = np.zeros(m2.n) if refine_f_load is None else m2.copy_vtx_values(refine_f_load)
+        s2 = ANMEqnSolver(api, m2.y, m2.lt_inp, m2.lt_out, m2.x0(), f_sub, hp2)
         rms = [s2.residual_rms()]
         while not s2.converged():
             s2.next_iter()

@@ -63,3 +63,118 @@ def test_gravity_task_from_files(api, tmp_path):
                    if line.startswith("v ")])
     assert Vd.shape == Vo.shape and np.abs(Vd - Vo).max() <= 1e-5 * np.abs(Vo).max()  # %g keeps 6 digits
     assert sum(1 for line in open(base + "-orig.obj") if line.startswith("f ")) == len(tris)
+
+
+def _block_files(tmp_path, dims=(5, 3, 3), sp=0.03):
+    om = ofea.make_cuboid(*dims, sp)
+    surf = set(om.surface_vtx.tolist())
+    tris = [(t[a], t[b], t[c]) for t in om.tets for a, b, c in ((0, 1, 2), (0, 1, 3), (0, 2, 3), (1, 2, 3))
+            if t[a] in surf and t[b] in surf and t[c] in surf]
+    os.makedirs(tmp_path / "model", exist_ok=True)
+    _write_tetgen(str(tmp_path / "model" / "block.1"), om.V, om.tets, tris)
+    json.dump({"verbosity": 0, "threads": 1}, open(tmp_path / "sys.json", "w"))
+    return om, tris
+
+
+def test_gravity_task_takes_the_fixed_set_from_the_bou_file(api, tmp_path):
+    """fea/main.cpp:1000-1013: `<mesh>.bou` (1-based vertex ids, all three coordinates fixed) wins over the
+    threshold rule of the config.  The same task with and without the file solves two different problems."""
+    om, tris = _block_files(tmp_path)
+    # fix the face x = max instead of what boundary_thresh / boundary_proj_dir would pick (x = min)
+    ids = np.nonzero(om.V[:, 0] >= om.V[:, 0].max() - 1e-12)[0]
+    open(tmp_path / "model" / "block.1.bou", "w").write("\n".join(str(i + 1) for i in ids) + "\n")
+    task = {"func": "gravity", "mesh": "model/block.1", "energy_model": "neohookean_c", "g": [0, -9.81, 0], "order": 10,
+            "material": {"type": "young_poisson", "young": 3e3, "poisson": 0.45, "density": 900.0},
+            "boundary_thresh": 0.05, "boundary_proj_dir": [-1, 0, 0], "out_filename": str(tmp_path / "out" / "b")}
+    json.dump(task, open(tmp_path / "task.json", "w"))
+    assert cli.main([str(tmp_path / "sys.json"), str(tmp_path / "task.json")], api=api, out=io.StringIO()) == 0
+    Vd = np.loadtxt(str(tmp_path / "out" / "b-i0-neohookean_c.vertices.txt"))
+    assert np.array_equal(Vd[ids], om.V[ids]), "the vertices named by the .bou file did not stay fixed"
+    assert np.abs(Vd - om.V)[om.V[:, 0] <= 1e-12].max() > 1e-4, "the x = min face must be free to move now"
+    # the oracle with the same fixed set
+    mat = ofea.Material(3e3, 0.45, 900.0)
+    fixed = np.zeros((om.nr_vertices, 3), dtype=bool)
+    fixed[ids] = True
+    f = ofea.gravity_load(om, mat, np.array([0, -9.81, 0]))
+    model, solver, x = ofea.solve_static(om, mat, fixed, "neohookean_c", f, dict(task))
+    Vo = model.lt_inp.full_vertices(x)
+    assert np.abs(Vd - Vo).max() <= 1e-8 * np.abs(Vo).max()  # the 17-digit vertex file, not the %g .obj
+    nb = sum(1 for line in open(str(tmp_path / "out" / "b-boundary.obj")) if line.startswith("f "))
+    assert 0 < nb < len(tris)
+
+
+def test_unsupported_config_keys_raise(api, tmp_path):
+    _block_files(tmp_path)
+    task = {"func": "gravity", "mesh": "model/block.1", "energy_model": "neohookean_c", "g": [0, -9.81, 0],
+            "material": {"young": 3e3, "poisson": 0.45, "density": 900.0}, "boundary_thresh": 0.05,
+            "out_filename": str(tmp_path / "out" / "b"), "baseline": {"use_levmar": True}}
+    json.dump(task, open(tmp_path / "task.json", "w"))
+    import pytest
+    with pytest.raises(ValueError, match="baseline"):
+        cli.main([str(tmp_path / "sys.json"), str(tmp_path / "task.json")], api=api, out=io.StringIO())
+
+
+def test_single_tet_inverse_task(api, tmp_path):
+    """config/test_single_tet_inverse.json through the CLI; the rest height of the apex against the oracle"""
+    json.dump({"verbosity": 0, "threads": 1}, open(tmp_path / "sys.json", "w"))
+    task = {"func": "test_single_tet_inverse", "spacing": 0.025, "energy_model": "neohookean_i", "order": 12,
+            "material": {"young": 1e7, "poisson": 0.45}, "out_filename": str(tmp_path / "out" / "tet")}
+    json.dump(task, open(tmp_path / "task.json", "w"))
+    log = io.StringIO()
+    assert cli.main([str(tmp_path / "sys.json"), str(tmp_path / "task.json")], api=api, out=log) == 0
+    Vd = np.loadtxt(str(tmp_path / "out" / "tet-i1-neohookean_i.vertices.txt"))
+    Vo, _ = ofea.test_single_tet_inverse(task)
+    assert np.abs(Vd - Vo).max() <= 1e-9 * np.abs(Vo).max()
+    assert "vertex 3:" in log.getvalue()
+
+
+def test_cuboid_task(api, tmp_path):
+    json.dump({"verbosity": 0, "threads": 1}, open(tmp_path / "sys.json", "w"))
+    task = {"func": "test_cuboid", "x": 6, "y": 3, "z": 3, "spacing": 0.025, "energy_model": "neohookean_c", "order": 10,
+            "material": {"young": 1e5, "poisson": 0.4}, "out_filename": str(tmp_path / "out" / "c")}
+    json.dump(task, open(tmp_path / "task.json", "w"))
+    assert cli.main([str(tmp_path / "sys.json"), str(tmp_path / "task.json")], api=api, out=io.StringIO()) == 0
+    st = json.load(open(str(tmp_path / "out" / "c-i0-neohookean_c.json")))
+    assert st["force_rms_recomp"] < 1e-8 and st["name"] == "cuboid"
+    om = ofea.make_cuboid(6, 3, 3, 0.025)
+    fixed = np.zeros((om.nr_vertices, 3), dtype=bool)
+    fixed[om.V[:, 0] <= 0.0125] = True
+    f = np.zeros((om.nr_vertices, 3))
+    f[(om.V[:, 0] > (6 // 2 - 1) * 0.025 - 0.0125) & (om.V[:, 2] < 0.0125), 2] = -50.0
+    model, solver, x = ofea.solve_static(om, ofea.Material(1e5, 0.4, 0.0), fixed, "neohookean_c", f, dict(task))
+    Vd = np.loadtxt(str(tmp_path / "out" / "c-i0-neohookean_c.vertices.txt"))
+    Vo = model.lt_inp.full_vertices(x)
+    assert st["iter"] == solver.get_nr_iter()
+    assert np.abs(Vd - Vo).max() <= 1e-8 * np.abs(Vo).max()
+
+
+def test_mesh_twist_task(api, tmp_path):
+    """mesh_twist (fea/main.cpp:774-919) from TetGen files: one end of a bar held, the other rotated by 20
+    degrees about the bar's axis; the oracle's run_with_vtx_delta on the same displacement."""
+    om, tris = _block_files(tmp_path, dims=(6, 3, 3), sp=0.025)
+    task = {"func": "mesh_twist", "mesh": "model/block.1", "energy_model": "arap", "order": 10,
+            "material": {"young": 1e6, "poisson": 0.4}, "axis": [1, 0, 0], "ratio_lo": 0.1, "ratio_hi": 0.1,
+            "angle": 20, "shift": [0, 0, 0], "rot_axis": 0, "out_filename": str(tmp_path / "out" / "tw")}
+    json.dump(task, open(tmp_path / "task.json", "w"))
+    assert cli.main([str(tmp_path / "sys.json"), str(tmp_path / "task.json")], api=api, out=io.StringIO()) == 0
+    st = json.load(open(str(tmp_path / "out" / "tw.json")))
+    assert st["force_rms_recomp"] < 1e-5 and st["iter_deform"] >= 1
+    Vd = np.loadtxt(str(tmp_path / "out" / "tw.vertices.txt"))
+    # the same displacement through the oracle
+    proj = om.V[:, 0]
+    pmin, pmax = proj.min(), proj.max()
+    on_surf = np.zeros(om.nr_vertices, dtype=bool)
+    on_surf[om.surface_vtx] = True
+    lo, hi = pmin + (pmax - pmin) * 0.1, pmin + (pmax - pmin) * 0.9
+    sel = ((proj <= lo) | (proj >= hi)) & on_surf
+    fixed = np.zeros((om.nr_vertices, 3), dtype=bool)
+    fixed[sel] = True
+    bnd = np.nonzero(sel & (proj >= hi))[0]
+    a = 20 * np.pi / 180
+    rmat = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+    delta = np.zeros_like(om.V)
+    delta[bnd] = om.V[bnd] @ rmat.T - om.V[bnd]
+    Vo, ost = ofea.run_with_vtx_delta(om, ofea.Material(1e6, 0.4, 0.0), fixed, "arap", dict(task), delta, om.V.copy(),
+                                      False)
+    assert st["iter_deform"] == ost["iter_deform"]
+    assert np.abs(Vd - Vo).max() <= 1e-6 * np.abs(Vo).max()
