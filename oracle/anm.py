@@ -124,7 +124,13 @@ class SparseSolver:
         self.lu = None
 
     def prepare(self, l2=0.0):
-        assert l2 == 0.0, "Tikhonov path (sparse_solver.cpp:366-395) is outside the hot path"
+        self.l2 = float(l2)
+        if self.l2:
+            # Tikhonov path (sparse_solver.cpp:366-395): min |Ax-b|^2 + l2 |x|^2 through the normal equations
+            # (A'A + l2 I) x = A'b; the reference factors the SPD matrix with PARDISO mtype 2
+            M = (self.A.T @ self.A + self.l2 * sp.identity(self.A.shape[0])).tocsc()
+            self.lu = spla.splu(M, permc_spec="MMD_AT_PLUS_A")
+            return
         if pardiso.available():
             self.lu = pardiso.Pardiso(self.A)
         else:
@@ -132,6 +138,8 @@ class SparseSolver:
 
     def solve(self, b):
         assert np.all(np.isfinite(b))
+        if getattr(self, "l2", 0.0):
+            return self.lu.solve(self.A.T @ b)  # sparse_solver.cpp:162-176
         return self.lu.solve(b)
 
     def apply(self, x):

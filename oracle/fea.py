@@ -325,10 +325,7 @@ def make_gravity_solver(mesh, config, hyper=None, inverse=False):
     model = make_inverse(mesh, mat, fixed, energy) if inverse else make_forward(mesh, mat, fixed, energy)
     f_sub = model.lt_inp.copy_vtx_values(f_load)
     if hyper is None:
-        hyper = HyperParam(order=int(config.get("order", 20)),
-                           use_pade=not config.get("disable_pade", False),
-                           sanity_check=not config.get("disable_anm_sanity_check", False),
-                           converge_rms=1e-10, solution_check_tol=1e-3)
+        hyper = default_hyper(config, converge_rms=1e-10, solution_check_tol=1e-3)
     solver = ANMEqnSolver(model.y, model.lt_inp.mat, model.lt_out, model.lt_inp.out_shape,
                           model.lt_inp.x0, f_sub, hyper)
     return model, solver, f_sub

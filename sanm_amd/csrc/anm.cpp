@@ -179,8 +179,103 @@ public:
 };
 }  // namespace
 
+namespace {
+// Tikhonov path (libsanm/sparse_solver.cpp:366-395, :162-176; HyperParam::xcoeff_l2_penalty): the coefficients
+// minimise |A x - b|^2 + lambda |x|^2, i.e. solve (A'A + lambda I) x = A'b.  The reference forms A'A with
+// mkl_sparse_syrk and factors it as SPD (PARDISO mtype 2) at every step; here the pattern of A'A is built once on
+// the host (the Jacobian's pattern is fixed), its values are sparse column dot products on the device
+// (Backend::ata), and the same multifrontal code factors it -- an LU of an SPD matrix needs no pivoting.
+class TikhonovSolver final : public LinearSolver {
+    Backend* m_be;
+    const JacobianPattern& m_pat;
+    const double m_lambda;
+    std::vector<uint32_t> m_h_mrowptr, m_h_mcol;
+    CsrDev m_at{}, m_m{};
+    uint32_t *m_perm = nullptr, *m_mrow = nullptr;
+    DVec m_atval, m_mval, m_rhs;
+    std::unique_ptr<Multifrontal> m_mf;
+    std::vector<void*> m_bufs;
+
+    template <class T>
+    T* upload(const std::vector<T>& v) {
+        void* p = m_be->alloc(std::max<size_t>(v.size(), 1) * sizeof(T));
+        if (!v.empty()) m_be->h2d(p, v.data(), v.size() * sizeof(T));
+        m_bufs.push_back(p);
+        return static_cast<T*>(p);
+    }
+
+public:
+    TikhonovSolver(Backend* be, const JacobianPattern& pat, double lambda, const double* coords)
+            : m_be{be}, m_pat{pat}, m_lambda{lambda} {
+        const int64_t n = pat.n();
+        const auto& rp = pat.h_rowptr();
+        const auto& col = pat.h_col();
+        const size_t nnz = col.size();
+        // A' in CSR form (= A in CSC), with the permutation that carries the values over
+        std::vector<uint32_t> cp(n + 1, 0), rows(nnz), perm(nnz);
+        for (size_t p = 0; p < nnz; ++p) cp[col[p] + 1]++;
+        for (int64_t i = 0; i < n; ++i) cp[i + 1] += cp[i];
+        {
+            std::vector<uint32_t> fill(cp.begin(), cp.end() - 1);
+            for (int64_t r = 0; r < n; ++r)
+                for (uint32_t p = rp[r]; p < rp[r + 1]; ++p) {
+                    const uint32_t q = fill[col[p]]++;
+                    rows[q] = (uint32_t)r;  // ascending: rows are visited in order
+                    perm[q] = p;
+                }
+        }
+        // pattern of A'A: column j belongs to row i iff some row of A holds both
+        m_h_mrowptr.assign(n + 1, 0);
+        std::vector<uint32_t> mrow, tmp;
+        for (int64_t i = 0; i < n; ++i) {
+            tmp.clear();
+            for (uint32_t q = cp[i]; q < cp[i + 1]; ++q) {
+                const uint32_t r = rows[q];
+                tmp.insert(tmp.end(), col.begin() + rp[r], col.begin() + rp[r + 1]);
+            }
+            tmp.push_back((uint32_t)i);  // the diagonal carries lambda even where A'A has none
+            std::sort(tmp.begin(), tmp.end());
+            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+            m_h_mcol.insert(m_h_mcol.end(), tmp.begin(), tmp.end());
+            mrow.insert(mrow.end(), tmp.size(), (uint32_t)i);
+            m_h_mrowptr[i + 1] = m_h_mcol.size();
+            sanm_check(m_h_mcol.size() < (size_t(1) << 31), "A'A exceeds 32-bit indexing");
+        }
+        m_atval = DVec{be, std::max<size_t>(nnz, 1)};
+        m_mval = DVec{be, m_h_mcol.size()};
+        m_rhs = DVec{be, (size_t)n};
+        m_at = {upload(cp), upload(rows), m_atval.p(), n, (int64_t)nnz};
+        m_m = {upload(m_h_mrowptr), upload(m_h_mcol), m_mval.p(), n, (int64_t)m_h_mcol.size()};
+        m_perm = upload(perm);
+        m_mrow = upload(mrow);
+        m_mf = std::make_unique<Multifrontal>(be, n, m_h_mrowptr, m_h_mcol, coords);
+        nnz_factors = m_mf->nnz_factors;
+        nr_front = m_mf->nr_front;
+        nr_level = m_mf->nr_level;
+        max_front = m_mf->max_front;
+        factor_flops = m_mf->factor_flops;
+    }
+    ~TikhonovSolver() override {
+        for (void* p : m_bufs) m_be->free(p);
+    }
+    void prepare() override {
+        m_be->gather(m_at.nnz, m_pat.csr().val, m_perm, m_atval.p());
+        m_be->ata(m_at, m_m, m_mrow, m_lambda);
+        const int bad = m_be->mf_factor(m_mf->dev(), m_mf->schedule(), m_m);
+        if (bad)
+            sanm_throw(SANM_ERR_NUMERICAL, "Tikhonov path: %d pivot(s) of A'A + %g I below the threshold", bad, m_lambda);
+    }
+    void solve(const double* b, double* x) override {
+        m_be->spmv(m_at, b, m_rhs.p());  // A'b
+        m_be->mf_solve(m_mf->dev(), m_mf->schedule(), m_rhs.p(), x);
+        ++nr_solve;
+    }
+};
+}  // namespace
+
 std::unique_ptr<LinearSolver> make_direct_solver(Backend* be, const JacobianPattern& pat,
                                                  const HyperParam& hp, const double* coords) {
+    if (hp.xcoeff_l2_penalty != 0) return std::make_unique<TikhonovSolver>(be, pat, hp.xcoeff_l2_penalty, coords);
     return std::make_unique<DirectSolver>(be, pat, hp, coords);
 }
 
@@ -546,8 +641,8 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
           m_shard{shard}, m_profile_mode{hp.profile} {
     sanm_check(hp.order >= 2, "order=%d", hp.order);  // anm.cpp:108-110
     sanm_check(remap_inp_in.out_size % 9 == 0, "remap_inp must produce a (T,3,3) tensor");
-    if (hp.xcoeff_l2_penalty != 0)
-        sanm_throw(SANM_ERR_UNSUPPORTED, "xcoeff_l2_penalty (Tikhonov path) is not on the device path");
+    if (hp.xcoeff_l2_penalty != 0 && hp.solver_kind != 1)
+        sanm_throw(SANM_ERR_UNSUPPORTED, "xcoeff_l2_penalty (Tikhonov path) needs the direct solver (solver_kind 1)");
     Graph g_perm;
     SparseDesc inp_perm, out_perm;
     const bool reorder = remap_out_in.out_coords.size() == (size_t)m_n * 3 &&
@@ -607,7 +702,7 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
     m_dev_scalars = DVec{be, (size_t)hp.order + 2};
     // per order: t_i, then (after all of them) the two results of its sanity check
     m_host_scalars = be->alloc_host(5 * ((size_t)hp.order + 2) + 8);
-    if (hp.sanity_check) {
+    if (hp.sanity_check && !hp.xcoeff_l2_penalty) {  // anm.cpp:271: no check on the regularised path
         m_bi_all.resize(hp.order + 1);
         for (int i = 1; i <= hp.order; ++i) m_bi_all[i] = DVec{be, (size_t)m_n};
     }
@@ -709,6 +804,7 @@ void AnmDriver::solve_expansion_coeffs() {
     const bool pade_riders = pade_steps && gs_mode == 2, pade_side = pade_steps && gs_mode == 1;
     m_pade_ws.done = 0;
     if (pade_steps) m_pade_ws.ensure(be, N + 1, n1);
+    const bool do_sanity = m_hp.sanity_check && !m_hp.xcoeff_l2_penalty;
     int sanity_done = 0;  // orders 1 .. sanity_done are queued
     auto queue_sanity = [&](int upto, const double* grad_t_dev) {
         // anm.cpp:271-285: A x_i = -(t_i g_t + b_i) and x_1 . x_i = delta_1i, in one pass over the matrix per 10
@@ -725,7 +821,7 @@ void AnmDriver::solve_expansion_coeffs() {
     };
     for (int i = 1; i <= N; ++i) {
         // (with the checks on, every order keeps its b_i: they are all verified in one pass after the loop)
-        double* const bi = m_hp.sanity_check ? m_bi_all[i].p() : m_bi.p();
+        double* const bi = do_sanity ? m_bi_all[i].p() : m_bi.p();
         if (i == 1) {
             ScopedTimer t{this, "jacobian"};
             be->run_pass(P, PASS_GRAD, 0, nullptr);
@@ -829,7 +925,7 @@ void AnmDriver::solve_expansion_coeffs() {
             bias_done = fuse_passes;
         }
     }
-    if (m_hp.sanity_check) queue_sanity(N, grad_t);  // the orders not checked beside the loop
+    if (do_sanity) queue_sanity(N, grad_t);  // the orders not checked beside the loop
     // the two norms of estimate_valid_range travel with the rest
     be->dot_async(n1, m_xt_coeffs[1].p(), m_xt_coeffs[1].p(), host_checks + 2);
     be->dot_async(n1, m_xt_coeffs[N].p(), m_xt_coeffs[N].p(), host_checks + 3);
@@ -842,7 +938,7 @@ void AnmDriver::solve_expansion_coeffs() {
         if (!std::isfinite(ti))
             sanm_throw(SANM_ERR_NUMERICAL, "non-finite right-hand side / solution at order %d", i);
         m_t_coeffs.push_back(ti);
-        if (m_hp.sanity_check) {
+        if (do_sanity) {
             const double ex = host_sanity[2 * (i - 1)], xdot = host_sanity[2 * (i - 1) + 1];
             sanm_check(ex < 0, "ANM check coeff eqn: order %d: excess %g", i, ex);
             if (i == 1) sanm_check(std::fabs(xdot - 1) < 1e-4, "xdot=%g", xdot);

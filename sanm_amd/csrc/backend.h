@@ -130,6 +130,12 @@ public:
     //! y = A x  (SparseSolver::apply, sparse_solver.cpp:202-215)
     virtual void spmv(const CsrDev& A, const double* x, double* y) = 0;
 
+    //! dst[i] = src[idx[i]]  (values of A' in CSR order from those of A)
+    virtual void gather(size_t n, const double* src, const uint32_t* idx, double* dst) = 0;
+    //! Normal equations of the Tikhonov path (libsanm/sparse_solver.cpp:366-395): M = A'A + lambda I on a fixed
+    //! pattern.  At: A' in CSR form (row i = column i of A, ascending row indices); entry e of M sits in row
+    //! mrow[e], column M.col[e]: M.val[e] = (column mrow[e] of A) . (column M.col[e] of A) + lambda [on the diagonal]
+    virtual void ata(const CsrDev& At, const CsrDev& M, const uint32_t* mrow, double lambda) = 0;
     //! r = b - A x for iterative refinement, accumulated in twice the working precision (the default, in
     //! backend_common.cpp, is the plain fp64 form); r may alias b
     virtual void residual(const CsrDev& A, const double* b, const double* x, double* r);

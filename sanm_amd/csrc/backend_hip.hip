@@ -162,6 +162,17 @@ __global__ void __launch_bounds__(256) assemble_kernel(AssemblyDev A, const doub
     if (s < A.nslots && sub == 0) val[s] = v;
 }
 
+__global__ void gather_kernel(size_t n, const double* __restrict__ src, const uint32_t* __restrict__ idx,
+                              double* __restrict__ dst) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+// A'A + lambda I entry by entry (row_ops.h: ata_entry): one thread per entry of the fixed pattern
+__global__ void ata_kernel(CsrDev At, CsrDev M, const uint32_t* __restrict__ mrow, double lambda) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < M.nnz) M.val[e] = ata_entry(At, mrow[e], M.col[e], lambda);
+}
+
 constexpr int SPMV_LANES = 8;
 __global__ void spmv_kernel(CsrDev A, const double* __restrict__ x, double* __restrict__ y) {
     int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1360,6 +1371,14 @@ public:
     void assemble(const AssemblyDev& A, const double* jac, double* val) override {
         hipLaunchKernelGGL(assemble_kernel, dim3(nblk((size_t)A.nslots * ROW_LANES, 256)), dim3(256), 0,
                            m_stream, A, jac, val);
+        HIP_CHECK(hipGetLastError());
+    }
+    void gather(size_t n, const double* src, const uint32_t* idx, double* dst) override {
+        hipLaunchKernelGGL(gather_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, src, idx, dst);
+        HIP_CHECK(hipGetLastError());
+    }
+    void ata(const CsrDev& At, const CsrDev& M, const uint32_t* mrow, double lambda) override {
+        hipLaunchKernelGGL(ata_kernel, dim3(nblk(M.nnz, 256)), dim3(256), 0, m_stream, At, M, mrow, lambda);
         HIP_CHECK(hipGetLastError());
     }
     void residual(const CsrDev& A, const double* b, const double* x, double* r) override {

@@ -32,6 +32,19 @@ SANM_HD double spmv_row(const CsrDev& A, const double* x, int64_t i) {
     return s;
 }
 
+// one entry of A'A + lambda I: sparse dot product of two columns of A (rows ascending in both), merge order
+SANM_HD double ata_entry(const CsrDev& At, uint32_t i, uint32_t j, double lambda) {
+    uint32_t p = At.rowptr[i], pe = At.rowptr[i + 1], q = At.rowptr[j], qe = At.rowptr[j + 1];
+    double s = i == j ? lambda : 0.0;
+    while (p < pe && q < qe) {
+        const uint32_t a = At.col[p], b = At.col[q];
+        if (a == b) s += At.val[p] * At.val[q];
+        p += a <= b;
+        q += b <= a;
+    }
+    return s;
+}
+
 SANM_HD double csr_diag(const CsrDev& A, int64_t i) {
     for (uint32_t p = A.rowptr[i], e = A.rowptr[i + 1]; p < e; ++p)
         if ((int64_t)A.col[p] == i) return A.val[p];

@@ -151,6 +151,12 @@ public:
             for (int64_t s = sb; s < se; ++s) val[s] = assemble_slot(A, jac, s);
         });
     }
+    void gather(size_t n, const double* src, const uint32_t* idx, double* dst) override {
+        for (size_t i = 0; i < n; ++i) dst[i] = src[idx[i]];
+    }
+    void ata(const CsrDev& At, const CsrDev& M, const uint32_t* mrow, double lambda) override {
+        for (int64_t e = 0; e < M.nnz; ++e) M.val[e] = ata_entry(At, mrow[e], M.col[e], lambda);
+    }
     void residual(const CsrDev& A, const double* b, const double* x, double* r) override {
         for (int64_t i = 0; i < A.n; ++i) {  // in extended precision, like the device's double-double kernel
             long double s = b[i];
