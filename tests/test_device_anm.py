@@ -157,8 +157,10 @@ def test_error_paths(api):
     # order < 2 -> assertion (anm.cpp:108-110)
     with pytest.raises(A.SanmAssertionError):
         A.ANMEqnSolver(api, m.y, m.lt_inp, m.lt_out, m.x0(), v, api.default_hyper(order=1))
+    # the Tikhonov path needs the direct solver: with the iterative one it is rejected, not ignored
     with pytest.raises(A.SanmUnsupportedError):
-        A.ANMEqnSolver(api, m.y, m.lt_inp, m.lt_out, m.x0(), v, api.default_hyper(order=4, xcoeff_l2_penalty=0.1))
+        A.ANMEqnSolver(api, m.y, m.lt_inp, m.lt_out, m.x0(), v,
+                       api.default_hyper(order=4, xcoeff_l2_penalty=0.1, solver_kind=0))
 
 
 def test_tet_renumbering_is_transparent(api, monkeypatch):
