@@ -8,6 +8,7 @@
 
 #include "multifrontal.h"
 #include "poly.h"
+#include "tet_ops.h"
 
 namespace sanm_hip {
 
@@ -774,7 +775,33 @@ void AnmDriver::solve_expansion_coeffs() {
         }
         allreduce(m_fx0.p(), n);
     }
-    if (!on_fx0_computed(m_fx0.p())) return;
+    // 0^p in a pow operator (analytic_unary.cpp:112-131): the order-0 pass raised a flag in the arena; its square
+    // travels to the host with the next synchronisation
+    double* const host_powflag = m_host_scalars + 5 * ((size_t)N + 2) + 4;
+    *host_powflag = 0;
+    const bool has_powflag = !m_prog->pow_flags().empty();
+    auto check_powflag = [&]() {
+        if (!has_powflag || *host_powflag == 0) return;
+        const bool unsupported = *host_powflag > 1.5;
+        double zero = 0;
+        be->h2d(m_prog->arena_dev() + m_prog->pow_flags()[0].off, &zero, 8);
+        std::string exps;
+        for (const auto& f : m_prog->pow_flags()) exps += (exps.empty() ? "" : ", ") + std::to_string(f.exponent);
+        if (unsupported)
+            sanm_throw(SANM_ERR_UNSUPPORTED, "integer power of a series through zero beyond order %d (exponents: %s)",
+                       POW_INT_MAX_ORDER, exps.c_str());
+        sanm_throw(SANM_ERR_NUMERICAL, "0^p when p is not integer (pow exponents in the graph: %s)", exps.c_str());
+    };
+    if (has_powflag) {
+        const double* fl = m_prog->arena_dev() + m_prog->pow_flags()[0].off;
+        be->dot_async(1, fl, fl, host_powflag);
+    }
+    if (!on_fx0_computed(m_fx0.p())) {
+        check_powflag();
+        return;
+    }
+    if (has_powflag) be->sync();  // (most on_fx0_computed variants have waited for the device already)
+    check_powflag();
 
     double t1 = 0, xgt_dot_x1 = 0;
     const double* grad_t = nullptr;

@@ -6,6 +6,7 @@
 #include <string>
 
 #include "anm.h"
+#include "tet_ops.h"
 #include "fea.h"
 #include "graph.h"
 #include "multifrontal.h"
@@ -274,6 +275,19 @@ int sanm_taylor_push_xi(sanm_taylor_prop* p, const double* x, double* y_k) {
         be->h2d(p->x.p(), x, p->n_in * 8);
         be->run_pass(p->prog->dev(), p->order == 0 ? PASS_EVAL0 : PASS_COEFF, p->order, p->x.p());
         be->sync();
+        if (p->order == 0 && !p->prog->pow_flags().empty()) {
+            // 0^p (analytic_unary.cpp:112-131): flagged by the order-0 pass
+            double fl = 0, zero = 0;
+            double* dev = p->prog->arena_dev() + p->prog->pow_flags()[0].off;
+            be->d2h(&fl, dev, 8);
+            if (fl != 0) {
+                be->h2d(dev, &zero, 8);
+                if (fl > 1.5)
+                    sanm_throw(SANM_ERR_UNSUPPORTED, "integer power of a series through zero beyond order %d",
+                               POW_INT_MAX_ORDER);
+                sanm_throw(SANM_ERR_NUMERICAL, "0^p when p is not integer");
+            }
+        }
         p->xi_known = true;
         if (y_k) {
             int T = p->prog->T();

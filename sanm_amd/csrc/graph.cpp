@@ -384,6 +384,13 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
                 break;
             case OP_POW:
                 o.p[0] = op.exponent;
+                if (op.exponent != 2.0) {
+                    // one double shared by all tets: set when an order-0 value is a zero (|x| < 1e-3) that the power
+                    // recurrence cannot divide by (analytic_unary.cpp:43, :112-131; Program::pow_flags)
+                    if (m_pow_flags.empty()) m_pow_flag_off = take(64);
+                    o.aux[2] = m_pow_flag_off;
+                    m_pow_flags.push_back({o.aux[2], op.exponent});
+                }
                 [[fallthrough]];
             case OP_LOG:
                 o.aux[0] = take((int64_t)osz * Tpad);
@@ -515,6 +522,7 @@ __device__ __forceinline__ void spec_body(const ProgramDev& P, int order, const 
     TetCtx c{P.arena, kVars, kTpad, tet, MODE == PASS_GRAD ? (int)blockIdx.y : order, 9, cur, 64, kOutVar, part, nparts,
              cur_lds + (int64_t)kCurSize * 64 + lane};
     c.out = P.arena + kOutAos;
+    c.max_order = P.max_order;
     if (MODE == PASS_GRAD) {
         c.grow = blockIdx.y;
         for (int e = 0; e < 9; ++e) cur[(int64_t)(kVars[kOutVar].cur + e) * 64] = (e == c.grow) ? 1.0 : 0.0;

@@ -114,10 +114,22 @@ public:
     void download_var(int graph_var, int order, double* dst) const;
     void download_jacobian(double* dst) const;  // (T, odim, 9)
     size_t arena_bytes() const { return m_arena_doubles * sizeof(double); }
+    //! per pow operator with an exponent other than 2: (arena offset of the zero flag -- one double shared by all of
+    //! them --, exponent).  The order-0 pass writes 1 there for "0^p with p not an integer above 1/2" (SANMNumericalError in the reference,
+    //! analytic_unary.cpp:115-120) and 2 for "integer power of a series through zero beyond the order the device
+    //! path carries" (32).
+    struct PowFlag {
+        int64_t off;
+        double exponent;
+    };
+    const std::vector<PowFlag>& pow_flags() const { return m_pow_flags; }
+    double* arena_dev() const { return m_dev.arena; }
 
 private:
     Backend* m_be;
     ProgramDev m_dev{};
+    std::vector<PowFlag> m_pow_flags;
+    int64_t m_pow_flag_off = -1;
     std::vector<OpDesc> m_ops;
     std::vector<VarDesc> m_vars;
     std::vector<int> m_var_map;  // graph var -> local var (-1 if unused)

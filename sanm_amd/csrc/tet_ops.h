@@ -62,6 +62,7 @@ struct TetCtx {
     // instead of 9 x size doubles per variable in HBM.
     int32_t grow = 0;
     double* out = nullptr;  // arena + ProgramDev::out_aos
+    int32_t max_order = 0;
 };
 
 // slice [lo, hi) of the convolution index range 1 .. order-1 taken by this part
@@ -489,7 +490,27 @@ SANM_HD void op_multiply(const TetCtx& c, const OpDesc& o, int mode) {
 }
 
 // ---- LOG / POW: oprs/analytic_unary.cpp:113-158, analytic_unary.cpp:13-139
-//      aux0 = k = f'(x0) [sz], aux1 = self_bias [sz]
+//      aux0 = k = f'(x0) [sz], aux1 = self_bias [sz], aux2 = zero flag of a pow with exponent != 2 (one double)
+constexpr int POW_INT_MAX_ORDER = 32;
+SANM_HD bool pow_is_zero(double x) { return fabs(x) < 1e-3; }  // analytic_unary.cpp:43
+// [a^k] of (x_0 + x_1 a + ... + x_{k-1} a^{k-1})^p for an integer p >= 2 by repeated multiplication of truncated
+// series: what prop_taylor_coeff_int (analytic_unary.cpp:46-92) computes by repeated squaring, for the elements
+// whose x_0 is a zero the division recurrence cannot start from.  O(p k^2) per element, only ever run for those.
+SANM_HD double pow_int_bias(const TetCtx& c, int x, int e, int k, int p) {
+    double y[POW_INT_MAX_ORDER + 1], acc[POW_INT_MAX_ORDER + 1], nxt[POW_INT_MAX_ORDER + 1];
+    for (int i = 0; i < k; ++i) y[i] = p_coef(c, x, i)[e * c.Tpad];
+    y[k] = 0;
+    for (int i = 0; i <= k; ++i) acc[i] = y[i];
+    for (int m = 2; m <= p; ++m) {
+        for (int d = 0; d <= k; ++d) {
+            double sum = 0;
+            for (int i = 0; i <= d; ++i) sum += acc[i] * y[d - i];
+            nxt[d] = sum;
+        }
+        for (int d = 0; d <= k; ++d) acc[d] = nxt[d];
+    }
+    return acc[k];
+}
 template <int SZ>
 SANM_HD void op_unary_t(const TetCtx& c, const OpDesc& o, int mode) {
     const int64_t s = c.Tpad;
@@ -512,6 +533,12 @@ SANM_HD void op_unary_t(const TetCtx& c, const OpDesc& o, int mode) {
             } else {
                 po[e * s] = pow(v, pw);
                 pk[e * s] = pw * pow(v, pw - 1.0);
+                if (pow_is_zero(v) && !c.vars[x].is_const) {
+                    // analytic_unary.cpp:112-131: an integer exponent continues on the convolution path, anything
+                    // else is SANMNumericalError{"0^p when p is not integer"} (reported by the driver)
+                    const bool integer = pw > 0.5 && floor(pw) == pw;
+                    c.arena[o.aux[2]] = (integer && c.max_order <= POW_INT_MAX_ORDER) ? 0.0 : (integer ? 2.0 : 1.0);
+                }
             }
         }
         return;
@@ -543,7 +570,12 @@ SANM_HD void op_unary_t(const TetCtx& c, const OpDesc& o, int mode) {
             if (c.part) return;
             if (!int2) {
                 const double* x0 = p_coef(c, x, 0);
-                for (int e = 0; e < sz; ++e) sb[e] /= x0[e * s];
+                const bool int_pow = !is_log && pw > 2.5 && floor(pw) == pw && k <= POW_INT_MAX_ORDER;
+                for (int e = 0; e < sz; ++e) {
+                    const double x0e = x0[e * s];
+                    if (int_pow && pow_is_zero(x0e)) sb[e] = pow_int_bias(c, x, e, k, (int)pw);
+                    else sb[e] /= x0e;
+                }
             }
         }
         if (c.part) return;
@@ -1077,6 +1109,7 @@ SANM_HD void exec_program_tet(const ProgramDev& P, int mode, int order, int64_t 
                               int nparts = 1, double* red = nullptr) {
     TetCtx c{P.arena, P.vars, P.Tpad, tet, order, P.odim, cur, cur_stride, P.out_var, part, nparts, red};
     c.out = P.arena + P.out_aos;
+    c.max_order = P.max_order;
     if (mode == PASS_GRAD) {
         // seed: row `order` of d(out)/d(out) = I  (symbolic.cpp:219-220); the launch passes the row in `order`
         c.grow = order;

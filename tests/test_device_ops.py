@@ -203,3 +203,42 @@ def test_host_poly_helpers(api):
         hi *= 2
         f[-1] = abs(f[-1]) + 0.1
     assert api.poly_solve_eqn(f, 0.0, hi) == up.solve_eqn(f, 0.0, hi)
+
+
+def test_integer_pow_through_zero_takes_the_convolution_path(api):
+    """analytic_unary.cpp:112-131: where the order-0 value is a zero (|x| < 1e-3) an integer exponent continues on
+    the convolution path (prop_taylor_coeff_int, :46-92) instead of the recurrence that divides by x_0.  The
+    reference switches the whole tensor, the device path each element on its own: same coefficients."""
+    T, N = 11, 6
+    rng = np.random.default_rng(5)
+    xs = _series(rng, T, N, near_identity=True)   # I + noise: the off-diagonal entries are near zero ...
+    xs[0][:, 0, 1] = 0.0                          # ... and these are exactly zero
+    xs[0][3, 2, 2] = 5e-4                         # a "zero" by the 1e-3 rule that is not 0.0
+    for p in (3.0, 4.0):
+        ocg = S.ComputingGraph()
+        oy = S.placeholder(ocg).pow(p)
+        oprop = S.TaylorCoeffProp(oy)
+        dcg = api.graph()
+        dy = dcg.placeholder().pow(p)
+        dprop = A.TaylorCoeffProp(api, dy, _identity_remap(api, T), N, T)
+        o0, d0 = oprop.push_xi([xs[0]]), dprop.push_xi(xs[0])
+        assert np.allclose(d0, o0, rtol=1e-12, atol=1e-300)
+        for k in range(1, N + 1):
+            ob, db = oprop.compute_next_order_bias(), dprop.compute_next_order_bias()
+            assert np.all(np.isfinite(db))
+            assert np.abs(db - ob).max() <= 1e-11 * max(np.abs(ob).max(), 1e-30), (p, k)
+            oc, dc = oprop.push_xi([xs[k]]), dprop.push_xi(xs[k])
+            assert np.abs(dc - oc).max() <= 1e-11 * max(np.abs(oc).max(), 1e-30), (p, k)
+
+
+def test_fractional_pow_of_zero_is_a_numerical_error(api):
+    """SANMNumericalError{"0^p when p is not integer"} (analytic_unary.cpp:115-120)"""
+    T = 5
+    x0 = np.tile(np.eye(3), (T, 1, 1))  # off-diagonal zeros
+    dcg = api.graph()
+    dprop = A.TaylorCoeffProp(api, dcg.placeholder().pow(1.5), _identity_remap(api, T), 3, T)
+    with pytest.raises(A.SanmNumericalError, match="0\\^p when p is not integer"):
+        dprop.push_xi(x0)
+    # the same input is fine for pow(2) (always on the convolution path) ...
+    dprop2 = A.TaylorCoeffProp(api, dcg.placeholder().pow(2), _identity_remap(api, T), 3, T)
+    assert np.allclose(dprop2.push_xi(x0), x0 ** 2)
