@@ -164,7 +164,7 @@ class NestedDissection {
     const SvGraph& g;
     std::vector<int32_t> stamp, dist, queue;
     int32_t cur_stamp = 0;
-    static constexpr int LEAF = 32;
+    const int LEAF = std::getenv("SANM_MF_LEAF") ? std::atoi(std::getenv("SANM_MF_LEAF")) : 32;
 
 public:
     std::vector<NdNode> nodes;
@@ -587,14 +587,15 @@ void amalgamate_levels(std::vector<NdNode>& nodes, const SvGraph& g) {
                 ++p;
             }
         }
-    } else if (H >= 8) {
+    } else if (H >= 8 && g.nsv <= 50000) {
+        // (small systems only: there a level is pure launch latency; on a 24^3-vertex block the two merges cost 7 %
+        // more factor entries, on larger ones the factorisation is bound by arithmetic and they would only cost)
         merge = {1, 3};
     }
     if (merge.empty()) return;
     std::vector<char> at(H + 1, 0);
     for (int h : merge)
         if (h >= 1 && h < H - 1) at[h] = 1;  // never the leaves (they hold the bulk of the factor) nor the roots
-    (void)g;
     std::vector<char> dead(F, 0);
     // top-down over the nodes (parents first): a merged node hands its variables and children up
     for (int32_t u = 0; u < F; ++u) {
@@ -877,14 +878,21 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     if (std::getenv("SANM_MF_DEBUG")) {
         for (int32_t h = 0; h < H; ++h) {
             const auto& L = m_sched.levels[h];
-            int64_t solve_elems = 0;
+            int64_t solve_elems = 0, fill = 0, sk = 0, sb = 0;
+            double fl = 0;
             for (int32_t i = L.front_begin; i < L.front_end; ++i) {
                 const auto& f = fr[level_fronts[i]];
                 solve_elems += (int64_t)(f.m + f.k) * f.k;
+                const double k = f.k, bb = f.m - f.k;
+                fill += (int64_t)(k * k + 2 * k * bb);
+                fl += 2.0 / 3 * k * k * k + 2 * k * k * bb + 2 * k * bb * bb + 2 * k * k * (k + bb);
+                sk += f.k;
+                sb += f.m - f.k;
             }
-            std::fprintf(stderr, "mf level %d: fronts=%d max_k=%d max_m=%d max_b=%d panels=%d solve_MB=%.2f\n", h,
-                         L.front_end - L.front_begin, L.max_k, L.max_m, L.max_b, L.nr_panel,
-                         solve_elems * 8 / 1e6);
+            const int nf = L.front_end - L.front_begin;
+            std::fprintf(stderr, "mf level %d: fronts=%d max_k=%d max_m=%d max_b=%d panels=%d solve_MB=%.2f fill=%.2fM "
+                         "GF=%.2f avg_k=%.0f avg_b=%.0f\n", h, nf, L.max_k, L.max_m, L.max_b, L.nr_panel,
+                         solve_elems * 8 / 1e6, fill / 1e6, fl / 1e9, (double)sk / nf, (double)sb / nf);
         }
     }
 
