@@ -284,8 +284,13 @@ def main(argv=None):
     barrier()
     t0 = time.perf_counter()
     it0 = run.solver.get_nr_iter() if state["started"] else 0
-    for _ in range(args.steps):
-        one_step()
+    if state["started"]:
+        # the K timed steps in one call (sanm_anm_run_steps: the same next_iter / restart sequence as one_step,
+        # driven from C++ like the reference's own loop, fea/main.cpp:172-190, without the interpreter in between)
+        state["solves"] += run.solver.run_steps(args.steps, x0)
+    else:
+        for _ in range(args.steps):
+            one_step()
     barrier()
     dt = time.perf_counter() - t0
     assert run.solver.get_nr_iter() - it0 == args.steps

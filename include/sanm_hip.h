@@ -177,6 +177,10 @@ int sanm_anm_update_approx(sanm_anm_solver* s);                  /* ANMDriverHel
  * ANMEqnSolver does in the reference (fea/main.cpp:418), minus rebuilding the
  * device program / CSR pattern, which depend on the mesh only */
 int sanm_anm_restart(sanm_anm_solver* s, const double* x0);
+/* exactly `count` more completed continuation steps without returning to the caller in between: next_iter while
+ * the solve has not converged, sanm_anm_restart(x0) when it has (what a driver loop around the two calls does,
+ * minus the caller's own time between them; bench.py's timed region) */
+int sanm_anm_run_steps(sanm_anm_solver* s, int count, const double* x0, int* nr_restart);
 /* measurement hook for bench.py: average duration (ms) of `reps` back-to-back
  * launches of one kernel on the solver's own data, HIP events on its stream.
  * kernel 0: Taylor pass (mode 0..3 = eval0/grad/bias/coeff at `order`),

@@ -81,7 +81,7 @@ SYMBOLS = [
     "sanm_hyper_param_default", "sanm_anm_eqn_solver_create", "sanm_anm_eqn_solver_create_sharded",
     "sanm_anm_vecscale_solver_create",
     "sanm_anm_implicit_solver_create", "sanm_anm_solver_destroy", "sanm_anm_next_iter",
-    "sanm_anm_update_approx", "sanm_anm_restart", "sanm_anm_spec_source", "sanm_rtc_compile_check", "sanm_anm_time_kernel", "sanm_anm_pass_timing", "sanm_anm_converged", "sanm_anm_residual_rms", "sanm_anm_get_x",
+    "sanm_anm_update_approx", "sanm_anm_restart", "sanm_anm_run_steps", "sanm_anm_spec_source", "sanm_rtc_compile_check", "sanm_anm_time_kernel", "sanm_anm_pass_timing", "sanm_anm_converged", "sanm_anm_residual_rms", "sanm_anm_get_x",
     "sanm_anm_get_t_upper", "sanm_anm_get_t_max_a", "sanm_anm_solve_a", "sanm_anm_eval",
     "sanm_anm_nr_iter", "sanm_anm_nr_xt_coeffs", "sanm_anm_xt_coeff", "sanm_anm_has_pade",
     "sanm_anm_get_stats", "sanm_anm_profile", "sanm_anm_profile_counts", "sanm_anm_set_profile", "sanm_anm_debug_inject", "sanm_anm_trace", "sanm_anm_jacobian_csr",
@@ -622,6 +622,13 @@ class ANMEqnSolver(_ANMSolver):
 
     def residual_rms(self):
         return self._get(self.api.lib.sanm_anm_residual_rms, C.c_double)
+
+    def run_steps(self, count, x0):
+        """exactly `count` more completed steps (restarting from x0 when the solve converges); returns restarts"""
+        x0 = _f64(x0).ravel()
+        r = C.c_int()
+        self.api.check(self.api.lib.sanm_anm_run_steps(self.h, C.c_int(count), _dp(x0), C.byref(r)))
+        return r.value
 
     def restart(self, x0):
         x0 = _f64(x0).ravel()

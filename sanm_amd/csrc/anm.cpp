@@ -748,6 +748,8 @@ void AnmDriver::init_xt0(const double* x_host, double t) {
     std::copy(x_host, x_host + m_n, h.begin());
     h[m_n] = t;
     m_be->h2d(m_xt0.p(), h.data(), h.size() * 8);
+    m_t0_host = t;
+    m_t0_known = true;
 }
 
 void AnmDriver::solve_expansion_coeffs() {
@@ -761,7 +763,10 @@ void AnmDriver::solve_expansion_coeffs() {
     be->d2d(m_xt_coeffs[0].p(), m_xt0.p(), n1 * 8);
     m_nr_valid_coeffs = 1;
     m_t_coeffs.assign(1, 0.0);
-    be->d2h(&m_t_coeffs[0], m_xt0.p() + n, 8);
+    // t_0: known on the host when the caller has just set it (no round trip to the device then)
+    if (m_t0_known) m_t_coeffs[0] = m_t0_host;
+    else be->d2h(&m_t_coeffs[0], m_xt0.p() + n, 8);
+    m_t0_known = false;
     trace_b_norm.clear();
     trace_x_norm.clear();
     trace_t.clear();
@@ -1116,8 +1121,9 @@ AnmEqnSolver& AnmEqnSolver::next_iter() {
     double a = get_t_upper() >= 1 ? solve_a(1) : get_t_max_a();
     eval_xt(a, m_tmp0.p());
     m_be->d2d(m_xt0.p(), m_tmp0.p(), (m_n + 1) * 8);
-    double zero = 0;
-    m_be->h2d(m_xt0.p() + m_n, &zero, 8);  // set t0 to 0
+    m_be->zero(m_xt0.p() + m_n, 8);  // set t0 to 0 (queued, like everything before the first check of the step)
+    m_t0_host = 0;
+    m_t0_known = true;
     solve_expansion_coeffs();
     return *this;
 }
@@ -1132,6 +1138,24 @@ bool AnmEqnSolver::on_fx0_computed(const double* fx_dev) {
         return false;
     }
     return true;
+}
+
+int AnmEqnSolver::run_steps(int count, const double* x0) {
+    // `count` completed expansions without going back to the caller in between: next_iter while the solve has
+    // not converged, a new solve from x0 when it has (the bench's step loop; a caller that only wants the
+    // solution loops on next_iter itself)
+    int solves = 0;
+    while (count > 0) {
+        const size_t before = m_iter;
+        if (!m_converged) next_iter();
+        if (m_iter == before) {  // converged (next_iter only evaluated f(x0)) or was already: start over
+            sanm_check(x0, "run_steps: the solve has converged and no restart point was given");
+            ++solves;
+            restart(x0);
+        }
+        count -= (int)(m_iter - before);
+    }
+    return solves;
 }
 
 void AnmEqnSolver::restart(const double* x0) {

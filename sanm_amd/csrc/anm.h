@@ -232,6 +232,8 @@ protected:
     std::unique_ptr<LinearSolver> m_solver;
 
     DVec m_xt0;
+    double m_t0_host = 0;
+    bool m_t0_known = false;
     size_t m_iter = 0;
     std::vector<DVec> m_xt_coeffs;
     int m_nr_valid_coeffs = 0;
@@ -284,6 +286,9 @@ public:
     //! start a new solve from x0 on the same model (a new ANMEqnSolver in the
     //! reference; here the device program, CSR pattern and solver analysis are kept)
     void restart(const double* x0);
+    //! exactly `count` more completed expansions (restarting from x0 whenever the solve converges); returns the
+    //! number of restarts
+    int run_steps(int count, const double* x0);
     void get_x(double* x_host) const;
 
 private:

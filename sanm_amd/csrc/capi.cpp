@@ -483,6 +483,13 @@ int sanm_anm_pass_timing(sanm_anm_solver* s, int enable, double* total_ms, int64
         be->enable_pass_timing(enable != 0);
     });
 }
+int sanm_anm_run_steps(sanm_anm_solver* s, int count, const double* x0, int* nr_restart) {
+    return guard([&] {
+        sanm_check(s->eqn, "run_steps is only defined for ANMEqnSolver");
+        const int r = s->eqn->run_steps(count, x0);
+        if (nr_restart) *nr_restart = r;
+    });
+}
 int sanm_anm_update_approx(sanm_anm_solver* s) {
     return guard([&] { s->drv->update_approx(); });
 }
