@@ -651,11 +651,27 @@ __device__ __forceinline__ void rows_consume(const RowChunks<R, U>& rc, const do
 #pragma unroll
         for (int q = 0; q < R; ++q) acc[q] += rc.a[u][q] * tv;
     }
-    for (int c = c0 + 64 * U; c < cmax; c += 64) {
-        const double tv = v[c];
+    // (fronts wider than the preloaded chunks -- thousands of columns on the large meshes, where these kernels are
+    // bound by bandwidth: TAIL chunks per trip with unconditional index-clamped loads, so that TAIL * R loads are in
+    // flight per lane instead of one; a plain loop with the range test around the load ran at 2.5 TB/s)
+    constexpr int TAIL = 8;
+    for (int c = c0 + 64 * U; c < cmax; c += 64 * TAIL) {
+        double a[TAIL][R], tv[TAIL];
 #pragma unroll
-        for (int q = 0; q < R; ++q)
-            if (c >= cbeg[q] && c < cend[q]) acc[q] += rowp[q][c] * tv;
+        for (int u = 0; u < TAIL; ++u) {
+            const int cc = c + 64 * u;
+            tv[u] = v[cc < cmax ? cc : csafe];
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const bool ok = cc >= cbeg[q] && cc < cend[q];
+                const double x = rowp[q][ok ? cc : 0];
+                a[u][q] = ok ? x : 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TAIL; ++u)
+#pragma unroll
+            for (int q = 0; q < R; ++q) acc[q] += a[u][q] * tv[u];
     }
 }
 
@@ -826,11 +842,26 @@ __global__ void __launch_bounds__(256) bwd_level_kernel(MfDev mf, int level_begi
 #pragma unroll
         for (int q = 0; q < R; ++q) acc[q] += a[u][q] * tv;
     }
-    for (int c = c0 + 64 * U; c < m; c += 64) {
-        const double tv = vs[c];
+    {
+        constexpr int TAIL = 8;  // as in rows_consume: TAIL * R loads in flight per lane on the wide fronts
+        for (int c = c0 + 64 * U; c < m; c += 64 * TAIL) {
+            double av[TAIL][R], tv[TAIL];
 #pragma unroll
-        for (int q = 0; q < R; ++q)
-            if (c >= cbeg[q] && c < cend[q]) acc[q] += rowp[q][c < k ? c : c + k] * tv;
+            for (int u = 0; u < TAIL; ++u) {
+                const int cc = c + 64 * u;
+                tv[u] = vs[cc < m ? cc : rb];
+#pragma unroll
+                for (int q = 0; q < R; ++q) {
+                    const bool ok = cc >= cbeg[q] && cc < cend[q];
+                    const double x = rowp[q][ok ? (cc < k ? cc : cc + k) : 0];
+                    av[u][q] = ok ? x : 0.0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < TAIL; ++u)
+#pragma unroll
+                for (int q = 0; q < R; ++q) acc[q] += av[u][q] * tv[u];
+        }
     }
 #pragma unroll
     for (int q = 0; q < R; ++q) {
@@ -854,11 +885,15 @@ __device__ __forceinline__ double wave_dot_global(const double* __restrict__ row
                                                   int cbeg, int cend, int lane) {
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     int c = cbeg + lane;
-    for (; c + 192 < cend; c += 256) {
-        a0 += row[c] * v[c];
-        a1 += row[c + 64] * v[c + 64];
-        a2 += row[c + 128] * v[c + 128];
-        a3 += row[c + 192] * v[c + 192];
+    for (; c + 448 < cend; c += 512) {  // 16 loads in flight per lane
+        const double r0 = row[c], r1 = row[c + 64], r2 = row[c + 128], r3 = row[c + 192], r4 = row[c + 256],
+                     r5 = row[c + 320], r6 = row[c + 384], r7 = row[c + 448];
+        const double v0 = v[c], v1 = v[c + 64], v2 = v[c + 128], v3 = v[c + 192], v4 = v[c + 256], v5 = v[c + 320],
+                     v6 = v[c + 384], v7 = v[c + 448];
+        a0 += r0 * v0 + r4 * v4;
+        a1 += r1 * v1 + r5 * v5;
+        a2 += r2 * v2 + r6 * v6;
+        a3 += r3 * v3 + r7 * v7;
     }
     for (; c < cend; c += 64) a0 += row[c] * v[c];
     return wave_sum((a0 + a1) + (a2 + a3));
