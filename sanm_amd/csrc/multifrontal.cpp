@@ -879,7 +879,7 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
         for (int32_t h = 0; h < H; ++h) {
             const auto& L = m_sched.levels[h];
             int64_t solve_elems = 0, fill = 0, sk = 0, sb = 0;
-            double fl = 0;
+            double fl = 0, g_schur = 0, g_k2b = 0;
             for (int32_t i = L.front_begin; i < L.front_end; ++i) {
                 const auto& f = fr[level_fronts[i]];
                 solve_elems += (int64_t)(f.m + f.k) * f.k;
@@ -888,11 +888,14 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
                 fl += 2.0 / 3 * k * k * k + 2 * k * k * bb + 2 * k * bb * bb + 2 * k * k * (k + bb);
                 sk += f.k;
                 sb += f.m - f.k;
+                g_schur += 2 * k * bb * bb;
+                g_k2b += k * k * bb;
             }
             const int nf = L.front_end - L.front_begin;
             std::fprintf(stderr, "mf level %d: fronts=%d max_k=%d max_m=%d max_b=%d panels=%d solve_MB=%.2f fill=%.2fM "
-                         "GF=%.2f avg_k=%.0f avg_b=%.0f\n", h, nf, L.max_k, L.max_m, L.max_b, L.nr_panel,
-                         solve_elems * 8 / 1e6, fill / 1e6, fl / 1e9, (double)sk / nf, (double)sb / nf);
+                         "GF=%.2f avg_k=%.0f avg_b=%.0f schurGF=%.2f k2bGF=%.2f\n", h, nf, L.max_k, L.max_m, L.max_b,
+                         L.nr_panel, solve_elems * 8 / 1e6, fill / 1e6, fl / 1e9, (double)sk / nf, (double)sb / nf,
+                         g_schur / 1e9, g_k2b / 1e9);
         }
     }
 
