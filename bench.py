@@ -241,9 +241,21 @@ def main(argv=None):
     shard = None
     if world > 1 and args.parallelism == "shard":
         from sanm_amd import dist as sdist
-        if args.dist_backend == "nccl" and not args.callback_allreduce:
-            # the library's own RCCL communicator: ncclAllReduce queued on the solver's stream
-            sdist.init_native_comm(api, rank, world)
+        native = args.dist_backend == "nccl" and not args.callback_allreduce
+        if native:
+            # the library's own RCCL communicator: ncclAllReduce queued on the solver's stream.  Should it fail to
+            # come up on ANY rank (RCCL not loadable from C++, ...), all ranks take the callback path together.
+            ok = 1
+            try:
+                sdist.init_native_comm(api, rank, world)
+            except Exception as e:  # noqa: BLE001
+                print(f"rank {rank}: library communicator unavailable ({e}); all-reduce through torch.distributed",
+                      file=sys.stderr, flush=True)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            native = bool(flag.item())
+        if native:
             fn = None
         else:
             fn = sdist.make_rccl_allreduce() if args.dist_backend == "nccl" else sdist.make_host_allreduce()

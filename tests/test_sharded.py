@@ -47,11 +47,11 @@ def _free_port():
     return p
 
 
-def _run(energy, young):
+def _run(energy, young, world=2):
     port = _free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, "-c", WORKER.format(root=ROOT, energy=energy, young=young)], env=env,
                                       cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
@@ -99,3 +99,12 @@ def test_single_rank_shard_runs_the_sharded_code_path():
     assert steps == ref.solver.get_nr_iter()
     assert np.array_equal(run.vertices(), ref.vertices())
     assert ncall[0] == steps * (1 + 1 + (12 - 1)) + 1
+
+
+def test_four_rank_tet_shard_matches_single_rank():
+    """the same with the tets in four ranges (one all-reduce per order sums four partial nodal vectors)"""
+    res = _run("neohookean_c", 3e3, world=4)
+    assert len(res) == 4
+    for r in res:
+        assert r["steps"] == r["ref_steps"] and r["err"] < 1e-9 and r["rms"] < 1e-10
+        assert r["ncall"] == r["steps"] * (1 + 1 + (12 - 1)) + 1
