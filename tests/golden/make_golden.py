@@ -79,6 +79,11 @@ CASES = {
                                               "g": [0, 0, -9.81], "boundary_thresh": 0.1,
                                               "boundary_proj_dir": [1, 0, 0], "energy_model": "neohookean_c",
                                               "order": 8, "disable_pade": True}),
+    # Tikhonov path (config/override_l2_penalty.json: xcoeff_l2_penalty), sparse_solver.cpp:366-395
+    "cuboid_nc_l2": ((6, 3, 3), 0.025, {"material": {"young": 3e3, "poisson": 0.45, "density": 1000.0},
+                                        "g": [0, -9.81, 0], "boundary_thresh": 0.05,
+                                        "boundary_proj_dir": [-1, 0, 0], "energy_model": "neohookean_c", "order": 10,
+                                        "xcoeff_l2_penalty": 1e-6}),
 }
 
 

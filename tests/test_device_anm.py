@@ -30,7 +30,7 @@ def _run_device(api, dims, spacing, cfg, **over):
     return run
 
 
-@pytest.mark.parametrize("name", ["cuboid_nc", "cuboid_ni", "cuboid_arap", "cuboid_nc_nopade_o8"])
+@pytest.mark.parametrize("name", ["cuboid_nc", "cuboid_ni", "cuboid_arap", "cuboid_nc_nopade_o8", "cuboid_nc_l2"])
 def test_gravity_cuboid_vs_golden_and_oracle(api, name):
     gold = json.load(open(os.path.join(GOLD, f"anm_{name}.json")))
     run = _run_device(api, gold["dims"], gold["spacing"], gold["config"], profile=1)
