@@ -45,6 +45,8 @@ def parse(argv=None):
     p.add_argument("--profile", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-threads", type=int, default=None, help="CPU baseline threads (default min(32, cores))")
+    p.add_argument("--cpu-baseline-only", action="store_true",
+                   help="print the cpu_baseline object alone (no GPU work); used for the 1-thread figure")
     p.add_argument("--cpu-seconds", type=float, default=20.0, help="stepping time of the CPU baseline sample")
     p.add_argument("--parallelism", default="shard", choices=["replicas", "shard"],
                    help="N>1: one tet-sharded problem with an RCCL all-reduce of b_k per Taylor order (strong "
@@ -98,6 +100,9 @@ def cpu_baseline(workload, budget_s=20.0, threads=None):
             "sample": f"{steps} ANM steps ({workload}, order {cfg.get('order', 20)}: whole solves from the rest "
                       f"state) in {t_step:.1f} s on {cores} threads of {avail} available (32 = the reference's "
                       f"sys-mt32 configuration); mesh-only setup {setup_s:.1f} s not counted",
+            # the keys the reference's stats json carries (fea/main.cpp:425-431; render/gen_table_figs.py:60-66)
+            "time_solve": t_step, "iter": steps, "threads": cores, "order": int(cfg.get("order", 20)),
+            "pade": not cfg.get("disable_pade", False),
             "seconds_per_step": {k: round(prof.get(k, 0.0) / max(steps, 1), 4) for k in tags}}
 
 
@@ -218,8 +223,26 @@ def measure_families(run, one_step, cfg, stats, args, nsteps=2):
             "ms_step_wall_measured": wall_ms / max(k, 1)}
 
 
+def cpu_baseline_single_thread(workload, budget_s=8.0):
+    """the same baseline on ONE thread (the reference's sys-mt1.json), in a process of its own: the worker pool
+    and MKL's thread count are fixed when the host backend is created"""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-threads", "1",
+                            "--cpu-seconds", str(budget_s), "--workload", workload],
+                           capture_output=True, text=True, timeout=600, cwd=ROOT)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        d = json.loads(line)
+        return {"value": d["value"], "unit": d["unit"], "cores": 1, "sample": d["sample"]}
+    except Exception as e:  # noqa: BLE001 - a missing figure must not cost the bench line
+        return {"error": str(e)[:200]}
+
+
 def main(argv=None):
     args = parse(argv)
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args.workload, args.cpu_seconds, args.cpu_threads)), flush=True)
+        return None
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -371,6 +394,7 @@ def main(argv=None):
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds, args.cpu_threads)
             cb = out["cpu_baseline"]
             cb["gpu_over_cpu"] = out["value"] / cb["value"] if cb["value"] > 0 else None
+            cb["single_thread"] = cpu_baseline_single_thread(args.workload)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
