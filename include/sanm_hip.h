@@ -98,6 +98,9 @@ int sanm_direct_solver_stats(const sanm_direct_solver* s, int64_t* nnz_factors, 
 int sanm_taylor_create(const sanm_graph* g, int out_var, const sanm_sparse_desc* remap_inp,
                        int max_order, sanm_taylor_prop** prop);
 void sanm_taylor_destroy(sanm_taylor_prop* p);
+/* per-tet size of the output variable: 9 (a 3x3 matrix, what the ANM drivers need) or 3 (the singular values of
+ * batched_svd_w); the (T,3,3) / (T,9,9) shapes below read (T,size) / (T,size,9) */
+int sanm_taylor_output_size(const sanm_taylor_prop* p, int* size);
 /* push_xi (symbolic.cpp:162-204): x has remap_inp.in_size doubles; y_k (T,3,3) may be NULL */
 int sanm_taylor_push_xi(sanm_taylor_prop* p, const double* x, double* y_k);
 /* compute_next_order_bias (symbolic.cpp:249-289): bias (T,3,3) */

@@ -76,7 +76,7 @@ SYMBOLS = [
     "sanm_sparse_desc_set_out_coords", "sanm_direct_solver_create", "sanm_direct_solver_destroy",
     "sanm_direct_solver_factor", "sanm_direct_solver_solve", "sanm_direct_solver_stats",
     "sanm_taylor_create", "sanm_taylor_destroy", "sanm_taylor_push_xi",
-    "sanm_taylor_compute_next_order_bias", "sanm_taylor_get_jacobian", "sanm_taylor_get_var",
+    "sanm_taylor_compute_next_order_bias", "sanm_taylor_output_size", "sanm_taylor_get_jacobian", "sanm_taylor_get_var",
     "sanm_taylor_reset",
     "sanm_hyper_param_default", "sanm_anm_eqn_solver_create", "sanm_anm_eqn_solver_create_sharded",
     "sanm_anm_vecscale_solver_create",
@@ -421,6 +421,10 @@ class TaylorCoeffProp:
                                              C.byref(h)))
         self.h = h
         self._keep = (y.graph, remap_inp)
+        sz = C.c_int()
+        api.check(api.lib.sanm_taylor_output_size(h, C.byref(sz)))
+        self.out_size = sz.value
+        self.out_shape = (3, 3) if sz.value == 9 else (sz.value,)
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -429,17 +433,17 @@ class TaylorCoeffProp:
 
     def push_xi(self, x):
         x = _f64(x).ravel()
-        y = np.zeros((self.T, 3, 3))
+        y = np.zeros((self.T,) + self.out_shape)
         self.api.check(self.api.lib.sanm_taylor_push_xi(self.h, _dp(x), _dp(y)))
         return y
 
     def compute_next_order_bias(self):
-        b = np.zeros((self.T, 3, 3))
+        b = np.zeros((self.T,) + self.out_shape)
         self.api.check(self.api.lib.sanm_taylor_compute_next_order_bias(self.h, _dp(b)))
         return b
 
     def get_jacobian(self):
-        j = np.zeros((self.T, 9, 9))
+        j = np.zeros((self.T, self.out_size, 9))
         self.api.check(self.api.lib.sanm_taylor_get_jacobian(self.h, _dp(j)))
         return j
 

@@ -674,6 +674,7 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
         sanm_check(te > tb, "more ranks than tets");
     }
     m_prog = std::make_unique<Program>(be, g, out_var, te - tb, hp.order, tb, T, /*full_history=*/false);
+    sanm_check(m_prog->dev().odim == 9, "the ANM solvers take a graph whose output is a batched 3x3 matrix");
     m_prog->set_remap_in(remap_inp.in_size, remap_inp.rowptr.data(), remap_inp.idx.data(),
                          remap_inp.coef.data());
     m_remap_out = std::make_unique<DeviceRows>(be, remap_out, te - tb, m_prog->Tpad(), tb, te);

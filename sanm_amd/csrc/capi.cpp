@@ -295,11 +295,11 @@ int sanm_taylor_push_xi(sanm_taylor_prop* p, const double* x, double* y_k) {
             // the output is a local var; find its graph id through download of local index
             const ProgramDev d = p->prog->dev();
             const VarDesc& vd = p->prog->vars()[d.out_var];
-            std::vector<double> soa((size_t)9 * d.Tpad);
-            be->d2h(soa.data(), d.arena + vd.coef + (int64_t)p->order * 9 * d.Tpad,
-                    soa.size() * 8);
+            const int sz = vd.size;
+            std::vector<double> soa((size_t)sz * d.Tpad);
+            be->d2h(soa.data(), d.arena + vd.coef + (int64_t)p->order * sz * d.Tpad, soa.size() * 8);
             for (int64_t e = 0; e < d.T; ++e)
-                for (int c = 0; c < 9; ++c) y_k[e * 9 + c] = soa[c * d.Tpad + e];
+                for (int c = 0; c < sz; ++c) y_k[e * sz + c] = soa[c * d.Tpad + e];
         }
     });
 }
@@ -317,12 +317,17 @@ int sanm_taylor_compute_next_order_bias(sanm_taylor_prop* p, double* bias) {
         if (bias) {
             const ProgramDev d = p->prog->dev();
             const VarDesc& vd = p->prog->vars()[d.out_var];
-            std::vector<double> soa((size_t)9 * d.Tpad);
+            const int sz = vd.size;
+            std::vector<double> soa((size_t)sz * d.Tpad);
             be->d2h(soa.data(), d.arena + vd.bias, soa.size() * 8);
             for (int64_t e = 0; e < d.T; ++e)
-                for (int c = 0; c < 9; ++c) bias[e * 9 + c] = soa[c * d.Tpad + e];
+                for (int c = 0; c < sz; ++c) bias[e * sz + c] = soa[c * d.Tpad + e];
         }
     });
+}
+
+int sanm_taylor_output_size(const sanm_taylor_prop* p, int* size) {
+    return guard([&] { *size = p->prog->dev().odim; });
 }
 
 int sanm_taylor_get_jacobian(sanm_taylor_prop* p, double* jac) {

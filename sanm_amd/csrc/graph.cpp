@@ -231,7 +231,9 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
                nr_placeholder);
     const int lout = m_var_map[out_var];
     const int odim = m_vars[lout].size;
-    sanm_check(odim == 9, "the graph output must be a batched 3x3 matrix");
+    // (3: the singular values of batched_svd_w as the output, for the operator-level API; the ANM drivers need the
+    // 3x3 form and check it through their remap_out)
+    sanm_check(odim == 9 || odim == 3, "the graph output must be a batched 3x3 matrix (or a batched 3-vector)");
     sanm_check(!m_vars[lout].is_const, "the output does not depend on the input");
 
     // arena layout
@@ -262,9 +264,14 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
             case OP_DET:
                 if (!lv(0).is_const) lv(0).hist = 1;
                 break;
-            case OP_SVDW:
-                if (!lv(0).is_const) lv(0).hist = m_vars[m_var_map[op.out[2]]].hist = 1;
+            case OP_SVDW: {
+                if (lv(0).is_const) break;
+                const int lu = m_var_map[op.out[0]], ls = m_var_map[op.out[1]], lw = m_var_map[op.out[2]];
+                const bool full = nr_reader[lu] || nr_reader[ls] || lout == lu || lout == ls;
+                if (full) m_vars[lu].hist = m_vars[ls].hist = m_vars[lw].hist = 1;  // the U, S, W recurrences
+                else lv(0).hist = m_vars[lw].hist = 1;                               // polar mode: M and W
                 break;
+            }
             default:
                 break;
         }
@@ -369,10 +376,12 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
         if (op.type == OP_LINCOMB || op.type == OP_MULTIPLY || op.type == OP_LOG || op.type == OP_POW ||
             op.type == OP_REDUCE_SUM) {
             // the device bodies of the elementwise operators exist for these sizes only (tet_ops.h)
-            bool ok = osz == 1 || osz == 9;
-            for (int i = 0; i < o.nin; ++i) ok = ok && (m_vars[o.in[i]].size == 1 || m_vars[o.in[i]].size == 9);
+            auto sized = [](int sz) { return sz == 1 || sz == 3 || sz == 9; };
+            bool ok = sized(osz);
+            for (int i = 0; i < o.nin; ++i) ok = ok && sized(m_vars[o.in[i]].size);
             if (!ok)
-                sanm_throw(SANM_ERR_UNSUPPORTED, "elementwise operators take 3x3 matrices and batched scalars only");
+                sanm_throw(SANM_ERR_UNSUPPORTED,
+                           "elementwise operators take 3x3 matrices, 3-vectors and batched scalars only");
         }
         switch (op.type) {
             case OP_LINCOMB:
@@ -409,19 +418,25 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
                 o.aux[2] = take((int64_t)(N + 1) * 3 * Tpad);
                 o.aux[3] = take(3 * Tpad);
                 break;
-            case OP_SVDW:
-                // pw_mode only (oprs/linalg.cpp:533): U and S must have no reader
-                if (nr_reader[o.out[0]] || nr_reader[o.out[1]] || lout == o.out[0] ||
-                    lout == o.out[1]) {
-                    sanm_throw(SANM_ERR_UNSUPPORTED,
-                               "batched_svd_w: only the W output may be read on the device path "
-                               "(polar-decomposition mode)");
+            case OP_SVDW: {
+                // pw_mode (oprs/linalg.cpp:533) when U and S have no reader; the full recurrences otherwise
+                const bool full = nr_reader[o.out[0]] || nr_reader[o.out[1]] || lout == o.out[0] || lout == o.out[1];
+                if (nr_reader[o.out[0]] || lout == o.out[0]) o.flags |= OP_FLAG_SVDW_GU;
+                if (nr_reader[o.out[1]] || lout == o.out[1]) o.flags |= OP_FLAG_SVDW_GS;
+                if (nr_reader[o.out[2]] || lout == o.out[2]) o.flags |= OP_FLAG_SVDW_GW;
+                if (full) {
+                    o.flags |= OP_FLAG_SVDW_FULL;
+                    o.aux[0] = take((int64_t)(N + 1) * 9 * Tpad);  // T0_i = sum_j U_j diag(S_{i-j})
+                    o.aux[1] = take((int64_t)(N + 1) * 9 * Tpad);  // T1_i = sum_j T0_j U_{i-j}'
+                    o.aux[2] = take(45 * Tpad);                    // Bu, Bw, Mbias_k, partial T0_k, partial T1_k
+                } else {
+                    o.aux[0] = take((int64_t)(N + 1) * 9 * Tpad);
+                    o.aux[1] = take(9 * Tpad);
+                    o.aux[2] = take(9 * Tpad);
+                    o.aux[3] = take(9 * Tpad);
                 }
-                o.aux[0] = take((int64_t)(N + 1) * 9 * Tpad);
-                o.aux[1] = take(9 * Tpad);
-                o.aux[2] = take(9 * Tpad);
-                o.aux[3] = take(9 * Tpad);
                 break;
+            }
             default:
                 break;
         }
@@ -519,21 +534,21 @@ __device__ __forceinline__ void spec_body(const ProgramDev& P, int order, const 
     const int64_t tet = (int64_t)blockIdx.x * 64 + lane;
     if (tet >= P.T) return;
     double* cur = cur_lds + lane;
-    TetCtx c{P.arena, kVars, kTpad, tet, MODE == PASS_GRAD ? (int)blockIdx.y : order, 9, cur, 64, kOutVar, part, nparts,
+    TetCtx c{P.arena, kVars, kTpad, tet, MODE == PASS_GRAD ? (int)blockIdx.y : order, kVars[kOutVar].size, cur, 64, kOutVar, part, nparts,
              cur_lds + (int64_t)kCurSize * 64 + lane};
     c.out = P.arena + kOutAos;
     c.max_order = P.max_order;
     if (MODE == PASS_GRAD) {
         c.grow = blockIdx.y;
-        for (int e = 0; e < 9; ++e) cur[(int64_t)(kVars[kOutVar].cur + e) * 64] = (e == c.grow) ? 1.0 : 0.0;
+        for (int e = 0; e < kVars[kOutVar].size; ++e) cur[(int64_t)(kVars[kOutVar].cur + e) * 64] = (e == c.grow) ? 1.0 : 0.0;
 )SRC";
     for (int i = (int)m_ops.size() - 1; i >= 0; --i) add("        exec_op(c, kOps[%d], MODE, P.rin, xvec);\n", i);
     src += "    } else {\n";
     for (size_t i = 0; i < m_ops.size(); ++i) add("        exec_op(c, kOps[%zu], MODE, P.rin, xvec);\n", i);
     src += R"SRC(        if (MODE == PASS_EVAL0) {
             double Y[9];
-            ld9(p_coef(c, kOutVar, 0), kTpad, Y);
-            st_out(c, 9, Y);
+            ld(p_coef(c, kOutVar, 0), kTpad, kVars[kOutVar].size, Y);
+            st_out(c, kVars[kOutVar].size, Y);
         }
     }
 }

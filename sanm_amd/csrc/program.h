@@ -50,6 +50,10 @@ enum PassMode : int32_t {
 constexpr int OP_FLAG_IS_LEFT = 1;         // MATINVMUL: Y X = A
 constexpr int OP_FLAG_USE_IDENTITY = 2;    // MATINVMUL: A = I
 constexpr int OP_FLAG_REQUIRE_ROT = 4;     // SVDW: force det(W) = +1
+constexpr int OP_FLAG_SVDW_FULL = 8;       // SVDW: U or S is read: the full U, S, W recurrences (oprs/linalg.cpp:533)
+constexpr int OP_FLAG_SVDW_GU = 16;        // SVDW, reverse sweep: the gradient slot of U / S / W is live (the output
+constexpr int OP_FLAG_SVDW_GS = 32;        // has a reader or is the graph output)
+constexpr int OP_FLAG_SVDW_GW = 64;
 constexpr int MAX_OP_IN = 4;
 
 struct VarDesc {

@@ -320,6 +320,40 @@ SANM_HD_NOINLINE void svdw_fwd_p3(const double* Mk, const double* U0, const doub
     mm3<false, false, false>(Wk, X, T1);
 }
 
+// order-k terms U_k, S_k, W_k of M = U S U' W (tensor_svd.cpp:275-387), on the logical (row-major) matrices.
+//   E = V0' (Mk - Mb)' U0;  X_ij = clip_div(E_ji - E_ij - (V0' Bw V0)_ij s_j, s_i + s_j);  Wk = U0 X V0'
+//   E_ij += (Bu_ji - X_ji) s_j;  Sk = diag E;  K_ij = clip_div(E_ij, s_i - s_j) (i < j),
+//   K_ji = -Bu_ij - K_ij,  K_jj = -Bu_jj / 2;  Uk = U0 K'
+SANM_HD_NOINLINE void svdw_fwd_full3(const double* Mk, const double* Mb, const double* U0, const double* S0,
+                                     const double* W0, const double* Bu, const double* Bw, double* Uk, double* Sk,
+                                     double* Wk) {
+    double V0[9], D[9], T1[9], E[9], R[9], X[9];
+    mm3<true, false, false>(V0, W0, U0);
+    for (int i = 0; i < 9; ++i) D[i] = Mk[i] - Mb[i];
+    mm3<true, true, false>(T1, V0, D);
+    mm3<false, false, false>(E, T1, U0);
+    mm3<true, false, false>(T1, V0, Bw);
+    mm3<false, false, false>(R, T1, V0);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            X[i * 3 + j] = clip_div(E[j * 3 + i] - E[i * 3 + j] - R[i * 3 + j] * S0[j], S0[i] + S0[j]);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) D[i * 3 + j] = E[i * 3 + j] - X[j * 3 + i] * S0[j] + Bu[j * 3 + i] * S0[j];
+    mm3<false, false, false>(T1, U0, X);
+    mm3<false, true, false>(Wk, T1, V0);
+    double K[9];
+    for (int j = 0; j < 3; ++j) {
+        Sk[j] = D[j * 4];
+        for (int i = 0; i < j; ++i) {
+            double v = clip_div(D[i * 3 + j], S0[i] - S0[j]);
+            K[i * 3 + j] = v;
+            K[j * 3 + i] = -Bu[i * 3 + j] - v;
+        }
+        K[j * 4] = -0.5 * Bu[j * 4];
+    }
+    mm3<false, true, false>(Uk, U0, K);
+}
+
 // ----------------------------------------------------- operator bodies --
 // broadcast helper: value c of a var of size sz (scalar -> all elements)
 SANM_HD double bval(const double* p, int64_t s, int sz, int c) { return sz == 1 ? p[0] : p[c * s]; }
@@ -406,7 +440,8 @@ SANM_HD void op_lincomb_t(const TetCtx& c, const OpDesc& o, int mode) {
 SANM_HD void op_lincomb(const TetCtx& c, const OpDesc& o, int mode) {
     const int osz = c.vars[o.out[0]].size;
     if (osz == 9) op_lincomb_t<9>(c, o, mode);
-    else op_lincomb_t<1>(c, o, mode);  // graph.cpp admits sizes 1 and 9 only
+    else if (osz == 3) op_lincomb_t<3>(c, o, mode);
+    else op_lincomb_t<1>(c, o, mode);  // graph.cpp admits sizes 1, 3 and 9 only
 }
 
 // ---- MULTIPLY: elem_arith.cpp:128-217   aux0 = self_bias[osz]
@@ -486,6 +521,9 @@ SANM_HD void op_multiply(const TetCtx& c, const OpDesc& o, int mode) {
     if (asz == 9 && bsz == 9) op_multiply_t<9, 9>(c, o, mode);
     else if (asz == 1 && bsz == 9) op_multiply_t<1, 9>(c, o, mode);
     else if (asz == 9 && bsz == 1) op_multiply_t<9, 1>(c, o, mode);
+    else if (asz == 3 && bsz == 3) op_multiply_t<3, 3>(c, o, mode);
+    else if (asz == 1 && bsz == 3) op_multiply_t<1, 3>(c, o, mode);
+    else if (asz == 3 && bsz == 1) op_multiply_t<3, 1>(c, o, mode);
     else op_multiply_t<1, 1>(c, o, mode);
 }
 
@@ -594,6 +632,7 @@ SANM_HD void op_unary_t(const TetCtx& c, const OpDesc& o, int mode) {
 SANM_HD void op_unary(const TetCtx& c, const OpDesc& o, int mode) {
     const int sz = c.vars[o.out[0]].size;
     if (sz == 1) op_unary_t<1>(c, o, mode);
+    else if (sz == 3) op_unary_t<3>(c, o, mode);
     else op_unary_t<9>(c, o, mode);
 }
 
@@ -624,6 +663,7 @@ SANM_HD void op_reduce_t(const TetCtx& c, const OpDesc& o, int mode) {
 
 SANM_HD void op_reduce(const TetCtx& c, const OpDesc& o, int mode) {
     if (c.vars[o.in[0]].size == 9) op_reduce_t<9>(c, o, mode);
+    else if (c.vars[o.in[0]].size == 3) op_reduce_t<3>(c, o, mode);
     else op_reduce_t<1>(c, o, mode);
 }
 
@@ -933,9 +973,119 @@ SANM_HD void op_muleye(const TetCtx& c, const OpDesc& o, int mode) {
     else st_cur(c, ov, 9, Y, mode == PASS_COEFF);
 }
 
-// ---- SVDW (pw_mode): oprs/linalg.cpp:483-615, tensor_svd.cpp
-//      out = {U, S, W}; aux0 = P series [(N+1)][9] (P_0 unused),
-//      aux1 = Bm[9], aux2 = Bp[9], aux3 = Bpw[9]
+// ---- SVDW: oprs/linalg.cpp:483-615, tensor_svd.cpp.  out = {U, S, W}
+//      pw_mode (U and S unread, the ARAP graph): aux0 = P series [(N+1)][9] (P_0 unused), aux1 = Bm[9],
+//      aux2 = Bp[9], aux3 = Bpw[9].
+//      full mode (OP_FLAG_SVDW_FULL): aux0 = T0 series, T0_i = sum_j U_j diag(S_{i-j}); aux1 = T1 series,
+//      T1_i = sum_j T0_j U_{i-j}' (the reference rebuilds both from scratch at every order, linalg.cpp:42-62 and
+//      :570-590; they are kept here, one order added per COEFF pass); aux2 = {Bu, Bw, Mbias_k, t0k, t1k} with
+//      t0k / t1k the order-k terms of T0 / T1 without U_k, S_k.
+SANM_HD void op_svdw_full(const TetCtx& c, const OpDesc& o, int mode) {
+    const int64_t s = c.Tpad;
+    const int x = o.in[0], uv = o.out[0], sv = o.out[1], wv = o.out[2];
+    double U[9], S[3], W[9];
+    double* pT0 = p_aux(c, o.aux[0]);
+    double* pT1 = p_aux(c, o.aux[1]);
+    double* pB = p_aux(c, o.aux[2]);
+    ld9(p_coef(c, uv, 0), s, U);
+    ld(p_coef(c, sv, 0), s, 3, S);
+    ld9(p_coef(c, wv, 0), s, W);
+    if (mode == PASS_GRAD) {
+        // dU/dM, dS/dM, dW/dM chained with the upstream Jacobians (tensor_svd.cpp:147-273): with V = W' U,
+        //   gM_r += U Z V',  Z = Z_W + diag(gS_r) + Z_U,
+        //   Z_W[i,j] = clip_div(G_ij - G_ji, s_i + s_j),            G = U' gW_r V
+        //   Z_U[i,j] = clip_div((H_ij - H_ji) s_j, s_j^2 - s_i^2),  H = U' gU_r          (i != j)
+        if (c.vars[x].is_const) return;
+        double V[9], G[9], Tm[9], Z[9];
+        mm3<true, false, false>(V, W, U);
+        for (int e = 0; e < 9; ++e) Z[e] = 0;
+        if (o.flags & OP_FLAG_SVDW_GW) {
+            for (int e = 0; e < 9; ++e) G[e] = jget(c, wv, c.grow, e);
+            mm3<true, false, false>(Tm, U, G);
+            mm3<false, false, false>(G, Tm, V);
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j)
+                    if (i != j) Z[i * 3 + j] += clip_div(G[i * 3 + j] - G[j * 3 + i], S[i] + S[j]);
+        }
+        if (o.flags & OP_FLAG_SVDW_GS)
+            for (int i = 0; i < 3; ++i) Z[i * 4] += jget(c, sv, c.grow, i);
+        if (o.flags & OP_FLAG_SVDW_GU) {
+            for (int e = 0; e < 9; ++e) Tm[e] = jget(c, uv, c.grow, e);
+            mm3<true, false, false>(G, U, Tm);
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j)
+                    if (i != j)
+                        Z[i * 3 + j] += clip_div((G[i * 3 + j] - G[j * 3 + i]) * S[j], S[j] * S[j] - S[i] * S[i]);
+        }
+        mm3<false, false, false>(Tm, U, Z);
+        mm3<false, true, false>(G, Tm, V);
+        for (int e = 0; e < 9; ++e) jadd(c, x, c.grow, e, G[e]);
+        return;
+    }
+    const bool in_coeff = mode == PASS_COEFF;
+    const int k = c.order;
+    double Bu[9], Bw[9], Mb[9], t0k[9], t1k[9], A[9], B[9], D[3];
+    if (!in_coeff) {
+        for (int e = 0; e < 9; ++e) Bu[e] = Bw[e] = Mb[e] = t0k[e] = t1k[e] = 0;
+        int lo, hi;
+        conv_range(c, lo, hi);
+        for (int i = lo; i < hi; ++i) {
+            ld9(p_coef(c, uv, i), s, A);
+            ld9(p_coef(c, uv, k - i), s, B);
+            mm3<true, false, true>(Bu, A, B);  // U_i' U_{k-i}
+            ld(p_coef(c, sv, k - i), s, 3, D);
+            for (int r = 0; r < 3; ++r)
+                for (int q = 0; q < 3; ++q) t0k[r * 3 + q] += A[r * 3 + q] * D[q];  // U_i diag(S_{k-i})
+            ld9(pT0 + (int64_t)i * 9 * s, s, A);
+            mm3<false, true, true>(t1k, A, B);  // T0_i U_{k-i}'
+            ld9(p_coef(c, wv, i), s, A);
+            ld9(p_coef(c, wv, k - i), s, B);
+            mm3<true, false, true>(Bw, A, B);  // W_i' W_{k-i}
+            ld9(pT1 + (int64_t)i * 9 * s, s, A);
+            mm3<false, false, true>(Mb, A, B);  // T1_i W_{k-i}
+        }
+        conv_reduce(c, Bu, 9);
+        conv_reduce(c, Bw, 9);
+        conv_reduce(c, t0k, 9);
+        conv_reduce(c, t1k, 9);
+        conv_reduce(c, Mb, 9);
+        if (c.part) return;
+        if (k > 1) {  // (order 1: every bias term is zero, linalg.cpp:556-568)
+            mm3<false, true, true>(t1k, t0k, U);  // the known part of T0_k times U_0'
+            mm3<false, false, true>(Mb, t1k, W);  // the known part of T1_k times W_0
+        }
+        st9(pB, s, Bu);
+        st9(pB + 9 * s, s, Bw);
+        st9(pB + 18 * s, s, Mb);
+        st9(pB + 27 * s, s, t0k);
+        st9(pB + 36 * s, s, t1k);
+    } else {
+        ld9(pB, s, Bu);
+        ld9(pB + 9 * s, s, Bw);
+        ld9(pB + 18 * s, s, Mb);
+    }
+    double M[9], Uk[9], Sk[3], Wk[9];
+    ld_cur(c, x, 9, M);
+    svdw_fwd_full3(M, Mb, U, S, W, Bu, Bw, Uk, Sk, Wk);
+    st_cur(c, uv, 9, Uk, in_coeff);
+    st_cur(c, sv, 3, Sk, in_coeff);
+    st_cur(c, wv, 9, Wk, in_coeff);
+    if (in_coeff && k < c.max_order) {
+        // T0_k = t0k + U_0 diag(S_k) + U_k diag(S_0);  T1_k = t1k + (T0_k - t0k) U_0' + T0_0 U_k'
+        ld9(pB + 27 * s, s, t0k);
+        ld9(pB + 36 * s, s, t1k);
+        for (int r = 0; r < 3; ++r)
+            for (int q = 0; q < 3; ++q) A[r * 3 + q] = U[r * 3 + q] * Sk[q] + Uk[r * 3 + q] * S[q];
+        mm3<false, true, true>(t1k, A, U);
+        for (int r = 0; r < 3; ++r)
+            for (int q = 0; q < 3; ++q) B[r * 3 + q] = U[r * 3 + q] * S[q];  // T0_0
+        mm3<false, true, true>(t1k, B, Uk);
+        for (int e = 0; e < 9; ++e) A[e] += t0k[e];
+        st9(pT0 + (int64_t)k * 9 * s, s, A);
+        st9(pT1 + (int64_t)k * 9 * s, s, t1k);
+    }
+}
+
 SANM_HD void op_svdw(const TetCtx& c, const OpDesc& o, int mode) {
     const int64_t s = c.Tpad;
     const int x = o.in[0], uv = o.out[0], sv = o.out[1], wv = o.out[2];
@@ -946,6 +1096,18 @@ SANM_HD void op_svdw(const TetCtx& c, const OpDesc& o, int mode) {
         st9(p_coef(c, uv, 0), s, U);
         st(p_coef(c, sv, 0), s, 3, S);
         st9(p_coef(c, wv, 0), s, W);
+        if (o.flags & OP_FLAG_SVDW_FULL) {
+            double T0[9], T1[9];
+            for (int r = 0; r < 3; ++r)
+                for (int q = 0; q < 3; ++q) T0[r * 3 + q] = U[r * 3 + q] * S[q];
+            mm3<false, true, false>(T1, T0, U);
+            st9(p_aux(c, o.aux[0]), s, T0);
+            st9(p_aux(c, o.aux[1]), s, T1);
+        }
+        return;
+    }
+    if (o.flags & OP_FLAG_SVDW_FULL) {
+        op_svdw_full(c, o, mode);
         return;
     }
     ld9(p_coef(c, uv, 0), s, U);
@@ -1044,7 +1206,7 @@ SANM_HD void op_placeholder(const TetCtx& c, const OpDesc& o, int mode, const Re
         // the end of the reverse sweep: row grow of d(out)/d(placeholder), what the assembly gathers
         // (tet-major [T][9][9]: the contributions to one Jacobian entry come from a few tets and from up to 9
         // entries of each; tet-major those share cache lines)
-        double* j = c.arena + c.vars[ov].jac + c.tet * 81 + c.grow * 9;
+        double* j = c.arena + c.vars[ov].jac + c.tet * (c.odim * 9) + c.grow * 9;
         for (int e = 0; e < 9; ++e) j[e] = jget(c, ov, c.grow, e);
         return;
     }
@@ -1120,8 +1282,8 @@ SANM_HD void exec_program_tet(const ProgramDev& P, int mode, int order, int64_t 
         for (int i = 0; i < P.nops; ++i) exec_op(c, P.ops[i], mode, P.rin, xvec);
         if (mode == PASS_EVAL0) {  // f(x0) for remap_out
             double Y[9];
-            ld9(p_coef(c, P.out_var, 0), P.Tpad, Y);
-            st_out(c, 9, Y);
+            ld(p_coef(c, P.out_var, 0), P.Tpad, P.odim, Y);
+            st_out(c, P.odim, Y);
         }
     }
 }

@@ -25,11 +25,13 @@ def _series(rng, T, N, near_identity=True, scale=0.3):
     return [x0] + [rng.standard_normal((T, 3, 3)) * scale for _ in range(N)]
 
 
-def _run_both(api, build, T=37, N=6, seed=0, near_identity=True, rtol=RTOL):
+def _run_both(api, build, T=37, N=6, seed=0, near_identity=True, rtol=RTOL, x0_base=None):
     """build(ops, X, const) -> output var, for ops in {oracle S, device A}."""
     rng = np.random.default_rng(seed)
     cvals = [np.eye(3)[None] + 0.1 * rng.standard_normal((T, 3, 3)), rng.uniform(0.5, 2.0, (T, 1))]
     xs = _series(rng, T, N, near_identity)
+    if x0_base is not None:
+        xs[0] = xs[0] - np.eye(3)[None] * near_identity + x0_base
     # oracle
     ocg = S.ComputingGraph()
     oy = build(S, S.placeholder(ocg), [S.constant(ocg, c) for c in cvals])
@@ -97,6 +99,38 @@ def test_svdw_polar(api):
     # polar decomposition rotation, incl. inverted inputs (det < 0 -> rotation fix)
     _run_both(api, lambda M, X, c: X - X.batched_svd_w(True)[2], N=6, rtol=1e-9)
     _run_both(api, lambda M, X, c: X.batched_svd_w(True)[2], N=3, near_identity=False, seed=3, rtol=1e-8)
+
+
+def _spread(T, seed=11):
+    """Order-0 matrices R1 diag(3, 2, 1) R2: well separated singular values, so that dU/dM (which divides by
+    s_j^2 - s_i^2, tensor_svd.cpp:236-262) is well conditioned and the comparison is not a test of clip_div."""
+    rng = np.random.default_rng(seed)
+    q1 = np.linalg.qr(rng.standard_normal((T, 3, 3)))[0]
+    q2 = np.linalg.qr(rng.standard_normal((T, 3, 3)))[0]
+    return q1 @ (np.diag([3.0, 2.0, 1.0])[None] * rng.uniform(0.9, 1.1, (T, 1, 1))) @ q2
+
+
+@pytest.mark.parametrize("case", ["U", "S", "USW", "S_vector_output", "U_only"])
+def test_svdw_full_mode(api, case):
+    """batched_svd_w with U or S read by other operators: the full U, S, W recurrences (oprs/linalg.cpp:533-600,
+    tensor_svd.cpp:275-387) and dU/dM, dS/dM (tensor_svd.cpp:147-273), which the FEA graphs never reach (the ARAP
+    energy reads W only) but the reference's operator tests do (tests/tensor.cpp:841-868, tests/oprs.cpp)."""
+    def build(M, X, c):
+        u, s, w = X.batched_svd_w(False)
+        # The columns of U are defined up to a sign (Eigen's JacobiSVD in the reference, LAPACK in the oracle, a
+        # one-sided Jacobi on the device); U enters through its elementwise square, which is not.
+        uu = u * u
+        if case == "U":  # U and W read
+            return uu.batched_matmul(w) + uu.batched_transpose()
+        if case == "S":  # S read through the 3-vector elementwise operators
+            return (s * s).reduce_sum(-1).batched_mul_eye(3).batched_matmul(w) + X
+        if case == "USW":  # all three outputs read
+            t = (s.log() * s).reduce_sum(-1)
+            return uu.batched_matmul(w) * t + c[1] * uu
+        if case == "S_vector_output":  # a (T, 3) output: Jacobian (T, 3, 9)
+            return M.linear_combine([(2.0, s), (0.5, s.pow(2))], 0.25)
+        return uu.batched_matmul(c[0])  # W unread: its gradient slot is dead (OP_FLAG_SVDW_GW clear)
+    _run_both(api, build, T=29, N=6, seed=5, near_identity=False, rtol=1e-9, x0_base=_spread(29))
 
 
 @pytest.mark.parametrize("energy", ["neohookean_c", "neohookean_i", "arap", "stvk_stretch"])
@@ -180,9 +214,8 @@ def test_unsupported_and_invalid_graphs(api):
         X.batched_det().batched_matmul(X)  # scalar into matmul
     with pytest.raises(A.SanmAssertionError):
         X.pow(0.0)
-    u, s, w = X.batched_svd_w(False)
-    with pytest.raises(A.SanmUnsupportedError):  # reading U is not on the device path
-        A.TaylorCoeffProp(api, u.batched_matmul(w), _identity_remap(api, 4), 3, 4)
+    with pytest.raises(A.SanmUnsupportedError):  # reduce on an axis other than the last one
+        X.reduce_sum(1)
 
 
 def test_host_poly_helpers(api):
