@@ -1556,16 +1556,21 @@ public:
         const int cnt = L.front_end - L.front_begin;
         const int rows = fwd ? L.max_m : L.max_k;
         const size_t lds = (size_t)(fwd ? L.max_k : L.max_m) * sizeof(double);
-        auto kern = fwd ? fwd_level_kernel<R, U> : bwd_level_kernel<R, U>;
+        const void* kern = fwd ? (const void*)fwd_level_kernel<R, U> : (const void*)bwd_level_kernel<R, U>;
         if (lds > 48 * 1024) {
             if (lds > (size_t)kSolveLdsMax)
                 sanm_throw(SANM_ERR_UNSUPPORTED,
                            "front of %d rows exceeds the LDS staging of the solve kernels", L.max_m);
-            HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          kSolveLdsMax));
+            HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, kSolveLdsMax));
         }
-        hipLaunchKernelGGL(kern, dim3((rows + 4 * R - 1) / (4 * R), cnt), dim3(256), lds, m_stream, mf,
-                           L.front_begin);
+        const dim3 grid((rows + 4 * R - 1) / (4 * R), cnt);
+        const MfFrontDev* lf = mf.lfronts + L.front_begin;
+        if (fwd)
+            hipLaunchKernelGGL((fwd_level_kernel<R, U>), grid, dim3(256), lds, m_stream, lf, mf.front_store,
+                               mf.inbox_store, mf.work, mf.work2, mf.upd_dst);
+        else
+            hipLaunchKernelGGL((bwd_level_kernel<R, U>), grid, dim3(256), lds, m_stream, lf, mf.front_store, mf.work,
+                               mf.work2, mf.bnd_idx);
     }
     void level_solve(bool fwd, const MfDev& mf, const MfSchedule::Level& L) {
         using namespace mfk;
@@ -1598,7 +1603,8 @@ public:
 #define SANM_FS(G, R)                                                                                          \
     if (g == G && rr == R) {                                                                                   \
         hipLaunchKernelGGL((fwd_level_sub_kernel<G, R>), dim3((L.max_m + 256 / G * R - 1) / (256 / G * R), cnt), \
-                           dim3(256), lds, m_stream, mf, L.front_begin);                                       \
+                           dim3(256), lds, m_stream, mf.lfronts + L.front_begin, mf.front_store, mf.inbox_store, \
+                           mf.work, mf.work2, mf.upd_dst);                                                     \
         return;                                                                                                \
     }
             SANM_FS(8, 1) SANM_FS(8, 2) SANM_FS(16, 1) SANM_FS(16, 2) SANM_FS(32, 1) SANM_FS(32, 2)

@@ -276,6 +276,14 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
                 break;
         }
     }
+    // a transpose whose input keeps its series is, for the fused convolution loop, a view of that series
+    for (auto& d : m_vars) d.alias = -1, d.pad_ = 0;
+    for (int oi : topo) {
+        const GraphOp& op = g.ops[oi];
+        if (op.type != OP_TRANSPOSE) continue;
+        const int li = m_var_map[op.in[0]], lo = m_var_map[op.out[0]];
+        if (!m_vars[lo].is_const && m_vars[li].hist && m_vars[li].alias < 0) m_vars[lo].alias = li;
+    }
     for (size_t i = 0; i < m_vars.size(); ++i) {
         VarDesc& d = m_vars[i];
         d.coef = take((int64_t)(d.hist ? N + 1 : 1) * d.size * Tpad);
@@ -353,6 +361,7 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
     std::vector<int> last_reader(m_vars.size(), -1);
     for (size_t pos = 0; pos < topo.size(); ++pos)
         for (int v : g.ops[topo[pos]].in) last_reader[m_var_map[v]] = pos;
+    int32_t conv_total = 0;
     for (size_t pos = 0; pos < topo.size(); ++pos) {
         const int oi = topo[pos];
         const GraphOp& op = g.ops[oi];
@@ -440,6 +449,22 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
             default:
                 break;
         }
+        // the operator's share of the fused convolution loop (tet_ops.h, conv_term)
+        o.conv_off = conv_total;
+        o.conv_n = 0;
+        if (!m_vars[o.out[0]].is_const) {
+            auto var_in = [&](int i) { return !m_vars[o.in[i]].is_const; };
+            switch (op.type) {
+                case OP_MULTIPLY: if (var_in(0) && var_in(1)) o.conv_n = osz; break;
+                case OP_LOG: case OP_POW: if (var_in(0)) o.conv_n = osz; break;
+                case OP_MATMUL: if (var_in(0) && var_in(1)) o.conv_n = 9; break;
+                case OP_MATINVMUL: if (var_in(0)) o.conv_n = 9; break;
+                case OP_DET: if (var_in(0)) o.conv_n = 4; break;
+                case OP_SVDW: if (var_in(0)) o.conv_n = (o.flags & OP_FLAG_SVDW_FULL) ? 45 : 27; break;
+                default: break;
+            }
+        }
+        conv_total += o.conv_n;
         m_ops.push_back(o);
     }
     m_arena_doubles = off;
@@ -485,6 +510,7 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
     m_dev.odim = odim;
     m_dev.max_order = N;
     m_dev.cur_size = cur_size;
+    m_dev.conv_total = conv_total;
     m_dev.T = T;
     m_dev.Tpad = Tpad;
     m_dev.out_aos = out_aos;
@@ -506,24 +532,37 @@ std::string Program::spec_source() const {
         std::snprintf(buf, sizeof(buf), fmt, a...);
         src += buf;
     };
+    // SANM_NO_CONV_FUSION: every operator walks the history itself, as in the interpreter kernels
+    const int conv_total = std::getenv("SANM_NO_CONV_FUSION") ? 0 : m_dev.conv_total;
+    add("#define SANM_CONV_MAX %d\n", std::max(conv_total, 1));
     src += "#include \"tet_ops.h\"\nusing namespace sanm_hip;\nnamespace {\n";
-    add("constexpr int kNops = %zu, kCurSize = %d, kOutVar = %d;\nconstexpr long long kTpad = %lld, kOutAos = %lld;\n",
-        m_ops.size(), (int)m_dev.cur_size, (int)m_dev.out_var, (long long)m_dev.Tpad, (long long)m_dev.out_aos);
+    add("constexpr int kNops = %zu, kCurSize = %d, kOutVar = %d, kConvTotal = %d;\nconstexpr long long kTpad = %lld, "
+        "kOutAos = %lld;\nconstexpr bool kNoOverlap = %s;\n",
+        m_ops.size(), (int)m_dev.cur_size, (int)m_dev.out_var, conv_total, (long long)m_dev.Tpad,
+        (long long)m_dev.out_aos, std::getenv("SANM_NO_COEFF_OVERLAP") ? "true" : "false");
     src += "#define SPEC_OPS { \\\n";
     for (const OpDesc& o : m_ops) {
         add("  {%d, %d, %d, %d, {%d, %d, %d, %d}, {%d, %d, %d}, %d, {", o.type, o.nin, o.nout, o.flags, o.in[0], o.in[1],
             o.in[2], o.in[3], o.out[0], o.out[1], o.out[2], o.grad_zero);
         for (int i = 0; i < MAX_OP_IN + 2; ++i) add("%a%s", o.p[i], i + 1 < MAX_OP_IN + 2 ? ", " : "}, {");
-        add("%lldLL, %lldLL, %lldLL, %lldLL}}, \\\n", (long long)o.aux[0], (long long)o.aux[1], (long long)o.aux[2],
-            (long long)o.aux[3]);
+        add("%lldLL, %lldLL, %lldLL, %lldLL}, %d, %d}, \\\n", (long long)o.aux[0], (long long)o.aux[1],
+            (long long)o.aux[2], (long long)o.aux[3], o.conv_off, o.conv_n);
     }
     src += "}\n#define SPEC_VARS { \\\n";
     for (const VarDesc& d : m_vars)
-        add("  {%lldLL, %lldLL, %lldLL, %d, %d, %d, %d}, \\\n", (long long)d.coef, (long long)d.bias, (long long)d.jac,
-            d.size, d.is_const, d.cur, d.hist);
+        add("  {%lldLL, %lldLL, %lldLL, %d, %d, %d, %d, %d, 0}, \\\n", (long long)d.coef, (long long)d.bias,
+            (long long)d.jac, d.size, d.is_const, d.cur, d.hist, d.alias);
+    src += "}\n#define SPEC_CONV_TERMS(I, J) { \\\n";
+    for (size_t i = 0; i < m_ops.size(); ++i)
+        if (m_ops[i].conv_n) add("  conv_term(c, kOps[%zu], I, J, conv); \\\n", i);
+    src += "}\n#define SPEC_CONV_REDUCE { \\\n";
+    for (size_t i = 0; i < m_ops.size(); ++i)
+        for (int e = 0; e < m_ops[i].conv_n; e += 9)  // chunks of the exchange buffer's 9 slots
+            add("  conv_reduce(c, conv + %d, %d); \\\n", m_ops[i].conv_off + e, std::min(9, m_ops[i].conv_n - e));
     src += "}\n";
     src += R"SRC(
-template <int MODE>
+// AFTER_COEFF: BIAS(order) in the launch that ran COEFF(order - 1) on wavefront 0 (spec_pass4)
+template <int MODE, bool AFTER_COEFF = false>
 __device__ __forceinline__ void spec_body(const ProgramDev& P, int order, const double* __restrict__ xvec) {
     extern __shared__ double cur_lds[];
     static constexpr OpDesc kOps[] = SPEC_OPS;
@@ -543,7 +582,46 @@ __device__ __forceinline__ void spec_body(const ProgramDev& P, int order, const 
         for (int e = 0; e < kVars[kOutVar].size; ++e) cur[(int64_t)(kVars[kOutVar].cur + e) * 64] = (e == c.grow) ? 1.0 : 0.0;
 )SRC";
     for (int i = (int)m_ops.size() - 1; i >= 0; --i) add("        exec_op(c, kOps[%d], MODE, P.rin, xvec);\n", i);
-    src += "    } else {\n";
+    src += R"SRC(    } else {
+        // BIAS: the convolution sums of all operators in one loop over the history, both orientations of a pair
+        // (i, k - i) in one body (tet_ops.h, conv_term); the middle term of an even order goes to the last wavefront
+        if (MODE == PASS_BIAS && kConvTotal > 0) {
+            double* const conv = c.conv;
+            for (int e = 0; e < kConvTotal; ++e) conv[e] = 0.0;
+            const int k = order, npair = (k - 1) / 2;
+            const bool mid = k >= 2 && !(k & 1);
+            if (AFTER_COEFF && nparts > 1) {
+                // Only the pair (1, k - 1) (and the middle term of order 2) reads the coefficient wavefront 0 has
+                // just computed: it takes that pair when it gets here, the helper wavefronts share the pairs
+                // 2 .. npair -- history only -- and run them WHILE wavefront 0 is busy with COEFF(k - 1).
+                if (part == 0) {
+                    if (npair >= 1) {
+                        SPEC_CONV_TERMS(1, k - 1)
+                        SPEC_CONV_TERMS(k - 1, 1)
+                    }
+                    if (k == 2) SPEC_CONV_TERMS(1, 1)
+                } else {
+                    const int n2 = npair > 1 ? npair - 1 : 0, np = nparts - 1, q = part - 1;
+                    const int lo = 2 + n2 * q / np, hi = 2 + n2 * (q + 1) / np;
+                    for (int i = lo; i < hi; ++i) {
+                        SPEC_CONV_TERMS(i, k - i)
+                        SPEC_CONV_TERMS(k - i, i)
+                    }
+                    if (mid && k >= 4 && part == nparts - 1) SPEC_CONV_TERMS(k / 2, k / 2)
+                }
+            } else {
+                const int lo = 1 + npair * part / nparts, hi = 1 + npair * (part + 1) / nparts;
+                for (int i = lo; i < hi; ++i) {
+                    SPEC_CONV_TERMS(i, k - i)
+                    SPEC_CONV_TERMS(k - i, i)
+                }
+                if (mid && part == nparts - 1) SPEC_CONV_TERMS(k / 2, k / 2)
+            }
+            SPEC_CONV_REDUCE
+            if (part) return;
+            c.has_conv = true;
+        }
+)SRC";
     for (size_t i = 0; i < m_ops.size(); ++i) add("        exec_op(c, kOps[%zu], MODE, P.rin, xvec);\n", i);
     src += R"SRC(        if (MODE == PASS_EVAL0) {
             double Y[9];
@@ -565,10 +643,15 @@ extern "C" __global__ void __launch_bounds__(256, 3) spec_pass2(ProgramDev P, in
 // COEFF(order) by wavefront 0 of every workgroup, then BIAS(order + 1) by all of them (PASS_COEFF_BIAS)
 extern "C" __global__ void __launch_bounds__(256, 3) spec_pass4(ProgramDev P, int order, const double* xvec) {
     if ((threadIdx.x >> 6) == 0) spec_body<PASS_COEFF>(P, order, xvec);
-    // the coefficients just stored are history for the other wavefronts' slices of the convolutions
+    // the coefficients just stored are history for the convolutions
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    spec_body<PASS_BIAS>(P, order + 1, xvec);
+    if (kConvTotal > 0 && !kNoOverlap) {
+        // (read back by wavefront 0 alone: no barrier, the helper wavefronts are already in their history-only pairs)
+        spec_body<PASS_BIAS, true>(P, order + 1, xvec);
+    } else {
+        __syncthreads();
+        spec_body<PASS_BIAS>(P, order + 1, xvec);
+    }
 }
 extern "C" __global__ void __launch_bounds__(256, 1) spec_pass3(ProgramDev P, int order, const double* xvec) {
     spec_body<PASS_COEFF>(P, order, xvec);

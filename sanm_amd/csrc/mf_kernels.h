@@ -684,9 +684,25 @@ __device__ __forceinline__ double inbox_sum(const double* __restrict__ inbox, in
     return v;
 }
 
+// (The solve kernels take their pointers as separate scalar arguments, not the MfDev record by value: built with
+// -amdgpu-kernarg-preload-count the first 14 argument dwords are in SGPRs when a wavefront starts, and the
+// descriptor load below is the first memory round trip of the launch instead of the second.)
+struct SolveArgs {  // what the bodies below call mf.*
+    const MfFrontDev* lfronts;
+    const double* front_store;
+    double* inbox_store;
+    double* work;
+    double* work2;
+    const int32_t* upd_dst;
+    const int32_t* bnd_idx;
+};
 template <int R, int U>
-__global__ void __launch_bounds__(256) fwd_level_kernel(MfDev mf, int level_begin) {
-    const MfFrontDev f = mf.lfronts[level_begin + blockIdx.y];
+__global__ void __launch_bounds__(256) fwd_level_kernel(const MfFrontDev* __restrict__ lfronts,
+                                                        const double* __restrict__ front_store, double* inbox_store,
+                                                        double* work, double* work2,
+                                                        const int32_t* __restrict__ upd_dst) {
+    const SolveArgs mf{lfronts, front_store, inbox_store, work, work2, upd_dst, nullptr};
+    const MfFrontDev f = mf.lfronts[blockIdx.y];
     const int m = f.m, k = f.k;
     const int rb = blockIdx.x * (4 * R);
     if (rb >= m) return;
@@ -741,8 +757,12 @@ __global__ void __launch_bounds__(256) fwd_level_kernel(MfDev mf, int level_begi
 // fronts with a few dozen pivots and a boundary several times that: with one row per wavefront they are
 // thousands of workgroups of mostly idle lanes and the launch is bound by dispatch.
 template <int G, int R>
-__global__ void __launch_bounds__(256) fwd_level_sub_kernel(MfDev mf, int level_begin) {
-    const MfFrontDev f = mf.lfronts[level_begin + blockIdx.y];
+__global__ void __launch_bounds__(256) fwd_level_sub_kernel(const MfFrontDev* __restrict__ lfronts,
+                                                            const double* __restrict__ front_store,
+                                                            double* inbox_store, double* work, double* work2,
+                                                            const int32_t* __restrict__ upd_dst) {
+    const SolveArgs mf{lfronts, front_store, inbox_store, work, work2, upd_dst, nullptr};
+    const MfFrontDev f = mf.lfronts[blockIdx.y];
     const int m = f.m, k = f.k;
     constexpr int RPB = 256 / G * R;  // rows per workgroup: R per lane group
     const int rb = blockIdx.x * RPB;
@@ -799,8 +819,12 @@ __global__ void __launch_bounds__(256) fwd_level_sub_kernel(MfDev mf, int level_
 }
 
 template <int R, int U>
-__global__ void __launch_bounds__(256) bwd_level_kernel(MfDev mf, int level_begin) {
-    const MfFrontDev f = mf.lfronts[level_begin + blockIdx.y];
+__global__ void __launch_bounds__(256) bwd_level_kernel(const MfFrontDev* __restrict__ lfronts,
+                                                        const double* __restrict__ front_store, double* work,
+                                                        const double* __restrict__ work2,
+                                                        const int32_t* __restrict__ bnd_idx) {
+    const SolveArgs mf{lfronts, front_store, nullptr, work, const_cast<double*>(work2), nullptr, bnd_idx};
+    const MfFrontDev f = mf.lfronts[blockIdx.y];
     const int m = f.m, k = f.k;
     const int rb = blockIdx.x * (4 * R);
     if (rb >= k) return;

@@ -65,6 +65,9 @@ struct VarDesc {
     int32_t cur;       // offset (in doubles) of the current-order value in the per-lane scratch
     int32_t hist;      // coefficients of order >= 1 are kept in the arena: some convolution reads them back
                        // (or the program keeps every series for the operator-level API)
+    int32_t alias;     // >= 0: this variable is the batched_transpose of variable `alias`, whose series is kept: the
+                       // fused convolution loop reads that series (one load serves both); -1 otherwise
+    int32_t pad_;
 };
 
 struct OpDesc {
@@ -75,6 +78,9 @@ struct OpDesc {
                         // into the gradient slot of input i and clears it first
     double p[MAX_OP_IN + 2];  // LINCOMB: coeffs then bias at p[MAX_OP_IN]; POW: p[0]=exponent
     int64_t aux[4];           // arena offsets of per-operator scratch (see tet_ops.h)
+    // fused convolution loop of the kernels compiled per graph (tet_ops.h, conv_term): this operator's sums live at
+    // [conv_off, conv_off + conv_n) of the pass's accumulator array; conv_n = 0: the operator has no convolution
+    int32_t conv_off, conv_n;
 };
 
 // remap_in as an ELL table: for output element (tet e, comp c) and slot s,
@@ -95,6 +101,7 @@ struct ProgramDev {
     int32_t max_order;
     int32_t cur_size;  // doubles of per-lane scratch (sum of the sizes of the non-constant vars)
     int32_t desc_lines;  // 64-byte lines of the block holding ops and vars (a multiple of 8)
+    int32_t conv_total;  // accumulators of the fused convolution loop (sum of OpDesc::conv_n)
     int64_t T, Tpad;
     // the graph output as remap_out gathers it: tet-major [T][9] (order-0 value after EVAL0, order-k bias after
     // BIAS(k)).  A row of remap_out takes 3 entries of each adjacent tet and the 3 rows of a vertex the same tets:

@@ -36,6 +36,10 @@
 #define SANM_HD_NOINLINE inline
 #endif
 
+#ifndef SANM_CONV_MAX
+#define SANM_CONV_MAX 1
+#endif
+
 namespace sanm_hip {
 
 struct TetCtx {
@@ -63,6 +67,13 @@ struct TetCtx {
     int32_t grow = 0;
     double* out = nullptr;  // arena + ProgramDev::out_aos
     int32_t max_order = 0;
+    // BIAS pass of the kernels compiled per graph: the convolution sums of ALL operators, accumulated by one loop
+    // over the history (conv_term below) before the operators run; an operator then takes its sums from
+    // conv[OpDesc::conv_off ..] instead of walking the history itself.  false: every operator runs its own loop.
+    // (A member array, sized by the generated source through SANM_CONV_MAX, rather than a pointer to a local one:
+    // the accumulators must end up in registers, and a pointer kept in the context defeats that.)
+    bool has_conv = false;
+    double conv[SANM_CONV_MAX];
 };
 
 // slice [lo, hi) of the convolution index range 1 .. order-1 taken by this part
@@ -80,9 +91,13 @@ SANM_HD void conv_reduce(const TetCtx& c, double* v, int n) {
     if (c.part)
         for (int e = 0; e < n; ++e) c.red[((c.part - 1) * 9 + e) * 64] = v[e];
     __syncthreads();
-    if (!c.part)
-        for (int p = 1; p < c.nparts; ++p)
-            for (int e = 0; e < n; ++e) v[e] += c.red[((p - 1) * 9 + e) * 64];
+    if (!c.part) {
+        // (compile-time trip counts: v stays in registers; a workgroup has at most 4 wavefronts)
+#pragma unroll
+        for (int p = 1; p < 4; ++p)
+            if (p < c.nparts)
+                for (int e = 0; e < n; ++e) v[e] += c.red[((p - 1) * 9 + e) * 64];
+    }
 #else
     (void)c; (void)v; (void)n;
 #endif
@@ -481,7 +496,9 @@ SANM_HD void op_multiply_t(const TetCtx& c, const OpDesc& o, int mode) {
     if (!in_coeff) {
         double sb2[9];
         for (int e = 0; e < osz; ++e) sb[e] = sb2[e] = 0;
-        if (!c.vars[a].is_const && !c.vars[b].is_const) {
+        if (c.has_conv) {
+            for (int e = 0; e < osz; ++e) sb[e] = o.conv_n ? c.conv[o.conv_off + e] : 0.0;
+        } else if (!c.vars[a].is_const && !c.vars[b].is_const) {
             int i, hi;
             conv_range(c, i, hi);
             for (; i + 1 < hi; i += 2) {  // two independent terms in flight
@@ -594,17 +611,21 @@ SANM_HD void op_unary_t(const TetCtx& c, const OpDesc& o, int mode) {
         for (int e = 0; e < sz; ++e) sb[e] = 0;
         if (!c.vars[x].is_const) {
             const bool int2 = (!is_log && pw == 2.0);
-            int lo, hi;
-            conv_range(c, lo, hi);
-            for (int i = lo; i < hi; ++i) {
-                // log: x[k-i]*f[i]*(-i/k); pow: f[k-i]*x[i]*((i/k)(p+1)-1); pow 2: x[i]*x[k-i]
-                const double* p1 = int2 ? p_coef(c, x, i) : (is_log ? p_coef(c, x, k - i) : p_coef(c, ov, k - i));
-                const double* p2 = int2 ? p_coef(c, x, k - i) : (is_log ? p_coef(c, ov, i) : p_coef(c, x, i));
-                double w = int2 ? 1.0 : (is_log ? -(double)i / (double)k
-                                                : (double)i / (double)k * (pw + 1.0) - 1.0);
-                for (int e = 0; e < sz; ++e) sb[e] += p1[e * s] * p2[e * s] * w;
+            if (c.has_conv) {
+                for (int e = 0; e < sz; ++e) sb[e] = c.conv[o.conv_off + e];
+            } else {
+                int lo, hi;
+                conv_range(c, lo, hi);
+                for (int i = lo; i < hi; ++i) {
+                    // log: x[k-i]*f[i]*(-i/k); pow: f[k-i]*x[i]*((i/k)(p+1)-1); pow 2: x[i]*x[k-i]
+                    const double* p1 = int2 ? p_coef(c, x, i) : (is_log ? p_coef(c, x, k - i) : p_coef(c, ov, k - i));
+                    const double* p2 = int2 ? p_coef(c, x, k - i) : (is_log ? p_coef(c, ov, i) : p_coef(c, x, i));
+                    double w = int2 ? 1.0 : (is_log ? -(double)i / (double)k
+                                                    : (double)i / (double)k * (pw + 1.0) - 1.0);
+                    for (int e = 0; e < sz; ++e) sb[e] += p1[e * s] * p2[e * s] * w;
+                }
+                conv_reduce(c, sb, sz);
             }
-            conv_reduce(c, sb, sz);
             if (c.part) return;
             if (!int2) {
                 const double* x0 = p_coef(c, x, 0);
@@ -701,7 +722,9 @@ SANM_HD void op_matmul(const TetCtx& c, const OpDesc& o, int mode) {
     if (!in_coeff) {
         double R2[9], A2[9], B2[9];
         for (int e = 0; e < 9; ++e) R[e] = R2[e] = 0;
-        if (!c.vars[a].is_const && !c.vars[b].is_const) {
+        if (c.has_conv) {
+            for (int e = 0; e < 9; ++e) R[e] = o.conv_n ? c.conv[o.conv_off + e] : 0.0;
+        } else if (!c.vars[a].is_const && !c.vars[b].is_const) {
             int i, hi;
             conv_range(c, i, hi);
             for (; i + 1 < hi; i += 2) {
@@ -787,7 +810,9 @@ SANM_HD void op_matinvmul(const TetCtx& c, const OpDesc& o, int mode) {
     if (!in_coeff) {
         double R2[9], X2[9], Y2[9];
         for (int e = 0; e < 9; ++e) R[e] = R2[e] = 0;
-        if (!c.vars[x].is_const) {
+        if (c.has_conv) {
+            for (int e = 0; e < 9; ++e) R[e] = o.conv_n ? c.conv[o.conv_off + e] : 0.0;
+        } else if (!c.vars[x].is_const) {
             // sum_{i=1}^{k-1} Y_i X_{k-i} (left) or X_i Y_{k-i}; two terms in flight
             int i, hi;
             conv_range(c, i, hi);
@@ -821,7 +846,7 @@ SANM_HD void op_matinvmul(const TetCtx& c, const OpDesc& o, int mode) {
             }
         }
         for (int e = 0; e < 9; ++e) R[e] = -(R[e] + R2[e]);
-        if (!c.vars[x].is_const) conv_reduce(c, R, 9);
+        if (!c.has_conv && !c.vars[x].is_const) conv_reduce(c, R, 9);
         if (c.part) return;
         st9(psb, s, R);
     }
@@ -895,6 +920,10 @@ SANM_HD void op_det(const TetCtx& c, const OpDesc& o, int mode) {
         int lo, hi;
         conv_range(c, lo, hi);
         double ck[4] = {0, 0, 0, 0}, t[3];  // ck[3]: this part's share of sum_i r0_i . c_{k-i}
+        if (c.has_conv) {
+            for (int e = 0; e < 4; ++e) ck[e] = c.conv[o.conv_off + e];
+            lo = hi = 0;
+        }
         for (int j = lo; j < hi; ++j) {  // both sums in one sweep: their loads share a memory round trip
             double r0[3], r1[3], r2[3], cm[3];
             ld(p_coef(c, x, j), s, 3, r0);
@@ -907,7 +936,7 @@ SANM_HD void op_det(const TetCtx& c, const OpDesc& o, int mode) {
         }
         double x0[3];
         ld(p_coef(c, x, 0), s, 3, x0);
-        conv_reduce(c, ck, 4);
+        if (!c.has_conv) conv_reduce(c, ck, 4);
         if (c.part) return;
         st(pck, s, 3, ck);
         sb = x0[0] * ck[0] + x0[1] * ck[1] + x0[2] * ck[2] + ck[3];
@@ -1029,6 +1058,17 @@ SANM_HD void op_svdw_full(const TetCtx& c, const OpDesc& o, int mode) {
         for (int e = 0; e < 9; ++e) Bu[e] = Bw[e] = Mb[e] = t0k[e] = t1k[e] = 0;
         int lo, hi;
         conv_range(c, lo, hi);
+        if (c.has_conv) {
+            const double* q = c.conv + o.conv_off;
+            for (int e = 0; e < 9; ++e) {
+                Bu[e] = q[e];
+                Bw[e] = q[9 + e];
+                Mb[e] = q[18 + e];
+                t0k[e] = q[27 + e];
+                t1k[e] = q[36 + e];
+            }
+            lo = hi = 0;
+        }
         for (int i = lo; i < hi; ++i) {
             ld9(p_coef(c, uv, i), s, A);
             ld9(p_coef(c, uv, k - i), s, B);
@@ -1044,11 +1084,13 @@ SANM_HD void op_svdw_full(const TetCtx& c, const OpDesc& o, int mode) {
             ld9(pT1 + (int64_t)i * 9 * s, s, A);
             mm3<false, false, true>(Mb, A, B);  // T1_i W_{k-i}
         }
-        conv_reduce(c, Bu, 9);
-        conv_reduce(c, Bw, 9);
-        conv_reduce(c, t0k, 9);
-        conv_reduce(c, t1k, 9);
-        conv_reduce(c, Mb, 9);
+        if (!c.has_conv) {
+            conv_reduce(c, Bu, 9);
+            conv_reduce(c, Bw, 9);
+            conv_reduce(c, t0k, 9);
+            conv_reduce(c, t1k, 9);
+            conv_reduce(c, Mb, 9);
+        }
         if (c.part) return;
         if (k > 1) {  // (order 1: every bias term is zero, linalg.cpp:556-568)
             mm3<false, true, true>(t1k, t0k, U);  // the known part of T0_k times U_0'
@@ -1141,6 +1183,15 @@ SANM_HD void op_svdw(const TetCtx& c, const OpDesc& o, int mode) {
         for (int e = 0; e < 9; ++e) Bm[e] = Bp[e] = Bpw[e] = 0;
         int lo, hi;
         conv_range(c, lo, hi);
+        if (c.has_conv) {
+            const double* q = c.conv + o.conv_off;
+            for (int e = 0; e < 9; ++e) {
+                Bm[e] = q[e];
+                Bp[e] = q[9 + e];
+                Bpw[e] = q[18 + e];
+            }
+            lo = hi = 0;
+        }
         for (int i = lo; i < hi; ++i) {
             ld9(p_coef(c, x, i), s, A);
             ld9(p_coef(c, x, k - i), s, B);
@@ -1151,9 +1202,11 @@ SANM_HD void op_svdw(const TetCtx& c, const OpDesc& o, int mode) {
             ld9(p_coef(c, wv, k - i), s, B);
             mm3<false, false, true>(Bpw, A, B);  // P_i W_{k-i}
         }
-        conv_reduce(c, Bm, 9);
-        conv_reduce(c, Bp, 9);
-        conv_reduce(c, Bpw, 9);
+        if (!c.has_conv) {
+            conv_reduce(c, Bm, 9);
+            conv_reduce(c, Bp, 9);
+            conv_reduce(c, Bpw, 9);
+        }
         if (c.part) return;
         st9(p_aux(c, o.aux[1]), s, Bm);
         st9(p_aux(c, o.aux[2]), s, Bp);
@@ -1170,6 +1223,137 @@ SANM_HD void op_svdw(const TetCtx& c, const OpDesc& o, int mode) {
     if (in_coeff) st9(pP + (int64_t)k * 9 * s, s, Pk);
 }
 
+// ---- fused convolution loop (kernels compiled per graph) ----------------------------------------------------
+// Every operator above walks the history for its own sum_{i=1}^{k-1} A_i (x) B_{k-i}; between them the operators of
+// a graph read the same series several times (Neo-Hookean: F by the inverse, by the determinant's rows and by its
+// cross-product series; F^-1 by the inverse and, transposed, by the product with log J): 42 doubles per term where
+// the union is 23.  conv_term(o, i, j) adds operator o's term A_i (x) B_j to its accumulators; the generated pass
+// calls it for ALL operators with (i, k-i) and (k-i, i) in one loop body over i < k/2, so that the loads of both
+// orientations of every series sit in one basic block and the compiler merges the identical ones.
+template <int SZ>
+SANM_HD void ldh(const TetCtx& c, int v, int i, double* m) {
+    if constexpr (SZ == 9) {
+        const int a = c.vars[v].alias;
+        if (a >= 0) {  // the transpose of a kept series: read the source
+            const double* p = p_coef(c, a, i);
+            for (int r = 0; r < 3; ++r)
+                for (int q = 0; q < 3; ++q) m[r * 3 + q] = p[(q * 3 + r) * c.Tpad];
+            return;
+        }
+    }
+    ld(p_coef(c, v, i), c.Tpad, SZ, m);
+}
+template <int ASZ, int BSZ>
+SANM_HD void conv_term_multiply(const TetCtx& c, const OpDesc& o, int i, int j, double* acc) {
+    constexpr int osz = ASZ > BSZ ? ASZ : BSZ;
+    double A[ASZ], B[BSZ];
+    ldh<ASZ>(c, o.in[0], i, A);
+    ldh<BSZ>(c, o.in[1], j, B);
+    for (int e = 0; e < osz; ++e) acc[e] += A[ASZ == 1 ? 0 : e] * B[BSZ == 1 ? 0 : e];
+}
+template <int SZ>
+SANM_HD void conv_term_unary(const TetCtx& c, const OpDesc& o, int i, int j, double* acc) {
+    const int x = o.in[0], ov = o.out[0];
+    const double k = (double)c.order, pw = o.p[0];
+    double P1[SZ], P2[SZ];
+    double w = 1.0;
+    if (o.type == OP_LOG) {  // x_j f_i (-i/k)
+        ldh<SZ>(c, x, j, P1);
+        ldh<SZ>(c, ov, i, P2);
+        w = -(double)i / k;
+    } else if (pw == 2.0) {  // x_i x_j
+        ldh<SZ>(c, x, i, P1);
+        ldh<SZ>(c, x, j, P2);
+    } else {  // f_j x_i ((i/k)(p+1) - 1)
+        ldh<SZ>(c, ov, j, P1);
+        ldh<SZ>(c, x, i, P2);
+        w = (double)i / k * (pw + 1.0) - 1.0;
+    }
+    for (int e = 0; e < SZ; ++e) acc[e] += P1[e] * P2[e] * w;
+}
+SANM_HD void conv_term(const TetCtx& c, const OpDesc& o, int i, int j, double* acc) {
+    if (!o.conv_n) return;
+    acc += o.conv_off;
+    const int64_t s = c.Tpad;
+    double A[9], B[9];
+    switch (o.type) {
+        case OP_MULTIPLY: {
+            const int asz = c.vars[o.in[0]].size, bsz = c.vars[o.in[1]].size;
+            if (asz == 9 && bsz == 9) conv_term_multiply<9, 9>(c, o, i, j, acc);
+            else if (asz == 1 && bsz == 9) conv_term_multiply<1, 9>(c, o, i, j, acc);
+            else if (asz == 9 && bsz == 1) conv_term_multiply<9, 1>(c, o, i, j, acc);
+            else if (asz == 3 && bsz == 3) conv_term_multiply<3, 3>(c, o, i, j, acc);
+            else if (asz == 1 && bsz == 3) conv_term_multiply<1, 3>(c, o, i, j, acc);
+            else if (asz == 3 && bsz == 1) conv_term_multiply<3, 1>(c, o, i, j, acc);
+            else conv_term_multiply<1, 1>(c, o, i, j, acc);
+            break;
+        }
+        case OP_LOG:
+        case OP_POW: {
+            const int sz = c.vars[o.out[0]].size;
+            if (sz == 1) conv_term_unary<1>(c, o, i, j, acc);
+            else if (sz == 3) conv_term_unary<3>(c, o, i, j, acc);
+            else conv_term_unary<9>(c, o, i, j, acc);
+            break;
+        }
+        case OP_MATMUL:
+            ldh<9>(c, o.in[0], i, A);
+            ldh<9>(c, o.in[1], j, B);
+            mm3<false, false, true>(acc, A, B);
+            break;
+        case OP_MATINVMUL:  // Y_i X_j (left) or X_i Y_j; op_matinvmul negates the sum
+            if (o.flags & OP_FLAG_IS_LEFT) {
+                ldh<9>(c, o.out[0], i, A);
+                ldh<9>(c, o.in[0], j, B);
+            } else {
+                ldh<9>(c, o.in[0], i, A);
+                ldh<9>(c, o.out[0], j, B);
+            }
+            mm3<false, false, true>(acc, A, B);
+            break;
+        case OP_DET: {  // r1_i x r2_j and r0_i . c_j
+            double t[3], cm[3];
+            ldh<9>(c, o.in[0], i, A);  // (rows 0 and 1 are used; the unused loads fold away)
+            ldh<9>(c, o.in[0], j, B);  // row 2
+            ld(p_aux(c, o.aux[2]) + (int64_t)j * 3 * s, s, 3, cm);
+            cross3(A + 3, B + 6, t);
+            acc[0] += t[0]; acc[1] += t[1]; acc[2] += t[2];
+            acc[3] += A[0] * cm[0] + A[1] * cm[1] + A[2] * cm[2];
+            break;
+        }
+        case OP_SVDW: {
+            const int x = o.in[0], uv = o.out[0], sv = o.out[1], wv = o.out[2];
+            if (o.flags & OP_FLAG_SVDW_FULL) {  // {Bu, Bw, Mb, t0k, t1k}: see op_svdw_full
+                double D[3];
+                ldh<9>(c, uv, i, A);
+                ldh<9>(c, uv, j, B);
+                mm3<true, false, true>(acc, A, B);
+                ldh<3>(c, sv, j, D);
+                for (int r = 0; r < 3; ++r)
+                    for (int q = 0; q < 3; ++q) acc[27 + r * 3 + q] += A[r * 3 + q] * D[q];
+                ld9(p_aux(c, o.aux[0]) + (int64_t)i * 9 * s, s, A);
+                mm3<false, true, true>(acc + 36, A, B);
+                ldh<9>(c, wv, i, A);
+                ldh<9>(c, wv, j, B);
+                mm3<true, false, true>(acc + 9, A, B);
+                ld9(p_aux(c, o.aux[1]) + (int64_t)i * 9 * s, s, A);
+                mm3<false, false, true>(acc + 18, A, B);
+            } else {  // {Bm, Bp, Bpw}: see op_svdw
+                const double* pP = p_aux(c, o.aux[0]);
+                ldh<9>(c, x, i, A);
+                ldh<9>(c, x, j, B);
+                mm3<false, true, true>(acc, A, B);
+                ld9(pP + (int64_t)i * 9 * s, s, A);
+                ld9(pP + (int64_t)j * 9 * s, s, B);
+                mm3<true, false, true>(acc + 9, A, B);
+                ldh<9>(c, wv, j, B);
+                mm3<false, false, true>(acc + 18, A, B);
+            }
+            break;
+        }
+        default: break;
+    }
+}
 // ---- PLACEHOLDER: oprs/misc.cpp:13-44 fused with remap_in
 //      (SparseLinearDesc::apply, anm.cpp:55-75): coef[k] = gather of x_k.
 template <int NSLOT>

@@ -133,6 +133,34 @@ def test_svdw_full_mode(api, case):
     _run_both(api, build, T=29, N=6, seed=5, near_identity=False, rtol=1e-9, x0_base=_spread(29))
 
 
+_FUSED_CASES = {
+    "matmul": lambda M, X, c: X.batched_matmul(X.batched_transpose()).batched_matmul(X),
+    "matinvmul": lambda M, X, c: M.batched_mat_inv_mul(X, X.batched_matmul(c[0]), True)
+    + M.batched_mat_inv_mul(X, c[0], False),
+    # F read by the inverse, the determinant and (transposed: an alias of the inverse's series) the product
+    "neohookean_like": lambda M, X, c: X.batched_det().log() * M.batched_mat_inv_mul(X, None, True).batched_transpose()
+    + X.batched_det().pow(-2.0 / 3.0) * X,
+    "pow": lambda M, X, c: (X.batched_det().pow(-2.0 / 3.0) * X.pow(2).reduce_sum(-1)) * X + X.pow(3),
+    "svdw_polar": lambda M, X, c: X - X.batched_svd_w(True)[2],
+}
+
+
+@pytest.mark.parametrize("case", sorted(_FUSED_CASES) + ["svdw_full"])
+def test_compiled_kernels_with_fused_convolutions(api, monkeypatch, case):
+    """The kernels compiled per graph (forced here for a small batch) compute the convolution sums of all operators
+    in one loop over the history, pairs (i, k-i) in both orientations, before the operators run (tet_ops.h,
+    conv_term); odd and even orders, the middle term and the wavefront split are all covered by orders 1..7.
+    (On the host harness there is no run-time compiler: the shared bodies run as in the other tests.)"""
+    monkeypatch.setenv("SANM_JIT_MIN_T", "1")
+    if case == "svdw_full":
+        def build(M, X, c):
+            u, s, w = X.batched_svd_w(False)
+            return (u * u).batched_matmul(w) * (s.log() * s).reduce_sum(-1) + c[1] * (u * u)
+        _run_both(api, build, T=100, N=7, seed=5, near_identity=False, rtol=1e-9, x0_base=_spread(100))
+    else:
+        _run_both(api, _FUSED_CASES[case], T=100, N=7, seed=2, rtol=1e-9 if case == "svdw_polar" else 1e-10)
+
+
 @pytest.mark.parametrize("energy", ["neohookean_c", "neohookean_i", "arap", "stvk_stretch"])
 def test_pk1_graphs(api, energy):
     mat = ofea.Material(1e3, 0.45)
