@@ -555,10 +555,19 @@ struct GsRider {
 // remap_out with its rows in triples (SparseRowsDev::bptr): GATHER_LANES lanes per vertex, one list entry feeds the
 // three components (their values sit 3 doubles apart in the tet's block of the tet-major output buffer)
 template <int RIDE_NVT>
-__global__ void __launch_bounds__(256) gather_rows3_kernel(SparseRowsDev R, const double* __restrict__ src,
-                                                           double* __restrict__ dst,
+__global__ void __launch_bounds__(256) gather_rows3_kernel(const uint32_t* __restrict__ bptr_,
+                                                           const uint32_t* __restrict__ bidx_,
+                                                           const double* __restrict__ bcoef_,
+                                                           const double* __restrict__ src, double* __restrict__ dst,
                                                            const int32_t* __restrict__ perm,
-                                                           double* __restrict__ dst2, unsigned own, GsRider rd) {
+                                                           double* __restrict__ dst2, int64_t nrows_, unsigned own,
+                                                           GsRider rd) {
+    // (scalar pointer arguments first: kernarg preload, see mf_kernels.h)
+    const struct {
+        const uint32_t *bptr, *bidx;
+        const double* bcoef;
+        int64_t nrows;
+    } R{bptr_, bidx_, bcoef_, nrows_};
     if constexpr (RIDE_NVT > 0) {
         if (blockIdx.x >= own) {
             multi_dot_body<RIDE_NVT>(rd.n, rd.x, rd.q, rd.norm2, rd.nn2, rd.eps, rd.g, blockIdx.x - own, rd.nblk);
@@ -1219,11 +1228,14 @@ public:
         }
         if (P.spec_id >= 0 && lds <= 48 * 1024) {
             // this program's own kernels (same grid, same LDS layout as the interpreter's)
-            struct {
-                ProgramDev P;
-                int order;
+            struct {  // SPEC_PARAMS of the generated source (graph.cpp)
+                double* arena;
+                const uint32_t* rin_idx;
+                const double* rin_coef;
                 const double* xvec;
-            } args{P, order, xvec};
+                long long T;
+                int order, max_order, rin_nslot;
+            } args{P.arena, P.rin.idx, P.rin.coef, xvec, (long long)P.T, order, P.max_order, P.rin.nslot};
             size_t arg_size = sizeof(args);
             void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_size,
                               HIP_LAUNCH_PARAM_END};
@@ -1351,8 +1363,8 @@ public:
                 const GsRider rd = take_rider();
 #define SANM_G3(NVT)                                                                                                \
     case NVT:                                                                                                       \
-        hipLaunchKernelGGL(gather_rows3_kernel<NVT>, dim3(own + rd.nblk), dim3(256), 0, m_stream, R, src, dst, perm, \
-                           dst2, own, rd);                                                                          \
+        hipLaunchKernelGGL(gather_rows3_kernel<NVT>, dim3(own + rd.nblk), dim3(256), 0, m_stream, R.bptr, R.bidx,   \
+                           R.bcoef, src, dst, perm, dst2, R.nrows, own, rd);                                        \
         break;
                 switch (nvt) {
                     SANM_G3(4) SANM_G3(8) SANM_G3(12) SANM_G3(16) SANM_G3(20) SANM_G3(24)
@@ -1360,8 +1372,8 @@ public:
                 }
 #undef SANM_G3
             } else {
-                hipLaunchKernelGGL(gather_rows3_kernel<0>, dim3(own), dim3(256), 0, m_stream, R, src, dst, perm, dst2, own,
-                                   GsRider{});
+                hipLaunchKernelGGL(gather_rows3_kernel<0>, dim3(own), dim3(256), 0, m_stream, R.bptr, R.bidx, R.bcoef, src,
+                                   dst, perm, dst2, R.nrows, own, GsRider{});
             }
         } else
             hipLaunchKernelGGL(gather_rows_kernel, dim3(nblk((size_t)R.nrows * GATHER_LANES, 256)), dim3(256), 0,
@@ -1489,7 +1501,8 @@ public:
                 int64_t mb = L.ea_max_b[r];
                 if (cnt == 0 || mb == 0) continue;
                 hipLaunchKernelGGL(extend_add_kernel, dim3(nblk(mb * mb, 256), cnt), dim3(256), 0,
-                                   m_stream, mf, sch.ea_children + L.ea_rounds[r].first);
+                                   m_stream, mf.fronts, mf.front_store, mf.rel,
+                                   sch.ea_children + L.ea_rounds[r].first);
             }
             const int nt = (2 * L.max_k + NB - 1) / NB;  // pivot + augmentation block
             const int nfront = L.front_end - L.front_begin;
@@ -1499,39 +1512,43 @@ public:
                 // one blocking level.  Panel 0's diagonal tile is factored by diag_kernel; every later
                 // diagonal tile by the update kernel of the previous panel (look-ahead)
                 if (L.nr_panel > 0)
-                    hipLaunchKernelGGL(diag_kernel, dim3(L.panel_cnt[0]), dim3(256), 0, m_stream, mf,
-                                       L.front_begin, 0);
+                    hipLaunchKernelGGL(diag_kernel, dim3(L.panel_cnt[0]), dim3(256), 0, m_stream,
+                                       MF_FACTOR_ARGS(mf, L.front_begin), 0);
                 for (int p = 0; p < L.nr_panel; ++p) {
                     const int rem = nt - p - 1;
                     if (rem <= 0) continue;
-                    hipLaunchKernelGGL(update_kernel, dim3(rem, rem, L.panel_cnt[p]), dim3(256), 0, m_stream, mf,
-                                       L.front_begin, p, nt);
+                    hipLaunchKernelGGL(update_kernel, dim3(rem, rem, L.panel_cnt[p]), dim3(256), 0, m_stream,
+                                       MF_FACTOR_ARGS(mf, L.front_begin), p, nt);
                 }
                 if (L.nr_panel > 0)
                     hipLaunchKernelGGL(panel_finalize_kernel,
                                        dim3((atiles + FIN_TILES - 1) / FIN_TILES, 2, nfront * L.nr_panel),
-                                       dim3(256), 0, m_stream, mf, L.front_begin, 0, L.nr_panel, -1);
+                                       dim3(256), 0, m_stream,
+                                       MF_FACTOR_ARGS(mf, L.front_begin), 0, L.nr_panel, -1);
             } else {
                 // two blocking levels (mf_kernels.h, update_kernel): outer blocks of kOuterPanels panels
                 for (int p0 = 0; p0 < L.nr_panel; p0 += kOuterPanels) {
                     const int p1 = std::min(p0 + kOuterPanels, L.nr_panel), cnt0 = L.panel_cnt[p0];
-                    hipLaunchKernelGGL(diag_kernel, dim3(cnt0), dim3(256), 0, m_stream, mf, L.front_begin, p0);
+                    hipLaunchKernelGGL(diag_kernel, dim3(cnt0), dim3(256), 0, m_stream,
+                                       MF_FACTOR_ARGS(mf, L.front_begin), p0);
                     for (int p = p0; p < p1; ++p) {
                         const int w = p1 - p - 1, rem = nt - p - 1, rem2 = nt - p1;
                         if (w <= 0 || rem <= 0) continue;
                         hipLaunchKernelGGL(update_kernel, dim3(w, rem + std::max(rem2, 0), L.panel_cnt[p]),
-                                           dim3(256), 0, m_stream, mf, L.front_begin, p, p1);
+                                           dim3(256), 0, m_stream,
+                                       MF_FACTOR_ARGS(mf, L.front_begin), p, p1);
                     }
                     const int tiles = nt - p1;  // trailing extent beyond the block
                     // (a smaller front of the level may start its augmentation tiles before p1)
                     hipLaunchKernelGGL(panel_finalize_kernel,
                                        dim3((std::max(tiles, atiles) + FIN_TILES - 1) / FIN_TILES, 2,
                                             cnt0 * (p1 - p0)),
-                                       dim3(256), 0, m_stream, mf, L.front_begin, p0, p1 - p0, p1);
+                                       dim3(256), 0, m_stream,
+                                       MF_FACTOR_ARGS(mf, L.front_begin), p0, p1 - p0, p1);
                     if (tiles <= 0) continue;
                     const int gt = (tiles * NB + GT - 1) / GT;
-                    hipLaunchKernelGGL(block_gemm_kernel, dim3(gt, gt, cnt0), dim3(256), 0, m_stream, mf,
-                                       L.front_begin, p0, p1);
+                    hipLaunchKernelGGL(block_gemm_kernel, dim3(gt, gt, cnt0), dim3(256), 0, m_stream,
+                                       MF_FACTOR_ARGS(mf, L.front_begin), p0, p1);
                 }
             }
             // Schur complement and the boundary blocks of the solve operators: two GEMM passes
@@ -1539,10 +1556,24 @@ public:
                 const int nfr = L.front_end - L.front_begin;
                 const int tb = (L.max_b + GT - 1) / GT, tk = (L.max_k + GT - 1) / GT;
                 const int tmax = std::max(tb, tk);
-                hipLaunchKernelGGL(gemm1_kernel, dim3(tmax, tmax, 2 * nfr), dim3(256), 0, m_stream, mf,
-                                   L.front_begin);
-                hipLaunchKernelGGL(gemm2_kernel, dim3(tmax, tmax, 3 * nfr), dim3(256), 0, m_stream, mf,
-                                   L.front_begin);
+                hipLaunchKernelGGL(gemm1_kernel, dim3(tmax, tmax, 2 * nfr), dim3(256), 0, m_stream,
+                                   MF_FACTOR_ARGS(mf, L.front_begin));
+                hipLaunchKernelGGL(gemm2_kernel, dim3(tmax, tmax, 3 * nfr), dim3(256), 0, m_stream,
+                                   MF_FACTOR_ARGS(mf, L.front_begin));
+            }
+        }
+        if (sch.top.enabled) {  // the top of the tree as one dense operator (mf_kernels.h)
+            const auto& T = sch.top;
+            for (int st = 0; st < 2; ++st) {
+                const int cnt = T.stage_begin[st + 1] - T.stage_begin[st];
+                if (!cnt) continue;
+                const int tiles = (T.stage_dim[st] + GT - 1) / GT;
+                if (T.indexed)
+                    hipLaunchKernelGGL(top_gemm_kernel<true>, dim3(tiles, tiles, cnt), dim3(256), 0, m_stream,
+                                       T.gemms + T.stage_begin[st]);
+                else
+                    hipLaunchKernelGGL(top_gemm_kernel<false>, dim3(tiles, tiles, cnt), dim3(256), 0, m_stream,
+                                       T.gemms + T.stage_begin[st]);
             }
         }
         HIP_CHECK(hipGetLastError());
@@ -1598,7 +1629,8 @@ public:
             const size_t lds = (size_t)L.max_k * sizeof(double);
             // 2 rows per lane group once the level has enough rows to fill the chip several times over
             // (leaf level of the armadillo mesh: 13.4 / 11.5 / 17.5 us with 1 / 2 / 4 rows)
-            const int rr = L.sum_m >= 16 * 2048 ? 2 : 1;
+            static const int env_fs_r = std::getenv("SANM_MF_FS_R") ? std::atoi(std::getenv("SANM_MF_FS_R")) : 0;
+            const int rr = env_fs_r ? env_fs_r : (L.sum_m >= 16 * 2048 ? 2 : 1);
             const int g = width <= 32 ? 8 : (width <= 64 ? 16 : 32);
 #define SANM_FS(G, R)                                                                                          \
     if (g == G && rr == R) {                                                                                   \
@@ -1608,6 +1640,7 @@ public:
         return;                                                                                                \
     }
             SANM_FS(8, 1) SANM_FS(8, 2) SANM_FS(16, 1) SANM_FS(16, 2) SANM_FS(32, 1) SANM_FS(32, 2)
+            SANM_FS(8, 4) SANM_FS(16, 4) SANM_FS(32, 4)
 #undef SANM_FS
         }
         int u = 1;
@@ -1615,6 +1648,8 @@ public:
         // R * U <= 16 row chunks in registers, and enough workgroups to fill the chip (measured: more than
         // 4 rows per wavefront never paid, even on the leaf level)
         int r = rows >= 16 * 2048 ? 4 : (rows >= 8 * 2048 ? 2 : 1);
+        static const int env_ls_r = std::getenv("SANM_MF_LS_R") ? std::atoi(std::getenv("SANM_MF_LS_R")) : 0;
+        if (env_ls_r && rows >= 8 * 2048) r = env_ls_r;
         while (r * u > 16) r /= 2;
 #define SANM_LS(R, U)                         \
     if (r == R && u == U) {                   \
@@ -1637,8 +1672,29 @@ public:
         if (b)
             hipLaunchKernelGGL(permute_in_kernel, dim3(nblk(mf.n, 256)), dim3(256), 0, m_stream, mf.n,
                                mf.perm, b, mf.work);
-        for (size_t li = 0; li < sch.levels.size(); ++li) level_solve(true, mf, sch.levels[li]);
-        for (int li = (int)sch.levels.size() - 1; li >= 0; --li) level_solve(false, mf, sch.levels[li]);
+        const int nl = (int)sch.levels.size(), below = sch.top.enabled ? nl - 2 : nl;
+        for (int li = 0; li < below; ++li) level_solve(true, mf, sch.levels[li]);
+        if (sch.top.enabled) {
+            const auto& T = sch.top;
+            constexpr int R = 1;
+            const dim3 grid((T.n + 4 * R - 1) / (4 * R));
+            const size_t lds = (size_t)T.n * sizeof(double);
+#define SANM_TS(WW)                                                                                              \
+    case WW:                                                                                                     \
+        hipLaunchKernelGGL((top_solve_kernel<R, WW>), grid, dim3(256), lds, m_stream, T.M, T.wsrc, T.ell,         \
+                           mf.inbox_store, mf.work, mf.work + mf.n, T.n);                                        \
+        break;
+            switch (T.W) {
+                SANM_TS(2) SANM_TS(4) SANM_TS(6) SANM_TS(8)
+                default: sanm_throw(SANM_ERR_ASSERT, "merged top block: lists of %d slots", T.W);
+            }
+#undef SANM_TS
+        }
+        // (with the merged block its solution sits behind the n entries of work: redirected lists, mf_types.h)
+        MfDev mb = mf;
+        if (sch.top.enabled) mb.bnd_idx = sch.top.bnd_x;
+        const int32_t* perm_out = sch.top.enabled ? sch.top.perm_x : mf.perm;
+        for (int li = below - 1; li >= 0; --li) level_solve(false, mb, sch.levels[li]);
         if (dot_y) {
             const unsigned own = red_grid(mf.n);
             if (m_pending.kind == 2 && m_stream == m_main) {  // the update of a Gram-Schmidt step rides along
@@ -1646,7 +1702,7 @@ public:
                 const GsRider rd = take_rider();
 #define SANM_POD(NVT)                                                                                              \
     case NVT:                                                                                                      \
-        hipLaunchKernelGGL(permute_out_dot_kernel<NVT>, dim3(own + rd.nblk), dim3(256), 0, m_stream, mf.n, mf.perm, \
+        hipLaunchKernelGGL(permute_out_dot_kernel<NVT>, dim3(own + rd.nblk), dim3(256), 0, m_stream, mf.n, perm_out, \
                            mf.work, x, dot_y, red_to(dot_out), own, rd);                                           \
         break;
                 switch (nvt) {
@@ -1655,12 +1711,12 @@ public:
                 }
 #undef SANM_POD
             } else {
-                hipLaunchKernelGGL(permute_out_dot_kernel<0>, dim3(own), dim3(256), 0, m_stream, mf.n, mf.perm, mf.work, x,
+                hipLaunchKernelGGL(permute_out_dot_kernel<0>, dim3(own), dim3(256), 0, m_stream, mf.n, perm_out, mf.work, x,
                                    dot_y, red_to(dot_out), own, GsRider{});
             }
         } else
             hipLaunchKernelGGL(permute_out_kernel, dim3(nblk(mf.n, 256)), dim3(256), 0, m_stream, mf.n,
-                               mf.perm, mf.work, x);
+                               perm_out, mf.work, x);
         HIP_CHECK(hipGetLastError());
     }
 

@@ -631,17 +631,31 @@ __device__ __forceinline__ void spec_body(const ProgramDev& P, int order, const 
     }
 }
 }  // namespace
-extern "C" __global__ void __launch_bounds__(256, 1) spec_pass0(ProgramDev P, int order, const double* xvec) {
+// (scalar arguments, pointers first: with -amdgpu-kernarg-preload-count they are in SGPRs when a wavefront starts)
+#define SPEC_PARAMS                                                                                              \
+    double *arena, const uint32_t *__restrict__ rin_idx, const double *__restrict__ rin_coef, const double *xvec, \
+        long long T, int order, int max_order, int rin_nslot
+#define SPEC_P             \
+    ProgramDev P{};        \
+    P.arena = arena;       \
+    P.T = T;               \
+    P.max_order = max_order; \
+    P.rin = {rin_idx, rin_coef, rin_nslot};
+extern "C" __global__ void __launch_bounds__(256, 1) spec_pass0(SPEC_PARAMS) {
+    SPEC_P
     spec_body<PASS_EVAL0>(P, order, xvec);
 }
-extern "C" __global__ void __launch_bounds__(256, 1) spec_pass1(ProgramDev P, int order, const double* xvec) {
+extern "C" __global__ void __launch_bounds__(256, 1) spec_pass1(SPEC_PARAMS) {
+    SPEC_P
     spec_body<PASS_GRAD>(P, order, xvec);
 }
-extern "C" __global__ void __launch_bounds__(256, 3) spec_pass2(ProgramDev P, int order, const double* xvec) {
+extern "C" __global__ void __launch_bounds__(256, 3) spec_pass2(SPEC_PARAMS) {
+    SPEC_P
     spec_body<PASS_BIAS>(P, order, xvec);
 }
 // COEFF(order) by wavefront 0 of every workgroup, then BIAS(order + 1) by all of them (PASS_COEFF_BIAS)
-extern "C" __global__ void __launch_bounds__(256, 3) spec_pass4(ProgramDev P, int order, const double* xvec) {
+extern "C" __global__ void __launch_bounds__(256, 3) spec_pass4(SPEC_PARAMS) {
+    SPEC_P
     if ((threadIdx.x >> 6) == 0) spec_body<PASS_COEFF>(P, order, xvec);
     // the coefficients just stored are history for the convolutions
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -653,7 +667,8 @@ extern "C" __global__ void __launch_bounds__(256, 3) spec_pass4(ProgramDev P, in
         spec_body<PASS_BIAS>(P, order + 1, xvec);
     }
 }
-extern "C" __global__ void __launch_bounds__(256, 1) spec_pass3(ProgramDev P, int order, const double* xvec) {
+extern "C" __global__ void __launch_bounds__(256, 1) spec_pass3(SPEC_PARAMS) {
+    SPEC_P
     spec_body<PASS_COEFF>(P, order, xvec);
 }
 )SRC";

@@ -28,6 +28,23 @@ constexpr int NB = MF_NB;
 constexpr int TPAD = NB + 1;  // LDS row stride (odd: no bank conflicts on column access)
 typedef double mfma_f64x4 __attribute__((ext_vector_type(4)));
 
+// The factor kernels take their pointers as leading scalar arguments (kernarg preload, see SolveArgs below); the
+// descriptor pointer arrives already advanced to the level's first front.
+struct FactorArgs {
+    const MfFrontDev* lfronts;
+    double* front_store;
+    double* tmp_store;
+    int32_t* status;
+    const double* piv_amax;
+};
+#define MF_FACTOR_PARAMS                                                                                  \
+    const MfFrontDev *__restrict__ lfronts_, double *front_store_, double *tmp_store_, int32_t *status_, \
+        const double *__restrict__ piv_amax_
+#define MF_FACTOR_INIT                                                           \
+    const FactorArgs mf{lfronts_, front_store_, tmp_store_, status_, piv_amax_}; \
+    constexpr int level_begin = 0;
+#define MF_FACTOR_ARGS(mf, lb) (mf).lfronts + (lb), (mf).front_store, (mf).tmp_store, (mf).status, (mf).piv_amax
+
 __global__ void scatter_kernel(int64_t nnz, const int64_t* __restrict__ a_dst,
                                const double* __restrict__ val, double* __restrict__ store) {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -46,7 +63,14 @@ __global__ void aug_identity_kernel(MfDev mf) {
 }
 
 // parent[rel[i], rel[j]] += child_schur[i, j]; one child per blockIdx.y
-__global__ void __launch_bounds__(256) extend_add_kernel(MfDev mf, const int32_t* __restrict__ children) {
+__global__ void __launch_bounds__(256) extend_add_kernel(const MfFrontDev* __restrict__ fronts_, double* front_store_,
+                                                         const int32_t* __restrict__ rel_,
+                                                         const int32_t* __restrict__ children) {
+    const struct {
+        const MfFrontDev* fronts;
+        double* front_store;
+        const int32_t* rel;
+    } mf{fronts_, front_store_, rel_};
     const MfFrontDev c = mf.fronts[children[blockIdx.y]];
     const int nb = c.m - c.k;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -123,7 +147,8 @@ __device__ __forceinline__ void tile_factor(double (*T)[TPAD], int kb, int tid, 
 }
 
 // diagonal tile of panel p of every front of a level
-__global__ void __launch_bounds__(256) diag_kernel(MfDev mf, int level_begin, int p) {
+__global__ void __launch_bounds__(256) diag_kernel(MF_FACTOR_PARAMS, int p) {
+    MF_FACTOR_INIT
     const MfFrontDev f = mf.lfronts[level_begin + blockIdx.x];
     const int ld = f.ld, m = 2 * f.k, r0 = p * NB;  // m: extent of the pivot + augmentation block
     const int kb = min(NB, f.k - r0);
@@ -211,7 +236,8 @@ __device__ unsigned long long g_phase[8];
 #else
 #define SANM_PHASE_MARK(name)
 #endif
-__global__ void __launch_bounds__(256) update_kernel(MfDev mf, int level_begin, int p, int t_end) {
+__global__ void __launch_bounds__(256) update_kernel(MF_FACTOR_PARAMS, int p, int t_end) {
+    MF_FACTOR_INIT
     SANM_PHASE_MARK(c0);
     const MfFrontDev f = mf.lfronts[level_begin + blockIdx.z];
     const int ld = f.ld, m = 2 * f.k, nt = (m + NB - 1) / NB;
@@ -333,8 +359,9 @@ __global__ void __launch_bounds__(256) update_kernel(MfDev mf, int level_begin, 
 constexpr int FIN_TILES = 8;
 // (Two blocking levels: called per outer block [p_begin, p_begin + nr_panel) with t_min = its end: the tiles
 // from t_min on are exactly what block_gemm_kernel multiplies, and they include the augmentation tiles.)
-__global__ void __launch_bounds__(256) panel_finalize_kernel(MfDev mf, int level_begin, int p_begin, int nr_panel,
+__global__ void __launch_bounds__(256) panel_finalize_kernel(MF_FACTOR_PARAMS, int p_begin, int nr_panel,
                                                              int t_min) {
+    MF_FACTOR_INIT
     const MfFrontDev f = mf.lfronts[level_begin + blockIdx.z / nr_panel];
     const int p = p_begin + blockIdx.z % nr_panel;
     if (p * NB >= f.k) return;
@@ -408,16 +435,13 @@ __global__ void __launch_bounds__(256) panel_finalize_kernel(MfDev mf, int level
 // C/D: register g of lane l is C[(l>>4) + 4g][l&15]).  K advances in steps of 16 through LDS; the next
 // step's global loads are issued before the current step's MFMAs (register prefetch).  Element (i,j) of
 // an operand is p[i*ld + j] inside (rows, cols), else 0.  K range [k0, k1) in elements.
-struct MatView {
-    const double* p;
-    int ld, rows, cols;
-};
 constexpr int GT = 64;   // GEMM tile edge
 constexpr int GK = 16;   // GEMM K step
 
 struct GemmStage {
     double a[4], b[4];
 };
+template <bool IDX = false>
 __device__ __forceinline__ void gemm_stage_load(GemmStage& st, const MatView& A, const MatView& B, int ti,
                                                 int tj, int kk, int k1) {
     const int tid = threadIdx.x;
@@ -426,11 +450,21 @@ __device__ __forceinline__ void gemm_stage_load(GemmStage& st, const MatView& A,
         const int idx = tid + 256 * s;             // 0..1023
         const int ar = idx / GK, ae = idx % GK;    // consecutive threads along K: contiguous in a row of A
         int gr = ti * GT + ar, gc = kk + ae;
-        st.a[s] = (gr < A.rows && gc < A.cols && gc < k1) ? A.p[(int64_t)gr * A.ld + gc] : 0.0;
+        if (IDX) {  // A's columns through an index map (MatView::cidx)
+            const bool ok = gr < A.rows && gc < A.cols && gc < k1;
+            const int pc = (ok && A.cidx) ? A.cidx[gc] : gc;
+            st.a[s] = ok ? A.p[(int64_t)gr * A.ld + pc] : 0.0;
+        } else
+            st.a[s] = (gr < A.rows && gc < A.cols && gc < k1) ? A.p[(int64_t)gr * A.ld + gc] : 0.0;
         const int be = idx / GT, bc = idx % GT;    // consecutive threads along the columns of B
         gr = kk + be;
         gc = tj * GT + bc;
-        st.b[s] = (gr < B.rows && gr < k1 && gc < B.cols) ? B.p[(int64_t)gr * B.ld + gc] : 0.0;
+        if (IDX) {  // B's rows through an index map (MatView::ridx)
+            const bool ok = gr < B.rows && gr < k1 && gc < B.cols;
+            const int pr = (ok && B.ridx) ? B.ridx[gr] : gr;
+            st.b[s] = ok ? B.p[(int64_t)pr * B.ld + gc] : 0.0;
+        } else
+            st.b[s] = (gr < B.rows && gr < k1 && gc < B.cols) ? B.p[(int64_t)gr * B.ld + gc] : 0.0;
     }
 }
 __device__ __forceinline__ void gemm_stage_store(const GemmStage& st, double (*As)[GT + 1],
@@ -445,6 +479,7 @@ __device__ __forceinline__ void gemm_stage_store(const GemmStage& st, double (*A
 }
 
 // acc[mi][ni]: the 16x16 tile at rows 32*(wave>>1) + 16*mi, columns 32*(wave&1) + 16*ni of the 64x64 tile
+template <bool IDX = false>
 __device__ __forceinline__ void gemm_tile(const MatView& A, const MatView& B, int ti, int tj, int k0,
                                           int k1, double (*As)[GT + 1], double (*Bs)[GT + 4],
                                           mfma_f64x4 acc[2][2]) {
@@ -455,12 +490,12 @@ __device__ __forceinline__ void gemm_tile(const MatView& A, const MatView& B, in
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma_f64x4{0, 0, 0, 0};
     GemmStage st;
-    if (k0 < k1) gemm_stage_load(st, A, B, ti, tj, k0, k1);
+    if (k0 < k1) gemm_stage_load<IDX>(st, A, B, ti, tj, k0, k1);
     for (int kk = k0; kk < k1; kk += GK) {
         __syncthreads();  // the previous step's fragments have been read
         gemm_stage_store(st, As, Bs);
         __syncthreads();
-        if (kk + GK < k1) gemm_stage_load(st, A, B, ti, tj, kk + GK, k1);
+        if (kk + GK < k1) gemm_stage_load<IDX>(st, A, B, ti, tj, kk + GK, k1);
 #pragma unroll
         for (int e = 0; e < GK; e += 4) {
             const double a0 = As[e + kq][r0], a1 = As[e + kq][r0 + 16];
@@ -472,6 +507,7 @@ __device__ __forceinline__ void gemm_tile(const MatView& A, const MatView& B, in
         }
     }
 }
+
 // visit every element of the accumulators: f(row in tile, column in tile, value)
 template <class F>
 __device__ __forceinline__ void gemm_tile_foreach(const mfma_f64x4 acc[2][2], F&& f) {
@@ -488,7 +524,8 @@ __device__ __forceinline__ void gemm_tile_foreach(const mfma_f64x4 acc[2][2], F&
 
 // step 2:  which = 0: tmpU (k x b) = L11^-1 F[P,B]     (L11^-1 lower: K tiles 0..ti)
 //          which = 1: tmpL (b x k) = F[B,P] U11^-1     (U11^-1 upper: K tiles 0..tj)
-__global__ void __launch_bounds__(256) gemm1_kernel(MfDev mf, int level_begin) {
+__global__ void __launch_bounds__(256) gemm1_kernel(MF_FACTOR_PARAMS) {
+    MF_FACTOR_INIT
     const MfFrontDev f = mf.lfronts[level_begin + blockIdx.z / 2];
     const int which = blockIdx.z & 1;
     const int k = f.k, b = f.m - f.k, ld = f.ld;
@@ -522,7 +559,8 @@ __global__ void __launch_bounds__(256) gemm1_kernel(MfDev mf, int level_begin) {
 // step 3:  which = 0: F[B,B] -= tmpL tmpU                        (b x b, K = k)
 //          which = 1: F[B,A]  = -tmpL L11^-1   (b x k; L11^-1 lower: K tiles tj..)
 //          which = 2: F[A,B]  = -U11^-1 tmpU   (k x b; U11^-1 upper: K tiles ti..)
-__global__ void __launch_bounds__(256) gemm2_kernel(MfDev mf, int level_begin) {
+__global__ void __launch_bounds__(256) gemm2_kernel(MF_FACTOR_PARAMS) {
+    MF_FACTOR_INIT
     const MfFrontDev f = mf.lfronts[level_begin + blockIdx.z / 3];
     const int which = blockIdx.z % 3;
     const int k = f.k, b = f.m - f.k, ld = f.ld;
@@ -566,7 +604,8 @@ __global__ void __launch_bounds__(256) gemm2_kernel(MfDev mf, int level_begin) {
 //   F[r, c] -= sum_{q in pivots of the block} L[r, q] U[q, c],   r, c >= p1 * NB,
 // as one rank-(p1 - p0) * NB product of the solved panel tiles (panel_finalize_kernel) on the matrix cores.
 // Tiles inside the (augmentation x augmentation) corner are never used and skipped.
-__global__ void __launch_bounds__(256) block_gemm_kernel(MfDev mf, int level_begin, int p0, int p1) {
+__global__ void __launch_bounds__(256) block_gemm_kernel(MF_FACTOR_PARAMS, int p0, int p1) {
+    MF_FACTOR_INIT
     const MfFrontDev f = mf.lfronts[level_begin + blockIdx.z];
     const int k = f.k, ld = f.ld, m = 2 * k, r0 = p1 * NB;
     if (p0 * NB >= k || r0 >= m) return;
@@ -957,6 +996,104 @@ __global__ void __launch_bounds__(256) bwd_big_kernel(MfDev mf, int level_begin)
     if (c < m - k) a0 += rowb[c] * mf.work[bi[c]];
     acc += wave_sum(a0 + a1);
     if (lane == 0) mf.work[f.own_start + r] = acc;
+}
+
+// ---- merged top of the tree (MfSchedule::Top) -----------------------------------------------------------
+// The last two levels of the tree -- the root and the fronts below it -- cost four dependent launches per solve
+// (two forward, two backward) that move a few megabytes each.  After the factorisation their solve operators are
+// multiplied out into ONE dense matrix M (n_T x n_T, n_T = the pivots of those fronts), so that the top of every
+// solve is a single mat-vec x_T = M t_T:
+//   M_RR  = U_R^-1 L_R^-1                                   (root R)
+//   M_Rc  = M_RR[:, rel_c] G_c,   G_c = -L21 L11^-1 of front c  (its boundary rows sit at rel_c in the root)
+//   M_cR  = E_c M_RR[rel_c, :],   E_c = -U11^-1 U12
+//   M_cc' = E_c M_Rc'[rel_c, :]  (+ U_c^-1 L_c^-1 for c' = c)
+// computed in two dependent batches: P_c = E_c U_R^-1[rel_c, :], Q_c = L_R^-1[:, rel_c] G_c and the diagonal
+// blocks first, then M_cR = P_c L_R^-1, M_Rc = U_R^-1 Q_c, M_cc' = P_c Q_c' -- two GEMM launches per factorisation
+// against 3 x N launches saved in the N solves that follow.
+template <bool IDX>
+__global__ void __launch_bounds__(256) top_gemm_kernel(const TopGemm* __restrict__ g) {
+    const TopGemm d = g[blockIdx.z];
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (ti * GT >= d.M || tj * GT >= d.N) return;
+    __shared__ double As[GK][GT + 1], Bs[GK][GT + 4];
+    mfma_f64x4 acc[2][2];
+    gemm_tile<IDX>(d.A, d.B, ti, tj, 0, d.K, As, Bs, acc);
+    gemm_tile_foreach(acc, [&](int i, int j, double v) {
+        const int r = ti * GT + i, c = tj * GT + j;
+        if (r < d.M && c < d.N) {
+            double* dst = d.C + (int64_t)r * d.ldc + c;
+            *dst = d.acc ? *dst + v : v;
+        }
+    });
+}
+
+
+// x_T = M t_T: every workgroup assembles t_T in LDS from the lists of MfSchedule::Top (own right-hand sides plus
+// what the fronts below the block left in the inboxes, W slots per entry in a fixed order), its 4 wavefronts then
+// take R rows of M each.  Everything the kernel needs comes as arguments: its first memory round trip already
+// fetches data.  The solution goes to a place of its own (xout = work + n): other workgroups of the launch may
+// still be reading the right-hand side.
+template <int R, int W>
+__global__ void __launch_bounds__(256) top_solve_kernel(const double* __restrict__ M,
+                                                        const int32_t* __restrict__ wsrc,
+                                                        const int32_t* __restrict__ ell,
+                                                        const double* __restrict__ inbox_store,
+                                                        const double* __restrict__ work, double* __restrict__ xout,
+                                                        int n) {
+    extern __shared__ double t[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int row0 = blockIdx.x * (4 * R) + wv * R;
+    // the rows' first chunks are requested before the staging (they do not depend on it)
+    constexpr int PRE = 4;
+    double a[PRE][R];
+    const double* rowp[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        rowp[q] = M + (int64_t)min(row0 + q, n - 1) * n;
+#pragma unroll
+        for (int u = 0; u < PRE; ++u) a[u][q] = rowp[q][min(lane + 64 * u, n - 1)];
+    }
+    for (int i = tid; i < n; i += 256) {
+        int sl[W];
+#pragma unroll
+        for (int s = 0; s < W; ++s) sl[s] = ell[(int64_t)s * n + i];
+        double v = work[wsrc[i]];
+#pragma unroll
+        for (int s = 0; s < W; ++s) v += inbox_store[sl[s]];
+        t[i] = v;
+    }
+    __syncthreads();
+    double acc[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) acc[q] = 0;
+#pragma unroll
+    for (int u = 0; u < PRE; ++u) {
+        const int c = lane + 64 * u;
+        const double tv = c < n ? t[c] : 0.0;
+#pragma unroll
+        for (int q = 0; q < R; ++q) acc[q] += a[u][q] * tv;
+    }
+    constexpr int TAIL = 8;
+    for (int c = lane + 64 * PRE; c < n; c += 64 * TAIL) {
+        double av[TAIL][R], tv[TAIL];
+#pragma unroll
+        for (int u = 0; u < TAIL; ++u) {
+            const int cc = c + 64 * u;
+            tv[u] = cc < n ? t[cc] : 0.0;
+#pragma unroll
+            for (int q = 0; q < R; ++q) av[u][q] = rowp[q][min(cc, n - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < TAIL; ++u)
+#pragma unroll
+            for (int q = 0; q < R; ++q) acc[q] += av[u][q] * tv[u];
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const double v = wave_sum(acc[q]);
+        const int row = row0 + q;
+        if (lane == 0 && row < n) xout[row] = v;  // (work[n + row]: see MfSchedule::Top::bnd_x)
+    }
 }
 
 }  // namespace mfk

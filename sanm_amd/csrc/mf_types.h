@@ -56,6 +56,22 @@ struct MfDev {
     int64_t front_store_size;
 };
 
+// Operand of the device GEMMs: element (i, j) at p[i*ld + j] inside (rows, cols), else 0.  The index maps are read
+// by the GEMMs of the merged top block only: column j of an A operand at cidx[j], row i of a B operand at ridx[i].
+struct MatView {
+    const double* p;
+    int ld, rows, cols;
+    const int32_t* ridx = nullptr;
+    const int32_t* cidx = nullptr;
+};
+// one product of the merged top block (mf_kernels.h, top_gemm_kernel): C (M x N) = [C +] A (M x K) B (K x N)
+struct TopGemm {
+    MatView A, B;
+    double* C;
+    int32_t ldc, M, N, K, acc;
+};
+constexpr int MF_TOP_MAXF = 8;
+
 // Host-side schedule (what to launch, in which order).  Within a level the
 // fronts are sorted by decreasing pivot count, so the fronts that still have a
 // panel p form a prefix of the level's list.
@@ -73,6 +89,30 @@ struct MfSchedule {
     };
     std::vector<Level> levels;
     const int32_t* ea_children = nullptr;  // device
+    // The root and the fronts of the level below it as one dense operator (device back end; mf_kernels.h).
+    // Fronts in block order: the level below the root, then the root; off[] = first row of each in the block.
+    struct Top {
+        bool enabled = false;
+        int32_t nf = 0, n = 0;
+        int32_t off[MF_TOP_MAXF + 1] = {};
+        double* M = nullptr;                 // device: n x n
+        const TopGemm* gemms = nullptr;      // device: the products, stage by stage
+        int32_t stage_begin[3] = {};         // [stage_begin[s], stage_begin[s + 1]) into gemms, two stages
+        int32_t stage_dim[2] = {};           // largest M / N of a stage (grid size)
+        bool indexed = false;                // some operand goes through an index map (MatView::ridx / cidx)
+        // right-hand side of the block, entry i: work[wsrc[i]] + sum_s inbox_store[ell[s * n + i]], s < W (lists
+        // padded with a slot that stays zero): the fronts' own inboxes and, for the root's rows, the boundary
+        // rows of the block's other fronts, in a fixed order
+        const int32_t* wsrc = nullptr;
+        const int32_t* ell = nullptr;
+        int32_t W = 0;
+        // The block's solution goes to work[n + row], not over the right-hand side the other workgroups of the
+        // launch are still reading: what reads it afterwards -- the boundary lists of the levels below and the
+        // permutation on the way out -- uses these copies of MfDev::bnd_idx / perm with the block's variables
+        // redirected there.
+        const int32_t* bnd_x = nullptr;
+        const int32_t* perm_x = nullptr;
+    } top;
 };
 
 }  // namespace sanm_hip

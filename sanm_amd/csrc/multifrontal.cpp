@@ -912,8 +912,9 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
         m_dev.lfronts = upload(lf);
     }
     m_dev.upd_dst = upload(upd_dst);
-    m_dev.inbox_store = static_cast<double*>(be->alloc(std::max<int64_t>(inbox_doubles, 1) * sizeof(double)));
-    be->zero(m_dev.inbox_store, std::max<int64_t>(inbox_doubles, 1) * sizeof(double));
+    // (one more double at the end that nothing writes: the padding slot of the merged top block's lists)
+    m_dev.inbox_store = static_cast<double*>(be->alloc((inbox_doubles + 1) * sizeof(double)));
+    be->zero(m_dev.inbox_store, (inbox_doubles + 1) * sizeof(double));
     m_bufs.push_back(m_dev.inbox_store);
     m_dev.bnd_idx = upload(bnd_idx);
     m_dev.rel = upload(rel);
@@ -923,7 +924,10 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     m_sched.ea_children = upload(ea_children);
     m_dev.front_store_size = off;
     m_dev.front_store = static_cast<double*>(be->alloc(off * sizeof(double)));
-    m_dev.work = static_cast<double*>(be->alloc(n * sizeof(double)));
+    // (n doubles, and room behind them for the solution of the merged top block, MfSchedule::Top)
+    const char* env_top = std::getenv("SANM_MF_TOP");
+    const int32_t top_max_n = env_top ? std::atoi(env_top) : 0;
+    m_dev.work = static_cast<double*>(be->alloc((n + std::max(top_max_n, 0)) * sizeof(double)));
     m_dev.work2 = static_cast<double*>(be->alloc(n * sizeof(double)));
     m_bufs.push_back(m_dev.work2);
     m_dev.tmp_store = static_cast<double*>(be->alloc(tmp_doubles * sizeof(double)));
@@ -934,6 +938,176 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     m_bufs.push_back(m_dev.front_store);
     m_bufs.push_back(m_dev.work);
     m_bufs.push_back(m_dev.status);
+
+    // ---- merged top block (mf_types.h, MfSchedule::Top): the root and the level below it ----------------------
+    // Opt-in (SANM_MF_TOP = largest n_T to merge, e.g. 2048: 32 MB; default 0 = off).  Measured on armadillo_small
+    // (n_T = 1071): 3 launches fewer per solve, 20 solves: -0.13 ms; two batched GEMM launches of 47 us per
+    // factorisation: +0.095 ms; the step time does not move.
+    {
+        auto& T = m_sched.top;
+        const int32_t max_n = top_max_n;
+        bool ok = max_n > 0 && H >= 3 && m_sched.levels[H - 1].front_end - m_sched.levels[H - 1].front_begin == 1;
+        std::vector<int32_t> tf;
+        if (ok) {
+            const auto& L = m_sched.levels[H - 2];
+            for (int32_t i = L.front_begin; i < L.front_end; ++i) tf.push_back(level_fronts[i]);
+            const int32_t root = level_fronts[m_sched.levels[H - 1].front_begin];
+            for (int32_t f : tf) ok = ok && parent[f] == root;
+            tf.push_back(root);
+            ok = ok && (int)tf.size() <= MF_TOP_MAXF && fr[root].m == fr[root].k;
+        }
+        if (ok) {
+            T.nf = tf.size();
+            T.off[0] = 0;
+            for (int i = 0; i < T.nf; ++i) T.off[i + 1] = T.off[i] + fr[tf[i]].k;
+            T.n = T.off[T.nf];
+            ok = T.n <= max_n;
+        }
+        if (ok) {
+            std::vector<MfFrontDev> tfd;
+            for (int32_t f : tf) tfd.push_back(fr[f]);
+            const int64_t n_t = T.n;
+            T.M = static_cast<double*>(be->alloc(n_t * n_t * sizeof(double)));
+            m_bufs.push_back(T.M);
+            const int R = T.nf - 1;  // the root's place in the block
+            auto Fp = [&](int i) { return m_dev.front_store + tfd[i].off; };
+            auto blockM = [&](int bi, int bj) { return T.M + (int64_t)T.off[bi] * n_t + T.off[bj]; };
+            auto relp = [&](int i) { return m_dev.rel + tfd[i].rel_off; };
+            // temporaries: P_c = E_c U_R^-1[rel_c, :] (k_c x k_R) and Q_c = L_R^-1[:, rel_c] G_c (k_R x k_c)
+            const int kR = tfd[R].k;
+            int64_t tmp_doubles = 0;
+            std::vector<int64_t> p_off(T.nf), q_off(T.nf);
+            for (int c = 0; c < R; ++c) {
+                p_off[c] = tmp_doubles;
+                tmp_doubles += (int64_t)tfd[c].k * kR;
+                q_off[c] = tmp_doubles;
+                tmp_doubles += (int64_t)tfd[c].k * kR;
+            }
+            double* tmp = static_cast<double*>(be->alloc(std::max<int64_t>(tmp_doubles, 1) * sizeof(double)));
+            m_bufs.push_back(tmp);
+            // a boundary that is the whole root in the root's own order needs no index map
+            auto rel_map = [&](int c) -> const int32_t* {
+                const int b = tfd[c].m - tfd[c].k;
+                bool ident = b == kR;
+                for (int j = 0; j < b && ident; ++j) ident = rel[tfd[c].rel_off + j] == j;
+                return ident ? nullptr : relp(c);
+            };
+            std::vector<TopGemm> g;
+            int dim[2] = {0, 0};
+            bool indexed = false;
+            auto push = [&](int stage, const TopGemm& t) {
+                g.push_back(t);
+                dim[stage] = std::max(dim[stage], std::max(t.M, t.N));
+                indexed = indexed || t.A.cidx || t.B.ridx;
+            };
+            const double* UinvR = Fp(R) + (int64_t)kR * tfd[R].ld;  // F[A,P] = U11^-1 of the root
+            const double* LinvR = Fp(R) + kR;                        // F[P,A] = L11^-1
+            const int ldR = tfd[R].ld;
+            // stage 0: U^-1 L^-1 of every front on its diagonal block of M; P_c and Q_c
+            T.stage_begin[0] = 0;
+            for (int i = 0; i < T.nf; ++i) {
+                const int k = tfd[i].k, ld = tfd[i].ld;
+                TopGemm t{};
+                t.A = MatView{Fp(i) + (int64_t)k * ld, ld, k, k};
+                t.B = MatView{Fp(i) + k, ld, k, k};
+                t.C = blockM(i, i);
+                t.ldc = n_t, t.M = k, t.N = k, t.K = k, t.acc = 0;
+                push(0, t);
+            }
+            for (int c = 0; c < R; ++c) {
+                const int k = tfd[c].k, b = tfd[c].m - k, ld = tfd[c].ld;
+                TopGemm t{};
+                t.A = MatView{Fp(c) + (int64_t)k * ld + 2 * k, ld, k, b};  // E_c = F[A,B] = -U11^-1 U12
+                t.B = MatView{UinvR, ldR, b, kR, rel_map(c), nullptr};    // U_R^-1[rel_c, :]
+                t.C = tmp + p_off[c];
+                t.ldc = kR, t.M = k, t.N = kR, t.K = b, t.acc = 0;
+                push(0, t);
+                TopGemm u{};
+                u.A = MatView{LinvR, ldR, kR, b, nullptr, rel_map(c)};            // L_R^-1[:, rel_c]
+                u.B = MatView{Fp(c) + (int64_t)2 * k * ld + k, ld, b, k};          // G_c = F[B,A] = -L21 L11^-1
+                u.C = tmp + q_off[c];
+                u.ldc = k, u.M = kR, u.N = k, u.K = b, u.acc = 0;
+                push(0, u);
+            }
+            // stage 1: M_cR = P_c L_R^-1, M_Rc = U_R^-1 Q_c, M_cc' = P_c Q_c' (+ the diagonal block of stage 0)
+            T.stage_begin[1] = g.size();
+            for (int c = 0; c < R; ++c) {
+                const int k = tfd[c].k;
+                TopGemm t{};
+                t.A = MatView{tmp + p_off[c], kR, k, kR};
+                t.B = MatView{LinvR, ldR, kR, kR};
+                t.C = blockM(c, R);
+                t.ldc = n_t, t.M = k, t.N = kR, t.K = kR, t.acc = 0;
+                push(1, t);
+                TopGemm u{};
+                u.A = MatView{UinvR, ldR, kR, kR};
+                u.B = MatView{tmp + q_off[c], k, kR, k};
+                u.C = blockM(R, c);
+                u.ldc = n_t, u.M = kR, u.N = k, u.K = kR, u.acc = 0;
+                push(1, u);
+                for (int c2 = 0; c2 < R; ++c2) {
+                    const int k2 = tfd[c2].k;
+                    TopGemm v{};
+                    v.A = MatView{tmp + p_off[c], kR, k, kR};
+                    v.B = MatView{tmp + q_off[c2], k2, kR, k2};
+                    v.C = blockM(c, c2);
+                    v.ldc = n_t, v.M = k, v.N = k2, v.K = kR, v.acc = c == c2;
+                    push(1, v);
+                }
+            }
+            T.stage_begin[2] = g.size();
+            T.stage_dim[0] = dim[0];
+            T.stage_dim[1] = dim[1];
+            T.indexed = indexed;
+            T.gemms = upload(g);
+            // the right-hand side lists
+            std::vector<std::vector<int32_t>> lists(T.n);
+            std::vector<int32_t> wsrc(T.n);
+            std::vector<char> in_top(F, 0);
+            for (int32_t f : tf) in_top[f] = 1;
+            for (int i = 0; i < T.nf; ++i) {
+                const MfFrontDev& fd = tfd[i];
+                for (int q = 0; q < fd.k; ++q) {
+                    wsrc[T.off[i] + q] = fd.own_start + q;
+                    for (int j = 0; j < fd.nch; ++j)
+                        if (!in_top[children[tf[i]][j]])  // (the block's own fronts no longer write their parent's inbox)
+                            lists[T.off[i] + q].push_back(fd.inbox_off + j * fd.m + q);
+                }
+            }
+            for (int c = 0; c < R; ++c) {
+                const MfFrontDev& fd = tfd[c];
+                for (int j = 0; j < fd.m - fd.k; ++j)
+                    for (int sl = 0; sl < fd.nch; ++sl)
+                        lists[T.off[R] + rel[fd.rel_off + j]].push_back(fd.inbox_off + sl * fd.m + fd.k + j);
+            }
+            size_t W = 0;
+            for (const auto& l : lists) W = std::max(W, l.size());
+            W = (W + 1) / 2 * 2;
+            if (W == 0) W = 2;
+            if (W > 8) {
+                T.enabled = false;  // (no kernel instance for lists this long)
+            } else {
+                std::vector<int32_t> ell(W * (size_t)T.n, (int32_t)inbox_doubles);
+                for (int i = 0; i < T.n; ++i)
+                    for (size_t sl = 0; sl < lists[i].size(); ++sl) ell[sl * T.n + i] = lists[i][sl];
+                T.wsrc = upload(wsrc);
+                T.ell = upload(ell);
+                T.W = W;
+                std::vector<int32_t> redirect(n);
+                for (int64_t q = 0; q < n; ++q) redirect[q] = q;
+                for (int i = 0; i < T.nf; ++i)
+                    for (int q = 0; q < tfd[i].k; ++q) redirect[tfd[i].own_start + q] = n + T.off[i] + q;
+                std::vector<int32_t> bnd_x(bnd_idx.size()), perm_x(n);
+                for (size_t q = 0; q < bnd_idx.size(); ++q) bnd_x[q] = redirect[bnd_idx[q]];
+                for (int64_t q = 0; q < n; ++q) perm_x[q] = redirect[perm[q]];
+                T.bnd_x = upload(bnd_x);
+                T.perm_x = upload(perm_x);
+            }
+            T.enabled = T.W > 0;
+            if (std::getenv("SANM_MF_DEBUG"))
+                std::fprintf(stderr, "mf top block: %d fronts, %d pivots, %zu products\n", T.nf, T.n, g.size());
+        }
+    }
 }
 
 }  // namespace sanm_hip

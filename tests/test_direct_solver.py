@@ -86,6 +86,21 @@ def test_fem_jacobian(api, with_coords):
     assert st["nr_level"] >= 3 and st["max_front"] < A.shape[0]
 
 
+@pytest.mark.parametrize("case", ["fem", "grid3d"])
+def test_merged_top_block(api, monkeypatch, case):
+    """SANM_MF_TOP: the root and the level below it multiplied out into one dense operator after the factorisation
+    (mf_kernels.h, top_gemm_kernel / top_solve_kernel; device back end only -- the host harness ignores the
+    switch): same solutions, several right-hand sides in a row (the block's solution must not land on the
+    right-hand side other workgroups are still reading), with and without index maps in its products."""
+    monkeypatch.setenv("SANM_MF_TOP", "2048")
+    if case == "fem":
+        test_fem_jacobian(api, True)
+        test_fem_jacobian(api, False)
+    else:
+        test_grid3d_wide_separators(api)
+        test_scalar_pattern_no_blocks(api)
+
+
 def test_singular_matrix_reports_bad_pivot(api):
     A = sp.csr_matrix(np.array([[1.0, 2.0, 0], [2.0, 4.0, 0], [0, 0, 1.0]]))
     ds = DirectSolver(api, A)

@@ -118,6 +118,17 @@ def test_refined_solves_do_not_move_the_device_oracle_gap(hip_api):
     assert d < 1e-9  # the refinement changes x_1 by about the plain LU's error (~4e-11)
 
 
+def test_merged_top_block_gives_the_same_continuation(hip_api, monkeypatch):
+    """SANM_MF_TOP (the top two levels of the elimination tree as one dense operator, opt-in): same step count and
+    the same equilibrium as the level-by-level solve on armadillo_small (n_T = 1071)."""
+    run0, _, seq0 = _device_sequence(hip_api, "armadillo_small")
+    monkeypatch.setenv("SANM_MF_TOP", "2048")
+    run1, _, seq1 = _device_sequence(hip_api, "armadillo_small")
+    assert len(seq0) == len(seq1)
+    V0, V1 = run0.vertices(), run1.vertices()
+    assert np.abs(V0 - V1).max() <= 1e-8 * np.abs(V0).max()
+
+
 def test_block32_converges_and_balances(hip_api):
     """A mesh of more than 100,000 tets in the GPU test set: the armadillo material, load and boundary rule on a
     32^3-vertex block (148,955 tets, 95 k unknowns; bench.py's `block:32`, the scaling stand-in for the missing full
