@@ -946,6 +946,16 @@ void AnmDriver::solve_expansion_coeffs() {
             m_pade_ws.step(m_xt_coeffs, i, anm_cond);
             be->side_end();
         }
+        // SANM_SANITY_SIDE: the checks of the orders finished so far, ten at a time, on the second queue beside the
+        // solves that follow instead of after the loop.  Measured on armadillo_small: the tail gets 0.12 ms
+        // shorter and the solves 0.26 ms longer (the pass over the matrix competes with the latency-bound level
+        // kernels for the whole of its 60 us, twice): off by default.
+        static const bool sanity_side = std::getenv("SANM_SANITY_SIDE") != nullptr;
+        if (do_sanity && sanity_side && !pade_side && i < N && (i - sanity_done == 10 || i == N - 1)) {
+            be->side_fork();
+            queue_sanity(i, grad_t);
+            be->side_end();
+        }
 
         if (m_profile_mode == 1) {
             trace_b_norm.push_back(std::sqrt(be->dot(n, bi, bi)));

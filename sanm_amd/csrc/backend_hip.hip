@@ -1912,6 +1912,10 @@ public:
                                   const double* const* bs, double eps, size_t n1, const double* x1, double*, double*,
                                   double* out) override {
         if (n1 > (size_t)A.n * SPMV_LANES) sanm_throw(SANM_ERR_ASSERT, "sanity_check: n1 too large");
+        if (nvec == 1) {  // one order: the single-vector kernel (the batch kernel gathers for all its slots)
+            sanity_check_async(A, xs[0], grad_t, bs[0], eps, n1, x1, nullptr, nullptr, out);
+            return;
+        }
         for (int q0 = 0; q0 < nvec; q0 += SANITY_ORDERS) {
             SanityBatch a{};
             a.n = std::min(SANITY_ORDERS, nvec - q0);
