@@ -112,6 +112,34 @@ __device__ __forceinline__ double pivot_reciprocal(double& piv, int& nbad, bool 
     r = __builtin_fma(__builtin_fma(-piv, r, 1.0), r, r);
     return r;
 }
+// a[c] -= l * (row J's a[c]) for the 8 columns C0 .. C0 + 7.  Left to itself the compiler funnels every broadcast
+// through ONE scalar register pair -- readlane, readlane, two wait states, multiply-add, and the next readlane
+// waits for the multiply-add to have read the pair: 26 cycles per column.  The empty asm statement keeps the 16
+// scalars of a chunk alive at once, so the 16 readlanes issue back to back and the 8 multiply-adds after them.
+template <int J, int C0>
+__device__ __forceinline__ void tile_lu_chunk8(double (&a)[NB], double l) {
+    int lo[8], hi[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        lo[q] = __builtin_amdgcn_readlane(__double2loint(a[C0 + q]), J);
+        hi[q] = __builtin_amdgcn_readlane(__double2hiint(a[C0 + q]), J);
+    }
+    asm volatile("" : "+s"(lo[0]), "+s"(hi[0]), "+s"(lo[1]), "+s"(hi[1]), "+s"(lo[2]), "+s"(hi[2]), "+s"(lo[3]),
+                      "+s"(hi[3]), "+s"(lo[4]), "+s"(hi[4]), "+s"(lo[5]), "+s"(hi[5]), "+s"(lo[6]), "+s"(hi[6]),
+                      "+s"(lo[7]), "+s"(hi[7]));
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[C0 + q] -= l * __hiloint2double(hi[q], lo[q]);
+}
+template <int J, int C0>
+__device__ __forceinline__ void tile_lu_columns(double (&a)[NB], double l) {
+    if constexpr (C0 + 8 <= NB) {
+        tile_lu_chunk8<J, C0>(a, l);
+        tile_lu_columns<J, C0 + 8>(a, l);
+    } else {
+#pragma unroll
+        for (int c = C0; c < NB; ++c) a[c] -= l * readlane_f64(a[c], J);
+    }
+}
 template <int J>
 __device__ __forceinline__ void tile_lu_step(double (&a)[NB], int r, int kb, double inv, double piv, int& nbad,
                                              double thr) {
@@ -125,8 +153,7 @@ __device__ __forceinline__ void tile_lu_step(double (&a)[NB], int r, int kb, dou
         piv_next = readlane_f64(a[J + 1], J + 1);
         inv_next = pivot_reciprocal(piv_next, nbad, J + 1 < kb, thr);
     }
-#pragma unroll
-    for (int c = J + 2; c < NB; ++c) a[c] -= l * readlane_f64(a[c], J);
+    tile_lu_columns<J, J + 2>(a, l);
     if constexpr (J + 1 < NB) tile_lu_step<J + 1>(a, r, kb, inv_next, piv_next, nbad, thr);
 }
 __device__ __forceinline__ void tile_factor(double (*T)[TPAD], int kb, int tid, int32_t* status, double thr) {
