@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <exception>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -968,30 +969,62 @@ void AnmDriver::solve_expansion_coeffs() {
             bias_done = fuse_passes;
         }
     }
-    if (do_sanity) queue_sanity(N, grad_t);  // the orders not checked beside the loop
+    // The checks of all orders are two passes over the matrix for ten right-hand sides each (0.12 ms on the armadillo
+    // mesh) whose verdict nothing needs before the step is declared good.  SANM_SANITY_BESIDE puts them on the
+    // second queue beside the Pade estimate that follows -- small kernels and host round trips that leave the
+    // device idle most of the time -- and waits for them after it (a failed check is still reported before
+    // anything the estimate may have had to say).  Measured: the tail gets 0.1 ms shorter, but once a second
+    // hardware queue has been in use every launch of the latency-bound chains of the NEXT step takes longer
+    // (solves 2.20 -> 2.39 ms per step): off by default, like the other uses of the second queue.
+    static const bool sanity_beside_env = std::getenv("SANM_SANITY_BESIDE") != nullptr;
+    const bool sanity_beside = do_sanity && sanity_beside_env && !pade_side && m_hp.use_pade;
+    if (do_sanity) {
+        if (sanity_beside) be->side_fork();
+        queue_sanity(N, grad_t);  // the orders not checked beside the loop
+        if (sanity_beside) {
+            be->side_end();
+            be->side_detach();
+        }
+    }
     // the two norms of estimate_valid_range travel with the rest
     be->dot_async(n1, m_xt_coeffs[1].p(), m_xt_coeffs[1].p(), host_checks + 2);
     be->dot_async(n1, m_xt_coeffs[N].p(), m_xt_coeffs[N].p(), host_checks + 3);
     be->sync();
-    sanm_check(host_checks[0] == 0, "non-finite Jacobian coefficient");
-    for (int i = 1; i <= N; ++i) {
-        const double ti = m_host_scalars[3 * i];
-        // the reference asserts a finite right-hand side before solving (sparse_solver.cpp:160-161);
-        // a non-finite b_i or solution makes t_i non-finite, which is checked instead of a separate pass
-        if (!std::isfinite(ti))
-            sanm_throw(SANM_ERR_NUMERICAL, "non-finite right-hand side / solution at order %d", i);
-        m_t_coeffs.push_back(ti);
-        if (do_sanity) {
+    auto check_sanity = [&]() {
+        for (int i = 1; i <= N && do_sanity; ++i) {
             const double ex = host_sanity[2 * (i - 1)], xdot = host_sanity[2 * (i - 1) + 1];
             sanm_check(ex < 0, "ANM check coeff eqn: order %d: excess %g", i, ex);
             if (i == 1) sanm_check(std::fabs(xdot - 1) < 1e-4, "xdot=%g", xdot);
             else sanm_check(std::fabs(xdot) < 1e-4, "i=%d: xdot=%g", i, xdot);
         }
+    };
+    try {
+        sanm_check(host_checks[0] == 0, "non-finite Jacobian coefficient");
+        for (int i = 1; i <= N; ++i) {
+            const double ti = m_host_scalars[3 * i];
+            // the reference asserts a finite right-hand side before solving (sparse_solver.cpp:160-161);
+            // a non-finite b_i or solution makes t_i non-finite, which is checked instead of a separate pass
+            if (!std::isfinite(ti))
+                sanm_throw(SANM_ERR_NUMERICAL, "non-finite right-hand side / solution at order %d", i);
+            m_t_coeffs.push_back(ti);
+        }
+        if (!sanity_beside) check_sanity();
+    } catch (...) {
+        be->side_wait();
+        throw;
     }
-    {
+    std::exception_ptr held;
+    try {
         ScopedTimer t{this, "estimate_valid_range"};
         estimate_valid_range();
+    } catch (...) {
+        held = std::current_exception();
     }
+    if (sanity_beside) {
+        be->side_wait();
+        check_sanity();
+    }
+    if (held) std::rethrow_exception(held);
     ++m_iter;
 }
 

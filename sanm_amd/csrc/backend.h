@@ -108,6 +108,11 @@ public:
     virtual void side_fork() {}
     virtual void side_end() {}
     virtual void side_join() {}
+    //! side_detach(): what the side queue holds is no longer waited for by sync(), by copies to the host or by
+    //! side_join(), until side_wait() has waited for it on the host (work whose result is read much later and
+    //! that should fill the gaps the main queue leaves in the meantime).
+    virtual void side_detach() {}
+    virtual void side_wait() {}
     //! host memory the device can write (pinned); results of the *_async reductions land here and are
     //! valid after the next sync()
     virtual double* alloc_host(size_t n_doubles) = 0;

@@ -953,6 +953,7 @@ class HipBackend final : public Backend {
     hipStream_t m_stream = nullptr;  // the queue launches currently go to: m_main, or m_side between side_fork / side_end
     hipStream_t m_main = nullptr, m_side = nullptr;
     bool m_side_dirty = false;  // the side queue got work since the last join / sync
+    bool m_side_detached = false;  // ... and nothing waits for it before side_wait()
     static constexpr int kForkEvents = 64;
     hipEvent_t m_fork_ev[kForkEvents] = {};
     int m_fork_next = 0;
@@ -1116,7 +1117,7 @@ public:
     void d2h(void* dst, const void* src, size_t bytes) override {
         if (!bytes) return;
         flush_deferred();
-        if (m_stream == m_main && m_side_dirty) {  // what the host reads may come from the side queue
+        if (m_stream == m_main && m_side_dirty && !m_side_detached) {  // what the host reads may come from the side queue
             HIP_CHECK(hipStreamSynchronize(m_side));
             m_side_dirty = false;
         }
@@ -1134,10 +1135,18 @@ public:
     void sync() override {
         flush_deferred();
         HIP_CHECK(hipStreamSynchronize(m_main));
-        if (m_side_dirty) {
+        if (m_side_dirty && !m_side_detached) {
             HIP_CHECK(hipStreamSynchronize(m_side));
             m_side_dirty = false;
         }
+    }
+    void side_detach() override {
+        if (m_stream != m_main) sanm_throw(SANM_ERR_ASSERT, "side_detach inside a fork");
+        m_side_detached = m_side_dirty;
+    }
+    void side_wait() override {
+        if (m_side_dirty) HIP_CHECK(hipStreamSynchronize(m_side));
+        m_side_dirty = m_side_detached = false;
     }
     hipEvent_t next_fork_event() {
         hipEvent_t& e = m_fork_ev[m_fork_next];
@@ -1147,6 +1156,7 @@ public:
     }
     void side_fork() override {
         if (m_stream != m_main) sanm_throw(SANM_ERR_ASSERT, "side_fork inside a fork");
+        if (m_side_detached) sanm_throw(SANM_ERR_ASSERT, "side_fork while the side queue is detached");
         if (!m_side) HIP_CHECK(hipStreamCreateWithFlags(&m_side, hipStreamNonBlocking));
         red_for(m_red_side);  // (allocated outside any launch sequence)
         hipEvent_t e = next_fork_event();
@@ -1158,7 +1168,7 @@ public:
     void side_end() override { m_stream = m_main; }
     void side_join() override {
         if (m_stream != m_main) sanm_throw(SANM_ERR_ASSERT, "side_join inside a fork");
-        if (!m_side_dirty) return;
+        if (!m_side_dirty || m_side_detached) return;
         hipEvent_t e = next_fork_event();
         HIP_CHECK(hipEventRecord(e, m_side));
         HIP_CHECK(hipStreamWaitEvent(m_main, e, 0));
