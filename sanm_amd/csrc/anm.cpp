@@ -296,6 +296,7 @@ void PadeWorkspace::ensure(Backend* be_, int nx, size_t len) {
     orth.resize(nx);
     for (int i = 1; i < nx; ++i) orth[i] = DVec{be, len};
     acoef = DVec{be, (size_t)nx * nx + nx};
+    host_acoef = be->alloc_host((size_t)nx * nx);
 }
 
 void PadeWorkspace::step(const std::vector<DVec>& xs, int i, bool anm_cond) {
@@ -381,7 +382,9 @@ PadeApproximation::PadeApproximation(Backend* be, const std::vector<DVec>& xs,
     ws->done = 0;  // consumed: the next series starts over
     {
         std::vector<double> h((size_t)nx * nx);
-        be->d2h(h.data(), ws->acoef.p(), h.size() * 8);
+        if (ws->host_valid) std::copy(ws->host_acoef, ws->host_acoef + h.size(), h.begin());  // (synchronised since)
+        else be->d2h(h.data(), ws->acoef.p(), h.size() * 8);
+        ws->host_valid = false;
         for (int i = 1; i <= n; ++i) {
             for (int j = 1; j < i; ++j) {
                 A(i, j) = h[(size_t)i * nx + j];
@@ -989,6 +992,15 @@ void AnmDriver::solve_expansion_coeffs() {
     // the two norms of estimate_valid_range travel with the rest
     be->dot_async(n1, m_xt_coeffs[1].p(), m_xt_coeffs[1].p(), host_checks + 2);
     be->dot_async(n1, m_xt_coeffs[N].p(), m_xt_coeffs[N].p(), host_checks + 3);
+    // ... and so does what is left of the Pade basis (the step of x_N) with its coefficient table: queued here,
+    // before the synchronisation, instead of by PadeApproximation behind one of its own
+    m_pade_ws.host_valid = false;
+    if (pade_steps && !pade_side) {
+        be->flush_deferred();
+        for (int i = m_pade_ws.done + 1; i <= N; ++i) m_pade_ws.step(m_xt_coeffs, i, anm_cond);
+        be->d2h_async(m_pade_ws.host_acoef, m_pade_ws.acoef.p(), (size_t)(N + 1) * (N + 1) * 8);
+        m_pade_ws.host_valid = true;
+    }
     be->sync();
     auto check_sanity = [&]() {
         for (int i = 1; i <= N && do_sanity; ++i) {

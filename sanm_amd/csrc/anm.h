@@ -132,8 +132,13 @@ struct PadeWorkspace {
     //! queue as soon as x_i exists: PadeApproximation then finds the basis ready); -1: steps not in use
     int done = 0;
     bool done_anm_cond = false;
+    //! the coefficient table on the host (pinned): the driver queues the copy behind the last step, before the
+    //! synchronisation the end of the order loop needs anyway; PadeApproximation then reads it without another
+    double* host_acoef = nullptr;
+    bool host_valid = false;
     ~PadeWorkspace() {
         if (graph) be->graph_destroy(graph);
+        if (host_acoef) be->free_host(host_acoef);
     }
     void ensure(Backend* be_, int nx, size_t len);
     //! one classical Gram-Schmidt step (pade.cpp:36-70) for xs[i], i = done + 1; the last step also completes

@@ -80,6 +80,8 @@ public:
     virtual void free(void* p) = 0;
     virtual void h2d(void* dst, const void* src, size_t bytes) = 0;
     virtual void d2h(void* dst, const void* src, size_t bytes) = 0;
+    //! queue a copy to pinned host memory (alloc_host) without waiting: valid after the next sync()
+    virtual void d2h_async(void* dst_pinned, const void* src, size_t bytes) { d2h(dst_pinned, src, bytes); }
     virtual void d2d(void* dst, const void* src, size_t bytes) = 0;
     virtual void zero(void* dst, size_t bytes) = 0;
     virtual void sync() = 0;

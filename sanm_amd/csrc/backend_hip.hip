@@ -1114,6 +1114,11 @@ public:
         HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, m_stream));
         HIP_CHECK(hipStreamSynchronize(m_stream));
     }
+    void d2h_async(void* dst_pinned, const void* src, size_t bytes) override {
+        if (!bytes) return;
+        flush_deferred();
+        HIP_CHECK(hipMemcpyAsync(dst_pinned, src, bytes, hipMemcpyDeviceToHost, m_stream));
+    }
     void d2h(void* dst, const void* src, size_t bytes) override {
         if (!bytes) return;
         flush_deferred();
