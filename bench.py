@@ -218,7 +218,11 @@ def measure_families(run, one_step, cfg, stats, args, nsteps=2):
     f["peak_tflops"] = FP64_MFMA_PEAK_TFLOPS
     f["frac_mfma"] = f["achieved_tflops"] / FP64_MFMA_PEAK_TFLOPS
     if pass_cnt:
-        fam["taylor"]["avg_launch_us_events"] = pass_ms / pass_cnt * 1e3
+        # the pass launches themselves, one HIP event pair around each (no bracket overhead, no gaps between them)
+        t = fam["taylor"]
+        t["avg_launch_us_events"] = pass_ms / pass_cnt * 1e3
+        t["achieved_by_launch_events"] = B["taylor"] / 1e9 / (pass_ms / pass_cnt * t["launches_per_step"] * 1e-3)
+        t["frac_by_launch_events"] = t["achieved_by_launch_events"] / HBM_PEAK_GBS
     return {"families": fam, "bytes_step": sum(B.values()), "ms_step_measured": whole,
             "ms_step_wall_measured": wall_ms / max(k, 1)}
 
