@@ -272,16 +272,10 @@ def main(argv=None):
         if native:
             # the library's own RCCL communicator: ncclAllReduce queued on the solver's stream.  Should it fail to
             # come up on ANY rank (RCCL not loadable from C++, ...), all ranks take the callback path together.
-            ok = 1
-            try:
-                sdist.init_native_comm(api, rank, world)
-            except Exception as e:  # noqa: BLE001
-                print(f"rank {rank}: library communicator unavailable ({e}); all-reduce through torch.distributed",
-                      file=sys.stderr, flush=True)
-                ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            native = bool(flag.item())
+            native = sdist.init_native_comm(api, rank, world)
+            if not native:
+                print(f"rank {rank}: library communicator unavailable on some rank; all-reduce through "
+                      "torch.distributed", file=sys.stderr, flush=True)
         if native:
             fn = None
         else:

@@ -152,6 +152,9 @@ typedef int (*sanm_allreduce_fn)(void* user, double* buf, int64_t count);
  * use).  Rank 0 calls sanm_hip_comm_unique_id (128 bytes = ncclUniqueId) and hands the bytes to every rank by any
  * out-of-band means; then every rank calls sanm_hip_comm_init, a collective.  Replaces the worker-thread pool of
  * ParallelTaylorCoeffProp (libsanm/symbolic.cpp:306-590) as the means by which shards exchange results. */
+/* 1 when RCCL can be loaded by this process, 0 otherwise; no collective, no error state.  Lets the ranks AGREE on
+ * the collective path before any of them enters sanm_hip_comm_init (sanm_amd/dist.py). */
+int sanm_hip_comm_available(void);
 int sanm_hip_comm_unique_id(void* id, size_t cap);
 int sanm_hip_comm_init(int rank, int world, const void* id, size_t id_bytes);
 int sanm_hip_comm_destroy(void);
@@ -231,7 +234,8 @@ int sanm_anm_get_stats(const sanm_anm_solver* s, sanm_anm_stats* st);
  * order (libsanm/anm.cpp:271-285, sparse_solver.cpp:160-161, :288-289) are batched after the order loop here;
  * tests/test_fault_injection.py uses this hook to show that each of them fires. */
 int sanm_anm_debug_inject(sanm_anm_solver* s, int kind, int order, int64_t index, double value, int scale);
-/* profile tags: returns the number of tags; names/seconds may be NULL */
+/* profile tags: returns the number of tags (or minus an error code: the call reads device events);
+ * names/seconds may be NULL */
 int sanm_anm_profile(const sanm_anm_solver* s, int max_tags, const char** names, double* seconds);
 /* how many times each tag was entered, in the order of sanm_anm_profile (call that first) */
 int sanm_anm_profile_counts(const sanm_anm_solver* s, int max_tags, double* counts);
@@ -284,8 +288,14 @@ int sanm_fea_boundary_by_threshold(int64_t nv, const double* vertices, const uin
 /* ---- host scalar helpers (exposed for tests): libsanm/unary_polynomial.h - */
 int sanm_poly_solve_eqn(const double* f, int n, double xmin, double xmax, double b, double eps,
                         double* x);
-/* roots must hold n-1 doubles; *nr_roots < 0 if the iteration failed */
+/* unary_polynomial::roots(f, only_real = true) as pade.cpp:113 calls it (ACM algorithm 30,
+ * unary_polynomial.cpp:154-334).  roots must hold n-1 doubles, written in the order the algorithm finds them;
+ * *nr_roots = -1 where the reference returns None */
 int sanm_poly_real_roots(const double* f, int n, double* roots, int* nr_roots);
+/* unary_polynomial::roots with all its arguments (unary_polynomial.h:50-52: max_iter 300, tol 1e-8).
+ * re / im must hold n-1 doubles each; *nr_roots = -1 where the reference returns None */
+int sanm_poly_roots(const double* f, int n, int only_real, int max_iter, double tol, double* re, double* im,
+                    int* nr_roots);
 
 #ifdef __cplusplus
 }

@@ -66,7 +66,7 @@ ENERGY = {"neohookean_i": 0, "neohookean_c": 1, "arap": 2, "stvk_stretch": 3}
 # every symbol include/sanm_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "sanm_hip_init", "sanm_hip_last_error", "sanm_hip_backend_name",
-    "sanm_hip_comm_unique_id", "sanm_hip_comm_init", "sanm_hip_comm_destroy",
+    "sanm_hip_comm_available", "sanm_hip_comm_unique_id", "sanm_hip_comm_init", "sanm_hip_comm_destroy",
     "sanm_graph_create", "sanm_graph_destroy", "sanm_graph_placeholder", "sanm_graph_constant",
     "sanm_graph_linear_combine", "sanm_graph_multiply", "sanm_graph_pow", "sanm_graph_log",
     "sanm_graph_reduce_sum", "sanm_graph_batched_matmul", "sanm_graph_batched_mat_inv_mul",
@@ -89,7 +89,7 @@ SYMBOLS = [
     "sanm_fea_model_graph", "sanm_fea_model_output_var", "sanm_fea_model_F_var",
     "sanm_fea_model_remap_inp", "sanm_fea_model_remap_out", "sanm_fea_model_x0",
     "sanm_fea_model_copy_vtx_values", "sanm_fea_model_scatter", "sanm_fea_gravity_load",
-    "sanm_fea_boundary_by_threshold", "sanm_poly_solve_eqn", "sanm_poly_real_roots",
+    "sanm_fea_boundary_by_threshold", "sanm_poly_solve_eqn", "sanm_poly_real_roots", "sanm_poly_roots",
 ]
 
 
@@ -126,6 +126,10 @@ class Api:
         self.check(self.lib.sanm_hip_init(C.c_int(device)))
         self._initialised = True
         return self
+
+    def comm_available(self):
+        """True when this process can load RCCL from C++ (no collective, never raises)"""
+        return bool(self.lib.sanm_hip_comm_available())
 
     def comm_unique_id(self):
         """ncclUniqueId (128 bytes) of a new communicator; rank 0 calls this and hands the bytes to all ranks"""
@@ -174,6 +178,15 @@ class Api:
         nr = C.c_int()
         self.check(self.lib.sanm_poly_real_roots(_dp(f), C.c_int(f.size), _dp(roots), C.byref(nr)))
         return None if nr.value < 0 else roots[:nr.value].copy()
+
+    def poly_roots(self, f, only_real=False, max_iter=300, tol=1e-8):
+        """unary_polynomial::roots: complex array, or None where the reference returns None."""
+        f = _f64(f)
+        re, im = np.zeros(max(f.size, 1)), np.zeros(max(f.size, 1))
+        nr = C.c_int()
+        self.check(self.lib.sanm_poly_roots(_dp(f), C.c_int(f.size), C.c_int(int(only_real)), C.c_int(max_iter),
+                                            C.c_double(tol), _dp(re), _dp(im), C.byref(nr)))
+        return None if nr.value < 0 else re[:nr.value] + 1j * im[:nr.value]
 
     # -- fea helpers --------------------------------------------------------
     def gravity_load(self, vertices, tets, density, g):
@@ -516,6 +529,8 @@ class _ANMSolver:
 
     def profile(self):
         n = self.api.lib.sanm_anm_profile(self.h, C.c_int(0), None, None)
+        if n < 0:
+            self.api.check(-n)
         names = (C.c_char_p * max(n, 1))()
         secs = (C.c_double * max(n, 1))()
         n = self.api.lib.sanm_anm_profile(self.h, C.c_int(n), names, secs)

@@ -317,6 +317,8 @@ void PadeWorkspace::phase(const std::vector<DVec>& xs, int i, int k, bool anm_co
     ph.n = orth[1].size();
     ph.x = xs[i].p();
     ph.nvec = i - 1;
+    sanm_check(ph.nvec <= GsPhase::kMaxVec, "pade basis: order %d exceeds the %d series vectors the Gram-Schmidt kernels take",
+               n, GsPhase::kMaxVec + 1);
     for (int j = 1; j < i; ++j) ph.vecs[j - 1] = orth[j].p();
     ph.eps = std::numeric_limits<double>::epsilon();
     if (k == 1) {
@@ -792,9 +794,10 @@ void AnmDriver::solve_expansion_coeffs() {
     const bool has_powflag = !m_prog->pow_flags().empty();
     auto check_powflag = [&]() {
         if (!has_powflag || *host_powflag == 0) return;
-        const bool unsupported = *host_powflag > 1.5;
-        double zero = 0;
-        be->h2d(m_prog->arena_dev() + m_prog->pow_flags()[0].off, &zero, 8);
+        // |flags|^2 = 1 or 5: a non-integer exponent met a zero (the reference's error; it wins); 4: only the order limit
+        const bool unsupported = *host_powflag == 4.0;
+        const double zero[2] = {0, 0};
+        be->h2d(m_prog->arena_dev() + m_prog->pow_flags()[0].off, zero, 16);
         std::string exps;
         for (const auto& f : m_prog->pow_flags()) exps += (exps.empty() ? "" : ", ") + std::to_string(f.exponent);
         if (unsupported)
@@ -804,7 +807,7 @@ void AnmDriver::solve_expansion_coeffs() {
     };
     if (has_powflag) {
         const double* fl = m_prog->arena_dev() + m_prog->pow_flags()[0].off;
-        be->dot_async(1, fl, fl, host_powflag);
+        be->dot_async(2, fl, fl, host_powflag);
     }
     if (!on_fx0_computed(m_fx0.p())) {
         check_powflag();

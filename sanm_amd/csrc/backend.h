@@ -61,7 +61,8 @@ struct GsPhase {
     size_t n = 0;
     const double* x = nullptr;
     int nvec = 0;
-    double* vecs[24] = {};
+    static constexpr int kMaxVec = 24;  // = MAX_VEC of the reduction kernels (backend_hip.hip)
+    double* vecs[kMaxVec] = {};
     const double* coefs = nullptr;
     int first = 0;
     double* out = nullptr;
@@ -224,6 +225,7 @@ public:
     // ---- collective of the tet-sharded mode (one process per GPU; RCCL over xGMI in the HIP backend) ----------
     //! 128-byte identifier of a new communicator (rank 0 creates it, the caller hands it to every rank).
     //! The defaults (backend_common.cpp) report UNSUPPORTED.
+    virtual bool comm_available() { return false; }
     virtual void comm_unique_id(void* id128);
     //! join the communicator; collective over all `world` ranks
     virtual void comm_init(int rank, int world, const void* id128);

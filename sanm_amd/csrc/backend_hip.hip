@@ -373,7 +373,7 @@ __global__ void axpby_tail_kernel(size_t n, double a, const double* x, double b,
     else if (i == n) out[i] = tail;
 }
 
-constexpr int MAX_VEC = 24;
+constexpr int MAX_VEC = GsPhase::kMaxVec;
 struct VecList {
     const double* p[MAX_VEC];
     double c[MAX_VEC];
@@ -1048,6 +1048,13 @@ public:
     }
     const char* name() const override { return "hip"; }
 
+    bool comm_available() override {
+        try {
+            return Rccl::get().AllReduce != nullptr;
+        } catch (...) {
+            return false;
+        }
+    }
     void comm_unique_id(void* id128) override {
         const Rccl& r = Rccl::get();
         Rccl::UniqueId id;
@@ -1298,7 +1305,8 @@ public:
         m_phase_open.pop_back();
     }
     void phase_collect(std::map<std::string, double>& acc, std::map<std::string, double>* cnt) override {
-        HIP_CHECK(hipStreamSynchronize(m_stream));
+        HIP_CHECK(hipStreamSynchronize(m_main));
+        if (m_side) HIP_CHECK(hipStreamSynchronize(m_side));  // brackets recorded on the side queue
         for (auto& b : m_phase_done) {
             float ms = 0;
             HIP_CHECK(hipEventElapsedTime(&ms, b.e0, b.e1));

@@ -277,12 +277,13 @@ int sanm_taylor_push_xi(sanm_taylor_prop* p, const double* x, double* y_k) {
         be->sync();
         if (p->order == 0 && !p->prog->pow_flags().empty()) {
             // 0^p (analytic_unary.cpp:112-131): flagged by the order-0 pass
-            double fl = 0, zero = 0;
+            double fl[2] = {0, 0};
+            const double zero[2] = {0, 0};
             double* dev = p->prog->arena_dev() + p->prog->pow_flags()[0].off;
-            be->d2h(&fl, dev, 8);
-            if (fl != 0) {
-                be->h2d(dev, &zero, 8);
-                if (fl > 1.5)
+            be->d2h(fl, dev, 16);
+            if (fl[0] != 0 || fl[1] != 0) {
+                be->h2d(dev, zero, 16);
+                if (fl[0] == 0)
                     sanm_throw(SANM_ERR_UNSUPPORTED, "integer power of a series through zero beyond order %d",
                                POW_INT_MAX_ORDER);
                 sanm_throw(SANM_ERR_NUMERICAL, "0^p when p is not integer");
@@ -402,6 +403,13 @@ int sanm_anm_eqn_solver_create_sharded(const sanm_graph* g, int out_var,
         p->eqn = e;
         *s = p.release();
     });
+}
+int sanm_hip_comm_available(void) {
+    try {
+        return backend()->comm_available() ? 1 : 0;
+    } catch (...) {
+        return 0;
+    }
 }
 int sanm_hip_comm_unique_id(void* id, size_t cap) {
     return guard([&] {
@@ -582,25 +590,30 @@ int sanm_anm_set_profile(sanm_anm_solver* s, int mode, int clear) {
     });
 }
 int sanm_anm_profile_counts(const sanm_anm_solver* s, int max_tags, double* counts) {
+    // (profile() reads device events: errors must not cross the C boundary; negative = error code)
     int k = 0;
-    for (auto& kv : s->drv->profile_counts()) {
-        if (k < max_tags && counts) counts[k] = kv.second;
-        ++k;
-    }
-    return k;
+    const int rc = guard([&] {
+        for (auto& kv : s->drv->profile_counts()) {
+            if (k < max_tags && counts) counts[k] = kv.second;
+            ++k;
+        }
+    });
+    return rc == 0 ? k : -std::abs(rc);
 }
 int sanm_anm_profile(const sanm_anm_solver* s, int max_tags, const char** names, double* seconds) {
     auto* ms = const_cast<sanm_anm_solver*>(s);
-    ms->tag_storage.clear();
     int k = 0;
-    for (auto& kv : ms->drv->profile()) {
-        ms->tag_storage.push_back(kv.first);
-        if (k < max_tags && seconds) seconds[k] = kv.second;
-        ++k;
-    }
-    if (names)
-        for (int i = 0; i < k && i < max_tags; ++i) names[i] = ms->tag_storage[i].c_str();
-    return k;
+    const int rc = guard([&] {
+        ms->tag_storage.clear();
+        for (auto& kv : ms->drv->profile()) {
+            ms->tag_storage.push_back(kv.first);
+            if (k < max_tags && seconds) seconds[k] = kv.second;
+            ++k;
+        }
+        if (names)
+            for (int i = 0; i < k && i < max_tags; ++i) names[i] = ms->tag_storage[i].c_str();
+    });
+    return rc == 0 ? k : -std::abs(rc);
 }
 int sanm_anm_trace(const sanm_anm_solver* s, int max_n, double* b_norm, double* x_norm, double* t) {
     int k = s->drv->trace_t.size();
@@ -712,6 +725,22 @@ int sanm_poly_real_roots(const double* f, int n, double* roots, int* nr_roots) {
         }
         *nr_roots = r.size();
         for (size_t i = 0; i < r.size(); ++i) roots[i] = r[i];
+    });
+}
+
+int sanm_poly_roots(const double* f, int n, int only_real, int max_iter, double tol, double* re, double* im,
+                    int* nr_roots) {
+    return guard([&] {
+        std::vector<std::complex<double>> z;
+        if (!poly::roots(std::vector<double>(f, f + n), only_real != 0, z, max_iter, tol)) {
+            *nr_roots = -1;
+            return;
+        }
+        *nr_roots = z.size();
+        for (size_t i = 0; i < z.size(); ++i) {
+            re[i] = z[i].real();
+            im[i] = z[i].imag();
+        }
     });
 }
 

@@ -128,7 +128,7 @@ __device__ __forceinline__ void tile_lu_chunk8(double (&a)[NB], double l) {
                       "+s"(hi[3]), "+s"(lo[4]), "+s"(hi[4]), "+s"(lo[5]), "+s"(hi[5]), "+s"(lo[6]), "+s"(hi[6]),
                       "+s"(lo[7]), "+s"(hi[7]));
 #pragma unroll
-    for (int q = 0; q < 8; ++q) a[C0 + q] -= l * __hiloint2double(hi[q], lo[q]);
+    for (int q = 0; q < 8; ++q) a[C0 + q] = __builtin_fma(-l, __hiloint2double(hi[q], lo[q]), a[C0 + q]);
 }
 template <int J, int C0>
 __device__ __forceinline__ void tile_lu_columns(double (&a)[NB], double l) {
@@ -137,7 +137,7 @@ __device__ __forceinline__ void tile_lu_columns(double (&a)[NB], double l) {
         tile_lu_columns<J, C0 + 8>(a, l);
     } else {
 #pragma unroll
-        for (int c = C0; c < NB; ++c) a[c] -= l * readlane_f64(a[c], J);
+        for (int c = C0; c < NB; ++c) a[c] = __builtin_fma(-l, readlane_f64(a[c], J), a[c]);
     }
 }
 template <int J>
@@ -149,7 +149,7 @@ __device__ __forceinline__ void tile_lu_step(double (&a)[NB], int r, int kb, dou
     a[J] = (r > J) ? l : (r == J ? piv : a[J]);  // row J keeps the pivot actually used
     double inv_next = 1.0, piv_next = 1.0;
     if constexpr (J + 1 < NB) {
-        a[J + 1] -= l * readlane_f64(a[J + 1], J);
+        a[J + 1] = __builtin_fma(-l, readlane_f64(a[J + 1], J), a[J + 1]);
         piv_next = readlane_f64(a[J + 1], J + 1);
         inv_next = pivot_reciprocal(piv_next, nbad, J + 1 < kb, thr);
     }
@@ -226,8 +226,8 @@ __device__ __forceinline__ void trsm_step(const double (*S)[SPAD], const double*
     const double xj = x[J];
 #pragma unroll
     for (int i = (J + 1) & ~1; i < NB; i += 2) {
-        if (i > J) x[i] -= cur[i / 2].x * xj;
-        x[i + 1] -= cur[i / 2].y * xj;
+        if (i > J) x[i] = __builtin_fma(-cur[i / 2].x, xj, x[i]);
+        x[i + 1] = __builtin_fma(-cur[i / 2].y, xj, x[i + 1]);
     }
     if constexpr (J + 1 < NB) trsm_step<SCALE, J + 1>(S, Dv, x, nxt);
 }
@@ -715,7 +715,7 @@ __device__ __forceinline__ void rows_consume(const RowChunks<R, U>& rc, const do
         const int c = c0 + 64 * u;
         const double tv = v[c < cmax ? c : csafe];
 #pragma unroll
-        for (int q = 0; q < R; ++q) acc[q] += rc.a[u][q] * tv;
+        for (int q = 0; q < R; ++q) acc[q] = __builtin_fma(rc.a[u][q], tv, acc[q]);
     }
     // (fronts wider than the preloaded chunks -- thousands of columns on the large meshes, where these kernels are
     // bound by bandwidth: TAIL chunks per trip with unconditional index-clamped loads, so that TAIL * R loads are in
@@ -737,7 +737,7 @@ __device__ __forceinline__ void rows_consume(const RowChunks<R, U>& rc, const do
 #pragma unroll
         for (int u = 0; u < TAIL; ++u)
 #pragma unroll
-            for (int q = 0; q < R; ++q) acc[q] += a[u][q] * tv[u];
+            for (int q = 0; q < R; ++q) acc[q] = __builtin_fma(a[u][q], tv[u], acc[q]);
     }
 }
 
@@ -872,8 +872,8 @@ __global__ void __launch_bounds__(256) fwd_level_sub_kernel(const MfFrontDev* __
 #pragma unroll
         // (entries beyond the row's extent carry a zero factor, but the vector entry they meet must still be an
         // initialised one: whatever an earlier kernel left in the LDS may be a NaN, and 0 * NaN is not 0)
-        for (int u = 0; u < 4; ++u) acc += a[q][u] * vs[min(sub + G * u, kneed - 1)];
-        for (int c = sub + 4 * G; c < cend[q]; c += G) acc += rowp[q][c] * vs[c];
+        for (int u = 0; u < 4; ++u) acc = __builtin_fma(a[q][u], vs[min(sub + G * u, kneed - 1)], acc);
+        for (int c = sub + 4 * G; c < cend[q]; c += G) acc = __builtin_fma(rowp[q][c], vs[c], acc);
 #pragma unroll
         for (int off = G / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, G);
         const int r = r0 + q;
@@ -930,7 +930,7 @@ __global__ void __launch_bounds__(256) bwd_level_kernel(const MfFrontDev* __rest
         const int c = c0 + 64 * u;
         const double tv = vs[c < m ? c : rb];
 #pragma unroll
-        for (int q = 0; q < R; ++q) acc[q] += a[u][q] * tv;
+        for (int q = 0; q < R; ++q) acc[q] = __builtin_fma(a[u][q], tv, acc[q]);
     }
     {
         constexpr int TAIL = 8;  // as in rows_consume: TAIL * R loads in flight per lane on the wide fronts
@@ -950,7 +950,7 @@ __global__ void __launch_bounds__(256) bwd_level_kernel(const MfFrontDev* __rest
 #pragma unroll
             for (int u = 0; u < TAIL; ++u)
 #pragma unroll
-                for (int q = 0; q < R; ++q) acc[q] += av[u][q] * tv[u];
+                for (int q = 0; q < R; ++q) acc[q] = __builtin_fma(av[u][q], tv[u], acc[q]);
         }
     }
 #pragma unroll
@@ -980,12 +980,12 @@ __device__ __forceinline__ double wave_dot_global(const double* __restrict__ row
                      r5 = row[c + 320], r6 = row[c + 384], r7 = row[c + 448];
         const double v0 = v[c], v1 = v[c + 64], v2 = v[c + 128], v3 = v[c + 192], v4 = v[c + 256], v5 = v[c + 320],
                      v6 = v[c + 384], v7 = v[c + 448];
-        a0 += r0 * v0 + r4 * v4;
-        a1 += r1 * v1 + r5 * v5;
-        a2 += r2 * v2 + r6 * v6;
-        a3 += r3 * v3 + r7 * v7;
+        a0 = __builtin_fma(r4, v4, __builtin_fma(r0, v0, a0));
+        a1 = __builtin_fma(r5, v5, __builtin_fma(r1, v1, a1));
+        a2 = __builtin_fma(r6, v6, __builtin_fma(r2, v2, a2));
+        a3 = __builtin_fma(r7, v7, __builtin_fma(r3, v3, a3));
     }
-    for (; c < cend; c += 64) a0 += row[c] * v[c];
+    for (; c < cend; c += 64) a0 = __builtin_fma(row[c], v[c], a0);
     return wave_sum((a0 + a1) + (a2 + a3));
 }
 __global__ void __launch_bounds__(256) fwd_big_kernel(MfDev mf, int level_begin) {
@@ -1017,10 +1017,10 @@ __global__ void __launch_bounds__(256) bwd_big_kernel(MfDev mf, int level_begin)
     double a0 = 0, a1 = 0;
     int c = lane;
     for (; c + 64 < m - k; c += 128) {
-        a0 += rowb[c] * mf.work[bi[c]];
-        a1 += rowb[c + 64] * mf.work[bi[c + 64]];
+        a0 = __builtin_fma(rowb[c], mf.work[bi[c]], a0);
+        a1 = __builtin_fma(rowb[c + 64], mf.work[bi[c + 64]], a1);
     }
-    if (c < m - k) a0 += rowb[c] * mf.work[bi[c]];
+    if (c < m - k) a0 = __builtin_fma(rowb[c], mf.work[bi[c]], a0);
     acc += wave_sum(a0 + a1);
     if (lane == 0) mf.work[f.own_start + r] = acc;
 }
@@ -1098,7 +1098,7 @@ __global__ void __launch_bounds__(256) top_solve_kernel(const double* __restrict
         const int c = lane + 64 * u;
         const double tv = c < n ? t[c] : 0.0;
 #pragma unroll
-        for (int q = 0; q < R; ++q) acc[q] += a[u][q] * tv;
+        for (int q = 0; q < R; ++q) acc[q] = __builtin_fma(a[u][q], tv, acc[q]);
     }
     constexpr int TAIL = 8;
     for (int c = lane + 64 * PRE; c < n; c += 64 * TAIL) {
@@ -1113,7 +1113,7 @@ __global__ void __launch_bounds__(256) top_solve_kernel(const double* __restrict
 #pragma unroll
         for (int u = 0; u < TAIL; ++u)
 #pragma unroll
-            for (int q = 0; q < R; ++q) acc[q] += av[u][q] * tv[u];
+            for (int q = 0; q < R; ++q) acc[q] = __builtin_fma(av[u][q], tv[u], acc[q]);
     }
 #pragma unroll
     for (int q = 0; q < R; ++q) {

@@ -18,6 +18,10 @@ double eval(const double* f, int n, double x) {
 
 double stable_x_range(int order) { return std::pow(1e15, 1.0 / static_cast<double>(order)); }
 
+// Brent's zero finder: R. P. Brent, "Algorithms for Minimization Without Derivatives" (1973), procedure `zero`,
+// in the form of J. Burkardt's C++ version that the reference vendors (third_party/BRENT/brent.cpp:1003-1130)
+// -- kept statement for statement (same local names) because `solve_a` must reproduce the reference's restart
+// parameter bit for bit (200/200 against the reference's own translation unit, tests/golden/ref_poly.json).
 double brent_zero(double a, double b, double t, const std::function<double(double)>& f) {
     const double macheps = std::numeric_limits<double>::epsilon();
     double sa = a, sb = b, fa = f(sa), fb = f(sb);
@@ -78,99 +82,195 @@ double solve_eqn(const std::vector<double>& f, double xmin, double xmax, double 
     return brent_zero(xmin, xmax, eps, fn);
 }
 
-// All complex roots by the Aberth-Ehrlich simultaneous iteration, then the
-// real ones are kept.  The reference uses ACM algorithm 30 (Bairstow+Newton);
-// only the set of real roots matters to its caller (pade.cpp:113-126).
-bool real_roots(const std::vector<double>& f, std::vector<double>& roots) {
-    roots.clear();
-    int n = (int)f.size() - 1;
-    while (n >= 0 && f[n] == 0.0) --n;
-    if (n <= 0) return true;
-    // strip zero roots
-    int lo = 0;
-    while (lo < n && f[lo] == 0.0) ++lo;
-    for (int i = 0; i < lo; ++i) roots.push_back(0.0);
-    std::vector<double> c(f.begin() + lo, f.begin() + n + 1);
-    n -= lo;
-    if (n == 0) return true;
-    // monic, long double for a little headroom.  Complex arithmetic is spelt out on the components: the
-    // library's std::complex<long double> operators go through the overflow / NaN recovery paths of
-    // __mulxc3 / __divxc3 and made this loop 4x slower (0.53 -> 0.13 ms at degree 19) -- the GPU waits for it once per continuation step.
-    // (double, not long double: x87 arithmetic made the iteration 3x slower, and the caller -- the pole bound of the
-    // Pade range -- needs the real roots to a few digits)
-    using ld = double;
-    struct cd {
-        ld re, im;
-    };
-    auto mul = [](cd x, cd y) { return cd{x.re * y.re - x.im * y.im, x.re * y.im + x.im * y.re}; };
-    auto inv = [](cd x) {
-        const ld d = x.re * x.re + x.im * x.im;
-        return cd{x.re / d, -x.im / d};
-    };
-    auto cabs = [](cd x) { return std::hypot(x.re, x.im); };
-    std::vector<ld> a(n + 1);
-    for (int i = 0; i <= n; ++i) a[i] = (ld)c[i] / (ld)c[n];
-    // Cauchy bound based start radius
-    ld radius = 0;
-    for (int i = 0; i < n; ++i) radius = std::max(radius, std::pow(std::fabs(a[i]), 1.0 / (n - i)));
-    if (radius == 0) {
-        for (int i = 0; i < n; ++i) roots.push_back(0.0);
-        return true;
+// ---------------------------------------------------------------------------------------------------
+// ACM algorithm 30 (K. W. Ellenberger, "On programming the numerical solution of polynomial equations",
+// Commun. ACM 3(12), 1960, 644-647): simultaneous Bairstow (quadratic factor x^2 + p x + q) and Newton
+// (linear factor x - r) iterated synthetic division on the polynomial or -- whichever converges -- its
+// reciprocal; after max_iter trips without a factor the polynomial is reversed, and after every second
+// failed round the accuracy requirement K drops by a decimal figure; below 1e-8 the search gives up.
+//
+// The reference's unary_polynomial::roots (unary_polynomial.cpp:154-334, defaults unary_polynomial.h:50-52)
+// is this algorithm, and the Pade range estimate REJECTS the approximant when it gives up (pade.cpp:113-116)
+// -- a discrete decision that changes continuation step counts.  On the ill-scaled degree-19 denominators of
+// the Pade approximant the outcome depends on every rounding, so the arithmetic below follows the
+// reference's order of operations exactly (strict double arithmetic: this library is built with
+// -ffp-contract=off); tests/golden/ref_poly.json holds outcomes of the reference's own translation unit
+// (g++ -O2) and tests/test_device_ops.py::test_host_poly_helpers compares valid flag and roots with them.
+// Kept quirks: zero constant terms are stripped without reporting the root 0; work arrays are not cleared
+// between deflations.
+namespace {
+class Acm30 {
+    // work arrays indexed -2 .. n
+    std::vector<double> m_store;
+    double *h, *b, *c, *d, *e;
+    int n, dir = 1;            // dir < 0: working on the reciprocal polynomial
+    double K;                  // relative accuracy required of a factor
+    double p = 0, q = 0, r = 0;
+    double p_prev = 0, q_prev = 0, p_last = 0, q_last = 0;  // quadratic factors of the two previous rounds
+    double flip = 1;
+    const int max_iter;
+    const bool only_real;
+    std::vector<std::complex<double>>& out;
+
+    enum class At { Init, Reverse, Start, Iterate, Linear, Quadratic, Done, GiveUp };
+
+    void reverse() {
+        dir = -dir;
+        for (int j = (n - 1) / 2; j >= 0; --j) std::swap(h[j], h[n - j]);
     }
-    std::vector<cd> z(n);
-    for (int i = 0; i < n; ++i) {
-        ld ang = 2.0 * 3.14159265358979323846264338327950288 * i / n + 0.4;
-        z[i] = cd{radius * std::cos(ang), radius * std::sin(ang)};
+    static void deflate(double* hh, const double* quot, int deg, double K) {
+        // keep a quotient coefficient only while it carries significance relative to the dividend's
+        for (int j = deg; j >= 0; --j) hh[j] = (quot[j] != 0.0 && std::fabs(hh[j] / quot[j]) < K) ? quot[j] : 0.0;
     }
-    bool converged = false;
-    for (int it = 0; it < 500 && !converged; ++it) {
-        ld maxstep = 0;
-        for (int i = 0; i < n; ++i) {
-            cd p{1.0, 0.0}, dp{0.0, 0.0};  // Horner for p and p'
-            for (int k = n - 1; k >= 0; --k) {
-                dp = mul(dp, z[i]);
-                dp.re += p.re;
-                dp.im += p.im;
-                p = mul(p, z[i]);
-                p.re += a[k];
-            }
-            if (p.re == 0 && p.im == 0) continue;
-            const cd ratio = mul(p, inv(dp));
-            cd sum{0.0, 0.0};
-            for (int j = 0; j < n; ++j)
-                if (j != i) {
-                    const cd t = inv(cd{z[i].re - z[j].re, z[i].im - z[j].im});
-                    sum.re += t.re;
-                    sum.im += t.im;
-                }
-            const cd rs = mul(ratio, sum);
-            const cd step = mul(ratio, inv(cd{1.0 - rs.re, -rs.im}));
-            z[i].re -= step.re;
-            z[i].im -= step.im;
-            maxstep = std::max(maxstep, cabs(step) / std::max<ld>(cabs(z[i]), 1e-300));
+
+    At init() {
+        if (n == 0) return At::Done;
+        p_prev = q_prev = p_last = q_last = 0.0;
+        flip = 1.0;
+        if (n == 1) {
+            r = -h[1] / h[0];
+            return At::Linear;
         }
-        if (maxstep < 1e-14) converged = true;
+        double s = 0.0;  // scale by the geometric mean of the coefficients
+        for (int j = n; j >= 0; --j)
+            if (h[j] != 0.0) s += std::log(std::fabs(h[j]));
+        s = std::exp(s / (n + 1));
+        for (int j = n; j >= 0; --j) h[j] /= s;
+        return std::fabs(h[1] / h[0]) < std::fabs(h[n - 1] / h[n]) ? At::Reverse : At::Start;
     }
-    if (!converged) {
-        // accept if every root has a tiny residual anyway
-        for (int i = 0; i < n; ++i) {
-            cd p{1.0, 0.0};
-            ld scale = 1.0;
-            const ld az = cabs(z[i]);
-            for (int k = n - 1; k >= 0; --k) {
-                p = mul(p, z[i]);
-                p.re += a[k];
-                scale = scale * az + std::fabs(a[k]);
+    At start() {
+        if (q_prev != 0.0) {
+            p = p_prev;
+            q = q_prev;
+            return At::Iterate;
+        }
+        if (h[n - 2] == 0.0) {
+            q = 1.0;
+            p = -2.0;
+        } else {
+            q = h[n] / h[n - 2];
+            p = (h[n - 1] - q * h[n - 3]) / h[n - 2];
+        }
+        if (n == 2) return At::Quadratic;
+        r = 0.0;
+        return At::Iterate;
+    }
+    At iterate() {
+        for (int it = max_iter; it > 0; --it) {
+            for (int j = 0; j <= n; ++j) {
+                b[j] = h[j] - p * b[j - 1] - q * b[j - 2];
+                c[j] = b[j] - p * c[j - 1] - q * c[j - 2];
             }
-            if (cabs(p) > 1e-10 * scale) return false;
+            if (h[n - 1] != 0.0 && b[n - 1] != 0.0) {
+                if (std::fabs(h[n - 1] / b[n - 1]) >= K) b[n] = h[n] - q * b[n - 2];  // guards the lost significance
+                if (b[n] == 0.0) return At::Quadratic;
+                if (K < std::fabs(h[n] / b[n])) return At::Quadratic;
+            }
+            for (int j = 0; j <= n; ++j) {
+                d[j] = h[j] + r * d[j - 1];
+                e[j] = d[j] + r * e[j - 1];
+            }
+            if (d[n] == 0.0) return At::Linear;
+            if (K < std::fabs(h[n] / d[n])) return At::Linear;
+            c[n - 1] = -p * c[n - 2] - q * c[n - 3];
+            const double s = c[n - 2] * c[n - 2] - c[n - 1] * c[n - 3];
+            if (s == 0.0) {
+                p -= 2.0;
+                q *= (q + 1.0);
+            } else {
+                p += (b[n - 1] * c[n - 2] - b[n] * c[n - 3]) / s;
+                q += (-b[n - 1] * c[n - 1] + b[n] * c[n - 2]) / s;
+            }
+            if (e[n - 1] == 0.0) r -= 1.0;
+            else r -= d[n] / e[n - 1];
+        }
+        p_prev = p_last;
+        q_prev = q_last;
+        p_last = p;
+        q_last = q;
+        if (flip < 0.0) K /= 10.0;
+        if (K < 1e-8) return At::GiveUp;
+        flip = -flip;
+        return At::Reverse;
+    }
+    At linear() {
+        if (dir < 0) r = 1.0 / r;
+        --n;
+        out.emplace_back(r, 0.0);
+        deflate(h, d, n, K);
+        return n == 0 ? At::Done : At::Iterate;
+    }
+    At quadratic() {
+        if (dir < 0) {
+            p /= q;
+            q = 1.0 / q;
+        }
+        n -= 2;
+        if (0.0 < (q - (p * p / 4.0))) {
+            const double s = std::sqrt(q - (p * p / 4.0));
+            if (!only_real) {
+                out.emplace_back(-p / 2.0, s);
+                out.emplace_back(-p / 2.0, -s);
+            }
+        } else {
+            const double s = std::sqrt(((p * p / 4.0)) - q);
+            const double big = p < 0.0 ? -p / 2.0 + s : -p / 2.0 - s;
+            out.emplace_back(big, 0.0);
+            out.emplace_back(q / big, 0.0);
+        }
+        deflate(h, b, n, K);
+        return At::Init;
+    }
+
+public:
+    Acm30(const std::vector<double>& f, bool only_real_, int max_iter_, double tol,
+          std::vector<std::complex<double>>& out_)
+            : max_iter{max_iter_}, only_real{only_real_}, out{out_} {
+        n = (int)f.size() - 1;
+        const size_t len = n + 3;
+        m_store.assign(len * 5, 0.0);
+        h = m_store.data() + 2;
+        b = h + len;
+        c = b + len;
+        d = c + len;
+        e = d + len;
+        for (int j = 0; j <= n; ++j) h[n - j] = f[j];
+        K = 1.0 / tol;
+        while (h[n] == 0.0) {
+            --n;
+            sanm_check(n > -2, "roots: zero polynomial");
         }
     }
-    for (int i = 0; i < n; ++i) {
-        const double re = z[i].re, im = z[i].im;
-        if (std::fabs(im) <= 1e-8 * std::max(1.0, std::fabs(re)))
-            roots.push_back((double)re);
+    bool run() {
+        At at = At::Init;
+        for (;;) {
+            switch (at) {
+                case At::Init: at = init(); break;
+                case At::Reverse: reverse(); at = At::Start; break;
+                case At::Start: at = start(); break;
+                case At::Iterate: at = iterate(); break;
+                case At::Linear: at = linear(); break;
+                case At::Quadratic: at = quadratic(); break;
+                case At::Done: return true;
+                case At::GiveUp: return false;
+            }
+        }
     }
-    std::sort(roots.begin(), roots.end());
+};
+}  // namespace
+
+bool roots(const std::vector<double>& f, bool only_real, std::vector<std::complex<double>>& out, int max_iter,
+           double tol) {
+    sanm_check(f.size() >= 2, "roots: need at least two coefficients");
+    out.clear();
+    return Acm30(f, only_real, max_iter, tol, out).run();
+}
+
+bool real_roots(const std::vector<double>& f, std::vector<double>& real) {
+    std::vector<std::complex<double>> z;
+    real.clear();
+    if (!roots(f, true, z)) return false;
+    for (auto& v : z) real.push_back(v.real());
     return true;
 }
 

@@ -1,6 +1,7 @@
 // Scalar polynomial helpers of the ANM driver (host side).
 // Mirrors libsanm/unary_polynomial.{h,cpp}.
 #pragma once
+#include <complex>
 #include <functional>
 #include <vector>
 
@@ -23,8 +24,13 @@ double brent_zero(double a, double b, double t, const std::function<double(doubl
 double solve_eqn(const std::vector<double>& f, double xmin, double xmax, double b = 0,
                  double eps = 1e-6);
 
-//! real roots of sum f[i] x^i; returns false if the iteration fails
-//! (role of unary_polynomial::roots(only_real=true), unary_polynomial.cpp:154-334)
+//! all roots of sum f[i] x^i by ACM algorithm 30 (Bairstow + Newton), complex pairs omitted when only_real;
+//! returns false where the reference returns None (unary_polynomial::roots, unary_polynomial.cpp:154-334,
+//! defaults unary_polynomial.h:50-52).  Roots come in the order the algorithm finds them.
+bool roots(const std::vector<double>& f, bool only_real, std::vector<std::complex<double>>& out,
+           int max_iter = 300, double tol = 1e-8);
+
+//! roots(f, only_real = true) as pade.cpp:113 calls it: real parts only
 bool real_roots(const std::vector<double>& f, std::vector<double>& roots);
 
 }  // namespace poly

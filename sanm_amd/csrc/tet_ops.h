@@ -136,7 +136,7 @@ SANM_HD void mm3(double* c, const double* a, const double* b) {
             for (int k = 0; k < 3; ++k) {
                 double av = TA ? a[k * 3 + i] : a[i * 3 + k];
                 double bv = TB ? b[j * 3 + k] : b[k * 3 + j];
-                s += av * bv;
+                s = __builtin_fma(av, bv, s);  // (explicit: the library is built with -ffp-contract=off)
             }
             r[i * 3 + j] = s;
         }
@@ -438,7 +438,7 @@ SANM_HD void op_lincomb_t(const TetCtx& c, const OpDesc& o, int mode) {
         for (int k = 0; k < o.nin; ++k) {
             int iv = o.in[k], isz = c.vars[iv].size;
             const double* p = p_coef(c, iv, 0);
-            for (int e = 0; e < osz; ++e) acc[e] += o.p[k] * bval(p, s, isz, e);
+            for (int e = 0; e < osz; ++e) acc[e] = __builtin_fma(o.p[k], bval(p, s, isz, e), acc[e]);
         }
         st(p_coef(c, ov, 0), s, osz, acc);
         return;
@@ -447,7 +447,7 @@ SANM_HD void op_lincomb_t(const TetCtx& c, const OpDesc& o, int mode) {
     for (int k = 0; k < o.nin; ++k) {
         int iv = o.in[k], isz = c.vars[iv].size;
         if (c.vars[iv].is_const) continue;
-        for (int e = 0; e < osz; ++e) acc[e] += o.p[k] * cur_bval(c, iv, isz, e);
+        for (int e = 0; e < osz; ++e) acc[e] = __builtin_fma(o.p[k], cur_bval(c, iv, isz, e), acc[e]);
     }
     st_cur(c, ov, osz, acc, mode == PASS_COEFF);
 }
@@ -483,7 +483,7 @@ SANM_HD void op_multiply_t(const TetCtx& c, const OpDesc& o, int mode) {
                         jadd(c, iv, r, e, jget(c, ov, r, e) * bval(po, s, otsz, e));
                 } else {
                     double sum = 0;
-                    for (int e = 0; e < osz; ++e) sum += jget(c, ov, r, e) * bval(po, s, otsz, e);
+                    for (int e = 0; e < osz; ++e) sum = __builtin_fma(jget(c, ov, r, e), bval(po, s, otsz, e), sum);
                     jadd(c, iv, r, 0, sum);
                 }
             }
@@ -505,13 +505,13 @@ SANM_HD void op_multiply_t(const TetCtx& c, const OpDesc& o, int mode) {
                 const double *pa = p_coef(c, a, i), *pb = p_coef(c, b, c.order - i);
                 const double *pa2 = p_coef(c, a, i + 1), *pb2 = p_coef(c, b, c.order - i - 1);
                 for (int e = 0; e < osz; ++e) {
-                    sb[e] += bval(pa, s, asz, e) * bval(pb, s, bsz, e);
-                    sb2[e] += bval(pa2, s, asz, e) * bval(pb2, s, bsz, e);
+                    sb[e] = __builtin_fma(bval(pa, s, asz, e), bval(pb, s, bsz, e), sb[e]);
+                    sb2[e] = __builtin_fma(bval(pa2, s, asz, e), bval(pb2, s, bsz, e), sb2[e]);
                 }
             }
             for (; i < hi; ++i) {
                 const double *pa = p_coef(c, a, i), *pb = p_coef(c, b, c.order - i);
-                for (int e = 0; e < osz; ++e) sb[e] += bval(pa, s, asz, e) * bval(pb, s, bsz, e);
+                for (int e = 0; e < osz; ++e) sb[e] = __builtin_fma(bval(pa, s, asz, e), bval(pb, s, bsz, e), sb[e]);
             }
             for (int e = 0; e < osz; ++e) sb[e] += sb2[e];
             conv_reduce(c, sb, osz);
@@ -527,9 +527,9 @@ SANM_HD void op_multiply_t(const TetCtx& c, const OpDesc& o, int mode) {
         if (in_coeff) sb[e] = psb[e * s];
     }
     if (!c.vars[b].is_const)
-        for (int e = 0; e < osz; ++e) sb[e] += A0[e] * cur_bval(c, b, bsz, e);
+        for (int e = 0; e < osz; ++e) sb[e] = __builtin_fma(A0[e], cur_bval(c, b, bsz, e), sb[e]);
     if (!c.vars[a].is_const)
-        for (int e = 0; e < osz; ++e) sb[e] += cur_bval(c, a, asz, e) * B0[e];
+        for (int e = 0; e < osz; ++e) sb[e] = __builtin_fma(cur_bval(c, a, asz, e), B0[e], sb[e]);
     st_cur(c, ov, osz, sb, in_coeff);
 }
 
@@ -545,7 +545,7 @@ SANM_HD void op_multiply(const TetCtx& c, const OpDesc& o, int mode) {
 }
 
 // ---- LOG / POW: oprs/analytic_unary.cpp:113-158, analytic_unary.cpp:13-139
-//      aux0 = k = f'(x0) [sz], aux1 = self_bias [sz], aux2 = zero flag of a pow with exponent != 2 (one double)
+//      aux0 = k = f'(x0) [sz], aux1 = self_bias [sz], aux2 = zero flags of a pow with exponent != 2 (two doubles, raise-only)
 constexpr int POW_INT_MAX_ORDER = 32;
 SANM_HD bool pow_is_zero(double x) { return fabs(x) < 1e-3; }  // analytic_unary.cpp:43
 // [a^k] of (x_0 + x_1 a + ... + x_{k-1} a^{k-1})^p for an integer p >= 2 by repeated multiplication of truncated
@@ -559,7 +559,7 @@ SANM_HD double pow_int_bias(const TetCtx& c, int x, int e, int k, int p) {
     for (int m = 2; m <= p; ++m) {
         for (int d = 0; d <= k; ++d) {
             double sum = 0;
-            for (int i = 0; i <= d; ++i) sum += acc[i] * y[d - i];
+            for (int i = 0; i <= d; ++i) sum = __builtin_fma(acc[i], y[d - i], sum);
             nxt[d] = sum;
         }
         for (int d = 0; d <= k; ++d) acc[d] = nxt[d];
@@ -592,7 +592,12 @@ SANM_HD void op_unary_t(const TetCtx& c, const OpDesc& o, int mode) {
                     // analytic_unary.cpp:112-131: an integer exponent continues on the convolution path, anything
                     // else is SANMNumericalError{"0^p when p is not integer"} (reported by the driver)
                     const bool integer = pw > 0.5 && floor(pw) == pw;
-                    c.arena[o.aux[2]] = (integer && c.max_order <= POW_INT_MAX_ORDER) ? 0.0 : (integer ? 2.0 : 1.0);
+                    // The flag words are only ever RAISED by the kernels (the host clears them): word 0 = "0^p with a
+                    // non-integer p", word 1 = "integer p beyond POW_INT_MAX_ORDER".  All pow operators of a graph
+                    // share them, and every lane that stores a word stores the same value, so no operator and no
+                    // tet can hide another one's report.
+                    if (!integer) c.arena[o.aux[2]] = 1.0;
+                    else if (c.max_order > POW_INT_MAX_ORDER) c.arena[o.aux[2] + 1] = 2.0;
                 }
             }
         }
@@ -622,7 +627,7 @@ SANM_HD void op_unary_t(const TetCtx& c, const OpDesc& o, int mode) {
                     const double* p2 = int2 ? p_coef(c, x, k - i) : (is_log ? p_coef(c, ov, i) : p_coef(c, x, i));
                     double w = int2 ? 1.0 : (is_log ? -(double)i / (double)k
                                                     : (double)i / (double)k * (pw + 1.0) - 1.0);
-                    for (int e = 0; e < sz; ++e) sb[e] += p1[e * s] * p2[e * s] * w;
+                    for (int e = 0; e < sz; ++e) sb[e] = __builtin_fma(p1[e * s] * p2[e * s], w, sb[e]);
                 }
                 conv_reduce(c, sb, sz);
             }
@@ -646,7 +651,7 @@ SANM_HD void op_unary_t(const TetCtx& c, const OpDesc& o, int mode) {
         if (in_coeff) sb[e] = psb[e * s];
     }
     if (!c.vars[x].is_const)
-        for (int e = 0; e < sz; ++e) sb[e] += K[e] * cur_bval(c, x, sz, e);
+        for (int e = 0; e < sz; ++e) sb[e] = __builtin_fma(K[e], cur_bval(c, x, sz, e), sb[e]);
     st_cur(c, ov, sz, sb, in_coeff);
 }
 
@@ -932,7 +937,7 @@ SANM_HD void op_det(const TetCtx& c, const OpDesc& o, int mode) {
             ld(pcs + (int64_t)(k - j) * 3 * s, s, 3, cm);
             cross3(r1, r2, t);
             ck[0] += t[0]; ck[1] += t[1]; ck[2] += t[2];
-            ck[3] += r0[0] * cm[0] + r0[1] * cm[1] + r0[2] * cm[2];
+            ck[3] += __builtin_fma(r0[2], cm[2], __builtin_fma(r0[1], cm[1], r0[0] * cm[0]));
         }
         double x0[3];
         ld(p_coef(c, x, 0), s, 3, x0);
@@ -961,7 +966,7 @@ SANM_HD void op_det(const TetCtx& c, const OpDesc& o, int mode) {
         st(pcs + (int64_t)k * 3 * s, s, 3, ck);
     }
     double d = sb;
-    for (int e = 0; e < 9; ++e) d += C[e] * X[e];
+    for (int e = 0; e < 9; ++e) d = __builtin_fma(C[e], X[e], d);
     st_cur(c, ov, 1, &d, in_coeff);
 }
 
@@ -1075,7 +1080,7 @@ SANM_HD void op_svdw_full(const TetCtx& c, const OpDesc& o, int mode) {
             mm3<true, false, true>(Bu, A, B);  // U_i' U_{k-i}
             ld(p_coef(c, sv, k - i), s, 3, D);
             for (int r = 0; r < 3; ++r)
-                for (int q = 0; q < 3; ++q) t0k[r * 3 + q] += A[r * 3 + q] * D[q];  // U_i diag(S_{k-i})
+                for (int q = 0; q < 3; ++q) t0k[r * 3 + q] = __builtin_fma(A[r * 3 + q], D[q], t0k[r * 3 + q]);  // U_i diag(S_{k-i})
             ld9(pT0 + (int64_t)i * 9 * s, s, A);
             mm3<false, true, true>(t1k, A, B);  // T0_i U_{k-i}'
             ld9(p_coef(c, wv, i), s, A);
@@ -1249,7 +1254,7 @@ SANM_HD void conv_term_multiply(const TetCtx& c, const OpDesc& o, int i, int j, 
     double A[ASZ], B[BSZ];
     ldh<ASZ>(c, o.in[0], i, A);
     ldh<BSZ>(c, o.in[1], j, B);
-    for (int e = 0; e < osz; ++e) acc[e] += A[ASZ == 1 ? 0 : e] * B[BSZ == 1 ? 0 : e];
+    for (int e = 0; e < osz; ++e) acc[e] = __builtin_fma(A[ASZ == 1 ? 0 : e], B[BSZ == 1 ? 0 : e], acc[e]);
 }
 template <int SZ>
 SANM_HD void conv_term_unary(const TetCtx& c, const OpDesc& o, int i, int j, double* acc) {
@@ -1269,7 +1274,7 @@ SANM_HD void conv_term_unary(const TetCtx& c, const OpDesc& o, int i, int j, dou
         ldh<SZ>(c, x, i, P2);
         w = (double)i / k * (pw + 1.0) - 1.0;
     }
-    for (int e = 0; e < SZ; ++e) acc[e] += P1[e] * P2[e] * w;
+    for (int e = 0; e < SZ; ++e) acc[e] = __builtin_fma(P1[e] * P2[e], w, acc[e]);
 }
 SANM_HD void conv_term(const TetCtx& c, const OpDesc& o, int i, int j, double* acc) {
     if (!o.conv_n) return;
@@ -1318,7 +1323,7 @@ SANM_HD void conv_term(const TetCtx& c, const OpDesc& o, int i, int j, double* a
             ld(p_aux(c, o.aux[2]) + (int64_t)j * 3 * s, s, 3, cm);
             cross3(A + 3, B + 6, t);
             acc[0] += t[0]; acc[1] += t[1]; acc[2] += t[2];
-            acc[3] += A[0] * cm[0] + A[1] * cm[1] + A[2] * cm[2];
+            acc[3] += __builtin_fma(A[2], cm[2], __builtin_fma(A[1], cm[1], A[0] * cm[0]));
             break;
         }
         case OP_SVDW: {
@@ -1330,7 +1335,7 @@ SANM_HD void conv_term(const TetCtx& c, const OpDesc& o, int i, int j, double* a
                 mm3<true, false, true>(acc, A, B);
                 ldh<3>(c, sv, j, D);
                 for (int r = 0; r < 3; ++r)
-                    for (int q = 0; q < 3; ++q) acc[27 + r * 3 + q] += A[r * 3 + q] * D[q];
+                    for (int q = 0; q < 3; ++q) acc[27 + r * 3 + q] = __builtin_fma(A[r * 3 + q], D[q], acc[27 + r * 3 + q]);
                 ld9(p_aux(c, o.aux[0]) + (int64_t)i * 9 * s, s, A);
                 mm3<false, true, true>(acc + 36, A, B);
                 ldh<9>(c, wv, i, A);
@@ -1368,7 +1373,7 @@ SANM_HD void gather_remap_in(const TetCtx& c, const RemapInDev& rin, const doubl
         }
         for (int e = 0; e < 9; ++e) {
             double acc = 0;
-            for (int sl = 0; sl < NSLOT; ++sl) acc += coef[sl * 9 + e] * xvec[idx[sl * 9 + e]];
+            for (int sl = 0; sl < NSLOT; ++sl) acc = __builtin_fma(coef[sl * 9 + e], xvec[idx[sl * 9 + e]], acc);
             X[e] = acc;
         }
     } else {
@@ -1376,7 +1381,7 @@ SANM_HD void gather_remap_in(const TetCtx& c, const RemapInDev& rin, const doubl
             double acc = 0;
             for (int sl = 0; sl < rin.nslot; ++sl) {
                 int64_t off = ((int64_t)sl * 9 + e) * s + c.tet;
-                acc += rin.coef[off] * xvec[rin.idx[off]];
+                acc = __builtin_fma(rin.coef[off], xvec[rin.idx[off]], acc);
             }
             X[e] = acc;
         }

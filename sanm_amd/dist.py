@@ -11,15 +11,51 @@ from __future__ import annotations
 import ctypes
 
 
-def init_native_comm(api, rank, world):
+def init_native_comm(api, rank, world, device="cuda"):
     """The library's own RCCL communicator (sanm_hip_comm_init): ncclAllReduce is queued on the solver's stream,
     so the sharded order loop runs without host synchronisation.  The 128-byte identifier travels from rank 0
-    to the others through torch.distributed's default group (any out-of-band channel would do)."""
-    uid = [api.comm_unique_id() if rank == 0 else None]
+    to the others through torch.distributed's default group (any out-of-band channel would do).
+
+    Returns True when EVERY rank holds the communicator, False when all ranks agreed to use the callback path
+    instead.  Every rank takes the same sequence of torch.distributed collectives whatever fails where:
+
+      1. each rank probes whether RCCL can be loaded from C++ (no collective involved); rank 0 also draws the
+         identifier -- a failure there becomes "not available", not an exception that skips the broadcast;
+      2. broadcast of the identifier (None on failure), MIN all-reduce of the availability flags;
+      3. only if all ranks are able: ncclCommInitRank (itself a collective), then a MIN all-reduce of its
+         outcomes; a rank whose init failed makes every rank drop its communicator again.
+    """
+    ok = 1 if api.comm_available() else 0
+    uid = [None]
+    if rank == 0 and ok:
+        try:
+            uid[0] = api.comm_unique_id()
+        except Exception:  # noqa: BLE001 -- reported through the flag below
+            ok = 0
+    dist = None
     if world > 1:
+        import torch
         import torch.distributed as dist
         dist.broadcast_object_list(uid, src=0)
-    api.comm_init(rank, world, uid[0])
+        if uid[0] is None:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = int(flag.item())
+    if not ok or uid[0] is None:
+        return False
+    try:
+        api.comm_init(rank, world, uid[0])
+    except Exception:  # noqa: BLE001
+        ok = 0
+    if dist is not None:
+        import torch
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if ok and not int(flag.item()):
+            api.comm_destroy()
+        ok = int(flag.item())
+    return bool(ok)
 
 
 class _DevicePtr:

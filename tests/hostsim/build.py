@@ -23,7 +23,7 @@ def build(force=False):
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
         return OUT
-    cmd = ["g++", "-O2", "-std=c++20", "-fPIC", "-shared", "-pthread", "-Wl,-Bsymbolic", "-Wall",
+    cmd = ["g++", "-O2", "-ffp-contract=off", "-mfma", "-std=c++20", "-fPIC", "-shared", "-pthread", "-Wl,-Bsymbolic", "-Wall",
            "-Wno-unused-function", "-I", CSRC, "-o", OUT] + srcs + ["-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

@@ -247,16 +247,45 @@ def test_unsupported_and_invalid_graphs(api):
 
 
 def test_host_poly_helpers(api):
-    rng = np.random.default_rng(5)
-    cf0 = rng.uniform(-1, 1, 8)
-    cf0[7] = 2.3
-    coeffs = np.convolve(cf0, [-12, 1, 1])  # tests/pade.cpp:16-62
-    roots = api.poly_real_roots(coeffs)
-    assert roots is not None and len(roots) >= 2
+    """sanm_poly_roots / sanm_poly_real_roots / sanm_poly_solve_eqn (the product's host code, poly.cpp) against
+    tests/golden/ref_poly.json -- outcomes of the reference's own unary_polynomial.cpp + BRENT compiled with g++ -O2
+    (tests/golden/make_ref_poly.py): the valid flag (None => the Pade approximant is rejected, pade.cpp:113-116)
+    exactly, roots and Brent zeros bit for bit."""
+    import json
+    import os
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_poly.json")))
+    unhex = lambda h: np.array([float.fromhex(v) for v in h])
+    n_invalid = 0
+    for rec in fx["roots"]:
+        f = unhex(rec["f"])
+        got = api.poly_real_roots(f)
+        assert (got is not None) == rec["valid"], rec["src"]
+        if got is None:
+            n_invalid += 1
+            continue
+        assert np.array_equal(got, unhex(rec["real"]), equal_nan=True), rec["src"]
+        full = api.poly_roots(f, only_real=False)
+        assert (full is None) == (rec["all"] is None)
+        if full is not None:
+            want = np.array([complex(float.fromhex(re), float.fromhex(im)) for re, im in rec["all"]])
+            assert np.array_equal(full.real, want.real, equal_nan=True) and np.array_equal(full.imag, want.imag)
+    assert n_invalid > 0
+    for rec in fx["solve_eqn"]:
+        a = [float.fromhex(rec[k]) for k in ("xmin", "xmax", "b", "eps")]
+        assert api.poly_solve_eqn(unhex(rec["f"]), *a) == float.fromhex(rec["x"])
+    kat = fx["kat"]  # tests/pade.cpp:16-62
+    roots = api.poly_real_roots(unhex(kat["f"]))
+    assert np.array_equal(roots, unhex(kat["real"]))
     assert min(abs(roots - 3)) < 1e-9 and min(abs(roots + 4)) < 1e-9
+    # and live against the oracle's restatement
     from oracle import unary_polynomial as up
-    want = sorted(up.real_roots(coeffs))
-    assert len(want) == len(roots) and np.allclose(sorted(roots), want, atol=1e-8)
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        f = rng.uniform(-1, 1, int(rng.integers(3, 21))) * 0.5 ** np.arange(1)
+        want, got = up.roots(f, False), api.poly_roots(f, False)
+        assert (want is None) == (got is None)
+        if want is not None:
+            assert np.array_equal(got, np.array(want, dtype=complex), equal_nan=True)
     f = rng.uniform(-1, 1, 7)
     f[0] = -abs(f[0])
     hi = 1.0

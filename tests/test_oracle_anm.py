@@ -48,17 +48,22 @@ def test_taylor_prop_matches_direct_evaluation(energy, mode):
 
 
 def test_polynomial_roots_kat():
-    # tests/pade.cpp:16-62: q(x) * (x-3)(x+4) has the real roots 3 and -4
+    # tests/pade.cpp:16-62: q(x) * (x-3)(x+4) has the real roots 3 and -4 (bit-exact pins: test_oracle_ref_poly.py)
     rng = np.random.default_rng(5)
     N = 10
     cf0 = rng.uniform(-1, 1, N - 2)
     cf0[N - 3] = 2.3
     coeffs = np.convolve(cf0, [-12, 1, 1])
+    allr = up.roots(coeffs, False)
+    assert allr is not None and len(allr) == N - 1
+    for z in allr:
+        s = 0j
+        for c in coeffs[::-1]:
+            s = s * z + c
+        assert abs(s.real) < 2e-4 and abs(s.imag) < 2e-4
     roots = up.real_roots(coeffs)
-    assert roots is not None and len(roots) >= 2
+    assert sorted(roots) == sorted(z.real for z in allr if z.imag == 0) and len(roots) >= 2
     assert min(abs(r - 3) for r in roots) < 1e-8 and min(abs(r + 4) for r in roots) < 1e-8
-    for r in roots:
-        assert abs(up.eval_poly(coeffs, r)) < 2e-4
 
 
 def test_brent_solve_eqn():
