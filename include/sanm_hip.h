@@ -244,6 +244,16 @@ int sanm_anm_profile_counts(const sanm_anm_solver* s, int max_tags, double* coun
 int sanm_anm_set_profile(sanm_anm_solver* s, int mode, int clear);
 /* per-order trace of the last expansion (needs hp.profile): |b_k|, |x_k|, t_k; returns count */
 int sanm_anm_trace(const sanm_anm_solver* s, int max_n, double* b_norm, double* x_norm, double* t);
+/* Decisions of the last Pade range estimate (PadeApproximation::estimate_valid_range, pade.cpp:107-173), for
+ * decision-by-decision comparison with another implementation:
+ *   head[0] attempted (use_pade && a_bound < stable range, anm.cpp:143-152)   head[1] denominator built
+ *   head[2] roots() returned a value (None => rejected, pade.cpp:113-116)     head[3] accepted
+ *   head[4] start (= a_bound)   head[5] pole   head[6] accepted range t_max_a   head[7] number of probes
+ * d: denominator coefficients m_d, low order first (*nd of them; d_cap entries are written at most);
+ * probes: triples (a, margin, ok) of every check(a) in the reference's order (pade.cpp:129-165), with
+ * margin = |pn_lo * D_n / D_lo - pn|^2 / (eps^2 |pn|^2): a probe passes iff margin <= 1. */
+int sanm_anm_pade_diag(const sanm_anm_solver* s, double head[8], double* d, int d_cap, int* nd, double* probes,
+                       int probe_cap);
 /* Jacobian CSR of the current step (SparseSolver contents, sparse_solver.cpp:327-421);
  * pass NULL pointers to query sizes only */
 int sanm_anm_jacobian_csr(const sanm_anm_solver* s, int64_t* n, int64_t* nnz, uint32_t* rowptr,

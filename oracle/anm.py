@@ -17,6 +17,7 @@ shape (out_size, in_size): ``apply`` (anm.cpp:55-75) is a mat-vec.
 """
 from __future__ import annotations
 
+import math
 import os
 import time
 
@@ -167,6 +168,7 @@ class ANMDriverHelper:
         self.xt_coeffs = []
         self.t_coeffs = []
         self.pade = None
+        self.pade_diags = []  # decision record of every range estimate (PadeApproximation.diag)
         self.verbose = os.environ.get("SANM_VERBOSE") is not None
         self.profile = {}
         self.trace = []  # per-step records (norms of b_k, x_k, t_k) for fixtures
@@ -284,7 +286,7 @@ class ANMDriverHelper:
         hp = self.hp
         x1 = float(np.linalg.norm(self.xt_coeffs[1]))
         xback = max(float(np.linalg.norm(self.xt_coeffs[-1])), 1e-15)
-        a_bound = float(np.power(hp.maxr / xback * x1, 1.0 / float(hp.order - 1)))
+        a_bound = math.pow(hp.maxr / xback * x1, 1.0 / float(hp.order - 1))  # libm pow (anm.cpp:126)
         a_bound = min(a_bound, self.max_a_bound)
         self.t_coeffs = [float(c[self.n]) for c in self.xt_coeffs]
         assert self.t_coeffs[1] > 0
@@ -293,9 +295,15 @@ class ANMDriverHelper:
         assert self.t_max > self.t_coeffs[0], "t does not incr"
         self.pade = None
         use_pade_env = os.environ.get("SANM_PADE") is not None
+        diag = {"attempted": False, "accepted": False, "start": a_bound}
+        self.pade_diags.append(diag)
+        self.a_bound = a_bound
         if (hp.use_pade or use_pade_env) and a_bound < self.max_a_bound:
             pade = PadeApproximation(self.xt_coeffs, not hp.xcoeff_l2_penalty, False)
-            if pade.estimate_valid_range(a_bound, hp.maxr, self.max_a_bound):
+            self.pade_candidate = pade  # (kept for the lock-step tests even when rejected)
+            ok = pade.estimate_valid_range(a_bound, hp.maxr, self.max_a_bound)
+            diag.update(pade.diag)
+            if ok:
                 self.pade = pade
                 self.t_max_a = pade.t_max_a
                 self.t_max = pade.t_max

@@ -22,6 +22,7 @@ class PadeApproximation:
         self.t0 = 0.0
         self.t_max = 0.0
         self.t_max_a = 0.0
+        self.diag = None
         nx = len(xs)
         assert nx >= 3 and xs[0].ndim == 1
         if xs[0].shape[0] < nx * 2 or nx <= 4:
@@ -86,19 +87,25 @@ class PadeApproximation:
         return up.eval_poly(self.t_nume, a) / up.eval_poly(self.d, a) + self.t0
 
     def estimate_valid_range(self, start, eps, limit=0.0):
-        """pade.cpp:107-173."""
+        """pade.cpp:107-173.  Every discrete decision is recorded with the quantity it was taken on in
+        ``self.diag`` (same fields as the product's sanm_anm_pade_diag): ``margin`` of a probe is
+        |pn_lo * D_n / D_lo - pn|^2 / (eps^2 |pn|^2) of check(a), pade.cpp:129-138 -- it passes iff margin <= 1."""
         assert start > 0 and eps > 0
+        dg = self.diag = {"attempted": True, "built": bool(self.d), "roots_valid": False, "accepted": False,
+                          "start": start, "pole": 0.0, "t_max_a": 0.0, "d": list(self.d), "probes": []}
         if not self.d:
             return False
         roots = up.real_roots(self.d)
         if roots is None:
             return False
+        dg["roots_valid"] = True
         pole = 0.0
         for r in roots:
             if r > 0 and (pole == 0 or r < pole):
                 pole = r
         if pole == 0:
             pole = start * 4
+        dg["pole"] = pole
         if pole <= start:
             return False
         n = len(self.xs) - 2
@@ -110,7 +117,10 @@ class PadeApproximation:
             pn = self.eval_nume(a, self.d, n)
             pn_lo = self.eval_nume(a, self.d_lo, n - 1)
             pn_lo = pn_lo * (denom_n / denom_lo) - pn
-            return float(np.dot(pn_lo, pn_lo)) <= float(np.dot(pn, pn)) * eps2
+            num, den = float(np.dot(pn_lo, pn_lo)), float(np.dot(pn, pn))
+            ok = num <= den * eps2
+            dg["probes"].append((a, num / (den * eps2) if den > 0 else float("inf"), ok))
+            return ok
 
         left = start * 1.001
         right = start + (pole - start) * 0.99
@@ -133,6 +143,8 @@ class PadeApproximation:
             it += 1
         self.t_max_a = left
         self.t_max = self.eval_t(left)
+        dg["accepted"] = True
+        dg["t_max_a"] = left
         return True
 
     def solve_a(self, t):

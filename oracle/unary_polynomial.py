@@ -35,7 +35,7 @@ def eval_poly(f, x):
 
 def stable_x_range(order):
     """unary_polynomial.cpp:97-103."""
-    return float(np.power(1e15, 1.0 / float(order)))
+    return math.pow(1e15, 1.0 / float(order))  # (libm pow like the reference; numpy differs in the last bit)
 
 
 def brent_zero(a, b, t, f):

@@ -84,7 +84,7 @@ SYMBOLS = [
     "sanm_anm_update_approx", "sanm_anm_restart", "sanm_anm_run_steps", "sanm_anm_spec_source", "sanm_rtc_compile_check", "sanm_anm_time_kernel", "sanm_anm_pass_timing", "sanm_anm_converged", "sanm_anm_residual_rms", "sanm_anm_get_x",
     "sanm_anm_get_t_upper", "sanm_anm_get_t_max_a", "sanm_anm_solve_a", "sanm_anm_eval",
     "sanm_anm_nr_iter", "sanm_anm_nr_xt_coeffs", "sanm_anm_xt_coeff", "sanm_anm_has_pade",
-    "sanm_anm_get_stats", "sanm_anm_profile", "sanm_anm_profile_counts", "sanm_anm_set_profile", "sanm_anm_debug_inject", "sanm_anm_trace", "sanm_anm_jacobian_csr",
+    "sanm_anm_get_stats", "sanm_anm_profile", "sanm_anm_profile_counts", "sanm_anm_set_profile", "sanm_anm_debug_inject", "sanm_anm_trace", "sanm_anm_pade_diag", "sanm_anm_jacobian_csr",
     "sanm_fea_model_create", "sanm_fea_model_destroy", "sanm_fea_model_nr_unknown",
     "sanm_fea_model_graph", "sanm_fea_model_output_var", "sanm_fea_model_F_var",
     "sanm_fea_model_remap_inp", "sanm_fea_model_remap_out", "sanm_fea_model_x0",
@@ -557,6 +557,20 @@ class _ANMSolver:
         b, x, t = np.zeros(max(n, 1)), np.zeros(max(n, 1)), np.zeros(max(n, 1))
         n = self.api.lib.sanm_anm_trace(self.h, C.c_int(n), _dp(b), _dp(x), _dp(t))
         return {"b_norm": b[:n].tolist(), "x_norm": x[:n].tolist(), "t": t[:n].tolist()}
+
+    def pade_diag(self):
+        """decisions of the last Pade range estimate (sanm_anm_pade_diag)"""
+        head = np.zeros(8)
+        d = np.zeros(64)
+        probes = np.zeros(3 * 32)
+        nd = C.c_int()
+        self.api.check(self.api.lib.sanm_anm_pade_diag(self.h, _dp(head), _dp(d), C.c_int(64), C.byref(nd),
+                                                       _dp(probes), C.c_int(32)))
+        npr = int(head[7])
+        return {"attempted": bool(head[0]), "built": bool(head[1]), "roots_valid": bool(head[2]),
+                "accepted": bool(head[3]), "start": head[4], "pole": head[5], "t_max_a": head[6],
+                "d": d[:nd.value].copy(),
+                "probes": [(probes[3 * i], probes[3 * i + 1], bool(probes[3 * i + 2])) for i in range(npr)]}
 
     def spec_source(self):
         """HIP source of the pass kernels specialised for this solver's graph (sanm_anm_spec_source)."""

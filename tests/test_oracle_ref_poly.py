@@ -85,12 +85,18 @@ def test_reference_kat_roots_3_and_minus_4():
 
 
 def test_degenerate_inputs():
-    assert up.roots([1.0, 0.0], False) == []                 # constant after stripping: no roots
-    assert up.roots([0.0, 0.0, 1.0], False) == []            # x^2: zero roots are stripped, not reported
-    assert up.roots([-6.0, 1.0, 1.0], True) in ([2 + 0j, -3 + 0j], [-3 + 0j, 2 + 0j])
+    # (expected values: the reference library itself on these inputs, oracle/_ref/libref_poly_O2.so)
+    assert up.roots([0.0, 1.0], False) == []                  # x: the zero root is stripped, not reported
+    assert up.roots([0.0, 0.0, 1.0], False) == []             # x^2 likewise
+    assert up.roots([0.0, 0.0, 2.0, 1.0], True) == [-2 + 0j]  # x^2 (x + 2)
+    assert up.roots([-6.0, 1.0, 1.0], True) == [-3 + 0j, 2 + 0j]
     assert up.roots([1.0, 0.0, 1.0], True) == []              # x^2 + 1: no real root
     r = up.roots([1.0, 0.0, 1.0], False)
-    assert sorted(z.imag for z in r) == [-1.0, 1.0]
+    assert [z.imag for z in r] == [1.0, -1.0] and all(z.real == 0 for z in r)
+    r = up.roots([1.0, 0.0], True)                            # zero leading coefficient: -1/0
+    assert len(r) == 1 and r[0].real == -np.inf
+    r = up.roots([1.0, 2.0, 0.0, 0.0], True)                  # two zero leading coefficients: a root and two NaNs
+    assert r[0] == -0.5 + 0j and len(r) == 3 and all(z.real != z.real for z in r[1:])
     with pytest.raises(AssertionError):
         up.roots([1.0], True)
 
@@ -116,6 +122,8 @@ def test_live_against_reference_library():
             f = rng.uniform(-1, 1, deg + 1) * 10.0 ** rng.uniform(-8, 8, deg + 1)
         if trial % 7 == 0:
             f[0] = 0.0
+        if trial % 11 == 0:
+            f[-1] = 0.0
         for only_real in (True, False):
             a, b = ref.roots(f, only_real), up.roots(f, only_real)
             assert (a is None) == (b is None)

@@ -21,7 +21,8 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
 api = get_hostsim_api()
 cfg = {{"material": {{"young": {young!r}, "poisson": 0.45, "density": 1000.0}}, "g": [0, -9.81, 0],
-       "boundary_thresh": 0.05, "boundary_proj_dir": [-1, 0, 0], "energy_model": {energy!r}, "order": 12}}
+       "boundary_thresh": 0.05, "boundary_proj_dir": [-1, 0, 0], "energy_model": {energy!r}, "order": 12,
+       "disable_pade": {nopade!r}}}
 ncall = [0]
 base = sdist.make_host_allreduce()
 def counted(ptr, count):
@@ -47,13 +48,13 @@ def _free_port():
     return p
 
 
-def _run(energy, young, world=2):
+def _run(energy, young, world=2, nopade=True):
     port = _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, "-c", WORKER.format(root=ROOT, energy=energy, young=young)], env=env,
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER.format(root=ROOT, energy=energy, young=young, nopade=nopade)], env=env,
                                       cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     res = []
     for p in procs:
@@ -64,12 +65,14 @@ def _run(energy, young, world=2):
 
 
 def test_two_rank_tet_shard_matches_single_rank():
-    # (the very soft ARAP cantilever sits on a knife-edge Pade decision that flips with
-    # the summation order of the all-reduce; a stiffer one is used for that energy)
-    for energy, young in (("neohookean_c", 3e3), ("arap", 2e4)):
-        res = _run(energy, young)
+    # Same equilibrium always; same step count without Pade.  (With Pade the summation order of the all-reduce can
+    # flip an ill-conditioned Pade decision -- tests/lockstep.py -- and with it the count: the ranks still agree
+    # with each other, because they all see the same reduced vectors.)
+    for energy, young, nopade in (("neohookean_c", 3e3, True), ("arap", 2e4, True), ("neohookean_c", 3e3, False)):
+        res = _run(energy, young, nopade=nopade)
         for r in res:
-            assert r["steps"] == r["ref_steps"]
+            if nopade:
+                assert r["steps"] == r["ref_steps"]
             assert r["err"] < 1e-9
             assert r["rms"] < 1e-10
             # per completed step: f(x0) + Jacobian values + (order-1) b_k; plus f(x0) of the converged call
