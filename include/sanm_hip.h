@@ -88,6 +88,10 @@ void sanm_direct_solver_destroy(sanm_direct_solver* s);
 int sanm_direct_solver_factor(sanm_direct_solver* s, const double* val, int* nr_bad_pivot);
 /* solve (sparse_solver.cpp:154-180) */
 int sanm_direct_solver_solve(sanm_direct_solver* s, const double* b, double* x);
+/* apply (sparse_solver.cpp:202-215): y = A x with the values of the last factor call */
+int sanm_direct_solver_apply(sanm_direct_solver* s, const double* x, double* y);
+/* coeff_l2 (sparse_solver.cpp:217-223): Frobenius norm of the values of the last factor call */
+int sanm_direct_solver_coeff_l2(sanm_direct_solver* s, double* l2);
 int sanm_direct_solver_stats(const sanm_direct_solver* s, int64_t* nnz_factors, double* flops,
                              int32_t* nr_front, int32_t* nr_level, int32_t* max_front,
                              int32_t* root_pivots, int32_t* nr_supervar);
@@ -244,6 +248,12 @@ int sanm_anm_profile_counts(const sanm_anm_solver* s, int max_tags, double* coun
 int sanm_anm_set_profile(sanm_anm_solver* s, int mode, int clear);
 /* per-order trace of the last expansion (needs hp.profile): |b_k|, |x_k|, t_k; returns count */
 int sanm_anm_trace(const sanm_anm_solver* s, int max_n, double* b_norm, double* x_norm, double* t);
+/* What the reference prints per expansion under SANM_VERBOSE (anm.cpp:200-203, :247-259, :295-309), in its format:
+ *   "=== ANM iter K:\ngt=.. xgt=.. jacob=.. 1:(bi=.. xbi=..) 2:(..) ...\nbound=.. t=..\nx(a): ..\nt(a): ..,\n"
+ * of the last expansion (needs hp.profile = 1, or the environment variable SANM_VERBOSE, which also makes the
+ * driver print it to stdout after every expansion like the reference).  Returns the length of the text; at most
+ * cap - 1 characters and a terminating 0 are written to buf (buf may be NULL to query the length). */
+int64_t sanm_anm_verbose_text(const sanm_anm_solver* s, char* buf, int64_t cap);
 /* Decisions of the last Pade range estimate (PadeApproximation::estimate_valid_range, pade.cpp:107-173), for
  * decision-by-decision comparison with another implementation:
  *   head[0] attempted (use_pade && a_bound < stable range, anm.cpp:143-152)   head[1] denominator built

@@ -47,6 +47,11 @@ class HyperParam:
             setattr(self, k, v)
 
 
+def _g(v, prec=6):
+    """C's %g / %.3g"""
+    return "%.*g" % (prec, float(v))
+
+
 def assert_allclose(msg, a, b, eps=1e-4):
     """TensorND::assert_allclose (libsanm/tensor.cpp:670-684): |a-b| <=
     eps*max(1, min(|a|,|b|))."""
@@ -242,11 +247,15 @@ class ANMDriverHelper:
                 self._tic("sparse_solve", t0)
                 xbi = bi
                 t1 = ti = 1.0 / np.sqrt(float(np.dot(xgt, xgt)) + 1.0)
+                # anm.cpp:247-250 (SANM_VERBOSE): |gt|, |xgt|, SparseSolver::coeff_l2
+                vtext = "gt=%s xgt=%s jacob=%s" % (_g(np.linalg.norm(grad_t)), _g(np.linalg.norm(xgt)),
+                                                   _g(solver.coeff_l2()))
             else:
                 t0 = time.perf_counter()
                 xbi = solver.solve(bi)
                 self._tic("sparse_solve", t0)
                 ti = float(np.dot(xbi, x1)) / (t1 - xgt_dot_x1)
+            vtext += " %d:(bi=%s xbi=%s)" % (i, _g(np.linalg.norm(bi)), _g(np.linalg.norm(xbi)))  # anm.cpp:257-259
             xi = np.empty(self.n + 1)
             xi[:self.n] = xgt * (-ti) - xbi
             xi[self.n] = ti
@@ -279,6 +288,15 @@ class ANMDriverHelper:
         rec["t_max"] = self.t_max
         rec["pade"] = self.pade is not None
         self.trace.append(rec)
+        # the reference's SANM_VERBOSE printout (anm.cpp:200-203, :295-309)
+        vtext = "=== ANM iter %d:\n" % self.iter + vtext + "\nbound=%s t=%s\n" % (_g(self.t_max_a), _g(self.t_max))
+        vtext += "x(a):" + "".join(" %s" % _g(np.linalg.norm(c), 3) for c in self.xt_coeffs)
+        vtext += "\nt(a):" + "".join(" %s," % _g(t, 3) for t in self.t_coeffs) + "\n"
+        if self.hp.xcoeff_l2_penalty:
+            vtext += "xcoeff_l2_penalty=%s\n" % _g(self.hp.xcoeff_l2_penalty)
+        self.verbose_text = vtext
+        if self.verbose:
+            print(vtext, end="", flush=True)
         self.iter += 1
 
     def estimate_valid_range(self):

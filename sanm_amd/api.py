@@ -74,7 +74,7 @@ SYMBOLS = [
     "sanm_graph_batched_svd_w",
     "sanm_sparse_desc_create", "sanm_sparse_desc_destroy", "sanm_sparse_desc_get",
     "sanm_sparse_desc_set_out_coords", "sanm_direct_solver_create", "sanm_direct_solver_destroy",
-    "sanm_direct_solver_factor", "sanm_direct_solver_solve", "sanm_direct_solver_stats",
+    "sanm_direct_solver_factor", "sanm_direct_solver_solve", "sanm_direct_solver_stats", "sanm_direct_solver_apply", "sanm_direct_solver_coeff_l2",
     "sanm_taylor_create", "sanm_taylor_destroy", "sanm_taylor_push_xi",
     "sanm_taylor_compute_next_order_bias", "sanm_taylor_output_size", "sanm_taylor_get_jacobian", "sanm_taylor_get_var",
     "sanm_taylor_reset",
@@ -84,7 +84,7 @@ SYMBOLS = [
     "sanm_anm_update_approx", "sanm_anm_restart", "sanm_anm_run_steps", "sanm_anm_spec_source", "sanm_rtc_compile_check", "sanm_anm_time_kernel", "sanm_anm_pass_timing", "sanm_anm_converged", "sanm_anm_residual_rms", "sanm_anm_get_x",
     "sanm_anm_get_t_upper", "sanm_anm_get_t_max_a", "sanm_anm_solve_a", "sanm_anm_eval",
     "sanm_anm_nr_iter", "sanm_anm_nr_xt_coeffs", "sanm_anm_xt_coeff", "sanm_anm_has_pade",
-    "sanm_anm_get_stats", "sanm_anm_profile", "sanm_anm_profile_counts", "sanm_anm_set_profile", "sanm_anm_debug_inject", "sanm_anm_trace", "sanm_anm_pade_diag", "sanm_anm_jacobian_csr",
+    "sanm_anm_get_stats", "sanm_anm_profile", "sanm_anm_profile_counts", "sanm_anm_set_profile", "sanm_anm_debug_inject", "sanm_anm_trace", "sanm_anm_pade_diag", "sanm_anm_verbose_text", "sanm_anm_jacobian_csr",
     "sanm_fea_model_create", "sanm_fea_model_destroy", "sanm_fea_model_nr_unknown",
     "sanm_fea_model_graph", "sanm_fea_model_output_var", "sanm_fea_model_F_var",
     "sanm_fea_model_remap_inp", "sanm_fea_model_remap_out", "sanm_fea_model_x0",
@@ -414,6 +414,19 @@ class DirectSolver:
         self.api.check(self.api.lib.sanm_direct_solver_solve(self.h, _dp(b), _dp(x)))
         return x
 
+    def apply(self, x):
+        """SparseSolver::apply: A @ x with the values of the last factor()"""
+        x = _f64(x)
+        y = np.zeros(self.n)
+        self.api.check(self.api.lib.sanm_direct_solver_apply(self.h, _dp(x), _dp(y)))
+        return y
+
+    def coeff_l2(self):
+        """SparseSolver::coeff_l2: Frobenius norm of the values of the last factor()"""
+        out = C.c_double()
+        self.api.check(self.api.lib.sanm_direct_solver_coeff_l2(self.h, C.byref(out)))
+        return out.value
+
     def stats(self):
         nnz, fl = C.c_int64(), C.c_double()
         nf, nl, mf, rp, nsv = (C.c_int32() for _ in range(5))
@@ -557,6 +570,14 @@ class _ANMSolver:
         b, x, t = np.zeros(max(n, 1)), np.zeros(max(n, 1)), np.zeros(max(n, 1))
         n = self.api.lib.sanm_anm_trace(self.h, C.c_int(n), _dp(b), _dp(x), _dp(t))
         return {"b_norm": b[:n].tolist(), "x_norm": x[:n].tolist(), "t": t[:n].tolist()}
+
+    def verbose_text(self):
+        """the reference's SANM_VERBOSE printout of the last expansion (sanm_anm_verbose_text)"""
+        self.api.lib.sanm_anm_verbose_text.restype = C.c_int64
+        n = self.api.lib.sanm_anm_verbose_text(self.h, None, C.c_int64(0))
+        buf = C.create_string_buffer(n + 1)
+        self.api.lib.sanm_anm_verbose_text(self.h, buf, C.c_int64(n + 1))
+        return buf.value.decode()
 
     def pade_diag(self):
         """decisions of the last Pade range estimate (sanm_anm_pade_diag)"""

@@ -2,6 +2,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdarg>
+#include <cstdio>
 #include <exception>
 #include <cstdlib>
 #include <cstring>
@@ -12,6 +14,18 @@
 #include "tet_ops.h"
 
 namespace sanm_hip {
+namespace {
+std::string ssprintf(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+std::string ssprintf(const char* fmt, ...) {
+    char buf[256];
+    va_list ap;
+    va_start(ap, fmt);
+    const int k = std::vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    return std::string(buf, buf + std::min<int>(std::max(k, 0), (int)sizeof buf - 1));
+}
+}  // namespace
+
 
 // ------------------------------------------------------------ profiling --
 class AnmDriver::ScopedTimer {
@@ -792,6 +806,9 @@ void AnmDriver::solve_expansion_coeffs() {
     trace_b_norm.clear();
     trace_x_norm.clear();
     trace_t.clear();
+    m_trace_xbi_norm.clear();
+    static const bool env_verbose = std::getenv("SANM_VERBOSE") != nullptr;
+    const bool verbose = env_verbose || m_profile_mode == 1;
 
     {
         ScopedTimer t{this, "taylor_order0"};
@@ -979,10 +996,16 @@ void AnmDriver::solve_expansion_coeffs() {
             be->side_end();
         }
 
-        if (m_profile_mode == 1) {
+        if (verbose) {
             trace_b_norm.push_back(std::sqrt(be->dot(n, bi, bi)));
             trace_x_norm.push_back(std::sqrt(be->dot(n1, xi, xi)));
             trace_t.push_back(m_host_scalars[3 * i]);  // valid: the dot above synchronised
+            m_trace_xbi_norm.push_back(std::sqrt(be->dot(n, xbi, xbi)));
+            if (i == 1) {  // anm.cpp:247-250: |gt|, |xgt|, SparseSolver::coeff_l2 (sparse_solver.cpp:217-223)
+                m_trace_gt = std::sqrt(be->dot(n, grad_t, grad_t));
+                m_trace_xgt = std::sqrt(be->dot(n, m_xgt.p(), m_xgt.p()));
+                m_trace_jacob = std::sqrt(be->dot(m_pattern->nnz(), m_pattern->csr().val, m_pattern->csr().val));
+            }
         }
         if (i < N) {
             ScopedTimer t{this, "taylor_push"};
@@ -1055,6 +1078,25 @@ void AnmDriver::solve_expansion_coeffs() {
         check_sanity();
     }
     if (held) std::rethrow_exception(held);
+    if (verbose) {
+        // the reference's printout, anm.cpp:200-203, :247-259, :295-309 (same format strings)
+        std::string& o = m_verbose_text;
+        o = ssprintf("=== ANM iter %zu:\n", m_iter);
+        o += ssprintf("gt=%g xgt=%g jacob=%g", m_trace_gt, m_trace_xgt, m_trace_jacob);
+        for (int i = 1; i <= N; ++i) o += ssprintf(" %d:(bi=%g xbi=%g)", i, trace_b_norm[i - 1], m_trace_xbi_norm[i - 1]);
+        o += ssprintf("\nbound=%g t=%g\n", m_t_max_a, m_t_max);
+        o += "x(a):";
+        o += ssprintf(" %.3g", std::sqrt(be->dot(n1, m_xt_coeffs[0].p(), m_xt_coeffs[0].p())));
+        for (int i = 1; i <= N; ++i) o += ssprintf(" %.3g", trace_x_norm[i - 1]);
+        o += "\nt(a):";
+        for (double t : m_t_coeffs) o += ssprintf(" %.3g,", t);
+        o += "\n";
+        if (m_hp.xcoeff_l2_penalty) o += ssprintf("xcoeff_l2_penalty=%g\n", m_hp.xcoeff_l2_penalty);
+        if (env_verbose) {
+            std::fputs(o.c_str(), stdout);
+            std::fflush(stdout);
+        }
+    }
     ++m_iter;
 }
 

@@ -243,6 +243,9 @@ public:
     void set_injection(const Injection& inj) { m_inject = inj; }
     //! per-order records of the last solve_expansion_coeffs (|b_k|, |x_k|, t_k)
     std::vector<double> trace_b_norm, trace_x_norm, trace_t;
+    //! what the reference prints per expansion under SANM_VERBOSE (anm.cpp:200-203, :247-259, :295-309), built when
+    //! profile mode 1 or SANM_VERBOSE is on
+    const std::string& verbose_text() const { return m_verbose_text; }
 
 protected:
     Backend* m_be;
@@ -269,6 +272,9 @@ protected:
     double m_t_max = 0, m_t_max_a = 0;
     std::unique_ptr<PadeApproximation> m_pade;
     PadeDiag m_pade_diag;
+    std::string m_verbose_text;
+    std::vector<double> m_trace_xbi_norm;
+    double m_trace_gt = 0, m_trace_xgt = 0, m_trace_jacob = 0;
     DVec m_fx0, m_bi, m_xbi, m_xgt, m_grad_t_buf, m_tmp0, m_tmp1;
     std::vector<DVec> m_bi_all;  // b_i of every order, kept for the checks after the order loop (sanity_check)
     PadeWorkspace m_pade_ws;

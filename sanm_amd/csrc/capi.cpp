@@ -236,6 +236,17 @@ int sanm_direct_solver_solve(sanm_direct_solver* s, const double* b, double* x) 
         be->d2h(x, s->x.p(), s->csr.n * 8);
     });
 }
+int sanm_direct_solver_apply(sanm_direct_solver* s, const double* x, double* y) {
+    return guard([&] {
+        Backend* be = backend();
+        be->h2d(s->b.p(), x, s->csr.n * 8);
+        be->spmv(s->csr, s->b.p(), s->x.p());
+        be->d2h(y, s->x.p(), s->csr.n * 8);
+    });
+}
+int sanm_direct_solver_coeff_l2(sanm_direct_solver* s, double* l2) {
+    return guard([&] { *l2 = std::sqrt(backend()->dot(s->csr.nnz, s->val.p(), s->val.p())); });
+}
 int sanm_direct_solver_stats(const sanm_direct_solver* s, int64_t* nnz_factors, double* flops,
                              int32_t* nr_front, int32_t* nr_level, int32_t* max_front,
                              int32_t* root_pivots, int32_t* nr_supervar) {
@@ -623,6 +634,15 @@ int sanm_anm_trace(const sanm_anm_solver* s, int max_n, double* b_norm, double* 
         if (t) t[i] = s->drv->trace_t[i];
     }
     return k;
+}
+int64_t sanm_anm_verbose_text(const sanm_anm_solver* s, char* buf, int64_t cap) {
+    const std::string& t = s->drv->verbose_text();
+    if (buf && cap > 0) {
+        const size_t k = std::min<size_t>(t.size(), (size_t)cap - 1);
+        std::memcpy(buf, t.data(), k);
+        buf[k] = 0;
+    }
+    return (int64_t)t.size();
 }
 int sanm_anm_pade_diag(const sanm_anm_solver* s, double head[8], double* d, int d_cap, int* nd, double* probes,
                        int probe_cap) {

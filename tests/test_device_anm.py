@@ -103,6 +103,38 @@ def test_first_step_coefficients_and_jacobian(api):
 
 
 @pytest.mark.parametrize("use_pade", [False, True])
+def _verbose_numbers(text):
+    import re
+    return [float(x) for x in re.findall(r"[-+]?(?:\d+\.?\d*|\.\d+)(?:[eE][-+]?\d+)?|nan|inf", text)]
+
+
+def test_verbose_printout_matches_the_reference_format(api):
+    """SANM_VERBOSE (anm.cpp:200-203, :247-259, :295-309): '=== ANM iter K:', gt / xgt / jacob (= coeff_l2),
+    'i:(bi=.. xbi=..)' per order, 'bound=.. t=..', 'x(a): ..', 't(a): ..,' -- same text layout as the oracle's
+    restatement, numbers equal to the printed precision."""
+    cfg = {"material": {"young": 3e3, "poisson": 0.45, "density": 900.0}, "g": [0, -9.81, 0],
+           "boundary_thresh": 0.05, "boundary_proj_dir": [-1, 0, 0], "energy_model": "neohookean_c", "order": 8,
+           "disable_pade": True}
+    dims, sp = (5, 3, 3), 0.03
+    _, osolver, _ = ofea.make_gravity_solver(ofea.make_cuboid(*dims, sp), cfg)
+    run = dfea.GravityRun(api, dfea.make_cuboid(*dims, sp), dict(cfg), solver_rtol=1e-15, profile=1).construct()
+    td, to = run.solver.verbose_text(), osolver.verbose_text
+    assert td.startswith("=== ANM iter 0:\ngt=") and " 8:(bi=" in td and "\nx(a):" in td and "\nt(a):" in td
+    import re
+    skeleton = lambda t: re.sub(r"[-+]?(?:\d+\.?\d*|\.\d+)(?:[eE][-+]?\d+)?", "#", t)
+    assert skeleton(td) == skeleton(to)
+    nd, no = _verbose_numbers(td), _verbose_numbers(to)
+    assert len(nd) == len(no)
+    # (%g prints 6 digits, %.3g 3: equal up to the last printed digit; the order-1 bias is exactly zero on both)
+    for a, b in zip(nd, no):
+        assert abs(a - b) <= 2e-3 * abs(b) + 1e-12, (a, b)
+    run.step()
+    osolver.next_iter()
+    assert run.solver.verbose_text().startswith("=== ANM iter 1:\n")
+    nd, no = _verbose_numbers(run.solver.verbose_text()), _verbose_numbers(osolver.verbose_text)
+    assert len(nd) == len(no) and all(abs(a - b) <= 2e-3 * abs(b) + 1e-12 for a, b in zip(nd, no))
+
+
 def test_vecscale_solver_path_following(api, use_pade):
     """ANMSolverVecScale: f(x) + t*v = 0 followed with update_approx (the
     save_interm branch of run_and_save, fea/main.cpp:386-414).  Without Pade both sides evaluate the same

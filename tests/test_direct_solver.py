@@ -24,6 +24,10 @@ def _check(api, A, coords=None, tol=1e-9, nrhs=3, seed=0):
         x = ds.solve(b)
         xr = lu.solve(b)
         assert np.abs(x - xr).max() <= tol * np.abs(xr).max()
+    # SparseSolver::apply / coeff_l2 (sparse_solver.cpp:202-223)
+    v = rng.standard_normal(A.shape[0])
+    assert np.abs(ds.apply(v) - A @ v).max() <= 1e-12 * max(1.0, np.abs(A @ v).max())
+    assert ds.coeff_l2() == pytest.approx(np.sqrt((A.data ** 2).sum()), rel=1e-12)
     # refactor with new values on the same pattern (one analysis, many steps)
     A2 = A.copy()
     A2.data = A.data * (1 + 0.1 * rng.standard_normal(A.nnz))
