@@ -142,7 +142,7 @@ def metric_name(workload, cfg):
     """BASELINE.json's metric, with the workload that was actually run"""
     energy = {"neohookean_c": "Neo-Hookean", "neohookean_i": "Neo-Hookean incompressible",
               "arap": "ARAP"}.get(cfg["energy_model"], cfg["energy_model"])
-    mesh = {"armadillo_small": "armadillo"}.get(workload, workload)
+    mesh = {"armadillo_small": "armadillo-small: stand-in for the missing Armadillo.1"}.get(workload, workload)
     return f"ANM continuation steps/sec ({mesh}, {energy}, order {int(cfg.get('order', 20))})"
 
 
@@ -153,6 +153,7 @@ FAMILY_KERNELS = {
     "taylor": "spec_pass* (taylor_pass_kernel: EVAL0, GRAD, COEFF+BIAS per order)",
     "io": "gather_rows3_kernel (remap_out; remap_in is fused into the Taylor passes)",
     "asm": "assemble_kernel + nonfinite_kernel",
+    "collective": "ncclAllReduce of f(x0), the Jacobian values and b_k per order (tet-sharded mode)",
     "tail": "sanity_check_multi + Pade (multi_dot, gs_update, scale_rsqrt, lincomb2_diff_norms_multi) + "
             "next_coeff / dot / lincomb + host root finder",
 }
@@ -175,15 +176,20 @@ def measure_families(run, one_step, cfg, stats, args, nsteps=2):
     prof = s.profile()  # waits for the device
     wall_ms = (time.perf_counter() - t0) * 1e3
     cnt = s.profile_counts()
+    lch = s.profile_launches()
     pass_ms, pass_cnt = s.pass_timing(False)
     s.set_profile(0)
     k = s.get_nr_iter() - it0
     g = lambda tag: prof.get(tag, 0.0) * 1e3 / k  # ms per step
     c = lambda tag: cnt.get(tag, 0.0) / k
+    nl = lambda tag: lch.get(tag, 0.0) / k        # kernel launches per step queued inside the tag's brackets
     whole = g("solve_expansion_coeffs")
-    t = {"taylor": g("taylor_order0") + g("jacobian") + g("taylor_next_order") + g("taylor_push") - g("remap_out"),
+    # brackets nest: remap_out and the per-order all-reduce sit inside taylor_next_order, the all-reduces of
+    # f(x0) / the Jacobian values inside taylor_order0 / build_sparse_coeff
+    taylor_tags = ("taylor_order0", "jacobian", "taylor_next_order", "taylor_push")
+    t = {"taylor": sum(g(x) for x in taylor_tags) - g("remap_out") - g("allreduce"),
          "io": g("remap_out"), "asm": g("build_sparse_coeff"), "factor": g("sparse_prep"),
-         "solve": g("sparse_solve")}
+         "solve": g("sparse_solve"), "collective": g("allreduce")}
     t["tail"] = max(whole - sum(t.values()), 0.0)
     # SURVEY.md 8(d), per ANM step
     SC = {"neohookean_c": (20, 45), "neohookean_i": (22, 45), "arap": (27, 39)}
@@ -195,14 +201,27 @@ def measure_families(run, one_step, cfg, stats, args, nsteps=2):
          "factor": fnnz * 8.0,          # the "1" of nnz(L+U)*8*(1+N)
          "solve": fnnz * 8.0 * N,       # N solves per step
          "tail": (2 + 3 * N) * 8.0 * (n + 1) + (2.5 * N * N + 44 * N) * 8.0 * (n + 1) + N * (12.0 * nnz + 16.0 * n)}
-    nlev = stats["nr_level"]
-    launches = {"taylor": pass_cnt / max(k, 1), "io": c("remap_out"), "asm": 2.0,
-                "solve": c("sparse_solve") * (2 * nlev + 1), "factor": None, "tail": None}
+    # The Pade basis (Gram-Schmidt, 2.5 N^2 of SURVEY's vector passes: 2 units per pair for the projection, 3 for
+    # the update) is built by RIDERS: extra workgroups of the remap_out gather (projections), of the solve's last
+    # kernel (update + norm) and of next_coeff (scaling) -- DESIGN.md section 8.  Its bytes are booked where its
+    # time lands; SANM_NO_RIDERS / SANM_GS_MODE=tail put kernels and bytes back into the tail.
+    riders = not (os.environ.get("SANM_NO_RIDERS") or os.environ.get("SANM_GS_MODE") in ("tail", "side")) \
+        and not cfg.get("disable_pade", False)
+    if riders:
+        gs = 2.5 * N * N * 8.0 * (n + 1)
+        B["tail"] -= gs
+        B["io"] += 0.4 * gs
+        B["solve"] += 0.6 * gs
+    B["collective"] = 0.0
+    tail_launches = nl("solve_expansion_coeffs") - sum(nl(x) for x in taylor_tags + ("build_sparse_coeff", "sparse_prep", "sparse_solve"))
+    launches = {"taylor": sum(nl(x) for x in taylor_tags) - nl("remap_out") - nl("allreduce"), "io": nl("remap_out"),
+                "asm": nl("build_sparse_coeff"), "solve": nl("sparse_solve"), "factor": nl("sparse_prep"),
+                "tail": tail_launches, "collective": nl("allreduce")}
     fam = {}
-    for name in ("solve", "factor", "taylor", "io", "asm", "tail"):
+    for name in ("solve", "factor", "taylor", "io", "asm", "tail") + (("collective",) if t["collective"] > 0 else ()):
         ms = t[name]
         e = {"ms_per_step": ms, "share_of_step": ms / whole if whole > 0 else 0.0, "bound": "hbm",
-             "algorithmic_per_step": B[name], "kernels": FAMILY_KERNELS[name],
+             "algorithmic_per_step": B[name], "kernels": FAMILY_KERNELS.get(name, name),
              "achieved": B[name] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
         e["frac"] = e["achieved"] / HBM_PEAK_GBS
         L = launches[name]
@@ -210,6 +229,8 @@ def measure_families(run, one_step, cfg, stats, args, nsteps=2):
         e["avg_launch_us"] = ms * 1e3 / L if L else None
         e["algorithmic_bytes_per_launch"] = B[name] / L if L else None
         fam[name] = e
+    if "collective" in fam:
+        fam["collective"]["bound"] = "xgmi"  # latency-bound all-reduces of n doubles: not priced against HBM
     # the factorisation is dense arithmetic on the fp64 matrix cores: priced in flops
     f = fam["factor"]
     f["bound"] = "mfma"
@@ -220,6 +241,7 @@ def measure_families(run, one_step, cfg, stats, args, nsteps=2):
     if pass_cnt:
         # the pass launches themselves, one HIP event pair around each (no bracket overhead, no gaps between them)
         t = fam["taylor"]
+        t["launches_per_step"] = pass_cnt / max(k, 1)  # the pass launches themselves (the bracket count includes riders' hosts)
         t["avg_launch_us_events"] = pass_ms / pass_cnt * 1e3
         t["achieved_by_launch_events"] = B["taylor"] / 1e9 / (pass_ms / pass_cnt * t["launches_per_step"] * 1e-3)
         t["frac_by_launch_events"] = t["achieved_by_launch_events"] / HBM_PEAK_GBS

@@ -243,6 +243,8 @@ int sanm_anm_debug_inject(sanm_anm_solver* s, int kind, int order, int64_t index
 int sanm_anm_profile(const sanm_anm_solver* s, int max_tags, const char** names, double* seconds);
 /* how many times each tag was entered, in the order of sanm_anm_profile (call that first) */
 int sanm_anm_profile_counts(const sanm_anm_solver* s, int max_tags, double* counts);
+/* kernel launches queued inside each tag (nested tags count in their parents too), same order */
+int sanm_anm_profile_launches(const sanm_anm_solver* s, int max_tags, double* launches);
 /* switch the phase profile of a live solver (modes as sanm_hyper_param.profile); clear != 0 drops
  * what was accumulated so far */
 int sanm_anm_set_profile(sanm_anm_solver* s, int mode, int clear);

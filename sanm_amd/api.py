@@ -84,7 +84,7 @@ SYMBOLS = [
     "sanm_anm_update_approx", "sanm_anm_restart", "sanm_anm_run_steps", "sanm_anm_spec_source", "sanm_rtc_compile_check", "sanm_anm_time_kernel", "sanm_anm_pass_timing", "sanm_anm_converged", "sanm_anm_residual_rms", "sanm_anm_get_x",
     "sanm_anm_get_t_upper", "sanm_anm_get_t_max_a", "sanm_anm_solve_a", "sanm_anm_eval",
     "sanm_anm_nr_iter", "sanm_anm_nr_xt_coeffs", "sanm_anm_xt_coeff", "sanm_anm_has_pade",
-    "sanm_anm_get_stats", "sanm_anm_profile", "sanm_anm_profile_counts", "sanm_anm_set_profile", "sanm_anm_debug_inject", "sanm_anm_trace", "sanm_anm_pade_diag", "sanm_anm_verbose_text", "sanm_anm_jacobian_csr",
+    "sanm_anm_get_stats", "sanm_anm_profile", "sanm_anm_profile_counts", "sanm_anm_profile_launches", "sanm_anm_set_profile", "sanm_anm_debug_inject", "sanm_anm_trace", "sanm_anm_pade_diag", "sanm_anm_verbose_text", "sanm_anm_jacobian_csr",
     "sanm_fea_model_create", "sanm_fea_model_destroy", "sanm_fea_model_nr_unknown",
     "sanm_fea_model_graph", "sanm_fea_model_output_var", "sanm_fea_model_F_var",
     "sanm_fea_model_remap_inp", "sanm_fea_model_remap_out", "sanm_fea_model_x0",
@@ -554,6 +554,13 @@ class _ANMSolver:
         keys = list(self.profile().keys())
         cnt = (C.c_double * max(len(keys), 1))()
         n = self.api.lib.sanm_anm_profile_counts(self.h, C.c_int(len(keys)), cnt)
+        return {keys[i]: cnt[i] for i in range(min(n, len(keys)))}
+
+    def profile_launches(self):
+        """kernel launches queued inside each profile tag (same keys as profile())"""
+        keys = list(self.profile().keys())
+        cnt = (C.c_double * max(len(keys), 1))()
+        n = self.api.lib.sanm_anm_profile_launches(self.h, C.c_int(len(keys)), cnt)
         return {keys[i]: cnt[i] for i in range(min(n, len(keys)))}
 
     def debug_inject(self, kind, order, index, value, scale=False):

@@ -32,11 +32,13 @@ class AnmDriver::ScopedTimer {
     AnmDriver* m_d;
     const char* m_tag;
     std::chrono::steady_clock::time_point m_t0;
+    int64_t m_l0 = 0;
 
 public:
     // mode 1: host clock around a synchronised region (the ScopedProfiler of the reference, utils.h:225-249);
     // mode 2: device events, no synchronisation (the launch mix of the timed run is undisturbed)
     ScopedTimer(AnmDriver* d, const char* tag) : m_d{d}, m_tag{tag} {
+        if (m_d->m_profile_mode) m_l0 = m_d->m_be->launch_count();
         if (m_d->m_profile_mode == 1) {
             m_d->m_be->sync();
             m_t0 = std::chrono::steady_clock::now();
@@ -45,6 +47,7 @@ public:
         }
     }
     ~ScopedTimer() {
+        if (m_d->m_profile_mode) m_d->m_profile_launches[m_tag] += double(m_d->m_be->launch_count() - m_l0);
         if (m_d->m_profile_mode == 1) {
             m_d->m_be->sync();
             m_d->m_profile[m_tag] +=

@@ -219,11 +219,14 @@ public:
     //! seconds per tag (HyperParam::profile != 0); with event timing this waits for the device first
     const std::map<std::string, double>& profile();
     const std::map<std::string, double>& profile_counts() const { return m_profile_cnt; }
+    //! kernel launches queued inside each tag's brackets (nested tags count in their parents too)
+    const std::map<std::string, double>& profile_launches() const { return m_profile_launches; }
     //! 0: off, 1: host clock around synchronised phases, 2: device events (no synchronisation)
     void set_profile_mode(int mode) { m_profile_mode = mode; }
     void clear_profile() {
         m_profile.clear();
         m_profile_cnt.clear();
+        m_profile_launches.clear();
     }
     const LinearSolver& linear_solver() const { return *m_solver; }
     const JacobianPattern& pattern() const { return *m_pattern; }
@@ -280,7 +283,7 @@ protected:
     PadeWorkspace m_pade_ws;
     DVec m_dev_scalars;                // per order: xb_i . x_1 (consumed on the device)
     double* m_host_scalars = nullptr;  // pinned, per order: t_i, sanity excess, sanity x-dot
-    std::map<std::string, double> m_profile, m_profile_cnt;
+    std::map<std::string, double> m_profile, m_profile_cnt, m_profile_launches;
 
     void init_xt0(const double* x_host, double t);
     void solve_expansion_coeffs();

@@ -247,6 +247,8 @@ public:
     //! between phase_begin(tag) and the matching phase_end() are bracketed by device events on the backend's
     //! stream; phase_collect() waits for the stream and adds the elapsed seconds of every closed bracket to
     //! acc[tag] / the number of brackets to cnt[tag].  Brackets nest.  Backends without events do nothing.
+    //! kernel launches issued so far (0 for backends that do not launch kernels)
+    virtual int64_t launch_count() const { return 0; }
     virtual void phase_begin(const char* tag) { (void)tag; }
     virtual void phase_end() {}
     virtual void phase_collect(std::map<std::string, double>& acc, std::map<std::string, double>* cnt) {

@@ -949,6 +949,14 @@ struct Rccl {
     }
 };
 
+// every kernel launch of the backend goes through this: the count lets the phase profile report launches per
+// family (bench.py: roofline_families[*].launches_per_step) instead of a formula
+#define SANM_LAUNCH(...)                    \
+    do {                                    \
+        ++m_launch_count;                   \
+        hipLaunchKernelGGL(__VA_ARGS__);    \
+    } while (0)
+
 class HipBackend final : public Backend {
     hipStream_t m_stream = nullptr;  // the queue launches currently go to: m_main, or m_side between side_fork / side_end
     hipStream_t m_main = nullptr, m_side = nullptr;
@@ -958,6 +966,7 @@ class HipBackend final : public Backend {
     hipEvent_t m_fork_ev[kForkEvents] = {};
     int m_fork_next = 0;
     Rccl::Comm m_comm = nullptr;
+    int64_t m_launch_count = 0;
     int m_comm_rank = 0, m_comm_world = 0;
     // pass kernels compiled at run time for one program each (specialize)
     struct SpecKernels {
@@ -1047,6 +1056,7 @@ public:
         (void)hipStreamDestroy(m_main);
     }
     const char* name() const override { return "hip"; }
+    int64_t launch_count() const override { return m_launch_count; }
 
     bool comm_available() override {
         try {
@@ -1285,7 +1295,7 @@ public:
         ProgramDev Pd = P;
         // measurement hook (scripts/time_nops.py): the pass truncated after n operators, interpreter kernels only
         if (const char* e = std::getenv("SANM_DBG_NOPS")) Pd.nops = std::min(P.nops, std::atoi(e));
-        hipLaunchKernelGGL(kern, dim3(nblk(P.T, 64), mode == PASS_GRAD ? P.odim : 1), dim3(64 * nparts), lds,
+        SANM_LAUNCH(kern, dim3(nblk(P.T, 64), mode == PASS_GRAD ? P.odim : 1), dim3(64 * nparts), lds,
                            m_stream, Pd, P.ops, P.vars, order, xvec);
         HIP_CHECK(hipGetLastError());
         if (m_time_passes) {
@@ -1386,7 +1396,7 @@ public:
                 const GsRider rd = take_rider();
 #define SANM_G3(NVT)                                                                                                \
     case NVT:                                                                                                       \
-        hipLaunchKernelGGL(gather_rows3_kernel<NVT>, dim3(own + rd.nblk), dim3(256), 0, m_stream, R.bptr, R.bidx,   \
+        SANM_LAUNCH(gather_rows3_kernel<NVT>, dim3(own + rd.nblk), dim3(256), 0, m_stream, R.bptr, R.bidx,   \
                            R.bcoef, src, dst, perm, dst2, R.nrows, own, rd);                                        \
         break;
                 switch (nvt) {
@@ -1395,34 +1405,34 @@ public:
                 }
 #undef SANM_G3
             } else {
-                hipLaunchKernelGGL(gather_rows3_kernel<0>, dim3(own), dim3(256), 0, m_stream, R.bptr, R.bidx, R.bcoef, src,
+                SANM_LAUNCH(gather_rows3_kernel<0>, dim3(own), dim3(256), 0, m_stream, R.bptr, R.bidx, R.bcoef, src,
                                    dst, perm, dst2, R.nrows, own, GsRider{});
             }
         } else
-            hipLaunchKernelGGL(gather_rows_kernel, dim3(nblk((size_t)R.nrows * GATHER_LANES, 256)), dim3(256), 0,
+            SANM_LAUNCH(gather_rows_kernel, dim3(nblk((size_t)R.nrows * GATHER_LANES, 256)), dim3(256), 0,
                                m_stream, R, src, dst, perm, dst2);
         HIP_CHECK(hipGetLastError());
     }
     void assemble(const AssemblyDev& A, const double* jac, double* val) override {
-        hipLaunchKernelGGL(assemble_kernel, dim3(nblk((size_t)A.nslots * ROW_LANES, 256)), dim3(256), 0,
+        SANM_LAUNCH(assemble_kernel, dim3(nblk((size_t)A.nslots * ROW_LANES, 256)), dim3(256), 0,
                            m_stream, A, jac, val);
         HIP_CHECK(hipGetLastError());
     }
     void gather(size_t n, const double* src, const uint32_t* idx, double* dst) override {
-        hipLaunchKernelGGL(gather_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, src, idx, dst);
+        SANM_LAUNCH(gather_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, src, idx, dst);
         HIP_CHECK(hipGetLastError());
     }
     void ata(const CsrDev& At, const CsrDev& M, const uint32_t* mrow, double lambda) override {
-        hipLaunchKernelGGL(ata_kernel, dim3(nblk(M.nnz, 256)), dim3(256), 0, m_stream, At, M, mrow, lambda);
+        SANM_LAUNCH(ata_kernel, dim3(nblk(M.nnz, 256)), dim3(256), 0, m_stream, At, M, mrow, lambda);
         HIP_CHECK(hipGetLastError());
     }
     void residual(const CsrDev& A, const double* b, const double* x, double* r) override {
-        hipLaunchKernelGGL(residual_dd_kernel, dim3(nblk((size_t)A.n * SPMV_LANES, 256)), dim3(256), 0, m_stream, A, b, x,
+        SANM_LAUNCH(residual_dd_kernel, dim3(nblk((size_t)A.n * SPMV_LANES, 256)), dim3(256), 0, m_stream, A, b, x,
                            r);
         HIP_CHECK(hipGetLastError());
     }
     void spmv(const CsrDev& A, const double* x, double* y) override {
-        hipLaunchKernelGGL(spmv_kernel, dim3(nblk((size_t)A.n * SPMV_LANES, 256)), dim3(256), 0,
+        SANM_LAUNCH(spmv_kernel, dim3(nblk((size_t)A.n * SPMV_LANES, 256)), dim3(256), 0,
                            m_stream, A, x, y);
         HIP_CHECK(hipGetLastError());
     }
@@ -1443,7 +1453,7 @@ public:
         }
         double *r = m_pcg_w[0], *z = m_pcg_w[1], *p = m_pcg_w[2], *q = m_pcg_w[3];
         HIP_CHECK(hipMemsetAsync(m_pcg_sc, 0, sizeof(PcgScalars), m_stream));
-        hipLaunchKernelGGL(pcg_init_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, sign, b,
+        SANM_LAUNCH(pcg_init_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, sign, b,
                            dinv, x, r, z, p, m_pcg_sc);
         auto fetch = [&]() {
             HIP_CHECK(hipMemcpyAsync(m_pcg_sc_host, m_pcg_sc, sizeof(PcgScalars),
@@ -1460,11 +1470,11 @@ public:
             while (it < maxit) {
                 int stop = std::min(maxit, it + PCG_CHECK_EVERY);
                 for (; it < stop; ++it) {
-                    hipLaunchKernelGGL(pcg_spmv_dot_kernel, dim3(g_spmv), dim3(256), 0, m_stream, A,
+                    SANM_LAUNCH(pcg_spmv_dot_kernel, dim3(g_spmv), dim3(256), 0, m_stream, A,
                                        sign, p, q, m_pcg_sc, it);
-                    hipLaunchKernelGGL(pcg_update_kernel, dim3(g_red), dim3(256), 0, m_stream, n,
+                    SANM_LAUNCH(pcg_update_kernel, dim3(g_red), dim3(256), 0, m_stream, n,
                                        sign, dinv, p, q, x, r, z, m_pcg_sc, it);
-                    hipLaunchKernelGGL(pcg_dir_kernel, dim3(g_n), dim3(256), 0, m_stream, n, z, p,
+                    SANM_LAUNCH(pcg_dir_kernel, dim3(g_n), dim3(256), 0, m_stream, n, z, p,
                                        m_pcg_sc, it);
                 }
                 HIP_CHECK(hipGetLastError());
@@ -1495,7 +1505,7 @@ public:
     }
     void mf_factor_async(const MfDev& mf, const MfSchedule& sch, const CsrDev& A, double* status) override {
         mf_factor_launch(mf, sch, A);
-        hipLaunchKernelGGL(status_to_double_kernel, dim3(1), dim3(1), 0, m_stream, mf.status, status);
+        SANM_LAUNCH(status_to_double_kernel, dim3(1), dim3(1), 0, m_stream, mf.status, status);
         HIP_CHECK(hipGetLastError());
     }
 #ifdef SANM_MF_PHASES
@@ -1511,11 +1521,11 @@ public:
         using namespace mfk;
         HIP_CHECK(hipMemsetAsync(mf.front_store, 0, mf.front_store_size * sizeof(double), m_stream));
         HIP_CHECK(hipMemsetAsync(mf.status, 0, sizeof(int32_t), m_stream));
-        hipLaunchKernelGGL(absmax_kernel, dim3(red_grid(mf.nnzA)), dim3(256), 0, m_stream, (size_t)mf.nnzA, A.val,
+        SANM_LAUNCH(absmax_kernel, dim3(red_grid(mf.nnzA)), dim3(256), 0, m_stream, (size_t)mf.nnzA, A.val,
                            red_to(mf.piv_amax));
-        hipLaunchKernelGGL(scatter_kernel, dim3(nblk(mf.nnzA, 256)), dim3(256), 0, m_stream, mf.nnzA,
+        SANM_LAUNCH(scatter_kernel, dim3(nblk(mf.nnzA, 256)), dim3(256), 0, m_stream, mf.nnzA,
                            mf.a_dst, A.val, mf.front_store);
-        hipLaunchKernelGGL(aug_identity_kernel, dim3(nblk(mf.n, 256)), dim3(256), 0, m_stream, mf);
+        SANM_LAUNCH(aug_identity_kernel, dim3(nblk(mf.n, 256)), dim3(256), 0, m_stream, mf);
         const char* env_min_k = std::getenv("SANM_MF_OUTER_MIN_K");
         const int outer_min_k = env_min_k ? std::atoi(env_min_k) : kOuterMinK;
         for (const auto& L : sch.levels) {
@@ -1523,7 +1533,7 @@ public:
                 int cnt = L.ea_rounds[r].second - L.ea_rounds[r].first;
                 int64_t mb = L.ea_max_b[r];
                 if (cnt == 0 || mb == 0) continue;
-                hipLaunchKernelGGL(extend_add_kernel, dim3(nblk(mb * mb, 256), cnt), dim3(256), 0,
+                SANM_LAUNCH(extend_add_kernel, dim3(nblk(mb * mb, 256), cnt), dim3(256), 0,
                                    m_stream, mf.fronts, mf.front_store, mf.rel,
                                    sch.ea_children + L.ea_rounds[r].first);
             }
@@ -1535,16 +1545,16 @@ public:
                 // one blocking level.  Panel 0's diagonal tile is factored by diag_kernel; every later
                 // diagonal tile by the update kernel of the previous panel (look-ahead)
                 if (L.nr_panel > 0)
-                    hipLaunchKernelGGL(diag_kernel, dim3(L.panel_cnt[0]), dim3(256), 0, m_stream,
+                    SANM_LAUNCH(diag_kernel, dim3(L.panel_cnt[0]), dim3(256), 0, m_stream,
                                        MF_FACTOR_ARGS(mf, L.front_begin), 0);
                 for (int p = 0; p < L.nr_panel; ++p) {
                     const int rem = nt - p - 1;
                     if (rem <= 0) continue;
-                    hipLaunchKernelGGL(update_kernel, dim3(rem, rem, L.panel_cnt[p]), dim3(256), 0, m_stream,
+                    SANM_LAUNCH(update_kernel, dim3(rem, rem, L.panel_cnt[p]), dim3(256), 0, m_stream,
                                        MF_FACTOR_ARGS(mf, L.front_begin), p, nt);
                 }
                 if (L.nr_panel > 0)
-                    hipLaunchKernelGGL(panel_finalize_kernel,
+                    SANM_LAUNCH(panel_finalize_kernel,
                                        dim3((atiles + FIN_TILES - 1) / FIN_TILES, 2, nfront * L.nr_panel),
                                        dim3(256), 0, m_stream,
                                        MF_FACTOR_ARGS(mf, L.front_begin), 0, L.nr_panel, -1);
@@ -1552,25 +1562,25 @@ public:
                 // two blocking levels (mf_kernels.h, update_kernel): outer blocks of kOuterPanels panels
                 for (int p0 = 0; p0 < L.nr_panel; p0 += kOuterPanels) {
                     const int p1 = std::min(p0 + kOuterPanels, L.nr_panel), cnt0 = L.panel_cnt[p0];
-                    hipLaunchKernelGGL(diag_kernel, dim3(cnt0), dim3(256), 0, m_stream,
+                    SANM_LAUNCH(diag_kernel, dim3(cnt0), dim3(256), 0, m_stream,
                                        MF_FACTOR_ARGS(mf, L.front_begin), p0);
                     for (int p = p0; p < p1; ++p) {
                         const int w = p1 - p - 1, rem = nt - p - 1, rem2 = nt - p1;
                         if (w <= 0 || rem <= 0) continue;
-                        hipLaunchKernelGGL(update_kernel, dim3(w, rem + std::max(rem2, 0), L.panel_cnt[p]),
+                        SANM_LAUNCH(update_kernel, dim3(w, rem + std::max(rem2, 0), L.panel_cnt[p]),
                                            dim3(256), 0, m_stream,
                                        MF_FACTOR_ARGS(mf, L.front_begin), p, p1);
                     }
                     const int tiles = nt - p1;  // trailing extent beyond the block
                     // (a smaller front of the level may start its augmentation tiles before p1)
-                    hipLaunchKernelGGL(panel_finalize_kernel,
+                    SANM_LAUNCH(panel_finalize_kernel,
                                        dim3((std::max(tiles, atiles) + FIN_TILES - 1) / FIN_TILES, 2,
                                             cnt0 * (p1 - p0)),
                                        dim3(256), 0, m_stream,
                                        MF_FACTOR_ARGS(mf, L.front_begin), p0, p1 - p0, p1);
                     if (tiles <= 0) continue;
                     const int gt = (tiles * NB + GT - 1) / GT;
-                    hipLaunchKernelGGL(block_gemm_kernel, dim3(gt, gt, cnt0), dim3(256), 0, m_stream,
+                    SANM_LAUNCH(block_gemm_kernel, dim3(gt, gt, cnt0), dim3(256), 0, m_stream,
                                        MF_FACTOR_ARGS(mf, L.front_begin), p0, p1);
                 }
             }
@@ -1579,9 +1589,9 @@ public:
                 const int nfr = L.front_end - L.front_begin;
                 const int tb = (L.max_b + GT - 1) / GT, tk = (L.max_k + GT - 1) / GT;
                 const int tmax = std::max(tb, tk);
-                hipLaunchKernelGGL(gemm1_kernel, dim3(tmax, tmax, 2 * nfr), dim3(256), 0, m_stream,
+                SANM_LAUNCH(gemm1_kernel, dim3(tmax, tmax, 2 * nfr), dim3(256), 0, m_stream,
                                    MF_FACTOR_ARGS(mf, L.front_begin));
-                hipLaunchKernelGGL(gemm2_kernel, dim3(tmax, tmax, 3 * nfr), dim3(256), 0, m_stream,
+                SANM_LAUNCH(gemm2_kernel, dim3(tmax, tmax, 3 * nfr), dim3(256), 0, m_stream,
                                    MF_FACTOR_ARGS(mf, L.front_begin));
             }
         }
@@ -1592,10 +1602,10 @@ public:
                 if (!cnt) continue;
                 const int tiles = (T.stage_dim[st] + GT - 1) / GT;
                 if (T.indexed)
-                    hipLaunchKernelGGL(top_gemm_kernel<true>, dim3(tiles, tiles, cnt), dim3(256), 0, m_stream,
+                    SANM_LAUNCH(top_gemm_kernel<true>, dim3(tiles, tiles, cnt), dim3(256), 0, m_stream,
                                        T.gemms + T.stage_begin[st]);
                 else
-                    hipLaunchKernelGGL(top_gemm_kernel<false>, dim3(tiles, tiles, cnt), dim3(256), 0, m_stream,
+                    SANM_LAUNCH(top_gemm_kernel<false>, dim3(tiles, tiles, cnt), dim3(256), 0, m_stream,
                                        T.gemms + T.stage_begin[st]);
             }
         }
@@ -1620,10 +1630,10 @@ public:
         const dim3 grid((rows + 4 * R - 1) / (4 * R), cnt);
         const MfFrontDev* lf = mf.lfronts + L.front_begin;
         if (fwd)
-            hipLaunchKernelGGL((fwd_level_kernel<R, U>), grid, dim3(256), lds, m_stream, lf, mf.front_store,
+            SANM_LAUNCH((fwd_level_kernel<R, U>), grid, dim3(256), lds, m_stream, lf, mf.front_store,
                                mf.inbox_store, mf.work, mf.work2, mf.upd_dst);
         else
-            hipLaunchKernelGGL((bwd_level_kernel<R, U>), grid, dim3(256), lds, m_stream, lf, mf.front_store, mf.work,
+            SANM_LAUNCH((bwd_level_kernel<R, U>), grid, dim3(256), lds, m_stream, lf, mf.front_store, mf.work,
                                mf.work2, mf.bnd_idx);
     }
     void level_solve(bool fwd, const MfDev& mf, const MfSchedule::Level& L) {
@@ -1634,12 +1644,12 @@ public:
             // vectors beyond the LDS: plain mat-vec kernels on operands in HBM (bandwidth-bound levels)
             const int cnt = L.front_end - L.front_begin;
             if (fwd) {
-                hipLaunchKernelGGL(fwd_prep_kernel, dim3((L.max_k + 255) / 256, cnt), dim3(256), 0, m_stream, mf,
+                SANM_LAUNCH(fwd_prep_kernel, dim3((L.max_k + 255) / 256, cnt), dim3(256), 0, m_stream, mf,
                                    L.front_begin);
-                hipLaunchKernelGGL(fwd_big_kernel, dim3((L.max_m + 3) / 4, cnt), dim3(256), 0, m_stream, mf,
+                SANM_LAUNCH(fwd_big_kernel, dim3((L.max_m + 3) / 4, cnt), dim3(256), 0, m_stream, mf,
                                    L.front_begin);
             } else {
-                hipLaunchKernelGGL(bwd_big_kernel, dim3((L.max_k + 3) / 4, cnt), dim3(256), 0, m_stream, mf,
+                SANM_LAUNCH(bwd_big_kernel, dim3((L.max_k + 3) / 4, cnt), dim3(256), 0, m_stream, mf,
                                    L.front_begin);
             }
             return;
@@ -1657,7 +1667,7 @@ public:
             const int g = width <= 32 ? 8 : (width <= 64 ? 16 : 32);
 #define SANM_FS(G, R)                                                                                          \
     if (g == G && rr == R) {                                                                                   \
-        hipLaunchKernelGGL((fwd_level_sub_kernel<G, R>), dim3((L.max_m + 256 / G * R - 1) / (256 / G * R), cnt), \
+        SANM_LAUNCH((fwd_level_sub_kernel<G, R>), dim3((L.max_m + 256 / G * R - 1) / (256 / G * R), cnt), \
                            dim3(256), lds, m_stream, mf.lfronts + L.front_begin, mf.front_store, mf.inbox_store, \
                            mf.work, mf.work2, mf.upd_dst);                                                     \
         return;                                                                                                \
@@ -1693,7 +1703,7 @@ public:
                         double* dot_out) override {
         using namespace mfk;
         if (b)
-            hipLaunchKernelGGL(permute_in_kernel, dim3(nblk(mf.n, 256)), dim3(256), 0, m_stream, mf.n,
+            SANM_LAUNCH(permute_in_kernel, dim3(nblk(mf.n, 256)), dim3(256), 0, m_stream, mf.n,
                                mf.perm, b, mf.work);
         const int nl = (int)sch.levels.size(), below = sch.top.enabled ? nl - 2 : nl;
         for (int li = 0; li < below; ++li) level_solve(true, mf, sch.levels[li]);
@@ -1704,7 +1714,7 @@ public:
             const size_t lds = (size_t)T.n * sizeof(double);
 #define SANM_TS(WW)                                                                                              \
     case WW:                                                                                                     \
-        hipLaunchKernelGGL((top_solve_kernel<R, WW>), grid, dim3(256), lds, m_stream, T.M, T.wsrc, T.ell,         \
+        SANM_LAUNCH((top_solve_kernel<R, WW>), grid, dim3(256), lds, m_stream, T.M, T.wsrc, T.ell,         \
                            mf.inbox_store, mf.work, mf.work + mf.n, T.n);                                        \
         break;
             switch (T.W) {
@@ -1725,7 +1735,7 @@ public:
                 const GsRider rd = take_rider();
 #define SANM_POD(NVT)                                                                                              \
     case NVT:                                                                                                      \
-        hipLaunchKernelGGL(permute_out_dot_kernel<NVT>, dim3(own + rd.nblk), dim3(256), 0, m_stream, mf.n, perm_out, \
+        SANM_LAUNCH(permute_out_dot_kernel<NVT>, dim3(own + rd.nblk), dim3(256), 0, m_stream, mf.n, perm_out, \
                            mf.work, x, dot_y, red_to(dot_out), own, rd);                                           \
         break;
                 switch (nvt) {
@@ -1734,11 +1744,11 @@ public:
                 }
 #undef SANM_POD
             } else {
-                hipLaunchKernelGGL(permute_out_dot_kernel<0>, dim3(own), dim3(256), 0, m_stream, mf.n, perm_out, mf.work, x,
+                SANM_LAUNCH(permute_out_dot_kernel<0>, dim3(own), dim3(256), 0, m_stream, mf.n, perm_out, mf.work, x,
                                    dot_y, red_to(dot_out), own, GsRider{});
             }
         } else
-            hipLaunchKernelGGL(permute_out_kernel, dim3(nblk(mf.n, 256)), dim3(256), 0, m_stream, mf.n,
+            SANM_LAUNCH(permute_out_kernel, dim3(nblk(mf.n, 256)), dim3(256), 0, m_stream, mf.n,
                                perm_out, mf.work, x);
         HIP_CHECK(hipGetLastError());
     }
@@ -1756,10 +1766,10 @@ public:
                 run_pass(*P, mode, order, x);
                 m_time_passes = timing;
             } else if (kernel == 1) {
-                hipLaunchKernelGGL(spmv_kernel, dim3(nblk((size_t)A->n * SPMV_LANES, 256)),
+                SANM_LAUNCH(spmv_kernel, dim3(nblk((size_t)A->n * SPMV_LANES, 256)),
                                    dim3(256), 0, m_stream, *A, x, y);
             } else {
-                hipLaunchKernelGGL(pcg_spmv_dot_kernel, dim3(nblk((size_t)A->n * SPMV_LANES, 256)),
+                SANM_LAUNCH(pcg_spmv_dot_kernel, dim3(nblk((size_t)A->n * SPMV_LANES, 256)),
                                    dim3(256), 0, m_stream, *A, -1.0, x, y, m_pcg_sc, 0);
             }
         };
@@ -1799,18 +1809,18 @@ public:
         return (m_stream == m_side && m_side ? m_red_side : m_red).host;
     }
     double dot(size_t n, const double* x, const double* y) override {
-        hipLaunchKernelGGL(dot_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, y, red());
+        SANM_LAUNCH(dot_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, y, red());
         return red_result()[0];
     }
     void axpby(size_t n, double a, const double* x, double b, const double* y,
                double* out) override {
-        hipLaunchKernelGGL(axpby_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, a, x, b, y,
+        SANM_LAUNCH(axpby_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, a, x, b, y,
                            out);
         HIP_CHECK(hipGetLastError());
     }
     void axpby_tail(size_t n, double a, const double* x, double b, const double* y, double* out,
                     double tail) override {
-        hipLaunchKernelGGL(axpby_tail_kernel, dim3(nblk(n + 1, 256)), dim3(256), 0, m_stream, n, a, x, b, y,
+        SANM_LAUNCH(axpby_tail_kernel, dim3(nblk(n + 1, 256)), dim3(256), 0, m_stream, n, a, x, b, y,
                            out, tail);
         HIP_CHECK(hipGetLastError());
     }
@@ -1823,7 +1833,7 @@ public:
             v.p[j] = ptrs[j];
             v.c[j] = coefs[j];
         }
-        hipLaunchKernelGGL(lincomb_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, v, out);
+        SANM_LAUNCH(lincomb_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, v, out);
         HIP_CHECK(hipGetLastError());
     }
     void lincomb2_diff_norms(size_t n, int nvec, const double* const* ptrs, const double* c1,
@@ -1836,7 +1846,7 @@ public:
             v.c[j] = c1[j];
             v2.c[j] = c2[j];
         }
-        hipLaunchKernelGGL(lincomb2_diff_norms_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, v, v2,
+        SANM_LAUNCH(lincomb2_diff_norms_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, v, v2,
                            scale, red());
         const double* r = red_result();
         out_host[0] = r[0];
@@ -1857,7 +1867,7 @@ public:
                 a.c2[c][j] = c2[(size_t)c * nvec + j];
             }
         }
-        hipLaunchKernelGGL(lincomb2_diff_norms_multi_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, a,
+        SANM_LAUNCH(lincomb2_diff_norms_multi_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, a,
                            red());
         const double* r = red_result();
         for (int c = 0; c < 2 * ncand; ++c) out_host[c] = r[c];
@@ -1874,31 +1884,31 @@ public:
         for (int j = 0; j < nvec; ++j) out_host[j] = r[j];
     }
     void vmul(size_t n, const double* x, const double* y, double* out) override {
-        hipLaunchKernelGGL(vmul_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, x, y, out);
+        SANM_LAUNCH(vmul_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, x, y, out);
         HIP_CHECK(hipGetLastError());
     }
     void csr_inv_diag(const CsrDev& A, double scale, double* d) override {
-        hipLaunchKernelGGL(inv_diag_kernel, dim3(nblk(A.n, 256)), dim3(256), 0, m_stream, A, scale,
+        SANM_LAUNCH(inv_diag_kernel, dim3(nblk(A.n, 256)), dim3(256), 0, m_stream, A, scale,
                            d);
         HIP_CHECK(hipGetLastError());
     }
     void count_nonfinite_async(size_t n, const double* x, double* out) override {
-        hipLaunchKernelGGL(nonfinite_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, red_to(out));
+        SANM_LAUNCH(nonfinite_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, red_to(out));
         HIP_CHECK(hipGetLastError());
     }
     int64_t count_nonfinite(size_t n, const double* x) override {
-        hipLaunchKernelGGL(nonfinite_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, red());
+        SANM_LAUNCH(nonfinite_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, red());
         return (int64_t)red_result()[0];
     }
     double allclose_excess(size_t n, const double* a, const double* b, double eps) override {
-        hipLaunchKernelGGL(allclose_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, a, b, eps,
+        SANM_LAUNCH(allclose_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, a, b, eps,
                            red());
         return red_result()[0];
     }
     void sanity_reduce(size_t n, const double* a, const double* b, double eps, size_t n1,
                        const double* x, const double* y, double out[2]) override {
         if (n1 < n) sanm_throw(SANM_ERR_ASSERT, "sanity_reduce: n1 < n");
-        hipLaunchKernelGGL(sanity_kernel, dim3(red_grid(n1)), dim3(256), 0, m_stream, n, a, b, eps, n1, x,
+        SANM_LAUNCH(sanity_kernel, dim3(red_grid(n1)), dim3(256), 0, m_stream, n, a, b, eps, n1, x,
                            y, red());
         const double* r = red_result();
         out[0] = r[0];
@@ -1907,7 +1917,7 @@ public:
     void sanity_check(const CsrDev& A, const double* xi, double ti, const double* grad_t, const double* bi,
                       double eps, size_t n1, const double* x1, double*, double*, double out[2]) override {
         if (n1 > (size_t)A.n * SPMV_LANES) sanm_throw(SANM_ERR_ASSERT, "sanity_check: n1 too large");
-        hipLaunchKernelGGL(sanity_check_kernel, dim3(red_grid((size_t)A.n * SPMV_LANES)), dim3(256), 0,
+        SANM_LAUNCH(sanity_check_kernel, dim3(red_grid((size_t)A.n * SPMV_LANES)), dim3(256), 0,
                            m_stream, A, xi, (const double*)nullptr, ti, grad_t, bi, eps, n1, x1, red());
         const double* r = red_result();
         out[0] = r[0];
@@ -1916,19 +1926,19 @@ public:
     void sanity_check_async(const CsrDev& A, const double* xi, const double* grad_t, const double* bi,
                             double eps, size_t n1, const double* x1, double*, double*, double* out2) override {
         if (n1 > (size_t)A.n * SPMV_LANES) sanm_throw(SANM_ERR_ASSERT, "sanity_check: n1 too large");
-        hipLaunchKernelGGL(sanity_check_kernel, dim3(red_grid((size_t)A.n * SPMV_LANES)), dim3(256), 0,
+        SANM_LAUNCH(sanity_check_kernel, dim3(red_grid((size_t)A.n * SPMV_LANES)), dim3(256), 0,
                            m_stream, A, xi, xi + A.n, 0.0, grad_t, bi, eps, n1, x1, red_to(out2));
         HIP_CHECK(hipGetLastError());
     }
     void launch_multi_dot(size_t n, const double* x, const VecList& v, const double* last_norm2,
                           const double* last_nn2, double eps, GridRed g) {
         switch ((v.n + 3) / 4) {
-            case 1: hipLaunchKernelGGL(multi_dot_kernel<4>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, last_norm2, last_nn2, eps, g); break;
-            case 2: hipLaunchKernelGGL(multi_dot_kernel<8>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, last_norm2, last_nn2, eps, g); break;
-            case 3: hipLaunchKernelGGL(multi_dot_kernel<12>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, last_norm2, last_nn2, eps, g); break;
-            case 4: hipLaunchKernelGGL(multi_dot_kernel<16>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, last_norm2, last_nn2, eps, g); break;
-            case 5: hipLaunchKernelGGL(multi_dot_kernel<20>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, last_norm2, last_nn2, eps, g); break;
-            default: hipLaunchKernelGGL(multi_dot_kernel<24>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, last_norm2, last_nn2, eps, g); break;
+            case 1: SANM_LAUNCH(multi_dot_kernel<4>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, last_norm2, last_nn2, eps, g); break;
+            case 2: SANM_LAUNCH(multi_dot_kernel<8>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, last_norm2, last_nn2, eps, g); break;
+            case 3: SANM_LAUNCH(multi_dot_kernel<12>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, last_norm2, last_nn2, eps, g); break;
+            case 4: SANM_LAUNCH(multi_dot_kernel<16>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, last_norm2, last_nn2, eps, g); break;
+            case 5: SANM_LAUNCH(multi_dot_kernel<20>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, last_norm2, last_nn2, eps, g); break;
+            default: SANM_LAUNCH(multi_dot_kernel<24>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, last_norm2, last_nn2, eps, g); break;
         }
     }
     void sanity_check_batch_async(const CsrDev& A, int nvec, const double* const* xs, const double* grad_t,
@@ -1946,7 +1956,7 @@ public:
                 a.x[q] = xs[q0 + (q < a.n ? q : 0)];
                 a.b[q] = bs[q0 + (q < a.n ? q : 0)];
             }
-            hipLaunchKernelGGL(sanity_check_multi_kernel, dim3(red_grid((size_t)A.n * SPMV_LANES)), dim3(256), 0,
+            SANM_LAUNCH(sanity_check_multi_kernel, dim3(red_grid((size_t)A.n * SPMV_LANES)), dim3(256), 0,
                                m_stream, A, a, grad_t, eps, n1, x1, red_to(out + 2 * q0));
         }
         HIP_CHECK(hipGetLastError());
@@ -1968,22 +1978,22 @@ public:
         v.n = nvec;
         for (int j = 0; j < nvec; ++j) v.p[j] = qs[j];
         switch ((nvec + 3) / 4) {
-            case 0: case 1: hipLaunchKernelGGL(gs_update_kernel<4>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, coefs, first, out, red_to(norm2)); break;
-            case 2: hipLaunchKernelGGL(gs_update_kernel<8>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, coefs, first, out, red_to(norm2)); break;
-            case 3: hipLaunchKernelGGL(gs_update_kernel<12>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, coefs, first, out, red_to(norm2)); break;
-            case 4: hipLaunchKernelGGL(gs_update_kernel<16>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, coefs, first, out, red_to(norm2)); break;
-            case 5: hipLaunchKernelGGL(gs_update_kernel<20>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, coefs, first, out, red_to(norm2)); break;
-            default: hipLaunchKernelGGL(gs_update_kernel<24>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, coefs, first, out, red_to(norm2)); break;
+            case 0: case 1: SANM_LAUNCH(gs_update_kernel<4>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, coefs, first, out, red_to(norm2)); break;
+            case 2: SANM_LAUNCH(gs_update_kernel<8>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, coefs, first, out, red_to(norm2)); break;
+            case 3: SANM_LAUNCH(gs_update_kernel<12>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, coefs, first, out, red_to(norm2)); break;
+            case 4: SANM_LAUNCH(gs_update_kernel<16>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, coefs, first, out, red_to(norm2)); break;
+            case 5: SANM_LAUNCH(gs_update_kernel<20>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, coefs, first, out, red_to(norm2)); break;
+            default: SANM_LAUNCH(gs_update_kernel<24>, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, v, coefs, first, out, red_to(norm2)); break;
         }
         HIP_CHECK(hipGetLastError());
     }
     void scale_rsqrt_async(size_t n, double* v, const double* norm2, double eps, double* nn2) override {
-        hipLaunchKernelGGL(scale_rsqrt_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, v, norm2, eps,
+        SANM_LAUNCH(scale_rsqrt_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, v, norm2, eps,
                            red_to(nn2));
         HIP_CHECK(hipGetLastError());
     }
     void gs_renorm_async(size_t n, double* v, const double* norm2, const double* nn2, double eps) override {
-        hipLaunchKernelGGL(renorm_scale_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, v, norm2, eps, nn2);
+        SANM_LAUNCH(renorm_scale_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, v, norm2, eps, nn2);
         HIP_CHECK(hipGetLastError());
     }
     bool graph_capture_begin() override {
@@ -2005,7 +2015,7 @@ public:
         if (g) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(g));
     }
     void dot_async(size_t n, const double* x, const double* y, double* out) override {
-        hipLaunchKernelGGL(dot_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, y, red_to(out));
+        SANM_LAUNCH(dot_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, y, red_to(out));
         HIP_CHECK(hipGetLastError());
     }
     void next_coeff_async(size_t n, const double* num, double scale, const double* x, const double* y,
@@ -2013,10 +2023,10 @@ public:
         const unsigned own = nblk(n + 1, 256);
         if (m_pending.kind == 3 && m_stream == m_main) {  // the scaling of a Gram-Schmidt step rides along
             const GsRider rd = take_rider();
-            hipLaunchKernelGGL(next_coeff_kernel<true>, dim3(own + rd.nblk), dim3(256), 0, m_stream, n, num, scale, x, y,
+            SANM_LAUNCH(next_coeff_kernel<true>, dim3(own + rd.nblk), dim3(256), 0, m_stream, n, num, scale, x, y,
                                out, t_out, own, rd);
         } else {
-            hipLaunchKernelGGL(next_coeff_kernel<false>, dim3(own), dim3(256), 0, m_stream, n, num, scale, x, y, out,
+            SANM_LAUNCH(next_coeff_kernel<false>, dim3(own), dim3(256), 0, m_stream, n, num, scale, x, y, out,
                                t_out, own, GsRider{});
         }
         HIP_CHECK(hipGetLastError());
@@ -2031,7 +2041,7 @@ public:
     }
     double t0v_excess(size_t n, const double* fx, const double* v, double t0,
                       double tol) override {
-        hipLaunchKernelGGL(t0v_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, fx, v, t0, tol,
+        SANM_LAUNCH(t0v_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, fx, v, t0, tol,
                            red());
         return red_result()[0];
     }

@@ -611,6 +611,18 @@ int sanm_anm_profile_counts(const sanm_anm_solver* s, int max_tags, double* coun
     });
     return rc == 0 ? k : -std::abs(rc);
 }
+int sanm_anm_profile_launches(const sanm_anm_solver* s, int max_tags, double* launches) {
+    int k = 0;
+    const int rc = guard([&] {
+        const auto& L = s->drv->profile_launches();
+        for (auto& kv : s->drv->profile()) {  // same order as sanm_anm_profile
+            auto it = L.find(kv.first);
+            if (k < max_tags && launches) launches[k] = it == L.end() ? 0.0 : it->second;
+            ++k;
+        }
+    });
+    return rc == 0 ? k : -std::abs(rc);
+}
 int sanm_anm_profile(const sanm_anm_solver* s, int max_tags, const char** names, double* seconds) {
     auto* ms = const_cast<sanm_anm_solver*>(s);
     int k = 0;

@@ -16,10 +16,11 @@ approximation within the range criterion -- to the same equilibrium.
 What is checked instead, at EVERY step, from a COMMON state:
   1. both sides expand at the same point (the oracle is re-started at the device's restart point, which was first
      compared with the oracle's own evaluation of the approximant at the device's parameter);
-  2. residual RMS, the plain-series range a_bound and the series themselves agree tightly (1e-7 / 1e-6);
+  2. residual RMS (1e-7), the series as functions on [0, a_bound] and their first coefficient (1e-6) and the
+     plain-series range a_bound (1e-7 + the relative error it inherits from |x_1| and |x_N|) agree;
   3. the outcome of the range estimate -- Pade accepted or not, accepted range -- is either identical, or CERTIFIED
      ill-conditioned: the oracle's own series of that step, perturbed by relative noise of the size of the measured
-     device-oracle difference of the series (>= 1e-13), makes the ORACLE produce the device's flag, and ranges on
+     device-oracle difference of each series coefficient (>= 1e-13), makes the ORACLE produce the device's flag, and ranges on
      both sides of the device's, within `trials` draws.  A decision the oracle keeps under all perturbations but the
      device takes differently fails the test;
   4. the root finder is outside that uncertainty (bit-exact on both sides, tests/golden/ref_poly.json): on the
@@ -33,28 +34,35 @@ from oracle import unary_polynomial as up
 from oracle.pade import PadeApproximation
 
 
-def series_gap(dev_coeffs, orc_coeffs):
-    """largest relative difference between the two sides' series coefficient vectors of one expansion"""
-    gap = 0.0
-    for d, o in zip(dev_coeffs, orc_coeffs):
-        s = float(np.abs(o).max())
-        if s > 0:
-            gap = max(gap, float(np.abs(np.asarray(d) - o).max()) / s)
-    return gap
+def series_gaps(dev_coeffs, orc_coeffs, a):
+    """per coefficient: relative difference of the two sides' vectors (max norm); and the difference of the two
+    SERIES on [0, a]: max_k |dx_k| a^k / max_k |x_k| a^k, k >= 1.  (Near convergence the high-order coefficients
+    are tiny and carry the round-off of the bias evaluation at a relative size that their own norm does not
+    excuse but their weight in the series does.)"""
+    rel, wd, wx = [], 0.0, 0.0
+    for k, (d, o) in enumerate(zip(dev_coeffs, orc_coeffs)):
+        sc = float(np.abs(o).max())
+        df = float(np.abs(np.asarray(d) - o).max())
+        rel.append(df / sc if sc > 0 else 0.0)
+        if k >= 1:
+            wd = max(wd, df * a ** k)
+            wx = max(wx, sc * a ** k)
+    return rel, (wd / wx if wx > 0 else 0.0)
 
 
 def _outcome(diag, a_bound):
     return (bool(diag.get("accepted")), float(diag["t_max_a"]) if diag.get("accepted") else float(a_bound))
 
 
-def certify(osolver, dev_outcome, gap, rng, trials):
-    """the oracle's range estimate on perturbed copies of its own series: returns (certified, draws)"""
+def certify(osolver, dev_outcome, rel_gaps, rng, trials):
+    """the oracle's range estimate on perturbed copies of its own series (coefficient k by relative noise of the
+    size of the measured device-oracle difference of that coefficient): returns (certified, draws, noise level)"""
     hp = osolver.hp
-    delta = min(max(gap, 1e-13), 1e-8)
+    delta = [min(max(g, 1e-13), 1e-4) for g in rel_gaps]
     own = _outcome(osolver.pade_diags[-1], osolver.a_bound)
     draws = [own]
     for _ in range(trials):
-        xs = [x * (1.0 + delta * rng.standard_normal(x.shape)) for x in osolver.xt_coeffs]
+        xs = [x * (1.0 + dk * rng.standard_normal(x.shape)) for x, dk in zip(osolver.xt_coeffs, delta)]
         p = PadeApproximation(xs, not hp.xcoeff_l2_penalty, False)
         p.estimate_valid_range(osolver.a_bound, hp.maxr, osolver.max_a_bound)
         draws.append(_outcome(p.diag, osolver.a_bound))
@@ -62,8 +70,8 @@ def certify(osolver, dev_outcome, gap, rng, trials):
         same = [d[1] for d in draws if d[0] == dev_outcome[0]]
         if dev_outcome[0] in flags and (not dev_outcome[0] or
                                         min(same) <= dev_outcome[1] * (1 + 1e-6) and max(same) >= dev_outcome[1] * (1 - 1e-6)):
-            return True, draws, delta
-    return False, draws, delta
+            return True, draws, max(delta)
+    return False, draws, max(delta)
 
 
 class LockStep:
@@ -88,12 +96,17 @@ class LockStep:
             self.steps.append(rec)
             return
         dd, od = s.pade_diag(), o.pade_diags[-1]
-        gap = series_gap(s.xt_coeffs(), o.xt_coeffs)
+        rel, gap = series_gaps(s.xt_coeffs(), o.xt_coeffs, o.a_bound)
         rec["series_gap"] = gap
-        assert gap <= self.series_rtol, f"step {k}: series coefficients differ by {gap:.2e}"
+        rec["coeff_gap_1_2_N"] = (rel[1], rel[2], rel[-1])
+        assert gap <= self.series_rtol and rel[1] <= self.series_rtol, \
+            f"step {k}: the series differ by {gap:.2e} on [0, a_bound] (x_1: {rel[1]:.2e})"
         assert bool(dd["attempted"]) == bool(od["attempted"]), f"step {k}: Pade attempted on one side only"
         a_bound_dev = dd["start"] if dd["attempted"] else s.get_t_max_a()
-        assert abs(a_bound_dev - o.a_bound) <= 1e-7 * o.a_bound, f"step {k}: a_bound {a_bound_dev} vs {o.a_bound}"
+        # a_bound = (maxr |x_1| / |x_N|)^(1/(N-1)), anm.cpp:126: it inherits the relative error of the two norms
+        N = len(rel) - 1
+        a_tol = 1e-7 + (rel[1] + rel[-1]) / (N - 1)
+        assert abs(a_bound_dev - o.a_bound) <= a_tol * o.a_bound, f"step {k}: a_bound {a_bound_dev} vs {o.a_bound}"
         dev = (bool(s.has_pade()), float(s.get_t_max_a()))
         own = _outcome(od, o.a_bound)
         rec.update(device=dev, oracle=own, margin_left=(dd["probes"][0][1] if dd["probes"] else None,
@@ -102,8 +115,8 @@ class LockStep:
             # the root finder is a deterministic function of the coefficients, bit-exact on both sides
             assert (up.real_roots(list(dd["d"])) is not None) == bool(dd["roots_valid"]), \
                 f"step {k}: root finder outcome on the device's own denominator"
-        if dev[0] != own[0] or abs(dev[1] - own[1]) > 1e-6 * own[1]:
-            ok, draws, delta = certify(o, dev, gap, self.rng, self.trials)
+        if dev[0] != own[0] or abs(dev[1] - own[1]) > (1e-6 + a_tol) * own[1]:
+            ok, draws, delta = certify(o, dev, rel, self.rng, self.trials)
             ev = {"step": k, "device": dev, "oracle": own, "series_gap": gap, "perturbation": delta,
                   "device_roots_valid": bool(dd.get("roots_valid")), "oracle_roots_valid": bool(od.get("roots_valid")),
                   "draws": sorted(set(draws)), "certified": ok}

@@ -60,7 +60,8 @@ def _run_two_ranks(extra):
 def _check_common(d):
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1
     fam = d["roofline_families"]
-    assert set(fam) == {"solve", "factor", "taylor", "io", "asm", "tail"}
+    # (the all-reduces of the tet-sharded mode are a family of their own, priced against nothing)
+    assert set(fam) - {"collective"} == {"solve", "factor", "taylor", "io", "asm", "tail"}
     assert d["roofline"]["family"] in fam and d["roofline"]["bound"] == "hbm"
     assert abs(sum(f["share_of_step"] for f in fam.values()) - 1) < 1e-6
     assert d["roofline_whole_step"]["algorithmic_bytes_per_step"] > 0

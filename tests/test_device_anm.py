@@ -102,7 +102,6 @@ def test_first_step_coefficients_and_jacobian(api):
     assert st["nr_unknown"] == omodel.lt_inp.n and st["nr_tet"] == omesh.nr_tet
 
 
-@pytest.mark.parametrize("use_pade", [False, True])
 def _verbose_numbers(text):
     import re
     return [float(x) for x in re.findall(r"[-+]?(?:\d+\.?\d*|\.\d+)(?:[eE][-+]?\d+)?|nan|inf", text)]
@@ -135,6 +134,7 @@ def test_verbose_printout_matches_the_reference_format(api):
     assert len(nd) == len(no) and all(abs(a - b) <= 2e-3 * abs(b) + 1e-12 for a, b in zip(nd, no))
 
 
+@pytest.mark.parametrize("use_pade", [False, True])
 def test_vecscale_solver_path_following(api, use_pade):
     """ANMSolverVecScale: f(x) + t*v = 0 followed with update_approx (the
     save_interm branch of run_and_save, fea/main.cpp:386-414).  Without Pade both sides evaluate the same
