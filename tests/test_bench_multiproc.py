@@ -81,5 +81,7 @@ def test_two_rank_shard_is_the_default_and_terminates():
     d = _run_two_ranks([])
     _check_common(d)
     assert d["scaling"] == "strong" and d["config"]["parallelism"].startswith("tet-shard")
+    assert "collective" in d["roofline_families"] and d["roofline_families"]["collective"]["bound"] == "xgmi"
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["launches_per_step"] is not None
     # one problem: value = K / max-over-ranks time
     assert abs(d["value"] - 3 / (d["ms_per_step"] * 3 / 1e3)) < 1e-6 * d["value"]

@@ -111,3 +111,122 @@ def test_four_rank_tet_shard_matches_single_rank():
     for r in res:
         assert r["steps"] == r["ref_steps"] and r["err"] < 1e-9 and r["rms"] < 1e-10
         assert r["ncall"] == r["steps"] * (1 + 1 + (12 - 1)) + 1
+
+
+WORKER_NAMED = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+from tests.hostsim import get_hostsim_api
+from sanm_amd import fea as dfea, dist as sdist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+api = get_hostsim_api()
+ncall, nbytes = [0], [0]
+base = sdist.make_host_allreduce()
+def counted(ptr, count):
+    ncall[0] += 1
+    nbytes[0] += 8 * int(count)
+    base(ptr, count)
+cfg, mesh = dfea.load_named_config({name!r})
+run = dfea.GravityRun(api, mesh, dict(cfg), shard=(rank, world, counted)).run()
+V = run.vertices()
+out = dict(rank=rank, steps=int(run.solver.get_nr_iter()), ncall=ncall[0], nbytes=nbytes[0], rms=run.rms,
+           order=int(cfg.get("order", 20)), st=run.solver.stats())
+if rank == 0:
+    cfg2, mesh2 = dfea.load_named_config({name!r})
+    ref = dfea.GravityRun(api, mesh2, dict(cfg2)).run()
+    Vr = ref.vertices()
+    out.update(ref_steps=int(ref.solver.get_nr_iter()), err=float(np.abs(V - Vr).max() / np.abs(Vr).max()),
+               ref_rms=ref.rms)
+print("RESULT " + json.dumps(out), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_shard_at_baseline_size():
+    """BASELINE config 2's input (bob: 27,577 tets, 22,128 unknowns, Neo-Hookean incompressible, order 20, Pade and
+    sanity checks on) tet-sharded over two ranks (gloo + host harness): the step count of the unsharded solve, its
+    vertices to 1e-9, and exactly the collectives DESIGN.md section 7 lists -- per completed step one all-reduce of
+    f(x0) (n doubles), one of the Jacobian values (nnz doubles) and order - 1 of b_k (n doubles each), plus f(x0)
+    of the converged call."""
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), SANM_CPU_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER_NAMED.format(root=ROOT, name="bob")], env=env,
+                                      cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = []
+    for p in procs:
+        so, se = p.communicate(timeout=900)
+        assert p.returncode == 0, se[-3000:]
+        res.append(json.loads([l for l in so.splitlines() if l.startswith("RESULT ")][0][7:]))
+    r0 = [r for r in res if r["rank"] == 0][0]
+    assert r0["steps"] == r0["ref_steps"] >= 1 and r0["err"] < 1e-9 and r0["rms"][-1] < 1e-10
+    assert res[0]["steps"] == res[1]["steps"]
+    for r in res:
+        steps, order = r["steps"], r["order"]
+        n, nnz = r["st"]["nr_unknown"], r["st"]["jacobian_nnz"]
+        assert r["ncall"] == steps * (1 + 1 + (order - 1)) + 1
+        assert r["nbytes"] == 8 * (steps * (n + nnz + (order - 1) * n) + n)
+
+
+WORKER_COMM = r"""
+import json, os, sys
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+from sanm_amd import dist as sdist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+class Fake:
+    def __init__(self, avail=True, uid_fails=False, init_fails_on=None):
+        self.avail, self.uid_fails, self.init_fails_on = avail, uid_fails, init_fails_on
+        self.inited = self.destroyed = False
+    def comm_available(self): return self.avail
+    def comm_unique_id(self):
+        if self.uid_fails: raise RuntimeError("RCCL could not be loaded")
+        return b"u" * 128
+    def comm_init(self, r, w, uid):
+        assert uid == b"u" * 128
+        if self.init_fails_on == r: raise RuntimeError("ncclCommInitRank failed")
+        self.inited = True
+    def comm_destroy(self): self.destroyed = True
+out = dict(rank=rank)
+cases = dict(ok=Fake(), unavailable_on_1=Fake(avail=(rank != 1)), uid_fails=Fake(uid_fails=True),
+             init_fails_on_1=Fake(init_fails_on=1))
+for name, api in cases.items():
+    out[name] = [sdist.init_native_comm(api, rank, world, device="cpu"), api.inited, api.destroyed]
+print("RESULT " + json.dumps(out), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_native_comm_setup_agrees_across_ranks_whatever_fails():
+    """sanm_amd.dist.init_native_comm: every rank must take the same sequence of collectives and reach the same
+    verdict when RCCL is unavailable on one rank, when rank 0 cannot draw the identifier, and when the collective
+    init fails on one rank (the others then drop their communicator again) -- round 2 let rank 0 raise before the
+    broadcast the other ranks were waiting in."""
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER_COMM.format(root=ROOT)], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = {}
+    for p in procs:
+        so, se = p.communicate(timeout=300)  # a hang is the failure mode
+        assert p.returncode == 0, se[-3000:]
+        r = json.loads([l for l in so.splitlines() if l.startswith("RESULT ")][0][7:])
+        res[r["rank"]] = r
+    for rank in (0, 1):
+        assert res[rank]["ok"] == [True, True, False]
+        assert res[rank]["unavailable_on_1"][0] is False and res[rank]["unavailable_on_1"][1] is False
+        assert res[rank]["uid_fails"][0] is False and res[rank]["uid_fails"][1] is False
+        assert res[rank]["init_fails_on_1"][0] is False
+    assert res[0]["init_fails_on_1"] == [False, True, True]   # rank 0 had joined and dropped it again
+    assert res[1]["init_fails_on_1"] == [False, False, False]
