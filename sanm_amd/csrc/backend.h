@@ -90,6 +90,8 @@ public:
     //! graph_launch (a launch-bound sequence of small kernels whose arguments do not change from one
     //! continuation step to the next).  begin returns false if the backend has no graphs: the caller then
     //! simply runs the sequence.
+    //! a buffer that keyed replayed launch chains (the direct solver's front store) is going away
+    virtual void forget_chains(const void* key) { (void)key; }
     virtual bool graph_capture_begin() { return false; }
     virtual void* graph_capture_end() { return nullptr; }
     virtual void graph_launch(void*) {}

@@ -967,6 +967,69 @@ class HipBackend final : public Backend {
     int m_fork_next = 0;
     Rccl::Comm m_comm = nullptr;
     int64_t m_launch_count = 0;
+    // Replayed launch chains (hipGraph): the level sweeps of a solve and the whole numeric factorisation are fixed
+    // sequences of kernels with fixed arguments per solver.  scripts/micro/graph_chain.hip: a dependent chain costs
+    // 3.1 us per kernel as stream launches and 2.5 (16 kernels) to 2.05 us (340 kernels) replayed as a graph.
+    // A chain is launched directly the first time (lazy allocations, function attributes), captured the second
+    // time and replayed from then on.  MEASURED ON THE REAL CHAINS (armadillo_small, round 3): bit-identical
+    // results and SLOWER -- 5.86 against 5.64 ms per step (solves 2.30 against 2.19 ms, factorisation 1.91
+    // against 1.90): a level kernel lasts 5-6 us because of its own chain of dependent memory round trips, behind
+    // which the command processor already hides the packet handling that a graph saves on empty kernels, and every
+    // replay adds its own launch.  Off by default; SANM_MF_GRAPH=1 switches it on.
+    struct ChainGraph {
+        hipGraphExec_t exec = nullptr;
+        int uses = 0;
+        int64_t launches = 0;          // kernel launches one replay stands for
+        const void* arg0 = nullptr;    // the pointer arguments the capture baked in
+        const void* arg1 = nullptr;
+    };
+    std::map<std::pair<const void*, int>, ChainGraph> m_chains;
+    const bool m_chain_graphs = std::getenv("SANM_MF_GRAPH") != nullptr;
+    bool m_capturing = false;
+    //! runs `body` (a fixed sequence of launches on m_stream): directly, or as a replay of its captured form
+    template <class F>
+    void run_chain(const void* key, int kind, const void* arg0, const void* arg1, F&& body) {
+        if (!m_chain_graphs || m_capturing || m_stream != m_main) {
+            body();
+            return;
+        }
+        ChainGraph& c = m_chains[{key, kind}];
+        if (c.exec && (c.arg0 != arg0 || c.arg1 != arg1)) {  // other buffers than the captured ones: start over
+            (void)hipGraphExecDestroy(c.exec);
+            c = ChainGraph{};
+        }
+        if (c.exec) {
+            HIP_CHECK(hipGraphLaunch(c.exec, m_stream));
+            m_launch_count += c.launches;
+            return;
+        }
+        if (c.uses++ == 0) {
+            body();
+            return;
+        }
+        const int64_t l0 = m_launch_count;
+        hipGraph_t graph = nullptr;
+        m_capturing = true;
+        HIP_CHECK(hipStreamBeginCapture(m_stream, hipStreamCaptureModeThreadLocal));
+        try {
+            body();
+        } catch (...) {
+            (void)hipStreamEndCapture(m_stream, &graph);
+            if (graph) (void)hipGraphDestroy(graph);
+            m_capturing = false;
+            throw;
+        }
+        HIP_CHECK(hipStreamEndCapture(m_stream, &graph));
+        m_capturing = false;
+        HIP_CHECK(hipGraphInstantiate(&c.exec, graph, nullptr, nullptr, 0));
+        HIP_CHECK(hipGraphDestroy(graph));
+        c.launches = m_launch_count - l0;
+        c.arg0 = arg0;
+        c.arg1 = arg1;
+        m_launch_count = l0;
+        HIP_CHECK(hipGraphLaunch(c.exec, m_stream));
+        m_launch_count += c.launches;
+    }
     int m_comm_rank = 0, m_comm_world = 0;
     // pass kernels compiled at run time for one program each (specialize)
     struct SpecKernels {
@@ -1030,7 +1093,22 @@ public:
         HIP_CHECK(hipMalloc(&m_scalar, 64));
         HIP_CHECK(hipHostMalloc(&m_scalar_host, 64));
     }
+    void forget_chains(const void* key) override {
+        for (auto it = m_chains.begin(); it != m_chains.end();) {
+            if (it->first.first == key) {
+                if (it->second.exec) {
+                    (void)hipStreamSynchronize(m_main);
+                    (void)hipGraphExecDestroy(it->second.exec);
+                }
+                it = m_chains.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    }
     ~HipBackend() override {
+        for (auto& kv : m_chains)
+            if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
         comm_destroy();
         (void)hipFree(m_scalar);
         for (auto& kv : m_pool_free)
@@ -1271,6 +1349,7 @@ public:
             size_t arg_size = sizeof(args);
             void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_size,
                               HIP_LAUNCH_PARAM_END};
+            ++m_launch_count;
             HIP_CHECK(hipModuleLaunchKernel(m_spec[P.spec_id].pass[mode], nblk(P.T, 64), mode == PASS_GRAD ? P.odim : 1,
                                             1, 64 * nparts, 1, 1, (unsigned)lds, m_stream, nullptr, config));
             if (m_time_passes) {
@@ -1504,8 +1583,10 @@ public:
         return *hs;
     }
     void mf_factor_async(const MfDev& mf, const MfSchedule& sch, const CsrDev& A, double* status) override {
-        mf_factor_launch(mf, sch, A);
-        SANM_LAUNCH(status_to_double_kernel, dim3(1), dim3(1), 0, m_stream, mf.status, status);
+        run_chain(mf.front_store, 1, A.val, status, [&] {
+            mf_factor_launch(mf, sch, A);
+            SANM_LAUNCH(status_to_double_kernel, dim3(1), dim3(1), 0, m_stream, mf.status, status);
+        });
         HIP_CHECK(hipGetLastError());
     }
 #ifdef SANM_MF_PHASES
@@ -1706,6 +1787,10 @@ public:
             SANM_LAUNCH(permute_in_kernel, dim3(nblk(mf.n, 256)), dim3(256), 0, m_stream, mf.n,
                                mf.perm, b, mf.work);
         const int nl = (int)sch.levels.size(), below = sch.top.enabled ? nl - 2 : nl;
+        MfDev mb = mf;
+        if (sch.top.enabled) mb.bnd_idx = sch.top.bnd_x;
+        const int32_t* perm_out = sch.top.enabled ? sch.top.perm_x : mf.perm;
+        run_chain(mf.front_store, 0, mf.work, nullptr, [&] {
         for (int li = 0; li < below; ++li) level_solve(true, mf, sch.levels[li]);
         if (sch.top.enabled) {
             const auto& T = sch.top;
@@ -1724,10 +1809,8 @@ public:
 #undef SANM_TS
         }
         // (with the merged block its solution sits behind the n entries of work: redirected lists, mf_types.h)
-        MfDev mb = mf;
-        if (sch.top.enabled) mb.bnd_idx = sch.top.bnd_x;
-        const int32_t* perm_out = sch.top.enabled ? sch.top.perm_x : mf.perm;
         for (int li = below - 1; li >= 0; --li) level_solve(false, mb, sch.levels[li]);
+        });
         if (dot_y) {
             const unsigned own = red_grid(mf.n);
             if (m_pending.kind == 2 && m_stream == m_main) {  // the update of a Gram-Schmidt step rides along
@@ -2000,11 +2083,13 @@ public:
         flush_deferred();
         red();  // no allocation while capturing
         HIP_CHECK(hipStreamBeginCapture(m_stream, hipStreamCaptureModeThreadLocal));
+        m_capturing = true;
         return true;
     }
     void* graph_capture_end() override {
         hipGraph_t graph = nullptr;
         HIP_CHECK(hipStreamEndCapture(m_stream, &graph));
+        m_capturing = false;
         hipGraphExec_t exec = nullptr;
         HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
         HIP_CHECK(hipGraphDestroy(graph));

@@ -646,6 +646,7 @@ T* Multifrontal::upload(const std::vector<T>& v) {
 }
 
 Multifrontal::~Multifrontal() {
+    m_be->forget_chains(m_dev.front_store);  // replayed launch chains captured on this solver's buffers
     for (void* p : m_bufs) m_be->free(p);
 }
 
