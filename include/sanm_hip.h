@@ -202,9 +202,6 @@ int sanm_anm_time_kernel(sanm_anm_solver* s, int kernel, int reps, int mode, int
  * time for batches of SANM_JIT_MIN_T tets or more).  Returns the length of the source;
  * copies at most cap-1 characters and a terminator into buf if it is not NULL. */
 int64_t sanm_anm_spec_source(sanm_anm_solver* s, char* buf, int64_t cap);
-/* test hook, needs no device: 0 if `source` (which may include "program.h" / "tet_ops.h") compiles for gfx950
- * with the run-time compiler; the compiler's log goes to `log`, the size of the code object to *code_size. */
-int sanm_rtc_compile_check(const char* source, char* log, size_t log_cap, size_t* code_size);
 /* measurement hook for bench.py: when enabled, every launch of the Taylor pass
  * kernel (the graph interpreter) is bracketed by HIP events on the solver's
  * stream.  Each call first returns the summed duration / launch count gathered
@@ -232,12 +229,6 @@ typedef struct sanm_anm_stats {
     double factor_flops;
 } sanm_anm_stats;
 int sanm_anm_get_stats(const sanm_anm_solver* s, sanm_anm_stats* st);
-/* test hook (fault injection): during the next expansion, corrupt one entry -- kind 1: coefficient x_order[index],
- * 2: right-hand side b_order[index] before its solve, 3: Jacobian values [index, index + max(order, 1)) after the
- * assembly; the entry is multiplied by `value` if scale != 0, else replaced by it (NaN allowed).  The checks the reference makes per
- * order (libsanm/anm.cpp:271-285, sparse_solver.cpp:160-161, :288-289) are batched after the order loop here;
- * tests/test_fault_injection.py uses this hook to show that each of them fires. */
-int sanm_anm_debug_inject(sanm_anm_solver* s, int kind, int order, int64_t index, double value, int scale);
 /* profile tags: returns the number of tags (or minus an error code: the call reads device events);
  * names/seconds may be NULL */
 int sanm_anm_profile(const sanm_anm_solver* s, int max_tags, const char** names, double* seconds);

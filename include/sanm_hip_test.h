@@ -1,0 +1,32 @@
+/* sanm_hip_test.h -- TEST HOOKS of libsanm_hip.so.
+ *
+ * Not part of the interface a maintainer of the reference binds (include/sanm_hip.h): these entry points exist for
+ * this repository's own tests (fault injection, a compile check of the generated kernels that needs no GPU, cache
+ * counters).  They are exported from the same library so that the tests exercise the product's own code paths. */
+#ifndef SANM_HIP_TEST_H
+#define SANM_HIP_TEST_H
+#include "sanm_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* test hook (fault injection): during the next expansion, corrupt one entry -- kind 1: coefficient x_order[index],
+ * 2: right-hand side b_order[index] before its solve, 3: Jacobian values [index, index + max(order, 1)) after the
+ * assembly; the entry is multiplied by `value` if scale != 0, else replaced by it (NaN allowed).  The checks the reference makes per
+ * order (libsanm/anm.cpp:271-285, sparse_solver.cpp:160-161, :288-289) are batched after the order loop here;
+ * tests/test_fault_injection.py uses this hook to show that each of them fires. */
+int sanm_anm_debug_inject(sanm_anm_solver* s, int kind, int order, int64_t index, double value, int scale);
+
+/* test hook, needs no device: 0 if `source` (which may include "program.h" / "tet_ops.h") compiles for gfx950
+ * with the run-time compiler; the compiler's log goes to `log`, the size of the code object to *code_size. */
+int sanm_rtc_compile_check(const char* source, char* log, size_t log_cap, size_t* code_size);
+/* how the code objects of the run-time compiled pass kernels were obtained in this process so far: compilations,
+ * hits of the in-process cache, hits of the on-disk cache (rtc.cpp) */
+int sanm_rtc_cache_stats(int64_t* compiled, int64_t* memory_hits, int64_t* disk_hits);
+/* obtains the code object of `source` through the caches exactly like a solver under construction does; 0 = ok */
+int sanm_rtc_cache_probe(const char* source);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SANM_HIP_TEST_H */

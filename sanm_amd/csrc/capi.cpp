@@ -1,5 +1,6 @@
 // extern "C" entry points declared in include/sanm_hip.h.
 #include "../../include/sanm_hip.h"
+#include "../../include/sanm_hip_test.h"
 
 #include <cstring>
 #include <memory>

@@ -1,9 +1,15 @@
-// hiprtc front end for the specialised pass kernels (rtc.cpp)
+// Run-time compilation of the pass kernels specialised for a graph (hiprtc bound with dlopen; rtc.cpp).
 #pragma once
+#include <cstdint>
 #include <string>
 #include <vector>
 
 namespace sanm_hip {
-//! compile `source` (which may include "program.h" / "tet_ops.h") for gfx950; false + log on failure
-bool rtc_compile(const char* source, std::vector<char>& code, std::string& log);
+struct RtcStats {
+    int64_t compiled = 0, memory_hits = 0, disk_hits = 0;
+};
+//! code object for gfx950 of `source` (which may include "program.h" / "tet_ops.h"); with use_cache the process-wide
+//! and the on-disk cache are consulted first and filled afterwards
+bool rtc_compile(const char* source, std::vector<char>& code, std::string& log, bool use_cache = true);
+RtcStats rtc_stats();
 }  // namespace sanm_hip

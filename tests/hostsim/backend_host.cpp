@@ -368,3 +368,10 @@ void hostsim_mf_solve(const MfDev& mf, const MfSchedule& sch, const double* b, d
 
 // the run-time compiler belongs to the product library only (sanm_amd/csrc/rtc.cpp)
 extern "C" int sanm_rtc_compile_check(const char*, char*, size_t, size_t*) { return 2; }
+extern "C" int sanm_rtc_cache_stats(int64_t* compiled, int64_t* memory_hits, int64_t* disk_hits) {
+    if (compiled) *compiled = 0;
+    if (memory_hits) *memory_hits = 0;
+    if (disk_hits) *disk_hits = 0;
+    return 0;
+}
+extern "C" int sanm_rtc_cache_probe(const char*) { return 2; }

@@ -1,4 +1,5 @@
-"""The C-ABI library loads and exports every symbol include/sanm_hip.h declares.
+"""The C-ABI library loads and exports every symbol include/sanm_hip.h (the interface) and include/sanm_hip_test.h
+(this repository's test hooks) declare.
 No compute calls: this runs in the GPU-less container."""
 import ctypes
 import os
@@ -9,10 +10,20 @@ import pytest
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-def _declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "sanm_hip.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(sanm_[A-Za-z0-9_]+)\s*\(", txt)))
+def _declared_symbols(headers=("sanm_hip.h", "sanm_hip_test.h")):
+    out = set()
+    for h in headers:
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        out |= set(re.findall(r"\b(sanm_[A-Za-z0-9_]+)\s*\(", txt))
+    return sorted(out)
+
+
+def test_the_interface_header_declares_no_test_hook():
+    iface = _declared_symbols(("sanm_hip.h",))
+    assert "sanm_anm_debug_inject" not in iface and "sanm_rtc_compile_check" not in iface
+    assert set(_declared_symbols(("sanm_hip_test.h",))) == {"sanm_anm_debug_inject", "sanm_rtc_compile_check",
+                                                            "sanm_rtc_cache_stats", "sanm_rtc_cache_probe"}
 
 
 def test_header_symbols_are_exported():

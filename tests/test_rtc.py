@@ -51,3 +51,32 @@ def test_generated_source_compiles(energy):
     src = run.solver.spec_source()
     assert "spec_pass3" in src and "SPEC_OPS" in src
     assert _check(lib, src) > 10000
+
+
+def test_code_object_cache(tmp_path, monkeypatch):
+    """rtc.cpp: a code object is compiled once; the second request of the same source is served from the process
+    cache and, in a new process, from the on-disk cache ($SANM_JIT_CACHE_DIR).  No GPU needed (hiprtc only compiles);
+    run in subprocesses because the process cache is what is being observed."""
+    import subprocess
+    import sys
+    prog = r'''
+import ctypes as C, os, sys
+lib = C.CDLL(os.path.join(%r, "sanm_amd", "libsanm_hip.so"))
+lib.sanm_rtc_cache_probe.argtypes = [C.c_char_p]
+src = b'#include "program.h"\nextern "C" __global__ void k(double* x) { x[threadIdx.x] = %s; }\n'
+n = int(sys.argv[1])
+for _ in range(n):
+    assert lib.sanm_rtc_cache_probe(src) == 0
+c, m, d = C.c_int64(), C.c_int64(), C.c_int64()
+lib.sanm_rtc_cache_stats(C.byref(c), C.byref(m), C.byref(d))
+print(c.value, m.value, d.value)
+''' % (ROOT, "1.5")
+    env = dict(os.environ, SANM_JIT_CACHE_DIR=str(tmp_path / "cache"))
+    run = lambda n, e=env: subprocess.run([sys.executable, "-c", prog, str(n)], env=e, capture_output=True, text=True,
+                                          check=True).stdout.split()
+    assert run(3) == ["1", "2", "0"]          # compiled once, twice from memory
+    files = os.listdir(tmp_path / "cache")
+    assert len(files) == 1 and files[0].endswith(".hsaco")
+    assert run(2) == ["0", "1", "1"]          # a new process: from disk, then from memory
+    env2 = dict(env, SANM_NO_JIT_CACHE="1")
+    assert run(1, env2) == ["1", "0", "0"]    # disk cache off: compiled again
