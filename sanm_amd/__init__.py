@@ -15,7 +15,8 @@ from .api import (ANMEqnSolver, ANMImplicitSolver, ANMSolverVecScale, Api, SanmE
                   SanmAssertionError, SanmNumericalError, SanmUnsupportedError, SymbolVar,
                   TaylorCoeffProp, batched_mat_inv_mul, constant, linear_combine, placeholder)
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsanm_hip.so")
+# (SANM_HIP_LIBRARY: another build of the same library, for A/B measurements -- scripts/build_variants.py)
+LIB_PATH = os.environ.get("SANM_HIP_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsanm_hip.so")
 _API = None
 
 

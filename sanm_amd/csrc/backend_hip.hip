@@ -1049,7 +1049,10 @@ class HipBackend final : public Backend {
     static constexpr int kSolveLdsMax = 150 * 1024;
     // fronts from this many pivots on are factored with two blocking levels (measured: pays from ~400) (outer blocks of kOuterPanels
     // 32-wide panels); SANM_MF_OUTER_MIN_K overrides it (tests force the path on small fronts)
-    static constexpr int kOuterPanels = 4;
+#ifndef SANM_MF_OUTER_PANELS
+#define SANM_MF_OUTER_PANELS 4
+#endif
+    static constexpr int kOuterPanels = SANM_MF_OUTER_PANELS;
     static constexpr int kOuterMinK = 512;
     int m_conv_parts = std::getenv("SANM_CONV_PARTS") ? std::atoi(std::getenv("SANM_CONV_PARTS")) : 4;
     int m_conv_split_order = std::getenv("SANM_CONV_SPLIT_ORDER") ? std::atoi(std::getenv("SANM_CONV_SPLIT_ORDER")) : 4;
@@ -1674,6 +1677,11 @@ public:
                                    MF_FACTOR_ARGS(mf, L.front_begin));
                 SANM_LAUNCH(gemm2_kernel, dim3(tmax, tmax, 3 * nfr), dim3(256), 0, m_stream,
                                    MF_FACTOR_ARGS(mf, L.front_begin));
+#ifndef SANM_MF_OLD_STAGING
+                if (L.max_k >= mfk::kTallMinK && L.max_b >= mfk::kTallMinB)  // big fronts: interior of the Schur complement
+                    SANM_LAUNCH(gemm2_tall_kernel, dim3(tmax, (tmax + 1) / 2, nfr), dim3(256), 0, m_stream,
+                                MF_FACTOR_ARGS(mf, L.front_begin));
+#endif
             }
         }
         if (sch.top.enabled) {  // the top of the tree as one dense operator (mf_kernels.h)

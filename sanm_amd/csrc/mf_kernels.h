@@ -505,17 +505,95 @@ __device__ __forceinline__ void gemm_stage_store(const GemmStage& st, double (*A
     }
 }
 
+// Fast path for interior tiles (round 3).  The guarded loads above put exec-mask branches into the K loop, and with
+// them the compiler kept the accumulators in VGPRs and copied all 32 of them to the matrix cores' registers and
+// back at EVERY K step (64 v_accvgpr moves and an s_nop 15 that drains the MFMA pipeline: the ISA of round 2's
+// gemm2).  A tile that lies inside both operands needs no guard at all for its full K steps: plain 16-byte loads,
+// no selects, nothing the compiler could turn into a branch (a first version with clamped addresses and selects
+// WAS turned into guarded loads with a wait after each one -- 34 % slower in place although faster in the
+// micro-benchmark); edge tiles and the last partial K step take the guarded loop.  With -amdgpu-mfma-vgpr-form
+// (build.py) the fast K loop is loads, LDS traffic and MFMAs.  scripts/micro/gemm_bench.hip, 8192^2, K = 128 / 256 /
+// 4096: 35.9 / 43.4 / 58.0 TFLOP/s before, 39.0 / 49.1 / 60.5 with this staging, 37.6 / 51.4 / 64.7 with the
+// 128 x 64 tile below; every variant gives the same bits (same summation order per element).
+typedef double2 __attribute__((aligned(8))) double2_u;  // a pair of doubles at any 8-byte address
+template <int TM>
+struct GemmStage2 {
+    double2 a[TM / 32], b[2];  // A tile TM x 16 and B tile 16 x 64 over 256 threads, two doubles at a time
+};
+template <int TM>
+__device__ __forceinline__ void gemm_stage2_load(GemmStage2<TM>& st, const MatView& A, const MatView& B, int ti, int tj,
+                                                 int kk) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int s = 0; s < TM / 32; ++s) {
+        const int idx = tid + 256 * s;
+        const int ar = idx >> 3, ae = (idx & 7) * 2;  // 8 pairs per row of the A tile
+        st.a[s] = *reinterpret_cast<const double2_u*>(A.p + (int64_t)(ti * TM + ar) * A.ld + kk + ae);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int idx = tid + 256 * s;
+        const int be = idx >> 5, bc = (idx & 31) * 2;  // 32 pairs per row of the B tile
+        st.b[s] = *reinterpret_cast<const double2_u*>(B.p + (int64_t)(kk + be) * B.ld + tj * GT + bc);
+    }
+}
+template <int TM>
+__device__ __forceinline__ void gemm_stage2_store(const GemmStage2<TM>& st, double (*As)[TM + 1], double (*Bs)[GT + 4]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int s = 0; s < TM / 32; ++s) {
+        const int idx = tid + 256 * s;
+        const int ar = idx >> 3, ae = (idx & 7) * 2;
+        As[ae][ar] = st.a[s].x;  // transposed: As[e][row]
+        As[ae + 1][ar] = st.a[s].y;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int idx = tid + 256 * s;
+        *reinterpret_cast<double2*>(&Bs[idx >> 5][(idx & 31) * 2]) = st.b[s];
+    }
+}
+
 // acc[mi][ni]: the 16x16 tile at rows 32*(wave>>1) + 16*mi, columns 32*(wave&1) + 16*ni of the 64x64 tile
 template <bool IDX = false>
 __device__ __forceinline__ void gemm_tile(const MatView& A, const MatView& B, int ti, int tj, int k0,
                                           int k1, double (*As)[GT + 1], double (*Bs)[GT + 4],
-                                          mfma_f64x4 acc[2][2]) {
+                                          mfma_f64x4 acc[2][2], bool zero = true) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r0 = 32 * (wv >> 1) + (lane & 15), c0 = 32 * (wv & 1) + (lane & 15), kq = lane >> 4;
+    if (zero) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_f64x4{0, 0, 0, 0};
+            for (int j = 0; j < 2; ++j) acc[i][j] = mfma_f64x4{0, 0, 0, 0};
+    }
+#ifndef SANM_MF_OLD_STAGING  // (A/B switch: round 2's guarded element loads everywhere)
+    if (!IDX) {
+        // interior tile (workgroup-uniform): its full K steps without a single guard
+        const int kin = min(k1, min(A.cols, B.rows));
+        const int kfull = k0 + (max(kin - k0, 0) / GK) * GK;
+        if (ti * GT + GT <= A.rows && tj * GT + GT <= B.cols && kfull > k0) {
+            GemmStage2<GT> st;
+            gemm_stage2_load<GT>(st, A, B, ti, tj, k0);
+            for (int kk = k0; kk < kfull; kk += GK) {
+                __syncthreads();  // the previous step's fragments have been read
+                gemm_stage2_store<GT>(st, As, Bs);
+                __syncthreads();
+                if (kk + GK < kfull) gemm_stage2_load<GT>(st, A, B, ti, tj, kk + GK);
+#pragma unroll
+                for (int e = 0; e < GK; e += 4) {
+                    const double a0 = As[e + kq][r0], a1 = As[e + kq][r0 + 16];
+                    const double b0 = Bs[e + kq][c0], b1 = Bs[e + kq][c0 + 16];
+                    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+                }
+            }
+            k0 = kfull;  // what is left (a partial last step) takes the guarded loop
+        }
+    }
+#endif
     GemmStage st;
     if (k0 < k1) gemm_stage_load<IDX>(st, A, B, ti, tj, k0, k1);
     for (int kk = k0; kk < k1; kk += GK) {
@@ -532,6 +610,66 @@ __device__ __forceinline__ void gemm_tile(const MatView& A, const MatView& B, in
             acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
         }
+    }
+}
+
+// The full K steps of an INTERIOR 128 x 64 tile (rows [128 ti, 128 ti + 128), columns [64 tj, 64 tj + 64) inside both
+// operands; K range inside them too): each wavefront a 64 x 32 block = 4 x 2 MFMA tiles, 6 LDS reads per 8 MFMAs instead of 4 per 4 and half
+// the B traffic per flop.  For the Schur complements of big fronts (long K).  acc[mi][ni]: rows 64*(wave>>1) +
+// 16*mi, columns 32*(wave&1) + 16*ni.  K range [k0, k1).
+constexpr int GT2 = 128;
+constexpr int kTallMinK = 512, kTallMinB = 1024;  // fronts from this size on take the tall tile for F[B,B] -= L U
+__device__ __forceinline__ void gemm_tile_tall(const MatView& A, const MatView& B, int ti, int tj, int k0, int k1,
+                                               double (*As)[GT2 + 1], double (*Bs)[GT + 4], mfma_f64x4 acc[4][2]) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r0 = 64 * (wv >> 1) + (lane & 15), c0 = 32 * (wv & 1) + (lane & 15), kq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_f64x4{0, 0, 0, 0};
+    const int kfull = k0 + ((k1 - k0) / GK) * GK;
+    auto mfma_step = [&]() {
+#pragma unroll
+        for (int e = 0; e < GK; e += 4) {
+            double a[4], b[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[e + kq][r0 + 16 * i];
+            b[0] = Bs[e + kq][c0];
+            b[1] = Bs[e + kq][c0 + 16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    if (kfull > k0) {
+        GemmStage2<GT2> st;
+        gemm_stage2_load<GT2>(st, A, B, ti, tj, k0);
+        for (int kk = k0; kk < kfull; kk += GK) {
+            __syncthreads();
+            gemm_stage2_store<GT2>(st, As, Bs);
+            __syncthreads();
+            if (kk + GK < kfull) gemm_stage2_load<GT2>(st, A, B, ti, tj, kk + GK);
+            mfma_step();
+        }
+    }
+    if (kfull < k1) {  // the last, partial K step: element loads with the K bound (same accumulation chain)
+        __syncthreads();
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {  // A tile 128 x 16
+            const int idx = tid + 256 * s, ar = idx / GK, ae = idx % GK;
+            const int gc = kfull + ae;
+            As[ae][ar] = gc < k1 ? A.p[(int64_t)(ti * GT2 + ar) * A.ld + gc] : 0.0;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {  // B tile 16 x 64
+            const int idx = tid + 256 * s, be = idx / GT, bc = idx % GT;
+            const int gr = kfull + be;
+            Bs[be][bc] = gr < k1 ? B.p[(int64_t)gr * B.ld + tj * GT + bc] : 0.0;
+        }
+        __syncthreads();
+        mfma_step();
     }
 }
 
@@ -583,6 +721,39 @@ __global__ void __launch_bounds__(256) gemm1_kernel(MF_FACTOR_PARAMS) {
     });
 }
 
+// F[B,B] -= tmpL tmpU of a big front: its interior 128 x 64 tiles go to gemm2_tall_kernel (a kernel of its own: the
+// eight accumulator tiles per wavefront cost 136 VGPRs, which would take a wavefront per SIMD from every other
+// product of gemm2_kernel), the tile rows at the lower edge and everything on smaller fronts stay here
+__device__ __forceinline__ bool gemm2_is_tall(int k, int b, int rows, int cols, int ti, int tj) {
+    return k >= kTallMinK && b >= kTallMinB && ((ti & ~1) + 2) * GT <= rows && (tj + 1) * GT <= cols;
+}
+__global__ void __launch_bounds__(256) gemm2_tall_kernel(MF_FACTOR_PARAMS) {
+    MF_FACTOR_INIT
+    const MfFrontDev f = mf.lfronts[level_begin + blockIdx.z];
+    const int k = f.k, b = f.m - f.k, ld = f.ld;
+    const int ti = 2 * blockIdx.y, tj = blockIdx.x;
+    if (!gemm2_is_tall(k, b, b, b, ti, tj)) return;
+    __shared__ double As[GK][GT2 + 1], Bs[GK][GT + 4];
+    double* F = mf.front_store + f.off;
+    const double* tmpU = mf.tmp_store + f.tmp_off;
+    const double* tmpL = tmpU + (int64_t)k * b;
+    const MatView A{tmpL, k, b, k}, B{tmpU, b, k, b};
+    double* C = F + (int64_t)2 * k * ld + 2 * k;
+    mfma_f64x4 acc4[4][2];
+    gemm_tile_tall(A, B, ti >> 1, tj, 0, k, As, Bs, acc4);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = (ti >> 1) * GT2 + 64 * (wv >> 1) + 16 * mi + (lane >> 4) + 4 * g;
+                const int c = tj * GT + 32 * (wv & 1) + 16 * ni + (lane & 15);
+                C[(int64_t)r * ld + c] -= acc4[mi][ni][g];
+            }
+}
+
 // step 3:  which = 0: F[B,B] -= tmpL tmpU                        (b x b, K = k)
 //          which = 1: F[B,A]  = -tmpL L11^-1   (b x k; L11^-1 lower: K tiles tj..)
 //          which = 2: F[A,B]  = -U11^-1 tmpU   (k x b; U11^-1 upper: K tiles ti..)
@@ -605,6 +776,10 @@ __global__ void __launch_bounds__(256) gemm2_kernel(MF_FACTOR_PARAMS) {
         A = {tmpL, k, b, k};
         B = {tmpU, b, k, b};
         C = F + (int64_t)2 * k * ld + 2 * k;
+#ifndef SANM_MF_OLD_STAGING
+        // (the interior of the Schur complement of a big front belongs to gemm2_tall_kernel)
+        if (gemm2_is_tall(k, b, rows, cols, ti, tj)) return;
+#endif
     } else if (which == 1) {
         A = {tmpL, k, b, k};
         B = {F + k, ld, k, k};  // L11^-1 (lower): rows >= column
