@@ -1617,7 +1617,7 @@ public:
                 int cnt = L.ea_rounds[r].second - L.ea_rounds[r].first;
                 int64_t mb = L.ea_max_b[r];
                 if (cnt == 0 || mb == 0) continue;
-                SANM_LAUNCH(extend_add_kernel, dim3(nblk(mb * mb, 256), cnt), dim3(256), 0,
+                SANM_LAUNCH(extend_add_kernel, dim3((unsigned)((mb + EA_ROWS - 1) / EA_ROWS), cnt), dim3(256), 0,
                                    m_stream, mf.fronts, mf.front_store, mf.rel,
                                    sch.ea_children + L.ea_rounds[r].first);
             }

@@ -62,24 +62,38 @@ __global__ void aug_identity_kernel(MfDev mf) {
     F[(int64_t)(f.k + r) * f.ld + r] = 1.0;
 }
 
-// parent[rel[i], rel[j]] += child_schur[i, j]; one child per blockIdx.y
+// parent[rel[i], rel[j]] += child_schur[i, j]; one child per blockIdx.y, EA_ROWS rows of its Schur complement per
+// workgroup, the threads along the columns.  (Round 2 gave every element a thread of its own: a 64-bit division per
+// element, one load in flight per lane and a grid sized for the largest child of the round -- 225 GB/s on the
+// 0.5 M-tet block, 16 of the 255 ms of a step.  Here a thread keeps EA_ROWS independent read-modify-writes per
+// column in flight and rel[j] is read once per column for all of them.)
+constexpr int EA_ROWS = 4;
 __global__ void __launch_bounds__(256) extend_add_kernel(const MfFrontDev* __restrict__ fronts_, double* front_store_,
                                                          const int32_t* __restrict__ rel_,
                                                          const int32_t* __restrict__ children) {
-    const struct {
-        const MfFrontDev* fronts;
-        double* front_store;
-        const int32_t* rel;
-    } mf{fronts_, front_store_, rel_};
-    const MfFrontDev c = mf.fronts[children[blockIdx.y]];
+    const MfFrontDev c = fronts_[children[blockIdx.y]];
     const int nb = c.m - c.k;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)nb * nb) return;
-    const int i = idx / nb, j = idx % nb;
-    const MfFrontDev p = mf.fronts[c.parent];
-    const int32_t* rel = mf.rel + c.rel_off;
-    double v = mf.front_store[c.off + (int64_t)(2 * c.k + i) * c.ld + 2 * c.k + j];
-    mf.front_store[p.off + (int64_t)rel[i] * p.ld + rel[j]] += v;
+    const int i0 = blockIdx.x * EA_ROWS;
+    if (i0 >= nb) return;
+    const MfFrontDev p = fronts_[c.parent];
+    const int32_t* __restrict__ rel = rel_ + c.rel_off;
+    const double* src = front_store_ + c.off + (int64_t)(2 * c.k) * c.ld + 2 * c.k;
+    double* dst = front_store_ + p.off;
+    int64_t drow[EA_ROWS];
+#pragma unroll
+    for (int q = 0; q < EA_ROWS; ++q) drow[q] = (int64_t)rel[min(i0 + q, nb - 1)] * p.ld;
+    for (int j = threadIdx.x; j < nb; j += 256) {
+        const int rj = rel[j];
+        double v[EA_ROWS], d[EA_ROWS];
+#pragma unroll
+        for (int q = 0; q < EA_ROWS; ++q) {
+            v[q] = src[(int64_t)min(i0 + q, nb - 1) * c.ld + j];
+            d[q] = dst[drow[q] + rj];
+        }
+#pragma unroll
+        for (int q = 0; q < EA_ROWS; ++q)
+            if (i0 + q < nb) dst[drow[q] + rj] = d[q] + v[q];
+    }
 }
 
 // LU of a diagonal tile (kb pivots, no pivoting) by ONE wavefront, in registers: lane r < 32 holds row r, the
