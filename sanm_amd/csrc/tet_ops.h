@@ -143,30 +143,36 @@ SANM_HD void mm3(double* c, const double* a, const double* b) {
     for (int i = 0; i < 9; ++i) c[i] = r[i];
 }
 
+// a*b - c*d with one rounding less (what the compiler's contraction made of it before -ffp-contract=off)
+SANM_HD double dif2(double a, double b, double c, double d) { return __builtin_fma(a, b, -(c * d)); }
+SANM_HD double dot3v(const double* a, const double* b) {
+    return __builtin_fma(a[2], b[2], __builtin_fma(a[1], b[1], a[0] * b[0]));
+}
+
 SANM_HD double det3(const double* a) {  // tensor_linalg.cpp:319-353
-    return a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) +
-           a[2] * (a[3] * a[7] - a[4] * a[6]);
+    const double m0 = dif2(a[4], a[8], a[5], a[7]), m1 = dif2(a[3], a[8], a[5], a[6]), m2 = dif2(a[3], a[7], a[4], a[6]);
+    return __builtin_fma(a[2], m2, __builtin_fma(-a[1], m1, a[0] * m0));
 }
 
 // cofactor matrix by minors.  The reference goes through an SVD with a rank
 // test (tensor_linalg.cpp:18-59); for 3x3 the minors are the same matrix up
 // to round-off, including rank 2, and are exactly what rank <= 1 collapses to.
 SANM_HD void cof3(const double* a, double* c) {
-    c[0] = a[4] * a[8] - a[5] * a[7];
-    c[1] = a[5] * a[6] - a[3] * a[8];
-    c[2] = a[3] * a[7] - a[4] * a[6];
-    c[3] = a[2] * a[7] - a[1] * a[8];
-    c[4] = a[0] * a[8] - a[2] * a[6];
-    c[5] = a[1] * a[6] - a[0] * a[7];
-    c[6] = a[1] * a[5] - a[2] * a[4];
-    c[7] = a[2] * a[3] - a[0] * a[5];
-    c[8] = a[0] * a[4] - a[1] * a[3];
+    c[0] = dif2(a[4], a[8], a[5], a[7]);
+    c[1] = dif2(a[5], a[6], a[3], a[8]);
+    c[2] = dif2(a[3], a[7], a[4], a[6]);
+    c[3] = dif2(a[2], a[7], a[1], a[8]);
+    c[4] = dif2(a[0], a[8], a[2], a[6]);
+    c[5] = dif2(a[1], a[6], a[0], a[7]);
+    c[6] = dif2(a[1], a[5], a[2], a[4]);
+    c[7] = dif2(a[2], a[3], a[0], a[5]);
+    c[8] = dif2(a[0], a[4], a[1], a[3]);
 }
 
 SANM_HD void inv3(const double* a, double* r) {  // tensor_linalg.cpp:285-317
     double c[9];
     cof3(a, c);
-    double d = a[0] * c[0] + a[1] * c[1] + a[2] * c[2];
+    double d = dot3v(a, c);
     double id = 1.0 / d;
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) r[i * 3 + j] = c[j * 3 + i] * id;
@@ -402,6 +408,10 @@ SANM_HD void st_cur(const TetCtx& c, int v, int n, const double* m, bool in_coef
 SANM_HD void jadd(const TetCtx& c, int v, int, int ci, double val) {
     c.cur[(int64_t)(c.vars[v].cur + ci) * c.cur_stride] += val;
 }
+SANM_HD void jfma(const TetCtx& c, int v, int, int ci, double a, double b) {  // += a * b, fused
+    double& d = c.cur[(int64_t)(c.vars[v].cur + ci) * c.cur_stride];
+    d = __builtin_fma(a, b, d);
+}
 SANM_HD double jget(const TetCtx& c, int v, int, int ci) {
     return c.cur[(int64_t)(c.vars[v].cur + ci) * c.cur_stride];
 }
@@ -422,11 +432,11 @@ SANM_HD void op_lincomb_t(const TetCtx& c, const OpDesc& o, int mode) {
             double ck = o.p[k];
             for (int r = c.grow; r <= c.grow; ++r) {
                 if (isz == osz) {
-                    for (int e = 0; e < osz; ++e) jadd(c, iv, r, e, ck * jget(c, ov, r, e));
+                    for (int e = 0; e < osz; ++e) jfma(c, iv, r, e, ck, jget(c, ov, r, e));
                 } else {
                     double sum = 0;
                     for (int e = 0; e < osz; ++e) sum += jget(c, ov, r, e);
-                    jadd(c, iv, r, 0, ck * sum);
+                    jfma(c, iv, r, 0, ck, sum);
                 }
             }
         }
@@ -480,7 +490,7 @@ SANM_HD void op_multiply_t(const TetCtx& c, const OpDesc& o, int mode) {
             for (int r = c.grow; r <= c.grow; ++r) {
                 if (isz == osz) {
                     for (int e = 0; e < osz; ++e)
-                        jadd(c, iv, r, e, jget(c, ov, r, e) * bval(po, s, otsz, e));
+                        jfma(c, iv, r, e, jget(c, ov, r, e), bval(po, s, otsz, e));
                 } else {
                     double sum = 0;
                     for (int e = 0; e < osz; ++e) sum = __builtin_fma(jget(c, ov, r, e), bval(po, s, otsz, e), sum);
@@ -606,7 +616,7 @@ SANM_HD void op_unary_t(const TetCtx& c, const OpDesc& o, int mode) {
     if (mode == PASS_GRAD) {
         if (c.vars[x].is_const) return;
         for (int r = c.grow; r <= c.grow; ++r)
-            for (int e = 0; e < sz; ++e) jadd(c, x, r, e, jget(c, ov, r, e) * pk[e * s]);
+            for (int e = 0; e < sz; ++e) jfma(c, x, r, e, jget(c, ov, r, e), pk[e * s]);
         return;
     }
     const bool in_coeff = mode == PASS_COEFF;
@@ -626,8 +636,12 @@ SANM_HD void op_unary_t(const TetCtx& c, const OpDesc& o, int mode) {
                     const double* p1 = int2 ? p_coef(c, x, i) : (is_log ? p_coef(c, x, k - i) : p_coef(c, ov, k - i));
                     const double* p2 = int2 ? p_coef(c, x, k - i) : (is_log ? p_coef(c, ov, i) : p_coef(c, x, i));
                     double w = int2 ? 1.0 : (is_log ? -(double)i / (double)k
-                                                    : (double)i / (double)k * (pw + 1.0) - 1.0);
-                    for (int e = 0; e < sz; ++e) sb[e] = __builtin_fma(p1[e * s] * p2[e * s], w, sb[e]);
+                                                    : __builtin_fma((double)i / (double)k, pw + 1.0, -1.0));
+                    if (int2) {
+                        for (int e = 0; e < sz; ++e) sb[e] = __builtin_fma(p1[e * s], p2[e * s], sb[e]);
+                    } else {
+                        for (int e = 0; e < sz; ++e) sb[e] = __builtin_fma(p1[e * s] * p2[e * s], w, sb[e]);
+                    }
                 }
                 conv_reduce(c, sb, sz);
             }
@@ -884,9 +898,9 @@ SANM_HD void op_matinvmul(const TetCtx& c, const OpDesc& o, int mode) {
 // which is the Leibniz expansion of the reference regrouped so that each
 // order costs O(k) instead of O(k^2).
 SANM_HD void cross3(const double* a, const double* b, double* r) {
-    r[0] = a[1] * b[2] - a[2] * b[1];
-    r[1] = a[2] * b[0] - a[0] * b[2];
-    r[2] = a[0] * b[1] - a[1] * b[0];
+    r[0] = dif2(a[1], b[2], a[2], b[1]);
+    r[1] = dif2(a[2], b[0], a[0], b[2]);
+    r[2] = dif2(a[0], b[1], a[1], b[0]);
 }
 SANM_HD void op_det(const TetCtx& c, const OpDesc& o, int mode) {
     const int64_t s = c.Tpad;
@@ -900,7 +914,7 @@ SANM_HD void op_det(const TetCtx& c, const OpDesc& o, int mode) {
         ld9(p_coef(c, x, 0), s, X);
         cof3(X, C);
         st9(pcof, s, C);
-        *p_coef(c, ov, 0) = X[0] * C[0] + X[1] * C[1] + X[2] * C[2];
+        *p_coef(c, ov, 0) = dot3v(X, C);
         st(pcs, s, 3, C);  // c_0 = r1_0 x r2_0 = first cofactor row
         return;
     }
@@ -909,7 +923,7 @@ SANM_HD void op_det(const TetCtx& c, const OpDesc& o, int mode) {
         ld9(pcof, s, C);
         for (int r = c.grow; r <= c.grow; ++r) {
             double g = jget(c, ov, r, 0);
-            for (int e = 0; e < 9; ++e) jadd(c, x, r, e, g * C[e]);
+            for (int e = 0; e < 9; ++e) jfma(c, x, r, e, g, C[e]);
         }
         return;
     }
@@ -944,7 +958,7 @@ SANM_HD void op_det(const TetCtx& c, const OpDesc& o, int mode) {
         if (!c.has_conv) conv_reduce(c, ck, 4);
         if (c.part) return;
         st(pck, s, 3, ck);
-        sb = x0[0] * ck[0] + x0[1] * ck[1] + x0[2] * ck[2] + ck[3];
+        sb = __builtin_fma(x0[2], ck[2], __builtin_fma(x0[1], ck[1], x0[0] * ck[0])) + ck[3];
         *psb = sb;
     }
     ld9(pcof, s, C);  // one batch of loads
@@ -1272,7 +1286,11 @@ SANM_HD void conv_term_unary(const TetCtx& c, const OpDesc& o, int i, int j, dou
     } else {  // f_j x_i ((i/k)(p+1) - 1)
         ldh<SZ>(c, ov, j, P1);
         ldh<SZ>(c, x, i, P2);
-        w = (double)i / k * (pw + 1.0) - 1.0;
+        w = __builtin_fma((double)i / k, pw + 1.0, -1.0);
+    }
+    if (o.type != OP_LOG && pw == 2.0) {  // x_i x_j: one fused multiply-add per element
+        for (int e = 0; e < SZ; ++e) acc[e] = __builtin_fma(P1[e], P2[e], acc[e]);
+        return;
     }
     for (int e = 0; e < SZ; ++e) acc[e] = __builtin_fma(P1[e] * P2[e], w, acc[e]);
 }
