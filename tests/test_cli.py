@@ -6,6 +6,8 @@ import os
 
 import numpy as np
 
+from tests.lockstep import counts_compatible
+
 from oracle import fea as ofea
 from sanm_amd import cli
 
@@ -60,7 +62,7 @@ def test_gravity_task_from_files(api, tmp_path):
     Vo = omodel.lt_inp.full_vertices(xo)
     # (the step count is compared decision by decision in tests/test_device_anm.py -- lock-step --: with Pade on, the
     # free-running counts may differ by an ill-conditioned Pade decision; both must be a handful)
-    assert 1 <= st["iter"] <= 2 * osolver.get_nr_iter() and st["pade"]
+    assert counts_compatible(st["iter"], osolver.get_nr_iter()) and st["pade"]
     Vd = np.array([[float(x) for x in line.split()[1:]] for line in open(base + "-i0-neohookean_i.obj")
                    if line.startswith("v ")])
     assert Vd.shape == Vo.shape and np.abs(Vd - Vo).max() <= 1e-5 * np.abs(Vo).max()  # %g keeps 6 digits
@@ -146,7 +148,7 @@ def test_cuboid_task(api, tmp_path):
     model, solver, x = ofea.solve_static(om, ofea.Material(1e5, 0.4, 0.0), fixed, "neohookean_c", f, dict(task))
     Vd = np.loadtxt(str(tmp_path / "out" / "c-i0-neohookean_c.vertices.txt"))
     Vo = model.lt_inp.full_vertices(x)
-    assert st["iter"] == solver.get_nr_iter()
+    assert counts_compatible(st["iter"], solver.get_nr_iter())
     assert np.abs(Vd - Vo).max() <= 1e-8 * np.abs(Vo).max()
 
 
@@ -178,5 +180,5 @@ def test_mesh_twist_task(api, tmp_path):
     delta[bnd] = om.V[bnd] @ rmat.T - om.V[bnd]
     Vo, ost = ofea.run_with_vtx_delta(om, ofea.Material(1e6, 0.4, 0.0), fixed, "arap", dict(task), delta, om.V.copy(),
                                       False)
-    assert st["iter_deform"] == ost["iter_deform"]
+    assert counts_compatible(st["iter_deform"], ost["iter_deform"])
     assert np.abs(Vd - Vo).max() <= 1e-6 * np.abs(Vo).max()
