@@ -510,44 +510,79 @@ bool PadeApproximation::estimate_valid_range(double start, double eps, double li
     auto note = [&](double a, int slot, bool ok) { m_diag.probes.push_back({a, m_probe_margin[slot], ok ? 1 : 0}); };
     double left = start * 1.001, right = start + (pole - start) * 0.99;
     if (limit && right > limit) right = limit;
+    // The probes of pade.cpp:143-165 in TWO batches (two host round trips instead of up to ten): every probe point
+    // of the bisection is a function of the interval it starts from, so the midpoints the next `depth` decisions can
+    // ask for form a binary tree that is probed as a whole (heap order: node v, children 2v = "failed: right = mid"
+    // and 2v + 1 = "passed: left = mid") and the decisions then walk down it.  Batch A = the two opening probes and
+    // three levels of the bisection for BOTH outcomes of the doubling probe (16 points), batch B = the remaining
+    // five levels (31 points).  Which probes count, and in which order, is decided by the reference's control
+    // flow below; the unused ones are discarded.
+    auto build_tree = [](double lo0, double hi0, int depth, std::vector<double>& mid) {
+        const int nn = (1 << depth) - 1;
+        std::vector<double> lo(nn + 1), hi(nn + 1);
+        mid.assign(nn + 1, 0.0);
+        lo[1] = lo0;
+        hi[1] = hi0;
+        for (int v = 1; v <= nn; ++v) {
+            mid[v] = (lo[v] + hi[v]) / 2;
+            if (2 * v + 1 <= nn) {
+                lo[2 * v] = lo[v];
+                hi[2 * v] = mid[v];
+                lo[2 * v + 1] = mid[v];
+                hi[2 * v + 1] = hi[v];
+            }
+        }
+    };
+    int iter = 0;
+    // walks a probed tree from its root; ok[] / margins are indexed like `as` of the batch, base = index of node 1 - 1
+    auto walk = [&](const std::vector<double>& mid, int depth, const std::vector<char>& ok, int base) {
+        const int nn = (1 << depth) - 1;
+        for (int v = 1; v <= nn && iter < 8 && right - left > 1e-3; ++iter) {
+            const bool pass = ok[base + v];
+            note(mid[v], base + v, pass);
+            if (pass) left = mid[v];
+            else right = mid[v];
+            v = 2 * v + (pass ? 1 : 0);
+        }
+    };
     {
-        // the two opening probes (pade.cpp:143-156) do not depend on each other
-        std::vector<double> as{left};
         const bool dbl = right > start * 2;
+        std::vector<double> as{left};
         if (dbl) as.push_back(start * 2);
+        const int first_tree = (int)as.size();
+        std::vector<double> midA, midB;
+        constexpr int kDepthA = 3;
+        if (dbl) {
+            build_tree(start * 2, right, kDepthA, midA);  // the doubling probe passed: left = 2 start
+            build_tree(left, start * 2, kDepthA, midB);   // it failed: right = 2 start
+            as.insert(as.end(), midA.begin() + 1, midA.end());
+            as.insert(as.end(), midB.begin() + 1, midB.end());
+        } else {
+            build_tree(left, right, kDepthA, midA);
+            as.insert(as.end(), midA.begin() + 1, midA.end());
+        }
         const std::vector<char> ok = check_many(as);
         note(left, 0, ok[0]);
         if (!ok[0]) return false;
         if (dbl) {
             note(start * 2, 1, ok[1]);
-            if (ok[1]) left = start * 2;
-            else right = start * 2;
+            if (ok[1]) {
+                left = start * 2;
+                walk(midA, kDepthA, ok, first_tree - 1);
+            } else {
+                right = start * 2;
+                walk(midB, kDepthA, ok, first_tree - 1 + (int)midA.size() - 1);
+            }
+        } else {
+            walk(midA, kDepthA, ok, first_tree - 1);
         }
     }
-    // bisection (pade.cpp:157-165), three levels per pass: the 7 midpoints the next three decisions can
-    // ask for are probed together and the decisions then walk down that tree
-    int iter = 0;
-    while (iter < 8 && right - left > 1e-3) {
-        const int depth = std::min(3, 8 - iter), nn = (1 << depth) - 1;
-        std::vector<double> lo(nn + 1), hi(nn + 1), mid(nn + 1);
-        lo[1] = left;
-        hi[1] = right;
-        for (int v = 1; v <= nn; ++v) {
-            mid[v] = (lo[v] + hi[v]) / 2;
-            if (2 * v + 1 <= nn) {
-                lo[2 * v] = lo[v];  // probe failed: right = mid
-                hi[2 * v] = mid[v];
-                lo[2 * v + 1] = mid[v];  // probe passed: left = mid
-                hi[2 * v + 1] = hi[v];
-            }
-        }
+    if (iter < 8 && right - left > 1e-3) {
+        const int depth = 8 - iter;
+        std::vector<double> mid;
+        build_tree(left, right, depth, mid);
         const std::vector<char> ok = check_many(std::vector<double>(mid.begin() + 1, mid.end()));
-        for (int v = 1; v <= nn && iter < 8 && right - left > 1e-3; ++iter) {
-            note(mid[v], v - 1, ok[v - 1]);
-            if (ok[v - 1]) left = mid[v];
-            else right = mid[v];
-            v = 2 * v + (ok[v - 1] ? 1 : 0);
-        }
+        walk(mid, depth, ok, -1);
     }
     m_t_max_a = left;
     m_t_max = eval_t(left);
@@ -963,7 +998,9 @@ void AnmDriver::solve_expansion_coeffs() {
             // x_1 = -t1*xgt - xbi ; t_1 appended  (anm.cpp:261-264)
             be->axpby_tail(n, -ti, m_xgt.p(), -1.0, xbi, xi, ti);
             m_host_scalars[3 * i] = ti;
-            xgt_dot_x1 = be->dot(n, xi, m_xgt.p());
+            // xgt . x_1 with x_1 = -t_1 xgt - 0 (the order-1 bias is exactly zero, anm.cpp:235): -t_1 |xgt|^2, the
+            // reduction already on the host, instead of another launch and host round trip
+            xgt_dot_x1 = -ti * xgt2;
         } else {
             // t_i = (xb_i . x_1) / (t1 - xgt . x_1);  x_i = -t_i*xgt - xb_i  (anm.cpp:246-264)
             if (pade_riders) m_pade_ws.phase(m_xt_coeffs, i - 1, 2, anm_cond, true);

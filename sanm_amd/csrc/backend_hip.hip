@@ -495,6 +495,60 @@ __global__ void __launch_bounds__(256) lincomb2_diff_norms_multi_kernel(size_t n
     grid_commit<2 * PROBE_MAX>(r, 2 * a.ncand, 0u, g);
 }
 
+// The same for up to PROBE_GROUPS * PROBE_MAX coefficient sets in ONE launch: blockIdx.y takes a group of PROBE_MAX
+// sets whose coefficients sit in pinned host memory (a launch's argument block holds one group; 2.7 KB per group are
+// read over the host link once per workgroup, from its scalar loads' cache afterwards), every group reduces into
+// partials / ticket / result slots of its own.  With it the range estimate of a step needs two host round trips
+// (opening probes + three bisection levels on both branches, then the remaining five levels: 16 and 31 probes)
+// instead of four.  Each set's arithmetic is the single probe's.
+constexpr int PROBE_GROUPS = 8;
+struct ProbeGroup {
+    double c1[PROBE_MAX][MAX_VEC], c2[PROBE_MAX][MAX_VEC];
+    double scale[PROBE_MAX];
+    int ncand, pad;
+};
+struct ProbePtrs {
+    const double* p[MAX_VEC];
+    int nvec;
+};
+__global__ void __launch_bounds__(256) lincomb2_diff_norms_grouped_kernel(size_t n, ProbePtrs a,
+                                                                          const ProbeGroup* __restrict__ groups,
+                                                                          double* partials, unsigned* tickets,
+                                                                          double* results) {
+    // the group's coefficients: one coalesced read over the host link per workgroup, broadcast reads from LDS after it
+    __shared__ ProbeGroup G;
+    {
+        const double* src = reinterpret_cast<const double*>(groups + blockIdx.y);
+        double* dst = reinterpret_cast<double*>(&G);
+        for (unsigned i = threadIdx.x; i < sizeof(ProbeGroup) / sizeof(double); i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    double r[2 * PROBE_MAX];
+    for (int c = 0; c < 2 * PROBE_MAX; ++c) r[c] = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        double u[PROBE_MAX], w[PROBE_MAX];
+#pragma unroll
+        for (int c = 0; c < PROBE_MAX; ++c) u[c] = w[c] = 0;
+        for (int j = 0; j < a.nvec; ++j) {
+            const double x = a.p[j][i];
+#pragma unroll
+            for (int c = 0; c < PROBE_MAX; ++c) {
+                u[c] += G.c1[c][j] * x;
+                w[c] += G.c2[c][j] * x;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < PROBE_MAX; ++c) {
+            const double d = G.scale[c] * w[c] - u[c];
+            r[2 * c] += d * d;
+            r[2 * c + 1] += u[c] * u[c];
+        }
+    }
+    const GridRed g{partials + (size_t)blockIdx.y * 2 * PROBE_MAX * RED_MAX_GRID, tickets + blockIdx.y,
+                    results + (size_t)blockIdx.y * 2 * PROBE_MAX};
+    grid_commit_at<2 * PROBE_MAX>(r, 2 * G.ncand, 0u, g, blockIdx.x, gridDim.x);
+}
+
 // out[j] = x . ys[j]; x is read once per element.  The newest vector ys[v.n-1] may still await the second
 // normalisation of an underflowed Gram-Schmidt direction (last_norm2 != null and sqrt(*last_norm2) < eps):
 // every element is read here anyway, so it is rescaled in place on the way.
@@ -967,6 +1021,10 @@ class HipBackend final : public Backend {
     int m_fork_next = 0;
     Rccl::Comm m_comm = nullptr;
     int64_t m_launch_count = 0;
+    ProbeGroup* m_probe_groups = nullptr;   // pinned: coefficient sets of a grouped range probe
+    double* m_probe_results = nullptr;      // pinned
+    double* m_probe_partials = nullptr;
+    unsigned* m_probe_tickets = nullptr;
     // Replayed launch chains (hipGraph): the level sweeps of a solve and the whole numeric factorisation are fixed
     // sequences of kernels with fixed arguments per solver.  scripts/micro/graph_chain.hip: a dependent chain costs
     // 3.1 us per kernel as stream launches and 2.5 (16 kernels) to 2.05 us (340 kernels) replayed as a graph.
@@ -1112,6 +1170,10 @@ public:
     ~HipBackend() override {
         for (auto& kv : m_chains)
             if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (m_probe_groups) (void)hipHostFree(m_probe_groups);
+        if (m_probe_results) (void)hipHostFree(m_probe_results);
+        if (m_probe_partials) (void)hipFree(m_probe_partials);
+        if (m_probe_tickets) (void)hipFree(m_probe_tickets);
         comm_destroy();
         (void)hipFree(m_scalar);
         for (auto& kv : m_pool_free)
@@ -1945,8 +2007,42 @@ public:
     }
     void lincomb2_diff_norms_multi(size_t n, int nvec, const double* const* ptrs, int ncand, const double* c1,
                                    const double* c2, const double* scale, double* out_host) override {
-        if (nvec > MAX_VEC || ncand > PROBE_MAX || ncand < 1)
+        if (nvec > MAX_VEC || ncand > PROBE_GROUPS * PROBE_MAX || ncand < 1)
             sanm_throw(SANM_ERR_ASSERT, "lincomb2_diff_norms_multi: %d vectors, %d candidates", nvec, ncand);
+        if (ncand > PROBE_MAX) {  // several groups in one launch, coefficients in pinned memory
+            if (!m_probe_groups) {
+                HIP_CHECK(hipHostMalloc(&m_probe_groups, PROBE_GROUPS * sizeof(ProbeGroup)));
+                HIP_CHECK(hipHostMalloc(&m_probe_results, PROBE_GROUPS * 2 * PROBE_MAX * sizeof(double)));
+                HIP_CHECK(hipMalloc(&m_probe_partials, (size_t)PROBE_GROUPS * 2 * PROBE_MAX * RED_MAX_GRID * sizeof(double)));
+                HIP_CHECK(hipMalloc(&m_probe_tickets, PROBE_GROUPS * sizeof(unsigned)));
+                HIP_CHECK(hipMemset(m_probe_tickets, 0, PROBE_GROUPS * sizeof(unsigned)));
+            }
+            const int ngroup = (ncand + PROBE_MAX - 1) / PROBE_MAX;
+            for (int gi = 0; gi < ngroup; ++gi) {
+                ProbeGroup& G = m_probe_groups[gi];
+                G.ncand = std::min(PROBE_MAX, ncand - gi * PROBE_MAX);
+                for (int c = 0; c < PROBE_MAX; ++c) {
+                    const int src = std::min(gi * PROBE_MAX + c, ncand - 1);  // (unused slots repeat the last set)
+                    G.scale[c] = scale[src];
+                    for (int j = 0; j < MAX_VEC; ++j) {
+                        G.c1[c][j] = j < nvec ? c1[(size_t)src * nvec + j] : 0.0;
+                        G.c2[c][j] = j < nvec ? c2[(size_t)src * nvec + j] : 0.0;
+                    }
+                }
+            }
+            ProbePtrs a{};
+            a.nvec = nvec;
+            for (int j = 0; j < nvec; ++j) a.p[j] = ptrs[j];
+            SANM_LAUNCH(lincomb2_diff_norms_grouped_kernel, dim3(red_grid(n), ngroup), dim3(256), 0, m_stream, n, a,
+                        m_probe_groups, m_probe_partials, m_probe_tickets, m_probe_results);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipStreamSynchronize(m_stream));
+            for (int c = 0; c < ncand; ++c) {
+                out_host[2 * c] = m_probe_results[(size_t)(c / PROBE_MAX) * 2 * PROBE_MAX + 2 * (c % PROBE_MAX)];
+                out_host[2 * c + 1] = m_probe_results[(size_t)(c / PROBE_MAX) * 2 * PROBE_MAX + 2 * (c % PROBE_MAX) + 1];
+            }
+            return;
+        }
         ProbeArgs a{};
         a.nvec = nvec;
         a.ncand = ncand;
