@@ -2009,6 +2009,13 @@ public:
                                    const double* c2, const double* scale, double* out_host) override {
         if (nvec > MAX_VEC || ncand > PROBE_GROUPS * PROBE_MAX || ncand < 1)
             sanm_throw(SANM_ERR_ASSERT, "lincomb2_diff_norms_multi: %d vectors, %d candidates", nvec, ncand);
+        static const bool split = std::getenv("SANM_PROBE_SPLIT") != nullptr;  // (debug: groups as launches of their own)
+        if (ncand > PROBE_MAX && split) {
+            for (int c0 = 0; c0 < ncand; c0 += PROBE_MAX)
+                lincomb2_diff_norms_multi(n, nvec, ptrs, std::min(PROBE_MAX, ncand - c0), c1 + (size_t)c0 * nvec,
+                                          c2 + (size_t)c0 * nvec, scale + c0, out_host + 2 * c0);
+            return;
+        }
         if (ncand > PROBE_MAX) {  // several groups in one launch, coefficients in pinned memory
             if (!m_probe_groups) {
                 HIP_CHECK(hipHostMalloc(&m_probe_groups, PROBE_GROUPS * sizeof(ProbeGroup)));

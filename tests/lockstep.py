@@ -77,7 +77,7 @@ def certify(osolver, dev_outcome, rel_gaps, rng, trials):
 class LockStep:
     """run: a sanm_amd.fea.GravityRun after construct(); osolver: the oracle's ANMEqnSolver for the same task."""
 
-    def __init__(self, run, osolver, trials=32, seed=0, series_rtol=1e-6, restart_rtol=1e-4):
+    def __init__(self, run, osolver, trials=256, seed=0, series_rtol=1e-6, restart_rtol=1e-4):
         self.run, self.o, self.trials = run, osolver, trials
         self.series_rtol, self.restart_rtol = series_rtol, restart_rtol
         self.rng = np.random.default_rng(seed)
