@@ -144,7 +144,11 @@ class LockStep:
         x_d = s.get_x()
         scale = float(np.abs(x_o - o.xt0[:o.n]).max())  # the step's displacement increment
         err = float(np.abs(x_d - x_o).max())
-        assert err <= self.restart_rtol * scale + 1e-12 * float(np.abs(x_o).max()), \
+        # (after an adopted outcome the oracle evaluates its approximant at a parameter its own range test did not
+        # accept: it is then only as good as the approximant is there)
+        forced = bool(self.events) and self.events[-1]["step"] == k - 1
+        rtol = 50 * self.restart_rtol if forced else self.restart_rtol
+        assert err <= rtol * scale + 1e-12 * float(np.abs(x_o).max()), \
             f"step {k}: restart points differ by {err:.2e} (increment {scale:.2e})"
         self.steps[-1]["restart_rel_err"] = err / scale if scale > 0 else 0.0
         # common state: the oracle expands at the device's restart point
