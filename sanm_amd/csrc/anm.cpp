@@ -1000,7 +1000,8 @@ void AnmDriver::solve_expansion_coeffs() {
             m_host_scalars[3 * i] = ti;
             // xgt . x_1 with x_1 = -t_1 xgt - 0 (the order-1 bias is exactly zero, anm.cpp:235): -t_1 |xgt|^2, the
             // reduction already on the host, instead of another launch and host round trip
-            xgt_dot_x1 = -ti * xgt2;
+            static const bool analytic = std::getenv("SANM_X1_DOT_ANALYTIC") != nullptr;
+            xgt_dot_x1 = analytic ? -ti * xgt2 : be->dot(n, xi, m_xgt.p());
         } else {
             // t_i = (xb_i . x_1) / (t1 - xgt . x_1);  x_i = -t_i*xgt - xb_i  (anm.cpp:246-264)
             if (pade_riders) m_pade_ws.phase(m_xt_coeffs, i - 1, 2, anm_cond, true);
