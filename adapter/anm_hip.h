@@ -83,6 +83,13 @@ struct BatchMulEyeParam {    // libsanm/oprs/linalg.h:161-163
 struct BatchSVDWParam {      // libsanm/oprs/linalg.h:205-207
     bool require_rotation;
 };
+struct SliceParam {          // libsanm/oprs/misc.h:80-83
+    int axis, stride;
+    Maybe<int> begin, end;
+};
+struct ConcatParam {         // libsanm/oprs/misc.h:136-138
+    int nr_input, axis;
+};
 template <class P>
 const P& mirror(symbolic::OperatorNode* opr) {
     return *static_cast<const P*>(opr->storage());
@@ -123,8 +130,9 @@ using DescPtr = std::unique_ptr<sanm_sparse_desc, detail::DescDeleter>;
 /*!
  * Replay the graph that produces \p y through the operator-construction entry points of the C ABI
  * (sanm_graph_* <-> libsanm/oprs.h:14-103), in topological order.  Returns the graph; *out_var is y's id in it.
+ * placeholder_vector_size > 0: the graph is one over (batch, n) vectors (Slice / Concat allowed; operator-level API).
  */
-inline GraphPtr export_graph(symbolic::VarNode* y, int* out_var) {
+inline GraphPtr export_graph(symbolic::VarNode* y, int* out_var, int placeholder_vector_size = 0) {
     using namespace symbolic;
     sanm_graph* raw = nullptr;
     check(sanm_graph_create(&raw));
@@ -134,7 +142,10 @@ inline GraphPtr export_graph(symbolic::VarNode* y, int* out_var) {
     for (OperatorNode* opr : topo_sort({y})) {
         int out = -1;
         if (opr->isinstance<PlaceholderOprMeta>()) {
-            check(sanm_graph_placeholder(g.get(), &out));
+            // (the reference infers a placeholder's shape when it is fed; the device graph declares it: a (T,3,3)
+            // matrix, or -- for graphs with Slice / Concat -- a (batch, n) vector of the given length)
+            if (placeholder_vector_size > 0) check(sanm_graph_placeholder_vector(g.get(), placeholder_vector_size, &out));
+            else check(sanm_graph_placeholder(g.get(), &out));
         } else if (opr->isinstance<ConstantOprMeta>()) {
             const TensorND& v = detail::mirror<detail::ConstantParam>(opr).val;
             const TensorShape& s = v.shape();
@@ -178,8 +189,16 @@ inline GraphPtr export_graph(symbolic::VarNode* y, int* out_var) {
                                            detail::mirror<detail::BatchSVDWParam>(opr).require_rotation ? 1 : 0, usw));
             for (int i = 0; i < 3; ++i) id[opr->output(i)] = usw[i];
             continue;
+        } else if (opr->isinstance<SliceOprMeta>()) {
+            const auto& p = detail::mirror<detail::SliceParam>(opr);
+            check(sanm_graph_slice(g.get(), in(opr, 0), p.axis, p.begin.valid() ? 1 : 0, p.begin.valid() ? p.begin.val() : 0,
+                                   p.end.valid() ? 1 : 0, p.end.valid() ? p.end.val() : 0, p.stride, &out));
+        } else if (opr->isinstance<ConcatOprMeta>()) {
+            std::vector<int> vars(opr->inputs().size());
+            for (size_t i = 0; i < vars.size(); ++i) vars[i] = in(opr, i);
+            check(sanm_graph_concat(g.get(), (int)vars.size(), vars.data(), detail::mirror<detail::ConcatParam>(opr).axis,
+                                    &out));
         } else {
-            // Slice / Concat (libsanm/oprs/misc.h:79-170) are not part of the FEA graphs
             throw SANMError{std::string{"hip adapter: operator not on the device path: "} + opr->meta()->name()};
         }
         id[opr->output(0)] = out;

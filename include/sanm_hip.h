@@ -52,6 +52,19 @@ int sanm_graph_create(sanm_graph** g);
 void sanm_graph_destroy(sanm_graph* g);
 int sanm_graph_placeholder(sanm_graph* g, int* var);                       /* oprs.h:80 */
 /* val: (batch, size) with size in {1,3,9}; batch is T or 1 */
+/* ---- graphs over vectors: Slice / Concat (libsanm/oprs/misc.cpp:104-331, oprs.h:60) ---------------------------
+ * A placeholder declared with sanm_graph_placeholder_vector is a (batch, size) tensor; graphs over it may use the
+ * elementwise operators (linear_combine, multiply, pow, log, reduce_sum axis -1), constants of any length, and
+ *   sanm_graph_slice:  x[:, begin:end]  (has_begin / has_end = 0 stand for the reference's None; negative values
+ *                      count from the end; axis must be 1 and stride 1 like the reference's implementation)
+ *   sanm_graph_concat: concatenation along axis 1.
+ * They run on a vector interpreter of their own on the device (one workgroup per batch item) and are served by the
+ * operator-level API (sanm_taylor_*: push_xi, compute_next_order_bias, get_jacobian -> (B, odim, idim)); the ANM
+ * drivers and the batched 3x3 operators stay with (T,3,3) graphs.  Vectors of up to 64 elements. */
+int sanm_graph_placeholder_vector(sanm_graph* g, int size, int* var);
+int sanm_graph_slice(sanm_graph* g, int x, int axis, int has_begin, int begin, int has_end, int end, int stride,
+                     int* var);
+int sanm_graph_concat(sanm_graph* g, int n, const int* vars, int axis, int* var);
 int sanm_graph_constant(sanm_graph* g, const double* val, int64_t batch, int size, int* var); /* oprs.h:88 */
 int sanm_graph_linear_combine(sanm_graph* g, int n, const double* coeffs, const int* vars,
                               double bias, int* var);                     /* oprs.h:76-77 */

@@ -760,6 +760,119 @@ _SVDW = BatchSVDWOprMeta()
 # --------------------------------------------------------------------------
 # SymbolVar sugar: libsanm/oprs.h:14-103, oprs.cpp:16-102
 # --------------------------------------------------------------------------
+class SliceOprMeta(OperatorMeta):
+    """x[:, begin:end] of a batch-1 (1, n) tensor; libsanm/oprs/misc.cpp:104-231 (axis 1, stride 1, one batch:
+    what the reference implements)."""
+    name = "slice"
+
+    @staticmethod
+    def abs_interval(param, size):
+        """misc.cpp:104-133."""
+        stride = param["stride"]
+        assert stride != 0 and size > 0
+        begin, end = param["begin"], param["end"]
+        if begin is None:
+            begin = 0 if stride > 0 else size - 1
+        elif begin < 0:
+            begin += size
+        if end is None:
+            end = size if stride > 0 else -1
+        elif end < 0:
+            end += size
+        if stride < 0:
+            assert begin > end and end >= -1 and begin < size
+        else:
+            assert begin < end and begin >= 0 and end <= size
+        return begin, end
+
+    def _cut(self, opr, x):
+        p = opr.param
+        assert p["axis"] == 1 and p["stride"] == 1 and x.shape[0] == 1, "unimplemented (misc.cpp:149-151)"
+        b, e = self.abs_interval(p, x.shape[1])
+        return x[:, b:e].copy()
+
+    def infer_shape(self, opr, ctx):
+        ishp = ctx.get(opr.input(0)).shape
+        p = opr.param
+        assert 0 <= p["axis"] < len(ishp)
+        b, e = self.abs_interval(p, ishp[p["axis"]])
+        oshp = list(ishp)
+        oshp[p["axis"]] = (abs(e - b) - 1) // abs(p["stride"]) + 1
+        ctx.get(opr.output(0)).shape = tuple(oshp)
+
+    def eval_bias(self, opr, ctx):
+        ctx.get(opr.output(0)).coeffs.append(self._cut(opr, ctx.get(opr.input(0)).coeffs[0]))
+
+    def accum_inp_grad(self, opr, ctx):
+        """misc.cpp:166-197"""
+        i, o = ctx.get(opr.input(0)), ctx.get(opr.output(0))
+        b, e = self.abs_interval(opr.param, i.shape[1])
+        T, odim, _ = o.jacobian.shape
+        g = np.zeros((T, odim, i.shape[1]))
+        g[:, :, b:e] = o.jacobian
+        i.accum_jac(g)
+
+    def compute_order_bias(self, opr, ctx):
+        i, o = ctx.get(opr.input(0)), ctx.get(opr.output(0))
+        o.cur_order_bias = np.zeros(o.shape) if ctx.order == 1 else self._cut(opr, i.cur_order_bias)
+
+    def compute_coeff(self, opr, ctx):
+        ctx.get(opr.output(0)).coeffs.append(self._cut(opr, ctx.get(opr.input(0)).coeffs[-1]))
+
+
+class ConcatOprMeta(OperatorMeta):
+    """concatenation along axis 1 of batch-1 tensors; libsanm/oprs/misc.cpp:233-331."""
+    name = "concat"
+
+    def infer_shape(self, opr, ctx):
+        axis = opr.param["axis"]
+        oshp = None
+        for v in opr.inputs:
+            ishp = list(ctx.get(v).shape)
+            if oshp is None:
+                oshp = ishp
+            else:
+                assert len(ishp) == len(oshp)
+                oshp[axis] += ishp[axis]
+                ishp[axis] = oshp[axis]
+                assert ishp == oshp, f"concat shape mismatch {ishp} vs {oshp}"
+        ctx.get(opr.output(0)).shape = tuple(oshp)
+
+    def _cat(self, opr, ctx, in_coeff):
+        o = ctx.get(opr.output(0))
+        assert opr.param["axis"] == 1 and o.shape[0] == 1, "unimplemented (misc.cpp:303)"
+        o.set_bias(in_coeff, np.concatenate([ctx.get(v).get_bias(in_coeff).reshape(1, -1) for v in opr.inputs], axis=1))
+
+    def eval_bias(self, opr, ctx):
+        ctx.get(opr.output(0)).coeffs.append(None)
+        self._cat(opr, ctx, True)
+
+    def accum_inp_grad(self, opr, ctx):
+        o = ctx.get(opr.output(0))
+        off = 0
+        for v in opr.inputs:
+            i = ctx.get(v)
+            n = i.shape[1]
+            i.accum_jac(o.jacobian[:, :, off:off + n])
+            off += n
+        assert off == o.shape[1]
+
+    def compute_order_bias(self, opr, ctx):
+        o = ctx.get(opr.output(0))
+        if ctx.order == 1:
+            o.cur_order_bias = np.zeros(o.shape)
+        else:
+            self._cat(opr, ctx, False)
+
+    def compute_coeff(self, opr, ctx):
+        ctx.get(opr.output(0)).coeffs.append(None)
+        self._cat(opr, ctx, True)
+
+
+_SLICE = SliceOprMeta()
+_CONCAT = ConcatOprMeta()
+
+
 class SymbolVar:
     def __init__(self, var):
         self.var = var.var if isinstance(var, SymbolVar) else var
@@ -819,6 +932,12 @@ class SymbolVar:
     def log(self):
         return SymbolVar(self._g.insert_opr(_UNARY, {"kind": "log"}, [self.var]).output(0))
 
+    def slice(self, axis, begin=None, end=None, stride=1):
+        """oprs.h:60 / misc.cpp:222-229"""
+        assert axis >= 0 and stride != 0
+        return SymbolVar(self._g.insert_opr(_SLICE, {"axis": int(axis), "begin": begin, "end": end, "stride": int(stride)},
+                                            [self.var]).output(0))
+
     def batched_svd_w(self, require_rotation=False):
         opr = self._g.insert_opr(_SVDW, {"require_rotation": bool(require_rotation)}, [self.var])
         return [SymbolVar(opr.output(i)) for i in range(3)]
@@ -836,6 +955,13 @@ def linear_combine(vars_, bias=0.0):
     assert inputs
     g = inputs[0].graph
     return SymbolVar(g.insert_opr(_LINCOMB, {"coeffs": coeffs, "bias": float(bias)}, inputs).output(0))
+
+
+def concat(vars_, axis):
+    """oprs.h / misc.cpp:321-331"""
+    inputs = [v.var for v in vars_]
+    assert inputs and axis >= 0
+    return SymbolVar(inputs[0].graph.insert_opr(_CONCAT, {"axis": int(axis)}, inputs).output(0))
 
 
 def placeholder(cg):

@@ -13,7 +13,7 @@ import os
 from . import api as _api
 from .api import (ANMEqnSolver, ANMImplicitSolver, ANMSolverVecScale, Api, SanmError,  # noqa: F401
                   SanmAssertionError, SanmNumericalError, SanmUnsupportedError, SymbolVar,
-                  TaylorCoeffProp, batched_mat_inv_mul, constant, linear_combine, placeholder)
+                  TaylorCoeffProp, batched_mat_inv_mul, concat, constant, linear_combine, placeholder)
 
 # (SANM_HIP_LIBRARY: another build of the same library, for A/B measurements -- scripts/build_variants.py)
 LIB_PATH = os.environ.get("SANM_HIP_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsanm_hip.so")

@@ -67,7 +67,7 @@ ENERGY = {"neohookean_i": 0, "neohookean_c": 1, "arap": 2, "stvk_stretch": 3}
 SYMBOLS = [
     "sanm_hip_init", "sanm_hip_last_error", "sanm_hip_backend_name",
     "sanm_hip_comm_available", "sanm_hip_comm_unique_id", "sanm_hip_comm_init", "sanm_hip_comm_destroy",
-    "sanm_graph_create", "sanm_graph_destroy", "sanm_graph_placeholder", "sanm_graph_constant",
+    "sanm_graph_create", "sanm_graph_destroy", "sanm_graph_placeholder", "sanm_graph_constant", "sanm_graph_placeholder_vector", "sanm_graph_slice", "sanm_graph_concat",
     "sanm_graph_linear_combine", "sanm_graph_multiply", "sanm_graph_pow", "sanm_graph_log",
     "sanm_graph_reduce_sum", "sanm_graph_batched_matmul", "sanm_graph_batched_mat_inv_mul",
     "sanm_graph_batched_det", "sanm_graph_batched_transpose", "sanm_graph_batched_mul_eye",
@@ -244,6 +244,13 @@ class SymbolVar:
     def __rsub__(self, lhs):
         return linear_combine([(-1.0, self)], float(lhs))
 
+    def slice(self, axis, begin=None, end=None, stride=1):
+        """SymbolVar::slice (oprs.h:60): x[:, begin:end]; None like the reference's Maybe<int>"""
+        lib = self.graph.api.lib
+        return self._mk(lib.sanm_graph_slice, C.c_int(self.id), C.c_int(int(axis)), C.c_int(begin is not None),
+                        C.c_int(0 if begin is None else int(begin)), C.c_int(end is not None),
+                        C.c_int(0 if end is None else int(end)), C.c_int(int(stride)))
+
     def __mul__(self, rhs):
         lib = self.graph.api.lib
         if isinstance(rhs, SymbolVar):
@@ -318,6 +325,14 @@ class ComputingGraph:
         self.api.check(self.api.lib.sanm_graph_placeholder(self.h, C.byref(out)))
         return SymbolVar(self, out.value)
 
+    def placeholder_vector(self, size):
+        """a (batch, size) vector input (graphs over it may use slice / concat: sanm_graph_placeholder_vector)"""
+        out = C.c_int()
+        self.api.check(self.api.lib.sanm_graph_placeholder_vector(self.h, C.c_int(int(size)), C.byref(out)))
+        v = SymbolVar(self, out.value)
+        v.vec_size = int(size)
+        return v
+
     def constant(self, val):
         val = _f64(val)
         batch = val.shape[0]
@@ -326,6 +341,16 @@ class ComputingGraph:
         self.api.check(self.api.lib.sanm_graph_constant(self.h, _dp(val), C.c_int64(batch),
                                                         C.c_int(size), C.byref(out)))
         return SymbolVar(self, out.value)
+
+
+def concat(vars_, axis):
+    """concat (oprs.h; misc.cpp:321-331)"""
+    vars_ = list(vars_)
+    g = vars_[0].graph
+    ids = (C.c_int * len(vars_))(*[v.id for v in vars_])
+    out = C.c_int()
+    g.api.check(g.api.lib.sanm_graph_concat(g.h, C.c_int(len(vars_)), ids, C.c_int(int(axis)), C.byref(out)))
+    return SymbolVar(g, out.value)
 
 
 def placeholder(cg):
@@ -439,9 +464,12 @@ class DirectSolver:
 class TaylorCoeffProp:
     """libsanm/symbolic.h:337-383 on the device."""
 
-    def __init__(self, api, y: SymbolVar, remap_inp: SparseLinearDesc, max_order, nr_tet):
+    def __init__(self, api, y: SymbolVar, remap_inp: SparseLinearDesc, max_order, nr_tet, in_size=9):
+        """nr_tet: the batch; in_size: elements of the placeholder per batch item (9 for (T,3,3) graphs, the vector
+        length for graphs over sanm_graph_placeholder_vector)"""
         self.api = api
         self.T = int(nr_tet)
+        self.in_size = int(in_size)
         h = C.c_void_p()
         api.check(api.lib.sanm_taylor_create(y.graph.h, C.c_int(y.id), remap_inp.h, C.c_int(max_order),
                                              C.byref(h)))
@@ -469,7 +497,7 @@ class TaylorCoeffProp:
         return b
 
     def get_jacobian(self):
-        j = np.zeros((self.T, self.out_size, 9))
+        j = np.zeros((self.T, self.out_size, self.in_size))
         self.api.check(self.api.lib.sanm_taylor_get_jacobian(self.h, _dp(j)))
         return j
 

@@ -10,6 +10,7 @@
 #include <limits>
 
 #include "multifrontal.h"
+#include "vecprog_host.h"
 #include "poly.h"
 #include "tet_ops.h"
 
@@ -714,6 +715,9 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
         : m_be{be}, m_hp{hp}, m_n{nr_unknown}, m_max_a_bound{poly::stable_x_range(hp.order)},
           m_shard{shard}, m_profile_mode{hp.profile} {
     sanm_check(hp.order >= 2, "order=%d", hp.order);  // anm.cpp:108-110
+    if (graph_is_vector(g_in, out_var))
+        sanm_throw(SANM_ERR_UNSUPPORTED, "the ANM drivers take (T,3,3) graphs; graphs over vectors (Slice / Concat) are "
+                                         "served by the operator-level API (sanm_taylor_*)");
     sanm_check(remap_inp_in.out_size % 9 == 0, "remap_inp must produce a (T,3,3) tensor");
     if (hp.xcoeff_l2_penalty != 0 && hp.solver_kind != 1)
         sanm_throw(SANM_ERR_UNSUPPORTED, "xcoeff_l2_penalty (Tikhonov path) needs the direct solver (solver_kind 1)");

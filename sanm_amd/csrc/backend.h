@@ -249,6 +249,9 @@ public:
     //! between phase_begin(tag) and the matching phase_end() are bracketed by device events on the backend's
     //! stream; phase_collect() waits for the stream and adds the elapsed seconds of every closed bracket to
     //! acc[tag] / the number of brackets to cnt[tag].  Brackets nest.  Backends without events do nothing.
+    //! one pass of a vector-graph program (vecprog.h): mode EVAL0 / COEFF (xin = the placeholder's values of this
+    //! order, (B, idim) in device memory), BIAS, GRAD
+    virtual void run_vec_pass(const struct VecProgDev& P, int mode, int order, const double* xin) = 0;
     //! kernel launches issued so far (0 for backends that do not launch kernels)
     virtual int64_t launch_count() const { return 0; }
     virtual void phase_begin(const char* tag) { (void)tag; }

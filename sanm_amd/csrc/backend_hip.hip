@@ -33,6 +33,7 @@
 #include "row_ops.h"
 #include "rtc.h"
 #include "tet_ops.h"
+#include "vecprog.h"
 
 namespace sanm_hip {
 
@@ -961,6 +962,32 @@ inline unsigned red_grid(size_t n) {
 }
 
 // ---- RCCL, bound at run time ------------------------------------------------------------------------------
+// ---- vector graphs (vecprog.h): one workgroup per batch item, one thread per element, a barrier between operators --
+__global__ void __launch_bounds__(VEC_MAX_SIZE) vec_pass_kernel(VecProgDev P, int mode, int order, const double* xin) {
+    const int64_t b = blockIdx.x;
+    const int e = threadIdx.x;
+    if (mode == PASS_GRAD) {
+        extern __shared__ double vg[];  // gradient rows of all variables for the Jacobian row in hand
+        for (int r = 0; r < P.odim; ++r) {
+            for (int i = e; i < P.grad_total; i += VEC_MAX_SIZE) vg[i] = 0.0;
+            __syncthreads();
+            if (e == 0) vg[P.vars[P.out_var].grad + r] = 1.0;  // symbolic.cpp:219-220
+            __syncthreads();
+            for (int i = P.nops - 1; i >= 0; --i) {
+                vec_backward(P, P.ops[i], b, e, vg);
+                __syncthreads();
+            }
+            if (e < P.idim) P.arena[P.jac + (b * P.odim + r) * P.idim + e] = vg[P.vars[P.in_var].grad + e];
+            __syncthreads();
+        }
+        return;
+    }
+    for (int i = 0; i < P.nops; ++i) {
+        vec_forward(P, P.ops[i], mode, order, b, e, xin);
+        __syncthreads();
+    }
+}
+
 // The tet-sharded mode sums nodal vectors over the ranks with ncclAllReduce on the backend's own stream, so the
 // order loop stays free of host synchronisation (the callback form of the C ABI has to synchronise on both sides
 // of the call).  RCCL is looked up with dlopen: a process that already holds it (torch.distributed's nccl backend
@@ -1200,6 +1227,11 @@ public:
     }
     const char* name() const override { return "hip"; }
     int64_t launch_count() const override { return m_launch_count; }
+    void run_vec_pass(const VecProgDev& P, int mode, int order, const double* xin) override {
+        const size_t lds = mode == PASS_GRAD ? (size_t)P.grad_total * sizeof(double) : 0;
+        SANM_LAUNCH(vec_pass_kernel, dim3((unsigned)P.B), dim3(VEC_MAX_SIZE), lds, m_stream, P, mode, order, xin);
+        HIP_CHECK(hipGetLastError());
+    }
 
     bool comm_available() override {
         try {

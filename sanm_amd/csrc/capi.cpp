@@ -1,6 +1,7 @@
 // extern "C" entry points declared in include/sanm_hip.h.
 #include "../../include/sanm_hip.h"
 #include "../../include/sanm_hip_test.h"
+#include "vecprog_host.h"
 
 #include <cstring>
 #include <memory>
@@ -75,6 +76,11 @@ HyperParam to_hp(const sanm_hyper_param* h) {
 // TaylorCoeffProp on the device (libsanm/symbolic.cpp:142-304)
 struct sanm_taylor_prop {
     std::unique_ptr<Program> prog;
+    // graphs over vectors (Slice / Concat, sizes other than 1 / 3 / 9): the vector interpreter (vecprog.h) and the
+    // remap_inp rows it is fed through
+    std::unique_ptr<VecProgram> vec;
+    SparseDesc vec_remap;
+    DVec xin;
     DVec x;
     int order = 0;
     bool xi_known = false, jacobian_done = false;
@@ -83,9 +89,11 @@ struct sanm_taylor_prop {
     void ensure_jacobian() {
         if (jacobian_done) return;
         sanm_check(order == 0, "jacobian must be taken at order 0");
-        backend()->run_pass(prog->dev(), PASS_GRAD, 0, nullptr);
+        if (vec) backend()->run_vec_pass(vec->dev(), PASS_GRAD, 0, nullptr);
+        else backend()->run_pass(prog->dev(), PASS_GRAD, 0, nullptr);
         jacobian_done = true;
     }
+    int max_order() const { return vec ? vec->max_order() : prog->max_order(); }
 };
 
 struct sanm_anm_solver {
@@ -118,6 +126,16 @@ int sanm_graph_create(sanm_graph** g) {
 void sanm_graph_destroy(sanm_graph* g) { delete g; }
 int sanm_graph_placeholder(sanm_graph* g, int* var) {
     return guard([&] { *var = g->g.placeholder(); });
+}
+int sanm_graph_placeholder_vector(sanm_graph* g, int size, int* var) {
+    return guard([&] { *var = g->g.placeholder_vector(size); });
+}
+int sanm_graph_slice(sanm_graph* g, int x, int axis, int has_begin, int begin, int has_end, int end, int stride,
+                     int* var) {
+    return guard([&] { *var = g->g.slice(x, axis, has_begin, begin, has_end, end, stride); });
+}
+int sanm_graph_concat(sanm_graph* g, int n, const int* vars, int axis, int* var) {
+    return guard([&] { *var = g->g.concat(n, vars, axis); });
 }
 int sanm_graph_constant(sanm_graph* g, const double* val, int64_t batch, int size, int* var) {
     return guard([&] { *var = g->g.constant(val, batch, size); });
@@ -267,6 +285,20 @@ int sanm_taylor_create(const sanm_graph* g, int out_var, const sanm_sparse_desc*
                        int max_order, sanm_taylor_prop** prop) {
     return guard([&] {
         Backend* be = backend();
+        if (graph_is_vector(g->g, out_var)) {
+            // batched vectors: the placeholder's length comes from the graph, the batch from remap_inp
+            int idim = 0;
+            for (const GraphOp& op : g->g.ops)
+                if (op.type == OP_PLACEHOLDER && !op.out.empty()) idim = g->g.vars[op.out[0]].size;
+            sanm_check(idim > 0 && remap_inp->d.out_size % idim == 0, "remap_inp must produce a (B,%d) tensor", idim);
+            auto p = std::make_unique<sanm_taylor_prop>();
+            p->vec = std::make_unique<VecProgram>(be, g->g, out_var, remap_inp->d.out_size / idim, max_order);
+            p->vec_remap = remap_inp->d;
+            p->n_in = remap_inp->d.in_size;
+            p->xin = DVec{be, (size_t)remap_inp->d.out_size};
+            *prop = p.release();
+            return;
+        }
         sanm_check(remap_inp->d.out_size % 9 == 0, "remap_inp must produce a (T,3,3) tensor");
         auto p = std::make_unique<sanm_taylor_prop>();
         p->prog = std::make_unique<Program>(be, g->g, out_var, remap_inp->d.out_size / 9, max_order);
@@ -283,7 +315,28 @@ int sanm_taylor_push_xi(sanm_taylor_prop* p, const double* x, double* y_k) {
     return guard([&] {
         Backend* be = backend();
         sanm_check(!p->xi_known, "push_xi called twice for one order");
-        sanm_check(p->order <= p->prog->max_order(), "order exceeds max_order");
+        sanm_check(p->order <= p->max_order(), "order exceeds max_order");
+        if (p->vec) {
+            // SparseLinearDesc::apply (anm.cpp:55-75) of a handful of entries, then the pass on the device
+            const SparseDesc& R = p->vec_remap;
+            std::vector<double> xin(R.out_size, 0.0);
+            for (int64_t i = 0; i < R.out_size; ++i)
+                for (uint64_t q = R.rowptr[i]; q < R.rowptr[i + 1]; ++q) xin[i] += R.coef[q] * x[R.idx[q]];
+            be->h2d(p->xin.p(), xin.data(), xin.size() * 8);
+            be->run_vec_pass(p->vec->dev(), p->order == 0 ? PASS_EVAL0 : PASS_COEFF, p->order, p->xin.p());
+            be->sync();
+            if (p->order == 0) {
+                double fl[2];
+                p->vec->take_flags(fl);
+                if (fl[0] != 0) sanm_throw(SANM_ERR_NUMERICAL, "0^p when p is not integer");
+                if (fl[1] != 0)
+                    sanm_throw(SANM_ERR_UNSUPPORTED, "integer power (other than the square) of a series through zero on "
+                                                     "the vector interpreter");
+            }
+            p->xi_known = true;
+            if (y_k) p->vec->download_out(p->order, y_k);
+            return;
+        }
         be->h2d(p->x.p(), x, p->n_in * 8);
         be->run_pass(p->prog->dev(), p->order == 0 ? PASS_EVAL0 : PASS_COEFF, p->order, p->x.p());
         be->sync();
@@ -322,9 +375,15 @@ int sanm_taylor_compute_next_order_bias(sanm_taylor_prop* p, double* bias) {
         Backend* be = backend();
         p->ensure_jacobian();
         sanm_check(p->xi_known, "push_xi must precede compute_next_order_bias");
-        sanm_check(p->order < p->prog->max_order(), "order exceeds max_order");
+        sanm_check(p->order < p->max_order(), "order exceeds max_order");
         ++p->order;
         p->xi_known = false;
+        if (p->vec) {
+            be->run_vec_pass(p->vec->dev(), PASS_BIAS, p->order, nullptr);
+            be->sync();
+            if (bias) p->vec->download_out(-1, bias);
+            return;
+        }
         be->run_pass(p->prog->dev(), PASS_BIAS, p->order, nullptr);
         be->sync();
         if (bias) {
@@ -340,7 +399,7 @@ int sanm_taylor_compute_next_order_bias(sanm_taylor_prop* p, double* bias) {
 }
 
 int sanm_taylor_output_size(const sanm_taylor_prop* p, int* size) {
-    return guard([&] { *size = p->prog->dev().odim; });
+    return guard([&] { *size = p->vec ? p->vec->odim() : p->prog->dev().odim; });
 }
 
 int sanm_taylor_get_jacobian(sanm_taylor_prop* p, double* jac) {
@@ -349,12 +408,16 @@ int sanm_taylor_get_jacobian(sanm_taylor_prop* p, double* jac) {
         sanm_check(p->xi_known || p->jacobian_done, "push_xi must precede get_jacobian");
         p->ensure_jacobian();
         backend()->sync();
-        p->prog->download_jacobian(jac);
+        if (p->vec) p->vec->download_jacobian(jac);
+        else p->prog->download_jacobian(jac);
     });
 }
 
 int sanm_taylor_get_var(sanm_taylor_prop* p, int var, int order, double* dst) {
-    return guard([&] { p->prog->download_var(var, order, dst); });
+    return guard([&] {
+        if (p->vec) p->vec->download_var(var, order, dst);
+        else p->prog->download_var(var, order, dst);
+    });
 }
 
 int sanm_taylor_reset(sanm_taylor_prop* p) {

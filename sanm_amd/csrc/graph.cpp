@@ -1,4 +1,5 @@
 #include "graph.h"
+#include "vecprog_host.h"
 
 #include <algorithm>
 #include <cmath>
@@ -42,8 +43,48 @@ int Graph::placeholder() {
     return add(std::move(op), {9});
 }
 
+int Graph::placeholder_vector(int size) {
+    sanm_check(size >= 1, "placeholder: bad size %d", size);
+    GraphOp op;
+    op.type = OP_PLACEHOLDER;
+    op.flags = OP_FLAG_VECTOR;
+    return add(std::move(op), {size});
+}
+
+int Graph::slice(int x, int axis, int has_begin, int begin, int has_end, int end, int stride) {
+    chk(x);
+    // misc.cpp:104-133 (abs_interval), :135-152: the reference implements axis 1 and stride 1
+    sanm_check(axis >= 0 && stride != 0, "slice: bad axis / stride");
+    if (axis != 1 || stride != 1)
+        sanm_throw(SANM_ERR_UNSUPPORTED, "slice: axis %d stride %d unimplemented (as in the reference)", axis, stride);
+    const int size = vars[x].size;
+    int b = has_begin ? begin : 0, e = has_end ? end : size;
+    if (has_begin && b < 0) b += size;
+    if (has_end && e < 0) e += size;
+    sanm_check(b < e && b >= 0 && e <= size, "slice: bad interval [%d, %d) of %d", b, e, size);
+    GraphOp op;
+    op.type = OP_SLICE;
+    op.in = {x};
+    op.begin = b;
+    return add(std::move(op), {e - b});
+}
+
+int Graph::concat(int n, const int* vs, int axis) {
+    sanm_check(n >= 1 && axis >= 0, "concat: bad arguments");
+    if (axis != 1) sanm_throw(SANM_ERR_UNSUPPORTED, "concat: axis %d unimplemented (as in the reference)", axis);
+    GraphOp op;
+    op.type = OP_CONCAT;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        chk(vs[i]);
+        op.in.push_back(vs[i]);
+        total += vars[vs[i]].size;
+    }
+    return add(std::move(op), {total});
+}
+
 int Graph::constant(const double* val, int64_t batch, int size) {
-    sanm_check(size == 1 || size == 3 || size == 9, "constant: unsupported per-tet size %d", size);
+    sanm_check(size >= 1, "constant: bad size %d", size);
     GraphOp op;
     op.type = OP_CONSTANT;
     op.batch = batch;
@@ -185,6 +226,10 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
         : m_be{be}, m_tet_begin{tet_begin} {
     if (T_global < 0) T_global = T;
     sanm_check(out_var >= 0 && out_var < (int)g.vars.size(), "invalid output var");
+    if (graph_is_vector(g, out_var))
+        sanm_throw(SANM_ERR_UNSUPPORTED,
+                   "a graph over vectors (Slice / Concat, sizes other than 1, 3, 9) runs on the vector interpreter: "
+                   "operator-level API (sanm_taylor_*) only");
     sanm_check(T > 0 && max_order >= 1, "invalid T/order");
     const int64_t Tpad = (T + 63) / 64 * 64;
     const int N = max_order;

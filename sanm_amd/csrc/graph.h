@@ -49,6 +49,7 @@ struct GraphOp {
     double exponent = 0;         // POW
     std::vector<double> value;   // CONSTANT, row-major (T, size)
     int64_t batch = 0;           // CONSTANT
+    int begin = 0;               // SLICE: first element taken (resolved, misc.cpp:104-133)
 };
 
 class Graph {
@@ -57,7 +58,14 @@ public:
     std::vector<GraphVar> vars;
 
     int placeholder();
+    //! a (batch, size) vector input: graphs over it run on the vector interpreter (vecprog.h)
+    int placeholder_vector(int size);
     int constant(const double* val, int64_t batch, int size);
+    //! x[:, begin:end] (SymbolVar::slice, oprs.h:60; misc.cpp:104-231): axis 1, stride 1 like the reference's
+    //! implementation; has_begin / has_end = 0 stand for None
+    int slice(int x, int axis, int has_begin, int begin, int has_end, int end, int stride);
+    //! concatenation along axis 1 (misc.cpp:233-331)
+    int concat(int n, const int* vars, int axis);
     int linear_combine(int n, const double* coeffs, const int* vars, double bias);
     int multiply(int a, int b);
     int pow(int x, double e);

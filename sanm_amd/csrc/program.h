@@ -35,6 +35,9 @@ enum OpType : int32_t {
     OP_TRANSPOSE = 10,   // libsanm/oprs/linalg.cpp:286-335
     OP_MULEYE = 11,      // libsanm/oprs/linalg.cpp:422-479
     OP_SVDW = 12,        // libsanm/oprs/linalg.cpp:483-615 (pw_mode)
+    // vector graphs only (vecprog.h): batch-1-style (batch, n) tensors
+    OP_SLICE = 13,       // libsanm/oprs/misc.cpp:104-231 (axis 1, stride 1)
+    OP_CONCAT = 14,      // libsanm/oprs/misc.cpp:233-331 (axis 1)
 };
 
 enum PassMode : int32_t {
@@ -54,6 +57,7 @@ constexpr int OP_FLAG_SVDW_FULL = 8;       // SVDW: U or S is read: the full U, 
 constexpr int OP_FLAG_SVDW_GU = 16;        // SVDW, reverse sweep: the gradient slot of U / S / W is live (the output
 constexpr int OP_FLAG_SVDW_GS = 32;        // has a reader or is the graph output)
 constexpr int OP_FLAG_SVDW_GW = 64;
+constexpr int OP_FLAG_VECTOR = 128;        // PLACEHOLDER: a (batch, n) vector, not a (T,3,3) matrix (vecprog.h)
 constexpr int MAX_OP_IN = 4;
 
 struct VarDesc {

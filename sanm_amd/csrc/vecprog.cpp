@@ -1,0 +1,191 @@
+#include "vecprog_host.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace sanm_hip {
+
+namespace {
+// operators `out_var` depends on, in creation (= topological) order
+std::vector<int> needed_ops(const Graph& g, int out_var) {
+    std::vector<char> need(g.ops.size(), 0);
+    std::vector<int> stack{g.vars.at(out_var).producer};
+    while (!stack.empty()) {
+        const int oi = stack.back();
+        stack.pop_back();
+        if (need[oi]) continue;
+        need[oi] = 1;
+        for (int v : g.ops[oi].in) stack.push_back(g.vars[v].producer);
+    }
+    std::vector<int> r;
+    for (size_t i = 0; i < g.ops.size(); ++i)
+        if (need[i]) r.push_back((int)i);
+    return r;
+}
+}  // namespace
+
+bool graph_is_vector(const Graph& g, int out_var) {
+    for (int oi : needed_ops(g, out_var)) {
+        const GraphOp& op = g.ops[oi];
+        if (op.type == OP_SLICE || op.type == OP_CONCAT) return true;
+        if (op.type == OP_PLACEHOLDER && (op.flags & OP_FLAG_VECTOR)) return true;
+        for (int v : op.out) {
+            const int s = g.vars[v].size;
+            if (s != 1 && s != 3 && s != 9) return true;
+        }
+    }
+    return false;
+}
+
+VecProgram::VecProgram(Backend* be, const Graph& g, int out_var, int64_t B, int max_order) : m_be{be} {
+    sanm_check(out_var >= 0 && out_var < (int)g.vars.size(), "invalid output var");
+    sanm_check(B > 0 && max_order >= 0, "invalid batch / order");
+    const std::vector<int> order = needed_ops(g, out_var);
+    m_var_map.assign(g.vars.size(), -1);
+    std::vector<VecOp> ops;
+    int64_t off = 0;
+    auto take = [&](int64_t n) {
+        const int64_t r = off;
+        off += n;
+        return r;
+    };
+    int nr_placeholder = 0, grad = 0;
+    m_dev.in_var = -1;
+    const int64_t flag = take(2);
+    for (int oi : order) {
+        const GraphOp& op = g.ops[oi];
+        VecOp o{};
+        o.type = op.type;
+        o.flags = op.flags;
+        o.nin = op.in.size();
+        sanm_check(o.nin <= VEC_MAX_IN, "vector graphs: at most %d inputs per operator", VEC_MAX_IN);
+        switch (op.type) {
+            case OP_PLACEHOLDER: case OP_CONSTANT: case OP_LINCOMB: case OP_MULTIPLY: case OP_LOG: case OP_POW:
+            case OP_REDUCE_SUM: case OP_SLICE: case OP_CONCAT: break;
+            default:
+                sanm_throw(SANM_ERR_UNSUPPORTED,
+                           "operator %d on vectors: the batched 3x3 linear-algebra operators need (T,3,3) operands",
+                           (int)op.type);
+        }
+        bool all_const = op.type != OP_PLACEHOLDER;
+        for (int i = 0; i < o.nin; ++i) {
+            o.in[i] = m_var_map[op.in[i]];
+            sanm_check(o.in[i] >= 0, "operand of operator %d is not computed", oi);
+            all_const = all_const && m_vars[o.in[i]].is_const;
+        }
+        sanm_check(op.out.size() == 1, "vector graphs: single-output operators only");
+        const int gv = op.out[0], sz = g.vars[gv].size;
+        sanm_check(sz >= 1 && sz <= VEC_MAX_SIZE, "vector of %d elements: at most %d", sz, VEC_MAX_SIZE);
+        VecVar v{};
+        v.size = sz;
+        v.is_const = all_const ? 1 : 0;
+        v.const_batch = 0;
+        if (op.type == OP_CONSTANT) {
+            sanm_check(op.batch == 1 || op.batch == B, "constant of batch %ld in a graph of batch %ld", (long)op.batch, (long)B);
+            v.const_batch = op.batch == 1 ? 1 : 0;
+            v.coef = take((op.batch == 1 ? 1 : B) * sz);
+            v.bias = -1;
+        } else {
+            v.coef = take((int64_t)(v.is_const ? 1 : max_order + 1) * B * sz);
+            v.bias = v.is_const ? -1 : take(B * sz);
+        }
+        v.grad = grad;
+        grad += sz;
+        const int lv = m_vars.size();
+        m_vars.push_back(v);
+        m_var_map[gv] = lv;
+        o.out = lv;
+        if (op.type == OP_PLACEHOLDER) {
+            ++nr_placeholder;
+            m_dev.in_var = lv;
+            m_dev.idim = sz;
+        } else if (op.type == OP_LINCOMB) {
+            for (int i = 0; i < o.nin; ++i) o.p[i] = op.coeffs[i];
+            o.p[VEC_MAX_IN] = op.bias;
+        } else if (op.type == OP_POW || op.type == OP_LOG) {
+            o.p[0] = op.exponent;
+            o.aux0 = take(B * sz);
+            o.aux1 = take(B * sz);
+        } else if (op.type == OP_MULTIPLY) {
+            o.aux1 = take(B * sz);
+        } else if (op.type == OP_SLICE) {
+            o.begin = op.begin;
+        }
+        ops.push_back(o);
+    }
+    sanm_check(nr_placeholder == 1, "exactly one placeholder input is supported, got %d", nr_placeholder);
+    m_out_graph_var = out_var;
+    m_dev.out_var = m_var_map[out_var];
+    sanm_check(!m_vars[m_dev.out_var].is_const, "the output does not depend on the input");
+    m_dev.odim = m_vars[m_dev.out_var].size;
+    m_dev.jac = take(B * m_dev.odim * m_dev.idim);
+    m_dev.flag = flag;
+    m_dev.B = B;
+    m_dev.max_order = max_order;
+    m_dev.nops = ops.size();
+    m_dev.nvars = m_vars.size();
+    m_dev.grad_total = grad;
+    sanm_check(grad <= 4096, "vector graph too large for the gradient scratch (%d doubles)", grad);
+    // arena, constants
+    std::vector<double> host(off, 0.0);
+    for (int oi : order) {
+        const GraphOp& op = g.ops[oi];
+        if (op.type != OP_CONSTANT) continue;
+        const VecVar& v = m_vars[m_var_map[op.out[0]]];
+        std::copy(op.value.begin(), op.value.end(), host.begin() + v.coef);
+    }
+    m_dev.arena = static_cast<double*>(be->alloc(std::max<int64_t>(off, 1) * sizeof(double)));
+    be->h2d(m_dev.arena, host.data(), off * sizeof(double));
+    m_d_ops = be->alloc(ops.size() * sizeof(VecOp));
+    be->h2d(m_d_ops, ops.data(), ops.size() * sizeof(VecOp));
+    m_d_vars = be->alloc(m_vars.size() * sizeof(VecVar));
+    be->h2d(m_d_vars, m_vars.data(), m_vars.size() * sizeof(VecVar));
+    m_dev.ops = static_cast<const VecOp*>(m_d_ops);
+    m_dev.vars = static_cast<const VecVar*>(m_d_vars);
+}
+
+VecProgram::~VecProgram() {
+    m_be->free(m_dev.arena);
+    m_be->free(m_d_ops);
+    m_be->free(m_d_vars);
+}
+
+void VecProgram::download_var(int graph_var, int order, double* dst) const {
+    sanm_check(graph_var >= 0 && graph_var < (int)m_var_map.size() && m_var_map[graph_var] >= 0,
+               "var %d is not part of the compiled program", graph_var);
+    const VecVar& v = m_vars[m_var_map[graph_var]];
+    const int64_t B = m_dev.B;
+    if (order < 0) {
+        sanm_check(v.bias >= 0, "var %d has no bias (constant)", graph_var);
+        m_be->d2h(dst, m_dev.arena + v.bias, B * v.size * 8);
+        return;
+    }
+    sanm_check(order <= m_dev.max_order, "order %d out of range", order);
+    if (v.is_const) {
+        if (order > 0) {
+            std::fill(dst, dst + B * v.size, 0.0);
+            return;
+        }
+        if (v.const_batch == 1) {
+            std::vector<double> row(v.size);
+            m_be->d2h(row.data(), m_dev.arena + v.coef, v.size * 8);
+            for (int64_t b = 0; b < B; ++b) std::copy(row.begin(), row.end(), dst + b * v.size);
+            return;
+        }
+    }
+    m_be->d2h(dst, m_dev.arena + v.coef + (int64_t)order * B * v.size, B * v.size * 8);
+}
+
+void VecProgram::download_jacobian(double* dst) const {
+    m_be->d2h(dst, m_dev.arena + m_dev.jac, m_dev.B * m_dev.odim * m_dev.idim * 8);
+}
+
+void VecProgram::take_flags(double fl[2]) {
+    m_be->d2h(fl, m_dev.arena + m_dev.flag, 16);
+    if (fl[0] != 0 || fl[1] != 0) {
+        const double zero[2] = {0, 0};
+        m_be->h2d(m_dev.arena + m_dev.flag, zero, 16);
+    }
+}
+
+}  // namespace sanm_hip

@@ -21,6 +21,7 @@
 #include "backend.h"
 #include "graph.h"
 #include "row_ops.h"
+#include "vecprog.h"
 #include "tet_ops.h"
 
 namespace sanm_hip {
@@ -100,6 +101,26 @@ class HostSimBackend final : public Backend {
 
 public:
     const char* name() const override { return "hostsim"; }
+    // vector graphs (vecprog.h): the device kernel's schedule as loops -- every "thread" e runs an operator before
+    // the next operator starts
+    void run_vec_pass(const VecProgDev& P, int mode, int order, const double* xin) override {
+        std::vector<double> g(P.grad_total);
+        for (int64_t b = 0; b < P.B; ++b) {
+            if (mode == PASS_GRAD) {
+                for (int r = 0; r < P.odim; ++r) {
+                    std::fill(g.begin(), g.end(), 0.0);
+                    g[P.vars[P.out_var].grad + r] = 1.0;
+                    for (int i = P.nops - 1; i >= 0; --i)
+                        for (int e = 0; e < VEC_MAX_SIZE; ++e) vec_backward(P, P.ops[i], b, e, g.data());
+                    for (int e = 0; e < P.idim; ++e)
+                        P.arena[P.jac + (b * P.odim + r) * P.idim + e] = g[P.vars[P.in_var].grad + e];
+                }
+                continue;
+            }
+            for (int i = 0; i < P.nops; ++i)
+                for (int e = 0; e < VEC_MAX_SIZE; ++e) vec_forward(P, P.ops[i], mode, order, b, e, xin);
+        }
+    }
     LinearSolver* make_external_solver(const JacobianPattern& pat, const HyperParam&) override {
         return hostsim_make_pardiso(pat, m_pool.size());
     }

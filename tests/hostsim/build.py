@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.abspath(os.path.join(HERE, "..", "..", "sanm_amd", "csrc"))
 OUT = os.path.join(HERE, "libsanm_hostsim.so")
-SOURCES = ["graph.cpp", "sparse.cpp", "backend_common.cpp", "poly.cpp", "anm.cpp", "multifrontal.cpp", "fea.cpp", "capi.cpp"]
+SOURCES = ["graph.cpp", "vecprog.cpp", "sparse.cpp", "backend_common.cpp", "poly.cpp", "anm.cpp", "multifrontal.cpp", "fea.cpp", "capi.cpp"]
 
 
 def build(force=False):
