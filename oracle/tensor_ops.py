@@ -264,8 +264,11 @@ def compute_polymat_det_coeff(coeffs, order):
     libsanm/tensor_polymat.cpp:344-379; dims <= 4 use the expansion
     (:201-264, :325-341): each Leibniz term is a product of m scalar
     polynomials, built by truncated Cauchy products (``conv`` :159-168) and a
-    final single-coefficient product (``conv_k`` :170-184).  The FFT path for
-    dim > 4 (:30-136) is outside the hot path (no FEA graph reaches it).
+    final single-coefficient product (``conv_k`` :170-184).  dim > 4: the
+    polynomial matrix is evaluated at P = next_pow2(nr_term) roots of unity
+    (``fft`` :30-89, here the DFT sum itself), a complex determinant is taken
+    at each, and the inverse transform's ``order``-th output is the
+    coefficient (:100-136, with its "IDFT not real" assertion).
     ``coeffs``: list of (T,m,m).  Returns (T,1).
     """
     T, m, _ = coeffs[0].shape
@@ -279,7 +282,19 @@ def compute_polymat_det_coeff(coeffs, order):
             return np.zeros((T, 1))
         return (batched_cofactor(coeffs[0]) * coeffs[1]).reshape(T, -1).sum(axis=1)[:, None]
     if m > 4:
-        raise NotImplementedError("FFT determinant path (dim>4) is outside the hot path")
+        P = 1
+        while P < nr_term:
+            P <<= 1
+        c = np.stack(coeffs, axis=0)  # (nc, T, m, m)
+        accum = np.zeros(T, dtype=complex)
+        for i in range(P):
+            w = np.exp(2j * np.pi * i * np.arange(len(coeffs)) / P)      # omega_P^(i q), q = 0..nc-1
+            val = np.tensordot(w, c, axes=(0, 0))                        # (T, m, m) complex
+            ang = -(2 * np.pi) * float(i * order) / P
+            accum += np.linalg.det(val) * complex(np.cos(ang), np.sin(ang))
+        accum /= P
+        assert np.all(np.abs(accum.imag) < 1e-4 * np.maximum(1.0, np.abs(accum.real))), "IDFT not real"
+        return np.ascontiguousarray(accum.real)[:, None]
     nc = len(coeffs)
     c = np.stack(coeffs, axis=0)  # (nc, T, m, m)
     ret = np.zeros(T)

@@ -67,7 +67,7 @@ ENERGY = {"neohookean_i": 0, "neohookean_c": 1, "arap": 2, "stvk_stretch": 3}
 SYMBOLS = [
     "sanm_hip_init", "sanm_hip_last_error", "sanm_hip_backend_name",
     "sanm_hip_comm_available", "sanm_hip_comm_unique_id", "sanm_hip_comm_init", "sanm_hip_comm_destroy",
-    "sanm_graph_create", "sanm_graph_destroy", "sanm_graph_placeholder", "sanm_graph_constant", "sanm_graph_placeholder_vector", "sanm_graph_slice", "sanm_graph_concat",
+    "sanm_graph_create", "sanm_graph_destroy", "sanm_graph_placeholder", "sanm_graph_constant", "sanm_graph_placeholder_vector", "sanm_graph_placeholder_matrix", "sanm_graph_constant_matrix", "sanm_graph_slice", "sanm_graph_concat",
     "sanm_graph_linear_combine", "sanm_graph_multiply", "sanm_graph_pow", "sanm_graph_log",
     "sanm_graph_reduce_sum", "sanm_graph_batched_matmul", "sanm_graph_batched_mat_inv_mul",
     "sanm_graph_batched_det", "sanm_graph_batched_transpose", "sanm_graph_batched_mul_eye",
@@ -333,11 +333,26 @@ class ComputingGraph:
         v.vec_size = int(size)
         return v
 
+    def placeholder_matrix(self, rows, cols):
+        """a (batch, rows, cols) matrix input (sanm_graph_placeholder_matrix): sizes other than 3 x 3 run on the
+        vector interpreter"""
+        out = C.c_int()
+        self.api.check(self.api.lib.sanm_graph_placeholder_matrix(self.h, C.c_int(int(rows)), C.c_int(int(cols)),
+                                                                  C.byref(out)))
+        v = SymbolVar(self, out.value)
+        if (int(rows), int(cols)) != (3, 3):
+            v.vec_size = int(rows) * int(cols)
+        return v
+
     def constant(self, val):
         val = _f64(val)
         batch = val.shape[0]
-        size = int(np.prod(val.shape[1:]))
         out = C.c_int()
+        if val.ndim == 3 and val.shape[1:] != (3, 3):
+            self.api.check(self.api.lib.sanm_graph_constant_matrix(
+                self.h, _dp(val), C.c_int64(batch), C.c_int(val.shape[1]), C.c_int(val.shape[2]), C.byref(out)))
+            return SymbolVar(self, out.value)
+        size = int(np.prod(val.shape[1:]))
         self.api.check(self.api.lib.sanm_graph_constant(self.h, _dp(val), C.c_int64(batch),
                                                         C.c_int(size), C.byref(out)))
         return SymbolVar(self, out.value)

@@ -130,6 +130,12 @@ int sanm_graph_placeholder(sanm_graph* g, int* var) {
 int sanm_graph_placeholder_vector(sanm_graph* g, int size, int* var) {
     return guard([&] { *var = g->g.placeholder_vector(size); });
 }
+int sanm_graph_placeholder_matrix(sanm_graph* g, int rows, int cols, int* var) {
+    return guard([&] { *var = g->g.placeholder_matrix(rows, cols); });
+}
+int sanm_graph_constant_matrix(sanm_graph* g, const double* val, int64_t batch, int rows, int cols, int* var) {
+    return guard([&] { *var = g->g.constant_matrix(val, batch, rows, cols); });
+}
 int sanm_graph_slice(sanm_graph* g, int x, int axis, int has_begin, int begin, int has_end, int end, int stride,
                      int* var) {
     return guard([&] { *var = g->g.slice(x, axis, has_begin, begin, has_end, end, stride); });

@@ -25,12 +25,15 @@ void Graph::chk(int v) const {
     sanm_check(v >= 0 && v < (int)vars.size(), "invalid var id %d", v);
 }
 
-int Graph::add(GraphOp op, std::initializer_list<int> out_sizes) {
+int Graph::add(GraphOp op, std::initializer_list<Shape> out_shapes) {
     int oi = ops.size();
     int k = 0;
-    for (int sz : out_sizes) {
+    for (Shape sh : out_shapes) {
         op.out.push_back(vars.size());
-        vars.push_back({sz, oi, k++});
+        GraphVar v{sh.rows * std::max(sh.cols, 1), oi, k++};
+        v.rows = sh.rows;
+        v.cols = sh.cols;
+        vars.push_back(v);
     }
     int first = op.out[0];
     ops.push_back(std::move(op));
@@ -40,7 +43,7 @@ int Graph::add(GraphOp op, std::initializer_list<int> out_sizes) {
 int Graph::placeholder() {
     GraphOp op;
     op.type = OP_PLACEHOLDER;
-    return add(std::move(op), {9});
+    return add(std::move(op), {{3, 3}});
 }
 
 int Graph::placeholder_vector(int size) {
@@ -48,7 +51,15 @@ int Graph::placeholder_vector(int size) {
     GraphOp op;
     op.type = OP_PLACEHOLDER;
     op.flags = OP_FLAG_VECTOR;
-    return add(std::move(op), {size});
+    return add(std::move(op), {{size, 0}});
+}
+
+int Graph::placeholder_matrix(int rows, int cols) {
+    sanm_check(rows >= 1 && cols >= 1, "placeholder: bad shape (%d, %d)", rows, cols);
+    GraphOp op;
+    op.type = OP_PLACEHOLDER;
+    if (rows != 3 || cols != 3) op.flags = OP_FLAG_VECTOR;
+    return add(std::move(op), {{rows, cols}});
 }
 
 int Graph::slice(int x, int axis, int has_begin, int begin, int has_end, int end, int stride) {
@@ -57,6 +68,9 @@ int Graph::slice(int x, int axis, int has_begin, int begin, int has_end, int end
     sanm_check(axis >= 0 && stride != 0, "slice: bad axis / stride");
     if (axis != 1 || stride != 1)
         sanm_throw(SANM_ERR_UNSUPPORTED, "slice: axis %d stride %d unimplemented (as in the reference)", axis, stride);
+    if (vars[x].is_matrix())
+        sanm_throw(SANM_ERR_UNSUPPORTED, "slice of a (batch, %d, %d) matrix: (batch, n) operands only", vars[x].rows,
+                   vars[x].cols);
     const int size = vars[x].size;
     int b = has_begin ? begin : 0, e = has_end ? end : size;
     if (has_begin && b < 0) b += size;
@@ -66,7 +80,7 @@ int Graph::slice(int x, int axis, int has_begin, int begin, int has_end, int end
     op.type = OP_SLICE;
     op.in = {x};
     op.begin = b;
-    return add(std::move(op), {e - b});
+    return add(std::move(op), {{e - b, 0}});
 }
 
 int Graph::concat(int n, const int* vs, int axis) {
@@ -77,10 +91,12 @@ int Graph::concat(int n, const int* vs, int axis) {
     int total = 0;
     for (int i = 0; i < n; ++i) {
         chk(vs[i]);
+        if (vars[vs[i]].is_matrix())
+            sanm_throw(SANM_ERR_UNSUPPORTED, "concat of (batch, rows, cols) matrices: (batch, n) operands only");
         op.in.push_back(vs[i]);
         total += vars[vs[i]].size;
     }
-    return add(std::move(op), {total});
+    return add(std::move(op), {{total, 0}});
 }
 
 int Graph::constant(const double* val, int64_t batch, int size) {
@@ -89,7 +105,30 @@ int Graph::constant(const double* val, int64_t batch, int size) {
     op.type = OP_CONSTANT;
     op.batch = batch;
     op.value.assign(val, val + batch * size);
-    return add(std::move(op), {size});
+    // (nine values: the (T,3,3) constants of the FEA graphs)
+    return add(std::move(op), {size == 9 ? Shape{3, 3} : Shape{size, 0}});
+}
+
+int Graph::constant_matrix(const double* val, int64_t batch, int rows, int cols) {
+    sanm_check(rows >= 1 && cols >= 1, "constant: bad shape (%d, %d)", rows, cols);
+    GraphOp op;
+    op.type = OP_CONSTANT;
+    op.batch = batch;
+    op.value.assign(val, val + batch * rows * cols);
+    return add(std::move(op), {{rows, cols}});
+}
+
+Graph::Shape Graph::elemwise_shape(Shape a, Shape b) const {
+    // only batched scalars broadcast (oprs/elem_arith.cpp:13-38)
+    const int sa = a.rows * std::max(a.cols, 1), sb = b.rows * std::max(b.cols, 1);
+    sanm_check(sa == sb || sa == 1 || sb == 1, "invalid shape in elem arith: %d vs %d", sa, sb);
+    if (sa == 1 && sb != 1) return b;
+    if (sb == 1 && sa != 1) return a;
+    // same element count: two matrices must agree in shape; a matrix and a flat operand keep the matrix's
+    if (a.cols > 0 && b.cols > 0)
+        sanm_check(a.rows == b.rows && a.cols == b.cols, "invalid shape in elem arith: (%d, %d) vs (%d, %d)", a.rows,
+                   a.cols, b.rows, b.cols);
+    return a.cols > 0 ? a : b;
 }
 
 int Graph::linear_combine(int n, const double* coeffs, const int* vs, double bias) {
@@ -98,29 +137,24 @@ int Graph::linear_combine(int n, const double* coeffs, const int* vs, double bia
     GraphOp op;
     op.type = OP_LINCOMB;
     op.bias = bias;
-    int osz = 1;
+    Shape osh{1, 0};
     for (int i = 0; i < n; ++i) {
         chk(vs[i]);
         op.in.push_back(vs[i]);
         op.coeffs.push_back(coeffs[i]);
-        int sz = vars[vs[i]].size;
-        // only batched scalars broadcast (oprs/elem_arith.cpp:13-38)
-        sanm_check(sz == osz || sz == 1 || osz == 1, "invalid shape in elem arith: %d vs %d", osz,
-                   sz);
-        osz = std::max(osz, sz);
+        osh = i == 0 ? shape(vs[i]) : elemwise_shape(osh, shape(vs[i]));
     }
-    return add(std::move(op), {osz});
+    return add(std::move(op), {osh});
 }
 
 int Graph::multiply(int a, int b) {
     chk(a);
     chk(b);
-    int sa = vars[a].size, sb = vars[b].size;
-    sanm_check(sa == sb || sa == 1 || sb == 1, "invalid shape in elem arith: %d vs %d", sa, sb);
+    const Shape osh = elemwise_shape(shape(a), shape(b));
     GraphOp op;
     op.type = OP_MULTIPLY;
     op.in = {a, b};
-    return add(std::move(op), {std::max(sa, sb)});
+    return add(std::move(op), {osh});
 }
 
 int Graph::pow(int x, double e) {
@@ -131,7 +165,7 @@ int Graph::pow(int x, double e) {
     op.type = OP_POW;
     op.exponent = e;
     op.in = {x};
-    return add(std::move(op), {vars[x].size});
+    return add(std::move(op), {shape(x)});
 }
 
 int Graph::log(int x) {
@@ -139,82 +173,92 @@ int Graph::log(int x) {
     GraphOp op;
     op.type = OP_LOG;
     op.in = {x};
-    return add(std::move(op), {vars[x].size});
+    return add(std::move(op), {shape(x)});
 }
 
 int Graph::reduce_sum(int x, int axis) {
     chk(x);
     sanm_check(axis != 0, "can not reduce on batch dim");
-    if (axis != -1) sanm_throw(SANM_ERR_UNSUPPORTED, "reduce_sum: only axis=-1 is on the hot path");
+    // reduce.cpp:11-102: axis -1 flattens everything behind the batch axis; axis 1 of a (batch, n) tensor is the
+    // same sum.  One axis of a (batch, rows, cols) matrix is not implemented.
+    if (!(axis == -1 || (axis == 1 && !vars[x].is_matrix())))
+        sanm_throw(SANM_ERR_UNSUPPORTED, "reduce_sum: axis %d of a (batch, %d, %d) tensor (axis -1, or axis 1 of a "
+                                         "(batch, n) tensor)", axis, vars[x].rows, vars[x].cols);
     GraphOp op;
     op.type = OP_REDUCE_SUM;
     op.in = {x};
-    return add(std::move(op), {1});
+    return add(std::move(op), {{1, 0}});
 }
 
 int Graph::batched_matmul(int a, int b) {
     chk(a);
     chk(b);
-    sanm_check(vars[a].size == 9 && vars[b].size == 9, "invalid operand shapes for matmul");
+    sanm_check(vars[a].is_matrix() && vars[b].is_matrix() && vars[a].cols == vars[b].rows,
+               "invalid operand shapes for matmul: (%d, %d) x (%d, %d)", vars[a].rows, vars[a].cols, vars[b].rows,
+               vars[b].cols);
     GraphOp op;
     op.type = OP_MATMUL;
     op.in = {a, b};
-    return add(std::move(op), {9});
+    return add(std::move(op), {{vars[a].rows, vars[b].cols}});
 }
 
 int Graph::batched_mat_inv_mul(int x, int a, bool is_left) {
     chk(x);
-    sanm_check(vars[x].size == 9, "invalid shape for matinv");
+    sanm_check(vars[x].is_matrix() && vars[x].rows == vars[x].cols, "invalid shape for matinv: (%d, %d)", vars[x].rows,
+               vars[x].cols);
     GraphOp op;
     op.type = OP_MATINVMUL;
     op.flags = is_left ? OP_FLAG_IS_LEFT : 0;
     op.in = {x};
     if (a >= 0) {
         chk(a);
-        sanm_check(vars[a].size == 9, "invalid shape for matinv");
+        sanm_check(vars[a].rows == vars[x].rows && vars[a].cols == vars[x].cols, "invalid shape for matinv");
         op.in.push_back(a);
     } else {
         op.flags |= OP_FLAG_USE_IDENTITY;
     }
-    return add(std::move(op), {9});
+    return add(std::move(op), {shape(x)});
 }
 
 int Graph::batched_det(int x) {
     chk(x);
-    sanm_check(vars[x].size == 9, "invalid shape for determinant");
+    // (tensor_polymat.cpp:354: dim >= 2)
+    sanm_check(vars[x].is_matrix() && vars[x].rows == vars[x].cols && vars[x].rows >= 2,
+               "invalid shape for determinant: (%d, %d)", vars[x].rows, vars[x].cols);
     GraphOp op;
     op.type = OP_DET;
     op.in = {x};
-    return add(std::move(op), {1});
+    return add(std::move(op), {{1, 0}});
 }
 
 int Graph::batched_transpose(int x) {
     chk(x);
-    sanm_check(vars[x].size == 9, "invalid shape for transpose");
+    sanm_check(vars[x].is_matrix(), "invalid shape for transpose");
     GraphOp op;
     op.type = OP_TRANSPOSE;
     op.in = {x};
-    return add(std::move(op), {9});
+    return add(std::move(op), {{vars[x].cols, vars[x].rows}});
 }
 
 int Graph::batched_mul_eye(int x, int dim) {
     chk(x);
     sanm_check(vars[x].size == 1, "the input shape must be a scalar");
-    sanm_check(dim == 3, "only dim=3 is supported");
+    sanm_check(dim >= 1, "bad dim %d", dim);
     GraphOp op;
     op.type = OP_MULEYE;
     op.in = {x};
-    return add(std::move(op), {9});
+    return add(std::move(op), {{dim, dim}});
 }
 
 void Graph::batched_svd_w(int x, bool require_rotation, int out[3]) {
     chk(x);
-    sanm_check(vars[x].size == 9, "invalid shape for SVD-W");
+    if (!(vars[x].rows == 3 && vars[x].cols == 3))
+        sanm_throw(SANM_ERR_UNSUPPORTED, "SVD-W of a (%d, %d) matrix: 3 x 3 only", vars[x].rows, vars[x].cols);
     GraphOp op;
     op.type = OP_SVDW;
     op.flags = require_rotation ? OP_FLAG_REQUIRE_ROT : 0;
     op.in = {x};
-    int first = add(std::move(op), {9, 3, 9});
+    int first = add(std::move(op), {{3, 3}, {3, 0}, {3, 3}});
     out[0] = first;
     out[1] = first + 1;
     out[2] = first + 2;

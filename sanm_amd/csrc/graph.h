@@ -35,9 +35,11 @@ constexpr int SANM_ERR_UNSUPPORTED = 4;
     } while (0)
 
 struct GraphVar {
-    int size;      // per-tet element count: 1, 3 or 9
+    int size;      // element count per batch item: 1, 3 or 9 on the per-tet path; anything up to 64 on the vector path
     int producer;  // index into Graph::ops
     int out_idx;
+    int rows = 0, cols = 0;  // (batch, rows, cols); cols = 0: a (batch, rows) tensor (batched vector / scalar)
+    bool is_matrix() const { return cols > 0; }
 };
 
 struct GraphOp {
@@ -60,7 +62,11 @@ public:
     int placeholder();
     //! a (batch, size) vector input: graphs over it run on the vector interpreter (vecprog.h)
     int placeholder_vector(int size);
+    //! a (batch, rows, cols) matrix input; sizes other than 3 x 3 run on the vector interpreter too
+    int placeholder_matrix(int rows, int cols);
     int constant(const double* val, int64_t batch, int size);
+    //! constant of shape (batch, rows, cols)
+    int constant_matrix(const double* val, int64_t batch, int rows, int cols);
     //! x[:, begin:end] (SymbolVar::slice, oprs.h:60; misc.cpp:104-231): axis 1, stride 1 like the reference's
     //! implementation; has_begin / has_end = 0 stand for None
     int slice(int x, int axis, int has_begin, int begin, int has_end, int end, int stride);
@@ -79,7 +85,12 @@ public:
     void batched_svd_w(int x, bool require_rotation, int out[3]);
 
 private:
-    int add(GraphOp op, std::initializer_list<int> out_sizes);
+    struct Shape {
+        int rows, cols;
+    };
+    int add(GraphOp op, std::initializer_list<Shape> out_shapes);
+    Shape shape(int v) const { return {vars[v].rows, vars[v].cols}; }
+    Shape elemwise_shape(Shape a, Shape b) const;
     void chk(int v) const;
 };
 

@@ -29,9 +29,12 @@ bool graph_is_vector(const Graph& g, int out_var) {
         const GraphOp& op = g.ops[oi];
         if (op.type == OP_SLICE || op.type == OP_CONCAT) return true;
         if (op.type == OP_PLACEHOLDER && (op.flags & OP_FLAG_VECTOR)) return true;
+        // the per-tet programs carry (T,3,3) matrices, batched scalars and the (T,3) singular values of SVD-W
         for (int v : op.out) {
-            const int s = g.vars[v].size;
-            if (s != 1 && s != 3 && s != 9) return true;
+            const GraphVar& gv = g.vars[v];
+            const bool tet_shape = (gv.rows == 3 && gv.cols == 3) || (gv.rows == 1 && gv.cols == 0) ||
+                                   (gv.rows == 3 && gv.cols == 0);
+            if (!tet_shape) return true;
         }
     }
     return false;
@@ -61,11 +64,12 @@ VecProgram::VecProgram(Backend* be, const Graph& g, int out_var, int64_t B, int 
         sanm_check(o.nin <= VEC_MAX_IN, "vector graphs: at most %d inputs per operator", VEC_MAX_IN);
         switch (op.type) {
             case OP_PLACEHOLDER: case OP_CONSTANT: case OP_LINCOMB: case OP_MULTIPLY: case OP_LOG: case OP_POW:
-            case OP_REDUCE_SUM: case OP_SLICE: case OP_CONCAT: break;
+            case OP_REDUCE_SUM: case OP_SLICE: case OP_CONCAT: case OP_MATMUL: case OP_MATINVMUL: case OP_DET:
+            case OP_TRANSPOSE: case OP_MULEYE: break;
             default:
                 sanm_throw(SANM_ERR_UNSUPPORTED,
-                           "operator %d on vectors: the batched 3x3 linear-algebra operators need (T,3,3) operands",
-                           (int)op.type);
+                           "operator %d in a graph on the vector interpreter (SVD-W runs in graphs of (T,3,3) "
+                           "matrices and batched scalars only)", (int)op.type);
         }
         bool all_const = op.type != OP_PLACEHOLDER;
         for (int i = 0; i < o.nin; ++i) {
@@ -78,6 +82,8 @@ VecProgram::VecProgram(Backend* be, const Graph& g, int out_var, int64_t B, int 
         sanm_check(sz >= 1 && sz <= VEC_MAX_SIZE, "vector of %d elements: at most %d", sz, VEC_MAX_SIZE);
         VecVar v{};
         v.size = sz;
+        v.rows = g.vars[gv].rows;
+        v.cols = g.vars[gv].cols;
         v.is_const = all_const ? 1 : 0;
         v.const_batch = 0;
         if (op.type == OP_CONSTANT) {
@@ -110,6 +116,33 @@ VecProgram::VecProgram(Backend* be, const Graph& g, int out_var, int64_t B, int 
             o.aux1 = take(B * sz);
         } else if (op.type == OP_SLICE) {
             o.begin = op.begin;
+        } else if (op.type == OP_MATMUL) {
+            o.aux1 = take(B * sz);
+        } else if (op.type == OP_MATINVMUL) {
+            // three records: X0^-1 (order 0), the inner product, the outer product
+            const int m = v.rows;
+            sanm_check(m <= VEC_MAX_DIM, "mat_inv_mul of a %d x %d matrix: at most %d", m, m, VEC_MAX_DIM);
+            o.aux0 = take(B * sz);
+            o.aux1 = take(B * sz);
+            o.aux2 = take(B * sz);
+            VecOp prep = o;
+            prep.type = VOP_INV_PREP;
+            prep.nact = 1;
+            ops.push_back(prep);
+            ops.push_back(o);
+            o.type = VOP_MATINV_FIN;
+        } else if (op.type == OP_DET) {
+            const int m = m_vars[o.in[0]].rows;
+            sanm_check(m <= VEC_MAX_DIM, "determinant of a %d x %d matrix: at most %d", m, m, VEC_MAX_DIM);
+            sanm_check(max_order <= VEC_MAX_ORDER, "graphs with a determinant on the vector interpreter: order <= %d",
+                       VEC_MAX_ORDER);
+            o.aux0 = take(B * m * m);
+            o.aux1 = take(B);
+            o.aux2 = take(B * VEC_MAX_SIZE);
+            o.nact = VEC_MAX_SIZE;
+            ops.push_back(o);
+            o.type = VOP_DET_FIN;
+            o.nact = 1;
         }
         ops.push_back(o);
     }

@@ -9,6 +9,14 @@
 // COEFF(k): TaylorCoeffProp::push_xi / ensure_jacobian / compute_next_order_bias, symbolic.cpp:162-289), same
 // operator recurrences (elem_arith.cpp:42-217, analytic_unary.cpp:13-139, reduce.cpp:11-102).
 //
+// Matrices of any size up to 8 x 8 (the reference's tests run its linear-algebra operators at 4 x 4, 4 x 6, 5 x 5, 7 x 7:
+// tests/symbolic.cpp:179-360, :389-424, :640-656) are vectors of rows * cols elements here with their shape kept in
+// VecVar: batched_matmul / transpose / mat_inv_mul / det / mul_eye (oprs/linalg.cpp:67-479) at run-time sizes, the
+// determinant's self-bias by the expansion for dim <= 4 and by the DFT of the polynomial matrix above
+// (tensor_polymat.cpp:30-136, :325-379).  An operator whose recurrence needs a workgroup-wide intermediate
+// (X0^-1, the inner product of mat_inv_mul, the partial sums of the determinant) is compiled into two or three
+// records, which puts the interpreter's barrier between its phases.
+//
 // The operator bodies are shared between the HIP kernel (backend_hip.hip: vec_pass_kernel) and the test-only host
 // harness (tests/hostsim/backend_host.cpp), which runs them in a loop over the elements.
 #pragma once
@@ -28,6 +36,13 @@ namespace sanm_hip {
 
 constexpr int VEC_MAX_SIZE = 64;   // longest vector (threads of the workgroup)
 constexpr int VEC_MAX_IN = 8;      // inputs of a concat / linear combination
+constexpr int VEC_MAX_DIM = 8;     // largest matrix: 8 x 8
+constexpr int VEC_MAX_ORDER = 32;  // highest expansion order of a graph with a determinant (per-thread series buffers)
+
+// records the compiler adds around the reference's operators (not part of the C ABI's operator numbering)
+constexpr int VOP_INV_PREP = 32;    // X0^-1 of the mat_inv_mul that follows, order 0 only (thread 0)
+constexpr int VOP_MATINV_FIN = 33;  // second product of mat_inv_mul's recurrence
+constexpr int VOP_DET_FIN = 34;     // determinant: partial sums -> self-bias; cof(X0) : X_k + self-bias
 
 struct VecVar {
     int64_t coef;   // arena offset of coefficient 0 of batch 0; order k, batch b at coef + (k * B + b) * size
@@ -36,15 +51,21 @@ struct VecVar {
     int32_t is_const;  // orders >= 1 are zero
     int32_t grad;      // offset of the variable's gradient row in the workgroup's scratch (GRAD pass)
     int32_t const_batch;  // CONSTANT: 1 = one row broadcast over the batch
+    int32_t rows, cols;   // (batch, rows, cols) tensors; cols = 0: a (batch, rows) vector
 };
 
 struct VecOp {
-    int32_t type, nin, flags, pad;
+    int32_t type, nin, flags;
+    int32_t nact;             // threads that take part in the forward passes (0: as many as the output has elements)
     int32_t in[VEC_MAX_IN];
     int32_t out;
     int32_t begin;            // SLICE: first element taken; CONCAT: unused
     double p[VEC_MAX_IN + 1]; // LINCOMB: coefficients, bias at p[VEC_MAX_IN]; POW: p[0] = exponent
     int64_t aux0, aux1;       // POW / LOG: K = f'(x0) [B][size], self-bias [B][size]; MULTIPLY: self-bias at aux1
+    // MATMUL: self-bias at aux1.  MATINVMUL (+ its PREP / FIN): X0^-1 at aux0, self-bias at aux1, the inner
+    // product at aux2 (all [B][m*m]).  DET (+ FIN): cof(X0) at aux0 [B][m*m], self-bias at aux1 [B], the threads'
+    // partial sums at aux2 [B][VEC_MAX_SIZE]
+    int64_t aux2;
 };
 
 struct VecProgDev {
@@ -84,12 +105,210 @@ VEC_HD void vec_store(const VecProgDev& P, int v, int k, bool in_coeff, int64_t 
     else P.arena[d.bias + b * d.size + e] = val;
 }
 
+// ---- small dense helpers of the matrix operators (run-time sizes, per-thread local arrays) ----------------------
+// determinant of the n x n row-major matrix a (destroyed): LU with partial pivoting
+VEC_HD double vec_lu_det(double* a, int n) {
+    double det = 1.0;
+    for (int c = 0; c < n; ++c) {
+        int p = c;
+        double best = fabs(a[c * n + c]);
+        for (int r = c + 1; r < n; ++r) {
+            const double v = fabs(a[r * n + c]);
+            if (v > best) {
+                best = v;
+                p = r;
+            }
+        }
+        if (best == 0.0) return 0.0;
+        if (p != c) {
+            for (int j = 0; j < n; ++j) {
+                const double t = a[c * n + j];
+                a[c * n + j] = a[p * n + j];
+                a[p * n + j] = t;
+            }
+            det = -det;
+        }
+        const double piv = a[c * n + c];
+        det *= piv;
+        for (int r = c + 1; r < n; ++r) {
+            const double f = a[r * n + c] / piv;
+            for (int j = c + 1; j < n; ++j) a[r * n + j] = __builtin_fma(-f, a[c * n + j], a[r * n + j]);
+        }
+    }
+    return det;
+}
+// the same for a complex matrix (re, im), the determinant in (dr, di)
+VEC_HD void vec_lu_det_complex(double* re, double* im, int n, double& dr, double& di) {
+    dr = 1.0;
+    di = 0.0;
+    for (int c = 0; c < n; ++c) {
+        int p = c;
+        double best = re[c * n + c] * re[c * n + c] + im[c * n + c] * im[c * n + c];
+        for (int r = c + 1; r < n; ++r) {
+            const double v = re[r * n + c] * re[r * n + c] + im[r * n + c] * im[r * n + c];
+            if (v > best) {
+                best = v;
+                p = r;
+            }
+        }
+        if (best == 0.0) {
+            dr = di = 0.0;
+            return;
+        }
+        if (p != c) {
+            for (int j = 0; j < n; ++j) {
+                double t = re[c * n + j];
+                re[c * n + j] = re[p * n + j];
+                re[p * n + j] = t;
+                t = im[c * n + j];
+                im[c * n + j] = im[p * n + j];
+                im[p * n + j] = t;
+            }
+            dr = -dr;
+            di = -di;
+        }
+        const double pr = re[c * n + c], pi = im[c * n + c];
+        const double ndr = dr * pr - di * pi;
+        di = dr * pi + di * pr;
+        dr = ndr;
+        for (int r = c + 1; r < n; ++r) {
+            // f = a[r][c] / pivot
+            const double ar = re[r * n + c], ai = im[r * n + c];
+            const double fr = (ar * pr + ai * pi) / best, fi = (ai * pr - ar * pi) / best;
+            for (int j = c + 1; j < n; ++j) {
+                const double br = re[c * n + j], bi = im[c * n + j];
+                re[r * n + j] -= fr * br - fi * bi;
+                im[r * n + j] -= fr * bi + fi * br;
+            }
+        }
+    }
+}
+// inverse of the n x n matrix a into inv (Gauss-Jordan with partial pivoting; a is destroyed).  A singular matrix
+// leaves non-finite entries, as Eigen's inverse() does for the reference (tensor_linalg.cpp:285-317).
+VEC_HD void vec_inverse(double* a, double* inv, int n) {
+    for (int i = 0; i < n * n; ++i) inv[i] = 0.0;
+    for (int i = 0; i < n; ++i) inv[i * n + i] = 1.0;
+    for (int c = 0; c < n; ++c) {
+        int p = c;
+        double best = fabs(a[c * n + c]);
+        for (int r = c + 1; r < n; ++r) {
+            const double v = fabs(a[r * n + c]);
+            if (v > best) {
+                best = v;
+                p = r;
+            }
+        }
+        if (p != c) {
+            for (int j = 0; j < n; ++j) {
+                double t = a[c * n + j];
+                a[c * n + j] = a[p * n + j];
+                a[p * n + j] = t;
+                t = inv[c * n + j];
+                inv[c * n + j] = inv[p * n + j];
+                inv[p * n + j] = t;
+            }
+        }
+        const double piv = a[c * n + c];
+        for (int j = 0; j < n; ++j) {
+            a[c * n + j] /= piv;
+            inv[c * n + j] /= piv;
+        }
+        for (int r = 0; r < n; ++r) {
+            if (r == c) continue;
+            const double f = a[r * n + c];
+            if (f == 0.0) continue;
+            for (int j = 0; j < n; ++j) {
+                a[r * n + j] = __builtin_fma(-f, a[c * n + j], a[r * n + j]);
+                inv[r * n + j] = __builtin_fma(-f, inv[c * n + j], inv[r * n + j]);
+            }
+        }
+    }
+}
+
+// Thread e's share of the determinant's self-bias at order k: the coefficient of a^k in det(sum_{i<k} X_i a^i)
+// (compute_polymat_det_coeff, tensor_polymat.cpp:344-379, called with the k known coefficients by
+// BatchDeterminantOprMeta::compute_order_bias, oprs/linalg.cpp:248-262).  dim <= 4: the Leibniz expansion
+// (:201-264, :325-341), one permutation per thread, truncated Cauchy products along the rows; dim > 4: the DFT of
+// the polynomial matrix at P = 2^ceil(log2((k-1) dim + 1)) roots of unity, a complex determinant at each, the
+// inverse transform's k-th output (:30-136), the points dealt to the threads.  The shares are summed by VOP_DET_FIN.
+VEC_HD double vec_det_selfbias_part(const VecProgDev& P, int x, int k, int64_t b, int e, int m) {
+    if (k < 2) return 0.0;  // order >= nr_term = (k-1) dim + 1: identically zero
+    const int nc = k;       // known coefficients X_0 .. X_{k-1}
+    if (m <= 4) {
+        int nperm = 1;
+        for (int i = 2; i <= m; ++i) nperm *= i;
+        if (e >= nperm) return 0.0;
+        // e-th permutation (factoradic digits pick from the columns left); the digit sum's parity is the sign
+        int perm[4], avail[4] = {0, 1, 2, 3};
+        int rest = e, inv_count = 0, fact = nperm;
+        for (int i = 0; i < m; ++i) {
+            fact /= (m - i);
+            const int d = rest / fact;
+            rest -= d * fact;
+            inv_count += d;
+            perm[i] = avail[d];
+            for (int j = d; j + 1 < m - i; ++j) avail[j] = avail[j + 1];
+        }
+        const double sign = (inv_count & 1) ? -1.0 : 1.0;
+        auto X = [&](int i, int r) { return vec_coef(P, x, i, b, r * m + perm[r]); };
+        if (m == 2) {
+            double acc = 0;
+            for (int i = 1; i < nc; ++i)  // conv_k: i + j = k with both below nc
+                acc = __builtin_fma(X(i, 0), X(k - i, 1), acc);
+            return sign * acc;
+        }
+        double pa[VEC_MAX_ORDER + 1], pb[VEC_MAX_ORDER + 1];
+        for (int d = 0; d <= k; ++d) pa[d] = 0.0;
+        for (int i = 0; i < nc; ++i)
+            for (int j = 0; j < nc && i + j <= k; ++j) pa[i + j] = __builtin_fma(X(i, 0), X(j, 1), pa[i + j]);
+        double* cur = pa;
+        double* nxt = pb;
+        for (int r = 2; r + 1 < m; ++r) {
+            for (int d = 0; d <= k; ++d) nxt[d] = 0.0;
+            for (int i = 0; i <= k; ++i)
+                for (int j = 0; j < nc && i + j <= k; ++j) nxt[i + j] = __builtin_fma(cur[i], X(j, r), nxt[i + j]);
+            double* t = cur;
+            cur = nxt;
+            nxt = t;
+        }
+        double acc = 0;
+        for (int i = 1; i <= k; ++i)  // the last row's coefficient k - i must be a known one: k - i <= nc - 1
+            acc = __builtin_fma(cur[i], X(k - i, m - 1), acc);
+        return sign * acc;
+    }
+    int Pn = 1;
+    while (Pn < (k - 1) * m + 1) Pn <<= 1;
+    const double two_pi = 6.283185307179586476925286766559;
+    double acc = 0;
+    for (int j = e; j < Pn; j += VEC_MAX_SIZE) {
+        const double ang = two_pi * (double)j / (double)Pn;
+        const double wr = cos(ang), wi = sin(ang);
+        double re[VEC_MAX_DIM * VEC_MAX_DIM], im[VEC_MAX_DIM * VEC_MAX_DIM];
+        for (int q = 0; q < m * m; ++q) {  // Horner from X_{k-1}
+            re[q] = vec_coef(P, x, nc - 1, b, q);
+            im[q] = 0.0;
+        }
+        for (int i = nc - 2; i >= 0; --i) {
+            for (int q = 0; q < m * m; ++q) {
+                const double nr = re[q] * wr - im[q] * wi + vec_coef(P, x, i, b, q);
+                im[q] = re[q] * wi + im[q] * wr;
+                re[q] = nr;
+            }
+        }
+        double dr, di;
+        vec_lu_det_complex(re, im, m, dr, di);
+        const double oang = -two_pi * (double)((j * k) % Pn) / (double)Pn;
+        acc += dr * cos(oang) - di * sin(oang);
+    }
+    return acc / (double)Pn;
+}
+
 // One operator, one element (thread) e of batch item b, forward passes.  Elements beyond the output's size do
 // nothing; reductions (reduce_sum) are done by element 0.  xin: the placeholder's values of this order, [B][idim].
 VEC_HD void vec_forward(const VecProgDev& P, const VecOp& o, int mode, int k, int64_t b, int e, const double* xin) {
     const VecVar& ov = P.vars[o.out];
     const int osz = ov.size;
-    if (e >= osz) return;
+    if (e >= (o.nact > 0 ? o.nact : osz)) return;
     const bool in_coeff = mode != PASS_BIAS;
     if (mode != PASS_EVAL0 && ov.is_const) return;
     switch (o.type) {
@@ -199,6 +418,149 @@ VEC_HD void vec_forward(const VecProgDev& P, const VecOp& o, int mode, int k, in
             }
             break;
         }
+        case OP_TRANSPOSE: {  // oprs/linalg.cpp:286-335; out is (cols x rows) of the input
+            const int orows = ov.rows, ocols = ov.cols;
+            const int r = e / ocols, c = e % ocols;
+            vec_store(P, o.out, k, in_coeff, b, e, vec_cur(P, o.in[0], k, in_coeff, b, c * orows + r));
+            break;
+        }
+        case OP_MULEYE: {  // oprs/linalg.cpp:422-479
+            const int d = ov.rows;
+            vec_store(P, o.out, k, in_coeff, b, e, (e / d == e % d) ? vec_cur(P, o.in[0], k, in_coeff, b, 0) : 0.0);
+            break;
+        }
+        case OP_MATMUL: {  // oprs/linalg.cpp:339-418: Y_k = A_0 B_k + A_k B_0 + sum_{0<i<k} A_i B_{k-i}
+            const int a = o.in[0], c = o.in[1];
+            const int K = P.vars[a].cols, n = ov.cols;
+            const int r = e / n, cc = e % n;
+            if (mode == PASS_EVAL0) {
+                double s = 0;
+                for (int j = 0; j < K; ++j) s = __builtin_fma(vec_coef(P, a, 0, b, r * K + j), vec_coef(P, c, 0, b, j * n + cc), s);
+                vec_store(P, o.out, 0, true, b, e, s);
+                break;
+            }
+            double* psb = P.arena + o.aux1 + b * osz + e;
+            double sb;
+            if (!in_coeff) {
+                sb = 0;
+                for (int i = 1; i < k; ++i)
+                    for (int j = 0; j < K; ++j)
+                        sb = __builtin_fma(vec_coef(P, a, i, b, r * K + j), vec_coef(P, c, k - i, b, j * n + cc), sb);
+                *psb = sb;
+            } else {
+                sb = *psb;
+            }
+            for (int j = 0; j < K; ++j) {
+                sb = __builtin_fma(vec_cur(P, a, k, in_coeff, b, r * K + j), vec_coef(P, c, 0, b, j * n + cc), sb);
+                sb = __builtin_fma(vec_coef(P, a, 0, b, r * K + j), vec_cur(P, c, k, in_coeff, b, j * n + cc), sb);
+            }
+            vec_store(P, o.out, k, in_coeff, b, e, sb);
+            break;
+        }
+        case VOP_INV_PREP: {  // X0^-1 for the two records that follow (oprs/linalg.cpp:82-96)
+            if (mode != PASS_EVAL0 || e != 0) break;
+            const int m = P.vars[o.in[0]].rows;
+            double a[VEC_MAX_DIM * VEC_MAX_DIM], inv[VEC_MAX_DIM * VEC_MAX_DIM];
+            for (int q = 0; q < m * m; ++q) a[q] = vec_coef(P, o.in[0], 0, b, q);
+            vec_inverse(a, inv, m);
+            for (int q = 0; q < m * m; ++q) P.arena[o.aux0 + b * m * m + q] = inv[q];
+            break;
+        }
+        case OP_MATINVMUL: {
+            // Y X = A (is_left) or X Y = A, oprs/linalg.cpp:67-217: order 0 directly; order k in two products, the
+            // inner one here:  tmp = A_k - sum_{0<i<k} (Y_i X_{k-i} | X_i Y_{k-i}) - (Y_0 X_k | X_k Y_0)
+            const int x = o.in[0];
+            const int m = ov.rows;
+            const int r = e / m, c = e % m;
+            const bool left = o.flags & OP_FLAG_IS_LEFT, ident = o.flags & OP_FLAG_USE_IDENTITY;
+            const double* xinv = P.arena + o.aux0 + b * m * m;
+            if (mode == PASS_EVAL0) {
+                double s;
+                if (ident) {
+                    s = xinv[e];
+                } else {
+                    s = 0;
+                    for (int j = 0; j < m; ++j)
+                        s = left ? __builtin_fma(vec_coef(P, o.in[1], 0, b, r * m + j), xinv[j * m + c], s)
+                                 : __builtin_fma(xinv[r * m + j], vec_coef(P, o.in[1], 0, b, j * m + c), s);
+                }
+                vec_store(P, o.out, 0, true, b, e, s);
+                break;
+            }
+            double* psb = P.arena + o.aux1 + b * osz + e;
+            double sb;
+            if (!in_coeff) {
+                sb = 0;
+                for (int i = 1; i < k; ++i)
+                    for (int j = 0; j < m; ++j)
+                        sb = left ? __builtin_fma(-vec_coef(P, o.out, i, b, r * m + j), vec_coef(P, x, k - i, b, j * m + c), sb)
+                                  : __builtin_fma(-vec_coef(P, x, i, b, r * m + j), vec_coef(P, o.out, k - i, b, j * m + c), sb);
+                *psb = sb;
+            } else {
+                sb = *psb;
+            }
+            if (!ident) sb += vec_cur(P, o.in[1], k, in_coeff, b, e);
+            for (int j = 0; j < m; ++j)
+                sb = left ? __builtin_fma(-vec_coef(P, o.out, 0, b, r * m + j), vec_cur(P, x, k, in_coeff, b, j * m + c), sb)
+                          : __builtin_fma(-vec_cur(P, x, k, in_coeff, b, r * m + j), vec_coef(P, o.out, 0, b, j * m + c), sb);
+            P.arena[o.aux2 + b * osz + e] = sb;
+            break;
+        }
+        case VOP_MATINV_FIN: {  // ... and the outer one: (tmp X0^-1 | X0^-1 tmp)
+            if (mode == PASS_EVAL0) break;
+            const int m = ov.rows;
+            const int r = e / m, c = e % m;
+            const bool left = o.flags & OP_FLAG_IS_LEFT;
+            const double* xinv = P.arena + o.aux0 + b * m * m;
+            const double* tmp = P.arena + o.aux2 + b * osz;
+            double s = 0;
+            for (int j = 0; j < m; ++j)
+                s = left ? __builtin_fma(tmp[r * m + j], xinv[j * m + c], s) : __builtin_fma(xinv[r * m + j], tmp[j * m + c], s);
+            vec_store(P, o.out, k, in_coeff, b, e, s);
+            break;
+        }
+        case OP_DET: {  // oprs/linalg.cpp:221-282, first phase: cof(X0) at order 0, the self-bias's shares at BIAS(k)
+            const int x = o.in[0];
+            const int m = P.vars[x].rows;
+            if (mode == PASS_EVAL0) {
+                if (e >= m * m) break;
+                const int r = e / m, c = e % m;
+                double minor[(VEC_MAX_DIM - 1) * (VEC_MAX_DIM - 1)];
+                int q = 0;
+                for (int i = 0; i < m; ++i) {
+                    if (i == r) continue;
+                    for (int j = 0; j < m; ++j)
+                        if (j != c) minor[q++] = vec_coef(P, x, 0, b, i * m + j);
+                }
+                const double d = m == 1 ? 1.0 : vec_lu_det(minor, m - 1);
+                P.arena[o.aux0 + b * m * m + e] = ((r + c) & 1) ? -d : d;
+            } else if (mode == PASS_BIAS) {
+                P.arena[o.aux2 + b * VEC_MAX_SIZE + e] = vec_det_selfbias_part(P, x, k, b, e, m);
+            }
+            break;
+        }
+        case VOP_DET_FIN: {  // second phase (thread 0): det(X0) along row 0 of the cofactors; cof : X_k + self-bias
+            const int x = o.in[0];
+            const int m = P.vars[x].rows;
+            const double* cof = P.arena + o.aux0 + b * m * m;
+            if (mode == PASS_EVAL0) {
+                double d = 0;
+                for (int c = 0; c < m; ++c) d = __builtin_fma(vec_coef(P, x, 0, b, c), cof[c], d);
+                vec_store(P, o.out, 0, true, b, 0, d);
+                break;
+            }
+            double sb;
+            if (!in_coeff) {
+                sb = 0;
+                for (int t = 0; t < VEC_MAX_SIZE; ++t) sb += P.arena[o.aux2 + b * VEC_MAX_SIZE + t];
+                P.arena[o.aux1 + b] = sb;
+            } else {
+                sb = P.arena[o.aux1 + b];
+            }
+            for (int q = 0; q < m * m; ++q) sb = __builtin_fma(cof[q], vec_cur(P, x, k, in_coeff, b, q), sb);
+            vec_store(P, o.out, k, in_coeff, b, 0, sb);
+            break;
+        }
         default: break;
     }
 }
@@ -256,6 +618,71 @@ VEC_HD void vec_backward(const VecProgDev& P, const VecOp& o, int64_t b, int e, 
                 if (e >= off && e < off + n && !P.vars[o.in[i]].is_const) add(o.in[i], e - off, go[e]);
                 off += n;
             }
+            break;
+        }
+        case OP_TRANSPOSE: {  // input (ir x ic), output (ic x ir)
+            const int v = o.in[0], ir = P.vars[v].rows, ic = P.vars[v].cols;
+            if (e < ir * ic && !P.vars[v].is_const) add(v, e, go[(e % ic) * ir + e / ic]);
+            break;
+        }
+        case OP_MULEYE:
+            if (e == 0 && !P.vars[o.in[0]].is_const) {
+                const int d = ov.rows;
+                double s = 0;
+                for (int i = 0; i < d; ++i) s += go[i * d + i];
+                add(o.in[0], 0, s);
+            }
+            break;
+        case OP_MATMUL: {  // g_A = g_Y B0^T, g_B = A0^T g_Y
+            const int a = o.in[0], c = o.in[1];
+            const int m = ov.rows, n = ov.cols, K = P.vars[a].cols;
+            if (e < m * K && !P.vars[a].is_const) {
+                const int r = e / K, j = e % K;
+                double s = 0;
+                for (int q = 0; q < n; ++q) s = __builtin_fma(go[r * n + q], vec_coef(P, c, 0, b, j * n + q), s);
+                add(a, e, s);
+            }
+            if (e < K * n && !P.vars[c].is_const) {
+                const int j = e / n, q = e % n;
+                double s = 0;
+                for (int r = 0; r < m; ++r) s = __builtin_fma(go[r * n + q], vec_coef(P, a, 0, b, r * K + j), s);
+                add(c, e, s);
+            }
+            break;
+        }
+        case OP_MATINVMUL: {
+            // oprs/linalg.cpp:98-150: g_X[i,j] = sum_pq g_Y[p,q] m0[p,i] m1[j,q] with (m0, m1) = (-Y0, X0^-1) for
+            // Y X = A and (X0^-1, -Y0) for X Y = A; g_A = g_Y X0^-T (left) or X0^-T g_Y (right)
+            const int x = o.in[0];
+            const int m = ov.rows;
+            if (e >= m * m) break;
+            const int i = e / m, j = e % m;
+            const bool left = o.flags & OP_FLAG_IS_LEFT, ident = o.flags & OP_FLAG_USE_IDENTITY;
+            const double* xinv = P.arena + o.aux0 + b * m * m;
+            if (!P.vars[x].is_const) {
+                double s = 0;
+                for (int p = 0; p < m; ++p) {
+                    const double m0 = left ? -vec_coef(P, o.out, 0, b, p * m + i) : xinv[p * m + i];
+                    double t = 0;
+                    for (int q = 0; q < m; ++q) {
+                        const double m1 = left ? xinv[j * m + q] : -vec_coef(P, o.out, 0, b, j * m + q);
+                        t = __builtin_fma(go[p * m + q], m1, t);
+                    }
+                    s = __builtin_fma(m0, t, s);
+                }
+                add(x, e, s);
+            }
+            if (!ident && !P.vars[o.in[1]].is_const) {
+                double s = 0;
+                for (int q = 0; q < m; ++q)
+                    s = left ? __builtin_fma(go[i * m + q], xinv[j * m + q], s) : __builtin_fma(go[q * m + j], xinv[q * m + i], s);
+                add(o.in[1], e, s);
+            }
+            break;
+        }
+        case OP_DET: {  // oprs/linalg.cpp:234-246: g_X = g_y cof(X0)
+            const int x = o.in[0], m = P.vars[x].rows;
+            if (e < m * m && !P.vars[x].is_const) add(x, e, go[0] * P.arena[o.aux0 + b * m * m + e]);
             break;
         }
         default: break;

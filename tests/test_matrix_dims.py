@@ -1,0 +1,177 @@
+"""Matrices of other sizes than 3 x 3 through the C ABI (libsanm/tensor_linalg.cpp:107-210 dynamic sizes,
+tensor_polymat.cpp:30-136 / :325-379 determinant series): the graphs of the reference's own operator tests
+(tests/symbolic.cpp:179-424, :640-656 -- 4 x 4 mat_inv_mul and elementwise arithmetic with batched_mul_eye(4),
+determinants at 4, 5 and 7, transposes and products of 4 x 6 matrices, reduce over 9 x 7, log det(X^T X) of 4 x 3)
+on the device's vector interpreter (sanm_amd/csrc/vecprog.h) against the oracle's restatement of the operator metas:
+order-0 values, Jacobians, biases and coefficients up to order 6, and the series against a direct evaluation."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import symbolic as S
+from oracle import tensor_ops as T_
+from sanm_amd import api as A
+
+
+def _mk_device(api, build, shape, batch, order):
+    g = api.graph()
+    x = g.placeholder_matrix(*shape) if len(shape) == 2 else g.placeholder_vector(shape[0])
+    y = build(x, A)
+    n = int(np.prod(shape))
+    ident = A.SparseLinearDesc(api, sp.identity(batch * n, format="csr"))
+    return A.TaylorCoeffProp(api, y, ident, order, batch, in_size=n), (g, ident)
+
+
+def _mk_oracle(build):
+    return S.TaylorCoeffProp(build(S.placeholder(S.ComputingGraph()), S))
+
+
+# ---- the graphs (one function serves both operator APIs; `M` is the module providing linear_combine etc.) ----------
+def g_inv_right(x, M):          # tests/symbolic.cpp:198-207 simple-inv (is_left = false)
+    return M.batched_mat_inv_mul(x, None, False)
+
+
+def g_inv_left(x, M):
+    return M.batched_mat_inv_mul(x, None, True)
+
+
+def g_inv_mul_left(x, M):       # :209-220
+    return M.batched_mat_inv_mul(x, x.pow(1.5), True)
+
+
+def g_inv_mul_right(x, M):      # :222-232
+    return M.batched_mat_inv_mul(x, x.pow(1.5), False)
+
+
+def g_bcast_fullgy(x, M):       # :286-298 (dim taken from the operand)
+    xs = x.reduce_sum(-1)
+    return M.batched_mat_inv_mul(x.pow(1.2) * xs + xs.batched_mul_eye(4), None, False)
+
+
+def g_det_x(x, M):              # :331-346: det(x) * x
+    return x.batched_det() * x
+
+
+def g_transpose(x, M):          # :389-406
+    return x.pow(1.5).batched_transpose()
+
+
+def g_trans_mul(x, M):          # :408-424: sum(x x^T) * x
+    return x.batched_matmul(x.batched_transpose()).reduce_sum(-1) * x
+
+
+def g_reduce(x, M):             # :362-387 reduce-flatten
+    return x.reduce_sum(-1) * x.pow(-2)
+
+
+def g_logdet(x, M):             # :640-656
+    return x.batched_transpose().batched_matmul(x).batched_det().log()
+
+
+def g_lincomb(x, M):            # :301-322
+    return M.linear_combine([(1.2, x.reduce_sum(-1)), (2.3, x.pow(2. / 3.)), (1.4, x.pow(1.5))], 2.5)
+
+
+CASES = [
+    # name, graph, placeholder shape, batch, value range, diagonal shift
+    ("inv_right_4", g_inv_right, (4, 4), 9, (1.0, 4.0), 4.0),
+    ("inv_left_4", g_inv_left, (4, 4), 9, (1.0, 4.0), 4.0),
+    ("inv_mul_left_4", g_inv_mul_left, (4, 4), 9, (1.0, 4.0), 4.0),
+    ("inv_mul_right_4", g_inv_mul_right, (4, 4), 9, (1.0, 4.0), 4.0),
+    ("bcast_fullgy_4", g_bcast_fullgy, (4, 4), 9, (2.0, 5.0), 0.0),
+    ("det_2", g_det_x, (2, 2), 3, (0.0, 1.0), 1.0),
+    ("det_4", g_det_x, (4, 4), 10, (0.0, 1.0), 1.0),
+    ("det_5", g_det_x, (5, 5), 10, (0.0, 1.0), 1.0),
+    ("det_7", g_det_x, (7, 7), 10, (0.0, 1.0), 1.0),
+    ("det_8", g_det_x, (8, 8), 2, (0.0, 1.0), 1.0),
+    ("transpose_4x6", g_transpose, (4, 6), 5, (1.0, 2.0), 0.0),
+    ("trans_mul_4x6", g_trans_mul, (4, 6), 5, (0.0, 1.0), 0.0),
+    ("reduce_9x7", g_reduce, (9, 7), 8, (0.5, 1.5), 0.0),
+    ("logdet_4x3", g_logdet, (4, 3), 10, (0.0, 1.0), 0.0),
+    ("lincomb_4", g_lincomb, (4, 4), 9, (2.0, 5.0), 0.0),
+]
+
+
+def _inputs(shape, batch, lo, hi, shift, N, seed):
+    rng = np.random.default_rng(seed)
+    x0 = rng.uniform(lo, hi, (batch,) + shape)
+    if shift:
+        for i in range(min(shape)):
+            x0[:, i, i] += shift
+    return [x0] + [0.1 * (hi - lo + 0.2) * rng.standard_normal((batch,) + shape) for _ in range(N)]
+
+
+@pytest.mark.parametrize("name,build,shape,batch,rng_,shift", CASES, ids=[c[0] for c in CASES])
+def test_matrix_graph_series_against_oracle(api, name, build, shape, batch, rng_, shift):
+    N = 6
+    xs = _inputs(shape, batch, rng_[0], rng_[1], shift, N, seed=len(name))
+    prop, keep = _mk_device(api, build, shape, batch, N)
+    oprop = _mk_oracle(build)
+    flat = lambda a: np.asarray(a).reshape(batch, -1)
+    y = flat(prop.push_xi(xs[0]))
+    yo = flat(oprop.push_xi([xs[0]]))
+    assert y.shape == yo.shape
+    scale = max(1.0, np.abs(yo).max())
+    assert np.abs(y - yo).max() <= 1e-11 * scale
+    J = prop.get_jacobian()
+    Jo = np.asarray(oprop.get_jacobian()).reshape(J.shape)
+    assert np.abs(J - Jo).max() <= 1e-10 * max(1.0, np.abs(Jo).max())
+    ys = [y]
+    n = int(np.prod(shape))
+    for k in range(1, N + 1):
+        b = flat(prop.compute_next_order_bias())
+        bo = flat(oprop.compute_next_order_bias())
+        if k == 1:
+            assert not np.any(b)  # symbolic.cpp:278-285
+        sk = max(1.0, np.abs(bo).max())
+        assert np.abs(b - bo).max() <= 1e-9 * sk, (k, np.abs(b - bo).max(), sk)
+        yk = flat(prop.push_xi(xs[k]))
+        yko = flat(oprop.push_xi([xs[k]]))
+        sk = max(1.0, np.abs(yko).max())
+        assert np.abs(yk - yko).max() <= 1e-9 * sk, (k, np.abs(yk - yko).max(), sk)
+        # coefficient = bias + Jacobian . x_k: what the ANM loop relies on (check_taylor_prop, tests/symbolic.cpp:96-103)
+        lin = b + np.einsum("bij,bj->bi", J, xs[k].reshape(batch, n))
+        assert np.abs(lin - yk).max() <= 1e-8 * sk
+        ys.append(yk)
+    # the series against a direct evaluation at a small a (check_taylor_prop's eps_eval leg, :131-137)
+    a = 0.02
+    direct, _ = _mk_device(api, build, shape, batch, 1)
+    yd = flat(direct.push_xi(sum(x * a ** k for k, x in enumerate(xs))))
+    series = sum(v * a ** k for k, v in enumerate(ys))
+    assert np.abs(yd - series).max() <= 1e-6 * max(1.0, np.abs(yd).max())
+
+
+@pytest.mark.parametrize("m", [2, 3, 4, 5, 6, 7])
+def test_oracle_polymat_det_coeff_against_evaluated_polynomial(m):
+    """the reference's own check of compute_polymat_det_coeff (tests/tensor.cpp: det of the evaluated polynomial
+    matrix against the polynomial of the coefficients) for both paths -- expansion (dim <= 4) and DFT (dim > 4)"""
+    rng = np.random.default_rng(m)
+    nc, batch = 4, 5
+    cs = [rng.standard_normal((batch, m, m)) for _ in range(nc)]
+    deg = (nc - 1) * m
+    co = np.stack([T_.compute_polymat_det_coeff(cs, k)[:, 0] for k in range(deg + 2)])  # (deg+2, batch)
+    assert not np.any(co[deg + 1])
+    for a in (0.3, -0.7, 1.1):
+        want = np.linalg.det(sum(c * a ** k for k, c in enumerate(cs)))
+        got = sum(co[k] * a ** k for k in range(deg + 1))
+        assert np.allclose(got, want, rtol=1e-9, atol=1e-9 * np.abs(co).max())
+
+
+def test_shape_rules(api):
+    g = api.graph()
+    x = g.placeholder_matrix(4, 6)
+    with pytest.raises(A.SanmAssertionError):
+        x.batched_matmul(x)                       # (4,6) x (4,6)
+    with pytest.raises(A.SanmAssertionError):
+        x.batched_det()
+    with pytest.raises(A.SanmAssertionError):
+        A.batched_mat_inv_mul(x, None, False)
+    assert x.batched_matmul(x.batched_transpose()).id >= 0
+    with pytest.raises(A.SanmUnsupportedError):   # SVD-W: 3 x 3 only
+        g.placeholder_matrix(4, 4).batched_svd_w()
+    with pytest.raises(A.SanmUnsupportedError):   # one axis of a matrix
+        x.reduce_sum(1)
+    y = g.placeholder_matrix(9, 9)                # larger than the interpreter's 8 x 8 linear algebra
+    ident = A.SparseLinearDesc(api, sp.identity(81, format="csr"))
+    with pytest.raises((A.SanmAssertionError, A.SanmUnsupportedError)):
+        A.TaylorCoeffProp(api, y.batched_det() * y, ident, 2, 1, in_size=81)
