@@ -293,6 +293,61 @@ public:
 };
 }  // namespace
 
+namespace {
+//! Dense LU with partial pivoting (Backend::dense_lu_factor) for the small general systems of graphs on the vector
+//! interpreter: the stand-in for the pivoting PARDISO does on them in the reference (sparse_solver.cpp:107-127)
+class DenseLuSolver final : public LinearSolver {
+    Backend* m_be;
+    const JacobianPattern& m_pat;
+    DVec m_lu, m_status;
+    void* m_piv = nullptr;
+    double* m_host_status = nullptr;
+
+public:
+    DenseLuSolver(Backend* be, const JacobianPattern& pat) : m_be{be}, m_pat{pat} {
+        const size_t n = pat.n();
+        m_lu = DVec{be, n * n};
+        m_status = DVec{be, 2};
+        m_piv = be->alloc(n * sizeof(int32_t));
+        m_host_status = be->alloc_host(2);
+        nnz_factors = (int64_t)(n * n);
+        factor_flops = 2.0 / 3.0 * (double)n * (double)n * (double)n;
+        nr_front = nr_level = 1;
+        max_front = (int64_t)n;
+    }
+    ~DenseLuSolver() override {
+        m_be->free(m_piv);
+        m_be->free_host(m_host_status);
+    }
+    void prepare() override {
+        prepare_async(nullptr);
+        m_be->sync();
+        check_prepared(nullptr);
+    }
+    void prepare_async(double* status) override {
+        (void)status;
+        m_be->dense_lu_factor(m_pat.csr(), m_lu.p(), static_cast<int32_t*>(m_piv), m_status.p());
+        m_be->d2h_async(m_host_status, m_status.p(), 16);
+    }
+    bool check_prepared(const double* status) override {
+        (void)status;
+        const double pmin = m_host_status[0], pmax = m_host_status[1];
+        // (PARDISO reports a zero pivot the same way: sparse_solver.cpp:118-127)
+        if (!(pmin > 0) || !std::isfinite(pmax) || pmin < 1e-14 * pmax)
+            sanm_throw(SANM_ERR_NUMERICAL, "dense LU: pivot %g of %g: the Jacobian is numerically singular", pmin, pmax);
+        return false;
+    }
+    void solve(const double* b, double* x) override {
+        m_be->dense_lu_solve(m_pat.n(), m_lu.p(), static_cast<const int32_t*>(m_piv), b, x);
+        ++nr_solve;
+    }
+};
+}  // namespace
+
+std::unique_ptr<LinearSolver> make_dense_solver(Backend* be, const JacobianPattern& pat) {
+    return std::make_unique<DenseLuSolver>(be, pat);
+}
+
 std::unique_ptr<LinearSolver> make_direct_solver(Backend* be, const JacobianPattern& pat,
                                                  const HyperParam& hp, const double* coords) {
     if (hp.xcoeff_l2_penalty != 0) return std::make_unique<TikhonovSolver>(be, pat, hp.xcoeff_l2_penalty, coords);
@@ -715,9 +770,10 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
         : m_be{be}, m_hp{hp}, m_n{nr_unknown}, m_max_a_bound{poly::stable_x_range(hp.order)},
           m_shard{shard}, m_profile_mode{hp.profile} {
     sanm_check(hp.order >= 2, "order=%d", hp.order);  // anm.cpp:108-110
-    if (graph_is_vector(g_in, out_var))
-        sanm_throw(SANM_ERR_UNSUPPORTED, "the ANM drivers take (T,3,3) graphs; graphs over vectors (Slice / Concat) are "
-                                         "served by the operator-level API (sanm_taylor_*)");
+    if (graph_is_vector(g_in, out_var)) {
+        construct_on_vector_interpreter(g_in, out_var, remap_inp_in, remap_out_in);
+        return;
+    }
     sanm_check(remap_inp_in.out_size % 9 == 0, "remap_inp must produce a (T,3,3) tensor");
     if (hp.xcoeff_l2_penalty != 0 && hp.solver_kind != 1)
         sanm_throw(SANM_ERR_UNSUPPORTED, "xcoeff_l2_penalty (Tikhonov path) needs the direct solver (solver_kind 1)");
@@ -757,8 +813,47 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
     m_remap_out = std::make_unique<DeviceRows>(be, remap_out, te - tb, m_prog->Tpad(), tb, te);
     m_pattern = std::make_unique<JacobianPattern>(be, remap_out, remap_inp, m_n, T, m_prog->Tpad(),
                                                   m_prog->dev().odim, tb, te);
-    if (hp.solver_kind == 1) {
-        const double* coords = remap_out.out_coords.size() == (size_t)m_n * 3 ? remap_out.out_coords.data() : nullptr;
+    construct_solver_and_vectors(remap_out.out_coords.size() == (size_t)m_n * 3 ? remap_out.out_coords.data() : nullptr);
+}
+
+void AnmDriver::construct_on_vector_interpreter(const Graph& g, int out_var, const SparseDesc& remap_inp,
+                                                const SparseDesc& remap_out) {
+    // tests/symbolic.cpp:140-560, :835-900: the ANM solvers over graphs of arbitrary (batch, ...) tensors
+    Backend* be = m_be;
+    if (m_shard.active())
+        sanm_throw(SANM_ERR_UNSUPPORTED, "tet-sharded solvers take (T,3,3) graphs (the vector interpreter is not sharded)");
+    if (m_hp.xcoeff_l2_penalty != 0 && m_hp.solver_kind != 1)
+        sanm_throw(SANM_ERR_UNSUPPORTED, "xcoeff_l2_penalty (Tikhonov path) needs the direct solver (solver_kind 1)");
+    int idim = 0;
+    for (const GraphOp& op : g.ops)
+        if (op.type == OP_PLACEHOLDER) idim = g.vars[op.out[0]].size;
+    sanm_check(idim > 0, "the graph has no placeholder");
+    sanm_check(remap_inp.out_size % idim == 0, "remap_inp produces %ld elements: not a batch of the placeholder's %d",
+               (long)remap_inp.out_size, idim);
+    const int64_t B = remap_inp.out_size / idim;
+    m_vprog = std::make_unique<VecProgram>(be, g, out_var, B, m_hp.order);
+    const int odim = m_vprog->odim();
+    sanm_check(remap_out.in_size == B * odim, "remap_out takes %ld elements, the graph produces (%ld, %d)",
+               (long)remap_out.in_size, (long)B, odim);
+    // x (n or n+1 entries) -> placeholder rows: one "batch item" holding the whole vector
+    m_vec_remap_in = std::make_unique<DeviceRows>(be, remap_inp, 1, 1, 0, 1, remap_inp.in_size);
+    m_vec_xin = DVec{be, (size_t)(B * idim)};
+    m_remap_out = std::make_unique<DeviceRows>(be, remap_out, B, B, 0, B, odim);
+    m_pattern = std::make_unique<JacobianPattern>(be, remap_out, remap_inp, m_n, B, B, odim, 0, B, idim);
+    construct_solver_and_vectors(nullptr);
+}
+
+void AnmDriver::construct_solver_and_vectors(const double* coords) {
+    Backend* be = m_be;
+    const HyperParam& hp = m_hp;
+    // Graphs on the vector interpreter: general small systems (a transpose or a random sparse map puts zeros on
+    // the diagonal) -- dense LU with partial pivoting up to kDenseMaxN unknowns, the multifrontal solver beyond
+    // and on the regularised path
+    constexpr int64_t kDenseMaxN = 4096;
+    if (hp.solver_kind == 1 && m_vprog && m_n <= kDenseMaxN && hp.xcoeff_l2_penalty == 0 &&
+        !std::getenv("SANM_VEC_MULTIFRONTAL")) {
+        m_solver = make_dense_solver(be, *m_pattern);
+    } else if (hp.solver_kind == 1) {
         m_solver = make_direct_solver(be, *m_pattern, hp, coords);
     } else if (hp.solver_kind == 0) {
         m_solver = make_pcg_solver(be, *m_pattern, hp);
@@ -788,6 +883,47 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
     m_xt_coeffs.resize(hp.order + 1);
     for (auto& v : m_xt_coeffs) v = DVec{be, n1};
 }
+
+void AnmDriver::run_pass(int mode, int order, const double* x) {
+    if (m_prog) {
+        m_be->run_pass(m_prog->dev(), (PassMode)mode, order, x);
+        return;
+    }
+    const double* xin = nullptr;
+    if (x) {  // remap_inp (anm.cpp:362-438's input side) as a gather in front of the interpreter
+        m_be->gather_rows(m_vec_remap_in->dev(), x, m_vec_xin.p());
+        xin = m_vec_xin.p();
+    }
+    if (mode == PASS_COEFF_BIAS) {
+        m_be->run_vec_pass(m_vprog->dev(), PASS_COEFF, order, xin);
+        m_be->run_vec_pass(m_vprog->dev(), PASS_BIAS, order + 1, nullptr);
+        return;
+    }
+    m_be->run_vec_pass(m_vprog->dev(), mode, order, xin);
+}
+
+// (the per-tet programs stage value and bias in one tet-major buffer)
+const double* AnmDriver::out_value0() const { return m_prog ? m_prog->out_coef0() : m_vprog->out_coef0_dev(); }
+const double* AnmDriver::out_bias() const { return m_prog ? m_prog->out_bias() : m_vprog->out_bias_dev(); }
+
+double* AnmDriver::pow_flag_words() const {
+    if (m_vprog) return m_vprog->flag_dev();
+    return m_prog->pow_flags().empty() ? nullptr : m_prog->arena_dev() + m_prog->pow_flags()[0].off;
+}
+
+std::string AnmDriver::pow_exponent_list() const {
+    std::string exps;
+    if (m_prog)
+        for (const auto& f : m_prog->pow_flags()) exps += (exps.empty() ? "" : ", ") + std::to_string(f.exponent);
+    else
+        for (double e : m_vprog->pow_exponents()) exps += (exps.empty() ? "" : ", ") + std::to_string(e);
+    return exps;
+}
+
+const double* AnmDriver::jacobian_blocks() const { return m_prog ? m_prog->placeholder_jac() : m_vprog->jac_dev(); }
+
+int64_t AnmDriver::batch() const { return m_prog ? m_prog->T() : m_vprog->B(); }
+size_t AnmDriver::arena_bytes() const { return m_prog ? m_prog->arena_bytes() : m_vprog->arena_bytes(); }
 
 const std::map<std::string, double>& AnmDriver::profile() {
     if (m_profile_mode == 2) m_be->phase_collect(m_profile, &m_profile_cnt);
@@ -836,7 +972,6 @@ void AnmDriver::solve_expansion_coeffs() {
     const int N = m_hp.order;
     const size_t n = m_n, n1 = m_n + 1;
     Backend* be = m_be;
-    ProgramDev P = m_prog->dev();
 
     be->d2d(m_xt_coeffs[0].p(), m_xt0.p(), n1 * 8);
     m_nr_valid_coeffs = 1;
@@ -854,10 +989,10 @@ void AnmDriver::solve_expansion_coeffs() {
 
     {
         ScopedTimer t{this, "taylor_order0"};
-        be->run_pass(P, PASS_EVAL0, 0, m_xt0.p());
+        run_pass(PASS_EVAL0, 0, m_xt0.p());
         {
             ScopedTimer t2{this, "remap_out"};
-            be->gather_rows(m_remap_out->dev(), m_prog->out_coef0(), m_fx0.p());
+            be->gather_rows(m_remap_out->dev(), out_value0(), m_fx0.p());
         }
         allreduce(m_fx0.p(), n);
     }
@@ -865,24 +1000,24 @@ void AnmDriver::solve_expansion_coeffs() {
     // travels to the host with the next synchronisation
     double* const host_powflag = m_host_scalars + 5 * ((size_t)N + 2) + 4;
     *host_powflag = 0;
-    const bool has_powflag = !m_prog->pow_flags().empty();
+    double* const flag_words = pow_flag_words();
+    const bool has_powflag = flag_words != nullptr;
     auto check_powflag = [&]() {
         if (!has_powflag || *host_powflag == 0) return;
         // |flags|^2 = 1 or 5: a non-integer exponent met a zero (the reference's error; it wins); 4: only the order limit
         const bool unsupported = *host_powflag == 4.0;
         const double zero[2] = {0, 0};
-        be->h2d(m_prog->arena_dev() + m_prog->pow_flags()[0].off, zero, 16);
-        std::string exps;
-        for (const auto& f : m_prog->pow_flags()) exps += (exps.empty() ? "" : ", ") + std::to_string(f.exponent);
+        be->h2d(flag_words, zero, 16);
+        const std::string exps = pow_exponent_list();
+        if (unsupported && !m_prog)
+            sanm_throw(SANM_ERR_UNSUPPORTED, "integer power other than a square of a series through zero on the vector "
+                                             "interpreter (exponents: %s)", exps.c_str());
         if (unsupported)
             sanm_throw(SANM_ERR_UNSUPPORTED, "integer power of a series through zero beyond order %d (exponents: %s)",
                        POW_INT_MAX_ORDER, exps.c_str());
         sanm_throw(SANM_ERR_NUMERICAL, "0^p when p is not integer (pow exponents in the graph: %s)", exps.c_str());
     };
-    if (has_powflag) {
-        const double* fl = m_prog->arena_dev() + m_prog->pow_flags()[0].off;
-        be->dot_async(2, fl, fl, host_powflag);
-    }
+    if (has_powflag) be->dot_async(2, flag_words, flag_words, host_powflag);
     if (!on_fx0_computed(m_fx0.p())) {
         check_powflag();
         return;
@@ -894,7 +1029,7 @@ void AnmDriver::solve_expansion_coeffs() {
     const double* grad_t = nullptr;
     const int32_t* rhs_perm = nullptr;
     // COEFF(i) and BIAS(i+1) are back to back: one launch among the kernels compiled for this graph
-    const bool fuse_passes = P.spec_id >= 0 && !std::getenv("SANM_NO_FUSED_PASS");
+    const bool fuse_passes = m_prog && m_prog->dev().spec_id >= 0 && !std::getenv("SANM_NO_FUSED_PASS");
     bool bias_done = false;
     double* const host_sanity = m_host_scalars + 3 * ((size_t)N + 2);  // [2 (i-1)], [2 (i-1) + 1]
     // asynchronous results examined after the loop: non-finite Jacobian entries, rejected pivots, |x_1|^2, |x_N|^2
@@ -938,17 +1073,17 @@ void AnmDriver::solve_expansion_coeffs() {
         double* const bi = do_sanity ? m_bi_all[i].p() : m_bi.p();
         if (i == 1) {
             ScopedTimer t{this, "jacobian"};
-            be->run_pass(P, PASS_GRAD, 0, nullptr);
+            run_pass(PASS_GRAD, 0, nullptr);
         }
         {
             ScopedTimer t{this, "taylor_next_order"};
-            if (!bias_done) be->run_pass(P, PASS_BIAS, i, nullptr);
+            if (!bias_done) run_pass(PASS_BIAS, i, nullptr);
             // (orders >= 2, single rank: remap_out drops b_i where the direct solver reads its right-hand side)
             rhs_perm = (i > 1 && !m_shard.active()) ? m_solver->rhs_perm() : nullptr;
             if (pade_riders && i >= 2) m_pade_ws.phase(m_xt_coeffs, i - 1, 1, anm_cond, true);
             {
                 ScopedTimer t2{this, "remap_out"};
-                be->gather_rows(m_remap_out->dev(), m_prog->out_bias(), bi, rhs_perm,
+                be->gather_rows(m_remap_out->dev(), out_bias(), bi, rhs_perm,
                                 rhs_perm ? m_solver->rhs_work() : nullptr);
             }
             // the one collective per Taylor order: sum of the per-shard nodal bias (n doubles)
@@ -968,9 +1103,9 @@ void AnmDriver::solve_expansion_coeffs() {
         if (i == 1) {
             {
                 ScopedTimer t{this, "build_sparse_coeff"};
-                be->assemble(m_pattern->assembly(), m_prog->placeholder_jac(), m_pattern->csr().val);
+                be->assemble(m_pattern->assembly(), jacobian_blocks(), m_pattern->csr().val);
                 if (m_pattern->has_t())
-                    be->assemble(m_pattern->assembly_grad_t(), m_prog->placeholder_jac(),
+                    be->assemble(m_pattern->assembly_grad_t(), jacobian_blocks(),
                                  m_grad_t_buf.p());
                 allreduce(m_pattern->csr().val, m_pattern->nnz());
                 if (m_pattern->has_t()) allreduce(m_grad_t_buf.p(), n);
@@ -1054,7 +1189,7 @@ void AnmDriver::solve_expansion_coeffs() {
         }
         if (i < N) {
             ScopedTimer t{this, "taylor_push"};
-            be->run_pass(P, fuse_passes ? PASS_COEFF_BIAS : PASS_COEFF, i, xi);
+            run_pass(fuse_passes ? PASS_COEFF_BIAS : PASS_COEFF, i, xi);
             bias_done = fuse_passes;
         }
     }

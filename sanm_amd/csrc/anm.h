@@ -17,6 +17,7 @@
 #include "backend.h"
 #include "graph.h"
 #include "sparse.h"
+#include "vecprog_host.h"
 
 namespace sanm_hip {
 
@@ -119,6 +120,9 @@ std::unique_ptr<LinearSolver> make_pcg_solver(Backend* be, const JacobianPattern
 //! multifrontal LU (multifrontal.h); coords: (n,3) ordering hint or null
 std::unique_ptr<LinearSolver> make_direct_solver(Backend* be, const JacobianPattern& pat,
                                                  const HyperParam& hp, const double* coords);
+
+//! dense LU with partial pivoting: the small general systems of graphs on the vector interpreter
+std::unique_ptr<LinearSolver> make_dense_solver(Backend* be, const JacobianPattern& pat);
 
 //! libsanm/pade.h on device vectors
 //! buffers of the Pade basis sweep that live as long as the driver, so that the sweep (a launch-bound
@@ -230,7 +234,14 @@ public:
     }
     const LinearSolver& linear_solver() const { return *m_solver; }
     const JacobianPattern& pattern() const { return *m_pattern; }
-    Program& program() { return *m_prog; }
+    //! the per-tet program of a (T,3,3) graph; graphs on the vector interpreter have none
+    Program& program() {
+        if (!m_prog) sanm_throw(SANM_ERR_UNSUPPORTED, "this solver runs its graph on the vector interpreter");
+        return *m_prog;
+    }
+    bool on_vector_interpreter() const { return (bool)m_vprog; }
+    int64_t batch() const;
+    size_t arena_bytes() const;
     Backend* backend() const { return m_be; }
     const double* last_xt_coeff_dev(int i) const { return m_xt_coeffs[i].p(); }
     double* scratch_dev(int i) const { return i == 0 ? m_tmp0.p() : m_tmp1.p(); }
@@ -261,6 +272,21 @@ protected:
     void apply_injection(double* vec, int64_t len);
     void allreduce(double* buf, int64_t count);
     std::unique_ptr<Program> m_prog;
+    // Graphs over vectors or matrices of other sizes than 3 x 3 (vecprog.h): the same order loop with the vector
+    // interpreter as its pass engine -- remap_inp as a device gather in front of it, the Jacobian's blocks
+    // (odim x idim per batch item) assembled through the same JacobianPattern.
+    std::unique_ptr<VecProgram> m_vprog;
+    std::unique_ptr<DeviceRows> m_vec_remap_in;
+    DVec m_vec_xin;
+    void run_pass(int mode, int order, const double* x);
+    const double* out_value0() const;       // graph output as remap_out gathers it: order-0 value ...
+    const double* out_bias() const;         // ... and order-k bias, [B][odim]
+    const double* jacobian_blocks() const;  // [B][odim][idim]
+    double* pow_flag_words() const;         // the two raise-only error words of the order-0 pass; nullptr: none
+    std::string pow_exponent_list() const;
+    void construct_on_vector_interpreter(const Graph& g, int out_var, const SparseDesc& remap_inp,
+                                         const SparseDesc& remap_out);
+    void construct_solver_and_vectors(const double* coords);
     std::unique_ptr<DeviceRows> m_remap_out;
     std::unique_ptr<JacobianPattern> m_pattern;
     std::unique_ptr<LinearSolver> m_solver;

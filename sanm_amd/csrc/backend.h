@@ -249,6 +249,14 @@ public:
     //! between phase_begin(tag) and the matching phase_end() are bracketed by device events on the backend's
     //! stream; phase_collect() waits for the stream and adds the elapsed seconds of every closed bracket to
     //! acc[tag] / the number of brackets to cnt[tag].  Brackets nest.  Backends without events do nothing.
+    //! Dense LU with partial pivoting for the small general systems of graphs on the vector interpreter (their
+    //! Jacobians may have a zero diagonal -- a transpose, a random sparse input map -- which the multifrontal
+    //! solver's static pivoting does not serve and the reference's PARDISO does): lu (n x n, row-major) is filled
+    //! from the CSR matrix and factored in place, piv[c] = the row swapped into position c; status[0] receives the
+    //! smallest |pivot| (0: singular), status[1] the largest.
+    virtual void dense_lu_factor(const CsrDev& A, double* lu, int32_t* piv, double* status) = 0;
+    //! x = A^-1 b with the factors above (b and x may alias)
+    virtual void dense_lu_solve(int64_t n, const double* lu, const int32_t* piv, const double* b, double* x) = 0;
     //! one pass of a vector-graph program (vecprog.h): mode EVAL0 / COEFF (xin = the placeholder's values of this
     //! order, (B, idim) in device memory), BIAS, GRAD
     virtual void run_vec_pass(const struct VecProgDev& P, int mode, int order, const double* xin) = 0;

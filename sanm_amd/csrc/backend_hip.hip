@@ -988,6 +988,111 @@ __global__ void __launch_bounds__(VEC_MAX_SIZE) vec_pass_kernel(VecProgDev P, in
     }
 }
 
+// ---- dense LU with partial pivoting (Backend::dense_lu_factor): one workgroup, the matrix in global memory --------
+// The systems are those of graphs on the vector interpreter (tests/symbolic.cpp's operator tests: a few hundred
+// unknowns); a generality path, not a hot one.
+constexpr int DLU_THREADS = 1024;
+__global__ void __launch_bounds__(DLU_THREADS) dense_from_csr_kernel(CsrDev A, double* lu) {
+    const int64_t n = A.n;
+    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+        for (int64_t j = threadIdx.x; j < n; j += blockDim.x) lu[i * n + j] = 0.0;
+        __syncthreads();
+        if (threadIdx.x == 0)  // (duplicate columns of a row add up, in their order)
+            for (uint32_t p = A.rowptr[i]; p < A.rowptr[i + 1]; ++p) lu[i * n + A.col[p]] += A.val[p];
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(DLU_THREADS) dense_lu_kernel(int64_t n, double* lu, int32_t* piv, double* status) {
+    __shared__ double s_val[DLU_THREADS];
+    __shared__ int s_idx[DLU_THREADS];
+    __shared__ double s_piv;
+    const int t = threadIdx.x;
+    double pmin = INFINITY, pmax = 0;
+    for (int64_t c = 0; c < n; ++c) {
+        // pivot: largest |lu[r][c]|, r >= c; ties to the lowest row (as a sequential scan does)
+        double best = -1.0;
+        int bi = 0x7fffffff;
+        for (int64_t r = c + t; r < n; r += DLU_THREADS) {
+            const double v = fabs(lu[r * n + c]);
+            if (v > best) {
+                best = v;
+                bi = (int)r;
+            }
+        }
+        s_val[t] = best;
+        s_idx[t] = bi;
+        __syncthreads();
+        for (int w = DLU_THREADS / 2; w > 0; w >>= 1) {
+            if (t < w) {
+                const double ov = s_val[t + w];
+                const int oi = s_idx[t + w];
+                if (ov > s_val[t] || (ov == s_val[t] && oi < s_idx[t])) {
+                    s_val[t] = ov;
+                    s_idx[t] = oi;
+                }
+            }
+            __syncthreads();
+        }
+        const int p = s_idx[0];
+        const double pabs = s_val[0];
+        __syncthreads();
+        if (t == 0) piv[c] = p;
+        pmin = fmin(pmin, pabs);
+        pmax = fmax(pmax, pabs);
+        if (p != (int)c)
+            for (int64_t j = t; j < n; j += DLU_THREADS) {
+                const double a = lu[c * n + j];
+                lu[c * n + j] = lu[(int64_t)p * n + j];
+                lu[(int64_t)p * n + j] = a;
+            }
+        __syncthreads();
+        if (pabs == 0.0) continue;
+        if (t == 0) s_piv = lu[c * n + c];
+        __syncthreads();
+        const double pv = s_piv;
+        for (int64_t r = c + 1 + t; r < n; r += DLU_THREADS) lu[r * n + c] = lu[r * n + c] / pv;
+        __syncthreads();
+        const int64_t m = n - c - 1;
+        for (int64_t q = t; q < m * m; q += DLU_THREADS) {
+            const int64_t r = c + 1 + q / m, j = c + 1 + q % m;
+            lu[r * n + j] = __builtin_fma(-lu[r * n + c], lu[c * n + j], lu[r * n + j]);
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        status[0] = pmin;
+        status[1] = pmax;
+    }
+}
+__global__ void __launch_bounds__(DLU_THREADS) dense_lu_solve_kernel(int64_t n, const double* lu, const int32_t* piv,
+                                                                     const double* b, double* x, double* work) {
+    const int t = threadIdx.x;
+    for (int64_t i = t; i < n; i += DLU_THREADS) work[i] = b[i];
+    __syncthreads();
+    // (the factor swapped whole rows, the finished part of L included: all interchanges first, as getrs does)
+    if (t == 0)
+        for (int64_t c = 0; c < n; ++c) {
+            const int p = piv[c];
+            const double a = work[c];
+            work[c] = work[p];
+            work[p] = a;
+        }
+    __syncthreads();
+    for (int64_t c = 0; c < n; ++c) {
+        const double yc = work[c];
+        for (int64_t r = c + 1 + t; r < n; r += DLU_THREADS) work[r] = __builtin_fma(-lu[r * n + c], yc, work[r]);
+        __syncthreads();
+    }
+    for (int64_t c = n - 1; c >= 0; --c) {
+        if (t == 0) work[c] = work[c] / lu[c * n + c];
+        __syncthreads();
+        const double yc = work[c];
+        for (int64_t r = t; r < c; r += DLU_THREADS) work[r] = __builtin_fma(-lu[r * n + c], yc, work[r]);
+        __syncthreads();
+    }
+    for (int64_t i = t; i < n; i += DLU_THREADS) x[i] = work[i];
+}
+
 // The tet-sharded mode sums nodal vectors over the ranks with ncclAllReduce on the backend's own stream, so the
 // order loop stays free of host synchronisation (the callback form of the C ABI has to synchronise on both sides
 // of the call).  RCCL is looked up with dlopen: a process that already holds it (torch.distributed's nccl backend
@@ -1197,6 +1302,7 @@ public:
     ~HipBackend() override {
         for (auto& kv : m_chains)
             if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (m_dlu_work) (void)hipFree(m_dlu_work);
         if (m_probe_groups) (void)hipHostFree(m_probe_groups);
         if (m_probe_results) (void)hipHostFree(m_probe_results);
         if (m_probe_partials) (void)hipFree(m_probe_partials);
@@ -1227,6 +1333,22 @@ public:
     }
     const char* name() const override { return "hip"; }
     int64_t launch_count() const override { return m_launch_count; }
+    void dense_lu_factor(const CsrDev& A, double* lu, int32_t* piv, double* status) override {
+        SANM_LAUNCH(dense_from_csr_kernel, dim3((unsigned)std::min<int64_t>(A.n, 1024)), dim3(256), 0, m_stream, A, lu);
+        SANM_LAUNCH(dense_lu_kernel, dim3(1), dim3(DLU_THREADS), 0, m_stream, A.n, lu, piv, status);
+        HIP_CHECK(hipGetLastError());
+    }
+    void dense_lu_solve(int64_t n, const double* lu, const int32_t* piv, const double* b, double* x) override {
+        if ((int64_t)m_dlu_work_n < n) {
+            if (m_dlu_work) HIP_CHECK(hipFree(m_dlu_work));
+            HIP_CHECK(hipMalloc(&m_dlu_work, n * sizeof(double)));
+            m_dlu_work_n = n;
+        }
+        SANM_LAUNCH(dense_lu_solve_kernel, dim3(1), dim3(DLU_THREADS), 0, m_stream, n, lu, piv, b, x, m_dlu_work);
+        HIP_CHECK(hipGetLastError());
+    }
+    double* m_dlu_work = nullptr;
+    size_t m_dlu_work_n = 0;
     void run_vec_pass(const VecProgDev& P, int mode, int order, const double* xin) override {
         const size_t lds = mode == PASS_GRAD ? (size_t)P.grad_total * sizeof(double) : 0;
         SANM_LAUNCH(vec_pass_kernel, dim3((unsigned)P.B), dim3(VEC_MAX_SIZE), lds, m_stream, P, mode, order, xin);

@@ -633,14 +633,14 @@ int sanm_anm_get_stats(const sanm_anm_solver* s, sanm_anm_stats* st) {
     return guard([&] {
         auto& d = *s->drv;
         st->nr_unknown = d.nr_unknown();
-        st->nr_tet = d.program().T();
+        st->nr_tet = d.batch();
         st->jacobian_nnz = d.pattern().nnz();
         st->assembly_contribs = d.pattern().nr_contrib();
         st->nr_linear_solve = d.linear_solver().nr_solve;
         st->linear_iters_total = d.linear_solver().tot_iters;
         st->linear_iters_last = d.linear_solver().last_iters;
         st->linear_relres_last = d.linear_solver().last_relres;
-        st->arena_bytes = d.program().arena_bytes();
+        st->arena_bytes = d.arena_bytes();
         st->factor_nnz = d.linear_solver().nnz_factors;
         st->factor_flops = d.linear_solver().factor_flops;
         st->nr_front = d.linear_solver().nr_front;

@@ -132,8 +132,8 @@ Graph::Shape Graph::elemwise_shape(Shape a, Shape b) const {
 }
 
 int Graph::linear_combine(int n, const double* coeffs, const int* vs, double bias) {
-    sanm_check(n >= 1 && n <= MAX_OP_IN, "linear_combine: 1..%d inputs supported, got %d",
-               MAX_OP_IN, n);
+    // (per-tet programs take up to MAX_OP_IN operands -- checked when one is compiled --, the vector interpreter 8)
+    sanm_check(n >= 1 && n <= 8, "linear_combine: 1..8 inputs supported, got %d", n);
     GraphOp op;
     op.type = OP_LINCOMB;
     op.bias = bias;

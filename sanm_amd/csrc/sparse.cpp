@@ -28,11 +28,11 @@ SparseDesc::SparseDesc(int64_t out_size_, int64_t in_size_, const uint64_t* rp, 
 }
 
 DeviceRows::DeviceRows(Backend* be, const SparseDesc& d, int64_t T, int64_t Tpad, int64_t tet_begin,
-                       int64_t tet_end)
+                       int64_t tet_end, int64_t block)
         : m_be{be} {
-    sanm_check(d.in_size % 9 == 0, "remap_out expects a (T,3,3) input, got %ld elements",
-               (long)d.in_size);
-    if (tet_end < 0) tet_end = d.in_size / 9;
+    sanm_check(block >= 1 && d.in_size % block == 0, "sparse map over a (T,%ld) tensor: got %ld input elements",
+               (long)block, (long)d.in_size);
+    if (tet_end < 0) tet_end = d.in_size / block;
     sanm_check(tet_end - tet_begin == T, "remap_out: shard size mismatch");
     sanm_check(d.idx.size() < std::numeric_limits<uint32_t>::max(), "remap_out too large");
     std::vector<uint32_t> ptr(d.out_size + 1, 0), idx;
@@ -41,9 +41,9 @@ DeviceRows::DeviceRows(Backend* be, const SparseDesc& d, int64_t T, int64_t Tpad
     coef.reserve(d.idx.size());
     for (int64_t i = 0; i < d.out_size; ++i) {
         for (uint64_t p = d.rowptr[i]; p < d.rowptr[i + 1]; ++p) {
-            int64_t e = d.idx[p] / 9, c = d.idx[p] % 9;
+            int64_t e = d.idx[p] / block, c = d.idx[p] % block;
             if (e < tet_begin || e >= tet_end) continue;
-            idx.push_back((e - tet_begin) * 9 + c);
+            idx.push_back((e - tet_begin) * block + c);
             coef.push_back(d.coef[p]);
         }
         ptr[i + 1] = idx.size();
@@ -58,7 +58,7 @@ DeviceRows::DeviceRows(Backend* be, const SparseDesc& d, int64_t T, int64_t Tpad
              static_cast<double*>(m_coef), d.out_size, nullptr, nullptr, nullptr};
     // rows in triples?  (SparseRowsDev: same coefficients, indices shifted by 0 / 3 / 6 inside one tet's block)
     const int64_t nr = d.out_size;
-    bool triples = nr > 0 && nr % 3 == 0;
+    bool triples = nr > 0 && nr % 3 == 0 && block == 9;
     for (int64_t u = 0; triples && u < nr / 3; ++u) {
         const uint32_t p0 = ptr[3 * u], len = ptr[3 * u + 1] - p0;
         for (int c = 1; triples && c < 3; ++c) {
@@ -110,10 +110,9 @@ T* JacobianPattern::upload(const std::vector<T>& v) {
 }
 
 JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const SparseDesc& ri, int64_t n,
-                                 int64_t T, int64_t Tpad, int odim, int64_t tet_begin, int64_t tet_end)
+                                 int64_t T, int64_t Tpad, int odim, int64_t tet_begin, int64_t tet_end, int idim)
         : m_be{be} {
     if (tet_end < 0) tet_end = T;
-    const int idim = 9;
     sanm_check(ro.out_size == n, "remap_out must produce %ld unknowns, got %ld", (long)n,
                (long)ro.out_size);
     sanm_check(ro.in_size == T * odim && ri.out_size == T * idim, "remap shapes mismatch");

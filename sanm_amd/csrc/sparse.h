@@ -37,8 +37,9 @@ class DeviceRows {
 public:
     //! only the entries whose input tet lies in [tet_begin, tet_end) are kept (all of
     //! them by default); T / Tpad describe the local SoA tensor
+    //! block: elements per batch item of the input tensor (9 for the (T,3,3) output of a tet program)
     DeviceRows(Backend* be, const SparseDesc& d, int64_t T, int64_t Tpad, int64_t tet_begin = 0,
-               int64_t tet_end = -1);
+               int64_t tet_end = -1, int64_t block = 9);
     ~DeviceRows();
     SparseRowsDev dev() const { return m_dev; }
 
@@ -55,8 +56,10 @@ public:
     //! the continuation parameter t of ANMImplicitSolver, anm.cpp:575-579)
     //! T: global number of tets; contributions of tets outside [tet_begin, tet_end)
     //! are left to the other ranks (the CSR pattern itself is always the global one)
+    //! odim / idim: elements per batch item of the graph's output / placeholder (the blocks of the Jacobian are
+    //! batch-major [T][odim][idim])
     JacobianPattern(Backend* be, const SparseDesc& remap_out, const SparseDesc& remap_in, int64_t n,
-                    int64_t T, int64_t Tpad, int odim, int64_t tet_begin = 0, int64_t tet_end = -1);
+                    int64_t T, int64_t Tpad, int odim, int64_t tet_begin = 0, int64_t tet_end = -1, int idim = 9);
     ~JacobianPattern();
 
     CsrDev csr() const { return m_csr; }

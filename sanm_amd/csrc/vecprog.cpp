@@ -110,6 +110,7 @@ VecProgram::VecProgram(Backend* be, const Graph& g, int out_var, int64_t B, int 
             o.p[VEC_MAX_IN] = op.bias;
         } else if (op.type == OP_POW || op.type == OP_LOG) {
             o.p[0] = op.exponent;
+            if (op.type == OP_POW && op.exponent != 2.0) m_pow_exponents.push_back(op.exponent);
             o.aux0 = take(B * sz);
             o.aux1 = take(B * sz);
         } else if (op.type == OP_MULTIPLY) {
@@ -160,6 +161,7 @@ VecProgram::VecProgram(Backend* be, const Graph& g, int out_var, int64_t B, int 
     m_dev.grad_total = grad;
     sanm_check(grad <= 4096, "vector graph too large for the gradient scratch (%d doubles)", grad);
     // arena, constants
+    m_arena_doubles = off;
     std::vector<double> host(off, 0.0);
     for (int oi : order) {
         const GraphOp& op = g.ops[oi];

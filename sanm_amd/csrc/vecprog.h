@@ -364,7 +364,11 @@ VEC_HD void vec_forward(const VecProgDev& P, const VecOp& o, int mode, int k, in
                     kk = pw * pow(v, pw - 1.0);
                     // analytic_unary.cpp:112-131: the division recurrence cannot start from a zero; the reference
                     // continues integer exponents on a convolution path, this interpreter carries the square only
-                    if (fabs(v) < 1e-3 && !P.vars[x].is_const) P.arena[P.flag + ((pw > 0.5 && floor(pw) == pw) ? 1 : 0)] = 1.0;
+                    // (word 0 <- 1: the reference's error; word 1 <- 2: unsupported here -- the values of Program's flags)
+                    if (fabs(v) < 1e-3 && !P.vars[x].is_const) {
+                        const bool integer = pw > 0.5 && floor(pw) == pw;
+                        P.arena[P.flag + (integer ? 1 : 0)] = integer ? 2.0 : 1.0;
+                    }
                 }
                 vec_store(P, o.out, 0, true, b, e, f);
                 *pk = kk;

@@ -31,6 +31,15 @@ public:
     void download_jacobian(double* dst) const;  // (B, odim, idim)
     //! the raise-only error words written by the order-0 pass (0^p): returns and clears them
     void take_flags(double fl[2]);
+    // device pointers for the ANM order loop: the output's order-0 value / current bias ([B][odim]), the Jacobian
+    // blocks ([B][odim][idim]), the two error words
+    const double* out_coef0_dev() const { return m_dev.arena + m_vars[m_dev.out_var].coef; }
+    const double* out_bias_dev() const { return m_dev.arena + m_vars[m_dev.out_var].bias; }
+    const double* jac_dev() const { return m_dev.arena + m_dev.jac; }
+    double* flag_dev() const { return m_dev.arena + m_dev.flag; }
+    size_t arena_bytes() const { return m_arena_doubles * sizeof(double); }
+    //! exponents of the pow operators other than squares (for the 0^p error message)
+    const std::vector<double>& pow_exponents() const { return m_pow_exponents; }
 
 private:
     Backend* m_be;
@@ -38,6 +47,8 @@ private:
     std::vector<VecVar> m_vars;
     std::vector<int> m_var_map;  // graph var -> local var
     int m_out_graph_var = -1;
+    int64_t m_arena_doubles = 0;
+    std::vector<double> m_pow_exponents;
     void *m_d_ops = nullptr, *m_d_vars = nullptr;
 };
 

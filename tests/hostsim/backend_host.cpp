@@ -13,6 +13,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -158,6 +159,49 @@ public:
             }
             for (int64_t t = tb; t < te; ++t) exec_program_tet(P, mode, order, t, xvec, cur.data(), 1);
         });
+    }
+    void dense_lu_factor(const CsrDev& A, double* lu, int32_t* piv, double* status) override {
+        const int64_t n = A.n;
+        std::fill(lu, lu + n * n, 0.0);
+        for (int64_t i = 0; i < n; ++i)
+            for (uint32_t p = A.rowptr[i]; p < A.rowptr[i + 1]; ++p) lu[i * n + A.col[p]] += A.val[p];
+        double pmin = std::numeric_limits<double>::infinity(), pmax = 0;
+        for (int64_t c = 0; c < n; ++c) {
+            int64_t p = c;
+            double best = std::fabs(lu[c * n + c]);
+            for (int64_t r = c + 1; r < n; ++r)
+                if (std::fabs(lu[r * n + c]) > best) {
+                    best = std::fabs(lu[r * n + c]);
+                    p = r;
+                }
+            piv[c] = (int32_t)p;
+            pmin = std::min(pmin, best);
+            pmax = std::max(pmax, best);
+            if (p != c)
+                for (int64_t j = 0; j < n; ++j) std::swap(lu[c * n + j], lu[p * n + j]);
+            if (best == 0.0) continue;
+            const double pv = lu[c * n + c];
+            for (int64_t r = c + 1; r < n; ++r) {
+                const double l = lu[r * n + c] / pv;
+                lu[r * n + c] = l;
+                if (l == 0.0) continue;
+                for (int64_t j = c + 1; j < n; ++j) lu[r * n + j] = __builtin_fma(-l, lu[c * n + j], lu[r * n + j]);
+            }
+        }
+        status[0] = pmin;
+        status[1] = pmax;
+    }
+    void dense_lu_solve(int64_t n, const double* lu, const int32_t* piv, const double* b, double* x) override {
+        std::vector<double> y(b, b + n);
+        // (the factor swapped whole rows, the finished part of L included: all interchanges first, as getrs does)
+        for (int64_t c = 0; c < n; ++c) std::swap(y[c], y[piv[c]]);
+        for (int64_t c = 0; c < n; ++c)
+            for (int64_t r = c + 1; r < n; ++r) y[r] = __builtin_fma(-lu[r * n + c], y[c], y[r]);
+        for (int64_t c = n - 1; c >= 0; --c) {
+            y[c] /= lu[c * n + c];
+            for (int64_t r = 0; r < c; ++r) y[r] = __builtin_fma(-lu[r * n + c], y[c], y[r]);
+        }
+        std::copy(y.begin(), y.end(), x);
     }
     void gather_rows(const SparseRowsDev& R, const double* src, double* dst, const int32_t* perm,
                      double* dst2) override {
