@@ -124,13 +124,18 @@ def test_slice_concat_argument_rules(api):
         x.slice(1, 0, 6)
     with pytest.raises(A.SanmUnsupportedError):
         A.concat([x, x], 0)
-    # the batched 3x3 operators and the ANM drivers stay with (T,3,3) graphs
+    # the linear-algebra operators take (batch, rows, cols) matrices, not vectors
     with pytest.raises(A.SanmAssertionError):
         x.batched_det()
+    # the ANM drivers run vector graphs too (tests/test_generic_anm.py): x -> x through slice / concat, solved for 2
     y = A.concat([x.slice(1, 0, 2), x.slice(1, 2, None)], 1)
     ident = A.SparseLinearDesc(api, sp.identity(5, format="csr"))
-    with pytest.raises(A.SanmUnsupportedError):
-        A.ANMEqnSolver(api, y, ident, ident, np.ones(5), np.zeros(5), api.default_hyper(order=4))
+    sol = A.ANMEqnSolver(api, y, ident, ident, np.ones(5), -2 * np.ones(5), api.default_hyper(order=4))
+    for _ in range(5):
+        if sol.converged():
+            break
+        sol.next_iter()
+    assert sol.converged() and np.allclose(sol.get_x(), 2.0, rtol=1e-9)
     # ... and a non-integer power of a zero is the reference's numerical error here too
     prop = A.TaylorCoeffProp(api, x.pow(0.5), ident, 2, 1, in_size=5)
     with pytest.raises(A.SanmNumericalError):
