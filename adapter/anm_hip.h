@@ -130,9 +130,11 @@ using DescPtr = std::unique_ptr<sanm_sparse_desc, detail::DescDeleter>;
 /*!
  * Replay the graph that produces \p y through the operator-construction entry points of the C ABI
  * (sanm_graph_* <-> libsanm/oprs.h:14-103), in topological order.  Returns the graph; *out_var is y's id in it.
- * placeholder_vector_size > 0: the graph is one over (batch, n) vectors (Slice / Concat allowed; operator-level API).
+ * placeholder_shape: the shape the placeholder will be fed with (remap_inp->out_shape() of a solver, the x of a
+ * TaylorCoeffProp) -- the reference infers it at the first push, the device graph declares it.  null or (T,3,3): the
+ * per-tet path; (batch, n): a vector (Slice / Concat allowed); (batch, rows, cols): a matrix of that size.
  */
-inline GraphPtr export_graph(symbolic::VarNode* y, int* out_var, int placeholder_vector_size = 0) {
+inline GraphPtr export_graph(symbolic::VarNode* y, int* out_var, const TensorShape* placeholder_shape = nullptr) {
     using namespace symbolic;
     sanm_graph* raw = nullptr;
     check(sanm_graph_create(&raw));
@@ -144,15 +146,21 @@ inline GraphPtr export_graph(symbolic::VarNode* y, int* out_var, int placeholder
         if (opr->isinstance<PlaceholderOprMeta>()) {
             // (the reference infers a placeholder's shape when it is fed; the device graph declares it: a (T,3,3)
             // matrix, or -- for graphs with Slice / Concat -- a (batch, n) vector of the given length)
-            if (placeholder_vector_size > 0) check(sanm_graph_placeholder_vector(g.get(), placeholder_vector_size, &out));
-            else check(sanm_graph_placeholder(g.get(), &out));
+            const TensorShape* ps = placeholder_shape;
+            if (!ps || (ps->rank == 3 && ps->dim[1] == 3 && ps->dim[2] == 3)) check(sanm_graph_placeholder(g.get(), &out));
+            else if (ps->rank == 3) check(sanm_graph_placeholder_matrix(g.get(), (int)ps->dim[1], (int)ps->dim[2], &out));
+            else if (ps->rank <= 2) check(sanm_graph_placeholder_vector(g.get(), ps->rank == 2 ? (int)ps->dim[1] : 1, &out));
+            else throw SANMError{"hip adapter: placeholder of rank above 3"};
         } else if (opr->isinstance<ConstantOprMeta>()) {
             const TensorND& v = detail::mirror<detail::ConstantParam>(opr).val;
             const TensorShape& s = v.shape();
             // scalar [1], batched scalar (b) / (b,1), or batched matrix (b,r,c): libsanm/tensor.h:20-30
             const int64_t batch = s.rank == 1 && s.dim[0] == 1 ? 1 : (int64_t)s.dim[0];
             const int size = (int)(s.total_nr_elems() / (size_t)batch);
-            check(sanm_graph_constant(g.get(), v.ptr(), batch, size, &out));
+            if (s.rank == 3 && !(s.dim[1] == 3 && s.dim[2] == 3))
+                check(sanm_graph_constant_matrix(g.get(), v.ptr(), batch, (int)s.dim[1], (int)s.dim[2], &out));
+            else
+                check(sanm_graph_constant(g.get(), v.ptr(), batch, size, &out));
         } else if (opr->isinstance<LinearCombinationOprMeta>()) {
             const auto& p = detail::mirror<detail::LinearCombinationParam>(opr);
             std::vector<int> vars(opr->inputs().size());
@@ -298,7 +306,8 @@ public:
                       fp_t t0, TensorND v, const HyperParam& hyper_param = {}, const double* unknown_coords = nullptr)
             : DriverBase{x0} {
         int out;
-        GraphPtr g = export_graph(f, &out);
+        const TensorShape fed = remap_inp->out_shape();  // what the placeholder is fed with
+        GraphPtr g = export_graph(f, &out, &fed);
         DescPtr in = export_desc(*remap_inp), ro = export_desc(*remap_out, unknown_coords);
         sanm_hyper_param p = detail::make_hyper(hyper_param, false);
         sanm_anm_solver* s = nullptr;
@@ -316,7 +325,8 @@ public:
                  TensorND y, const HyperParam& hyper_param = {}, const double* unknown_coords = nullptr)
             : DriverBase{x0} {
         int out;
-        GraphPtr g = export_graph(f, &out);
+        const TensorShape fed = remap_inp->out_shape();  // what the placeholder is fed with
+        GraphPtr g = export_graph(f, &out, &fed);
         DescPtr in = export_desc(*remap_inp), ro = export_desc(*remap_out, unknown_coords);
         sanm_hyper_param p = detail::make_hyper(hyper_param, true);
         p.converge_rms = hyper_param.converge_rms;
@@ -354,7 +364,8 @@ public:
                       const double* unknown_coords = nullptr)
             : DriverBase{x0} {
         int out;
-        GraphPtr g = export_graph(f, &out);
+        const TensorShape fed = remap_inp->out_shape();  // what the placeholder is fed with
+        GraphPtr g = export_graph(f, &out, &fed);
         DescPtr in = export_desc(*remap_inp), ro = export_desc(*remap_out, unknown_coords);
         sanm_hyper_param p = detail::make_hyper(hyper_param, false);
         sanm_anm_solver* s = nullptr;

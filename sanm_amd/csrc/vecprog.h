@@ -303,6 +303,25 @@ VEC_HD double vec_det_selfbias_part(const VecProgDev& P, int x, int k, int64_t b
     return acc / (double)Pn;
 }
 
+// [a^k] of (x_0 + x_1 a + ... + x_{k-1} a^{k-1})^p for an integer p >= 3 by repeated multiplication of truncated
+// series: what prop_taylor_coeff_int (analytic_unary.cpp:46-92) computes by repeated squaring, for the elements
+// whose x_0 is a zero the division recurrence cannot start from (as pow_int_bias of tet_ops.h)
+VEC_HD double vec_pow_int_bias(const VecProgDev& P, int x, int k, int64_t b, int e, int p) {
+    double y[VEC_MAX_ORDER + 1], acc[VEC_MAX_ORDER + 1], nxt[VEC_MAX_ORDER + 1];
+    for (int i = 0; i < k; ++i) y[i] = vec_coef(P, x, i, b, e);
+    y[k] = 0;
+    for (int i = 0; i <= k; ++i) acc[i] = y[i];
+    for (int m = 2; m <= p; ++m) {
+        for (int d = 0; d <= k; ++d) {
+            double sum = 0;
+            for (int i = 0; i <= d; ++i) sum = __builtin_fma(acc[i], y[d - i], sum);
+            nxt[d] = sum;
+        }
+        for (int d = 0; d <= k; ++d) acc[d] = nxt[d];
+    }
+    return acc[k];
+}
+
 // One operator, one element (thread) e of batch item b, forward passes.  Elements beyond the output's size do
 // nothing; reductions (reduce_sum) are done by element 0.  xin: the placeholder's values of this order, [B][idim].
 VEC_HD void vec_forward(const VecProgDev& P, const VecOp& o, int mode, int k, int64_t b, int e, const double* xin) {
@@ -362,12 +381,13 @@ VEC_HD void vec_forward(const VecProgDev& P, const VecOp& o, int mode, int k, in
                 } else {
                     f = pow(v, pw);
                     kk = pw * pow(v, pw - 1.0);
-                    // analytic_unary.cpp:112-131: the division recurrence cannot start from a zero; the reference
-                    // continues integer exponents on a convolution path, this interpreter carries the square only
-                    // (word 0 <- 1: the reference's error; word 1 <- 2: unsupported here -- the values of Program's flags)
+                    // analytic_unary.cpp:112-131: the division recurrence cannot start from a zero; integer
+                    // exponents continue on the convolution path (vec_pow_int_bias), up to VEC_MAX_ORDER
+                    // (word 0 <- 1: the reference's error; word 1 <- 2: beyond that order -- the values of Program's flags)
                     if (fabs(v) < 1e-3 && !P.vars[x].is_const) {
                         const bool integer = pw > 0.5 && floor(pw) == pw;
-                        P.arena[P.flag + (integer ? 1 : 0)] = integer ? 2.0 : 1.0;
+                        if (!integer) P.arena[P.flag] = 1.0;
+                        else if (P.max_order > VEC_MAX_ORDER) P.arena[P.flag + 1] = 2.0;
                     }
                 }
                 vec_store(P, o.out, 0, true, b, e, f);
@@ -389,7 +409,11 @@ VEC_HD void vec_forward(const VecProgDev& P, const VecOp& o, int mode, int k, in
                                                     : __builtin_fma((double)i / (double)k, pw + 1.0, -1.0);
                             sb = __builtin_fma(p1 * p2, w, sb);
                         }
-                        sb /= vec_coef(P, x, 0, b, e);
+                        const double x0 = vec_coef(P, x, 0, b, e);
+                        if (!is_log && pw > 2.5 && floor(pw) == pw && fabs(x0) < 1e-3 && k <= VEC_MAX_ORDER)
+                            sb = vec_pow_int_bias(P, x, k, b, e, (int)pw);
+                        else
+                            sb /= x0;
                     }
                 }
                 *psb = sb;

@@ -293,6 +293,20 @@ def test_general_solve(api, name):
     _close(f(xt), ysol)
 
 
+@pytest.mark.parametrize("exp", [2, 5, 6, 8, 15])
+def test_general_solve_pow_with_zero_gradient(api, exp):
+    """pow-zg (tests/symbolic.cpp:611-628): x^1.7 + log(x)^exp from a start with one entry at exactly 1 -- an integer
+    power of a series through zero, which continues on the convolution path (analytic_unary.cpp:46-92)"""
+    r = np.random.default_rng(16)
+    f = lambda x: x ** 1.7 + np.log(x) ** exp
+    xsol = r.uniform(0.8, 1.5, (10, 8, 3))
+    ysol = f(xsol)
+    xinit = xsol * r.uniform(0.8, 1.2, xsol.shape)
+    xinit.flat[2] = 1.0
+    xt = _general_solve(api, lambda x, M: x.pow(1.7) + x.log().pow(exp), xinit, ysol)
+    _close(f(xt), ysol)
+
+
 # --------------------------------------------------------------------------- Symbolic.ANMImplicitSolver (:775-833)
 def test_implicit_solver(api):
     """pow(x + t dx, 1.5) held at pow(x0, 1.5) while t goes from 0 to 1: the input map carries t as its last column"""
