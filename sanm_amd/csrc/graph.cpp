@@ -252,13 +252,14 @@ int Graph::batched_mul_eye(int x, int dim) {
 
 void Graph::batched_svd_w(int x, bool require_rotation, int out[3]) {
     chk(x);
-    if (!(vars[x].rows == 3 && vars[x].cols == 3))
-        sanm_throw(SANM_ERR_UNSUPPORTED, "SVD-W of a (%d, %d) matrix: 3 x 3 only", vars[x].rows, vars[x].cols);
+    sanm_check(vars[x].is_matrix() && vars[x].rows == vars[x].cols, "invalid shape for SVD-W: (%d, %d)", vars[x].rows,
+               vars[x].cols);
+    const int n = vars[x].rows;
     GraphOp op;
     op.type = OP_SVDW;
     op.flags = require_rotation ? OP_FLAG_REQUIRE_ROT : 0;
     op.in = {x};
-    int first = add(std::move(op), {{3, 3}, {3, 0}, {3, 3}});
+    int first = add(std::move(op), {{n, n}, {n, 0}, {n, n}});
     out[0] = first;
     out[1] = first + 1;
     out[2] = first + 2;

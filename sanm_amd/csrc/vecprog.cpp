@@ -65,20 +65,22 @@ VecProgram::VecProgram(Backend* be, const Graph& g, int out_var, int64_t B, int 
         switch (op.type) {
             case OP_PLACEHOLDER: case OP_CONSTANT: case OP_LINCOMB: case OP_MULTIPLY: case OP_LOG: case OP_POW:
             case OP_REDUCE_SUM: case OP_SLICE: case OP_CONCAT: case OP_MATMUL: case OP_MATINVMUL: case OP_DET:
-            case OP_TRANSPOSE: case OP_MULEYE: break;
+            case OP_TRANSPOSE: case OP_MULEYE: case OP_SVDW: break;
             default:
-                sanm_throw(SANM_ERR_UNSUPPORTED,
-                           "operator %d in a graph on the vector interpreter (SVD-W runs in graphs of (T,3,3) "
-                           "matrices and batched scalars only)", (int)op.type);
+                sanm_throw(SANM_ERR_UNSUPPORTED, "operator %d in a graph on the vector interpreter", (int)op.type);
         }
         bool all_const = op.type != OP_PLACEHOLDER;
         for (int i = 0; i < o.nin; ++i) {
             o.in[i] = m_var_map[op.in[i]];
+            if (o.in[i] < 0 && g.ops[g.vars[op.in[i]].producer].type == OP_SVDW)
+                sanm_throw(SANM_ERR_UNSUPPORTED, "U or S of batched_svd_w on the vector interpreter: only W (the polar "
+                                                 "recurrences); the full SVD-W series run in (T,3,3) graphs");
             sanm_check(o.in[i] >= 0, "operand of operator %d is not computed", oi);
             all_const = all_const && m_vars[o.in[i]].is_const;
         }
-        sanm_check(op.out.size() == 1, "vector graphs: single-output operators only");
-        const int gv = op.out[0], sz = g.vars[gv].size;
+        // (SVD-W: W is the output this interpreter carries; U and S stay unmapped)
+        sanm_check(op.out.size() == 1 || op.type == OP_SVDW, "vector graphs: single-output operators only");
+        const int gv = op.type == OP_SVDW ? op.out[2] : op.out[0], sz = g.vars[gv].size;
         sanm_check(sz >= 1 && sz <= VEC_MAX_SIZE, "vector of %d elements: at most %d", sz, VEC_MAX_SIZE);
         VecVar v{};
         v.size = sz;
@@ -132,6 +134,17 @@ VecProgram::VecProgram(Backend* be, const Graph& g, int out_var, int64_t B, int 
             ops.push_back(prep);
             ops.push_back(o);
             o.type = VOP_MATINV_FIN;
+        } else if (op.type == OP_SVDW) {
+            const int n = v.rows;
+            sanm_check(n <= VEC_MAX_DIM, "SVD-W of a %d x %d matrix: at most %d", n, n, VEC_MAX_DIM);
+            o.aux0 = take(B * sz);
+            o.aux1 = take(B * n);
+            o.aux2 = take(B * 2 * sz);
+            o.aux3 = take((int64_t)(max_order + 1) * B * sz);
+            o.nact = sz;
+            ops.push_back(o);
+            o.type = VOP_SVDW_FIN;
+            o.nact = 1;
         } else if (op.type == OP_DET) {
             const int m = m_vars[o.in[0]].rows;
             sanm_check(m <= VEC_MAX_DIM, "determinant of a %d x %d matrix: at most %d", m, m, VEC_MAX_DIM);
@@ -149,6 +162,8 @@ VecProgram::VecProgram(Backend* be, const Graph& g, int out_var, int64_t B, int 
     }
     sanm_check(nr_placeholder == 1, "exactly one placeholder input is supported, got %d", nr_placeholder);
     m_out_graph_var = out_var;
+    if (m_var_map[out_var] < 0 && g.ops[g.vars[out_var].producer].type == OP_SVDW)
+        sanm_throw(SANM_ERR_UNSUPPORTED, "U or S of batched_svd_w as the output of a graph on the vector interpreter");
     m_dev.out_var = m_var_map[out_var];
     sanm_check(!m_vars[m_dev.out_var].is_const, "the output does not depend on the input");
     m_dev.odim = m_vars[m_dev.out_var].size;

@@ -43,6 +43,7 @@ constexpr int VEC_MAX_ORDER = 32;  // highest expansion order of a graph with a 
 constexpr int VOP_INV_PREP = 32;    // X0^-1 of the mat_inv_mul that follows, order 0 only (thread 0)
 constexpr int VOP_MATINV_FIN = 33;  // second product of mat_inv_mul's recurrence
 constexpr int VOP_DET_FIN = 34;     // determinant: partial sums -> self-bias; cof(X0) : X_k + self-bias
+constexpr int VOP_SVDW_FIN = 35;    // SVD-W (W only): the dense algebra of the polar recurrence (thread 0)
 
 struct VecVar {
     int64_t coef;   // arena offset of coefficient 0 of batch 0; order k, batch b at coef + (k * B + b) * size
@@ -66,6 +67,9 @@ struct VecOp {
     // product at aux2 (all [B][m*m]).  DET (+ FIN): cof(X0) at aux0 [B][m*m], self-bias at aux1 [B], the threads'
     // partial sums at aux2 [B][VEC_MAX_SIZE]
     int64_t aux2;
+    // SVDW (+ FIN; only W is read: the polar recurrences of tensor_svd.cpp:389-475): U0 at aux0 [B][n*n], S0 at aux1
+    // [B][n], (Bm - Bp, Bpw) at aux2 [B][2][n*n], the polar factors P_k at aux3 [order][B][n*n]
+    int64_t aux3;
 };
 
 struct VecProgDev {
@@ -223,6 +227,146 @@ VEC_HD void vec_inverse(double* a, double* inv, int n) {
             }
         }
     }
+}
+
+// ---- SVD-W of an n x n matrix (tensor_svd.cpp:48-145) --------------------------------------------------------------
+VEC_HD double vec_clip_div(double x, double y) { return x * y / (y * y + 1e-12); }  // tensor_svd.cpp:28-31
+// One-sided Jacobi SVD: a = U diag(s) V', s descending and >= 0 (svd3 of tet_ops.h at a run-time size; the reference:
+// Eigen JacobiSVD, tensor_svd.cpp:66-87)
+VEC_HD void vec_svd_n(const double* a, int n, double* U, double* S, double* V) {
+    double B[VEC_MAX_DIM * VEC_MAX_DIM];  // working copy, columns get orthogonalised: B = A V
+    for (int i = 0; i < n * n; ++i) B[i] = a[i];
+    for (int i = 0; i < n * n; ++i) V[i] = (i / n == i % n) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int i = 0; i < n; ++i) {
+                    alpha += B[i * n + p] * B[i * n + p];
+                    beta += B[i * n + q] * B[i * n + q];
+                    gamma += B[i * n + p] * B[i * n + q];
+                }
+                const double lim = 1e-32 + 1e-30 * alpha * beta;
+                if (gamma * gamma <= lim) continue;
+                const double rel = fabs(gamma) / sqrt(alpha * beta);
+                if (rel > off) off = rel;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                for (int i = 0; i < n; ++i) {
+                    const double bp = B[i * n + p], bq = B[i * n + q];
+                    B[i * n + p] = cs * bp - sn * bq;
+                    B[i * n + q] = sn * bp + cs * bq;
+                    const double vp = V[i * n + p], vq = V[i * n + q];
+                    V[i * n + p] = cs * vp - sn * vq;
+                    V[i * n + q] = sn * vp + cs * vq;
+                }
+            }
+        if (off < 1e-15) break;
+    }
+    double sv[VEC_MAX_DIM];
+    int idx[VEC_MAX_DIM];
+    for (int j = 0; j < n; ++j) {
+        double q = 0;
+        for (int i = 0; i < n; ++i) q += B[i * n + j] * B[i * n + j];
+        sv[j] = sqrt(q);
+        idx[j] = j;
+    }
+    for (int i = 1; i < n; ++i) {  // descending, stable
+        const int key = idx[i];
+        int j = i - 1;
+        while (j >= 0 && sv[idx[j]] < sv[key]) {
+            idx[j + 1] = idx[j];
+            --j;
+        }
+        idx[j + 1] = key;
+    }
+    double Vs[VEC_MAX_DIM * VEC_MAX_DIM];
+    const double smax = sv[idx[0]];
+    for (int j = 0; j < n; ++j) {
+        const int k = idx[j];
+        S[j] = sv[k];
+        const bool tiny = !(sv[k] > 1e-300 + 1e-15 * smax);
+        for (int i = 0; i < n; ++i) {
+            Vs[i * n + j] = V[i * n + k];
+            U[i * n + j] = tiny ? 0.0 : B[i * n + k] / sv[k];
+        }
+    }
+    for (int i = 0; i < n * n; ++i) V[i] = Vs[i];
+    // complete U for (numerically) zero singular values: the unit vector with the largest part outside the span so far
+    for (int j = 0; j < n; ++j) {
+        if (S[j] > 1e-300 + 1e-15 * smax) continue;
+        double best = -1, w[VEC_MAX_DIM];
+        for (int m = 0; m < n; ++m) {
+            double c[VEC_MAX_DIM];
+            for (int i = 0; i < n; ++i) c[i] = (i == m) ? 1.0 : 0.0;
+            for (int q = 0; q < n; ++q) {  // columns set so far: the non-zero ones and the completed ones before j
+                if (q == j || (q > j && !(S[q] > 1e-300 + 1e-15 * smax))) continue;
+                double d = 0;
+                for (int i = 0; i < n; ++i) d += c[i] * U[i * n + q];
+                for (int i = 0; i < n; ++i) c[i] -= d * U[i * n + q];
+            }
+            double nn = 0;
+            for (int i = 0; i < n; ++i) nn += c[i] * c[i];
+            if (nn > best) {
+                best = nn;
+                for (int i = 0; i < n; ++i) w[i] = c[i];
+            }
+        }
+        const double inv = 1.0 / sqrt(best);
+        for (int i = 0; i < n; ++i) U[i * n + j] = w[i] * inv;
+    }
+}
+// Which singular values get negated so that det(W) = +1: the selection loop of tensor_svd.cpp:88-128 (note the
+// reference's `i = j` inside a `for(...; ++i)`); a bit mask
+VEC_HD int vec_rotation_fix_mask(const double* ms, int n) {
+    const double EPS = 1e-3;
+    int best_idx = -1, best_idx_nr = n + 1;
+    for (int i = 0; i < n; ++i) {
+        int j = i + 1;
+        while (j < n && fabs(ms[i] - ms[j]) < EPS) ++j;
+        const int nr = j - i;
+        if (nr <= best_idx_nr || (nr == best_idx_nr + 1 && nr % 2 == 1)) {
+            best_idx = i;
+            best_idx_nr = nr;
+            if (nr == 1) break;
+        }
+        i = j;
+    }
+    int mask = 0;
+    if (best_idx_nr == 1 || best_idx_nr % 2 == 0) {
+        mask = 1 << best_idx;
+    } else {
+        for (int i = best_idx; i < best_idx + best_idx_nr; ++i) mask |= 1 << i;
+    }
+    return mask;
+}
+// M = U S U' W with W = U V' (tensor_svd.cpp:48-145)
+VEC_HD void vec_svdw_n(const double* m, int n, bool require_rotation, double* U, double* S, double* W) {
+    double V[VEC_MAX_DIM * VEC_MAX_DIM];
+    vec_svd_n(m, n, U, S, V);
+    if (require_rotation) {
+        double t[VEC_MAX_DIM * VEC_MAX_DIM];
+        for (int i = 0; i < n * n; ++i) t[i] = U[i];
+        const double du = vec_lu_det(t, n);
+        for (int i = 0; i < n * n; ++i) t[i] = V[i];
+        const double dv = vec_lu_det(t, n);
+        if ((du < 0) != (dv < 0)) {
+            const int mask = vec_rotation_fix_mask(S, n);
+            for (int j = 0; j < n; ++j)
+                if (mask >> j & 1) {
+                    S[j] = -S[j];
+                    for (int i = 0; i < n; ++i) U[i * n + j] = -U[i * n + j];
+                }
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            double acc = 0;
+            for (int q = 0; q < n; ++q) acc = __builtin_fma(U[i * n + q], V[j * n + q], acc);
+            W[i * n + j] = acc;
+        }
 }
 
 // Thread e's share of the determinant's self-bias at order k: the coefficient of a^k in det(sum_{i<k} X_i a^i)
@@ -589,6 +733,123 @@ VEC_HD void vec_forward(const VecProgDev& P, const VecOp& o, int mode, int k, in
             vec_store(P, o.out, k, in_coeff, b, 0, sb);
             break;
         }
+        case OP_SVDW: {
+            // oprs/linalg.cpp:483-615 with only W read (pw_mode, :533-560): order 0 by thread 0; at BIAS(k) the three
+            // convolutions Bm - Bp = sum M_i M_{k-i}' - P_i' P_{k-i} and Bpw = sum P_i W_{k-i} (0 < i < k), an
+            // element per thread
+            const int x = o.in[0];
+            const int n = ov.rows, nn = n * n;
+            if (mode == PASS_EVAL0) {
+                if (e != 0) break;
+                double m[VEC_MAX_DIM * VEC_MAX_DIM], U[VEC_MAX_DIM * VEC_MAX_DIM], S[VEC_MAX_DIM], W[VEC_MAX_DIM * VEC_MAX_DIM];
+                for (int q = 0; q < nn; ++q) m[q] = vec_coef(P, x, 0, b, q);
+                vec_svdw_n(m, n, o.flags & OP_FLAG_REQUIRE_ROT, U, S, W);
+                for (int q = 0; q < nn; ++q) {
+                    P.arena[o.aux0 + b * nn + q] = U[q];
+                    vec_store(P, o.out, 0, true, b, q, W[q]);
+                }
+                for (int q = 0; q < n; ++q) P.arena[o.aux1 + b * n + q] = S[q];
+                break;
+            }
+            if (mode != PASS_BIAS || e >= nn) break;
+            const int r = e / n, c = e % n;
+            double d = 0, bpw = 0;
+            for (int i = 1; i < k; ++i) {
+                const double* Pi = P.arena + o.aux3 + ((int64_t)i * P.B + b) * nn;
+                const double* Pk = P.arena + o.aux3 + ((int64_t)(k - i) * P.B + b) * nn;
+                for (int j = 0; j < n; ++j) {
+                    d = __builtin_fma(vec_coef(P, x, i, b, r * n + j), vec_coef(P, x, k - i, b, c * n + j), d);
+                    d = __builtin_fma(-Pi[j * n + r], Pk[j * n + c], d);
+                    bpw = __builtin_fma(Pi[r * n + j], vec_coef(P, o.out, k - i, b, j * n + c), bpw);
+                }
+            }
+            P.arena[o.aux2 + (b * 2 + 0) * nn + e] = d;
+            P.arena[o.aux2 + (b * 2 + 1) * nn + e] = bpw;
+            break;
+        }
+        case VOP_SVDW_FIN: {
+            // svd_w_taylor_fwd_p, tensor_svd.cpp:389-475 (thread 0): with V0 = W0' U0,
+            //   Q = S0 V0' Mk' U0;  E = U0' (Bm - Bp)' U0 + Q + Q';  X = clip_div(E_ij, s_i + s_j)
+            //   Pk = (U0 X U0')';  Wk = U0 diag(clip_div(1, s_i)) U0' (Mk - Bpw - Pk W0)
+            if (mode == PASS_EVAL0 || e != 0) break;
+            const int x = o.in[0];
+            const int n = ov.rows, nn = n * n;
+            const double* U0 = P.arena + o.aux0 + b * nn;
+            const double* S0 = P.arena + o.aux1 + b * n;
+            const double* D = P.arena + o.aux2 + (b * 2 + 0) * nn;
+            const double* Bpw = P.arena + o.aux2 + (b * 2 + 1) * nn;
+            double W0[VEC_MAX_DIM * VEC_MAX_DIM], Mk[VEC_MAX_DIM * VEC_MAX_DIM], V0[VEC_MAX_DIM * VEC_MAX_DIM];
+            double T0[VEC_MAX_DIM * VEC_MAX_DIM], T1[VEC_MAX_DIM * VEC_MAX_DIM], X[VEC_MAX_DIM * VEC_MAX_DIM];
+            for (int q = 0; q < nn; ++q) {
+                W0[q] = vec_coef(P, o.out, 0, b, q);
+                Mk[q] = vec_cur(P, x, k, in_coeff, b, q);
+            }
+            auto at = [n](const double* a, int i, int j) { return a[i * n + j]; };
+            for (int i = 0; i < n; ++i)  // V0 = W0' U0
+                for (int j = 0; j < n; ++j) {
+                    double acc = 0;
+                    for (int q = 0; q < n; ++q) acc = __builtin_fma(at(W0, q, i), at(U0, q, j), acc);
+                    V0[i * n + j] = acc;
+                }
+            // T0 = D' U0 ; T1 = Mk' U0
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
+                    double a0 = 0, a1 = 0;
+                    for (int q = 0; q < n; ++q) {
+                        a0 = __builtin_fma(at(D, q, i), at(U0, q, j), a0);
+                        a1 = __builtin_fma(at(Mk, q, i), at(U0, q, j), a1);
+                    }
+                    T0[i * n + j] = a0;
+                    T1[i * n + j] = a1;
+                }
+            // E = U0' T0 + Q + Q' with Q_ij = s_i (V0' T1)_ij ; held in X, then divided
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
+                    double acc = 0, qij = 0, qji = 0;
+                    for (int q = 0; q < n; ++q) {
+                        acc = __builtin_fma(at(U0, q, i), at(T0, q, j), acc);
+                        qij = __builtin_fma(at(V0, q, i), at(T1, q, j), qij);
+                        qji = __builtin_fma(at(V0, q, j), at(T1, q, i), qji);
+                    }
+                    X[i * n + j] = vec_clip_div(acc + S0[i] * qij + S0[j] * qji, S0[i] + S0[j]);
+                }
+            // Pk' = U0 X U0'  (T0 = U0 X, then Pk[r][c] = sum_j T0[c][j] U0[r][j])
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
+                    double acc = 0;
+                    for (int q = 0; q < n; ++q) acc = __builtin_fma(at(U0, i, q), at(X, q, j), acc);
+                    T0[i * n + j] = acc;
+                }
+            double* Pk = T1;
+            for (int r = 0; r < n; ++r)
+                for (int c = 0; c < n; ++c) {
+                    double acc = 0;
+                    for (int j = 0; j < n; ++j) acc = __builtin_fma(at(T0, c, j), at(U0, r, j), acc);
+                    Pk[r * n + c] = acc;
+                }
+            if (in_coeff)
+                for (int q = 0; q < nn; ++q) P.arena[o.aux3 + ((int64_t)k * P.B + b) * nn + q] = Pk[q];
+            // R = Mk - Bpw - Pk W0 (into X); Z = diag(1/s) U0' R (into T0); Wk = U0 Z
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
+                    double acc = Mk[i * n + j] - Bpw[i * n + j];
+                    for (int q = 0; q < n; ++q) acc = __builtin_fma(-at(Pk, i, q), at(W0, q, j), acc);
+                    X[i * n + j] = acc;
+                }
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
+                    double acc = 0;
+                    for (int q = 0; q < n; ++q) acc = __builtin_fma(at(U0, q, i), at(X, q, j), acc);
+                    T0[i * n + j] = acc * vec_clip_div(1.0, S0[i]);
+                }
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
+                    double acc = 0;
+                    for (int q = 0; q < n; ++q) acc = __builtin_fma(at(U0, i, q), at(T0, q, j), acc);
+                    vec_store(P, o.out, k, in_coeff, b, i * n + j, acc);
+                }
+            break;
+        }
         default: break;
     }
 }
@@ -711,6 +972,40 @@ VEC_HD void vec_backward(const VecProgDev& P, const VecOp& o, int64_t b, int e, 
         case OP_DET: {  // oprs/linalg.cpp:234-246: g_X = g_y cof(X0)
             const int x = o.in[0], m = P.vars[x].rows;
             if (e < m * m && !P.vars[x].is_const) add(x, e, go[0] * P.arena[o.aux0 + b * m * m + e]);
+            break;
+        }
+        case OP_SVDW: {
+            // dW/dM of tensor_svd.cpp:147-273 applied to the gradient row: with G' = U0' g_W V0 (V0 = W0' U0),
+            // g_M[k,l] = sum_{a != b} G'[a,b] clip_div(U0[k,a] V0[l,b] - U0[k,b] V0[l,a], s_a + s_b)
+            const int x = o.in[0];
+            const int n = ov.rows, nn = n * n;
+            if (e >= nn || P.vars[x].is_const) break;
+            const int kk = e / n, l = e % n;
+            const double* U0 = P.arena + o.aux0 + b * nn;
+            const double* S0 = P.arena + o.aux1 + b * n;
+            double V0[VEC_MAX_DIM * VEC_MAX_DIM], T[VEC_MAX_DIM * VEC_MAX_DIM];
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
+                    double acc = 0;
+                    for (int q = 0; q < n; ++q) acc = __builtin_fma(vec_coef(P, o.out, 0, b, q * n + i), U0[q * n + j], acc);
+                    V0[i * n + j] = acc;
+                }
+            for (int i = 0; i < n; ++i)  // T = g_W V0
+                for (int j = 0; j < n; ++j) {
+                    double acc = 0;
+                    for (int q = 0; q < n; ++q) acc = __builtin_fma(go[i * n + q], V0[q * n + j], acc);
+                    T[i * n + j] = acc;
+                }
+            double s = 0;
+            for (int a = 0; a < n; ++a)
+                for (int c = 0; c < n; ++c) {
+                    if (a == c) continue;
+                    double gp = 0;  // G'[a,c] = sum_i U0[i,a] T[i,c]
+                    for (int i = 0; i < n; ++i) gp = __builtin_fma(U0[i * n + a], T[i * n + c], gp);
+                    const double num = U0[kk * n + a] * V0[l * n + c] - U0[kk * n + c] * V0[l * n + a];
+                    s = __builtin_fma(gp, vec_clip_div(num, S0[a] + S0[c]), s);
+                }
+            add(x, e, s);
             break;
         }
         default: break;

@@ -307,6 +307,79 @@ def test_general_solve_pow_with_zero_gradient(api, exp):
     _close(f(xt), ysol)
 
 
+# ----------------------------------------------------------------------------- Symbolic.PolarDecompSolve (:677-728)
+def _svdw(x, rot):
+    from oracle import tensor_ops as T_
+    return T_.batched_svd_w(x, rot)
+
+
+def _polar_case(seed, rot, eq_singular):
+    r = np.random.default_rng(seed)
+    batch, n = 7, 4
+    x0 = r.uniform(-1, 1, (batch, n, n))
+    dx = r.uniform(-0.05, 0.05, x0.shape)
+    if eq_singular:  # make_eq_singular (:698-709): s_1 := s_0, M = U S U' W
+        u, sv, w = _svdw(x0, rot)
+        sv = sv.copy()
+        sv[:, 1] = sv[:, 0]
+        x0 = np.einsum("bij,bj,bkj,bkl->bil", u, sv, u, w)
+    xsol = x0 + dx
+    return x0, xsol, xsol - _svdw(xsol, rot)[2]
+
+
+@pytest.mark.parametrize("name,seed,rot,eq_singular", [
+    ("simple", 17, False, False), ("simple-rot", 17, True, False),
+    ("eqs-x0", 22, False, True), ("eqs-x0-rot", 22, True, True), ("eqs-x0-b", 27, False, True),
+    ("eqs-x0-slow", 26, True, True)])
+def test_polar_decomp_solve(api, name, seed, rot, eq_singular):
+    """x - W(x) = y solved from x0 = xsol - dx for 4 x 4 matrices (SVD-W outside 3 x 3, only W read: the polar
+    recurrences on the vector interpreter), also from starts whose two largest singular values coincide.  How fast
+    those converge depends on the draw (the reference remarks on it, :719); the oracle's ANMEqnSolver runs beside the
+    device on the same input: same number of iterations, same residuals."""
+    from oracle.anm import ANMEqnSolver as OEqn
+    x0, xsol, ysol = _polar_case(seed, rot, eq_singular)
+    ident = sp.identity(x0.size, format="csr")
+    build = lambda x, M: x - x.batched_svd_w(rot)[2]
+    g = api.graph()
+    di = A.SparseLinearDesc(api, ident)
+    dsol = A.ANMEqnSolver(api, build(g.placeholder_matrix(4, 4), A), di, di, x0, -ysol,
+                          api.default_hyper(order=8, use_pade=0))
+    osol = OEqn(build(S.placeholder(S.ComputingGraph()), S), ident, ident, x0.shape, x0, -ysol.ravel(),
+                OHyper(order=8, use_pade=False))
+    it = 0
+    while not dsol.converged():
+        assert not osol.converged
+        assert dsol.residual_rms() == pytest.approx(osol.residual_rms, rel=1e-5)
+        it += 1
+        assert it <= 40  # anm_general_solve(..., 40)
+        dsol.next_iter()
+        osol.next_iter()
+    assert osol.converged
+    _close(dsol.get_x().reshape(x0.shape), xsol, margin=1e-7)
+    assert np.abs(dsol.get_x() - osol.get_x()).max() <= 1e-7
+
+
+def test_polar_decomp_solve_failing_draw(api):
+    """a draw on which the reference algorithm itself gives up (the order-8 coefficient fails the orthogonality check
+    of anm.cpp:271-285): the device reports the same assertion"""
+    from oracle.anm import ANMEqnSolver as OEqn
+    x0, xsol, ysol = _polar_case(23, True, True)
+    ident = sp.identity(x0.size, format="csr")
+    build = lambda x, M: x - x.batched_svd_w(True)[2]
+    with pytest.raises(AssertionError, match="xdot"):
+        o = OEqn(build(S.placeholder(S.ComputingGraph()), S), ident, ident, x0.shape, x0, -ysol.ravel(),
+                 OHyper(order=8, use_pade=False))
+        for _ in range(60):
+            o.next_iter()
+    g = api.graph()
+    di = A.SparseLinearDesc(api, ident)
+    with pytest.raises(A.SanmAssertionError, match="xdot"):
+        d = A.ANMEqnSolver(api, build(g.placeholder_matrix(4, 4), A), di, di, x0, -ysol,
+                           api.default_hyper(order=8, use_pade=0))
+        for _ in range(60):
+            d.next_iter()
+
+
 # --------------------------------------------------------------------------- Symbolic.ANMImplicitSolver (:775-833)
 def test_implicit_solver(api):
     """pow(x + t dx, 1.5) held at pow(x0, 1.5) while t goes from 0 to 1: the input map carries t as its last column"""
