@@ -60,13 +60,15 @@ int sanm_graph_placeholder(sanm_graph* g, int* var);                       /* op
  *   sanm_graph_concat: concatenation along axis 1.
  * They run on a vector interpreter of their own on the device (one workgroup per batch item) and are served by the
  * operator-level API (sanm_taylor_*: push_xi, compute_next_order_bias, get_jacobian -> (B, odim, idim)); the ANM
- * drivers and SVD-W stay with (T,3,3) graphs.  Vectors of up to 64 elements.
+ * drivers run them as well (a dense LU with partial pivoting solves their small general systems).  Vectors of up
+ * to 64 elements.
  *
  * Matrices of other sizes than 3 x 3 (libsanm/tensor_linalg.cpp:107-210 dynamic sizes; tests/symbolic.cpp:179-424 run
  * the operators at 4 x 4, 4 x 6, 5 x 5, 7 x 7): sanm_graph_placeholder_matrix declares a (batch, rows, cols) input,
  * sanm_graph_constant_matrix a constant of that rank.  batched_matmul (any conforming shapes), batched_transpose,
  * batched_mat_inv_mul / batched_det (square, up to 8 x 8; the determinant's series by the expansion up to 4 x 4 and by
- * the DFT of the polynomial matrix above, tensor_polymat.cpp:30-136, :325-379) and batched_mul_eye(dim) take them;
+ * the DFT of the polynomial matrix above, tensor_polymat.cpp:30-136, :325-379), batched_mul_eye(dim) and
+ * batched_svd_w with only W read (the polar recurrences, tensor_svd.cpp:389-475) take them;
  * a graph with any shape other than (T,3,3) / (T,1) runs on the same interpreter as the vector graphs. */
 int sanm_graph_placeholder_vector(sanm_graph* g, int size, int* var);
 int sanm_graph_placeholder_matrix(sanm_graph* g, int rows, int cols, int* var);
