@@ -104,6 +104,9 @@ struct DescDeleter {
 struct SolverDeleter {
     void operator()(sanm_anm_solver* s) const { sanm_anm_solver_destroy(s); }
 };
+struct TaylorDeleter {
+    void operator()(sanm_taylor_prop* p) const { sanm_taylor_destroy(p); }
+};
 
 //! which analytic function a trait is: evaluates it at 2 and 3 (log: ln 2, ln 3; pow p: 2^p, 3^p)
 inline bool classify_unary(const UnaryAnalyticTrait& trait, double* exponent) {
@@ -297,6 +300,58 @@ public:
     }
 };
 }  // namespace detail
+
+//! symbolic::TaylorCoeffProp for a single-input graph (libsanm/symbolic.h:337-383; what check_taylor_prop of
+//! tests/symbolic.cpp:76-137 and ANMDriverHelper::solve_expansion_coeffs drive): push_xi / compute_next_order_bias
+//! alternate; the Jacobian comes back as its dense blocks.  The placeholder's shape is given up front (the
+//! reference learns it at the first push_xi).
+class TaylorCoeffProp : public NonCopyable {
+    GraphPtr m_g;
+    DescPtr m_ident;
+    std::unique_ptr<sanm_taylor_prop, detail::TaylorDeleter> m_p;
+    size_t m_batch = 0, m_idim = 0;
+    int m_odim = 0;
+    TensorND m_out, m_bias;
+
+public:
+    TaylorCoeffProp(symbolic::VarNode* output, const TensorShape& x_shape, int max_order) {
+        int out;
+        m_g = export_graph(output, &out, &x_shape);
+        const size_t n = x_shape.total_nr_elems();
+        m_batch = x_shape.dim[0];
+        m_idim = n / m_batch;
+        std::vector<uint64_t> rowptr(n + 1), idx(n);
+        std::vector<double> one(n, 1.0);
+        for (size_t i = 0; i < n; ++i) rowptr[i] = idx[i] = i;
+        rowptr[n] = n;
+        sanm_sparse_desc* raw = nullptr;
+        check(sanm_sparse_desc_create((int64_t)n, (int64_t)n, rowptr.data(), idx.data(), one.data(), &raw));
+        m_ident.reset(raw);
+        sanm_taylor_prop* p = nullptr;
+        check(sanm_taylor_create(m_g.get(), out, m_ident.get(), max_order, &p));
+        m_p.reset(p);
+        check(sanm_taylor_output_size(p, &m_odim));
+        m_out.set_shape({m_batch, (size_t)m_odim});
+        m_bias.set_shape({m_batch, (size_t)m_odim});
+    }
+    //! the coefficient at the output node, (batch, elements of the output) -- reshape as needed
+    const TensorND& push_xi(const TensorND& xi) {
+        check(sanm_taylor_push_xi(m_p.get(), xi.ptr(), m_out.woptr()));
+        return m_out;
+    }
+    const TensorND& compute_next_order_bias() {
+        check(sanm_taylor_compute_next_order_bias(m_p.get(), m_bias.woptr()));
+        return m_bias;
+    }
+    const TensorND& get_prev_next_order_bias() const { return m_bias; }
+    //! d output / d input per batch item: (batch, output elements, input elements), what StSparseLinearTrans holds
+    //! in its batched-full form (libsanm/sparse_linear_trans.h)
+    TensorND get_jacobian_blocks() {
+        TensorND j{TensorShape{m_batch, (size_t)m_odim, m_idim}};
+        check(sanm_taylor_get_jacobian(m_p.get(), j.woptr()));
+        return j;
+    }
+};
 
 //! f(x) + t v = 0 (libsanm/anm.h:209-243; constructed at fea/main.cpp:393-399)
 class ANMSolverVecScale final : public detail::DriverBase {

