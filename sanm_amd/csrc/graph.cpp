@@ -179,14 +179,20 @@ int Graph::log(int x) {
 int Graph::reduce_sum(int x, int axis) {
     chk(x);
     sanm_check(axis != 0, "can not reduce on batch dim");
-    // reduce.cpp:11-102: axis -1 flattens everything behind the batch axis; axis 1 of a (batch, n) tensor is the
-    // same sum.  One axis of a (batch, rows, cols) matrix is not implemented.
-    if (!(axis == -1 || (axis == 1 && !vars[x].is_matrix())))
-        sanm_throw(SANM_ERR_UNSUPPORTED, "reduce_sum: axis %d of a (batch, %d, %d) tensor (axis -1, or axis 1 of a "
-                                         "(batch, n) tensor)", axis, vars[x].rows, vars[x].cols);
+    // reduce.cpp:11-102 (keepdim): axis -1 flattens everything behind the batch axis -> (batch, 1); axis 1 of a
+    // (batch, n) tensor is the same sum; one axis of a (batch, rows, cols) matrix gives (batch, 1, cols) /
+    // (batch, rows, 1).  (axis -2, the sum over the batch as well, has no batched output: not on the device.)
+    const bool mat = vars[x].is_matrix();
+    if (!(axis == -1 || (axis == 1 && !mat) || (mat && (axis == 1 || axis == 2))))
+        sanm_throw(SANM_ERR_UNSUPPORTED, "reduce_sum: axis %d of a (batch, %d, %d) tensor", axis, vars[x].rows,
+                   vars[x].cols);
     GraphOp op;
     op.type = OP_REDUCE_SUM;
     op.in = {x};
+    if (mat && axis != -1) {
+        op.begin = axis;  // 1: over the rows, 2: over the columns
+        return add(std::move(op), {axis == 1 ? Shape{1, vars[x].cols} : Shape{vars[x].rows, 1}});
+    }
     return add(std::move(op), {{1, 0}});
 }
 

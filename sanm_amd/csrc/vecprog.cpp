@@ -117,8 +117,8 @@ VecProgram::VecProgram(Backend* be, const Graph& g, int out_var, int64_t B, int 
             o.aux1 = take(B * sz);
         } else if (op.type == OP_MULTIPLY) {
             o.aux1 = take(B * sz);
-        } else if (op.type == OP_SLICE) {
-            o.begin = op.begin;
+        } else if (op.type == OP_SLICE || op.type == OP_REDUCE_SUM) {
+            o.begin = op.begin;  // (REDUCE_SUM: 0 = everything, 1 / 2 = one axis of a matrix)
         } else if (op.type == OP_MATMUL) {
             o.aux1 = take(B * sz);
         } else if (op.type == OP_MATINVMUL) {

@@ -569,6 +569,16 @@ VEC_HD void vec_forward(const VecProgDev& P, const VecOp& o, int mode, int k, in
             break;
         }
         case OP_REDUCE_SUM: {  // reduce.cpp:11-102, axis -1: element 0 sums
+            if (o.begin == 1 || o.begin == 2) {  // one axis of a matrix: (1 x cols) or (rows x 1)
+                const int ir = P.vars[o.in[0]].rows, ic = P.vars[o.in[0]].cols;
+                double sum = 0;
+                if (o.begin == 1)
+                    for (int i = 0; i < ir; ++i) sum += vec_cur(P, o.in[0], k, in_coeff, b, i * ic + e);
+                else
+                    for (int j = 0; j < ic; ++j) sum += vec_cur(P, o.in[0], k, in_coeff, b, e * ic + j);
+                vec_store(P, o.out, k, in_coeff, b, e, sum);
+                break;
+            }
             const int isz = P.vars[o.in[0]].size;
             double sum = 0;
             for (int i = 0; i < isz; ++i) sum += vec_cur(P, o.in[0], k, in_coeff, b, i);
@@ -895,7 +905,10 @@ VEC_HD void vec_backward(const VecProgDev& P, const VecOp& o, int64_t b, int e, 
             if (e < osz && !P.vars[o.in[0]].is_const) add(o.in[0], e, go[e] * P.arena[o.aux0 + b * osz + e]);
             break;
         case OP_REDUCE_SUM:
-            if (e < P.vars[o.in[0]].size && !P.vars[o.in[0]].is_const) add(o.in[0], e, go[0]);
+            if (e < P.vars[o.in[0]].size && !P.vars[o.in[0]].is_const) {
+                const int ic = P.vars[o.in[0]].cols;
+                add(o.in[0], e, o.begin == 1 ? go[e % ic] : (o.begin == 2 ? go[e / ic] : go[0]));
+            }
             break;
         case OP_SLICE:
             if (e < osz && !P.vars[o.in[0]].is_const) add(o.in[0], o.begin + e, go[e]);

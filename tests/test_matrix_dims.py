@@ -76,6 +76,10 @@ def g_polar_norot(x, M):
     return x - x.batched_svd_w(False)[2]
 
 
+def g_axis_sums(x, M):          # reduce over one axis of a matrix (reduce.cpp:36-47): (rows x 1) (1 x cols) -> rows x cols
+    return x.reduce_sum(2).batched_matmul(x.pow(2).reduce_sum(1)) + x
+
+
 def g_lincomb(x, M):            # :301-322
     return M.linear_combine([(1.2, x.reduce_sum(-1)), (2.3, x.pow(2. / 3.)), (1.4, x.pow(1.5))], 2.5)
 
@@ -97,6 +101,7 @@ CASES = [
     ("reduce_9x7", g_reduce, (9, 7), 8, (0.5, 1.5), 0.0),
     ("logdet_4x3", g_logdet, (4, 3), 10, (0.0, 1.0), 0.0),
     ("lincomb_4", g_lincomb, (4, 4), 9, (2.0, 5.0), 0.0),
+    ("axis_sums_4x6", g_axis_sums, (4, 6), 5, (0.5, 1.5), 0.0),
     ("polar_4", g_polar, (4, 4), 7, (-1.0, 1.0), 0.0),
     ("polar_norot_4", g_polar_norot, (4, 4), 7, (-1.0, 1.0), 0.0),
     ("polar_5", g_polar, (5, 5), 4, (-1.0, 1.0), 0.0),
@@ -191,8 +196,9 @@ def test_shape_rules(api):
         A.TaylorCoeffProp(api, u, ident16, 2, 1, in_size=16)
     with pytest.raises(A.SanmUnsupportedError):
         A.TaylorCoeffProp(api, w * sv.reduce_sum(-1), ident16, 2, 1, in_size=16)
-    with pytest.raises(A.SanmUnsupportedError):   # one axis of a matrix
-        x.reduce_sum(1)
+    with pytest.raises(A.SanmUnsupportedError):   # the sum over the batch as well has no batched output
+        x.reduce_sum(-2)
+    assert x.reduce_sum(1).id >= 0 and x.reduce_sum(2).id >= 0
     y = g.placeholder_matrix(9, 9)                # larger than the interpreter's 8 x 8 linear algebra
     ident = A.SparseLinearDesc(api, sp.identity(81, format="csr"))
     with pytest.raises((A.SanmAssertionError, A.SanmUnsupportedError)):
