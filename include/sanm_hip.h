@@ -51,7 +51,8 @@ const char* sanm_hip_backend_name(void);
 int sanm_graph_create(sanm_graph** g);
 void sanm_graph_destroy(sanm_graph* g);
 int sanm_graph_placeholder(sanm_graph* g, int* var);                       /* oprs.h:80 */
-/* val: (batch, size) with size in {1,3,9}; batch is T or 1 */
+/* sanm_graph_constant: val is (batch, size), batch = the graph's batch or 1 (broadcast); nine values are a (T,3,3)
+ * matrix, any other size a (batch, size) vector (sanm_graph_constant_matrix declares other matrix shapes) */
 /* ---- graphs over vectors: Slice / Concat (libsanm/oprs/misc.cpp:104-331, oprs.h:60) ---------------------------
  * A placeholder declared with sanm_graph_placeholder_vector is a (batch, size) tensor; graphs over it may use the
  * elementwise operators (linear_combine, multiply, pow, log, reduce_sum axis -1), constants of any length, and

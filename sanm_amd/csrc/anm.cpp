@@ -832,6 +832,8 @@ void AnmDriver::construct_on_vector_interpreter(const Graph& g, int out_var, con
                (long)remap_inp.out_size, idim);
     const int64_t B = remap_inp.out_size / idim;
     m_vprog = std::make_unique<VecProgram>(be, g, out_var, B, m_hp.order);
+    sanm_check(m_vprog->idim() == idim, "the graph holds several placeholders of different sizes (%d, %d): only the "
+               "one the output depends on may be declared", m_vprog->idim(), idim);
     const int odim = m_vprog->odim();
     sanm_check(remap_out.in_size == B * odim, "remap_out takes %ld elements, the graph produces (%ld, %d)",
                (long)remap_out.in_size, (long)B, odim);
