@@ -69,7 +69,7 @@ int sanm_graph_placeholder(sanm_graph* g, int* var);                       /* op
  * sanm_graph_constant_matrix a constant of that rank.  batched_matmul (any conforming shapes), batched_transpose,
  * batched_mat_inv_mul / batched_det (square, up to 8 x 8; the determinant's series by the expansion up to 4 x 4 and by
  * the DFT of the polynomial matrix above, tensor_polymat.cpp:30-136, :325-379), batched_mul_eye(dim) and
- * batched_svd_w with only W read (the polar recurrences, tensor_svd.cpp:389-475) take them;
+ * batched_svd_w (the polar recurrences when only W is read, the full ones otherwise: tensor_svd.cpp:275-475) take them;
  * a graph with any shape other than (T,3,3) / (T,1) runs on the same interpreter as the vector graphs. */
 int sanm_graph_placeholder_vector(sanm_graph* g, int size, int* var);
 int sanm_graph_placeholder_matrix(sanm_graph* g, int rows, int cols, int* var);

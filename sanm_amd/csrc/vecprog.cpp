@@ -54,6 +54,15 @@ VecProgram::VecProgram(Backend* be, const Graph& g, int out_var, int64_t B, int 
     };
     int nr_placeholder = 0, grad = 0;
     m_dev.in_var = -1;
+    // SVD-W operators whose U or S is read (or is the output): the full recurrences; W alone: the polar ones
+    std::vector<char> svdw_full(g.ops.size(), 0);
+    auto mark_full = [&](int v) {
+        const GraphVar& gv = g.vars[v];
+        if (g.ops[gv.producer].type == OP_SVDW && gv.out_idx < 2) svdw_full[gv.producer] = 1;
+    };
+    mark_full(out_var);
+    for (int oi : order)
+        for (int v : g.ops[oi].in) mark_full(v);
     const int64_t flag = take(2);
     for (int oi : order) {
         const GraphOp& op = g.ops[oi];
@@ -72,9 +81,6 @@ VecProgram::VecProgram(Backend* be, const Graph& g, int out_var, int64_t B, int 
         bool all_const = op.type != OP_PLACEHOLDER;
         for (int i = 0; i < o.nin; ++i) {
             o.in[i] = m_var_map[op.in[i]];
-            if (o.in[i] < 0 && g.ops[g.vars[op.in[i]].producer].type == OP_SVDW)
-                sanm_throw(SANM_ERR_UNSUPPORTED, "U or S of batched_svd_w on the vector interpreter: only W (the polar "
-                                                 "recurrences); the full SVD-W series run in (T,3,3) graphs");
             sanm_check(o.in[i] >= 0, "operand of operator %d is not computed", oi);
             all_const = all_const && m_vars[o.in[i]].is_const;
         }
@@ -139,12 +145,40 @@ VecProgram::VecProgram(Backend* be, const Graph& g, int out_var, int64_t B, int 
             sanm_check(n <= VEC_MAX_DIM, "SVD-W of a %d x %d matrix: at most %d", n, n, VEC_MAX_DIM);
             o.aux0 = take(B * sz);
             o.aux1 = take(B * n);
-            o.aux2 = take(B * 2 * sz);
-            o.aux3 = take((int64_t)(max_order + 1) * B * sz);
             o.nact = sz;
-            ops.push_back(o);
-            o.type = VOP_SVDW_FIN;
-            o.nact = 1;
+            if (svdw_full[oi]) {
+                // U and S as variables of their own beside W; four records per order
+                o.flags |= OP_FLAG_SVDW_FULL;
+                for (int q = 0; q < 2; ++q) {
+                    VecVar w{};
+                    w.rows = n;
+                    w.cols = q == 0 ? n : 0;
+                    w.size = q == 0 ? sz : n;
+                    w.is_const = v.is_const;
+                    w.coef = take((int64_t)(w.is_const ? 1 : max_order + 1) * B * w.size);
+                    w.bias = w.is_const ? -1 : take(B * w.size);
+                    w.grad = grad;
+                    grad += w.size;
+                    m_var_map[op.out[q]] = m_vars.size();
+                    (q == 0 ? o.out_u : o.out_s) = m_vars.size();
+                    m_vars.push_back(w);
+                }
+                o.aux2 = take(B * 3 * sz);
+                o.aux3 = take(B * 2 * (int64_t)(max_order + 1) * sz);
+                ops.push_back(o);
+                o.type = VOP_SVDWF_B;
+                ops.push_back(o);
+                o.type = VOP_SVDWF_C;
+                ops.push_back(o);
+                o.type = VOP_SVDWF_FIN;
+                o.nact = 1;
+            } else {
+                o.aux2 = take(B * 2 * sz);
+                o.aux3 = take((int64_t)(max_order + 1) * B * sz);
+                ops.push_back(o);
+                o.type = VOP_SVDW_FIN;
+                o.nact = 1;
+            }
         } else if (op.type == OP_DET) {
             const int m = m_vars[o.in[0]].rows;
             sanm_check(m <= VEC_MAX_DIM, "determinant of a %d x %d matrix: at most %d", m, m, VEC_MAX_DIM);
@@ -162,8 +196,6 @@ VecProgram::VecProgram(Backend* be, const Graph& g, int out_var, int64_t B, int 
     }
     sanm_check(nr_placeholder == 1, "exactly one placeholder input is supported, got %d", nr_placeholder);
     m_out_graph_var = out_var;
-    if (m_var_map[out_var] < 0 && g.ops[g.vars[out_var].producer].type == OP_SVDW)
-        sanm_throw(SANM_ERR_UNSUPPORTED, "U or S of batched_svd_w as the output of a graph on the vector interpreter");
     m_dev.out_var = m_var_map[out_var];
     sanm_check(!m_vars[m_dev.out_var].is_const, "the output does not depend on the input");
     m_dev.odim = m_vars[m_dev.out_var].size;

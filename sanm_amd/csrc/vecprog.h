@@ -44,6 +44,9 @@ constexpr int VOP_INV_PREP = 32;    // X0^-1 of the mat_inv_mul that follows, or
 constexpr int VOP_MATINV_FIN = 33;  // second product of mat_inv_mul's recurrence
 constexpr int VOP_DET_FIN = 34;     // determinant: partial sums -> self-bias; cof(X0) : X_k + self-bias
 constexpr int VOP_SVDW_FIN = 35;    // SVD-W (W only): the dense algebra of the polar recurrence (thread 0)
+constexpr int VOP_SVDWF_B = 36;     // SVD-W with U or S read (full recurrences): (U S)(i) U' for i <= k
+constexpr int VOP_SVDWF_C = 37;     //   ... Bu, Bw and the known part of coefficient k of U S U' W
+constexpr int VOP_SVDWF_FIN = 38;   //   ... U_k, S_k, W_k (thread 0)
 
 struct VecVar {
     int64_t coef;   // arena offset of coefficient 0 of batch 0; order k, batch b at coef + (k * B + b) * size
@@ -60,6 +63,7 @@ struct VecOp {
     int32_t nact;             // threads that take part in the forward passes (0: as many as the output has elements)
     int32_t in[VEC_MAX_IN];
     int32_t out;
+    int32_t out_u, out_s;     // SVDW with U or S read: their variables (out is W)
     int32_t begin;            // SLICE: first element taken; CONCAT: unused
     double p[VEC_MAX_IN + 1]; // LINCOMB: coefficients, bias at p[VEC_MAX_IN]; POW: p[0] = exponent
     int64_t aux0, aux1;       // POW / LOG: K = f'(x0) [B][size], self-bias [B][size]; MULTIPLY: self-bias at aux1
@@ -68,7 +72,9 @@ struct VecOp {
     // partial sums at aux2 [B][VEC_MAX_SIZE]
     int64_t aux2;
     // SVDW (+ FIN; only W is read: the polar recurrences of tensor_svd.cpp:389-475): U0 at aux0 [B][n*n], S0 at aux1
-    // [B][n], (Bm - Bp, Bpw) at aux2 [B][2][n*n], the polar factors P_k at aux3 [order][B][n*n]
+    // [B][n], (Bm - Bp, Bpw) at aux2 [B][2][n*n], the polar factors P_k at aux3 [order][B][n*n].
+    // SVDW with U or S read (tensor_svd.cpp:275-387): (Bu, Bw, Mbias) at aux2 [B][3][n*n], the two product series
+    // (U S)(i), ((U S) U')(i) at aux3 [B][2][order + 1][n*n]
     int64_t aux3;
 };
 
@@ -757,12 +763,29 @@ VEC_HD void vec_forward(const VecProgDev& P, const VecOp& o, int mode, int k, in
                 for (int q = 0; q < nn; ++q) {
                     P.arena[o.aux0 + b * nn + q] = U[q];
                     vec_store(P, o.out, 0, true, b, q, W[q]);
+                    if (o.flags & OP_FLAG_SVDW_FULL) vec_store(P, o.out_u, 0, true, b, q, U[q]);
                 }
-                for (int q = 0; q < n; ++q) P.arena[o.aux1 + b * n + q] = S[q];
+                for (int q = 0; q < n; ++q) {
+                    P.arena[o.aux1 + b * n + q] = S[q];
+                    if (o.flags & OP_FLAG_SVDW_FULL) vec_store(P, o.out_s, 0, true, b, q, S[q]);
+                }
                 break;
             }
             if (mode != PASS_BIAS || e >= nn) break;
             const int r = e / n, c = e % n;
+            if (o.flags & OP_FLAG_SVDW_FULL) {
+                // first of the four phases of the full recurrences (VOP_SVDWF_*): T0_i = sum_j U_j diag(S_{i-j}) over
+                // the known terms (both indices below k), i <= k  (oprs/linalg.cpp:42-62, :570-590)
+                if (k < 2) break;
+                double* T0 = P.arena + o.aux3 + (b * 2 + 0) * (int64_t)(P.max_order + 1) * nn;
+                for (int i = 0; i <= k; ++i) {
+                    double acc = 0;
+                    for (int j = (i >= k ? i - k + 1 : 0); j <= i && j < k; ++j)
+                        acc = __builtin_fma(vec_coef(P, o.out_u, j, b, e), vec_coef(P, o.out_s, i - j, b, c), acc);
+                    T0[i * nn + e] = acc;
+                }
+                break;
+            }
             double d = 0, bpw = 0;
             for (int i = 1; i < k; ++i) {
                 const double* Pi = P.arena + o.aux3 + ((int64_t)i * P.B + b) * nn;
@@ -857,6 +880,124 @@ VEC_HD void vec_forward(const VecProgDev& P, const VecOp& o, int mode, int k, in
                     double acc = 0;
                     for (int q = 0; q < n; ++q) acc = __builtin_fma(at(U0, i, q), at(T0, q, j), acc);
                     vec_store(P, o.out, k, in_coeff, b, i * n + j, acc);
+                }
+            break;
+        }
+        case VOP_SVDWF_B:
+        case VOP_SVDWF_C:
+        case VOP_SVDWF_FIN: {
+            // Full SVD-W recurrences (U or S is read; oprs/linalg.cpp:561-600, tensor_svd.cpp:275-387).  At BIAS(k):
+            // OP_SVDW has left T0_i = sum_j U_j diag(S_{i-j}) (known terms, i <= k); B: T1_i = sum_j T0_j U_{i-j}';
+            // C: Mbias = sum_{0<i<=k} T1_i W_{k-i}, Bu = sum U_i' U_{k-i}, Bw = sum W_i' W_{k-i} (0 < i < k);
+            // FIN (BIAS and COEFF, thread 0): U_k, S_k, W_k from M_k, Mbias, Bu, Bw.
+            if (mode == PASS_EVAL0) break;
+            const int x = o.in[0];
+            const int n = ov.rows, nn = n * n;
+            const int64_t No = P.max_order + 1;
+            double* T0 = P.arena + o.aux3 + (b * 2 + 0) * No * nn;
+            double* T1 = P.arena + o.aux3 + (b * 2 + 1) * No * nn;
+            double* Bu = P.arena + o.aux2 + (b * 3 + 0) * nn;
+            double* Bw = P.arena + o.aux2 + (b * 3 + 1) * nn;
+            double* Mb = P.arena + o.aux2 + (b * 3 + 2) * nn;
+            if (o.type == VOP_SVDWF_B) {
+                if (mode != PASS_BIAS || e >= nn || k < 2) break;
+                const int r = e / n, c = e % n;
+                for (int i = 0; i <= k; ++i) {
+                    double acc = 0;
+                    for (int j = (i >= k ? i - k + 1 : 0); j <= i; ++j)  // T0_j known for j <= k, U_{i-j} for i - j < k
+                        for (int q = 0; q < n; ++q)
+                            acc = __builtin_fma(T0[j * nn + r * n + q], vec_coef(P, o.out_u, i - j, b, c * n + q), acc);
+                    T1[i * nn + e] = acc;
+                }
+                break;
+            }
+            if (o.type == VOP_SVDWF_C) {
+                if (mode != PASS_BIAS || e >= nn) break;
+                const int r = e / n, c = e % n;
+                double mb = 0, bu = 0, bw = 0;
+                if (k >= 2) {
+                    for (int i = 1; i <= k; ++i)
+                        for (int q = 0; q < n; ++q)
+                            mb = __builtin_fma(T1[i * nn + r * n + q], vec_coef(P, o.out, k - i, b, q * n + c), mb);
+                    for (int i = 1; i < k; ++i)
+                        for (int q = 0; q < n; ++q) {
+                            bu = __builtin_fma(vec_coef(P, o.out_u, i, b, q * n + r), vec_coef(P, o.out_u, k - i, b, q * n + c), bu);
+                            bw = __builtin_fma(vec_coef(P, o.out, i, b, q * n + r), vec_coef(P, o.out, k - i, b, q * n + c), bw);
+                        }
+                }
+                Mb[e] = mb;
+                Bu[e] = bu;
+                Bw[e] = bw;
+                break;
+            }
+            if (e != 0) break;
+            // svd_w_taylor_fwd (tensor_svd.cpp:275-387), on plain (untransposed) matrices:
+            //   Et = V0' (M_k - Mb)' U0;  R = Et' - Et - (V0' Bw V0) diag(s);  X_ij = clip_div(R_ij, s_i + s_j)
+            //   W_k = U0 X V0';  Et -= X' diag(s);  Et += Bu' diag(s);  S_k = diag Et
+            //   K_ij = clip_div(Et_ij, s_i - s_j), K_ji = -Bu_ij - K_ij (i < j), K_jj = -Bu_jj / 2;  U_k = U0 K'
+            double U0[VEC_MAX_DIM * VEC_MAX_DIM], V0[VEC_MAX_DIM * VEC_MAX_DIM], S0[VEC_MAX_DIM];
+            double A[VEC_MAX_DIM * VEC_MAX_DIM], Et[VEC_MAX_DIM * VEC_MAX_DIM], X[VEC_MAX_DIM * VEC_MAX_DIM];
+            for (int q = 0; q < nn; ++q) U0[q] = vec_coef(P, o.out_u, 0, b, q);
+            for (int q = 0; q < n; ++q) S0[q] = vec_coef(P, o.out_s, 0, b, q);
+            for (int i = 0; i < n; ++i)  // V0 = W0' U0
+                for (int j = 0; j < n; ++j) {
+                    double acc = 0;
+                    for (int q = 0; q < n; ++q) acc = __builtin_fma(vec_coef(P, o.out, 0, b, q * n + i), U0[q * n + j], acc);
+                    V0[i * n + j] = acc;
+                }
+            for (int i = 0; i < n; ++i)  // A = (M_k - Mb)' U0
+                for (int j = 0; j < n; ++j) {
+                    double acc = 0;
+                    for (int q = 0; q < n; ++q)
+                        acc = __builtin_fma(vec_cur(P, x, k, in_coeff, b, q * n + i) - Mb[q * n + i], U0[q * n + j], acc);
+                    A[i * n + j] = acc;
+                }
+            for (int i = 0; i < n; ++i)  // Et = V0' A
+                for (int j = 0; j < n; ++j) {
+                    double acc = 0;
+                    for (int q = 0; q < n; ++q) acc = __builtin_fma(V0[q * n + i], A[q * n + j], acc);
+                    Et[i * n + j] = acc;
+                }
+            for (int i = 0; i < n; ++i)  // A = Bw V0
+                for (int j = 0; j < n; ++j) {
+                    double acc = 0;
+                    for (int q = 0; q < n; ++q) acc = __builtin_fma(Bw[i * n + q], V0[q * n + j], acc);
+                    A[i * n + j] = acc;
+                }
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
+                    double acc = 0;  // (V0' Bw V0)_ij
+                    for (int q = 0; q < n; ++q) acc = __builtin_fma(V0[q * n + i], A[q * n + j], acc);
+                    X[i * n + j] = vec_clip_div(Et[j * n + i] - Et[i * n + j] - acc * S0[j], S0[i] + S0[j]);
+                }
+            for (int i = 0; i < n; ++i)  // A = X V0' ; W_k = U0 A
+                for (int j = 0; j < n; ++j) {
+                    double acc = 0;
+                    for (int q = 0; q < n; ++q) acc = __builtin_fma(X[i * n + q], V0[j * n + q], acc);
+                    A[i * n + j] = acc;
+                }
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
+                    double acc = 0;
+                    for (int q = 0; q < n; ++q) acc = __builtin_fma(U0[i * n + q], A[q * n + j], acc);
+                    vec_store(P, o.out, k, in_coeff, b, i * n + j, acc);
+                }
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) Et[i * n + j] += (Bu[j * n + i] - X[j * n + i]) * S0[j];
+            for (int i = 0; i < n; ++i) vec_store(P, o.out_s, k, in_coeff, b, i, Et[i * n + i]);
+            for (int j = 0; j < n; ++j) {  // K (into A)
+                for (int i = 0; i < j; ++i) {
+                    const double vv = vec_clip_div(Et[i * n + j], S0[i] - S0[j]);
+                    A[i * n + j] = vv;
+                    A[j * n + i] = -Bu[i * n + j] - vv;
+                }
+                A[j * n + j] = -Bu[j * n + j] / 2;
+            }
+            for (int i = 0; i < n; ++i)  // U_k = U0 K'
+                for (int j = 0; j < n; ++j) {
+                    double acc = 0;
+                    for (int q = 0; q < n; ++q) acc = __builtin_fma(U0[i * n + q], A[j * n + q], acc);
+                    vec_store(P, o.out_u, k, in_coeff, b, i * n + j, acc);
                 }
             break;
         }
@@ -1018,6 +1159,21 @@ VEC_HD void vec_backward(const VecProgDev& P, const VecOp& o, int64_t b, int e, 
                     const double num = U0[kk * n + a] * V0[l * n + c] - U0[kk * n + c] * V0[l * n + a];
                     s = __builtin_fma(gp, vec_clip_div(num, S0[a] + S0[c]), s);
                 }
+            if (o.flags & OP_FLAG_SVDW_FULL) {
+                // dS/dM and dU/dM (tensor_svd.cpp:147-273): dS_i/dM_kl = U0[k,i] V0[l,i];
+                // g_M[k,l] += sum_{a != j} (U0' g_U)[a,j] clip_div(U0[k,a] V0[l,j] s_j + U0[k,j] V0[l,a] s_a, s_j^2 - s_a^2)
+                const double* gs = g + P.vars[o.out_s].grad;
+                const double* gu = g + P.vars[o.out_u].grad;
+                for (int i = 0; i < n; ++i) s = __builtin_fma(gs[i], U0[kk * n + i] * V0[l * n + i], s);
+                for (int a = 0; a < n; ++a)
+                    for (int j = 0; j < n; ++j) {
+                        if (a == j) continue;
+                        double gp = 0;
+                        for (int i = 0; i < n; ++i) gp = __builtin_fma(U0[i * n + a], gu[i * n + j], gp);
+                        const double num = U0[kk * n + a] * V0[l * n + j] * S0[j] + U0[kk * n + j] * V0[l * n + a] * S0[a];
+                        s = __builtin_fma(gp, vec_clip_div(num, S0[j] * S0[j] - S0[a] * S0[a]), s);
+                    }
+            }
             add(x, e, s);
             break;
         }

@@ -164,6 +164,54 @@ def test_matrix_graph_series_against_oracle(api, name, build, shape, batch, rng_
     assert np.abs(yd - series).max() <= 1e-6 * max(1.0, np.abs(yd).max())
 
 
+def _spread(batch, n, seed):
+    """order-0 matrices Q1 diag(n, ..., 2, 1) Q2: well separated singular values, so that dU/dM (which divides by
+    s_j^2 - s_i^2, tensor_svd.cpp:236-262) is well conditioned and the comparison is not a test of clip_div"""
+    rng = np.random.default_rng(seed)
+    q1 = np.linalg.qr(rng.standard_normal((batch, n, n)))[0]
+    q2 = np.linalg.qr(rng.standard_normal((batch, n, n)))[0]
+    return q1 @ (np.diag(np.arange(n, 0, -1.0))[None] * rng.uniform(0.9, 1.1, (batch, 1, 1))) @ q2
+
+
+@pytest.mark.parametrize("n", [2, 4, 5])
+@pytest.mark.parametrize("case", ["U", "S", "USW", "S_vector_output"])
+def test_svdw_full_recurrences_outside_3x3(api, case, n):
+    """batched_svd_w of n x n matrices with U or S read by other operators: the full U, S, W recurrences
+    (oprs/linalg.cpp:561-600, tensor_svd.cpp:275-387) and dU/dM, dS/dM (tensor_svd.cpp:147-273) on the vector
+    interpreter, the graphs of tests/test_device_ops.py::test_svdw_full_mode at other sizes.  (The columns of U are
+    defined up to a sign -- Eigen's JacobiSVD in the reference, LAPACK in the oracle, a one-sided Jacobi on the
+    device --; U enters through its elementwise square, which is not.)"""
+    batch, N = 6, 5
+
+    def build(x, M):
+        u, sv, w = x.batched_svd_w(False)
+        uu = u * u
+        if case == "U":
+            return uu.batched_matmul(w) + uu.batched_transpose()
+        if case == "S":
+            return (sv * sv).reduce_sum(-1).batched_mul_eye(n).batched_matmul(w) + x
+        if case == "USW":
+            return uu.batched_matmul(w) * (sv.log() * sv).reduce_sum(-1) + uu
+        return M.linear_combine([(2.0, sv), (0.5, sv.pow(2))], 0.25)
+    rng = np.random.default_rng(n)
+    xs = [_spread(batch, n, 7 + n)] + [0.1 * rng.standard_normal((batch, n, n)) for _ in range(N)]
+    prop, keep = _mk_device(api, build, (n, n), batch, N)
+    oprop = _mk_oracle(build)
+    flat = lambda a: np.asarray(a).reshape(batch, -1)
+    y, yo = flat(prop.push_xi(xs[0])), flat(oprop.push_xi([xs[0]]))
+    assert y.shape == yo.shape and np.abs(y - yo).max() <= 1e-10 * max(1.0, np.abs(yo).max())
+    J = prop.get_jacobian()
+    Jo = np.asarray(oprop.get_jacobian()).reshape(J.shape)
+    assert np.abs(J - Jo).max() <= 1e-9 * max(1.0, np.abs(Jo).max())
+    for k in range(1, N + 1):
+        b, bo = flat(prop.compute_next_order_bias()), flat(oprop.compute_next_order_bias())
+        assert np.abs(b - bo).max() <= 1e-8 * max(1.0, np.abs(bo).max()), k
+        yk, yko = flat(prop.push_xi(xs[k])), flat(oprop.push_xi([xs[k]]))
+        assert np.abs(yk - yko).max() <= 1e-8 * max(1.0, np.abs(yko).max()), k
+        lin = b + np.einsum("bij,bj->bi", J, xs[k].reshape(batch, n * n))
+        assert np.abs(lin - yk).max() <= 1e-6 * max(1.0, np.abs(yk).max())
+
+
 @pytest.mark.parametrize("m", [2, 3, 4, 5, 6, 7])
 def test_oracle_polymat_det_coeff_against_evaluated_polynomial(m):
     """the reference's own check of compute_polymat_det_coeff (tests/tensor.cpp: det of the evaluated polynomial
@@ -190,12 +238,8 @@ def test_shape_rules(api):
     with pytest.raises(A.SanmAssertionError):
         A.batched_mat_inv_mul(x, None, False)
     assert x.batched_matmul(x.batched_transpose()).id >= 0
-    u, sv, w = g.placeholder_matrix(4, 4).batched_svd_w(False)
-    ident16 = A.SparseLinearDesc(api, sp.identity(16, format="csr"))
-    with pytest.raises(A.SanmUnsupportedError):   # SVD-W on the vector interpreter: W only
-        A.TaylorCoeffProp(api, u, ident16, 2, 1, in_size=16)
-    with pytest.raises(A.SanmUnsupportedError):
-        A.TaylorCoeffProp(api, w * sv.reduce_sum(-1), ident16, 2, 1, in_size=16)
+    with pytest.raises(A.SanmAssertionError):     # SVD-W: square matrices
+        x.batched_svd_w(False)
     with pytest.raises(A.SanmUnsupportedError):   # the sum over the batch as well has no batched output
         x.reduce_sum(-2)
     assert x.reduce_sum(1).id >= 0 and x.reduce_sum(2).id >= 0
