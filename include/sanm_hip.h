@@ -62,7 +62,7 @@ int sanm_graph_placeholder(sanm_graph* g, int* var);                       /* op
  * They run on a vector interpreter of their own on the device (one workgroup per batch item) and are served by the
  * operator-level API (sanm_taylor_*: push_xi, compute_next_order_bias, get_jacobian -> (B, odim, idim)); the ANM
  * drivers run them as well (a dense LU with partial pivoting solves their small general systems).  Vectors of up
- * to 64 elements.
+ * to 256 elements.
  *
  * Matrices of other sizes than 3 x 3 (libsanm/tensor_linalg.cpp:107-210 dynamic sizes; tests/symbolic.cpp:179-424 run
  * the operators at 4 x 4, 4 x 6, 5 x 5, 7 x 7): sanm_graph_placeholder_matrix declares a (batch, rows, cols) input,

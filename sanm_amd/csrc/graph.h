@@ -35,7 +35,7 @@ constexpr int SANM_ERR_UNSUPPORTED = 4;
     } while (0)
 
 struct GraphVar {
-    int size;      // element count per batch item: 1, 3 or 9 on the per-tet path; anything up to 64 on the vector path
+    int size;      // element count per batch item: 1, 3 or 9 on the per-tet path; anything up to 256 on the vector path
     int producer;  // index into Graph::ops
     int out_idx;
     int rows = 0, cols = 0;  // (batch, rows, cols); cols = 0: a (batch, rows) tensor (batched vector / scalar)

@@ -206,7 +206,7 @@ VecProgram::VecProgram(Backend* be, const Graph& g, int out_var, int64_t B, int 
     m_dev.nops = ops.size();
     m_dev.nvars = m_vars.size();
     m_dev.grad_total = grad;
-    sanm_check(grad <= 4096, "vector graph too large for the gradient scratch (%d doubles)", grad);
+    sanm_check(grad <= 8192, "vector graph too large for the gradient scratch (%d doubles of LDS; at most 8192)", grad);
     // arena, constants
     m_arena_doubles = off;
     std::vector<double> host(off, 0.0);

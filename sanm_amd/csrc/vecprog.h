@@ -4,7 +4,7 @@
 // tensors with elementwise arithmetic -- the Rosenbrock gradient of tests/symbolic.cpp:722-763 is the one user -- and
 // no FEA graph contains them.  The per-tet machinery of program.h / tet_ops.h is built around 1, 3 or 9 doubles per
 // tet; graphs with other sizes, or with Slice / Concat, are compiled into a VecProgram instead and run by the small
-// interpreter below: one workgroup per batch item, one thread per vector element, the operators of the graph in
+// interpreter below: one workgroup (256 threads) per batch item, one thread per vector element, the operators of the graph in
 // sequence with a workgroup barrier between them.  Same pass structure as the tet programs (EVAL0 / GRAD / BIAS(k) /
 // COEFF(k): TaylorCoeffProp::push_xi / ensure_jacobian / compute_next_order_bias, symbolic.cpp:162-289), same
 // operator recurrences (elem_arith.cpp:42-217, analytic_unary.cpp:13-139, reduce.cpp:11-102).
@@ -34,7 +34,7 @@
 
 namespace sanm_hip {
 
-constexpr int VEC_MAX_SIZE = 64;   // longest vector (threads of the workgroup)
+constexpr int VEC_MAX_SIZE = 256;  // longest vector (threads of the workgroup)
 constexpr int VEC_MAX_IN = 8;      // inputs of a concat / linear combination
 constexpr int VEC_MAX_DIM = 8;     // largest matrix: 8 x 8
 constexpr int VEC_MAX_ORDER = 32;  // highest expansion order of a graph with a determinant (per-thread series buffers)

@@ -263,6 +263,21 @@ def test_analytic_log(api):
     _close(np.log(sol), y0 * 2, margin=1e-9)
 
 
+def test_long_vectors_and_larger_matrices(api):
+    """beyond the reference's own test sizes: (batch, 200) vectors and 12 x 12 matrices through the elementwise
+    operators, a transpose and a product (one thread per element: up to 256 elements per batch item)"""
+    x0 = _rng(18, 1.2, 2.0)((3, 200))  # (away from the fold of log(x) x^1.5 at x = exp(-2/3))
+    y0 = np.log(x0) * x0 ** 1.5
+    sol = _solve(api, lambda x, M: x.log() * x.pow(1.5), x0, y0, 2.0)
+    _close(np.log(sol) * sol ** 1.5, y0 * 2, margin=1e-9)
+    x0 = _rng(19, 0.5, 1.5)((2, 12, 12))
+    f = lambda x: x * (x @ np.swapaxes(x, 1, 2)).sum(axis=(1, 2), keepdims=True)  # cubic: the path is x0 t^(1/3)
+    y0 = f(x0)
+    sol = _solve(api, lambda x, M: x.batched_matmul(x.batched_transpose()).reduce_sum(-1) * x, x0, y0, 2.0)
+    _close(f(sol), y0 * 2, margin=1e-9)
+    _close(sol, x0 * 2 ** (1 / 3), margin=1e-9)
+
+
 # --------------------------------------------------------------------------------- Symbolic.GeneralSolve (:583-638)
 def _general_solve(api, build, x0, y, maxiter=20):
     """anm_general_solve (tests/symbolic.cpp:56-73): ANMEqnSolver{f, id, id, x0, -y} iterated until converged"""
