@@ -323,6 +323,18 @@ int sanm_fea_boundary_by_threshold(int64_t nv, const double* vertices, const uin
                                    const double* filter_dir, double filter_min, double filter_max,
                                    uint8_t* fixed_mask);
 
+/* ---- PadeApproximation on its own (libsanm/pade.h:21-62; what tests/pade.cpp:64-110 drives) --------------------
+ * xs: (nr_coeff, len) row-major, the coefficients of a vector polynomial whose LAST entry is t (as the reference
+ * assumes, pade.h:47); copied to the device.  anm_cond: xs[i] . xs[1] == (i == 1). */
+typedef struct sanm_pade sanm_pade;
+int sanm_pade_create(int nr_coeff, int64_t len, const double* xs, int anm_cond, sanm_pade** p);
+void sanm_pade_destroy(sanm_pade* p);
+/* estimate_valid_range(start, eps, limit): *ok = 0 where the reference returns false */
+int sanm_pade_estimate_valid_range(sanm_pade* p, double start, double eps, double limit, int* ok);
+int sanm_pade_get_t_max(const sanm_pade* p, double* t_max, double* t_max_a);
+int sanm_pade_solve_a(const sanm_pade* p, double t, double* a);
+int sanm_pade_eval_xt(const sanm_pade* p, double a, double* xt); /* len doubles: x(a) then t(a) */
+
 /* ---- host scalar helpers (exposed for tests): libsanm/unary_polynomial.h - */
 int sanm_poly_solve_eqn(const double* f, int n, double xmin, double xmax, double b, double eps,
                         double* x);

@@ -90,6 +90,8 @@ SYMBOLS = [
     "sanm_fea_model_remap_inp", "sanm_fea_model_remap_out", "sanm_fea_model_x0",
     "sanm_fea_model_copy_vtx_values", "sanm_fea_model_scatter", "sanm_fea_gravity_load",
     "sanm_fea_boundary_by_threshold", "sanm_poly_solve_eqn", "sanm_poly_real_roots", "sanm_poly_roots",
+    "sanm_pade_create", "sanm_pade_destroy", "sanm_pade_estimate_valid_range", "sanm_pade_get_t_max", "sanm_pade_solve_a",
+    "sanm_pade_eval_xt",
 ]
 
 
@@ -523,6 +525,51 @@ class TaylorCoeffProp:
 
     def reset(self):
         self.api.check(self.api.lib.sanm_taylor_reset(self.h))
+
+
+class PadeApproximation:
+    """libsanm/pade.h:21-62 on its own (the ANM solvers hold one internally): xs is (nr_coeff, len) with t as the last
+    entry of every coefficient"""
+
+    def __init__(self, api, xs, anm_cond):
+        self.api = api
+        xs = _f64(np.stack([np.asarray(x, dtype=np.float64).ravel() for x in xs]))
+        self.len = xs.shape[1]
+        self.h = C.c_void_p()
+        api.check(api.lib.sanm_pade_create(C.c_int(xs.shape[0]), C.c_int64(self.len), _dp(xs),
+                                           C.c_int(1 if anm_cond else 0), C.byref(self.h)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.api.lib.sanm_pade_destroy(self.h)
+            self.h = None
+
+    def estimate_valid_range(self, start, eps, limit=0.0):
+        ok = C.c_int()
+        self.api.check(self.api.lib.sanm_pade_estimate_valid_range(self.h, C.c_double(start), C.c_double(eps),
+                                                                   C.c_double(limit), C.byref(ok)))
+        return bool(ok.value)
+
+    def _tmax(self):
+        t, a = C.c_double(), C.c_double()
+        self.api.check(self.api.lib.sanm_pade_get_t_max(self.h, C.byref(t), C.byref(a)))
+        return t.value, a.value
+
+    def get_t_max(self):
+        return self._tmax()[0]
+
+    def get_t_max_a(self):
+        return self._tmax()[1]
+
+    def solve_a(self, t):
+        a = C.c_double()
+        self.api.check(self.api.lib.sanm_pade_solve_a(self.h, C.c_double(t), C.byref(a)))
+        return a.value
+
+    def eval_xt(self, a):
+        out = np.zeros(self.len)
+        self.api.check(self.api.lib.sanm_pade_eval_xt(self.h, C.c_double(a), _dp(out)))
+        return out
 
 
 class _ANMSolver:

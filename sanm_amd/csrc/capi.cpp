@@ -829,6 +829,51 @@ int sanm_fea_boundary_by_threshold(int64_t nv, const double* vertices, const uin
     });
 }
 
+// ---- stand-alone Pade approximation ----------------------------------------
+struct sanm_pade {
+    std::vector<DVec> xs;
+    std::vector<double> t_coeffs;
+    std::unique_ptr<PadeApproximation> pade;
+    int64_t len = 0;
+};
+int sanm_pade_create(int nr_coeff, int64_t len, const double* xs, int anm_cond, sanm_pade** out) {
+    return guard([&] {
+        sanm_check(nr_coeff >= 3 && len >= 2, "pade: %d coefficients of %ld entries", nr_coeff, (long)len);
+        Backend* be = backend();
+        auto p = std::make_unique<sanm_pade>();
+        p->len = len;
+        p->xs.resize(nr_coeff);
+        for (int i = 0; i < nr_coeff; ++i) {
+            p->xs[i] = DVec{be, (size_t)len};
+            be->h2d(p->xs[i].p(), xs + (int64_t)i * len, len * 8);
+            p->t_coeffs.push_back(xs[(int64_t)i * len + len - 1]);
+        }
+        p->pade = std::make_unique<PadeApproximation>(be, p->xs, p->t_coeffs, anm_cond != 0);
+        *out = p.release();
+    });
+}
+void sanm_pade_destroy(sanm_pade* p) { delete p; }
+int sanm_pade_estimate_valid_range(sanm_pade* p, double start, double eps, double limit, int* ok) {
+    return guard([&] { *ok = p->pade->estimate_valid_range(start, eps, limit) ? 1 : 0; });
+}
+int sanm_pade_get_t_max(const sanm_pade* p, double* t_max, double* t_max_a) {
+    return guard([&] {
+        *t_max = p->pade->get_t_max();
+        *t_max_a = p->pade->get_t_max_a();
+    });
+}
+int sanm_pade_solve_a(const sanm_pade* p, double t, double* a) {
+    return guard([&] { *a = p->pade->solve_a(t); });
+}
+int sanm_pade_eval_xt(const sanm_pade* p, double a, double* xt) {
+    return guard([&] {
+        Backend* be = backend();
+        DVec out{be, (size_t)p->len};
+        p->pade->eval_xt(a, out.p());
+        be->d2h(xt, out.p(), p->len * 8);
+    });
+}
+
 // ---- host scalar helpers -----------------------------------------------------
 int sanm_poly_solve_eqn(const double* f, int n, double xmin, double xmax, double b, double eps,
                         double* x) {

@@ -309,3 +309,39 @@ def test_jacobian_of_a_mesh_built_by_several_host_threads(api):
     assert Ad.shape == Ao.shape and abs(Ad - Ao).max() <= 1e-10 * abs(Ao).max()
     assert run.solver.get_nr_iter() == osolver.get_nr_iter() == 1
     assert run.rms[-1] == pytest.approx(osolver.residual_rms, rel=1e-6, abs=1e-14)
+
+
+def test_pade_approx_on_its_own(api):
+    """tests/pade.cpp:64-110 (Pade.Approx) through the C ABI: a stand-alone PadeApproximation over nine coefficient
+    vectors of 500 entries (the last entry is t), its range accepted from range0 / 10, eval against the plain
+    polynomial inside the range and solve_a / eval consistent -- with the reference's tolerances -- and the
+    oracle's PadeApproximation on the same series beside it: same t_max_a (the bisection's probes agree), same
+    values."""
+    from oracle import unary_polynomial as up
+    from oracle.pade import PadeApproximation as OPade
+    rng = np.random.default_rng(7)
+    SIZE, N, eps = 500, 9, 1e-5
+    xs = [rng.uniform(-1, 1, SIZE) * 0.5 ** (i + 1) for i in range(N)]
+    xs[1][SIZE - 1] = 2.3
+    range0 = (eps * np.linalg.norm(xs[1]) / np.linalg.norm(xs[N - 1])) ** (1.0 / (N - 2))
+    pade = A.PadeApproximation(api, xs, False)
+    assert pade.estimate_valid_range(range0 / 10, eps)
+    opade = OPade(xs, False, True)
+    assert opade.estimate_valid_range(range0 / 10, eps)
+    assert pade.get_t_max_a() == pytest.approx(opade.t_max_a, rel=1e-6)
+    assert pade.get_t_max() == pytest.approx(opade.t_max, rel=1e-6)
+    tmin, tmax = xs[0][SIZE - 1], pade.get_t_max()
+    assert tmax > tmin
+    for div in (8.0, 3.0, 1.01):
+        a = pade.get_t_max_a() / div
+        expect, got = up.eval_tensor(xs, a), pade.eval_xt(a)
+        assert np.allclose(expect, got, rtol=1e-4, atol=1e-4)
+        assert expect[-1] == pytest.approx(got[-1], rel=1.2e-5)
+        assert np.abs(got - opade.eval_xt(a)).max() <= 1e-9 * np.abs(got).max()
+    for frac in (1e-3, 0.27, 0.96):
+        t = tmin * (1 - frac) + tmax * frac
+        a = pade.solve_a(t)
+        assert a == pytest.approx(opade.solve_a(t), rel=1e-5, abs=2.5e-6)
+        got = pade.eval_xt(a)
+        assert got[-1] == pytest.approx(t, rel=1.2e-5)
+        assert np.allclose(up.eval_tensor(xs, a), got, rtol=1e-4, atol=1e-4)

@@ -151,3 +151,23 @@ def test_solve_kernels_for_vectors_beyond_lds(api, monkeypatch):
     test_grid3d_wide_separators(api)
     test_random_block_unsymmetric(api)
     test_tiny_and_diagonal(api)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_reference_sparse_solver_case(api, seed):
+    """Tensor.SparseSolver (tests/tensor.cpp:44-70): a random 8 x 8 system in [-1, 1] with one structural zero per
+    row, A x = b to Catch2's Approx.  (Its second half -- prepare(alpha), the regularised normal equations -- is
+    the solver of the Tikhonov path: tests/test_tikhonov.py.)"""
+    rng = np.random.default_rng(seed)
+    N = 8
+    A = rng.uniform(-1, 1, (N, N))
+    b = rng.uniform(-1, 1, N)
+    for i in range(N):
+        A[i, (i + 2) % N] = 0
+    S = sp.csr_matrix(A)
+    S.sort_indices()
+    ds = DirectSolver(api, S)
+    ds.factor(S)
+    x = ds.solve(b)
+    assert np.allclose(A @ x, b, rtol=1.2e-5, atol=1e-12)
+    assert np.abs(x - np.linalg.solve(A, b)).max() <= 1e-9 * np.abs(x).max()
