@@ -247,3 +247,26 @@ def test_shape_rules(api):
     ident = A.SparseLinearDesc(api, sp.identity(81, format="csr"))
     with pytest.raises((A.SanmAssertionError, A.SanmUnsupportedError)):
         A.TaylorCoeffProp(api, y.batched_det() * y, ident, 2, 1, in_size=81)
+
+
+@pytest.mark.parametrize("n,rank", [(4, 3), (4, 2), (5, 4), (5, 3), (2, 1)])
+def test_cofactor_of_rank_deficient_matrices(api, n, rank):
+    """Tensor.DetCofactor's rank-deficient leg (tests/tensor.cpp:416-498) at other sizes: the Jacobian of
+    batched_det is the cofactor matrix -- non-zero at rank n - 1, exactly zero at rank <= n - 2 (where the
+    reference's SVD formula applies its rank test, tensor_linalg.cpp:18-59, and the device takes determinants of the
+    minors, which vanish by themselves)."""
+    rng = np.random.default_rng(10 * n + rank)
+    batch = 4
+    x0 = rng.standard_normal((batch, n, rank)) @ rng.standard_normal((batch, rank, n))
+    prop, keep = _mk_device(api, lambda x, M: x.batched_det(), (n, n), batch, 1)
+    oprop = _mk_oracle(lambda x, M: x.batched_det())
+    d, do = prop.push_xi(x0), oprop.push_xi([x0])
+    assert np.abs(d).max() <= 1e-12 and np.abs(np.asarray(do)).max() <= 1e-12
+    J = prop.get_jacobian().reshape(batch, n, n)
+    Jo = np.asarray(oprop.get_jacobian()).reshape(batch, n, n)
+    scale = np.abs(x0).max() ** (n - 1)
+    assert np.abs(J - Jo).max() <= 1e-10 * scale
+    if rank <= n - 2:
+        assert np.abs(J).max() <= 1e-12 * scale and not np.any(Jo)
+    else:
+        assert np.abs(J).max() > 1e-3 * scale
