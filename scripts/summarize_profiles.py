@@ -1,7 +1,7 @@
 """Turn gpurun_out/prof_<tag>/{stats,fetch,write} (scripts/collect_profiles.sh) into the committed summaries:
    profiles/<tag>_kernel_stats.{csv,md}, profiles/<tag>_pmc_traffic.md, profiles/pmc_traffic.json
 
-   python scripts/summarize_profiles.py r01b [steps=14]
+   python scripts/summarize_profiles.py r01b [steps]      (default: the number of assemble_kernel launches = expansions)
 """
 import collections
 import csv
@@ -13,7 +13,7 @@ import shutil
 import sys
 
 tag = sys.argv[1]
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 14  # 12 timed + 2 warm-up
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # 0: counted below from the trace (one assembly per expansion)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
@@ -40,10 +40,12 @@ for r in rows:
     f[1] += float(r["TotalDurationNs"])
 tot = sum(v[1] for v in fam.values())
 with open(os.path.join(dst, f"{tag}_kernel_stats.md"), "w") as fo:
+    if not steps:
+        steps = next((c for k, (c, t) in fam.items() if k == "assemble_kernel"), 14)
     fo.write(f"# rocprofv3 --kernel-trace --stats of `bench.py --steps 12 --warmup 2` ({tag})\n\n")
     fo.write("armadillo_small, Neo-Hookean compressible, order 20, 1 MI355X.  Template instantiations of one kernel are\n"
-             f"summed.  {steps} ANM steps (12 timed + 2 warm-up; the bench's extra roofline steps are not in this run's\n"
-             f"step count) -> per-step column = total / {steps}.  Full per-instantiation table: `{tag}_kernel_stats.csv`.\n\n")
+             f"summed.  {steps} ANM steps in the run (12 timed + 2 warm-up + the bench's 2 family-measurement steps: one\n"
+             f"`assemble_kernel` launch each) -> per-step column = total / {steps}.  Full per-instantiation table: `{tag}_kernel_stats.csv`.\n\n")
     fo.write(f"Total kernel time {tot / 1e6:.1f} ms.\n\n")
     fo.write("| kernel | calls | total ms | avg us | ms/step | % |\n|---|---|---|---|---|---|\n")
     for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
