@@ -267,14 +267,71 @@ def cpu_baseline_single_thread(workload, budget_s=8.0):
         return {"error": str(e)[:200]}
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` as a plain command (no torchrun around it): this process becomes the launcher of N
+    fresh rank processes, one per GPU -- the reference's scaling harness is likewise one command per thread count
+    (render/run_armadillo_exprs.sh:30-36).  The launcher makes NO GPU call and does not import torch (a process that
+    has touched the GPU must not start or replace programs on this pool); the ranks are ordinary children with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, rank 0 prints the JSON line on the stdout they
+    inherit, and the launcher exits with the first non-zero child status (the other ranks are then ended by PID, so a
+    rank that died before a collective cannot leave the rest waiting for it)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SANM_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen(cmd, env=env, cwd=os.getcwd()))
+    rc = 0
+    try:
+        live = list(procs)
+        while live:
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print(f"bench.py launcher: rank {procs.index(p)} exited with status {code}; ending the other "
+                          "ranks", file=sys.stderr, flush=True)
+                    time.sleep(2.0)  # (let them fail by themselves first: their messages are worth more)
+                    for q in live:
+                        if q.poll() is None:
+                            q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main(argv=None):
     args = parse(argv)
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args.workload, args.cpu_seconds, args.cpu_threads)), flush=True)
         return None
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a plain `python bench.py --gpus N`: start the N ranks ourselves (before anything touches the GPU)
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:] if argv is None else argv))
+    hook = os.environ.get("SANM_BENCH_TEST_HOOK")
+    if hook:
+        # tests only (tests/test_bench_multiproc.py): a module that replaces make_api / device_sync with the host
+        # harness so that the N > 1 launcher can run in the GPU-less container.  The line says which backend ran.
+        import importlib
+        importlib.import_module(hook).install(sys.modules[__name__])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher created WORLD_SIZE={world} ranks; reporting "
+              f"n_gpus={world}", file=sys.stderr, flush=True)
     dist = None
     # torch must load its HIP runtime before libsanm_hip.so pulls in the system one
     # (the other order leaves torch without visible devices)
@@ -291,6 +348,9 @@ def main(argv=None):
     api = make_api(local_rank)
     cfg, mesh = load_workload(args.workload)
     shard = None
+    # which collective implementation the data path uses, and how many ranks IT says it spans
+    coll = {"impl": "none (single rank)" if world == 1 else "none on the data path (independent replicas)",
+            "ranks": world if world == 1 else (dist.get_world_size() if dist is not None else 1)}
     if world > 1 and args.parallelism == "shard":
         from sanm_amd import dist as sdist
         native = args.dist_backend == "nccl" and not args.callback_allreduce
@@ -303,8 +363,13 @@ def main(argv=None):
                       "torch.distributed", file=sys.stderr, flush=True)
         if native:
             fn = None
+            # ncclCommCount of the library's communicator: the rank count RCCL itself reports
+            coll = {"impl": "library ncclAllReduce queued on the solver stream (RCCL, dlopen)",
+                    "ranks": api.comm_query()[0]}
         else:
             fn = sdist.make_rccl_allreduce() if args.dist_backend == "nccl" else sdist.make_host_allreduce()
+            coll = {"impl": f"C-ABI callback -> torch.distributed all_reduce ({dist.get_backend()})",
+                    "ranks": dist.get_world_size()}
         shard = (rank, world, fn)
     run = dfea.GravityRun(api, mesh, cfg, shard=shard, solver_rtol=args.solver_rtol,
                           solver_kind=args.solver_kind, profile=args.profile)
@@ -389,7 +454,11 @@ def main(argv=None):
             "value": (1 if shard else world) * args.steps / dt, "unit": "ANM steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong" if (shard or world == 1) else "weak", "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64", "backend": api.backend_name(),
+            # the ranks the data path's collective spans as the communication library reports them
+            # (ncclCommCount of the library communicator in the default tet-sharded mode)
+            "rccl_ranks": coll["ranks"], "collective_impl": coll["impl"],
+            "collective_ms_per_step": fam["collective"]["ms_per_step"] if "collective" in fam else 0.0,
             "data": ("real mesh Armadillo-small.1 (stand-in for the missing Armadillo.1), rest state"
                      if args.workload == "armadillo_small" else f"workload {args.workload}, rest state"),
             "config": {"workload": (f"config/{args.workload}.json" if ":" not in args.workload

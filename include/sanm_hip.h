@@ -187,6 +187,9 @@ int sanm_hip_comm_available(void);
 int sanm_hip_comm_unique_id(void* id, size_t cap);
 int sanm_hip_comm_init(int rank, int world, const void* id, size_t id_bytes);
 int sanm_hip_comm_destroy(void);
+/* Size and rank of the live communicator as RCCL itself reports them (ncclCommCount / ncclCommUserRank); 0, 0 when
+ * the process holds none.  bench.py prints the size as "rccl_ranks": proof of how many ranks the collectives span. */
+int sanm_hip_comm_query(int* world, int* rank);
 int sanm_anm_eqn_solver_create_sharded(const sanm_graph* g, int out_var,
                                        const sanm_sparse_desc* remap_inp,
                                        const sanm_sparse_desc* remap_out, const double* x0,

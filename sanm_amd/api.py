@@ -66,7 +66,7 @@ ENERGY = {"neohookean_i": 0, "neohookean_c": 1, "arap": 2, "stvk_stretch": 3}
 # every symbol include/sanm_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "sanm_hip_init", "sanm_hip_last_error", "sanm_hip_backend_name",
-    "sanm_hip_comm_available", "sanm_hip_comm_unique_id", "sanm_hip_comm_init", "sanm_hip_comm_destroy",
+    "sanm_hip_comm_available", "sanm_hip_comm_unique_id", "sanm_hip_comm_init", "sanm_hip_comm_destroy", "sanm_hip_comm_query",
     "sanm_graph_create", "sanm_graph_destroy", "sanm_graph_placeholder", "sanm_graph_constant", "sanm_graph_placeholder_vector", "sanm_graph_placeholder_matrix", "sanm_graph_constant_matrix", "sanm_graph_slice", "sanm_graph_concat",
     "sanm_graph_linear_combine", "sanm_graph_multiply", "sanm_graph_pow", "sanm_graph_log",
     "sanm_graph_reduce_sum", "sanm_graph_batched_matmul", "sanm_graph_batched_mat_inv_mul",
@@ -142,6 +142,12 @@ class Api:
     def comm_init(self, rank, world, uid: bytes):
         """join the library's RCCL communicator (collective over all ranks)"""
         self.check(self.lib.sanm_hip_comm_init(C.c_int(rank), C.c_int(world), C.c_char_p(uid), C.c_size_t(len(uid))))
+
+    def comm_query(self):
+        """(size, rank) of the live communicator as RCCL reports them; (0, 0) without one"""
+        w, r = C.c_int(0), C.c_int(0)
+        self.check(self.lib.sanm_hip_comm_query(C.byref(w), C.byref(r)))
+        return w.value, r.value
 
     def comm_destroy(self):
         self.check(self.lib.sanm_hip_comm_destroy())

@@ -234,6 +234,8 @@ public:
     virtual void comm_destroy() {}
     virtual int comm_world() const { return 0; }  // 0: no communicator
     virtual int comm_rank() const { return 0; }
+    //! size and rank as the communication library reports them for the live communicator (0, 0 without one)
+    virtual void comm_query(int* world, int* rank) { *world = *rank = 0; }
     //! in-place sum of `count` doubles over all ranks, queued on the backend's stream (no host synchronisation)
     virtual void allreduce_sum(double* buf, int64_t count);
 

@@ -1108,6 +1108,8 @@ struct Rccl {
     int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
     int (*CommDestroy)(Comm) = nullptr;
+    int (*CommCount)(Comm, int*) = nullptr;
+    int (*CommUserRank)(Comm, int*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     static const Rccl& get() {
         static Rccl r = [] {
@@ -1120,6 +1122,8 @@ struct Rccl {
                 x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
                 x.AllReduce = reinterpret_cast<decltype(x.AllReduce)>(dlsym(h, "ncclAllReduce"));
                 x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+                x.CommCount = reinterpret_cast<decltype(x.CommCount)>(dlsym(h, "ncclCommCount"));
+                x.CommUserRank = reinterpret_cast<decltype(x.CommUserRank)>(dlsym(h, "ncclCommUserRank"));
                 x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
                 if (x.GetUniqueId && x.CommInitRank && x.AllReduce && x.CommDestroy) break;
                 x = Rccl{};
@@ -1386,6 +1390,15 @@ public:
     }
     int comm_world() const override { return m_comm_world; }
     int comm_rank() const override { return m_comm_rank; }
+    void comm_query(int* world, int* rank) override {
+        // what RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank), not what we passed in
+        *world = *rank = 0;
+        if (!m_comm) return;
+        const Rccl& r = Rccl::get();
+        if (!r.CommCount || !r.CommUserRank) sanm_throw(SANM_ERR_UNSUPPORTED, "this RCCL has no ncclCommCount");
+        r.check(r.CommCount(m_comm, world), "ncclCommCount");
+        r.check(r.CommUserRank(m_comm, rank), "ncclCommUserRank");
+    }
     void allreduce_sum(double* buf, int64_t count) override {
         if (!m_comm) sanm_throw(SANM_ERR_ASSERT, "all-reduce without a communicator (sanm_hip_comm_init first)");
         const Rccl& r = Rccl::get();

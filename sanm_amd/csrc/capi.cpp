@@ -504,6 +504,13 @@ int sanm_hip_comm_init(int rank, int world, const void* id, size_t id_bytes) {
         backend()->comm_init(rank, world, id);
     });
 }
+int sanm_hip_comm_query(int* world, int* rank) {
+    return guard([&] {
+        sanm_check(world && rank, "null output");
+        *world = *rank = 0;
+        if (g_backend) g_backend->comm_query(world, rank);
+    });
+}
 int sanm_hip_comm_destroy(void) {
     return guard([&] {
         if (g_backend) g_backend->comm_destroy();

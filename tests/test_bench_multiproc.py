@@ -85,3 +85,33 @@ def test_two_rank_shard_is_the_default_and_terminates():
     assert d["roofline"]["frac"] > 0 and d["roofline"]["launches_per_step"] is not None
     # one problem: value = K / max-over-ranks time
     assert abs(d["value"] - 3 / (d["ms_per_step"] * 3 / 1e3)) < 1e-6 * d["value"]
+
+
+def test_plain_command_with_gpus_2_starts_two_ranks_itself():
+    """`python bench.py --gpus 2 ...` with no torchrun around it and no WORLD_SIZE in the environment: the process
+    becomes the launcher of two fresh rank processes (bench.spawn_ranks), rank 0's line comes out on its stdout and
+    says n_gpus == 2; the collective's own rank count is reported (gloo here: the host harness has no RCCL)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["SANM_BENCH_TEST_HOOK"] = "tests.hostsim.bench_hook"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--workload", "cuboid:5,3,3", "--no-cpu-baseline", "--dist-backend", "gloo"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    _check_common(d)
+    assert d["n_gpus"] == 2 and d["backend"] == "hostsim"
+    assert d["rccl_ranks"] == 2 and "gloo" in d["collective_impl"]
+    assert d["scaling"] == "strong" and d["collective_ms_per_step"] > 0
+
+
+def test_launcher_reports_a_failing_rank():
+    """a rank that dies takes the launcher's exit status with it (and the other ranks are ended, not left waiting)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["SANM_BENCH_TEST_HOOK"] = "tests.hostsim.no_such_hook_module"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--workload", "cuboid:5,3,3", "--no-cpu-baseline", "--dist-backend", "gloo"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "launcher: rank" in r.stderr

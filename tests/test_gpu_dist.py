@@ -94,3 +94,52 @@ def test_sharded_hip_path_with_the_callback_equals_the_unsharded_solve():
         assert ncall[0] == steps * (1 + 1 + (12 - 1)) + 1
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["armadillo_small", "human_arap16"])
+def test_full_size_configs_through_the_sharded_solver(name):
+    """BASELINE configs 4 and 5 take `sanm_anm_eqn_solver_create_sharded` (symbolic.cpp:525-536 is what it replaces)
+    with the library's RCCL communicator.  The test box has one GPU, so world = 1 -- every line of the N-rank code
+    runs (tet range, gather restricted to own tets, ncclAllReduce of f(x0) / the Jacobian values / b_k per order on
+    the solver's stream, solve without the fused ends), the collectives reduce over one rank.  Checked like the
+    unsharded full-size runs: convergence, the oracle's equilibrium (tests/golden/full_*.npz) to 1e-6, the
+    continuation step by step beside a live oracle (tests/lockstep.py), and the free-running step count identical
+    to the oracle's wherever no ill-conditioned Pade decision was met."""
+    import json
+    import sanm_amd
+    from oracle import fea as ofea
+    from sanm_amd import dist as sdist
+    from sanm_amd import fea as dfea
+    from tests.lockstep import LockStep
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    api = sanm_amd.get_api(0)
+    assert sdist.init_native_comm(api, 0, 1)
+    try:
+        assert api.comm_query() == (1, 0)  # ncclCommCount / ncclCommUserRank of the live communicator
+        cfg, mesh = dfea.load_named_config(name)
+        run = dfea.GravityRun(api, mesh, dict(cfg), shard=(0, 1, None)).run()
+        assert run.solver.converged() and run.rms[-1] < 1e-10
+        steps = run.solver.get_nr_iter()
+        gold = np.load(os.path.join(root, "tests", "golden", f"full_{name}.npz"))
+        Vo, osteps = gold["vertices"], int(gold["steps"])
+        V = run.vertices()
+        err = float(np.abs(V - Vo).max() / np.abs(Vo).max())
+        assert err <= 1e-6, err
+        # lock-step beside the oracle
+        cfg2, mesh2 = dfea.load_named_config(name)
+        run2 = dfea.GravityRun(api, mesh2, dict(cfg2), shard=(0, 1, None)).construct()
+        cfg3, mesh3 = dfea.load_named_config(name)
+        _, osolver, _ = ofea.make_gravity_solver(ofea.TetMesh(mesh3.V, mesh3.tets, mesh3.surface_vtx), cfg3)
+        ls = LockStep(run2, osolver).run_to_convergence()
+        assert ls.nr_steps == steps
+        rec = {"config": name, "path": "sanm_anm_eqn_solver_create_sharded, world 1, library communicator",
+               "device_steps": int(steps), "oracle_free_running_steps": osteps, "vertex_rel_err": err,
+               "lockstep": ls.summary()}
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        json.dump(rec, open(os.path.join(root, "gpurun_out", f"parity_steps_sharded_{name}.json"), "w"), indent=1)
+        print(json.dumps({k: rec[k] for k in ("config", "device_steps", "oracle_free_running_steps", "vertex_rel_err")}),
+              "events:", [(e["step"], e["device"], e["oracle"]) for e in ls.events])
+        if not ls.events:
+            assert steps == osteps
+    finally:
+        api.comm_destroy()
