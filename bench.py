@@ -345,6 +345,10 @@ def main(argv=None):
             dist.init_process_group(args.dist_backend)
 
     from sanm_amd import fea as dfea
+    if args.dist_backend != "nccl" and torch.cuda.device_count() > 0:
+        # host-side process group with the HIP backend: ranks may share a GPU (tests on a single-GPU box)
+        local_rank %= torch.cuda.device_count()
+        torch.cuda.set_device(local_rank)
     api = make_api(local_rank)
     cfg, mesh = load_workload(args.workload)
     shard = None
@@ -367,7 +371,12 @@ def main(argv=None):
             coll = {"impl": "library ncclAllReduce queued on the solver stream (RCCL, dlopen)",
                     "ranks": api.comm_query()[0]}
         else:
-            fn = sdist.make_rccl_allreduce() if args.dist_backend == "nccl" else sdist.make_host_allreduce()
+            if args.dist_backend == "nccl":
+                fn = sdist.make_rccl_allreduce()
+            elif api.backend_name() == "hip":
+                fn = sdist.make_staged_allreduce()  # several ranks on one GPU (single-GPU test boxes): staged through the host
+            else:
+                fn = sdist.make_host_allreduce()
             coll = {"impl": f"C-ABI callback -> torch.distributed all_reduce ({dist.get_backend()})",
                     "ranks": dist.get_world_size()}
         shard = (rank, world, fn)

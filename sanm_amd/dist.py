@@ -90,3 +90,20 @@ def make_host_allreduce():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
     return allreduce
+
+
+def make_staged_allreduce():
+    """sum over ranks of a DEVICE buffer through a host-side process group (gloo): device -> pinned host copy,
+    all-reduce, copy back.  Not a fast path: it lets several ranks share ONE GPU (RCCL refuses two ranks on one
+    device), which is how the world > 1 branch of the sharded HIP path is exercised on a single-GPU test box."""
+    import torch
+    import torch.distributed as dist
+
+    def allreduce(ptr, count):
+        t = torch.as_tensor(_DevicePtr(ptr, count), device="cuda")
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+        torch.cuda.current_stream().synchronize()
+
+    return allreduce

@@ -143,3 +143,26 @@ def test_full_size_configs_through_the_sharded_solver(name):
             assert steps == osteps
     finally:
         api.comm_destroy()
+
+
+def test_two_ranks_on_one_gpu_run_the_world_2_branch_of_the_sharded_hip_path():
+    """`python bench.py --gpus 2` as a plain command on the GPU box: the launcher starts two ranks, both on cuda:0
+    (RCCL refuses two ranks on one device, so the all-reduce goes through the C ABI's callback, staged through a
+    gloo group: sanm_amd.dist.make_staged_allreduce).  Not a measurement -- it makes the world = 2 branch of the
+    library (tet ranges of rank 0 and 1, gathers restricted to own tets, per-order all-reduce of partial nodal
+    sums that are NOT the whole sum) execute on the device before the driver's first multi-GPU run, on the
+    BASELINE-size mesh; then the two ranks' solve must equal the unsharded one."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--workload", "armadillo_small", "--no-cpu-baseline", "--dist-backend", "gloo"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["backend"] == "hip" and d["rccl_ranks"] == 2
+    assert d["config"]["parallelism"].startswith("tet-shard") and d["collective_ms_per_step"] > 0
+    # armadillo_small converges in 2 steps from the rest state: 1 + 4 steps = two whole solves and a started one
+    assert d["config"]["steps_per_solve"][:2] == [2, 2], d["config"]["steps_per_solve"]
