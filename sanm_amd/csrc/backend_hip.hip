@@ -1007,9 +1007,13 @@ __global__ void __launch_bounds__(DLU_THREADS) dense_lu_kernel(int64_t n, double
     __shared__ int s_idx[DLU_THREADS];
     __shared__ double s_piv;
     const int t = threadIdx.x;
+    const int lane = t & 63, wv = t >> 6;
+    constexpr int kWaves = DLU_THREADS / 64;
     double pmin = INFINITY, pmax = 0;
+    bool bad = false;  // a column without a single comparable entry (all NaN): reported through status[0] = NaN
     for (int64_t c = 0; c < n; ++c) {
-        // pivot: largest |lu[r][c]|, r >= c; ties to the lowest row (as a sequential scan does)
+        // pivot: largest |lu[r][c]|, r >= c; ties to the lowest row (as a sequential scan does).  NaN entries never
+        // win a comparison; a column made of them alone leaves the search empty-handed (bi stays INT_MAX).
         double best = -1.0;
         int bi = 0x7fffffff;
         for (int64_t r = c + t; r < n; r += DLU_THREADS) {
@@ -1033,9 +1037,14 @@ __global__ void __launch_bounds__(DLU_THREADS) dense_lu_kernel(int64_t n, double
             }
             __syncthreads();
         }
-        const int p = s_idx[0];
-        const double pabs = s_val[0];
+        int p = s_idx[0];
+        double pabs = s_val[0];
         __syncthreads();
+        if (p >= n) {  // nothing comparable in this column (non-finite Jacobian): no exchange, no elimination
+            p = (int)c;
+            pabs = 0.0;
+            bad = true;
+        }
         if (t == 0) piv[c] = p;
         pmin = fmin(pmin, pabs);
         pmax = fmax(pmax, pabs);
@@ -1052,15 +1061,15 @@ __global__ void __launch_bounds__(DLU_THREADS) dense_lu_kernel(int64_t n, double
         const double pv = s_piv;
         for (int64_t r = c + 1 + t; r < n; r += DLU_THREADS) lu[r * n + c] = lu[r * n + c] / pv;
         __syncthreads();
-        const int64_t m = n - c - 1;
-        for (int64_t q = t; q < m * m; q += DLU_THREADS) {
-            const int64_t r = c + 1 + q / m, j = c + 1 + q % m;
-            lu[r * n + j] = __builtin_fma(-lu[r * n + c], lu[c * n + j], lu[r * n + j]);
+        // trailing update: a wavefront per row, its lanes along the columns (coalesced; no index division)
+        for (int64_t r = c + 1 + wv; r < n; r += kWaves) {
+            const double l = lu[r * n + c];
+            for (int64_t j = c + 1 + lane; j < n; j += 64) lu[r * n + j] = __builtin_fma(-l, lu[c * n + j], lu[r * n + j]);
         }
         __syncthreads();
     }
     if (t == 0) {
-        status[0] = pmin;
+        status[0] = bad ? NAN : pmin;
         status[1] = pmax;
     }
 }

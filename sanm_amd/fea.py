@@ -232,8 +232,11 @@ def run_with_vtx_delta(api: Api, mesh: Mesh, fixed, config, vtx_delta, vtx_coord
     return vtx_coord, stat
 
 
-def test_cuboid_twist(api: Api, config):
-    """test_cuboid_twist, fea/main.cpp:665-772 (config/test_simple_cuboid_twist.json)."""
+def test_cuboid_twist(api: Api, config, stage=None):
+    """test_cuboid_twist, fea/main.cpp:665-772 (config/test_simple_cuboid_twist.json).  `stage`: the function that
+    runs one prescribed-displacement stage (default run_with_vtx_delta; the parity tests pass one that runs the
+    oracle beside it)."""
+    stage = stage or run_with_vtx_delta
     nx, ny, nz = int(config["x"]), int(config["y"]), int(config["z"])
     spacing = float(config["spacing"])
     mesh = make_cuboid(nx, ny, nz, spacing)
@@ -250,7 +253,7 @@ def test_cuboid_twist(api: Api, config):
         nonlocal vtx_cur
         delta = np.zeros_like(vtx_cur)
         delta[bnd_idx] = bnd_next - vtx_cur[bnd_idx]
-        vtx_cur, st = run_with_vtx_delta(api, mesh, fixed, config, delta, vtx_cur, require_refine)
+        vtx_cur, st = stage(api, mesh, fixed, config, delta, vtx_cur, require_refine)
         stats.append(st)
 
     bnd_init = vtx_cur[bnd_idx].copy()

@@ -166,14 +166,22 @@ public:
         for (int64_t i = 0; i < n; ++i)
             for (uint32_t p = A.rowptr[i]; p < A.rowptr[i + 1]; ++p) lu[i * n + A.col[p]] += A.val[p];
         double pmin = std::numeric_limits<double>::infinity(), pmax = 0;
+        bool bad = false;
         for (int64_t c = 0; c < n; ++c) {
-            int64_t p = c;
-            double best = std::fabs(lu[c * n + c]);
-            for (int64_t r = c + 1; r < n; ++r)
+            // the device kernel's rule (backend_hip.hip dense_lu_kernel): NaN entries never win; a column of NaNs
+            // alone is left as it is and reported through status[0] = NaN
+            int64_t p = -1;
+            double best = -1.0;
+            for (int64_t r = c; r < n; ++r)
                 if (std::fabs(lu[r * n + c]) > best) {
                     best = std::fabs(lu[r * n + c]);
                     p = r;
                 }
+            if (p < 0) {
+                p = c;
+                best = 0.0;
+                bad = true;
+            }
             piv[c] = (int32_t)p;
             pmin = std::min(pmin, best);
             pmax = std::max(pmax, best);
@@ -188,7 +196,7 @@ public:
                 for (int64_t j = c + 1; j < n; ++j) lu[r * n + j] = __builtin_fma(-l, lu[c * n + j], lu[r * n + j]);
             }
         }
-        status[0] = pmin;
+        status[0] = bad ? std::numeric_limits<double>::quiet_NaN() : pmin;
         status[1] = pmax;
     }
     void dense_lu_solve(int64_t n, const double* lu, const int32_t* piv, const double* b, double* x) override {

@@ -76,3 +76,31 @@ def test_refinement_steps_on_request_leave_the_solution_in_place(api):
             assert run.solver.get_nr_iter() == ref.solver.get_nr_iter()
         assert np.abs(run.vertices() - ref.vertices()).max() < 1e-9 * np.abs(ref.vertices()).max()
         assert run.rms[-1] < 1e-10
+
+
+def test_nan_jacobian_of_a_vector_graph_is_reported_not_a_memory_fault(api):
+    """Graphs on the vector interpreter solve their small general systems by a dense LU with partial pivoting
+    (dense_lu_kernel), queued BEFORE the host has looked at the finiteness count of the Jacobian.  A column of NaNs
+    alone used to leave the pivot search without a winner (row index INT_MAX) and the row exchange then wrote far out
+    of bounds -- a GPU memory fault instead of the reference's error (sparse_solver.cpp:288-289).  One batch item with
+    a dense 6 x 6 block, every coefficient replaced by NaN."""
+    import scipy.sparse as sp
+    from sanm_amd import api as A
+    x0 = np.random.default_rng(5).uniform(1, 2, (1, 6))
+    g = api.graph()
+    x = g.placeholder_vector(6)
+    y = x.pow(2.3) * x.reduce_sum(-1)
+    y0 = x0 ** 2.3 * x0.sum(axis=1, keepdims=True)
+    eye = sp.identity(6, format="csr")
+    hp = api.default_hyper(order=6, use_pade=0)
+    sol = A.ANMSolverVecScale(api, y, A.SparseLinearDesc(api, eye), A.SparseLinearDesc(api, eye), x0.ravel(), 1.0,
+                              -y0.ravel(), hp)
+    sol.debug_inject(3, 36, 0, float("nan"))
+    with pytest.raises(SanmAssertionError, match=r"non-finite Jacobian coefficient"):
+        sol.update_approx()
+    # one NaN among finite coefficients: the pivot search passes it over, the error is the same
+    sol2 = A.ANMSolverVecScale(api, y, A.SparseLinearDesc(api, eye), A.SparseLinearDesc(api, eye), x0.ravel(), 1.0,
+                               -y0.ravel(), hp)
+    sol2.debug_inject(3, 1, 7, float("nan"))
+    with pytest.raises(SanmAssertionError, match=r"non-finite Jacobian coefficient"):
+        sol2.update_approx()
