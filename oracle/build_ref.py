@@ -20,7 +20,7 @@ Variants (the root finder is sensitive to floating-point contraction on the ill-
   native  g++ -O2 -g -DNDEBUG -march=native        the reference's own flags (CMakeLists.txt:5-12, RelWithDebInfo);
                                                    machine dependent: gcc contracts a*b+c into FMA where the CPU has it
 
-Outputs: oracle/_ref/ (git-ignored, not gpurun-ignored).  /root/reference does not exist on the GPU box; nothing at
+Outputs: oracle/_ref/ (git-ignored and, since round 4, gpurun-ignored: nothing on the GPU box loads it).  /root/reference does not exist on the GPU box; nothing at
 run time needs these libraries there (tests that use them skip when they are absent).
 
 Usage: python -m oracle.build_ref [--force]

@@ -38,59 +38,79 @@ def stable_x_range(order):
     return math.pow(1e15, 1.0 / float(order))  # (libm pow like the reference; numpy differs in the last bit)
 
 
+class _Brent:
+    """State of Brent's zero finder (R. P. Brent, "Algorithms for Minimization Without Derivatives", 1973, chapter 4,
+    procedure `zero`): `best` = the point with the smallest |f| seen, `prev` = the best before it, `brk` = the last
+    point whose f has the other sign (the zero lies between best and brk), `step` = the step about to be taken,
+    `before` = the one before it.  The reference's solve_eqn calls the vendored third_party/BRENT
+    (unary_polynomial.cpp:88-95); the formulas are evaluated in the operation order of Brent's publication, which
+    makes the zeros bit-identical to the reference's (tests/test_oracle_ref_poly.py); the organisation is ours."""
+
+    def __init__(self, a, b, f):
+        self.prev, self.f_prev = a, f(a)
+        self.best, self.f_best = b, f(b)
+        assert (self.f_prev < 0) != (self.f_best < 0) or self.f_prev == 0 or self.f_best == 0
+        self.rebracket()
+
+    def rebracket(self):
+        self.brk, self.f_brk = self.prev, self.f_prev
+        self.before = self.best - self.prev
+        self.step = self.before
+
+    def order_by_residual(self):
+        if abs(self.f_brk) < abs(self.f_best):
+            self.prev, self.best, self.brk = self.best, self.brk, self.best
+            self.f_prev, self.f_best, self.f_brk = self.f_best, self.f_brk, self.f_best
+
+    def bisect(self, half):
+        self.before = half
+        self.step = half
+
+    def interpolate(self, half, tol):
+        ratio = self.f_best / self.f_prev
+        if self.prev == self.brk:  # two distinct points: secant
+            num = 2.0 * half * ratio
+            den = 1.0 - ratio
+        else:  # three: inverse quadratic interpolation
+            qa = self.f_prev / self.f_brk
+            qb = self.f_best / self.f_brk
+            num = ratio * (2.0 * half * qa * (qa - qb) - (self.best - self.prev) * (qb - 1.0))
+            den = (qa - 1.0) * (qb - 1.0) * (ratio - 1.0)
+        if 0.0 < num:
+            den = -den
+        else:
+            num = -num
+        two_back = self.before
+        self.before = self.step
+        if 2.0 * num < 3.0 * half * den - abs(tol * den) and num < abs(0.5 * two_back * den):
+            self.step = num / den
+        else:
+            self.bisect(half)
+
+
 def brent_zero(a, b, t, f):
-    """Brent's ``zero`` on a change-of-sign interval [a, b]."""
-    sa, sb = a, b
-    fa, fb = f(sa), f(sb)
-    assert (fa < 0) != (fb < 0) or fa == 0 or fb == 0
-    c, fc = sa, fa
-    e = sb - sa
-    d = e
+    """Brent's ``zero`` on a change-of-sign interval [a, b], absolute tolerance t."""
+    z = _Brent(a, b, f)
     while True:
-        if abs(fc) < abs(fb):
-            sa, sb, c = sb, c, sb
-            fa, fb, fc = fb, fc, fb
-        tol = 2.0 * MACHEPS * abs(sb) + t
-        m = 0.5 * (c - sb)
-        if abs(m) <= tol or fb == 0.0:
-            break
-        if abs(e) < tol or abs(fa) <= abs(fb):
-            e = m
-            d = e
+        z.order_by_residual()
+        tol = 2.0 * MACHEPS * abs(z.best) + t
+        half = 0.5 * (z.brk - z.best)
+        if abs(half) <= tol or z.f_best == 0.0:
+            return z.best
+        if abs(z.before) < tol or abs(z.f_prev) <= abs(z.f_best):
+            z.bisect(half)
         else:
-            s = fb / fa
-            if sa == c:
-                p = 2.0 * m * s
-                q = 1.0 - s
-            else:
-                q = fa / fc
-                r = fb / fc
-                p = s * (2.0 * m * q * (q - r) - (sb - sa) * (r - 1.0))
-                q = (q - 1.0) * (r - 1.0) * (s - 1.0)
-            if 0.0 < p:
-                q = -q
-            else:
-                p = -p
-            s = e
-            e = d
-            if 2.0 * p < 3.0 * m * q - abs(tol * q) and p < abs(0.5 * s * q):
-                d = p / q
-            else:
-                e = m
-                d = e
-        sa, fa = sb, fb
-        if tol < abs(d):
-            sb = sb + d
-        elif 0.0 < m:
-            sb = sb + tol
+            z.interpolate(half, tol)
+        z.prev, z.f_prev = z.best, z.f_best
+        if tol < abs(z.step):
+            z.best = z.best + z.step
+        elif 0.0 < half:
+            z.best = z.best + tol
         else:
-            sb = sb - tol
-        fb = f(sb)
-        if (0.0 < fb and 0.0 < fc) or (fb <= 0.0 and fc <= 0.0):
-            c, fc = sa, fa
-            e = sb - sa
-            d = e
-    return sb
+            z.best = z.best - tol
+        z.f_best = f(z.best)
+        if (0.0 < z.f_best and 0.0 < z.f_brk) or (z.f_best <= 0.0 and z.f_brk <= 0.0):
+            z.rebracket()
 
 
 def solve_eqn(f, xmin, xmax, b=0.0, eps=1e-6):

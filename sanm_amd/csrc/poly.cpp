@@ -18,60 +18,92 @@ double eval(const double* f, int n, double x) {
 
 double stable_x_range(int order) { return std::pow(1e15, 1.0 / static_cast<double>(order)); }
 
-// Brent's zero finder: R. P. Brent, "Algorithms for Minimization Without Derivatives" (1973), procedure `zero`,
-// in the form of J. Burkardt's C++ version that the reference vendors (third_party/BRENT/brent.cpp:1003-1130)
-// -- kept statement for statement (same local names) because `solve_a` must reproduce the reference's restart
-// parameter bit for bit (200/200 against the reference's own translation unit, tests/golden/ref_poly.json).
-double brent_zero(double a, double b, double t, const std::function<double(double)>& f) {
-    const double macheps = std::numeric_limits<double>::epsilon();
-    double sa = a, sb = b, fa = f(sa), fb = f(sb);
-    double c = sa, fc = fa, e = sb - sa, d = e;
-    for (;;) {
-        if (std::fabs(fc) < std::fabs(fb)) {
-            sa = sb; sb = c; c = sa;
-            fa = fb; fb = fc; fc = fa;
-        }
-        double tol = 2.0 * macheps * std::fabs(sb) + t;
-        double m = 0.5 * (c - sb);
-        if (std::fabs(m) <= tol || fb == 0.0) break;
-        if (std::fabs(e) < tol || std::fabs(fa) <= std::fabs(fb)) {
-            e = m;
-            d = e;
-        } else {
-            double p, q, r, s = fb / fa;
-            if (sa == c) {
-                p = 2.0 * m * s;
-                q = 1.0 - s;
-            } else {
-                q = fa / fc;
-                r = fb / fc;
-                p = s * (2.0 * m * q * (q - r) - (sb - sa) * (r - 1.0));
-                q = (q - 1.0) * (r - 1.0) * (s - 1.0);
-            }
-            if (0.0 < p) q = -q; else p = -p;
-            s = e;
-            e = d;
-            if (2.0 * p < 3.0 * m * q - std::fabs(tol * q) && p < std::fabs(0.5 * s * q)) {
-                d = p / q;
-            } else {
-                e = m;
-                d = e;
-            }
-        }
-        sa = sb;
-        fa = fb;
-        if (tol < std::fabs(d)) sb += d;
-        else if (0.0 < m) sb += tol;
-        else sb -= tol;
-        fb = f(sb);
-        if ((0.0 < fb && 0.0 < fc) || (fb <= 0.0 && fc <= 0.0)) {
-            c = sa;
-            fc = fa;
-            e = sb - sa;
-            d = e;
+// Zero of f on a change-of-sign interval by the method of R. P. Brent, "Algorithms for Minimization Without
+// Derivatives" (Prentice-Hall 1973), chapter 4, procedure `zero`: the best point `best` (smallest |f| seen), the
+// previous best `prev`, and `brk`, the last point whose f has the other sign -- the zero lies between `best` and
+// `brk`.  A step is inverse quadratic interpolation through the three points (linear when only two are distinct),
+// accepted when it stays in the first three quarters of the bracket and is at most half the step before last;
+// otherwise the bracket is bisected.  Steps shorter than the tolerance are replaced by a tolerance-sized step towards
+// `brk`.  The reference calls the vendored third_party/BRENT for `solve_a` (unary_polynomial.cpp:88-95); the
+// restart parameter must come out bit for bit, so the FORMULAS below are evaluated in the operation order of
+// Brent's publication (which the vendored code also follows) -- 200/200 identical zeros against the reference's own
+// translation unit (tests/golden/ref_poly.json).  The organisation (state record, named steps) is this file's.
+namespace {
+struct BrentState {
+    double best, f_best;  // current iterate
+    double prev, f_prev;  // the iterate before it
+    double brk, f_brk;    // bracket end: f_brk and f_best differ in sign (or one is zero)
+    double step;          // the step about to be taken
+    double before;        // the step before that (acceptance test of the interpolation)
+
+    //! the bracket end becomes the previous iterate (after a sign change, or at the start)
+    void rebracket() {
+        brk = prev;
+        f_brk = f_prev;
+        before = best - prev;
+        step = before;
+    }
+    //! keep the smaller residual in `best`
+    void order_by_residual() {
+        if (std::fabs(f_brk) < std::fabs(f_best)) {
+            prev = best;
+            best = brk;
+            brk = prev;
+            f_prev = f_best;
+            f_best = f_brk;
+            f_brk = f_prev;
         }
     }
-    return sb;
+    void bisect(double half) {
+        before = half;
+        step = before;
+    }
+    //! secant / inverse quadratic step; falls back to bisection when it is not trusted
+    void interpolate(double half, double tol) {
+        double num, den;
+        const double ratio = f_best / f_prev;
+        if (prev == brk) {  // two distinct points: secant
+            num = 2.0 * half * ratio;
+            den = 1.0 - ratio;
+        } else {  // three: inverse quadratic
+            const double qa = f_prev / f_brk, qb = f_best / f_brk;
+            num = ratio * (2.0 * half * qa * (qa - qb) - (best - prev) * (qb - 1.0));
+            den = (qa - 1.0) * (qb - 1.0) * (ratio - 1.0);
+        }
+        if (0.0 < num) den = -den;
+        else num = -num;
+        const double two_back = before;
+        before = step;
+        if (2.0 * num < 3.0 * half * den - std::fabs(tol * den) && num < std::fabs(0.5 * two_back * den)) step = num / den;
+        else bisect(half);
+    }
+};
+}  // namespace
+
+double brent_zero(double a, double b, double t, const std::function<double(double)>& f) {
+    const double macheps = std::numeric_limits<double>::epsilon();
+    BrentState z{};
+    z.prev = a;
+    z.f_prev = f(a);
+    z.best = b;
+    z.f_best = f(b);
+    z.rebracket();
+    for (;;) {
+        z.order_by_residual();
+        const double tol = 2.0 * macheps * std::fabs(z.best) + t;
+        const double half = 0.5 * (z.brk - z.best);
+        if (std::fabs(half) <= tol || z.f_best == 0.0) return z.best;
+        if (std::fabs(z.before) < tol || std::fabs(z.f_prev) <= std::fabs(z.f_best)) z.bisect(half);
+        else z.interpolate(half, tol);
+        z.prev = z.best;
+        z.f_prev = z.f_best;
+        if (tol < std::fabs(z.step)) z.best += z.step;
+        else if (0.0 < half) z.best += tol;
+        else z.best -= tol;
+        z.f_best = f(z.best);
+        const bool same_side = (0.0 < z.f_best && 0.0 < z.f_brk) || (z.f_best <= 0.0 && z.f_brk <= 0.0);
+        if (same_side) z.rebracket();
+    }
 }
 
 double solve_eqn(const std::vector<double>& f, double xmin, double xmax, double b, double eps) {
