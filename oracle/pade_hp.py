@@ -10,10 +10,11 @@ Gram-Schmidt sweep (pade.cpp:30-55) in double precision, where the loss of ortho
 rounding taken out:
 
   * every inner product of two series vectors is formed EXACTLY: a_i * b_i = p_i + e_i by Dekker's error-free
-    product, the 2n terms summed by math.fsum (correctly rounded), the remainder summed again, three times over
-    (relative error < 1e-45);
+    product, the 2n terms summed by math.fsum (correctly rounded), the remainder summed again, six times over
+    (relative error < 1e-90: the residual norms of the Gram-Schmidt sweep are differences of such products that cancel
+    to kappa^-2 of their size, and kappa is large on these series -- `min_residual_ratio` in the record);
   * everything the algorithm does with the vectors is linear in them, so it is carried out on coefficient vectors over
-    the basis {x_1 .. x_N} with the Gram matrix G = [<x_i, x_j>] in mpmath arithmetic (default 100 digits):
+    the basis {x_1 .. x_N} with the Gram matrix G = [<x_i, x_j>] in mpmath arithmetic (default 200 digits):
     <x_i, q_j> = c_j^T G e_i, |u|^2 = c^T G c, the accept test |pn_lo D_n / D_lo - pn|^2 <= eps^2 |pn|^2 likewise;
   * the poles come from mpmath.polyroots on the exact denominator.
 
@@ -47,7 +48,7 @@ def _two_prod(a, b):
     return p, e
 
 
-def exact_dot(a, b, terms=3):
+def exact_dot(a, b, terms=6):
     """<a, b> as an mpmath number: the exact sum of the exact products, to `terms` doubles"""
     p, e = _two_prod(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64))
     vals = np.concatenate([p, e]).tolist()
@@ -74,7 +75,7 @@ def gram_matrix(xs):
 class PadeHP:
     """pade.cpp:13-105 on coefficient vectors over {x_1..x_N}; `xs` as PadeApproximation takes them"""
 
-    def __init__(self, xs, anm_cond, dps=100, gram=None):
+    def __init__(self, xs, anm_cond, dps=200, gram=None):
         mp.mp.dps = dps
         self.nx = nx = len(xs)
         self.n = n = nx - 1
@@ -82,6 +83,7 @@ class PadeHP:
         self.G = G = gram if gram is not None else gram_matrix(xs)
         self.d, self.d_lo, self.t_nume = [], [], []
         self.diag = None
+        self.degenerate = 0
         if xs[0].shape[0] < nx * 2 or nx <= 4:
             return
         eps = mp.mpf(np.finfo(np.float64).eps)
@@ -103,9 +105,11 @@ class PadeHP:
                     a[i][j] = mp.mpf(0)  # (pade.cpp:40-44: asserted small, then dropped -- projection and all)
                 else:
                     u = [uk - a[i][j] * cj for uk, cj in zip(u, C[j])]
-            aii = mp.sqrt(gnorm2(u))
-            if aii == 0:
+            n2 = gnorm2(u)
+            if n2 <= 0:  # x_i lies in the span of its predecessors to working precision (pade.cpp:57-60: aii == 0)
+                self.degenerate = i
                 return
+            aii = mp.sqrt(n2)
             a[i][i] = aii
             u = [uk / max(aii, eps) for uk in u]
             if aii < eps:
@@ -227,11 +231,13 @@ class PadeHP:
         return dg
 
 
-def arbitrate(xs, anm_cond, start, eps, limit=0.0, dps=100):
+def arbitrate(xs, anm_cond, start, eps, limit=0.0, dps=200):
     """both high-precision outcomes for one series: {"exact": diag, "ref_roots": diag, "d": [...]}.  An outcome is
     (accepted, range) like tests/lockstep.py::_outcome."""
     p = PadeHP(xs, anm_cond, dps=dps)
-    out = {"d": [float(c) for c in p.d]}
+    out = {"d": [float(c) for c in p.d], "degenerate_at": p.degenerate,
+           # conditioning of the sweep: the smallest ratio |u_i| / |x_i| (the fp64 sweep loses kappa^2 eps)
+           "min_residual_ratio": (min(float(p.a[i][i] / mp.sqrt(p.G[i][i])) for i in range(1, p.n + 1)) if p.d else None)}
     for key, roots in (("exact", "exact"), ("ref_roots", "ref")):
         out[key] = p.estimate_valid_range(start, eps, limit, roots=roots)
     return out

@@ -60,6 +60,42 @@ public:
     }
 };
 
+// ---- host-side trace of the step's tail (SANM_TAIL_TRACE=1; scripts/tail_trace.py) ----------------------------
+// mark(label): the host clock at a point of the step; at exit the mean interval between consecutive marks is printed.
+// What it is for: the device sits idle between the probe kernels of the Pade range estimate and the restart (the
+// kernel trace shows the gaps, not what the host does in them).
+namespace {
+struct HostTrace {
+    const bool on = std::getenv("SANM_TAIL_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point last;
+    const char* last_label = nullptr;
+    std::vector<std::pair<std::string, std::pair<double, int>>> acc;
+    void mark(const char* label) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        if (last_label) {
+            const std::string key = std::string(last_label) + " -> " + label;
+            const double us = std::chrono::duration<double, std::micro>(now - last).count();
+            auto it = std::find_if(acc.begin(), acc.end(), [&](const auto& e) { return e.first == key; });
+            if (it == acc.end()) acc.push_back({key, {us, 1}});
+            else {
+                it->second.first += us;
+                it->second.second += 1;
+            }
+        }
+        last = now;
+        last_label = label;
+    }
+    ~HostTrace() {
+        if (!on) return;
+        for (const auto& e : acc)
+            std::fprintf(stderr, "tail_trace %-58s %9.1f us mean over %d\n", e.first.c_str(),
+                         e.second.first / e.second.second, e.second.second);
+    }
+};
+HostTrace g_trace;
+}  // namespace
+
 // ------------------------------------------------------------------ PCG --
 namespace {
 class PcgSolver final : public LinearSolver {
@@ -486,6 +522,7 @@ PadeApproximation::PadeApproximation(Backend* be, const std::vector<DVec>& xs,
             d[i] = -s * y / (y * y + 1e-20);
         }
     };
+    g_trace.mark("pade: basis on host");
     solve_d(m_d, n);
     solve_d(m_d_lo, n - 1);
     m_t_nume.assign(n, 0.0);
@@ -531,7 +568,10 @@ bool PadeApproximation::estimate_valid_range(double start, double eps, double li
     m_diag.built = 1;
     m_diag.d = m_d;
     std::vector<double> roots;
-    if (!poly::real_roots(m_d, roots)) return false;
+    g_trace.mark("pade: denominators");
+    const bool roots_ok = poly::real_roots(m_d, roots);
+    g_trace.mark("pade: roots");
+    if (!roots_ok) return false;
     m_diag.roots_valid = 1;
     double pole = 0;
     for (double r : roots)
@@ -556,7 +596,9 @@ bool PadeApproximation::estimate_valid_range(double start, double eps, double li
             nume_coefs(as[c], m_d_lo.data(), n - 1, c2.data() + (size_t)c * n);
             scale[c] = poly::eval(m_d, as[c]) / poly::eval(m_d_lo, as[c]);
         }
+        g_trace.mark("pade: probe batch prepared");
         m_be->lincomb2_diff_norms_multi(m_len, n, ptrs.data(), nc, c1.data(), c2.data(), scale.data(), r.data());
+        g_trace.mark("pade: probe batch returned");
         std::vector<char> ok(nc);
         for (int c = 0; c < nc; ++c) ok[c] = r[2 * c] <= r[2 * c + 1] * eps2;
         m_probe_margin.resize(nc);
@@ -1102,6 +1144,7 @@ void AnmDriver::solve_expansion_coeffs() {
         double ti = 0;
         const double* xbi;
         double* xi = m_xt_coeffs[i].p();
+        bool pass_done = false;  // COEFF(i) + BIAS(i + 1) already queued together with next_coeff
         if (i == 1) {
             {
                 ScopedTimer t{this, "build_sparse_coeff"};
@@ -1124,7 +1167,9 @@ void AnmDriver::solve_expansion_coeffs() {
             {
                 ScopedTimer t{this, "sparse_solve"};
                 m_solver->solve(grad_t, m_xgt.p());
+                g_trace.mark("order 1 queued");
                 xgt2 = be->dot(n, m_xgt.p(), m_xgt.p());  // (waits for the device: the factor's status is in)
+                g_trace.mark("order 1: |xgt|^2 returned");
                 // sparse_solver.cpp:288-289: the coefficients must be finite
                 sanm_check(host_checks[0] == 0, "non-finite Jacobian coefficient");
                 if (m_solver->check_prepared(host_checks + 1)) {
@@ -1143,6 +1188,7 @@ void AnmDriver::solve_expansion_coeffs() {
             // reduction already on the host, instead of another launch and host round trip
             static const bool analytic = std::getenv("SANM_X1_DOT_ANALYTIC") != nullptr;
             xgt_dot_x1 = analytic ? -ti * xgt2 : be->dot(n, xi, m_xgt.p());
+            g_trace.mark("order 1: xgt.x1 returned");
         } else {
             // t_i = (xb_i . x_1) / (t1 - xgt . x_1);  x_i = -t_i*xgt - xb_i  (anm.cpp:246-264)
             if (pade_riders) m_pade_ws.phase(m_xt_coeffs, i - 1, 2, anm_cond, true);
@@ -1157,8 +1203,20 @@ void AnmDriver::solve_expansion_coeffs() {
             }
             xbi = m_xbi.p();
             if (pade_riders) m_pade_ws.phase(m_xt_coeffs, i - 1, 3, anm_cond, true);
-            be->next_coeff_async(n, m_dev_scalars.p() + i, 1.0 / (t1 - xgt_dot_x1), m_xgt.p(), xbi, xi,
-                                 m_host_scalars + 3 * i);
+            // next_coeff and the COEFF(i) + BIAS(i + 1) pass that consumes x_i as ONE launch where the backend offers
+            // it (the pass forms x_i in its gather, rider workgroups store it: Backend::run_pass_next_coeff) and
+            // nothing between the two looks at x_i; two launches otherwise -- the same arithmetic
+            const NextCoeff nc{n, m_dev_scalars.p() + i, 1.0 / (t1 - xgt_dot_x1), m_xgt.p(), xbi, xi,
+                               m_host_scalars + 3 * i};
+            static const bool sanity_side_env = std::getenv("SANM_SANITY_SIDE") != nullptr;
+            const bool nothing_between = !(m_inject.kind == 1 && m_inject.order == i) && !pade_side && !verbose &&
+                                         !(do_sanity && sanity_side_env);
+            if (fuse_passes && i < N && nothing_between && !m_pattern->has_t() && m_prog) {
+                ScopedTimer t{this, "taylor_push"};
+                pass_done = be->run_pass_next_coeff(m_prog->dev(), i, nc);
+                if (pass_done) bias_done = true;
+            }
+            if (!pass_done) be->next_coeff_async(nc.n, nc.num, nc.scale, nc.xg, nc.xb, nc.out, nc.t_out);
         }
         m_nr_valid_coeffs = i + 1;
         if (m_inject.kind == 1 && m_inject.order == i) apply_injection(xi, n1);
@@ -1189,7 +1247,7 @@ void AnmDriver::solve_expansion_coeffs() {
                 m_trace_jacob = std::sqrt(be->dot(m_pattern->nnz(), m_pattern->csr().val, m_pattern->csr().val));
             }
         }
-        if (i < N) {
+        if (i < N && !pass_done) {
             ScopedTimer t{this, "taylor_push"};
             run_pass(fuse_passes ? PASS_COEFF_BIAS : PASS_COEFF, i, xi);
             bias_done = fuse_passes;
@@ -1224,7 +1282,9 @@ void AnmDriver::solve_expansion_coeffs() {
         be->d2h_async(m_pade_ws.host_acoef, m_pade_ws.acoef.p(), (size_t)(N + 1) * (N + 1) * 8);
         m_pade_ws.host_valid = true;
     }
+    g_trace.mark("loop queued");
     be->sync();
+    g_trace.mark("loop-end sync returned");
     auto check_sanity = [&]() {
         for (int i = 1; i <= N && do_sanity; ++i) {
             const double ex = host_sanity[2 * (i - 1)], xdot = host_sanity[2 * (i - 1) + 1];
@@ -1248,6 +1308,7 @@ void AnmDriver::solve_expansion_coeffs() {
         be->side_wait();
         throw;
     }
+    g_trace.mark("checks done");
     std::exception_ptr held;
     try {
         ScopedTimer t{this, "estimate_valid_range"};
@@ -1259,6 +1320,7 @@ void AnmDriver::solve_expansion_coeffs() {
         be->side_wait();
         check_sanity();
     }
+    g_trace.mark("range estimate done");
     if (held) std::rethrow_exception(held);
     if (verbose) {
         // the reference's printout, anm.cpp:200-203, :247-259, :295-309 (same format strings)
@@ -1421,9 +1483,12 @@ AnmEqnSolver::AnmEqnSolver(Backend* be, const Graph& g, int out_var, const Spars
 AnmEqnSolver& AnmEqnSolver::next_iter() {
     // libsanm/anm.cpp:464-478
     if (m_converged) return *this;
+    g_trace.mark("next_iter");
     double a = get_t_upper() >= 1 ? solve_a(1) : get_t_max_a();
+    g_trace.mark("restart parameter");
     eval_xt(a, m_tmp0.p());
     m_be->d2d(m_xt0.p(), m_tmp0.p(), (m_n + 1) * 8);
+    g_trace.mark("restart point queued");
     m_be->zero(m_xt0.p() + m_n, 8);  // set t0 to 0 (queued, like everything before the first check of the step)
     m_t0_host = 0;
     m_t0_known = true;
@@ -1435,7 +1500,9 @@ bool AnmEqnSolver::on_fx0_computed(const double* fx_dev) {
     // libsanm/anm.cpp:480-491
     if (m_converged) return false;
     m_be->axpby(m_n, 1.0, fx_dev, 1.0, m_eqn_y.p(), m_v.p());
+    g_trace.mark("order 0 queued");
     m_residual_rms = std::sqrt(m_be->dot(m_n, m_v.p(), m_v.p()) / double(m_n));
+    g_trace.mark("residual returned");
     if (m_residual_rms < m_converge_rms) {
         m_converged = true;
         return false;

@@ -72,6 +72,17 @@ struct GsPhase {
     double* red_out = nullptr;      // device memory
 };
 
+//! the order loop's x_i = -t xg - xb, t = *num * scale (Backend::next_coeff_async), as arguments
+struct NextCoeff {
+    size_t n = 0;
+    const double* num = nullptr;  // device scalar
+    double scale = 0;
+    const double* xg = nullptr;
+    const double* xb = nullptr;
+    double* out = nullptr;    // n + 1 entries: x_i, t
+    double* t_out = nullptr;  // pinned host memory
+};
+
 class Backend {
 public:
     virtual ~Backend() = default;
@@ -302,6 +313,10 @@ public:
     //! *out = x . y  (out: device or pinned host memory)
     virtual void dot_async(size_t n, const double* x, const double* y, double* out) = 0;
     //! t = *num * scale;  out[0..n) = -t * x - y;  out[n] = t;  *t_out = t   (anm.cpp:258-264)
+    //! next_coeff and the COEFF(order) + BIAS(order + 1) pass that follows it as ONE launch: the pass forms x_i in its
+    //! gather, extra workgroups store it (and carry a pending Gram-Schmidt scaling phase).  false: not offered for
+    //! this program here -- the caller queues the two separately.  Same arithmetic either way.
+    virtual bool run_pass_next_coeff(const ProgramDev&, int /*order*/, const NextCoeff&) { return false; }
     virtual void next_coeff_async(size_t n, const double* num, double scale, const double* x, const double* y,
                                   double* out, double* t_out) = 0;
     // One classical Gram-Schmidt step of the Pade basis (pade.cpp:36-70) is three queued kernels; scalars stay

@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -30,6 +31,7 @@
 #include "backend.h"
 #include "graph.h"
 #include "mf_kernels.h"
+#include "red_ops.h"
 #include "row_ops.h"
 #include "rtc.h"
 #include "tet_ops.h"
@@ -220,15 +222,6 @@ __global__ void residual_dd_kernel(CsrDev A, const double* __restrict__ b, const
     if (row < A.n && sub == 0) r[row] = s.hi + s.lo;
 }
 
-__device__ __forceinline__ double wave_reduce_sum(double v) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-__device__ __forceinline__ double wave_reduce_max(double v) {
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
-    return v;
-}
-
 // block reduce (256 threads = 4 waves) then one atomic per block
 template <bool IS_MAX>
 __device__ __forceinline__ void block_reduce_commit(double v, double* out) {
@@ -253,103 +246,6 @@ __device__ __forceinline__ void block_reduce_commit(double v, double* out) {
             atomicAdd(out, r);
         }
     }
-}
-
-// Grid-wide reduction of nv values whose result the HOST reads: every workgroup stores its partials,
-// the last one to arrive (device-scope ticket) combines them in workgroup order -- deterministic, unlike
-// an atomic accumulation -- and writes straight into pinned host memory, so a reduction costs one launch
-// and one stream synchronisation (no accumulator memset, no read-back copy kernel).
-constexpr unsigned RED_MAX_GRID = 512;  // one same-address atomic per workgroup (~12 ns each) bounds the useful grid
-struct GridRed {
-    double* partials;  // [MAX_RED][RED_MAX_GRID]
-    unsigned* ticket;
-    double* host;      // pinned, device-accessible
-};
-// (bid of nb: the workgroup's place among the workgroups that take part -- all of a launch, or the extra ones a
-// launch carries for a deferred Gram-Schmidt phase, see GsRider)
-template <int NV>
-__device__ __forceinline__ void grid_commit_at(const double (&v)[NV], int nv, unsigned maxmask, GridRed g,
-                                               unsigned bid, unsigned nb) {
-    // A wavefront reduction is 6 cross-lane steps of ~100 cycles; with many values per thread (the Gram-Schmidt
-    // projections: up to 24) they are spread over the 4 wavefronts through LDS instead of every wavefront
-    // reducing every value (multi_dot_kernel: 17.6 -> see DESIGN.md for 20 vectors).
-    constexpr bool kViaLds = NV > 4;
-    __shared__ double sh[NV][4];
-    __shared__ double stage[kViaLds ? NV : 1][kViaLds ? 256 : 1];
-    __shared__ bool last;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if constexpr (kViaLds) {
-#pragma unroll
-        for (int j = 0; j < NV; ++j)
-            if (j < nv) stage[j][threadIdx.x] = v[j];
-        __syncthreads();
-        for (int j = w; j < nv; j += 4) {
-            const bool mx = (maxmask >> j) & 1;
-            const double a = stage[j][lane], b = stage[j][lane + 64], c = stage[j][lane + 128],
-                         d = stage[j][lane + 192];
-            const double r = mx ? wave_reduce_max(fmax(fmax(a, b), fmax(c, d))) : wave_reduce_sum((a + b) + (c + d));
-            if (lane == 0) {
-                sh[j][0] = r;
-                sh[j][1] = sh[j][2] = sh[j][3] = mx ? -1e300 : 0.0;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < NV; ++j)
-            if (j < nv) {
-                const double r = ((maxmask >> j) & 1) ? wave_reduce_max(v[j]) : wave_reduce_sum(v[j]);
-                if (lane == 0) sh[j][w] = r;
-            }
-    }
-    __syncthreads();
-    // Hand-off without cache-wide fences (MI355X_MICROARCH.md, inter-workgroup visibility): the partials are
-    // written through (agent-scope atomic stores), the storing wavefront drains them, one lane signals with
-    // an agent-scope add behind the workgroup barrier, and the workgroup whose add came last reads them
-    // with agent-scope loads.
-    if ((int)threadIdx.x < nv) {
-        const int j = threadIdx.x;
-        const bool mx = (maxmask >> j) & 1;
-        double r = sh[j][0];
-        for (int i = 1; i < 4; ++i) r = mx ? fmax(r, sh[j][i]) : r + sh[j][i];
-        __hip_atomic_store(&g.partials[j * RED_MAX_GRID + bid], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0)
-        last = __hip_atomic_fetch_add(g.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nb - 1;
-    __syncthreads();
-    if (!last) return;
-    // one wavefront per value; the (up to KV) values of a wavefront are read in lock step, so that their
-    // partials -- agent-scope loads that go all the way to memory -- share the round trips
-    constexpr int KV = (NV + 3) / 4;
-    double r[KV];
-#pragma unroll
-    for (int q = 0; q < KV; ++q) r[q] = ((maxmask >> (w + 4 * q)) & 1) ? -1e300 : 0.0;
-    for (unsigned b0 = 0; b0 < nb; b0 += 64) {
-        const unsigned b = b0 + lane;
-#pragma unroll
-        for (int q = 0; q < KV; ++q) {
-            const int j = w + 4 * q;
-            if (j < nv && b < nb) {
-                const double pv = __hip_atomic_load(&g.partials[j * RED_MAX_GRID + b], __ATOMIC_RELAXED,
-                                                    __HIP_MEMORY_SCOPE_AGENT);
-                r[q] = ((maxmask >> j) & 1) ? fmax(r[q], pv) : r[q] + pv;
-            }
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < KV; ++q) {
-        const int j = w + 4 * q;
-        if (j < nv) {
-            const double t = ((maxmask >> j) & 1) ? wave_reduce_max(r[q]) : wave_reduce_sum(r[q]);
-            if (lane == 0) g.host[j] = t;
-        }
-    }
-    if (threadIdx.x == 0) *g.ticket = 0;  // launches on the stream are serialised
-}
-template <int NV>
-__device__ __forceinline__ void grid_commit(const double (&v)[NV], int nv, unsigned maxmask, GridRed g) {
-    grid_commit_at<NV>(v, nv, maxmask, g, blockIdx.x, gridDim.x);
 }
 
 __global__ void __launch_bounds__(256) dot_kernel(size_t n, const double* __restrict__ x,
@@ -417,18 +313,6 @@ __global__ void __launch_bounds__(256) gs_update_kernel(size_t n, const double* 
                                                         const double* __restrict__ coefs, int first, double* out,
                                                         GridRed g) {
     gs_update_body<NVT>(n, x, q, coefs, first, out, g, blockIdx.x, gridDim.x);
-}
-// v *= 1 / max(sqrt(*norm2), eps), and the squared norm of the result for the (rare) second normalisation
-__device__ __forceinline__ void scale_rsqrt_body(size_t n, double* v, const double* __restrict__ norm2, double eps,
-                                                 GridRed g, unsigned bid, unsigned nb) {
-    const double f = 1.0 / fmax(sqrt(*norm2), eps);
-    double s[1] = {0};
-    for (size_t i = (size_t)bid * blockDim.x + threadIdx.x; i < n; i += (size_t)nb * blockDim.x) {
-        const double w = v[i] * f;
-        v[i] = w;
-        s[0] += w * w;
-    }
-    grid_commit_at<1>(s, 1, 0u, g, bid, nb);
 }
 __global__ void __launch_bounds__(256) scale_rsqrt_kernel(size_t n, double* v, const double* __restrict__ norm2,
                                                           double eps, GridRed g) {
@@ -1551,6 +1435,88 @@ public:
         (void)hipModuleUnload(m_spec[id].mod);
         m_spec[id] = SpecKernels{};
     }
+    //! one launch of a pass kernel compiled for P's graph.  nc (PASS_COEFF_BIAS only): the launch also stands for
+    //! next_coeff -- see spec_pass4 in the generated source (graph.cpp)
+    void launch_spec(const ProgramDev& P, int mode, int order, const double* xvec, int nparts, size_t lds,
+                     const NextCoeff* nc) {
+        struct Args {  // SPEC_PARAMS of the generated source (graph.cpp) ...
+            double* arena;
+            const uint32_t* rin_idx;
+            const double* rin_coef;
+            const double* xvec;
+            long long T;
+            int order, max_order, rin_nslot;
+        };
+        struct Args4 {  // ... and what spec_pass4 takes behind them
+            Args a;  // (56 bytes with its tail padding: the first pointer behind it is 8-aligned in the kernel's list too)
+            const double* nc_xg;
+            const double* nc_num;
+            double nc_scale;
+            double* nc_out;
+            double* nc_thost;
+            unsigned long long nc_n;
+            double* rd_out;
+            const double* rd_norm2;
+            double rd_eps;
+            unsigned long long rd_n;
+            double* g_partials;
+            unsigned* g_ticket;
+            double* g_host;
+            unsigned own, nc_blocks, rd_nblk;
+        };
+        static_assert(offsetof(Args4, nc_xg) == 56, "kernel argument layout");
+        const unsigned own = nblk(P.T, 64);
+        Args4 a4{};
+        a4.a = Args{P.arena, P.rin.idx, P.rin.coef, xvec, (long long)P.T, order, P.max_order, P.rin.nslot};
+        a4.own = own;
+        unsigned extra = 0;
+        if (nc) {
+            a4.a.xvec = nc->xb;
+            a4.nc_xg = nc->xg;
+            a4.nc_num = nc->num;
+            a4.nc_scale = nc->scale;
+            a4.nc_out = nc->out;
+            a4.nc_thost = nc->t_out;
+            a4.nc_n = nc->n;
+            a4.nc_blocks = std::min<unsigned>(nblk(nc->n + 1, 256), 256);
+            if (m_pending.kind == 3 && m_stream == m_main) {  // the scaling of a Gram-Schmidt step rides along
+                const GsRider rd = take_rider();
+                a4.rd_out = rd.out;
+                a4.rd_norm2 = rd.norm2;
+                a4.rd_eps = rd.eps;
+                a4.rd_n = rd.n;
+                a4.g_partials = rd.g.partials;
+                a4.g_ticket = rd.g.ticket;
+                a4.g_host = rd.g.host;
+                a4.rd_nblk = rd.nblk;
+            }
+            extra = a4.nc_blocks + a4.rd_nblk;
+        }
+        size_t arg_size = mode == PASS_COEFF_BIAS ? sizeof(Args4) : sizeof(Args);
+        void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a4, HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_size,
+                          HIP_LAUNCH_PARAM_END};
+        ++m_launch_count;
+        HIP_CHECK(hipModuleLaunchKernel(m_spec[P.spec_id].pass[mode], own + extra, mode == PASS_GRAD ? P.odim : 1, 1,
+                                        64 * nparts, 1, 1, (unsigned)lds, m_stream, nullptr, config));
+    }
+    bool run_pass_next_coeff(const ProgramDev& P, int order, const NextCoeff& nc) override {
+        static const bool off = std::getenv("SANM_NO_NEXT_COEFF_FUSION") != nullptr;
+        const int nparts = order + 1 >= m_conv_split_order ? m_conv_parts : 1;
+        const size_t lds = (size_t)(P.cur_size + (nparts - 1) * 9) * 64 * sizeof(double);
+        if (off || P.spec_id < 0 || lds > 48 * 1024 || m_stream != m_main) return false;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (m_time_passes) {
+            HIP_CHECK(hipEventCreate(&e0));
+            HIP_CHECK(hipEventCreate(&e1));
+            HIP_CHECK(hipEventRecord(e0, m_stream));
+        }
+        launch_spec(P, PASS_COEFF_BIAS, order, nc.xb, nparts, lds, &nc);
+        if (m_time_passes) {
+            HIP_CHECK(hipEventRecord(e1, m_stream));
+            m_pass_events.emplace_back(e0, e1);
+        }
+        return true;
+    }
     void run_pass(const ProgramDev& P, int mode, int order, const double* xvec) override {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (m_time_passes) {
@@ -1579,20 +1545,7 @@ public:
         }
         if (P.spec_id >= 0 && lds <= 48 * 1024) {
             // this program's own kernels (same grid, same LDS layout as the interpreter's)
-            struct {  // SPEC_PARAMS of the generated source (graph.cpp)
-                double* arena;
-                const uint32_t* rin_idx;
-                const double* rin_coef;
-                const double* xvec;
-                long long T;
-                int order, max_order, rin_nslot;
-            } args{P.arena, P.rin.idx, P.rin.coef, xvec, (long long)P.T, order, P.max_order, P.rin.nslot};
-            size_t arg_size = sizeof(args);
-            void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_size,
-                              HIP_LAUNCH_PARAM_END};
-            ++m_launch_count;
-            HIP_CHECK(hipModuleLaunchKernel(m_spec[P.spec_id].pass[mode], nblk(P.T, 64), mode == PASS_GRAD ? P.odim : 1,
-                                            1, 64 * nparts, 1, 1, (unsigned)lds, m_stream, nullptr, config));
+            launch_spec(P, mode, order, xvec, nparts, lds, nullptr);
             if (m_time_passes) {
                 HIP_CHECK(hipEventRecord(e1, m_stream));
                 m_pass_events.emplace_back(e0, e1);

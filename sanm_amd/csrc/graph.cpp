@@ -631,7 +631,7 @@ std::string Program::spec_source() const {
     // SANM_NO_CONV_FUSION: every operator walks the history itself, as in the interpreter kernels
     const int conv_total = std::getenv("SANM_NO_CONV_FUSION") ? 0 : m_dev.conv_total;
     add("#define SANM_CONV_MAX %d\n", std::max(conv_total, 1));
-    src += "#include \"tet_ops.h\"\nusing namespace sanm_hip;\nnamespace {\n";
+    src += "#include \"tet_ops.h\"\n#include \"red_ops.h\"\nusing namespace sanm_hip;\nnamespace {\n";
     add("constexpr int kNops = %zu, kCurSize = %d, kOutVar = %d, kConvTotal = %d;\nconstexpr long long kTpad = %lld, "
         "kOutAos = %lld;\nconstexpr bool kNoOverlap = %s;\n",
         m_ops.size(), (int)m_dev.cur_size, (int)m_dev.out_var, conv_total, (long long)m_dev.Tpad,
@@ -749,9 +749,41 @@ extern "C" __global__ void __launch_bounds__(256, 3) spec_pass2(SPEC_PARAMS) {
     SPEC_P
     spec_body<PASS_BIAS>(P, order, xvec);
 }
-// COEFF(order) by wavefront 0 of every workgroup, then BIAS(order + 1) by all of them (PASS_COEFF_BIAS)
-extern "C" __global__ void __launch_bounds__(256, 3) spec_pass4(SPEC_PARAMS) {
+// COEFF(order) by wavefront 0 of every workgroup, then BIAS(order + 1) by all of them (PASS_COEFF_BIAS).
+// With nc_xg set the launch also stands for the order loop's next_coeff (Backend::run_pass_next_coeff): the gather of
+// the placeholder forms x_order = -t xg - xvec on the way (t = *nc_num * nc_scale, a device scalar), and the
+// workgroups behind the first `own` are riders: nc_blocks of them store x_order (and t, also to pinned memory), rd_nblk
+// more run the scaling phase of a deferred Gram-Schmidt step -- what next_coeff_kernel and its rider did in a launch
+// of their own.
+extern "C" __global__ void __launch_bounds__(256, 3) spec_pass4(SPEC_PARAMS, const double* nc_xg, const double* nc_num,
+                                                                double nc_scale, double* nc_out, double* nc_thost,
+                                                                unsigned long long nc_n, double* rd_out,
+                                                                const double* rd_norm2, double rd_eps,
+                                                                unsigned long long rd_n, double* g_partials,
+                                                                unsigned* g_ticket, double* g_host, unsigned own,
+                                                                unsigned nc_blocks, unsigned rd_nblk) {
+    if (blockIdx.x >= own) {
+        const unsigned r = blockIdx.x - own;
+        if (r < nc_blocks) {
+            const double t = *nc_num * nc_scale;
+            for (unsigned long long i = (unsigned long long)r * blockDim.x + threadIdx.x; i <= nc_n;
+                 i += (unsigned long long)nc_blocks * blockDim.x) {
+                if (i < nc_n) nc_out[i] = -t * nc_xg[i] - xvec[i];
+                else {
+                    nc_out[i] = t;
+                    *nc_thost = t;
+                }
+            }
+        } else {
+            scale_rsqrt_body(rd_n, rd_out, rd_norm2, rd_eps, GridRed{g_partials, g_ticket, g_host}, r - nc_blocks, rd_nblk);
+        }
+        return;
+    }
     SPEC_P
+    if (nc_xg) {
+        P.rin.xg = nc_xg;
+        P.rin.t = *nc_num * nc_scale;
+    }
     if ((threadIdx.x >> 6) == 0) spec_body<PASS_COEFF>(P, order, xvec);
     // the coefficients just stored are history for the convolutions
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -93,6 +93,11 @@ struct RemapInDev {
     const uint32_t* idx;
     const double* coef;
     int32_t nslot;
+    // next_coeff fused into the gather (Backend::run_pass_next_coeff): with xg set, the gathered vector is not read
+    // from memory but formed on the way, x[j] = -t * xg[j] - xvec[j] -- the x_i of the order loop (anm.cpp:261-264)
+    // with xvec = A^-1 b_i and xg = A^-1 g_t; same two roundings as the kernel that stores x_i
+    const double* xg = nullptr;
+    double t = 0;
 };
 
 struct ProgramDev {

@@ -1389,9 +1389,17 @@ SANM_HD void gather_remap_in(const TetCtx& c, const RemapInDev& rin, const doubl
             idx[i] = rin.idx[(int64_t)i * s + c.tet];
             coef[i] = rin.coef[(int64_t)i * s + c.tet];
         }
+        double v[9 * NSLOT];
+        for (int i = 0; i < 9 * NSLOT; ++i) v[i] = xvec[idx[i]];
+        if (rin.xg) {  // (uniform) x_i formed on the way: both vectors requested together
+            double g[9 * NSLOT];
+            for (int i = 0; i < 9 * NSLOT; ++i) g[i] = rin.xg[idx[i]];
+            const double mt = -rin.t;
+            for (int i = 0; i < 9 * NSLOT; ++i) v[i] = mt * g[i] - v[i];
+        }
         for (int e = 0; e < 9; ++e) {
             double acc = 0;
-            for (int sl = 0; sl < NSLOT; ++sl) acc = __builtin_fma(coef[sl * 9 + e], xvec[idx[sl * 9 + e]], acc);
+            for (int sl = 0; sl < NSLOT; ++sl) acc = __builtin_fma(coef[sl * 9 + e], v[sl * 9 + e], acc);
             X[e] = acc;
         }
     } else {
@@ -1399,7 +1407,9 @@ SANM_HD void gather_remap_in(const TetCtx& c, const RemapInDev& rin, const doubl
             double acc = 0;
             for (int sl = 0; sl < rin.nslot; ++sl) {
                 int64_t off = ((int64_t)sl * 9 + e) * s + c.tet;
-                acc = __builtin_fma(rin.coef[off], xvec[rin.idx[off]], acc);
+                double v = xvec[rin.idx[off]];
+                if (rin.xg) v = -rin.t * rin.xg[rin.idx[off]] - v;
+                acc = __builtin_fma(rin.coef[off], v, acc);
             }
             X[e] = acc;
         }

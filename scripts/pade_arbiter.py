@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Third arbiter for the Pade decisions: every range estimate of the lock-step continuations is
 taken a third time in HIGH precision (oracle/pade_hp.py: exact inner products of the series vectors, the reference's
-Gram-Schmidt / solve_d / probes / bisection in 100-digit arithmetic) on the device's series and on the fp64 oracle's,
+Gram-Schmidt / solve_d / probes / bisection in 200-digit arithmetic) on the device's series and on the fp64 oracle's,
 and the record says, per decision, which fp64 side agrees with the rounding-free outcome.
 
   python scripts/pade_arbiter.py [--api hip|hostsim] [--cases cuboid_nc,...,human_arap16] [--out file.json]
@@ -58,7 +58,7 @@ def main():
     else:
         from tests.hostsim import get_hostsim_api
         api = get_hostsim_api()
-    res = {"device_backend": api.backend_name(), "precision": "exact inner products + 100-digit algebra "
+    res = {"device_backend": api.backend_name(), "precision": "exact inner products + 200-digit algebra "
            "(oracle/pade_hp.py)", "cases": {}}
     tally = {"decisions": 0, "fp64_sides_agree": 0, "events": 0,
              "event_device_matches_hp": 0, "event_oracle_matches_hp": 0, "event_both": 0, "event_neither": 0,

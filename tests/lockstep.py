@@ -170,7 +170,7 @@ class _LockStepBase:
                 f"step {k}: restart points differ by {err:.2e} (increment {scale:.2e})"
 
     def _arbitrate(self, dev_coeffs, dev, own):
-        """the same range estimate in high precision (exact inner products, 100-digit algebra: oracle/pade_hp.py) on
+        """the same range estimate in high precision (exact inner products, 200-digit algebra: oracle/pade_hp.py) on
         the device's series and on the oracle's: which fp64 side took the decision the rounding-free algorithm takes"""
         from oracle import pade_hp
         o, hp = self.o, self.o.hp
