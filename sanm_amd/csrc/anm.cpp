@@ -1070,6 +1070,7 @@ void AnmDriver::solve_expansion_coeffs() {
     check_powflag();
 
     double t1 = 0, xgt_dot_x1 = 0;
+    bool order1_on_device = false;  // t_1 and xgt . x_1 never came to the host (Backend::x1_async)
     const double* grad_t = nullptr;
     const int32_t* rhs_perm = nullptr;
     // COEFF(i) and BIAS(i+1) are back to back: one launch among the kernels compiled for this graph
@@ -1164,31 +1165,48 @@ void AnmDriver::solve_expansion_coeffs() {
                 m_solver->prepare_async(host_checks + 1);
             }
             double xgt2 = 0;
+            xbi = bi;  // zero at first order (anm.cpp:235)
+            // Order 1 needs two reductions (|xgt|^2 for t_1, xgt . x_1 for the scale of every later t_i).  Where the
+            // backend offers it they stay on the device (Backend::x1_async; NextCoeff::sc) and the host queues the
+            // whole order loop behind the factorisation without waiting once: the factor's status and the Jacobian's
+            // finiteness are then examined with everything else after the loop.  SANM_ORDER1_HOST=1 (and the
+            // printout / profile mode that needs the scalars) takes them to the host as before -- same arithmetic.
+            static const bool order1_host = std::getenv("SANM_ORDER1_HOST") != nullptr || std::getenv("SANM_X1_DOT_ANALYTIC") != nullptr;
             {
                 ScopedTimer t{this, "sparse_solve"};
                 m_solver->solve(grad_t, m_xgt.p());
                 g_trace.mark("order 1 queued");
-                xgt2 = be->dot(n, m_xgt.p(), m_xgt.p());  // (waits for the device: the factor's status is in)
-                g_trace.mark("order 1: |xgt|^2 returned");
-                // sparse_solver.cpp:288-289: the coefficients must be finite
-                sanm_check(host_checks[0] == 0, "non-finite Jacobian coefficient");
-                if (m_solver->check_prepared(host_checks + 1)) {
-                    // perturbed pivots: the solver refines from now on (sparse_solver.cpp:107-127: PARDISO's
-                    // behaviour); this first solution is computed again
-                    m_solver->solve(grad_t, m_xgt.p());
-                    xgt2 = be->dot(n, m_xgt.p(), m_xgt.p());
+                if (!order1_host && !verbose && !m_force_order1_host) {
+                    if (m_order1_sc.empty()) m_order1_sc = DVec{be, 4};
+                    double* sc = m_order1_sc.p();
+                    be->dot_async(n, m_xgt.p(), m_xgt.p(), sc + 2);
+                    order1_on_device = be->x1_async(n, sc + 2, m_xgt.p(), xbi, xi, sc, m_host_scalars + 3 * i);
+                    if (order1_on_device) be->dot_async(n, xi, m_xgt.p(), sc + 1);
+                }
+                if (!order1_on_device) {
+                    xgt2 = be->dot(n, m_xgt.p(), m_xgt.p());  // (waits for the device: the factor's status is in)
+                    g_trace.mark("order 1: |xgt|^2 returned");
+                    // sparse_solver.cpp:288-289: the coefficients must be finite
+                    sanm_check(host_checks[0] == 0, "non-finite Jacobian coefficient");
+                    if (m_solver->check_prepared(host_checks + 1)) {
+                        // perturbed pivots: the solver refines from now on (sparse_solver.cpp:107-127: PARDISO's
+                        // behaviour); this first solution is computed again
+                        m_solver->solve(grad_t, m_xgt.p());
+                        xgt2 = be->dot(n, m_xgt.p(), m_xgt.p());
+                    }
                 }
             }
-            xbi = bi;  // zero at first order (anm.cpp:235)
-            t1 = ti = 1.0 / std::sqrt(xgt2 + 1.0);
-            // x_1 = -t1*xgt - xbi ; t_1 appended  (anm.cpp:261-264)
-            be->axpby_tail(n, -ti, m_xgt.p(), -1.0, xbi, xi, ti);
-            m_host_scalars[3 * i] = ti;
-            // xgt . x_1 with x_1 = -t_1 xgt - 0 (the order-1 bias is exactly zero, anm.cpp:235): -t_1 |xgt|^2, the
-            // reduction already on the host, instead of another launch and host round trip
-            static const bool analytic = std::getenv("SANM_X1_DOT_ANALYTIC") != nullptr;
-            xgt_dot_x1 = analytic ? -ti * xgt2 : be->dot(n, xi, m_xgt.p());
-            g_trace.mark("order 1: xgt.x1 returned");
+            if (!order1_on_device) {
+                t1 = ti = 1.0 / std::sqrt(xgt2 + 1.0);
+                // x_1 = -t1*xgt - xbi ; t_1 appended  (anm.cpp:261-264)
+                be->axpby_tail(n, -ti, m_xgt.p(), -1.0, xbi, xi, ti);
+                m_host_scalars[3 * i] = ti;
+                // xgt . x_1 with x_1 = -t_1 xgt - 0 (the order-1 bias is exactly zero, anm.cpp:235): -t_1 |xgt|^2, the
+                // reduction already on the host, instead of another launch and host round trip
+                static const bool analytic = std::getenv("SANM_X1_DOT_ANALYTIC") != nullptr;
+                xgt_dot_x1 = analytic ? -ti * xgt2 : be->dot(n, xi, m_xgt.p());
+                g_trace.mark("order 1: xgt.x1 returned");
+            }
         } else {
             // t_i = (xb_i . x_1) / (t1 - xgt . x_1);  x_i = -t_i*xgt - xb_i  (anm.cpp:246-264)
             if (pade_riders) m_pade_ws.phase(m_xt_coeffs, i - 1, 2, anm_cond, true);
@@ -1206,8 +1224,8 @@ void AnmDriver::solve_expansion_coeffs() {
             // next_coeff and the COEFF(i) + BIAS(i + 1) pass that consumes x_i as ONE launch where the backend offers
             // it (the pass forms x_i in its gather, rider workgroups store it: Backend::run_pass_next_coeff) and
             // nothing between the two looks at x_i; two launches otherwise -- the same arithmetic
-            const NextCoeff nc{n, m_dev_scalars.p() + i, 1.0 / (t1 - xgt_dot_x1), m_xgt.p(), xbi, xi,
-                               m_host_scalars + 3 * i};
+            const NextCoeff nc{n, m_dev_scalars.p() + i, order1_on_device ? 0.0 : 1.0 / (t1 - xgt_dot_x1), m_xgt.p(), xbi, xi,
+                               m_host_scalars + 3 * i, order1_on_device ? m_order1_sc.p() : nullptr};
             static const bool sanity_side_env = std::getenv("SANM_SANITY_SIDE") != nullptr;
             const bool nothing_between = !(m_inject.kind == 1 && m_inject.order == i) && !pade_side && !verbose &&
                                          !(do_sanity && sanity_side_env);
@@ -1216,7 +1234,7 @@ void AnmDriver::solve_expansion_coeffs() {
                 pass_done = be->run_pass_next_coeff(m_prog->dev(), i, nc);
                 if (pass_done) bias_done = true;
             }
-            if (!pass_done) be->next_coeff_async(nc.n, nc.num, nc.scale, nc.xg, nc.xb, nc.out, nc.t_out);
+            if (!pass_done) be->next_coeff_async(nc);
         }
         m_nr_valid_coeffs = i + 1;
         if (m_inject.kind == 1 && m_inject.order == i) apply_injection(xi, n1);
@@ -1285,6 +1303,24 @@ void AnmDriver::solve_expansion_coeffs() {
     g_trace.mark("loop queued");
     be->sync();
     g_trace.mark("loop-end sync returned");
+    if (order1_on_device) {
+        // what order 1 would have looked at before going on (sparse_solver.cpp:288-289, :107-127)
+        sanm_check(host_checks[0] == 0, "non-finite Jacobian coefficient");
+        if (m_solver->check_prepared(host_checks + 1)) {
+            // The factorisation perturbed pivots: every solve of this expansion should have been refined (PARDISO's
+            // behaviour with the reference's settings).  Rare; the expansion is simply taken again along the
+            // synchronous order-1 path, which re-solves with refinement as soon as it sees the status.
+            m_force_order1_host = true;
+            try {
+                solve_expansion_coeffs();
+            } catch (...) {
+                m_force_order1_host = false;
+                throw;
+            }
+            m_force_order1_host = false;
+            return;
+        }
+    }
     auto check_sanity = [&]() {
         for (int i = 1; i <= N && do_sanity; ++i) {
             const double ex = host_sanity[2 * (i - 1)], xdot = host_sanity[2 * (i - 1) + 1];

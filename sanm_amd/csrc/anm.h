@@ -308,6 +308,8 @@ protected:
     std::vector<DVec> m_bi_all;  // b_i of every order, kept for the checks after the order loop (sanity_check)
     PadeWorkspace m_pade_ws;
     DVec m_dev_scalars;                // per order: xb_i . x_1 (consumed on the device)
+    DVec m_order1_sc;                  // {t_1, xgt . x_1, |xgt|^2}: order 1's scalars when they stay on the device
+    bool m_force_order1_host = false;  // an expansion taken again after perturbed pivots
     double* m_host_scalars = nullptr;  // pinned, per order: t_i, sanity excess, sanity x-dot
     std::map<std::string, double> m_profile, m_profile_cnt, m_profile_launches;
 

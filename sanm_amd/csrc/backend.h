@@ -81,6 +81,9 @@ struct NextCoeff {
     const double* xb = nullptr;
     double* out = nullptr;    // n + 1 entries: x_i, t
     double* t_out = nullptr;  // pinned host memory
+    //! device pair {t_1, xg . x_1} of an order 1 that never came to the host (Backend::x1_async): when set, the scale
+    //! is formed on the device, 1 / (sc[0] - sc[1]) -- the division the host would have made (anm.cpp:246-250)
+    const double* sc = nullptr;
 };
 
 class Backend {
@@ -317,8 +320,14 @@ public:
     //! gather, extra workgroups store it (and carry a pending Gram-Schmidt scaling phase).  false: not offered for
     //! this program here -- the caller queues the two separately.  Same arithmetic either way.
     virtual bool run_pass_next_coeff(const ProgramDev&, int /*order*/, const NextCoeff&) { return false; }
-    virtual void next_coeff_async(size_t n, const double* num, double scale, const double* x, const double* y,
-                                  double* out, double* t_out) = 0;
+    virtual void next_coeff_async(const NextCoeff& nc) = 0;
+    //! Order 1 without a host round trip (anm.cpp:228-245): t_1 = 1 / sqrt(*xgt2 + 1) formed on the device from the
+    //! reduction's result, out = -t_1 xg - xb (n entries), out[n] = t_1; t_1 also to sc[0] (device) and *t_host
+    //! (pinned).  false: not offered -- the caller takes the reductions to the host.
+    virtual bool x1_async(size_t /*n*/, const double* /*xgt2*/, const double* /*xg*/, const double* /*xb*/, double* /*out*/,
+                          double* /*sc*/, double* /*t_host*/) {
+        return false;
+    }
     // One classical Gram-Schmidt step of the Pade basis (pade.cpp:36-70) is three queued kernels; scalars stay
     // in device memory.  A vector whose norm underflows (sqrt(norm2) < eps) is normalised a second time by
     // its own norm: that rare fix-up is applied by the NEXT step's projection kernel, which reads the vector

@@ -576,8 +576,22 @@ __global__ void __launch_bounds__(256) permute_out_dot_kernel(int64_t n, const i
 }
 
 // x_i of the order loop with t_i taken from the device: t = *num * scale
+// order 1 of the expansion with t_1 formed on the device: t_1 = 1 / sqrt(|xg|^2 + 1), x_1 = -t_1 xg - xb
+__global__ void __launch_bounds__(256) x1_kernel(size_t n, const double* __restrict__ xgt2, const double* __restrict__ x,
+                                                 const double* __restrict__ y, double* out, double* sc, double* t_out) {
+    const double t = 1.0 / sqrt(*xgt2 + 1.0);
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = -t * x[i] - y[i];
+    else if (i == n) {
+        out[i] = t;
+        sc[0] = t;
+        *t_out = t;
+    }
+}
+
 template <bool RIDE>
 __global__ void __launch_bounds__(256) next_coeff_kernel(size_t n, const double* __restrict__ num, double scale,
+                                                         const double* __restrict__ sc,
                                                          const double* __restrict__ x, const double* __restrict__ y,
                                                          double* out, double* t_out, unsigned own, GsRider rd) {
     if constexpr (RIDE) {
@@ -586,6 +600,7 @@ __global__ void __launch_bounds__(256) next_coeff_kernel(size_t n, const double*
             return;
         }
     }
+    if (sc) scale = 1.0 / (sc[0] - sc[1]);
     const double t = *num * scale;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = -t * x[i] - y[i];
@@ -1452,6 +1467,7 @@ public:
             const double* nc_xg;
             const double* nc_num;
             double nc_scale;
+            const double* nc_sc;
             double* nc_out;
             double* nc_thost;
             unsigned long long nc_n;
@@ -1475,6 +1491,7 @@ public:
             a4.nc_xg = nc->xg;
             a4.nc_num = nc->num;
             a4.nc_scale = nc->scale;
+            a4.nc_sc = nc->sc;
             a4.nc_out = nc->out;
             a4.nc_thost = nc->t_out;
             a4.nc_n = nc->n;
@@ -2343,18 +2360,23 @@ public:
         SANM_LAUNCH(dot_kernel, dim3(red_grid(n)), dim3(256), 0, m_stream, n, x, y, red_to(out));
         HIP_CHECK(hipGetLastError());
     }
-    void next_coeff_async(size_t n, const double* num, double scale, const double* x, const double* y,
-                          double* out, double* t_out) override {
-        const unsigned own = nblk(n + 1, 256);
+    void next_coeff_async(const NextCoeff& nc) override {
+        const unsigned own = nblk(nc.n + 1, 256);
         if (m_pending.kind == 3 && m_stream == m_main) {  // the scaling of a Gram-Schmidt step rides along
             const GsRider rd = take_rider();
-            SANM_LAUNCH(next_coeff_kernel<true>, dim3(own + rd.nblk), dim3(256), 0, m_stream, n, num, scale, x, y,
-                               out, t_out, own, rd);
+            SANM_LAUNCH(next_coeff_kernel<true>, dim3(own + rd.nblk), dim3(256), 0, m_stream, nc.n, nc.num, nc.scale, nc.sc,
+                        nc.xg, nc.xb, nc.out, nc.t_out, own, rd);
         } else {
-            SANM_LAUNCH(next_coeff_kernel<false>, dim3(own), dim3(256), 0, m_stream, n, num, scale, x, y, out,
-                               t_out, own, GsRider{});
+            SANM_LAUNCH(next_coeff_kernel<false>, dim3(own), dim3(256), 0, m_stream, nc.n, nc.num, nc.scale, nc.sc, nc.xg,
+                        nc.xb, nc.out, nc.t_out, own, GsRider{});
         }
         HIP_CHECK(hipGetLastError());
+    }
+    bool x1_async(size_t n, const double* xgt2, const double* xg, const double* xb, double* out, double* sc,
+                  double* t_host) override {
+        SANM_LAUNCH(x1_kernel, dim3(nblk(n + 1, 256)), dim3(256), 0, m_stream, n, xgt2, xg, xb, out, sc, t_host);
+        HIP_CHECK(hipGetLastError());
+        return true;
     }
     double* alloc_host(size_t n) override {
         double* p = nullptr;

@@ -756,12 +756,15 @@ extern "C" __global__ void __launch_bounds__(256, 3) spec_pass2(SPEC_PARAMS) {
 // more run the scaling phase of a deferred Gram-Schmidt step -- what next_coeff_kernel and its rider did in a launch
 // of their own.
 extern "C" __global__ void __launch_bounds__(256, 3) spec_pass4(SPEC_PARAMS, const double* nc_xg, const double* nc_num,
-                                                                double nc_scale, double* nc_out, double* nc_thost,
+                                                                double nc_scale, const double* nc_sc, double* nc_out,
+                                                                double* nc_thost,
                                                                 unsigned long long nc_n, double* rd_out,
                                                                 const double* rd_norm2, double rd_eps,
                                                                 unsigned long long rd_n, double* g_partials,
                                                                 unsigned* g_ticket, double* g_host, unsigned own,
                                                                 unsigned nc_blocks, unsigned rd_nblk) {
+    // (the scale of an order 1 that stayed on the device: 1 / (t_1 - xg . x_1), Backend::x1_async)
+    if (nc_xg && nc_sc) nc_scale = 1.0 / (nc_sc[0] - nc_sc[1]);
     if (blockIdx.x >= own) {
         const unsigned r = blockIdx.x - own;
         if (r < nc_blocks) {

@@ -276,11 +276,11 @@ public:
         const double s = 1.0 / std::sqrt(*nn2);
         for (size_t i = 0; i < n; ++i) v[i] *= s;
     }
-    void next_coeff_async(size_t n, const double* num, double scale, const double* x, const double* y,
-                          double* out, double* t_out) override {
-        const double t = *num * scale;
-        axpby_tail(n, -t, x, -1.0, y, out, t);
-        *t_out = t;
+    void next_coeff_async(const NextCoeff& nc) override {
+        const double scale = nc.sc ? 1.0 / (nc.sc[0] - nc.sc[1]) : nc.scale;
+        const double t = *nc.num * scale;
+        axpby_tail(nc.n, -t, nc.xg, -1.0, nc.xb, nc.out, t);
+        *nc.t_out = t;
     }
     void sanity_check_async(const CsrDev& A, const double* xi, const double* grad_t, const double* bi,
                             double eps, size_t n1, const double* x1, double* tmp0, double* tmp1,
