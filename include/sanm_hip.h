@@ -259,6 +259,11 @@ typedef struct sanm_anm_stats {
     /* direct solver analysis (0 with the iterative solver) */
     int64_t factor_nnz, nr_front, nr_level, max_front;
     double factor_flops;
+    /* tet-sharded solver with the factorisation distributed by subtrees (sanm_anm_eqn_solver_create_sharded, world > 1,
+     * systems from 50 GFLOP per factorisation or SANM_DIST_SOLVER=1): what THIS rank factors -- its own subtrees and the
+     * replicated top of the elimination tree -- in the units of factor_flops; nr_subtree == 0: replicated solver */
+    double factor_flops_own, factor_flops_top;
+    int64_t nr_subtree, nr_subtree_own;
 } sanm_anm_stats;
 int sanm_anm_get_stats(const sanm_anm_solver* s, sanm_anm_stats* st);
 /* profile tags: returns the number of tags (or minus an error code: the call reads device events);

@@ -58,7 +58,9 @@ class StatsC(C.Structure):
                 ("linear_iters_total", C.c_int64), ("linear_iters_last", C.c_int64),
                 ("linear_relres_last", C.c_double), ("arena_bytes", C.c_double),
                 ("factor_nnz", C.c_int64), ("nr_front", C.c_int64), ("nr_level", C.c_int64),
-                ("max_front", C.c_int64), ("factor_flops", C.c_double)]
+                ("max_front", C.c_int64), ("factor_flops", C.c_double),
+                ("factor_flops_own", C.c_double), ("factor_flops_top", C.c_double),
+                ("nr_subtree", C.c_int64), ("nr_subtree_own", C.c_int64)]
 
 
 ENERGY = {"neohookean_i": 0, "neohookean_c": 1, "arap": 2, "stvk_stretch": 3}

@@ -166,7 +166,8 @@ class DirectSolver final : public LinearSolver {
         }
         for (int s = 0; s < m_refine; ++s) {
             m_be->residual(m_pat.csr(), b, x, m_r.p());
-            m_be->mf_solve(m_mf.dev(), m_mf.schedule(), m_r.p(), m_d.p());
+            if (dist()) dist_solve(m_r.p(), m_d.p());
+            else m_be->mf_solve(m_mf.dev(), m_mf.schedule(), m_r.p(), m_d.p());
             m_be->axpby(n, 1.0, x, 1.0, m_d.p(), x);
         }
         if (!m_residual_checked) {
@@ -181,26 +182,94 @@ class DirectSolver final : public LinearSolver {
         }
     }
 
+    // ---- distributed by subtrees (MfSchedule::Dist): pieces of the factorisation / the sweeps with the exchanges
+    //      between them.  Every exchange is a sum over the ranks in which each entry has one non-zero contributor,
+    //      so the factors and solutions are those of the single-rank run bit for bit.
+    const Collective m_coll;
+    DVec m_dist_status;
+    bool dist() const { return m_mf.schedule().dist.enabled; }
+    void dist_factor(double* status) {
+        const MfDev& mf = m_mf.dev();
+        const MfSchedule& sch = m_mf.schedule();
+        const auto& D = sch.dist;
+        const int nl = (int)sch.levels.size();
+        m_be->mf_factor_piece(mf, sch, m_pat.csr(), 0, D.cut, true);
+        if (D.schur_doubles > 0) {
+            // the Schur complements of all cut roots: own ones packed into the staging buffer, the rest of it zero
+            m_be->zero(D.stage, (size_t)D.schur_doubles * 8);
+            m_be->copy2d_batch(D.schur_pack, D.n_schur_pack, D.schur_max_b, D.schur_max_b, mf.front_store, D.stage);
+            m_coll(D.stage, D.schur_doubles);
+            m_be->copy2d_batch(D.schur_unpack, D.n_schur_unpack, D.schur_max_b, D.schur_max_b, D.stage, mf.front_store);
+        }
+        m_be->mf_factor_piece(mf, sch, m_pat.csr(), D.cut, nl, false);
+        // perturbed pivots anywhere decide for everybody (the refinement they switch on contains collectives)
+        if (m_dist_status.empty()) m_dist_status = DVec{m_be, 1};
+        m_be->mf_factor_status(mf, m_dist_status.p());
+        m_coll(m_dist_status.p(), 1);
+        m_be->d2h_async(status, m_dist_status.p(), 8);
+    }
+    void dist_solve(const double* b, double* x) {
+        const MfDev& mf = m_mf.dev();
+        const MfSchedule& sch = m_mf.schedule();
+        const auto& D = sch.dist;
+        const int nl = (int)sch.levels.size();
+        m_be->mf_permute(mf, b, nullptr);
+        m_be->mf_solve_piece(mf, sch, true, 0, D.cut);
+        if (D.inbox_doubles > 0) {
+            // the cut roots' update rows in their parents' inboxes
+            m_be->zero(D.stage, (size_t)D.inbox_doubles * 8);
+            m_be->copy2d_batch(D.inbox_pack, D.n_inbox_pack, 1, D.inbox_max_m, mf.inbox_store, D.stage);
+            m_coll(D.stage, D.inbox_doubles);
+            m_be->copy2d_batch(D.inbox_unpack, D.n_inbox_unpack, 1, D.inbox_max_m, D.stage, mf.inbox_store);
+        }
+        m_be->mf_solve_piece(mf, sch, true, D.cut, nl);
+        m_be->mf_solve_piece(mf, sch, false, D.cut, nl);
+        m_be->mf_solve_piece(mf, sch, false, 0, D.cut);
+        // every rank ends with the whole solution: each entry of the permuted vector from the one rank that speaks
+        // for it (the owner of its subtree; rank 0 for the replicated top)
+        for (const auto& r : D.zero_ranges) m_be->zero(mf.work + r.first, (size_t)(r.second - r.first) * 8);
+        m_coll(mf.work, mf.n);
+        m_be->mf_permute(mf, nullptr, x);
+    }
+
 public:
-    DirectSolver(Backend* be, const JacobianPattern& pat, const HyperParam& hp, const double* coords)
-            : m_be{be}, m_pat{pat}, m_mf{be, pat.n(), pat.h_rowptr(), pat.h_col(), coords},
+    DirectSolver(Backend* be, const JacobianPattern& pat, const HyperParam& hp, const double* coords, int rank,
+                 int world, Collective coll)
+            : m_be{be}, m_pat{pat}, m_mf{be, pat.n(), pat.h_rowptr(), pat.h_col(), coords, rank, world},
               m_refine_always{std::getenv("SANM_SOLVER_REFINE") ? std::atoi(std::getenv("SANM_SOLVER_REFINE"))
-                                                                : hp.solver_refine} {
+                                                                : hp.solver_refine},
+              m_coll{std::move(coll)} {
+        sanm_check(!dist() || m_coll, "distributed direct solver without a collective");
         nnz_factors = m_mf.nnz_factors;
         nr_front = m_mf.nr_front;
         nr_level = m_mf.nr_level;
         max_front = m_mf.max_front;
         factor_flops = m_mf.factor_flops;
+        const auto& D = m_mf.schedule().dist;
+        factor_flops_own = D.flops_own;
+        factor_flops_top = D.flops_top;
+        nr_subtree = D.nr_subtree;
+        nr_subtree_own = D.nr_subtree_own;
         m_refine = m_refine_always;
     }
     void prepare() override {
+        if (dist()) {
+            double* st = m_be->alloc_host(1);
+            dist_factor(st);
+            m_be->sync();
+            const double v = *st;
+            m_be->free_host(st);
+            (void)check_prepared(&v);
+            return;
+        }
         int bad = m_be->mf_factor(m_mf.dev(), m_mf.schedule(), m_pat.csr());
         double st = bad;
         (void)check_prepared(&st);
     }
     void prepare_async(double* status) override {
         m_refine = m_refine_always;
-        m_be->mf_factor_async(m_mf.dev(), m_mf.schedule(), m_pat.csr(), status);
+        if (dist()) dist_factor(status);
+        else m_be->mf_factor_async(m_mf.dev(), m_mf.schedule(), m_pat.csr(), status);
     }
     bool check_prepared(const double* status) override {
         nr_perturbed_pivots = (int64_t)*status;
@@ -215,12 +284,13 @@ public:
         return true;
     }
     void solve(const double* b, double* x) override {
-        m_be->mf_solve(m_mf.dev(), m_mf.schedule(), b, x);
+        if (dist()) dist_solve(b, x);
+        else m_be->mf_solve(m_mf.dev(), m_mf.schedule(), b, x);
         if (m_refine > 0) refine(b, x);
         ++nr_solve;
     }
     // (with refinement the right-hand side is needed again after the solve: no fused ends then)
-    const int32_t* rhs_perm() const override { return m_refine > 0 ? nullptr : m_mf.dev().perm; }
+    const int32_t* rhs_perm() const override { return m_refine > 0 || dist() ? nullptr : m_mf.dev().perm; }
     double* rhs_work() const override { return m_mf.dev().work; }
     void solve_fused(const double* b, double* x, const double* dot_y, double* dot_out) override {
         sanm_check(m_refine == 0 || b, "solve_fused without a right-hand side while refining");
@@ -385,9 +455,11 @@ std::unique_ptr<LinearSolver> make_dense_solver(Backend* be, const JacobianPatte
 }
 
 std::unique_ptr<LinearSolver> make_direct_solver(Backend* be, const JacobianPattern& pat,
-                                                 const HyperParam& hp, const double* coords) {
+                                                 const HyperParam& hp, const double* coords, int rank, int world,
+                                                 Collective coll) {
+    // (the regularised path factors A'A on every rank: replicated)
     if (hp.xcoeff_l2_penalty != 0) return std::make_unique<TikhonovSolver>(be, pat, hp.xcoeff_l2_penalty, coords);
-    return std::make_unique<DirectSolver>(be, pat, hp, coords);
+    return std::make_unique<DirectSolver>(be, pat, hp, coords, rank, world, std::move(coll));
 }
 
 std::unique_ptr<LinearSolver> make_pcg_solver(Backend* be, const JacobianPattern& pat,
@@ -898,7 +970,12 @@ void AnmDriver::construct_solver_and_vectors(const double* coords) {
         !std::getenv("SANM_VEC_MULTIFRONTAL")) {
         m_solver = make_dense_solver(be, *m_pattern);
     } else if (hp.solver_kind == 1) {
-        m_solver = make_direct_solver(be, *m_pattern, hp, coords);
+        // tet-sharded over several ranks: factorisation and solves by subtrees where that pays (multifrontal.cpp)
+        if (m_shard.active() && m_shard.world > 1)
+            m_solver = make_direct_solver(be, *m_pattern, hp, coords, m_shard.rank, m_shard.world,
+                                          [this](double* p, int64_t c) { allreduce(p, c); });
+        else
+            m_solver = make_direct_solver(be, *m_pattern, hp, coords);
     } else if (hp.solver_kind == 0) {
         m_solver = make_pcg_solver(be, *m_pattern, hp);
     } else if (hp.solver_kind == 2) {

@@ -10,6 +10,7 @@
 #pragma once
 #include <chrono>
 #include <map>
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -114,12 +115,21 @@ public:
     // direct solver analysis (0 for iterative solvers)
     int64_t nnz_factors = 0, nr_front = 0, nr_level = 0, max_front = 0;
     double factor_flops = 0;
+    // distributed direct solver (subtree-to-rank, MfSchedule::Dist): what THIS rank factors
+    double factor_flops_own = 0, factor_flops_top = 0;
+    int64_t nr_subtree = 0, nr_subtree_own = 0;
 };
+//! sum over the ranks of `count` doubles at a device pointer, in place (the driver's all-reduce: RCCL on the solver's
+//! stream or the C ABI's callback)
+using Collective = std::function<void(double*, int64_t)>;
 std::unique_ptr<LinearSolver> make_pcg_solver(Backend* be, const JacobianPattern& pat,
                                               const HyperParam& hp);
 //! multifrontal LU (multifrontal.h); coords: (n,3) ordering hint or null
+//! world > 1: the factorisation and the solves distributed by subtrees over the ranks (multifrontal.h), `coll` for
+//! the exchanges
 std::unique_ptr<LinearSolver> make_direct_solver(Backend* be, const JacobianPattern& pat,
-                                                 const HyperParam& hp, const double* coords);
+                                                 const HyperParam& hp, const double* coords, int rank = 0,
+                                                 int world = 1, Collective coll = {});
 
 //! dense LU with partial pivoting: the small general systems of graphs on the vector interpreter
 std::unique_ptr<LinearSolver> make_dense_solver(Backend* be, const JacobianPattern& pat);

@@ -221,6 +221,19 @@ public:
     virtual void mf_factor_async(const MfDev& mf, const MfSchedule& sch, const CsrDev& A, double* status) {
         *status = mf_factor(mf, sch, A);
     }
+    // -- the same in pieces, for the distributed schedule (MfSchedule::Dist; anm.cpp: DirectSolver): the caller
+    //    runs levels [l0, l1) and puts its exchanges between the pieces.  Nothing here waits for the device.
+    //! numeric factorisation of levels [l0, l1); prologue: clear the fronts, scatter A, pivot threshold first
+    virtual void mf_factor_piece(const MfDev&, const MfSchedule&, const CsrDev& A, int l0, int l1, bool prologue);
+    //! *out (device memory) = number of perturbed pivots so far, as a double
+    virtual void mf_factor_status(const MfDev&, double* out);
+    //! forward (levels l0 .. l1-1) or backward (l1-1 .. l0) sweep over mf.work
+    virtual void mf_solve_piece(const MfDev&, const MfSchedule&, bool fwd, int l0, int l1);
+    //! b != null: mf.work[perm[i]] = b[i];  x != null: x[i] = mf.work[perm[i]]
+    virtual void mf_permute(const MfDev&, const double* b, double* x);
+    //! a batch of strided block copies (descriptors in device memory), src_base -> dst_base
+    virtual void copy2d_batch(const MfCopy2D* d, int count, int max_rows, int max_cols, const double* src_base,
+                              double* dst_base);
     //! x = A^-1 b with the factors of the last mf_factor (b, x: n doubles, may alias)
     virtual void mf_solve(const MfDev& mf, const MfSchedule& sch, const double* b, double* x) = 0;
     //! the same with the two ends of the solve fused into its neighbours in the order loop: b == nullptr means the

@@ -36,6 +36,21 @@ void Backend::run_gs_phase(const GsPhase& ph) {
     }
 }
 
+void Backend::mf_factor_piece(const MfDev&, const MfSchedule&, const CsrDev&, int, int, bool) {
+    sanm_throw(SANM_ERR_UNSUPPORTED, "backend %s: no piecewise multifrontal factorisation", name());
+}
+void Backend::mf_factor_status(const MfDev&, double*) {
+    sanm_throw(SANM_ERR_UNSUPPORTED, "backend %s: no piecewise multifrontal factorisation", name());
+}
+void Backend::mf_solve_piece(const MfDev&, const MfSchedule&, bool, int, int) {
+    sanm_throw(SANM_ERR_UNSUPPORTED, "backend %s: no piecewise multifrontal solve", name());
+}
+void Backend::mf_permute(const MfDev&, const double*, double*) {
+    sanm_throw(SANM_ERR_UNSUPPORTED, "backend %s: no piecewise multifrontal solve", name());
+}
+void Backend::copy2d_batch(const MfCopy2D*, int, int, int, const double*, double*) {
+    sanm_throw(SANM_ERR_UNSUPPORTED, "backend %s: no batched block copy", name());
+}
 void Backend::mf_solve_fused(const MfDev& mf, const MfSchedule& sch, const double* b, double* x, const double* dot_y,
                              double* dot_out) {
     if (!b) sanm_throw(SANM_ERR_ASSERT, "mf_solve_fused: this backend needs the right-hand side");

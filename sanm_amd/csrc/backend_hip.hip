@@ -620,6 +620,15 @@ __global__ void inv_diag_kernel(CsrDev A, double scale, double* d) {
     if (i < A.n) d[i] = 1.0 / (scale * csr_diag(A, i));
 }
 
+// a batch of strided block copies (MfCopy2D): the exchanges of the distributed multifrontal schedule
+__global__ void __launch_bounds__(256) copy2d_kernel(const MfCopy2D* __restrict__ d, const double* __restrict__ src,
+                                                     double* __restrict__ dst) {
+    const MfCopy2D c = d[blockIdx.z];
+    for (int i = blockIdx.y; i < c.rows; i += gridDim.y)
+        for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < c.cols; j += gridDim.x * blockDim.x)
+            dst[c.dst + (int64_t)i * c.ldd + j] = src[c.src + (int64_t)i * c.lds + j];
+}
+
 // the pivot counter of a factorisation as a double where the host reads its asynchronous results
 __global__ void status_to_double_kernel(const int32_t* status, double* out) { *out = (double)*status; }
 
@@ -1810,7 +1819,19 @@ public:
     }
 #endif
     void mf_factor_launch(const MfDev& mf, const MfSchedule& sch, const CsrDev& A) {
+        mf_factor_levels(mf, sch, A, 0, (int)sch.levels.size(), true, true);
+    }
+    void mf_factor_piece(const MfDev& mf, const MfSchedule& sch, const CsrDev& A, int l0, int l1, bool prologue) override {
+        mf_factor_levels(mf, sch, A, l0, l1, prologue, false);
+    }
+    void mf_factor_status(const MfDev& mf, double* out) override {
+        SANM_LAUNCH(status_to_double_kernel, dim3(1), dim3(1), 0, m_stream, mf.status, out);
+        HIP_CHECK(hipGetLastError());
+    }
+    void mf_factor_levels(const MfDev& mf, const MfSchedule& sch, const CsrDev& A, int l0, int l1, bool prologue,
+                          bool epilogue) {
         using namespace mfk;
+        if (prologue) {
         HIP_CHECK(hipMemsetAsync(mf.front_store, 0, mf.front_store_size * sizeof(double), m_stream));
         HIP_CHECK(hipMemsetAsync(mf.status, 0, sizeof(int32_t), m_stream));
         SANM_LAUNCH(absmax_kernel, dim3(red_grid(mf.nnzA)), dim3(256), 0, m_stream, (size_t)mf.nnzA, A.val,
@@ -1818,9 +1839,11 @@ public:
         SANM_LAUNCH(scatter_kernel, dim3(nblk(mf.nnzA, 256)), dim3(256), 0, m_stream, mf.nnzA,
                            mf.a_dst, A.val, mf.front_store);
         SANM_LAUNCH(aug_identity_kernel, dim3(nblk(mf.n, 256)), dim3(256), 0, m_stream, mf);
+        }
         const char* env_min_k = std::getenv("SANM_MF_OUTER_MIN_K");
         const int outer_min_k = env_min_k ? std::atoi(env_min_k) : kOuterMinK;
-        for (const auto& L : sch.levels) {
+        for (int li = l0; li < l1; ++li) {
+            const auto& L = sch.levels[li];
             for (size_t r = 0; r < L.ea_rounds.size(); ++r) {
                 int cnt = L.ea_rounds[r].second - L.ea_rounds[r].first;
                 int64_t mb = L.ea_max_b[r];
@@ -1892,7 +1915,7 @@ public:
 #endif
             }
         }
-        if (sch.top.enabled) {  // the top of the tree as one dense operator (mf_kernels.h)
+        if (epilogue && sch.top.enabled) {  // the top of the tree as one dense operator (mf_kernels.h)
             const auto& T = sch.top;
             for (int st = 0; st < 2; ++st) {
                 const int cnt = T.stage_begin[st + 1] - T.stage_begin[st];
@@ -1995,6 +2018,26 @@ public:
 
     void mf_solve(const MfDev& mf, const MfSchedule& sch, const double* b, double* x) override {
         mf_solve_fused(mf, sch, b, x, nullptr, nullptr);
+    }
+    void mf_solve_piece(const MfDev& mf, const MfSchedule& sch, bool fwd, int l0, int l1) override {
+        if (fwd)
+            for (int li = l0; li < l1; ++li) level_solve(true, mf, sch.levels[li]);
+        else
+            for (int li = l1 - 1; li >= l0; --li) level_solve(false, mf, sch.levels[li]);
+        HIP_CHECK(hipGetLastError());
+    }
+    void mf_permute(const MfDev& mf, const double* b, double* x) override {
+        using namespace mfk;
+        if (b) SANM_LAUNCH(permute_in_kernel, dim3(nblk(mf.n, 256)), dim3(256), 0, m_stream, mf.n, mf.perm, b, mf.work);
+        if (x) SANM_LAUNCH(permute_out_kernel, dim3(nblk(mf.n, 256)), dim3(256), 0, m_stream, mf.n, mf.perm, mf.work, x);
+        HIP_CHECK(hipGetLastError());
+    }
+    void copy2d_batch(const MfCopy2D* d, int count, int max_rows, int max_cols, const double* src_base,
+                      double* dst_base) override {
+        if (count <= 0 || max_rows <= 0 || max_cols <= 0) return;
+        SANM_LAUNCH(copy2d_kernel, dim3((max_cols + 255) / 256, std::min(max_rows, 1024), count), dim3(256), 0, m_stream, d,
+                    src_base, dst_base);
+        HIP_CHECK(hipGetLastError());
     }
     void mf_solve_fused(const MfDev& mf, const MfSchedule& sch, const double* b, double* x, const double* dot_y,
                         double* dot_out) override {

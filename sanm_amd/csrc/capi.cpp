@@ -653,6 +653,10 @@ int sanm_anm_get_stats(const sanm_anm_solver* s, sanm_anm_stats* st) {
         st->nr_front = d.linear_solver().nr_front;
         st->nr_level = d.linear_solver().nr_level;
         st->max_front = d.linear_solver().max_front;
+        st->factor_flops_own = d.linear_solver().factor_flops_own;
+        st->factor_flops_top = d.linear_solver().factor_flops_top;
+        st->nr_subtree = d.linear_solver().nr_subtree;
+        st->nr_subtree_own = d.linear_solver().nr_subtree_own;
     });
 }
 int sanm_anm_debug_inject(sanm_anm_solver* s, int kind, int order, int64_t index, double value, int scale) {

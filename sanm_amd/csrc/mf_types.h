@@ -72,6 +72,13 @@ struct TopGemm {
 };
 constexpr int MF_TOP_MAXF = 8;
 
+// one strided block copy of a batch (Backend::copy2d_batch): rows x cols doubles from src_base[src + i * lds + j] to
+// dst_base[dst + i * ldd + j]
+struct MfCopy2D {
+    int64_t src, dst;
+    int32_t rows, cols, lds, ldd;
+};
+
 // Host-side schedule (what to launch, in which order).  Within a level the
 // fronts are sorted by decreasing pivot count, so the fronts that still have a
 // panel p form a prefix of the level's list.
@@ -89,6 +96,33 @@ struct MfSchedule {
     };
     std::vector<Level> levels;
     const int32_t* ea_children = nullptr;  // device
+    // Subtree-to-rank distribution (stage 1 of DESIGN.md section 7; multifrontal.cpp).  The elimination tree is cut
+    // into subtrees, each owned by one rank; the fronts above the cut (`top`) are replicated.  This rank's level list
+    // holds its own subtrees' fronts first -- levels [0, cut) -- then the top fronts -- levels [cut, size) --, and
+    // three exchanges (sums over ranks in which every entry has exactly one non-zero contributor, i.e. gathers) tie
+    // the ranks together:
+    //   factor, between the two parts: the Schur complements F[B,B] of all cut roots (packed into `stage`);
+    //   forward solve, between the two parts: the cut roots' update rows in their parents' inboxes;
+    //   backward solve, at the end: the solution entries of the subtrees' pivots (the permuted vector `work`, the
+    //   ranges this rank does not speak for zeroed first).
+    struct Dist {
+        bool enabled = false;
+        int32_t rank = 0, world = 1;
+        int32_t cut = 0;
+        int64_t schur_doubles = 0, inbox_doubles = 0;
+        const MfCopy2D* schur_pack = nullptr;    // device; own cut roots: front_store -> stage
+        const MfCopy2D* schur_unpack = nullptr;  // the other ranks' cut roots: stage -> front_store
+        int32_t n_schur_pack = 0, n_schur_unpack = 0, schur_max_b = 0;
+        const MfCopy2D* inbox_pack = nullptr;    // inbox_store -> stage, one row per cut root
+        const MfCopy2D* inbox_unpack = nullptr;
+        int32_t n_inbox_pack = 0, n_inbox_unpack = 0, inbox_max_m = 0;
+        std::vector<std::pair<int32_t, int32_t>> zero_ranges;  // [begin, end) of `work` before the last exchange
+        double* stage = nullptr;                               // device: max(schur_doubles, inbox_doubles)
+        // what this rank factors: its subtrees and the replicated top (flops as Multifrontal::factor_flops counts them)
+        double flops_own = 0, flops_top = 0;
+        double imbalance = 1;  // largest subtree load of a rank over the mean
+        int32_t nr_front_own = 0, nr_front_top = 0, nr_subtree = 0, nr_subtree_own = 0;
+    } dist;
     // The root and the fronts of the level below it as one dense operator (device back end; mf_kernels.h).
     // Fronts in block order: the level below the root, then the root; off[] = first row of each in the block.
     struct Top {

@@ -651,8 +651,9 @@ Multifrontal::~Multifrontal() {
 }
 
 Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& rowptr,
-                           const std::vector<uint32_t>& col, const double* coords)
+                           const std::vector<uint32_t>& col, const double* coords, int rank, int world)
         : m_be{be} {
+    sanm_check(world >= 1 && rank >= 0 && rank < world, "multifrontal: rank %d of %d", rank, world);
     sanm_check(n > 0 && (int64_t)rowptr.size() == n + 1, "bad CSR pattern");
     sanm_check(n < INT32_MAX / 2, "system too large for 32-bit indices");
     SvGraph g = build_sv_graph(n, rowptr, col, coords);
@@ -743,6 +744,7 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     }
 
     std::vector<MfFrontDev> fr(F);
+    std::vector<double> front_flops(F, 0.0);
     std::vector<int32_t> bnd_idx;
     int64_t off = 0;
     for (int32_t f = 0; f < F; ++f) {
@@ -763,9 +765,93 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
         double k = fr[f].k, bb = b;
         nnz_factors += (int64_t)(k * k + 2 * k * bb);
         // LU of the front plus the row / column operations on the augmentation
-        factor_flops += 2.0 / 3 * k * k * k + 2 * k * k * bb + 2 * k * bb * bb + 2 * k * k * (k + bb);
+        front_flops[f] = 2.0 / 3 * k * k * k + 2 * k * k * bb + 2 * k * bb * bb + 2 * k * k * (k + bb);
+        factor_flops += front_flops[f];
     }
     front_doubles = off;
+
+    // ---- subtree-to-rank distribution (MfSchedule::Dist) ---------------------------------------------------------
+    // The tree is cut from the root down: the subtree with the most factor work is replaced by its children (its
+    // root joins the replicated top) until there are 4 subtrees per rank to balance with, or none can be split;
+    // the subtrees go to the ranks largest first, each to the rank with the least work so far.  owner[f] = rank of
+    // front f's subtree, -1 for the top.  One rank: everything is "top" and the schedule is the plain one.
+    std::vector<int32_t> f_owner(F, -1);
+    std::vector<int32_t> cut_roots;  // in front order (the same on every rank)
+    auto& D = m_sched.dist;
+    D.rank = rank;
+    D.world = world;
+    // When it pays: the exchanges add two collectives to every solve, so small systems (a BASELINE-size mesh
+    // factors 6 GFLOP in 1.9 ms of launch latency) stay replicated; SANM_DIST_SOLVER=1 / 0 forces it on / off, the
+    // default takes it from 50 GFLOP per factorisation (block:24 and larger).
+    const char* env_dist = std::getenv("SANM_DIST_SOLVER");
+    const bool want_dist = world > 1 && (env_dist ? std::atoi(env_dist) != 0 : factor_flops >= 50e9);
+    if (want_dist) {
+        std::vector<double> sub_flops(front_flops);
+        for (int32_t f = 0; f < F; ++f)
+            if (parent[f] >= 0) sub_flops[parent[f]] += sub_flops[f];  // (postorder: children come first)
+        std::vector<int32_t> S;
+        for (int32_t f = 0; f < F; ++f)
+            if (parent[f] < 0) S.push_back(f);
+        // greedy assignment, largest first, each to the rank with the least work so far
+        auto assign = [&](const std::vector<int32_t>& set, std::vector<int32_t>* root_owner) {
+            std::vector<int32_t> by_work(set);
+            std::stable_sort(by_work.begin(), by_work.end(), [&](int32_t a, int32_t b) { return sub_flops[a] > sub_flops[b]; });
+            std::vector<double> load(world, 0.0);
+            for (int32_t c : by_work) {
+                int r = 0;
+                for (int q = 1; q < world; ++q)
+                    if (load[q] < load[r]) r = q;
+                load[r] += sub_flops[c];
+                if (root_owner) (*root_owner)[c] = r;
+            }
+            double mx = 0, sum = 0;
+            for (double l : load) {
+                mx = std::max(mx, l);
+                sum += l;
+            }
+            return sum > 0 ? mx * world / sum : 1.0;  // imbalance: largest load over the mean
+        };
+        // Every split moves a front into the replicated top, so the cut stays as high as balance allows: split
+        // until there is a subtree per rank and the assignment is within 15 % of even, 4 subtrees per rank at most.
+        for (;;) {
+            if (S.size() >= (size_t)world * 4) break;
+            if (S.size() >= (size_t)world && assign(S, nullptr) <= 1.15) break;
+            int best = -1;
+            for (size_t i = 0; i < S.size(); ++i)
+                if (!children[S[i]].empty() && (best < 0 || sub_flops[S[i]] > sub_flops[S[best]])) best = (int)i;
+            if (best < 0) break;
+            // (never split a subtree that is already lighter than a 64th of a rank's share: latency, not work)
+            if (sub_flops[S[best]] * 64 * world < factor_flops) break;
+            const int32_t s0 = S[best];
+            S.erase(S.begin() + best);
+            S.insert(S.end(), children[s0].begin(), children[s0].end());
+        }
+        std::sort(S.begin(), S.end());
+        cut_roots = S;
+        std::vector<int32_t> root_owner(F, -1);
+        D.imbalance = assign(S, &root_owner);
+        // fronts inherit from the cut root above them (parents have larger ids: walk down from the top)
+        for (int32_t f = F - 1; f >= 0; --f) {
+            if (root_owner[f] >= 0) f_owner[f] = root_owner[f];
+            else if (parent[f] >= 0 && f_owner[parent[f]] >= 0) f_owner[f] = f_owner[parent[f]];
+        }
+        // (a tree root that could not be split is a subtree of its own: then there is no top at all)
+        D.enabled = true;
+        D.nr_subtree = (int32_t)cut_roots.size();
+        for (int32_t c : cut_roots) D.nr_subtree_own += f_owner[c] == rank;
+        for (int32_t f = 0; f < F; ++f) {
+            if (f_owner[f] < 0) {
+                D.flops_top += front_flops[f];
+                ++D.nr_front_top;
+            } else if (f_owner[f] == rank) {
+                D.flops_own += front_flops[f];
+                ++D.nr_front_own;
+            }
+        }
+    } else {
+        D.flops_top = factor_flops;
+        D.nr_front_top = F;
+    }
 
     // position of a (new-numbered) variable x inside front f
     auto pos_in_front = [&](int32_t f, int32_t x) -> int32_t {
@@ -823,20 +909,30 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
             a_dst[p] = fr[f].off + (int64_t)pos_in_front(f, pi) * fr[f].ld + pos_in_front(f, pj);
         }
 
-    // levels: fronts by height, by decreasing k inside a level
+    // levels: fronts by height, by decreasing k inside a level.  Distributed: this rank's own subtrees first (part 0),
+    // then the replicated top (part 1); fronts of other ranks' subtrees are in no level of this schedule.
     int32_t H = 0;
     for (int32_t f = 0; f < F; ++f) H = std::max(H, height[f] + 1);
-    nr_level = H;
     std::vector<int32_t> level_fronts;
     std::vector<int32_t> ea_children;
     int64_t tmp_doubles = 1;
+    std::vector<std::vector<int32_t>> level_lists;
+    for (int part = 0; part < 2; ++part) {
+        if (part == 1) D.cut = (int32_t)level_lists.size();
+        for (int32_t h = 0; h < H; ++h) {
+            std::vector<int32_t> fs;
+            for (int32_t f = 0; f < F; ++f)
+                if (height[f] == h && (part == 0 ? (f_owner[f] >= 0 && f_owner[f] == rank) : f_owner[f] < 0)) fs.push_back(f);
+            if (!fs.empty()) level_lists.push_back(std::move(fs));
+        }
+    }
+    H = (int32_t)level_lists.size();
+    nr_level = H;
     m_sched.levels.resize(H);
     for (int32_t h = 0; h < H; ++h) {
         auto& L = m_sched.levels[h];
         L.front_begin = level_fronts.size();
-        std::vector<int32_t> fs;
-        for (int32_t f = 0; f < F; ++f)
-            if (height[f] == h) fs.push_back(f);
+        std::vector<int32_t> fs = level_lists[h];
         std::stable_sort(fs.begin(), fs.end(), [&](int32_t a, int32_t b) { return fr[a].k > fr[b].k; });
         level_fronts.insert(level_fronts.end(), fs.begin(), fs.end());
         L.front_end = level_fronts.size();
@@ -940,6 +1036,56 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     m_bufs.push_back(m_dev.work);
     m_bufs.push_back(m_dev.status);
 
+    // ---- exchange tables of the distributed schedule (MfSchedule::Dist) -----------------------------------------
+    if (D.enabled) {
+        std::vector<MfCopy2D> sp, su, ip, iu;
+        int64_t so = 0, io = 0;
+        for (int32_t c : cut_roots) {
+            const int32_t b = fr[c].m - fr[c].k, p = parent[c];
+            if (p < 0 || b == 0) continue;  // (a tree root that is a subtree of its own has nobody above it)
+            const bool mine = f_owner[c] == rank;
+            const int64_t blk = fr[c].off + (int64_t)2 * fr[c].k * fr[c].ld + 2 * fr[c].k;  // F[B,B]
+            if (mine) sp.push_back({blk, so, b, b, fr[c].ld, b});
+            else su.push_back({so, blk, b, b, b, fr[c].ld});
+            so += (int64_t)b * b;
+            D.schur_max_b = std::max(D.schur_max_b, b);
+            // the cut root's slot row in its parent's inbox
+            const auto& ch = children[p];
+            const int32_t j = (int32_t)(std::find(ch.begin(), ch.end(), c) - ch.begin());
+            const int64_t row = fr[p].inbox_off + (int64_t)j * fr[p].m;
+            if (mine) ip.push_back({row, io, 1, fr[p].m, fr[p].m, fr[p].m});
+            else iu.push_back({io, row, 1, fr[p].m, fr[p].m, fr[p].m});
+            io += fr[p].m;
+            D.inbox_max_m = std::max(D.inbox_max_m, fr[p].m);
+        }
+        D.schur_doubles = so;
+        D.inbox_doubles = io;
+        D.n_schur_pack = sp.size();
+        D.n_schur_unpack = su.size();
+        D.n_inbox_pack = ip.size();
+        D.n_inbox_unpack = iu.size();
+        D.schur_pack = upload(sp);
+        D.schur_unpack = upload(su);
+        D.inbox_pack = upload(ip);
+        D.inbox_unpack = upload(iu);
+        D.stage = static_cast<double*>(be->alloc(std::max<int64_t>(std::max(so, io), 1) * sizeof(double)));
+        m_bufs.push_back(D.stage);
+        // entries of the permuted solution this rank must not contribute to the last exchange: the pivots of the
+        // other ranks' subtrees, and -- except on rank 0 -- the replicated top's
+        for (int32_t f = 0; f < F; ++f) {
+            const bool speak = f_owner[f] >= 0 ? f_owner[f] == rank : rank == 0;
+            if (speak) continue;
+            const int32_t b0 = fr[f].own_start, e0 = b0 + fr[f].k;
+            if (!D.zero_ranges.empty() && D.zero_ranges.back().second == b0) D.zero_ranges.back().second = e0;
+            else D.zero_ranges.emplace_back(b0, e0);
+        }
+        if (std::getenv("SANM_MF_DEBUG"))
+            std::fprintf(stderr, "mf dist: rank %d of %d: %d subtrees (%d own), fronts own %d top %d, GF own %.2f top %.2f of "
+                         "%.2f, levels %d (cut at %d), schur exchange %.2f MB, inbox %.1f KB, %zu zero ranges\n", rank,
+                         world, D.nr_subtree, D.nr_subtree_own, D.nr_front_own, D.nr_front_top, D.flops_own / 1e9,
+                         D.flops_top / 1e9, factor_flops / 1e9, H, D.cut, so * 8 / 1e6, io * 8 / 1e3, D.zero_ranges.size());
+    }
+
     // ---- merged top block (mf_types.h, MfSchedule::Top): the root and the level below it ----------------------
     // Opt-in (SANM_MF_TOP = largest n_T to merge, e.g. 2048: 32 MB; default 0 = off).  Measured on armadillo_small
     // (n_T = 1071): 3 launches fewer per solve, 20 solves: -0.13 ms; two batched GEMM launches of 47 us per
@@ -947,7 +1093,7 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     {
         auto& T = m_sched.top;
         const int32_t max_n = top_max_n;
-        bool ok = max_n > 0 && H >= 3 && m_sched.levels[H - 1].front_end - m_sched.levels[H - 1].front_begin == 1;
+        bool ok = max_n > 0 && !D.enabled && H >= 3 && m_sched.levels[H - 1].front_end - m_sched.levels[H - 1].front_begin == 1;
         std::vector<int32_t> tf;
         if (ok) {
             const auto& L = m_sched.levels[H - 2];

@@ -40,9 +40,11 @@ namespace sanm_hip {
 
 class Multifrontal {
 public:
-    //! pattern of the n x n matrix (CSR, original numbering); coords (n,3) or null
+    //! pattern of the n x n matrix (CSR, original numbering); coords (n,3) or null.  world > 1: this rank's part of
+    //! the subtree-to-rank distribution (MfSchedule::Dist): every rank runs the same analysis on the same pattern
+    //! and keeps its own subtrees plus the replicated top of the tree in its schedule.
     Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& rowptr,
-                 const std::vector<uint32_t>& col, const double* coords);
+                 const std::vector<uint32_t>& col, const double* coords, int rank = 0, int world = 1);
     ~Multifrontal();
     Multifrontal(const Multifrontal&) = delete;
 

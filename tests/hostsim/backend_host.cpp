@@ -28,6 +28,8 @@
 namespace sanm_hip {
 int hostsim_mf_factor(const MfDev& mf, const MfSchedule& sch, const CsrDev& A);
 void hostsim_mf_solve(const MfDev& mf, const MfSchedule& sch, const double* b, double* x);
+void hostsim_mf_factor_piece(const MfDev& mf, const MfSchedule& sch, const CsrDev& A, int l0, int l1, bool prologue);
+void hostsim_mf_solve_piece(const MfDev& mf, const MfSchedule& sch, bool fwd, int l0, int l1);
 LinearSolver* hostsim_make_pardiso(const JacobianPattern& pat, int threads);  // pardiso_solver.cpp
 namespace {
 // Worker threads over contiguous ranges, like the reference's ParallelTaylorCoeffProp
@@ -319,6 +321,25 @@ public:
     void mf_solve(const MfDev& mf, const MfSchedule& sch, const double* b, double* x) override {
         hostsim_mf_solve(mf, sch, b, x);
     }
+    void mf_factor_piece(const MfDev& mf, const MfSchedule& sch, const CsrDev& A, int l0, int l1, bool prologue) override {
+        hostsim_mf_factor_piece(mf, sch, A, l0, l1, prologue);
+    }
+    void mf_factor_status(const MfDev& mf, double* out) override { *out = (double)*mf.status; }
+    void mf_solve_piece(const MfDev& mf, const MfSchedule& sch, bool fwd, int l0, int l1) override {
+        hostsim_mf_solve_piece(mf, sch, fwd, l0, l1);
+    }
+    void mf_permute(const MfDev& mf, const double* b, double* x) override {
+        if (b)
+            for (int64_t i = 0; i < mf.n; ++i) mf.work[mf.perm[i]] = b[i];
+        if (x)
+            for (int64_t i = 0; i < mf.n; ++i) x[i] = mf.work[mf.perm[i]];
+    }
+    void copy2d_batch(const MfCopy2D* d, int count, int, int, const double* src, double* dst) override {
+        for (int q = 0; q < count; ++q)
+            for (int i = 0; i < d[q].rows; ++i)
+                for (int j = 0; j < d[q].cols; ++j)
+                    dst[d[q].dst + (int64_t)i * d[q].ldd + j] = src[d[q].src + (int64_t)i * d[q].lds + j];
+    }
     double t0v_excess(size_t n, const double* fx, const double* v, double t0,
                       double tol) override {
         double m = -1e300;
@@ -342,14 +363,22 @@ namespace sanm_hip {
 namespace {
 struct HostMf {
     static int factor(const MfDev& mf, const MfSchedule& sch, const CsrDev& A) {
-        std::memset(mf.front_store, 0, mf.front_store_size * sizeof(double));
-        for (int64_t p = 0; p < mf.nnzA; ++p) mf.front_store[mf.a_dst[p]] += A.val[p];
+        factor_piece(mf, sch, A, 0, (int)sch.levels.size(), true);
+        return *mf.status;
+    }
+    static void factor_piece(const MfDev& mf, const MfSchedule& sch, const CsrDev& A, int l0, int l1, bool prologue) {
+        if (prologue) {
+            std::memset(mf.front_store, 0, mf.front_store_size * sizeof(double));
+            for (int64_t p = 0; p < mf.nnzA; ++p) mf.front_store[mf.a_dst[p]] += A.val[p];
+            double amax = 0;
+            for (int64_t p = 0; p < mf.nnzA; ++p) amax = std::fmax(amax, std::fabs(A.val[p]));
+            *mf.piv_amax = amax;
+            *mf.status = 0;
+        }
         int bad = 0;
-        double amax = 0;
-        for (int64_t p = 0; p < mf.nnzA; ++p) amax = std::fmax(amax, std::fabs(A.val[p]));
-        *mf.piv_amax = amax;
-        const double thr = MF_PIVOT_EPS * amax;  // static pivot perturbation, as in the HIP kernels (mf_kernels.h)
-        for (const auto& L : sch.levels) {
+        const double thr = MF_PIVOT_EPS * *mf.piv_amax;  // static pivot perturbation, as in the HIP kernels (mf_kernels.h)
+        for (int li = l0; li < l1; ++li) {
+            const auto& L = sch.levels[li];
             // extend-add the children of this level's fronts
             for (auto [b, e] : L.ea_rounds)
                 for (int32_t q = b; q < e; ++q) {
@@ -386,37 +415,48 @@ struct HostMf {
                 }
             }
         }
-        return bad;
+        *mf.status += bad;
     }
 
     static void solve(const MfDev& mf, const MfSchedule& sch, const double* b, double* x) {
         double* w = mf.work;
         if (b)  // (nullptr: the caller already put the permuted right-hand side into mf.work)
             for (int64_t i = 0; i < mf.n; ++i) w[mf.perm[i]] = b[i];
+        solve_piece(mf, sch, true, 0, (int)sch.levels.size());
+        solve_piece(mf, sch, false, 0, (int)sch.levels.size());
+        for (int64_t i = 0; i < mf.n; ++i) x[i] = w[mf.perm[i]];
+    }
+    static void solve_piece(const MfDev& mf, const MfSchedule& sch, bool fwd, int l0, int l1) {
+        double* w = mf.work;
         std::vector<double> t;
-        for (const auto& L : sch.levels)  // forward
-            for (int32_t q = L.front_begin; q < L.front_end; ++q) {
-                const MfFrontDev& f = mf.lfronts[q];
-                const double* F = mf.front_store + f.off;
-                const int m = f.m, k = f.k;
-                t.assign(m, 0.0);
-                for (int r = 0; r < k; ++r) t[r] = w[f.own_start + r];
-                // children's update entries arrive through the inbox (one slot per child and row)
-                for (int j = 0; j < f.nch; ++j)
-                    for (int r = 0; r < m; ++r) t[r] += mf.inbox_store[f.inbox_off + (int64_t)j * m + r];
-                for (int r = 0; r < k; ++r) {  // unit lower L11
-                    double v = t[r];
-                    for (int c2 = 0; c2 < r; ++c2) v -= F[(int64_t)r * f.ld + c2] * t[c2];
-                    t[r] = v;
+        if (fwd) {
+            for (int li = l0; li < l1; ++li) {
+                const auto& L = sch.levels[li];
+                for (int32_t q = L.front_begin; q < L.front_end; ++q) {
+                    const MfFrontDev& f = mf.lfronts[q];
+                    const double* F = mf.front_store + f.off;
+                    const int m = f.m, k = f.k;
+                    t.assign(m, 0.0);
+                    for (int r = 0; r < k; ++r) t[r] = w[f.own_start + r];
+                    // children's update entries arrive through the inbox (one slot per child and row)
+                    for (int j = 0; j < f.nch; ++j)
+                        for (int r = 0; r < m; ++r) t[r] += mf.inbox_store[f.inbox_off + (int64_t)j * m + r];
+                    for (int r = 0; r < k; ++r) {  // unit lower L11
+                        double v = t[r];
+                        for (int c2 = 0; c2 < r; ++c2) v -= F[(int64_t)r * f.ld + c2] * t[c2];
+                        t[r] = v;
+                    }
+                    for (int r = k; r < m; ++r) {
+                        double v = t[r];
+                        for (int c2 = 0; c2 < k; ++c2) v -= F[(int64_t)(r + k) * f.ld + c2] * t[c2];
+                        mf.inbox_store[mf.upd_dst[f.bnd_off + r - k]] = v;
+                    }
+                    for (int r = 0; r < k; ++r) w[f.own_start + r] = t[r];
                 }
-                for (int r = k; r < m; ++r) {
-                    double v = t[r];
-                    for (int c2 = 0; c2 < k; ++c2) v -= F[(int64_t)(r + k) * f.ld + c2] * t[c2];
-                    mf.inbox_store[mf.upd_dst[f.bnd_off + r - k]] = v;
-                }
-                for (int r = 0; r < k; ++r) w[f.own_start + r] = t[r];
             }
-        for (int li = (int)sch.levels.size() - 1; li >= 0; --li) {  // backward
+            return;
+        }
+        for (int li = l1 - 1; li >= l0; --li) {  // backward
             const auto& L = sch.levels[li];
             for (int32_t q = L.front_begin; q < L.front_end; ++q) {
                 const MfFrontDev& f = mf.fronts[mf.level_fronts[q]];
@@ -431,12 +471,17 @@ struct HostMf {
                 }
             }
         }
-        for (int64_t i = 0; i < mf.n; ++i) x[i] = w[mf.perm[i]];
     }
 };
 }  // namespace
 int hostsim_mf_factor(const MfDev& mf, const MfSchedule& sch, const CsrDev& A) { return HostMf::factor(mf, sch, A); }
 void hostsim_mf_solve(const MfDev& mf, const MfSchedule& sch, const double* b, double* x) { HostMf::solve(mf, sch, b, x); }
+void hostsim_mf_factor_piece(const MfDev& mf, const MfSchedule& sch, const CsrDev& A, int l0, int l1, bool prologue) {
+    HostMf::factor_piece(mf, sch, A, l0, l1, prologue);
+}
+void hostsim_mf_solve_piece(const MfDev& mf, const MfSchedule& sch, bool fwd, int l0, int l1) {
+    HostMf::solve_piece(mf, sch, fwd, l0, l1);
+}
 }  // namespace sanm_hip
 
 // the run-time compiler belongs to the product library only (sanm_amd/csrc/rtc.cpp)

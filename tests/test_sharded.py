@@ -230,3 +230,107 @@ def test_native_comm_setup_agrees_across_ranks_whatever_fails():
         assert res[rank]["init_fails_on_1"][0] is False
     assert res[0]["init_fails_on_1"] == [False, True, True]   # rank 0 had joined and dropped it again
     assert res[1]["init_fails_on_1"] == [False, False, False]
+
+
+WORKER_DIST = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+from tests.hostsim import get_hostsim_api
+from sanm_amd import fea as dfea, dist as sdist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+api = get_hostsim_api()
+cfg = {{"material": {{"young": 3e3, "poisson": 0.45, "density": 1000.0}}, "g": [0, -9.81, 0],
+       "boundary_thresh": 0.05, "boundary_proj_dir": [-1, 0, 0], "energy_model": "neohookean_c", "order": 10,
+       "disable_pade": {nopade!r}}}
+ncall = [0]
+base = sdist.make_host_allreduce()
+def counted(ptr, count):
+    ncall[0] += 1
+    base(ptr, count)
+dims = {dims!r}
+run = dfea.GravityRun(api, dfea.make_cuboid(*dims, 0.025), dict(cfg), shard=(rank, world, counted), solver_rtol=1e-15).run()
+st = run.solver.stats()
+ref = dfea.GravityRun(api, dfea.make_cuboid(*dims, 0.025), dict(cfg), solver_rtol=1e-15).run()
+V, Vr = run.vertices(), ref.vertices()
+out = dict(rank=rank, steps=int(run.solver.get_nr_iter()), ref_steps=int(ref.solver.get_nr_iter()),
+           err=float(np.abs(V - Vr).max() / np.abs(Vr).max()), ncall=ncall[0], rms=run.rms[-1], st=st,
+           ref_st=ref.solver.stats(), vsum=float(V.sum()))
+print("RESULT " + json.dumps(out), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def _run_dist(world, dims, nopade=True, env_extra=None):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), SANM_DIST_SOLVER="1", SANM_CPU_THREADS="1", **(env_extra or {}))
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER_DIST.format(root=ROOT, dims=dims, nopade=nopade)],
+                                      env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = []
+    try:
+        for p in procs:
+            so, se = p.communicate(timeout=900)
+            assert p.returncode == 0, se[-3000:]
+            res.append(json.loads([l for l in so.splitlines() if l.startswith("RESULT ")][0][7:]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return sorted(res, key=lambda r: r["rank"])
+
+
+def _check_dist(res, world):
+    total = res[0]["ref_st"]["factor_flops"]
+    top = res[0]["st"]["factor_flops_top"]
+    own = [r["st"]["factor_flops_own"] for r in res]
+    for r in res:
+        st = r["st"]
+        assert st["nr_subtree"] >= world and st["factor_flops"] == total and st["factor_flops_top"] == top
+        # same continuation, same equilibrium: every exchange is a gather, so the factors are the single-rank ones
+        assert r["steps"] == r["ref_steps"] and r["err"] < 1e-9 and r["rms"] < 1e-10
+        assert r["vsum"] == res[0]["vsum"]
+        # collectives: the tet-sharded driver's (f(x0), Jacobian values, b_k per order; f(x0) of the converged
+        # call) + per factorisation the Schur complements of the cut and the pivot status + per solve the inbox rows
+        # of the cut and the solution entries
+        steps, order, solves = r["steps"], 10, st["nr_linear_solve"]
+        assert r["ncall"] == steps * (1 + 1 + (order - 1)) + 1 + 2 * steps + 2 * solves
+    # the subtrees partition the work below the cut ...
+    assert abs(sum(own) + top - total) <= 1e-9 * total
+    # ... evenly enough that every rank factors clearly less than the whole (no 2-D LU of the top yet: the replicated
+    # top is what each rank still repeats)
+    sub = total - top
+    assert sub > 0.3 * total
+    for o in own:
+        assert o <= 1.6 * sub / world + 1e-9 * total, (own, top, total)
+    return own, top, total
+
+
+def test_subtree_distributed_factor_and_solve_two_ranks():
+    """Stage 1 of DESIGN.md section 7: the elimination tree cut into subtrees, each rank factors
+    and solves its own subtrees and the replicated top, the Schur complements of the cut / the inbox rows / the
+    solution entries exchanged.  Two ranks (gloo + host harness) on a 12 x 6 x 6 cantilever: the unsharded solve's
+    step count and vertices, the same result on both ranks bit for bit, flops per rank = top + about half of the
+    rest."""
+    res = _run_dist(2, (12, 6, 6))
+    own, top, total = _check_dist(res, 2)
+    print("2 ranks: own GF", [o / 1e9 for o in own], "top", top / 1e9, "total", total / 1e9)
+
+
+def test_subtree_distributed_factor_and_solve_four_ranks_with_pade():
+    """the same over four ranks, Pade on (the distributed solver's results are the replicated solver's bit for bit,
+    so its decisions are too: same step count as the unsharded run is asserted only through the sharded driver's
+    own summation-order caveat -- here the steps do agree)"""
+    res = _run_dist(4, (12, 6, 6), nopade=False)
+    for r in res:
+        assert r["err"] < 1e-9 and r["rms"] < 1e-10 and r["st"]["nr_subtree"] >= 4
+    assert len({r["vsum"] for r in res}) == 1 and len({r["steps"] for r in res}) == 1
+    top, total = res[0]["st"]["factor_flops_top"], res[0]["ref_st"]["factor_flops"]
+    own = [r["st"]["factor_flops_own"] for r in res]
+    assert abs(sum(own) + top - total) <= 1e-9 * total
+    print("4 ranks: own GF", [o / 1e9 for o in own], "top", top / 1e9, "total", total / 1e9)
