@@ -1094,6 +1094,7 @@ void AnmDriver::solve_expansion_coeffs() {
     const size_t n = m_n, n1 = m_n + 1;
     Backend* be = m_be;
 
+    const auto inject_at_entry = m_inject;
     be->d2d(m_xt_coeffs[0].p(), m_xt0.p(), n1 * 8);
     m_nr_valid_coeffs = 1;
     m_t_coeffs.assign(1, 0.0);
@@ -1388,6 +1389,7 @@ void AnmDriver::solve_expansion_coeffs() {
             // behaviour with the reference's settings).  Rare; the expansion is simply taken again along the
             // synchronous order-1 path, which re-solves with refinement as soon as it sees the status.
             m_force_order1_host = true;
+            m_inject = inject_at_entry;  // (a test's fault belongs to the expansion, not to its first attempt)
             try {
                 solve_expansion_coeffs();
             } catch (...) {

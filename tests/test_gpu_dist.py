@@ -164,10 +164,59 @@ gold = np.load(os.path.join({root!r}, "tests", "golden", "full_" + {name!r} + ".
 V, Vo = run.vertices(), gold["vertices"]
 print("RESULT " + json.dumps(dict(rank=rank, steps=int(run.solver.get_nr_iter()), gold_steps=int(gold["steps"]),
                                   err=float(np.abs(V - Vo).max() / np.abs(Vo).max()), rms=float(run.rms[-1]),
-                                  vsum=float(V.sum()))), flush=True)
+                                  vsum=float(V.sum()), st=run.solver.stats())), flush=True)
 dist.barrier()
 dist.destroy_process_group()
 """
+
+
+def _two_ranks_on_one_gpu(name, env_extra):
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    base_env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    base_env.update(env_extra)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for rank in range(2):
+        env = dict(base_env, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER_2ON1.format(root=root, name=name)],
+                                      env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = []
+    try:
+        for p in procs:
+            so, se = p.communicate(timeout=900)
+            assert p.returncode == 0, se[-3000:]
+            res.append(json.loads([l for l in so.splitlines() if l.startswith("RESULT ")][0][7:]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return sorted(res, key=lambda r: r["rank"])
+
+
+def test_subtree_distributed_solver_on_the_device_two_ranks_on_one_gpu():
+    """Stage 1 of the distributed direct solver (multifrontal.cpp, MfSchedule::Dist) on the HIP backend: two ranks
+    share cuda:0 (staged gloo all-reduce), SANM_DIST_SOLVER=1 forces the subtree distribution on the BASELINE-size
+    mesh of config 4.  Each rank factors its own subtrees and the replicated top; the Schur complements of the cut,
+    the inbox rows and the solution entries are exchanged (copy2d_kernel, mf_factor_piece / mf_solve_piece).  Every
+    exchange is a gather, so the result must be the oracle's equilibrium in the oracle's 2 steps, identical on both
+    ranks, and the flops of the two ranks' subtrees must add up to the whole minus the top."""
+    res = _two_ranks_on_one_gpu("armadillo_small", {"SANM_DIST_SOLVER": "1"})
+    print([(r["rank"], r["steps"], r["err"], r["st"]["factor_flops_own"], r["st"]["factor_flops_top"]) for r in res])
+    for r in res:
+        assert r["steps"] == r["gold_steps"] == 2 and r["err"] < 1e-9 and r["rms"] < 1e-10
+        assert r["st"]["nr_subtree"] >= 2 and r["st"]["nr_subtree_own"] >= 1
+    assert res[0]["vsum"] == res[1]["vsum"]
+    total, top = res[0]["st"]["factor_flops"], res[0]["st"]["factor_flops_top"]
+    own = [r["st"]["factor_flops_own"] for r in res]
+    assert abs(sum(own) + top - total) <= 1e-9 * total
+    assert max(own) <= 0.65 * (total - top)
 
 
 def test_two_ranks_on_one_gpu_run_the_world_2_branch_of_the_sharded_hip_path():
@@ -183,26 +232,7 @@ def test_two_ranks_on_one_gpu_run_the_world_2_branch_of_the_sharded_hip_path():
     import sys
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
     base_env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for rank in range(2):
-        env = dict(base_env, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, "-c", WORKER_2ON1.format(root=root, name="armadillo_small")],
-                                      env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    res = []
-    try:
-        for p in procs:
-            so, se = p.communicate(timeout=900)
-            assert p.returncode == 0, se[-3000:]
-            res.append(json.loads([l for l in so.splitlines() if l.startswith("RESULT ")][0][7:]))
-    finally:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
+    res = _two_ranks_on_one_gpu("armadillo_small", {})
     print(res)
     for r in res:
         assert r["steps"] == r["gold_steps"] == 2 and r["err"] < 1e-9 and r["rms"] < 1e-10
