@@ -74,14 +74,30 @@ def cpu_baseline(workload, budget_s=20.0, threads=None):
     cores = min(32, avail) if threads is None else threads
     os.environ["SANM_CPU_THREADS"] = str(cores)
     os.environ.setdefault("MKL_THREADING_LAYER", "GNU")  # libgomp is what this process has loaded already
-    from tests.hostsim import get_hostsim_api
+    # (pinned: MKL would otherwise size its team by the box -- 256 hardware threads on the GPU host)
+    os.environ["OMP_NUM_THREADS"] = os.environ["MKL_NUM_THREADS"] = str(cores)
+    os.environ.setdefault("MKL_DYNAMIC", "FALSE")
+    from tests.hostsim import get_hostsim_native_api
     from sanm_amd import fea as dfea
-    capi = get_hostsim_api()
-    cfg, mesh = load_workload(workload)
-    run = dfea.GravityRun(capi, mesh, cfg, solver_kind=2, profile=1)
+    setup = {}
     t0 = time.perf_counter()
-    run.construct()  # builds the tables that depend on the mesh only (untimed) and takes the first step
-    setup_s = time.perf_counter() - t0
+    capi = get_hostsim_native_api()  # -O3 -march=native build of the harness, made on this box on first use
+    setup["harness_build_or_load"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    try:
+        import ctypes
+        ctypes.CDLL("libmkl_rt.so", mode=ctypes.RTLD_GLOBAL)  # (page-in of MKL: tens of seconds on a cold box)
+    except OSError:
+        pass
+    setup["mkl_load"] = time.perf_counter() - t0
+    cfg, mesh = load_workload(workload)
+    t0 = time.perf_counter()
+    run = dfea.GravityRun(capi, mesh, cfg, solver_kind=2, profile=1)
+    setup["model_tables"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    run.construct()  # the solver's mesh-only tables (untimed) + the first step incl. PARDISO's analysis
+    setup["solver_tables_and_first_step"] = time.perf_counter() - t0
+    setup_s = sum(setup.values())
     s = run.solver
     x0 = run.model.x0()
     s.set_profile(1)  # clears what the constructor accumulated
@@ -98,11 +114,14 @@ def cpu_baseline(workload, budget_s=20.0, threads=None):
     tags = ("taylor_order0", "jacobian", "taylor_next_order", "taylor_push", "remap_out", "build_sparse_coeff",
             "sparse_prep", "sparse_solve", "anm_sanity_check", "estimate_valid_range", "solve_expansion_coeffs")
     return {"value": steps / t_step, "unit": "ANM steps/s", "cores": cores, "kind": "port",
-            "impl": "C++ host path of this build (tests/hostsim: worker threads over tet ranges) + MKL PARDISO "
-                    "(dlopen, reference settings)",
+            "impl": "NON-REFERENCE CPU port: the C++ host path of this build (tests/hostsim, g++ -O3 -march=native on this "
+                    "box: worker threads over tet ranges for the Taylor passes and the assembly, serial remaps as in the "
+                    "reference's SparseLinearDesc::apply) + MKL PARDISO (dlopen, reference settings, "
+                    f"MKL_NUM_THREADS={cores})",
             "sample": f"{steps} ANM steps ({workload}, order {cfg.get('order', 20)}: whole solves from the rest "
                       f"state) in {t_step:.1f} s on {cores} threads of {avail} available (32 = the reference's "
-                      f"sys-mt32 configuration); mesh-only setup {setup_s:.1f} s not counted",
+                      f"sys-mt32 configuration); setup {setup_s:.1f} s not counted",
+            "setup_seconds": {k: round(v, 2) for k, v in setup.items()},
             # the keys the reference's stats json carries (fea/main.cpp:425-431; render/gen_table_figs.py:60-66)
             "time_solve": t_step, "iter": steps, "threads": cores, "order": int(cfg.get("order", 20)),
             "pade": not cfg.get("disable_pade", False),
@@ -262,7 +281,8 @@ def cpu_baseline_single_thread(workload, budget_s=8.0):
                            capture_output=True, text=True, timeout=600, cwd=ROOT)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
         d = json.loads(line)
-        return {"value": d["value"], "unit": d["unit"], "cores": 1, "sample": d["sample"]}
+        return {"value": d["value"], "unit": d["unit"], "cores": 1, "sample": d["sample"],
+                "seconds_per_step": d["seconds_per_step"], "setup_seconds": d.get("setup_seconds")}
     except Exception as e:  # noqa: BLE001 - a missing figure must not cost the bench line
         return {"error": str(e)[:200]}
 

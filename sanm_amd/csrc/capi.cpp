@@ -293,12 +293,24 @@ int sanm_taylor_create(const sanm_graph* g, int out_var, const sanm_sparse_desc*
         Backend* be = backend();
         if (graph_is_vector(g->g, out_var)) {
             // batched vectors: the placeholder's length comes from the graph, the batch from remap_inp
+            // (the placeholder the OUTPUT depends on: a graph object may hold others that this output does not use)
             int idim = 0;
-            for (const GraphOp& op : g->g.ops)
-                if (op.type == OP_PLACEHOLDER && !op.out.empty()) idim = g->g.vars[op.out[0]].size;
+            {
+                std::vector<char> need(g->g.vars.size(), 0);
+                need[out_var] = 1;
+                for (int oi = (int)g->g.ops.size() - 1; oi >= 0; --oi) {
+                    const GraphOp& op = g->g.ops[oi];
+                    bool used = false;
+                    for (int o : op.out) used = used || need[o];
+                    if (!used) continue;
+                    for (int in : op.in) need[in] = 1;
+                    if (op.type == OP_PLACEHOLDER && !op.out.empty()) idim = g->g.vars[op.out[0]].size;
+                }
+            }
             sanm_check(idim > 0 && remap_inp->d.out_size % idim == 0, "remap_inp must produce a (B,%d) tensor", idim);
             auto p = std::make_unique<sanm_taylor_prop>();
             p->vec = std::make_unique<VecProgram>(be, g->g, out_var, remap_inp->d.out_size / idim, max_order);
+            sanm_check(p->vec->idim() == idim, "placeholder of %d elements, program input of %d", idim, p->vec->idim());
             p->vec_remap = remap_inp->d;
             p->n_in = remap_inp->d.in_size;
             p->xin = DVec{be, (size_t)remap_inp->d.out_size};

@@ -33,6 +33,7 @@ int Graph::add(GraphOp op, std::initializer_list<Shape> out_shapes) {
         GraphVar v{sh.rows * std::max(sh.cols, 1), oi, k++};
         v.rows = sh.rows;
         v.cols = sh.cols;
+        v.soft9 = sh.soft9;
         vars.push_back(v);
     }
     int first = op.out[0];
@@ -106,7 +107,7 @@ int Graph::constant(const double* val, int64_t batch, int size) {
     op.batch = batch;
     op.value.assign(val, val + batch * size);
     // (nine values: the (T,3,3) constants of the FEA graphs)
-    return add(std::move(op), {size == 9 ? Shape{3, 3} : Shape{size, 0}});
+    return add(std::move(op), {size == 9 ? Shape{3, 3, true} : Shape{size, 0}});
 }
 
 int Graph::constant_matrix(const double* val, int64_t batch, int rows, int cols) {
@@ -124,6 +125,10 @@ Graph::Shape Graph::elemwise_shape(Shape a, Shape b) const {
     sanm_check(sa == sb || sa == 1 || sb == 1, "invalid shape in elem arith: %d vs %d", sa, sb);
     if (sa == 1 && sb != 1) return b;
     if (sb == 1 && sa != 1) return a;
+    // a shapeless nine-value constant follows a flat operand (GraphVar::soft9); two of them stay what they are
+    if (a.soft9 && !b.soft9 && b.cols == 0) return b;
+    if (b.soft9 && !a.soft9 && a.cols == 0) return a;
+    if (a.soft9 != b.soft9) return a.soft9 ? b : a;
     // same element count: two matrices must agree in shape; a matrix and a flat operand keep the matrix's
     if (a.cols > 0 && b.cols > 0)
         sanm_check(a.rows == b.rows && a.cols == b.cols, "invalid shape in elem arith: (%d, %d) vs (%d, %d)", a.rows,

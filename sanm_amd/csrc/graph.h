@@ -39,6 +39,11 @@ struct GraphVar {
     int producer;  // index into Graph::ops
     int out_idx;
     int rows = 0, cols = 0;  // (batch, rows, cols); cols = 0: a (batch, rows) tensor (batched vector / scalar)
+    // a constant of nine values given without a shape: (3,3) by default -- the (T,3,3) constants of the FEA graphs --
+    // but it takes the shape of a flat (batch, 9) operand it meets in an elementwise operator (the reference's
+    // tensors carry their own shape; here a flat constant must not turn a graph over vectors of length 9 into one
+    // over matrices)
+    bool soft9 = false;
     bool is_matrix() const { return cols > 0; }
 };
 
@@ -87,9 +92,10 @@ public:
 private:
     struct Shape {
         int rows, cols;
+        bool soft9 = false;
     };
     int add(GraphOp op, std::initializer_list<Shape> out_shapes);
-    Shape shape(int v) const { return {vars[v].rows, vars[v].cols}; }
+    Shape shape(int v) const { return {vars[v].rows, vars[v].cols, vars[v].soft9}; }
     Shape elemwise_shape(Shape a, Shape b) const;
     void chk(int v) const;
 };

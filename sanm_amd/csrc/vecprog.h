@@ -1055,11 +1055,24 @@ VEC_HD void vec_backward(const VecProgDev& P, const VecOp& o, int64_t b, int e, 
             if (e < osz && !P.vars[o.in[0]].is_const) add(o.in[0], o.begin + e, go[e]);
             break;
         case OP_CONCAT: {
-            int off = 0;
+            // Thread e owns element e of every DISTINCT operand: a variable listed twice (concat([x, x])) receives
+            // the sum of its occurrences in one add -- one thread per output element adding into the operand's
+            // gradient would race on such a variable (the adds into the LDS scratch are not atomic).
+            int off_i = 0;
             for (int i = 0; i < o.nin; ++i) {
-                const int n = P.vars[o.in[i]].size;
-                if (e >= off && e < off + n && !P.vars[o.in[i]].is_const) add(o.in[i], e - off, go[e]);
-                off += n;
+                const int v = o.in[i], n = P.vars[v].size;
+                bool first = true;
+                for (int j = 0; j < i; ++j) first = first && o.in[j] != v;
+                if (first && e < n && !P.vars[v].is_const) {
+                    double s = 0;
+                    int off_j = off_i;
+                    for (int j = i; j < o.nin; ++j) {
+                        if (o.in[j] == v) s += go[off_j + e];
+                        off_j += P.vars[o.in[j]].size;
+                    }
+                    add(v, e, s);
+                }
+                off_i += n;
             }
             break;
         }

@@ -140,3 +140,33 @@ def test_slice_concat_argument_rules(api):
     prop = A.TaylorCoeffProp(api, x.pow(0.5), ident, 2, 1, in_size=5)
     with pytest.raises(A.SanmNumericalError):
         prop.push_xi(np.array([[1.0, 0.0, 2.0, 3.0, 4.0]]))
+
+
+def dup_graph(x, lc, cat):
+    """a variable listed twice in one concat, and once more beside a function of itself: the gradient of x is the sum
+    over its occurrences (the device's reverse sweep once let two threads add into one slot: ADVICE r3)"""
+    return cat([x, x.pow(2), x], 1)
+
+
+def test_concat_with_a_repeated_operand(api):
+    N, batch, n = 4, 3, 5
+    rng = np.random.default_rng(3)
+    xs = [rng.uniform(0.5, 1.5, (batch, n))] + [0.2 * rng.standard_normal((batch, n)) for _ in range(N)]
+    prop, keep = _device(api, dup_graph, n, batch, N)
+    oprops = [_oracle(dup_graph) for _ in range(batch)]
+    y = prop.push_xi(xs[0])
+    yo = np.concatenate([o.push_xi([xs[0][b:b + 1]]) for b, o in enumerate(oprops)])
+    assert y.shape == (batch, 3 * n) and np.allclose(y, yo, rtol=1e-13)
+    J, Jo = prop.get_jacobian(), np.concatenate([o.get_jacobian() for o in oprops])
+    assert np.allclose(J, Jo, rtol=1e-12, atol=1e-12)
+    # rows 0..n-1 and 2n..3n-1 are identity blocks, the middle one diag(2 x)
+    for b in range(batch):
+        assert np.allclose(J[b][:n], np.eye(n)) and np.allclose(J[b][2 * n:], np.eye(n))
+        assert np.allclose(J[b][n:2 * n], np.diag(2 * xs[0][b]))
+    for k in range(1, N + 1):
+        bias = prop.compute_next_order_bias()
+        bo = np.concatenate([o.compute_next_order_bias() for o in oprops])
+        assert np.allclose(bias, bo, rtol=1e-10, atol=1e-10)
+        yk = prop.push_xi(xs[k])
+        yko = np.concatenate([o.push_xi([xs[k][q:q + 1]]) for q, o in enumerate(oprops)])
+        assert np.allclose(yk, yko, rtol=1e-10, atol=1e-10)
