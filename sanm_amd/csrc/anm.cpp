@@ -1358,7 +1358,14 @@ void AnmDriver::solve_expansion_coeffs() {
     // (solves 2.20 -> 2.39 ms per step): off by default, like the other uses of the second queue.
     static const bool sanity_beside_env = std::getenv("SANM_SANITY_BESIDE") != nullptr;
     const bool sanity_beside = do_sanity && sanity_beside_env && !pade_side && m_hp.use_pade;
-    if (do_sanity) {
+    // Default since round 4: the checks are queued LAST, behind a mark in the (one) queue, and the host only waits
+    // for the mark -- the scalars of the order loop, the two norms and the Pade table are in by then -- so the root
+    // finder and the preparation of the first probe batch (0.08 ms of host time, profiles/r04_tail_trace.txt) run
+    // while the device is busy with the checks; their verdict is read at the range estimate's first synchronisation
+    // (or one of its own) and still reported first.  SANM_SANITY_FIRST=1: the checks in front, everything waited for.
+    static const bool sanity_first_env = std::getenv("SANM_SANITY_FIRST") != nullptr;
+    const bool sanity_behind = do_sanity && !sanity_beside && !pade_side && !sanity_first_env;
+    if (do_sanity && !sanity_behind) {
         if (sanity_beside) be->side_fork();
         queue_sanity(N, grad_t);  // the orders not checked beside the loop
         if (sanity_beside) {
@@ -1378,8 +1385,13 @@ void AnmDriver::solve_expansion_coeffs() {
         be->d2h_async(m_pade_ws.host_acoef, m_pade_ws.acoef.p(), (size_t)(N + 1) * (N + 1) * 8);
         m_pade_ws.host_valid = true;
     }
+    if (sanity_behind) {
+        be->mark();
+        queue_sanity(N, grad_t);
+    }
     g_trace.mark("loop queued");
-    be->sync();
+    if (sanity_behind) be->wait_mark();
+    else be->sync();
     g_trace.mark("loop-end sync returned");
     if (order1_on_device) {
         // what order 1 would have looked at before going on (sparse_solver.cpp:288-289, :107-127)
@@ -1418,9 +1430,10 @@ void AnmDriver::solve_expansion_coeffs() {
                 sanm_throw(SANM_ERR_NUMERICAL, "non-finite right-hand side / solution at order %d", i);
             m_t_coeffs.push_back(ti);
         }
-        if (!sanity_beside) check_sanity();
+        if (!sanity_beside && !sanity_behind) check_sanity();
     } catch (...) {
         be->side_wait();
+        if (sanity_behind) be->sync();  // (the checks are still running on buffers of this driver)
         throw;
     }
     g_trace.mark("checks done");
@@ -1433,6 +1446,10 @@ void AnmDriver::solve_expansion_coeffs() {
     }
     if (sanity_beside) {
         be->side_wait();
+        check_sanity();
+    }
+    if (sanity_behind) {
+        be->sync();  // (returns at once when the estimate has synchronised since)
         check_sanity();
     }
     g_trace.mark("range estimate done");

@@ -100,6 +100,10 @@ public:
     virtual void d2d(void* dst, const void* src, size_t bytes) = 0;
     virtual void zero(void* dst, size_t bytes) = 0;
     virtual void sync() = 0;
+    //! mark(): a point in the queue; wait_mark(): wait until everything queued BEFORE the last mark has run (what is
+    //! queued behind it may still be running).  Backends without queues: the default (everything has run already).
+    virtual void mark() {}
+    virtual void wait_mark() { sync(); }
     //! Record the launches queued between begin and end instead of running them, for replay with
     //! graph_launch (a launch-bound sequence of small kernels whose arguments do not change from one
     //! continuation step to the next).  begin returns false if the backend has no graphs: the caller then

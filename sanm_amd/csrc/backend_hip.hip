@@ -1223,6 +1223,7 @@ public:
     ~HipBackend() override {
         for (auto& kv : m_chains)
             if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (m_mark_ev) (void)hipEventDestroy(m_mark_ev);
         if (m_dlu_work) (void)hipFree(m_dlu_work);
         if (m_probe_groups) (void)hipHostFree(m_probe_groups);
         if (m_probe_results) (void)hipHostFree(m_probe_results);
@@ -1380,6 +1381,19 @@ public:
     void zero(void* dst, size_t bytes) override {
         if (!bytes) return;
         HIP_CHECK(hipMemsetAsync(dst, 0, bytes, m_stream));
+    }
+    hipEvent_t m_mark_ev = nullptr;
+    void mark() override {
+        flush_deferred();
+        if (!m_mark_ev) HIP_CHECK(hipEventCreateWithFlags(&m_mark_ev, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(m_mark_ev, m_stream));
+    }
+    void wait_mark() override {
+        if (!m_mark_ev) {
+            sync();
+            return;
+        }
+        HIP_CHECK(hipEventSynchronize(m_mark_ev));
     }
     void sync() override {
         flush_deferred();
