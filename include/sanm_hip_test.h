@@ -26,6 +26,11 @@ int sanm_rtc_cache_stats(int64_t* compiled, int64_t* memory_hits, int64_t* disk_
 /* obtains the code object of `source` through the caches exactly like a solver under construction does; 0 = ok */
 int sanm_rtc_cache_probe(const char* source);
 
+/* the subtree-to-rank plan of a direct solver created with SANM_MF_PLAN_WORLD=G in the environment (analysis as rank 0
+ * of G; scripts/dist_plan.py): rank_flops[r] = factor flops of rank r's subtrees, out8 = {world, total flops, flops of
+ * the replicated top, subtrees, doubles of the Schur exchange, doubles of the inbox exchange, imbalance, factor nnz} */
+int sanm_direct_solver_dist_plan(const sanm_direct_solver* s, int world_cap, double* rank_flops, double* out8);
+
 #ifdef __cplusplus
 }
 #endif

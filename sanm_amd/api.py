@@ -83,7 +83,7 @@ SYMBOLS = [
     "sanm_hyper_param_default", "sanm_anm_eqn_solver_create", "sanm_anm_eqn_solver_create_sharded",
     "sanm_anm_vecscale_solver_create",
     "sanm_anm_implicit_solver_create", "sanm_anm_solver_destroy", "sanm_anm_next_iter",
-    "sanm_anm_update_approx", "sanm_anm_restart", "sanm_anm_run_steps", "sanm_anm_spec_source", "sanm_rtc_compile_check", "sanm_rtc_cache_stats", "sanm_rtc_cache_probe", "sanm_anm_time_kernel", "sanm_anm_pass_timing", "sanm_anm_converged", "sanm_anm_residual_rms", "sanm_anm_get_x",
+    "sanm_anm_update_approx", "sanm_anm_restart", "sanm_anm_run_steps", "sanm_anm_spec_source", "sanm_rtc_compile_check", "sanm_rtc_cache_stats", "sanm_rtc_cache_probe", "sanm_direct_solver_dist_plan", "sanm_anm_time_kernel", "sanm_anm_pass_timing", "sanm_anm_converged", "sanm_anm_residual_rms", "sanm_anm_get_x",
     "sanm_anm_get_t_upper", "sanm_anm_get_t_max_a", "sanm_anm_solve_a", "sanm_anm_eval",
     "sanm_anm_nr_iter", "sanm_anm_nr_xt_coeffs", "sanm_anm_xt_coeff", "sanm_anm_has_pade",
     "sanm_anm_get_stats", "sanm_anm_profile", "sanm_anm_profile_counts", "sanm_anm_profile_launches", "sanm_anm_set_profile", "sanm_anm_debug_inject", "sanm_anm_trace", "sanm_anm_pade_diag", "sanm_anm_verbose_text", "sanm_anm_jacobian_csr",
@@ -448,6 +448,15 @@ class DirectSolver:
         if getattr(self, "h", None):
             self.api.lib.sanm_direct_solver_destroy(self.h)
             self.h = None
+
+    def dist_plan(self, world_cap=64):
+        """the subtree-to-rank plan of a solver created under SANM_MF_PLAN_WORLD (test hook, sanm_hip_test.h)"""
+        rf, out = np.zeros(world_cap), np.zeros(8)
+        self.api.check(self.api.lib.sanm_direct_solver_dist_plan(self.h, C.c_int(world_cap), _dp(rf), _dp(out)))
+        w = int(out[0])
+        return {"world": w, "total_flops": out[1], "top_flops": out[2], "nr_subtree": int(out[3]),
+                "schur_exchange_doubles": out[4], "inbox_exchange_doubles": out[5], "imbalance": out[6],
+                "factor_nnz": out[7], "rank_flops": rf[:w].tolist()}
 
     def factor(self, A):
         A = A.tocsr()

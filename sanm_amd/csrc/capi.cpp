@@ -224,7 +224,10 @@ int sanm_direct_solver_create(int64_t n, const uint32_t* rowptr, const uint32_t*
         auto s = std::make_unique<sanm_direct_solver>();
         s->rowptr.assign(rowptr, rowptr + n + 1);
         s->col.assign(col, col + rowptr[n]);
-        s->mf = std::make_unique<Multifrontal>(be, n, s->rowptr, s->col, coords);
+        // (SANM_MF_PLAN_WORLD=G: analysis as rank 0 of G -- what scripts/dist_plan.py reads back through
+        // sanm_direct_solver_dist_plan; factor / solve of such a handle are not offered)
+        const char* plan = std::getenv("SANM_MF_PLAN_WORLD");
+        s->mf = std::make_unique<Multifrontal>(be, n, s->rowptr, s->col, coords, 0, plan ? std::max(std::atoi(plan), 1) : 1);
         void* drp = be->alloc((n + 1) * 4);
         void* dcol = be->alloc(std::max<size_t>(s->col.size(), 1) * 4);
         be->h2d(drp, s->rowptr.data(), (n + 1) * 4);
@@ -235,6 +238,21 @@ int sanm_direct_solver_create(int64_t n, const uint32_t* rowptr, const uint32_t*
         s->csr = {static_cast<uint32_t*>(drp), static_cast<uint32_t*>(dcol), s->val.p(), n,
                   (int64_t)s->col.size()};
         *out = s.release();
+    });
+}
+int sanm_direct_solver_dist_plan(const sanm_direct_solver* s, int world_cap, double* rank_flops, double* out8) {
+    return guard([&] {
+        const auto& D = s->mf->schedule().dist;
+        sanm_check(rank_flops && out8, "null output");
+        for (int r = 0; r < world_cap; ++r) rank_flops[r] = r < (int)D.rank_flops.size() ? D.rank_flops[r] : 0.0;
+        out8[0] = D.enabled ? D.world : 1;
+        out8[1] = s->mf->factor_flops;
+        out8[2] = D.flops_top;
+        out8[3] = D.nr_subtree;
+        out8[4] = (double)D.schur_doubles;
+        out8[5] = (double)D.inbox_doubles;
+        out8[6] = D.imbalance;
+        out8[7] = (double)s->mf->nnz_factors;
     });
 }
 void sanm_direct_solver_destroy(sanm_direct_solver* s) {

@@ -121,6 +121,7 @@ struct MfSchedule {
         // what this rank factors: its subtrees and the replicated top (flops as Multifrontal::factor_flops counts them)
         double flops_own = 0, flops_top = 0;
         double imbalance = 1;  // largest subtree load of a rank over the mean
+        std::vector<double> rank_flops;  // subtree flops per rank (the same table on every rank)
         int32_t nr_front_own = 0, nr_front_top = 0, nr_subtree = 0, nr_subtree_own = 0;
     } dist;
     // The root and the fronts of the level below it as one dense operator (device back end; mf_kernels.h).

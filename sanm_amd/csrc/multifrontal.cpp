@@ -809,13 +809,23 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
                 mx = std::max(mx, l);
                 sum += l;
             }
+            if (root_owner) m_sched.dist.rank_flops = load;
             return sum > 0 ? mx * world / sum : 1.0;  // imbalance: largest load over the mean
         };
-        // Every split moves a front into the replicated top, so the cut stays as high as balance allows: split
-        // until there is a subtree per rank and the assignment is within 15 % of even, 4 subtrees per rank at most.
+        // Every split moves a front into the replicated top and (usually) evens out the ranks' loads.  What a rank
+        // has to factor is the top plus its own subtrees, so the cut is the one -- among those the splitting sequence
+        // passes through, largest subtree first, up to 4 subtrees per rank -- with the smallest
+        // top + largest rank load.
+        auto makespan = [&](const std::vector<int32_t>& set) {
+            double below = 0;
+            for (int32_t c : set) below += sub_flops[c];
+            const double imb = assign(set, nullptr);
+            return (factor_flops - below) + imb * below / world;
+        };
+        std::vector<int32_t> best_S = S;
+        double best_cost = makespan(S);
         for (;;) {
             if (S.size() >= (size_t)world * 4) break;
-            if (S.size() >= (size_t)world && assign(S, nullptr) <= 1.15) break;
             int best = -1;
             for (size_t i = 0; i < S.size(); ++i)
                 if (!children[S[i]].empty() && (best < 0 || sub_flops[S[i]] > sub_flops[S[best]])) best = (int)i;
@@ -825,7 +835,13 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
             const int32_t s0 = S[best];
             S.erase(S.begin() + best);
             S.insert(S.end(), children[s0].begin(), children[s0].end());
+            const double c = makespan(S);
+            if (c < best_cost) {
+                best_cost = c;
+                best_S = S;
+            }
         }
+        S = best_S;
         std::sort(S.begin(), S.end());
         cut_roots = S;
         std::vector<int32_t> root_owner(F, -1);
