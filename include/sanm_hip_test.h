@@ -27,8 +27,9 @@ int sanm_rtc_cache_stats(int64_t* compiled, int64_t* memory_hits, int64_t* disk_
 int sanm_rtc_cache_probe(const char* source);
 
 /* the subtree-to-rank plan of a direct solver created with SANM_MF_PLAN_WORLD=G in the environment (analysis as rank 0
- * of G; scripts/dist_plan.py): rank_flops[r] = factor flops of rank r's subtrees, out8 = {world, total flops, flops of
- * the replicated top, subtrees, doubles of the Schur exchange, doubles of the inbox exchange, imbalance, factor nnz} */
+ * of G; scripts/dist_plan.py): rank_flops[r] = factor flops of rank r's subtrees, rank_flops[world_cap + r] = their
+ * factor entries (2 * world_cap doubles), out8 = {world, total flops, flops of the replicated top, subtrees, doubles of
+ * the Schur exchange, doubles of the inbox exchange, factor entries of the top, factor entries in all} */
 int sanm_direct_solver_dist_plan(const sanm_direct_solver* s, int world_cap, double* rank_flops, double* out8);
 
 #ifdef __cplusplus

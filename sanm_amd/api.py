@@ -451,12 +451,14 @@ class DirectSolver:
 
     def dist_plan(self, world_cap=64):
         """the subtree-to-rank plan of a solver created under SANM_MF_PLAN_WORLD (test hook, sanm_hip_test.h)"""
-        rf, out = np.zeros(world_cap), np.zeros(8)
+        rf, out = np.zeros(2 * world_cap), np.zeros(8)
         self.api.check(self.api.lib.sanm_direct_solver_dist_plan(self.h, C.c_int(world_cap), _dp(rf), _dp(out)))
         w = int(out[0])
+        rfl = rf[:w].tolist()
         return {"world": w, "total_flops": out[1], "top_flops": out[2], "nr_subtree": int(out[3]),
-                "schur_exchange_doubles": out[4], "inbox_exchange_doubles": out[5], "imbalance": out[6],
-                "factor_nnz": out[7], "rank_flops": rf[:w].tolist()}
+                "schur_exchange_doubles": out[4], "inbox_exchange_doubles": out[5], "top_nnz": out[6],
+                "factor_nnz": out[7], "rank_flops": rfl, "rank_nnz": rf[world_cap:world_cap + w].tolist(),
+                "imbalance": (max(rfl) * w / sum(rfl)) if sum(rfl) > 0 else 1.0}
 
     def factor(self, A):
         A = A.tocsr()

@@ -244,14 +244,16 @@ int sanm_direct_solver_dist_plan(const sanm_direct_solver* s, int world_cap, dou
     return guard([&] {
         const auto& D = s->mf->schedule().dist;
         sanm_check(rank_flops && out8, "null output");
+        // rank_flops: 2 * world_cap doubles -- flops, then factor entries, of each rank's subtrees
         for (int r = 0; r < world_cap; ++r) rank_flops[r] = r < (int)D.rank_flops.size() ? D.rank_flops[r] : 0.0;
+        for (int r = 0; r < world_cap; ++r) rank_flops[world_cap + r] = r < (int)D.rank_nnz.size() ? D.rank_nnz[r] : 0.0;
         out8[0] = D.enabled ? D.world : 1;
         out8[1] = s->mf->factor_flops;
         out8[2] = D.flops_top;
         out8[3] = D.nr_subtree;
         out8[4] = (double)D.schur_doubles;
         out8[5] = (double)D.inbox_doubles;
-        out8[6] = D.imbalance;
+        out8[6] = D.nnz_top;
         out8[7] = (double)s->mf->nnz_factors;
     });
 }

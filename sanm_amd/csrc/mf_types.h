@@ -122,6 +122,8 @@ struct MfSchedule {
         double flops_own = 0, flops_top = 0;
         double imbalance = 1;  // largest subtree load of a rank over the mean
         std::vector<double> rank_flops;  // subtree flops per rank (the same table on every rank)
+        std::vector<double> rank_nnz;    // factor entries of each rank's subtrees; nnz_top: of the replicated top
+        double nnz_top = 0;
         int32_t nr_front_own = 0, nr_front_top = 0, nr_subtree = 0, nr_subtree_own = 0;
     } dist;
     // The root and the fronts of the level below it as one dense operator (device back end; mf_kernels.h).

@@ -855,6 +855,12 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
         D.enabled = true;
         D.nr_subtree = (int32_t)cut_roots.size();
         for (int32_t c : cut_roots) D.nr_subtree_own += f_owner[c] == rank;
+        D.rank_nnz.assign(world, 0.0);
+        for (int32_t f = 0; f < F; ++f) {
+            const double fk = fr[f].k, fb = fr[f].m - fr[f].k, fnnz = fk * fk + 2 * fk * fb;
+            if (f_owner[f] < 0) D.nnz_top += fnnz;
+            else D.rank_nnz[f_owner[f]] += fnnz;
+        }
         for (int32_t f = 0; f < F; ++f) {
             if (f_owner[f] < 0) {
                 D.flops_top += front_flops[f];

@@ -56,9 +56,11 @@ def main():
         own = max(plan["rank_flops"])
         plan["factor_flops_of_the_slowest_rank"] = top + own
         plan["factor_speedup_if_flops_bound"] = tot / (top + own)
+        plan["solve_bytes_speedup"] = plan["factor_nnz"] / (plan["top_nnz"] + max(plan["rank_nnz"]))
         rec["plans"].append(plan)
         print(f"world {w}: {plan['nr_subtree']} subtrees, top {top / tot:.1%} of {tot / 1e12:.2f} TFLOP, slowest rank's "
-              f"subtrees {own / tot:.1%} (imbalance {plan['imbalance']:.2f}) -> factor x{tot / (top + own):.2f}; "
+              f"subtrees {own / tot:.1%} (imbalance {plan['imbalance']:.2f}) -> factor x{tot / (top + own):.2f}, solve bytes "
+              f"x{plan['solve_bytes_speedup']:.2f} (top {plan['top_nnz'] / plan['factor_nnz']:.1%} of the entries); "
               f"Schur exchange {plan['schur_exchange_doubles'] * 8 / 1e9:.2f} GB, inbox {plan['inbox_exchange_doubles'] * 8 / 1e6:.2f} MB "
               f"per solve", flush=True)
     os.environ.pop("SANM_MF_PLAN_WORLD", None)
