@@ -31,7 +31,11 @@ from sanm_amd import fea as dfea  # noqa: E402
 
 api = sanm_amd.get_api()
 name = args[0] if args else "human_arap16"
-cfg, mesh = dfea.load_named_config(name)
+if ":" in name:  # a synthetic workload of bench.py (block:N, cuboid:x,y,z)
+    import bench
+    cfg, mesh = bench.load_workload(name)
+else:
+    cfg, mesh = dfea.load_named_config(name)
 run = dfea.GravityRun(api, mesh, dict(cfg)).construct()
 s = run.solver
 c = s.xt_coeffs()
