@@ -143,11 +143,9 @@ int sanm_taylor_reset(sanm_taylor_prop* p);
 
 /* ---- ANM solvers: libsanm/anm.h:96-305 ---------------------------------- */
 typedef struct sanm_hyper_param { /* ANMDriverHelper::HyperParam, anm.h:100-114, :247-251 */
-    int use_pade;       /* LIMIT: the Pade basis (pade.cpp:13-105) is built for order <= 25 -- the device's Gram-Schmidt
-                           kernels take 24 basis vectors per launch (GsPhase::kMaxVec); with use_pade and a larger
-                           order the range estimate fails with SANM_ERR_ASSERT ("pade basis: order ... exceeds ...").
-                           The reference takes any order (its shipped configs use 6, 16 and 20); plain-series
-                           continuation (use_pade = 0) has no such limit here either. */
+    int use_pade;       /* any order, as in the reference (pade.cpp:13-30): the device's Gram-Schmidt / probe kernels take
+                           24 series vectors per launch and run longer series in chunks (orders beyond 25: same arithmetic
+                           order as one pass, more launches; rounds 1-3 refused them) */
     int sanity_check;
     int order;
     double maxr;

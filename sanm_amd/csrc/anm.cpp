@@ -498,8 +498,8 @@ void PadeWorkspace::phase(const std::vector<DVec>& xs, int i, int k, bool anm_co
     ph.n = orth[1].size();
     ph.x = xs[i].p();
     ph.nvec = i - 1;
-    sanm_check(ph.nvec <= GsPhase::kMaxVec, "pade basis: order %d exceeds the %d series vectors the Gram-Schmidt kernels take",
-               n, GsPhase::kMaxVec + 1);
+    // (more than GsPhase::kMaxVec vectors -- orders beyond 25 --: the backend runs the phase in chunks)
+    ph.vecs.resize(ph.nvec);
     for (int j = 1; j < i; ++j) ph.vecs[j - 1] = orth[j].p();
     ph.eps = std::numeric_limits<double>::epsilon();
     if (k == 1) {

@@ -8,6 +8,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <vector>
 #include <map>
 #include <string>
 
@@ -61,8 +62,9 @@ struct GsPhase {
     size_t n = 0;
     const double* x = nullptr;
     int nvec = 0;
-    static constexpr int kMaxVec = 24;  // = MAX_VEC of the reduction kernels (backend_hip.hip)
-    double* vecs[kMaxVec] = {};
+    static constexpr int kMaxVec = 24;  // = MAX_VEC of the reduction kernels (backend_hip.hip): vectors per launch;
+                                        // a phase over more of them runs in chunks (orders beyond 25)
+    std::vector<double*> vecs;
     const double* coefs = nullptr;
     int first = 0;
     double* out = nullptr;

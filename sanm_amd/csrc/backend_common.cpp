@@ -23,10 +23,10 @@ void Backend::residual(const CsrDev& A, const double* b, const double* x, double
 void Backend::run_gs_phase(const GsPhase& ph) {
     switch (ph.kind) {
         case 1:
-            multi_dot_async(ph.n, ph.x, ph.nvec, ph.vecs, ph.red_out, ph.norm2, ph.nn2, ph.eps);
+            multi_dot_async(ph.n, ph.x, ph.nvec, ph.vecs.data(), ph.red_out, ph.norm2, ph.nn2, ph.eps);
             break;
         case 2:
-            gs_update_async(ph.n, ph.x, ph.nvec, ph.vecs, ph.coefs, ph.first, ph.out, ph.red_out);
+            gs_update_async(ph.n, ph.x, ph.nvec, ph.vecs.data(), ph.coefs, ph.first, ph.out, ph.red_out);
             break;
         case 3:
             scale_rsqrt_async(ph.n, ph.out, ph.norm2, ph.eps, ph.red_out);

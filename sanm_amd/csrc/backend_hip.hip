@@ -290,7 +290,8 @@ __global__ void lincomb_kernel(size_t n, VecList v, double* out) {
 // classical Gram-Schmidt update with the projections read from device memory, and the squared norm of
 // the result
 template <int NVT>
-__device__ __forceinline__ void gs_update_body(size_t n, const double* __restrict__ x, const VecList& q,
+// (x may be `out` itself -- the later chunks of a step over more than MAX_VEC vectors --: no restrict on it)
+__device__ __forceinline__ void gs_update_body(size_t n, const double* x, const VecList& q,
                                                const double* __restrict__ coefs, int first, double* out, GridRed g,
                                                unsigned bid, unsigned nb) {
     double s[1] = {0};
@@ -309,7 +310,7 @@ __device__ __forceinline__ void gs_update_body(size_t n, const double* __restric
     grid_commit_at<1>(s, 1, 0u, g, bid, nb);
 }
 template <int NVT>
-__global__ void __launch_bounds__(256) gs_update_kernel(size_t n, const double* __restrict__ x, VecList q,
+__global__ void __launch_bounds__(256) gs_update_kernel(size_t n, const double* x, VecList q,
                                                         const double* __restrict__ coefs, int first, double* out,
                                                         GridRed g) {
     gs_update_body<NVT>(n, x, q, coefs, first, out, g, blockIdx.x, gridDim.x);
@@ -1074,6 +1075,8 @@ class HipBackend final : public Backend {
     int m_fork_next = 0;
     Rccl::Comm m_comm = nullptr;
     int64_t m_launch_count = 0;
+    double* m_probe_work = nullptr;         // two work vectors of the range probes over more than MAX_VEC vectors
+    size_t m_probe_work_n = 0;
     ProbeGroup* m_probe_groups = nullptr;   // pinned: coefficient sets of a grouped range probe
     double* m_probe_results = nullptr;      // pinned
     double* m_probe_partials = nullptr;
@@ -1225,6 +1228,7 @@ public:
             if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
         if (m_mark_ev) (void)hipEventDestroy(m_mark_ev);
         if (m_dlu_work) (void)hipFree(m_dlu_work);
+        if (m_probe_work) (void)hipFree(m_probe_work);
         if (m_probe_groups) (void)hipHostFree(m_probe_groups);
         if (m_probe_results) (void)hipHostFree(m_probe_results);
         if (m_probe_partials) (void)hipFree(m_probe_partials);
@@ -2182,14 +2186,23 @@ public:
     }
     void lincomb(size_t n, int nvec, const double* const* ptrs, const double* coefs,
                  double* out) override {
-        if (nvec > MAX_VEC) sanm_throw(SANM_ERR_ASSERT, "lincomb: too many vectors");
-        VecList v{};
-        v.n = nvec;
-        for (int j = 0; j < nvec; ++j) {
-            v.p[j] = ptrs[j];
-            v.c[j] = coefs[j];
+        // more than MAX_VEC vectors: in chunks, `out` itself leading every chunk after the first with coefficient 1
+        // (0 + 1 * out is out: the sum is accumulated in the order of a single pass)
+        for (int j0 = 0; j0 < nvec || j0 == 0;) {
+            VecList v{};
+            int m = 0;
+            if (j0 > 0) {
+                v.p[m] = out;
+                v.c[m++] = 1.0;
+            }
+            for (; m < MAX_VEC && j0 < nvec; ++j0) {
+                v.p[m] = ptrs[j0];
+                v.c[m++] = coefs[j0];
+            }
+            v.n = m;
+            SANM_LAUNCH(lincomb_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, v, out);
+            if (nvec == 0) break;
         }
-        SANM_LAUNCH(lincomb_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, v, out);
         HIP_CHECK(hipGetLastError());
     }
     void lincomb2_diff_norms(size_t n, int nvec, const double* const* ptrs, const double* c1,
@@ -2210,7 +2223,26 @@ public:
     }
     void lincomb2_diff_norms_multi(size_t n, int nvec, const double* const* ptrs, int ncand, const double* c1,
                                    const double* c2, const double* scale, double* out_host) override {
-        if (nvec > MAX_VEC || ncand > PROBE_GROUPS * PROBE_MAX || ncand < 1)
+        if (nvec > MAX_VEC) {
+            // orders beyond 25: both combinations of every candidate through two work vectors (chunked lincomb), then
+            // the norms kernel on the pair -- u = 1 * u_buf + 0 * w_buf, w likewise: the values of a single pass
+            if (m_probe_work_n < n) {
+                if (m_probe_work) HIP_CHECK(hipFree(m_probe_work));
+                HIP_CHECK(hipMalloc(&m_probe_work, 2 * n * sizeof(double)));
+                m_probe_work_n = n;
+            }
+            double* u = m_probe_work;
+            double* w = m_probe_work + n;
+            const double* pair[2] = {u, w};
+            const double one_zero[2] = {1.0, 0.0}, zero_one[2] = {0.0, 1.0};
+            for (int c = 0; c < ncand; ++c) {
+                lincomb(n, nvec, ptrs, c1 + (size_t)c * nvec, u);
+                lincomb(n, nvec, ptrs, c2 + (size_t)c * nvec, w);
+                lincomb2_diff_norms(n, 2, pair, one_zero, zero_one, scale[c], out_host + 2 * c);
+            }
+            return;
+        }
+        if (ncand > PROBE_GROUPS * PROBE_MAX || ncand < 1)
             sanm_throw(SANM_ERR_ASSERT, "lincomb2_diff_norms_multi: %d vectors, %d candidates", nvec, ncand);
         static const bool split = std::getenv("SANM_PROBE_SPLIT") != nullptr;  // (debug: groups as launches of their own)
         if (ncand > PROBE_MAX && split) {
@@ -2271,14 +2303,14 @@ public:
     }
     void multi_dot(size_t n, const double* x, int nvec, const double* const* ys,
                    double* out_host) override {
-        if (nvec > MAX_VEC) sanm_throw(SANM_ERR_ASSERT, "multi_dot: too many vectors");
-        if (nvec == 0) return;
-        VecList v{};
-        v.n = nvec;
-        for (int j = 0; j < nvec; ++j) v.p[j] = ys[j];
-        launch_multi_dot(n, x, v, nullptr, nullptr, 0.0, red());
-        const double* r = red_result();
-        for (int j = 0; j < nvec; ++j) out_host[j] = r[j];
+        for (int j0 = 0; j0 < nvec; j0 += MAX_VEC) {
+            VecList v{};
+            v.n = std::min(MAX_VEC, nvec - j0);
+            for (int j = 0; j < v.n; ++j) v.p[j] = ys[j0 + j];
+            launch_multi_dot(n, x, v, nullptr, nullptr, 0.0, red());
+            const double* r = red_result();
+            for (int j = 0; j < v.n; ++j) out_host[j0 + j] = r[j];
+        }
     }
     void vmul(size_t n, const double* x, const double* y, double* out) override {
         SANM_LAUNCH(vmul_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, x, y, out);
@@ -2360,17 +2392,27 @@ public:
     }
     void multi_dot_async(size_t n, const double* x, int nvec, double* const* ys, double* out,
                          const double* last_norm2, const double* last_nn2, double eps) override {
-        if (nvec > MAX_VEC) sanm_throw(SANM_ERR_ASSERT, "multi_dot: too many vectors");
         if (nvec == 0) return;
-        VecList v{};
-        v.n = nvec;
-        for (int j = 0; j < nvec; ++j) v.p[j] = ys[j];
-        launch_multi_dot(n, x, v, last_norm2, last_nn2, eps, red_to(out));
+        // (chunks of MAX_VEC vectors; the second normalisation of the last vector belongs to the chunk that holds it)
+        for (int j0 = 0; j0 < nvec; j0 += MAX_VEC) {
+            VecList v{};
+            v.n = std::min(MAX_VEC, nvec - j0);
+            for (int j = 0; j < v.n; ++j) v.p[j] = ys[j0 + j];
+            const bool last = j0 + v.n == nvec;
+            launch_multi_dot(n, x, v, last ? last_norm2 : nullptr, last ? last_nn2 : nullptr, eps, red_to(out + j0));
+        }
         HIP_CHECK(hipGetLastError());
     }
     void gs_update_async(size_t n, const double* x, int nvec, const double* const* qs, const double* coefs,
                          int first, double* out, double* norm2) override {
-        if (nvec > MAX_VEC) sanm_throw(SANM_ERR_ASSERT, "gs_update: too many vectors");
+        if (nvec > MAX_VEC) {
+            // chunks of MAX_VEC vectors: the first from x, the others in place on `out` (same order of subtractions as a
+            // single pass; every chunk leaves the norm of what it wrote, the last one's is the result's)
+            for (int j0 = 0; j0 < nvec; j0 += MAX_VEC)
+                gs_update_async(n, j0 == 0 ? x : out, std::min(MAX_VEC, nvec - j0), qs + j0, coefs + j0,
+                                std::max(first - j0, 0), out, norm2);
+            return;
+        }
         VecList v{};
         v.n = nvec;
         for (int j = 0; j < nvec; ++j) v.p[j] = qs[j];

@@ -368,3 +368,51 @@ def test_pade_approx_on_its_own(api):
         got = pade.eval_xt(a)
         assert got[-1] == pytest.approx(t, rel=1.2e-5)
         assert np.allclose(up.eval_tensor(xs, a), got, rtol=1e-4, atol=1e-4)
+
+
+def test_pade_approx_beyond_order_25(api):
+    """The reference's PadeApproximation takes any order (pade.cpp:13-30); the device's Gram-Schmidt / linear-combination
+    kernels take 24 vectors per launch and run longer series in chunks (round 4; rounds 1-3 refused order > 25).  31
+    coefficient vectors: same accepted range, same values and same solve_a as the oracle's on the same series."""
+    from oracle import unary_polynomial as up
+    from oracle.pade import PadeApproximation as OPade
+    rng = np.random.default_rng(11)
+    SIZE, N, eps = 700, 31, 1e-5
+    xs = [rng.uniform(-1, 1, SIZE) * 0.6 ** (i + 1) for i in range(N)]
+    xs[1][SIZE - 1] = 2.3
+    range0 = (eps * np.linalg.norm(xs[1]) / np.linalg.norm(xs[N - 1])) ** (1.0 / (N - 2))
+    pade = A.PadeApproximation(api, xs, False)
+    opade = OPade(xs, False, True)
+    ok_d, ok_o = pade.estimate_valid_range(range0 / 10, eps), opade.estimate_valid_range(range0 / 10, eps)
+    assert ok_d == ok_o
+    assert ok_d, "the series was chosen so that the approximant is accepted"
+    assert pade.get_t_max_a() == pytest.approx(opade.t_max_a, rel=1e-6)
+    assert pade.get_t_max() == pytest.approx(opade.t_max, rel=1e-6)
+    for div in (8.0, 3.0, 1.01):
+        a = pade.get_t_max_a() / div
+        got = pade.eval_xt(a)
+        assert np.abs(got - opade.eval_xt(a)).max() <= 1e-9 * np.abs(got).max()
+        assert np.allclose(up.eval_tensor(xs, a), got, rtol=1e-4, atol=1e-4)
+    tmin, tmax = xs[0][SIZE - 1], pade.get_t_max()
+    for frac in (0.27, 0.96):
+        t = tmin * (1 - frac) + tmax * frac
+        assert pade.solve_a(t) == pytest.approx(opade.solve_a(t), rel=1e-5, abs=2.5e-6)
+
+
+def test_anm_solver_at_order_30(api):
+    """a whole continuation at order 30 with Pade on (orders beyond 25 were refused until round 4): the oracle's
+    equilibrium, the oracle's step count unless a certified ill-conditioned decision is met (tests/lockstep.py)"""
+    cfg = {"material": {"young": 3e3, "poisson": 0.45, "density": 1000.0}, "g": [0, -9.81, 0],
+           "boundary_thresh": 0.05, "boundary_proj_dir": [-1, 0, 0], "energy_model": "neohookean_c", "order": 30}
+    dims, sp = (5, 3, 3), 0.03
+    run = dfea.GravityRun(api, dfea.make_cuboid(*dims, sp), dict(cfg), solver_rtol=1e-15).construct()
+    _, osolver, _ = ofea.make_gravity_solver(ofea.make_cuboid(*dims, sp), cfg)
+    ls = LockStep(run, osolver).run_to_convergence()
+    omodel, ofree, _ = ofea.make_gravity_solver(ofea.make_cuboid(*dims, sp), cfg)
+    xo, _ = ofea.run_anm(ofree)
+    Vo = omodel.lt_inp.full_vertices(xo)
+    V = run.vertices()
+    assert np.abs(V - Vo).max() <= VTX_RTOL * np.abs(Vo).max()
+    print("order 30: steps", ls.nr_steps, "oracle", ofree.get_nr_iter(), "events", len(ls.events))
+    if not ls.events:
+        assert ls.nr_steps == ofree.get_nr_iter()
