@@ -14,8 +14,10 @@ enough) take the same ones; the continuations then pass through different interm
 approximation within the range criterion -- to the same equilibrium.
 
 What is checked instead, at EVERY step, from a COMMON state:
-  1. both sides expand at the same point (the oracle is re-started at the device's restart point, which was first
-     compared with the oracle's own evaluation of the approximant at the device's parameter);
+  1. both sides expand at the same point: the oracle is re-started at the device's restart point, which was first
+     compared (a) always, at 1e-8 of the step's increment, with the oracle's evaluation code applied to what the device
+     exports -- its series and, with Pade, its own denominator --, and (b) where both sides took the same decision, at
+     1e-4 with the oracle's own approximant (_check_restart; round 3 widened (b) by x50 after an adopted outcome);
   2. residual RMS (1e-7), the series as functions on [0, a_bound] and their first coefficient (1e-6) and the
      plain-series range a_bound (1e-7 + the relative error it inherits from |x_1| and |x_N|) agree;
   3. the outcome of the range estimate -- Pade accepted or not, accepted range -- is either identical, or CERTIFIED
@@ -27,6 +29,11 @@ What is checked instead, at EVERY step, from a COMMON state:
      DEVICE's denominator the oracle's implementation must reproduce the device's valid flag exactly;
   5. convergence is declared at the same step, and the equilibrium agrees to 1e-6 relative (north_star).
 The free-running oracle's step count is reported next to it; callers assert equality where no event occurred.
+
+LockStep drives an ANMEqnSolver (next_iter until converged), LockStepPath the path-following drivers ANMSolverVecScale /
+ANMImplicitSolver (update_approx), lockstep_vtx_delta_stage one stage of run_with_vtx_delta (implicit solver, then the
+order-6 refinement) -- BASELINE config 1 and the CLI's mesh_twist.  With arbiter=True every range estimate is also
+taken in high precision (oracle/pade_hp.py) on both sides' series: scripts/pade_arbiter.py.
 """
 import numpy as np
 
