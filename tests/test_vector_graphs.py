@@ -170,3 +170,26 @@ def test_concat_with_a_repeated_operand(api):
         yk = prop.push_xi(xs[k])
         yko = np.concatenate([o.push_xi([xs[k][q:q + 1]]) for q, o in enumerate(oprops)])
         assert np.allclose(yk, yko, rtol=1e-10, atol=1e-10)
+
+
+def test_flat_constant_of_nine_values_follows_a_vector_operand(api):
+    """A constant given as nine values without a shape is (3,3) by default -- the (T,3,3) constants of the FEA graphs --
+    but in a graph over vectors of LENGTH 9 it must stay a vector: placeholder_vector(9) * constant((B,9)) followed by a
+    slice was refused ('(batch, n) operands only') before round 4, and the reference accepts it."""
+    B, n = 2, 9
+    rng = np.random.default_rng(5)
+    cval = rng.uniform(0.5, 1.5, (B, n))
+    x0 = rng.uniform(0.5, 1.5, (B, n))
+    g = api.graph()
+    x = g.placeholder_vector(n)
+    c = A.constant(g, cval)
+    y = (x * c).slice(1, 2, 7)
+    ident = A.SparseLinearDesc(api, sp.identity(B * n, format="csr"))
+    prop = A.TaylorCoeffProp(api, y, ident, 2, B, in_size=n)
+    out = prop.push_xi(x0)
+    assert out.shape == (B, 5) and np.allclose(out, (x0 * cval)[:, 2:7], rtol=1e-14)
+    J = prop.get_jacobian()
+    for b in range(B):
+        expect = np.zeros((5, n))
+        expect[np.arange(5), np.arange(2, 7)] = cval[b, 2:7]
+        assert np.allclose(J[b], expect)
