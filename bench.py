@@ -498,6 +498,9 @@ def main(argv=None):
                        "linear_solver": "jacobi-pcg" if args.solver_kind == 0 else "multifrontal-lu",
                        "solver_stats": {k: stats[k] for k in ("factor_nnz", "factor_flops", "nr_front",
                                                               "nr_level", "max_front")},
+                       # rank 0's share when the direct solver is distributed by subtrees (nr_subtree > 0)
+                       "dist_solver": {k: stats[k] for k in ("nr_subtree", "nr_subtree_own", "factor_flops_own",
+                                                             "factor_flops_top")},
                        "steps_per_solve": state["steps_per_solve"]},
             # the family of kernels the step spends most of its time in (HBM-bound families only; the
             # factorisation is priced against the fp64 matrix-core peak in roofline_families)
