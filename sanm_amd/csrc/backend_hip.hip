@@ -1161,6 +1161,7 @@ class HipBackend final : public Backend {
     double* m_pcg_w[4] = {nullptr, nullptr, nullptr, nullptr};
     PcgScalars* m_pcg_sc = nullptr;
     static constexpr int kSolveLdsMax = 150 * 1024;
+    static constexpr int kWideMinM = 4096;  // backward levels with fronts this wide take bwd_wide_kernel
     // fronts from this many pivots on are factored with two blocking levels (measured: pays from ~400) (outer blocks of kOuterPanels
     // 32-wide panels); SANM_MF_OUTER_MIN_K overrides it (tests force the path on small fronts)
 #ifndef SANM_MF_OUTER_PANELS
@@ -1978,6 +1979,29 @@ public:
         using namespace mfk;
         const char* env_lds = std::getenv("SANM_MF_LDS_MAX");  // tests force the large-front path
         const size_t lds_max = env_lds ? (size_t)std::atol(env_lds) : (size_t)kSolveLdsMax;
+        // backward sweep over fronts with long rows: the workgroup-per-rows kernel without LDS staging (mf_kernels.h,
+        // bwd_wide_kernel).  SANM_MF_WIDE_MIN_M: the front width it starts at (tests force it on small fronts;
+        // huge: never); SANM_MF_WIDE_R: rows per workgroup
+        const char* env_wide = std::getenv("SANM_MF_WIDE_MIN_M");
+        const int wide_min_m = env_wide ? std::atoi(env_wide) : kWideMinM;
+        if (!fwd && L.max_m >= wide_min_m) {
+            const char* env_wr = std::getenv("SANM_MF_WIDE_R");
+            const int env_r = env_wr ? std::atoi(env_wr) : 0;
+            const int cnt = L.front_end - L.front_begin;
+            // 4 rows per workgroup once that still leaves every CU two workgroups (block:48, all wide levels at
+            // 1 / 2 / 4 rows: solves 51.2 / 48.0 / 47.7 ms per step; the LDS-staged kernel 53.0)
+            const int r = env_r ? env_r : (L.sum_k >= 2048 ? 4 : 2);
+            if (r == 1)
+                SANM_LAUNCH((bwd_wide_kernel<1>), dim3(L.max_k, cnt), dim3(256), 0, m_stream, mf.lfronts + L.front_begin,
+                            mf.front_store, mf.work, mf.work2, mf.bnd_idx);
+            else if (r == 2)
+                SANM_LAUNCH((bwd_wide_kernel<2>), dim3((L.max_k + 1) / 2, cnt), dim3(256), 0, m_stream,
+                            mf.lfronts + L.front_begin, mf.front_store, mf.work, mf.work2, mf.bnd_idx);
+            else
+                SANM_LAUNCH((bwd_wide_kernel<4>), dim3((L.max_k + 3) / 4, cnt), dim3(256), 0, m_stream,
+                            mf.lfronts + L.front_begin, mf.front_store, mf.work, mf.work2, mf.bnd_idx);
+            return;
+        }
         if ((size_t)(fwd ? L.max_k : L.max_m) * sizeof(double) > lds_max) {
             // vectors beyond the LDS: plain mat-vec kernels on operands in HBM (bandwidth-bound levels)
             const int cnt = L.front_end - L.front_begin;

@@ -1214,6 +1214,68 @@ __global__ void __launch_bounds__(256) bwd_big_kernel(MfDev mf, int level_begin)
     if (lane == 0) mf.work[f.own_start + r] = acc;
 }
 
+// ---- backward level kernel for fronts with long rows (round 4) --------------------------------------------------
+// A backward row is a dot product over the whole front width m.  bwd_level_kernel gives a row to one wavefront and
+// stages all m entries of the input vector in LDS per workgroup: on fronts of thousands of rows that is 70 KB of LDS
+// (two workgroups per CU) and, on the chains of ~1000-pivot fronts at the top of a big tree (multifrontal.cpp,
+// split_big_fronts), k / 4 = 240 workgroups for 50 MB of operator -- 2 TB/s where the forward kernel of the same level
+// (m rows of k entries, 8 KB of LDS) streams at 4-5.  Here the four wavefronts of a workgroup share R rows: wavefront
+// w takes the 64-column chunks w, w + 4, w + 8, ... of every row (the workgroup reads 2 KB of a row at a time),
+// the vector comes straight from the work vectors (the boundary part through bnd_idx: L2 hits after the first row),
+// no LDS but the 4 x R partial sums, which wavefront 0 adds in the order w = 0..3.  k / R workgroups of 4 wavefronts.
+template <int R>
+__global__ void __launch_bounds__(256) bwd_wide_kernel(const MfFrontDev* __restrict__ lfronts,
+                                                       const double* __restrict__ front_store, double* work,
+                                                       const double* __restrict__ work2,
+                                                       const int32_t* __restrict__ bnd_idx) {
+    const MfFrontDev f = lfronts[blockIdx.y];
+    const int m = f.m, k = f.k;
+    const int rb = blockIdx.x * R;
+    if (rb >= k) return;
+    __shared__ double part[4][R];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double* rowp[R];
+    double acc[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const int r = rb + q;
+        rowp[q] = front_store + f.off + (int64_t)(k + (r < k ? r : rb)) * f.ld;
+        acc[q] = 0;
+    }
+    const int32_t* bi = bnd_idx + f.bnd_off;
+    const double* z = work2 + f.own_start;
+    constexpr int TAIL = 8;
+    // virtual column c of a row: physical column c (c < k: U11^-1, from the diagonal on) or c + k (boundary block)
+    for (int c = rb + 64 * wv + lane; c < m; c += 256 * TAIL) {
+        double av[TAIL][R], tv[TAIL];
+#pragma unroll
+        for (int u = 0; u < TAIL; ++u) {
+            const int cc = c + 256 * u;
+            const bool in = cc < m;
+            const int cs = in ? cc : rb;
+            tv[u] = cs < k ? z[cs] : work[bi[cs - k]];
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const bool ok = in && cc >= rb + q && rb + q < k;
+                const double x = rowp[q][ok ? (cc < k ? cc : cc + k) : 0];
+                av[u][q] = ok ? x : 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TAIL; ++u)
+#pragma unroll
+            for (int q = 0; q < R; ++q) acc[q] = __builtin_fma(av[u][q], tv[u], acc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const double v = wave_sum(acc[q]);
+        if (lane == 0) part[wv][q] = v;
+    }
+    __syncthreads();
+    if (tid < R && rb + tid < k)
+        work[f.own_start + rb + tid] = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
+}
+
 // ---- merged top of the tree (MfSchedule::Top) -----------------------------------------------------------
 // The last two levels of the tree -- the root and the fronts below it -- cost four dependent launches per solve
 // (two forward, two backward) that move a few megabytes each.  After the factorisation their solve operators are

@@ -634,6 +634,78 @@ void amalgamate_levels(std::vector<NdNode>& nodes, const SvGraph& g) {
     nodes.swap(out);
 }
 
+// ---------------------------------------------------------------------------
+// Chains in place of big fronts.  A front of k pivots and b boundary rows pays, beside its LU (2/3 k^3 + 2 k^2 b +
+// 2 k b^2), 2 k^3 + 2 k^2 b for the explicit inverses of its pivot block and the boundary blocks of the solve
+// operators (mf_kernels.h: that is what makes every solve level one mat-vec launch) -- a third of all factor flops on a
+// 48^3 block, nearly all of it in the dozen separators at the top.  Cutting the pivots of such a front into chunks
+// of about W, each a front of its own whose boundary is the rest of the pivots plus the old boundary, leaves the
+// elimination order, the permutation and the factor entries what they were and turns the inverse work into W k^2 + 2 W k b:
+// the rest of the front's elimination becomes Schur products with K = W (the fast tall tiles).  The price is one
+// more level per chunk (two launches per solve each, 5 us where a level of this size streams for 15-90) and the
+// chunk's Schur complement handed on through an extend-add.  SANM_MF_SPLIT_K = W: fixed width (0: never cut).
+bool split_big_fronts(std::vector<NdNode>& nodes, const SvGraph& g, const std::vector<int32_t>& node_k) {
+    // chunk width W: fronts beyond 1.5 W pivots are cut into ceil(k / W) chunks.  One width for the whole tree (fronts
+    // of a level are batched into one launch each: chunks of one size keep the levels homogeneous; a width per front
+    // from a cost model -- c chunks leave (k^3 + 2 k^2 b) / c of the inverse work and cost c extend-adds of about
+    // (b + k/2)^2 entries, smallest sum at 12.4 sqrt(b + k/2) pivots by the rates of one MI355X -- measured 1-4 %
+    // slower on the 48^3 block for that reason).  The width that measured best grows with the tree: 896-1088 on the 48^3
+    // block (largest front 6756 pivots; 1280+: 4 % slower), 1536-2048 on the 60^3 block (1024: 4 % slower), i.e.
+    // about 1/6.75 of the largest front, kept inside [1024, 1536]: no front of fewer than 1537 pivots is ever cut, so
+    // that every BASELINE mesh (fronts of <= 1032 rows: a level there is launch latency, not arithmetic) stays as it
+    // was, bit for bit.  SANM_MF_SPLIT_K = W fixes the width (tests force the path on small fronts); 0: never cut.
+    int W = -1;
+    if (const char* e = std::getenv("SANM_MF_SPLIT_K")) W = std::atoi(e);
+    if (W == 0) return false;
+    const int32_t F = nodes.size();
+    if (W < 0) {
+        int32_t kmax = 0;
+        for (int32_t u = 0; u < F; ++u) kmax = std::max(kmax, node_k[u]);
+        W = std::min(1536, std::max(1024, (int)std::lround(kmax / 6.75 / 32) * 32));
+    }
+    bool any = false;
+    for (int32_t u = 0; u < F; ++u) {
+        const int64_t piv = node_k[u];
+        const int nchunk = piv > W + W / 2 ? (int)((piv + W - 1) / W) : 1;
+        if (nchunk < 2) continue;
+        any = true;
+        const int64_t target = (piv + nchunk - 1) / nchunk;
+        // consecutive ranges of the front's variables; the node itself keeps the last one (and its place under its parent)
+        std::vector<int32_t> vars = std::move(nodes[u].vars);
+        std::vector<int32_t> below = std::move(nodes[u].children);
+        size_t pos = 0;
+        int32_t prev = -1;
+        for (int c = 0; c < nchunk; ++c) {
+            std::vector<int32_t> mine;
+            int64_t got = 0;
+            while (pos < vars.size() && (c == nchunk - 1 || got < target)) {
+                got += g.size(vars[pos]);
+                mine.push_back(vars[pos++]);
+            }
+            if (mine.empty()) continue;
+            const bool last = pos == vars.size();
+            int32_t id = u;
+            if (!last) {
+                id = nodes.size();
+                nodes.emplace_back();
+            }
+            NdNode& nd = nodes[id];
+            nd.vars = std::move(mine);
+            nd.children.clear();
+            if (prev < 0) {
+                nd.children = below;
+                for (int32_t ch : below) nodes[ch].parent = id;
+            } else {
+                nd.children.push_back(prev);
+                nodes[prev].parent = id;
+            }
+            prev = id;
+            if (last) break;
+        }
+    }
+    return any;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -662,86 +734,107 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     NestedDissection nd{g};
     nd.run();
     amalgamate_levels(nd.nodes, g);
-    const int32_t F = nd.nodes.size();
-    nr_front = F;
+    int32_t F = 0;
+    std::vector<int32_t> post, fid, parent, height, sv_front, sv_start, own_start, kf, perm;
+    std::vector<std::vector<int32_t>> children, bnd_sv;
+    // numbering of the fronts and of the unknowns, boundaries (run once more after big fronts were cut into chains:
+    // the cut needs every front's pivot and boundary counts, and leaves the numbering of the unknowns what it was)
+    auto order_tree = [&]() {
+    F = nd.nodes.size();
 
-    // postorder: children before parents; front ids follow the postorder
-    std::vector<int32_t> post;
-    post.reserve(F);
-    {
-        std::vector<std::pair<int32_t, size_t>> st;
-        for (int32_t r = 0; r < F; ++r) {
-            if (nd.nodes[r].parent >= 0) continue;
-            st.emplace_back(r, 0);
-            while (!st.empty()) {
-                auto& [u, ci] = st.back();
-                if (ci < nd.nodes[u].children.size()) {
-                    int32_t c = nd.nodes[u].children[ci++];
-                    st.emplace_back(c, 0);
-                } else {
-                    post.push_back(u);
-                    st.pop_back();
+        // postorder: children before parents; front ids follow the postorder
+        post.clear();
+        post.reserve(F);
+        {
+            std::vector<std::pair<int32_t, size_t>> st;
+            for (int32_t r = 0; r < F; ++r) {
+                if (nd.nodes[r].parent >= 0) continue;
+                st.emplace_back(r, 0);
+                while (!st.empty()) {
+                    auto& [u, ci] = st.back();
+                    if (ci < nd.nodes[u].children.size()) {
+                        int32_t c = nd.nodes[u].children[ci++];
+                        st.emplace_back(c, 0);
+                    } else {
+                        post.push_back(u);
+                        st.pop_back();
+                    }
                 }
             }
         }
-    }
-    sanm_check((int32_t)post.size() == F, "postorder failed");
-    std::vector<int32_t> fid(F);  // nd node -> front id
-    for (int32_t i = 0; i < F; ++i) fid[post[i]] = i;
+        sanm_check((int32_t)post.size() == F, "postorder failed");
+        fid.assign(F, 0);  // nd node -> front id
+        for (int32_t i = 0; i < F; ++i) fid[post[i]] = i;
 
-    std::vector<int32_t> parent(F, -1), height(F, 0);
-    std::vector<std::vector<int32_t>> children(F);
-    for (int32_t u = 0; u < F; ++u) {
-        if (nd.nodes[u].parent >= 0) {
-            parent[fid[u]] = fid[nd.nodes[u].parent];
-            children[fid[nd.nodes[u].parent]].push_back(fid[u]);
+        parent.assign(F, -1);
+        height.assign(F, 0);
+        children.assign(F, {});
+        for (int32_t u = 0; u < F; ++u) {
+            if (nd.nodes[u].parent >= 0) {
+                parent[fid[u]] = fid[nd.nodes[u].parent];
+                children[fid[nd.nodes[u].parent]].push_back(fid[u]);
+            }
         }
-    }
-    for (int32_t f = 0; f < F; ++f) {
-        std::sort(children[f].begin(), children[f].end());
-        if (parent[f] >= 0) height[parent[f]] = std::max(height[parent[f]], height[f] + 1);
-    }
-
-    // new numbering of the unknowns; owner front of every supervariable
-    std::vector<int32_t> sv_front(g.nsv, -1), sv_start(g.nsv, 0);
-    std::vector<int32_t> own_start(F), kf(F, 0);
-    std::vector<int32_t> perm(n, -1);
-    {
-        int32_t next = 0;
         for (int32_t f = 0; f < F; ++f) {
-            own_start[f] = next;
-            // (elimination order inside a front: as the dissection left it -- an amalgamated front lists the
-            // variables of its former children first, i.e. keeps the order of the tree it came from)
-            const auto& vars = nd.nodes[post[f]].vars;
-            for (int32_t s : vars) {
-                sanm_check(sv_front[s] < 0, "supervariable assigned twice");
-                sv_front[s] = f;
-                sv_start[s] = next;
-                for (int32_t q = g.sv_ptr[s]; q < g.sv_ptr[s + 1]; ++q) perm[g.sv_members[q]] = next++;
-            }
-            kf[f] = next - own_start[f];
-            sanm_check(kf[f] > 0, "empty front");
+            std::sort(children[f].begin(), children[f].end());
+            if (parent[f] >= 0) height[parent[f]] = std::max(height[parent[f]], height[f] + 1);
         }
-        sanm_check(next == n, "ordering does not cover all unknowns");
-    }
 
-    // boundaries (in supervariables, then expanded)
-    std::vector<std::vector<int32_t>> bnd_sv(F);
-    for (int32_t f = 0; f < F; ++f) {
-        std::vector<int32_t>& b = bnd_sv[f];
-        for (int32_t s : nd.nodes[post[f]].vars)
-            for (int32_t q = g.adj_ptr[s]; q < g.adj_ptr[s + 1]; ++q) {
-                int32_t t = g.adj[q];
-                if (sv_front[t] > f) b.push_back(t);
+        // new numbering of the unknowns; owner front of every supervariable
+        sv_front.assign(g.nsv, -1);
+        sv_start.assign(g.nsv, 0);
+        own_start.assign(F, 0);
+        kf.assign(F, 0);
+        perm.assign(n, -1);
+        {
+            int32_t next = 0;
+            for (int32_t f = 0; f < F; ++f) {
+                own_start[f] = next;
+                // (elimination order inside a front: as the dissection left it -- an amalgamated front lists the
+                // variables of its former children first, i.e. keeps the order of the tree it came from)
+                const auto& vars = nd.nodes[post[f]].vars;
+                for (int32_t s : vars) {
+                    sanm_check(sv_front[s] < 0, "supervariable assigned twice");
+                    sv_front[s] = f;
+                    sv_start[s] = next;
+                    for (int32_t q = g.sv_ptr[s]; q < g.sv_ptr[s + 1]; ++q) perm[g.sv_members[q]] = next++;
+                }
+                kf[f] = next - own_start[f];
+                sanm_check(kf[f] > 0, "empty front");
             }
-        for (int32_t c : children[f])
-            for (int32_t t : bnd_sv[c])
-                if (sv_front[t] != f) b.push_back(t);
-        // order by new index so that expanded lists are ascending
-        std::sort(b.begin(), b.end(), [&](int32_t a, int32_t c2) { return sv_start[a] < sv_start[c2]; });
-        b.erase(std::unique(b.begin(), b.end()), b.end());
-        for (int32_t t : b) sanm_check(sv_front[t] > f, "boundary variable is not in an ancestor");
+            sanm_check(next == n, "ordering does not cover all unknowns");
+        }
+
+        // boundaries (in supervariables, then expanded)
+        bnd_sv.assign(F, {});
+        for (int32_t f = 0; f < F; ++f) {
+            std::vector<int32_t>& b = bnd_sv[f];
+            for (int32_t s : nd.nodes[post[f]].vars)
+                for (int32_t q = g.adj_ptr[s]; q < g.adj_ptr[s + 1]; ++q) {
+                    int32_t t = g.adj[q];
+                    if (sv_front[t] > f) b.push_back(t);
+                }
+            for (int32_t c : children[f])
+                for (int32_t t : bnd_sv[c])
+                    if (sv_front[t] != f) b.push_back(t);
+            // order by new index so that expanded lists are ascending
+            std::sort(b.begin(), b.end(), [&](int32_t a, int32_t c2) { return sv_start[a] < sv_start[c2]; });
+            b.erase(std::unique(b.begin(), b.end()), b.end());
+            for (int32_t t : b) sanm_check(sv_front[t] > f, "boundary variable is not in an ancestor");
+        }
+
+    };
+    order_tree();
+    {
+        std::vector<int32_t> node_k(F);
+        for (int32_t u = 0; u < F; ++u) node_k[u] = kf[fid[u]];
+        const std::vector<int32_t> perm_before = perm;
+        if (split_big_fronts(nd.nodes, g, node_k)) {
+            order_tree();
+            sanm_check(perm == perm_before, "cutting fronts into chains changed the elimination order");
+        }
     }
+    nr_front = F;
 
     std::vector<MfFrontDev> fr(F);
     std::vector<double> front_flops(F, 0.0);

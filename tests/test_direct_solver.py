@@ -153,6 +153,35 @@ def test_solve_kernels_for_vectors_beyond_lds(api, monkeypatch):
     test_tiny_and_diagonal(api)
 
 
+@pytest.mark.parametrize("width", ["24", "48", "96"])
+def test_big_fronts_cut_into_chains_forced(api, monkeypatch, width):
+    """fronts of more than 1536 pivots are cut into chains of ~1000-pivot fronts (multifrontal.cpp, split_big_fronts:
+    the explicit inverses of a k-pivot front cost 2 k^3 + 2 k^2 b on top of its LU); SANM_MF_SPLIT_K forces the cut
+    on the fronts of the small test systems.  Same elimination order, no more factor entries (fewer where a chunk does not touch all of the pivots after it), fewer
+    flops, more levels;
+    together with the backward kernel for long rows (bwd_wide_kernel, from 4096 rows on; SANM_MF_WIDE_MIN_M) at each
+    of its rows-per-workgroup settings.  (The host harness takes the chains, and ignores the kernel switches.)"""
+    k = 14
+    T = sp.diags([-1, 2.2, -1], [-1, 0, 1], shape=(k, k))
+    I = sp.identity(k)
+    A = sp.csr_matrix(sp.kron(sp.kron(T, I), I) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(I, I), T))
+    A = sp.csr_matrix(sp.kron(A, np.array([[1.0, 0.2, 0], [0.1, 1.0, 0.3], [0, 0.2, 1.0]])))
+    monkeypatch.setenv("SANM_MF_SPLIT_K", "0")
+    plain = _check(api, A).stats()
+    monkeypatch.setenv("SANM_MF_SPLIT_K", width)
+    for rows in ["1", "2", "4"]:
+        monkeypatch.setenv("SANM_MF_WIDE_MIN_M", "0")
+        monkeypatch.setenv("SANM_MF_WIDE_R", rows)
+        cut = _check(api, A).stats()
+    assert cut["nnz_factors"] <= plain["nnz_factors"] and cut["nr_supervar"] == plain["nr_supervar"]
+    assert cut["nr_level"] > plain["nr_level"] and cut["nr_front"] > plain["nr_front"]
+    assert cut["flops"] < plain["flops"]
+    assert cut["max_front"] <= plain["max_front"]
+    test_random_block_unsymmetric(api)
+    test_tiny_and_diagonal(api)
+    test_fem_jacobian(api, True)
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_reference_sparse_solver_case(api, seed):
     """Tensor.SparseSolver (tests/tensor.cpp:44-70): a random 8 x 8 system in [-1, 1] with one structural zero per

@@ -322,6 +322,16 @@ def test_subtree_distributed_factor_and_solve_two_ranks():
     print("2 ranks: own GF", [o / 1e9 for o in own], "top", top / 1e9, "total", total / 1e9)
 
 
+def test_subtree_distributed_solver_over_chains_of_cut_fronts():
+    """the distributed solver when the big fronts at the top of the tree were cut into chains (multifrontal.cpp,
+    split_big_fronts; SANM_MF_SPLIT_K forces the cut on this small mesh): the replicated top is then a chain of
+    single-child fronts and the cut of the tree walks down it.  Same checks as the two-rank case: the unsharded
+    solve's steps and vertices, both ranks bit for bit."""
+    res = _run_dist(2, (12, 6, 6), env_extra={"SANM_MF_SPLIT_K": "48"})
+    _check_dist(res, 2)
+    assert res[0]["st"]["nr_level"] > 6
+
+
 def test_subtree_distributed_factor_and_solve_four_ranks_with_pade():
     """the same over four ranks, Pade on (the distributed solver's results are the replicated solver's bit for bit,
     so its decisions are too: same step count as the unsharded run is asserted only through the sharded driver's
