@@ -1923,10 +1923,12 @@ public:
                 const int nfr = L.front_end - L.front_begin;
                 const int tb = (L.max_b + GT - 1) / GT, tk = (L.max_k + GT - 1) / GT;
                 const int tmax = std::max(tb, tk);
+                // (two-phase levels: the triangular products are the boundary operators, products 1 and 2 left out)
+                const int nwhich = L.two_phase ? 1 : 3;
                 SANM_LAUNCH(gemm1_kernel, dim3(tmax, tmax, 2 * nfr), dim3(256), 0, m_stream,
-                                   MF_FACTOR_ARGS(mf, L.front_begin));
-                SANM_LAUNCH(gemm2_kernel, dim3(tmax, tmax, 3 * nfr), dim3(256), 0, m_stream,
-                                   MF_FACTOR_ARGS(mf, L.front_begin));
+                                   MF_FACTOR_ARGS(mf, L.front_begin), (int)L.two_phase);
+                SANM_LAUNCH(gemm2_kernel, dim3(tmax, tmax, nwhich * nfr), dim3(256), 0, m_stream,
+                                   MF_FACTOR_ARGS(mf, L.front_begin), nwhich);
 #ifndef SANM_MF_OLD_STAGING
                 if (L.max_k >= mfk::kTallMinK && L.max_b >= mfk::kTallMinB)  // big fronts: interior of the Schur complement
                     SANM_LAUNCH(gemm2_tall_kernel, dim3(tmax, (tmax + 1) / 2, nfr), dim3(256), 0, m_stream,
@@ -1954,11 +1956,13 @@ public:
     // Level solve kernels are instantiated for R rows per wave and U preloaded 64-column chunks per row
     // with R * U == 16: U covers the level's widest row where it can, R takes what is left.
     template <int R, int U>
-    void launch_level_solve(bool fwd, const MfDev& mf, const MfSchedule::Level& L) {
+    void launch_level_solve(bool fwd, const MfDev& mf, const MfSchedule::Level& L, int phase) {
         using namespace mfk;
         const int cnt = L.front_end - L.front_begin;
-        const int rows = fwd ? L.max_m : L.max_k;
-        const size_t lds = (size_t)(fwd ? L.max_k : L.max_m) * sizeof(double);
+        // rows of the launch and entries of the staged vector, by phase (mf_kernels.h: 0 whole sweep; 1 / 2 the halves
+        // of a two-phase level)
+        const int rows = fwd ? (phase == 0 ? L.max_m : (phase == 1 ? L.max_k : L.max_b)) : L.max_k;
+        const size_t lds = (size_t)(fwd || phase == 2 ? L.max_k : L.max_m) * sizeof(double);
         const void* kern = fwd ? (const void*)fwd_level_kernel<R, U> : (const void*)bwd_level_kernel<R, U>;
         if (lds > 48 * 1024) {
             if (lds > (size_t)kSolveLdsMax)
@@ -1970,21 +1974,31 @@ public:
         const MfFrontDev* lf = mf.lfronts + L.front_begin;
         if (fwd)
             SANM_LAUNCH((fwd_level_kernel<R, U>), grid, dim3(256), lds, m_stream, lf, mf.front_store,
-                               mf.inbox_store, mf.work, mf.work2, mf.upd_dst);
+                               mf.inbox_store, mf.work, mf.work2, mf.upd_dst, phase);
         else
             SANM_LAUNCH((bwd_level_kernel<R, U>), grid, dim3(256), lds, m_stream, lf, mf.front_store, mf.work,
-                               mf.work2, mf.bnd_idx);
+                               mf.work2, mf.bnd_idx, phase);
     }
     void level_solve(bool fwd, const MfDev& mf, const MfSchedule::Level& L) {
+        if (!L.two_phase) return level_solve_phase(fwd, mf, L, 0);
+        // (Level::two_phase: pivot block and boundary block as two dependent launches)
+        level_solve_phase(fwd, mf, L, 1);
+        if (fwd ? L.max_b > 0 : true) level_solve_phase(fwd, mf, L, 2);
+    }
+    void level_solve_phase(bool fwd, const MfDev& mf, const MfSchedule::Level& L, int phase) {
         using namespace mfk;
+        if (!fwd && phase == 1 && L.max_b == 0) return;  // (no boundary: nothing to add to z)
         const char* env_lds = std::getenv("SANM_MF_LDS_MAX");  // tests force the large-front path
         const size_t lds_max = env_lds ? (size_t)std::atol(env_lds) : (size_t)kSolveLdsMax;
+        // longest row and number of rows of this launch
+        const int width = fwd ? L.max_k : (phase == 0 ? L.max_m : (phase == 1 ? L.max_b : L.max_k));
+        const int64_t rows = fwd ? (phase == 0 ? L.sum_m : (phase == 1 ? L.sum_k : L.sum_m - L.sum_k)) : L.sum_k;
         // backward sweep over fronts with long rows: the workgroup-per-rows kernel without LDS staging (mf_kernels.h,
-        // bwd_wide_kernel).  SANM_MF_WIDE_MIN_M: the front width it starts at (tests force it on small fronts;
+        // bwd_wide_kernel).  SANM_MF_WIDE_MIN_M: the row length it starts at (tests force it on small fronts;
         // huge: never); SANM_MF_WIDE_R: rows per workgroup
         const char* env_wide = std::getenv("SANM_MF_WIDE_MIN_M");
         const int wide_min_m = env_wide ? std::atoi(env_wide) : kWideMinM;
-        if (!fwd && L.max_m >= wide_min_m) {
+        if (!fwd && width >= wide_min_m) {
             const char* env_wr = std::getenv("SANM_MF_WIDE_R");
             const int env_r = env_wr ? std::atoi(env_wr) : 0;
             const int cnt = L.front_end - L.front_begin;
@@ -1993,33 +2007,32 @@ public:
             const int r = env_r ? env_r : (L.sum_k >= 2048 ? 4 : 2);
             if (r == 1)
                 SANM_LAUNCH((bwd_wide_kernel<1>), dim3(L.max_k, cnt), dim3(256), 0, m_stream, mf.lfronts + L.front_begin,
-                            mf.front_store, mf.work, mf.work2, mf.bnd_idx);
+                            mf.front_store, mf.work, mf.work2, mf.bnd_idx, phase);
             else if (r == 2)
                 SANM_LAUNCH((bwd_wide_kernel<2>), dim3((L.max_k + 1) / 2, cnt), dim3(256), 0, m_stream,
-                            mf.lfronts + L.front_begin, mf.front_store, mf.work, mf.work2, mf.bnd_idx);
+                            mf.lfronts + L.front_begin, mf.front_store, mf.work, mf.work2, mf.bnd_idx, phase);
             else
                 SANM_LAUNCH((bwd_wide_kernel<4>), dim3((L.max_k + 3) / 4, cnt), dim3(256), 0, m_stream,
-                            mf.lfronts + L.front_begin, mf.front_store, mf.work, mf.work2, mf.bnd_idx);
+                            mf.lfronts + L.front_begin, mf.front_store, mf.work, mf.work2, mf.bnd_idx, phase);
             return;
         }
-        if ((size_t)(fwd ? L.max_k : L.max_m) * sizeof(double) > lds_max) {
+        if ((size_t)(fwd || phase == 2 ? L.max_k : L.max_m) * sizeof(double) > lds_max) {
             // vectors beyond the LDS: plain mat-vec kernels on operands in HBM (bandwidth-bound levels)
             const int cnt = L.front_end - L.front_begin;
             if (fwd) {
-                SANM_LAUNCH(fwd_prep_kernel, dim3((L.max_k + 255) / 256, cnt), dim3(256), 0, m_stream, mf,
-                                   L.front_begin);
+                if (phase != 2)
+                    SANM_LAUNCH(fwd_prep_kernel, dim3((L.max_k + 255) / 256, cnt), dim3(256), 0, m_stream, mf,
+                                       L.front_begin);
                 SANM_LAUNCH(fwd_big_kernel, dim3((L.max_m + 3) / 4, cnt), dim3(256), 0, m_stream, mf,
-                                   L.front_begin);
+                                   L.front_begin, phase);
             } else {
                 SANM_LAUNCH(bwd_big_kernel, dim3((L.max_k + 3) / 4, cnt), dim3(256), 0, m_stream, mf,
-                                   L.front_begin);
+                                   L.front_begin, phase);
             }
             return;
         }
-        const int width = fwd ? L.max_k : L.max_m;  // longest row
-        const int64_t rows = fwd ? L.sum_m : L.sum_k;
         static const bool no_sub = std::getenv("SANM_MF_NO_SUB") != nullptr;
-        if (fwd && width <= 128 && !no_sub) {  // short rows: several rows per wavefront (mf_kernels.h)
+        if (fwd && phase == 0 && width <= 128 && !no_sub) {  // short rows: several rows per wavefront (mf_kernels.h)
             const int cnt = L.front_end - L.front_begin;
             const size_t lds = (size_t)L.max_k * sizeof(double);
             // 2 rows per lane group once the level has enough rows to fill the chip several times over
@@ -2046,10 +2059,10 @@ public:
         static const int env_ls_r = std::getenv("SANM_MF_LS_R") ? std::atoi(std::getenv("SANM_MF_LS_R")) : 0;
         if (env_ls_r && rows >= 8 * 2048) r = env_ls_r;
         while (r * u > 16) r /= 2;
-#define SANM_LS(R, U)                         \
-    if (r == R && u == U) {                   \
-        launch_level_solve<R, U>(fwd, mf, L); \
-        return;                               \
+#define SANM_LS(R, U)                                \
+    if (r == R && u == U) {                          \
+        launch_level_solve<R, U>(fwd, mf, L, phase); \
+        return;                                      \
     }
         SANM_LS(4, 1) SANM_LS(4, 2) SANM_LS(4, 4)
         SANM_LS(2, 1) SANM_LS(2, 2) SANM_LS(2, 4) SANM_LS(2, 8)

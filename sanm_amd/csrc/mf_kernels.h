@@ -703,7 +703,9 @@ __device__ __forceinline__ void gemm_tile_foreach(const mfma_f64x4 acc[2][2], F&
 
 // step 2:  which = 0: tmpU (k x b) = L11^-1 F[P,B]     (L11^-1 lower: K tiles 0..ti)
 //          which = 1: tmpL (b x k) = F[B,P] U11^-1     (U11^-1 upper: K tiles 0..tj)
-__global__ void __launch_bounds__(256) gemm1_kernel(MF_FACTOR_PARAMS) {
+// two_phase (Level::two_phase): the negated results are also the front's boundary operators, -U12 in the F[A,B] slot and
+// -L21 in the F[B,A] slot (gemm2_kernel then leaves its products 1 and 2 out)
+__global__ void __launch_bounds__(256) gemm1_kernel(MF_FACTOR_PARAMS, int two_phase) {
     MF_FACTOR_INIT
     const MfFrontDev f = mf.lfronts[level_begin + blockIdx.z / 2];
     const int which = blockIdx.z & 1;
@@ -729,9 +731,13 @@ __global__ void __launch_bounds__(256) gemm1_kernel(MF_FACTOR_PARAMS) {
     gemm_tile(A, B, ti, tj, 0, k1, As, Bs, acc);
     double* C = which ? tmp + (int64_t)k * b : tmp;  // tmpU: ld b ; tmpL: ld k
     const int cld = which ? k : b;
+    double* slot = const_cast<double*>(F) + (which ? (int64_t)2 * k * ld + k : (int64_t)k * ld + 2 * k);  // F[B,A] : F[A,B]
     gemm_tile_foreach(acc, [&](int i, int j, double v) {
         const int r = ti * GT + i, c = tj * GT + j;
-        if (r < rows && c < cols) C[(int64_t)r * cld + c] = v;
+        if (r < rows && c < cols) {
+            C[(int64_t)r * cld + c] = v;
+            if (two_phase) slot[(int64_t)r * ld + c] = -v;
+        }
     });
 }
 
@@ -771,10 +777,11 @@ __global__ void __launch_bounds__(256) gemm2_tall_kernel(MF_FACTOR_PARAMS) {
 // step 3:  which = 0: F[B,B] -= tmpL tmpU                        (b x b, K = k)
 //          which = 1: F[B,A]  = -tmpL L11^-1   (b x k; L11^-1 lower: K tiles tj..)
 //          which = 2: F[A,B]  = -U11^-1 tmpU   (k x b; U11^-1 upper: K tiles ti..)
-__global__ void __launch_bounds__(256) gemm2_kernel(MF_FACTOR_PARAMS) {
+//          nwhich = 1 (two-phase levels): product 0 only
+__global__ void __launch_bounds__(256) gemm2_kernel(MF_FACTOR_PARAMS, int nwhich) {
     MF_FACTOR_INIT
-    const MfFrontDev f = mf.lfronts[level_begin + blockIdx.z / 3];
-    const int which = blockIdx.z % 3;
+    const MfFrontDev f = mf.lfronts[level_begin + blockIdx.z / nwhich];
+    const int which = blockIdx.z % nwhich;
     const int k = f.k, b = f.m - f.k, ld = f.ld;
     const int rows = which == 2 ? k : b, cols = which == 1 ? k : b;
     const int ti = blockIdx.y, tj = blockIdx.x;
@@ -955,13 +962,15 @@ template <int R, int U>
 __global__ void __launch_bounds__(256) fwd_level_kernel(const MfFrontDev* __restrict__ lfronts,
                                                         const double* __restrict__ front_store, double* inbox_store,
                                                         double* work, double* work2,
-                                                        const int32_t* __restrict__ upd_dst) {
+                                                        const int32_t* __restrict__ upd_dst, int phase) {
+    // phase 0: the whole sweep, [z; upd] = [L11^-1; F[B,A]] t.  Two-phase levels (Level::two_phase: F[B,A] holds -L21):
+    // phase 1: z = L11^-1 t (rows < k), phase 2, a launch later: upd = F[B,A] z (rows >= k, the vector is z)
     const SolveArgs mf{lfronts, front_store, inbox_store, work, work2, upd_dst, nullptr};
     const MfFrontDev f = mf.lfronts[blockIdx.y];
-    const int m = f.m, k = f.k;
-    const int rb = blockIdx.x * (4 * R);
+    const int k = f.k, m = phase == 1 ? k : f.m;  // (m: end of this launch's rows)
+    const int rb = (phase == 2 ? k : 0) + blockIdx.x * (4 * R);
     if (rb >= m) return;
-    extern __shared__ double vs[];  // t = w_own + children's contributions (k entries)
+    extern __shared__ double vs[];  // t = w_own + children's contributions (k entries); phase 2: z
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const double* inbox = mf.inbox_store + f.inbox_off;
     // rows of this wave; boundary rows also pick up the children's entries and forward the sum to the parent
@@ -988,11 +997,14 @@ __global__ void __launch_bounds__(256) fwd_level_kernel(const MfFrontDev* __rest
         dst[q] = -1;
         if (r[q] >= k && r[q] < m) {
             dst[q] = mf.upd_dst[f.bnd_off + r[q] - k];
-            pre[q] = inbox_sum(inbox, f.nch, m, r[q]);
+            pre[q] = inbox_sum(inbox, f.nch, f.m, r[q]);
         }
     }
     const int kneed = min(k, rb + 4 * R);  // own rows read t[0..r] only
-    for (int c = tid; c < kneed; c += 256) vs[c] = mf.work[f.own_start + c] + inbox_sum(inbox, f.nch, m, c);
+    if (phase == 2)
+        for (int c = tid; c < k; c += 256) vs[c] = mf.work2[f.own_start + c];
+    else
+        for (int c = tid; c < kneed; c += 256) vs[c] = mf.work[f.own_start + c] + inbox_sum(inbox, f.nch, f.m, c);
     __syncthreads();
     rows_consume<R, U>(rc, rowp, cbeg, cend, cmax, lane, vs, 0, acc);
 #pragma unroll
@@ -1076,13 +1088,16 @@ __global__ void __launch_bounds__(256) fwd_level_sub_kernel(const MfFrontDev* __
 template <int R, int U>
 __global__ void __launch_bounds__(256) bwd_level_kernel(const MfFrontDev* __restrict__ lfronts,
                                                         const double* __restrict__ front_store, double* work,
-                                                        const double* __restrict__ work2,
-                                                        const int32_t* __restrict__ bnd_idx) {
-    const SolveArgs mf{lfronts, front_store, nullptr, work, const_cast<double*>(work2), nullptr, bnd_idx};
+                                                        double* work2,
+                                                        const int32_t* __restrict__ bnd_idx, int phase) {
+    // phase 0: the whole sweep, x_own = [U11^-1, F[A,B]] [z; x_bnd].  Two-phase levels (F[A,B] holds -U12):
+    // phase 1: z += F[A,B] x_bnd (in work2), phase 2, a launch later: x_own = U11^-1 z
+    const SolveArgs mf{lfronts, front_store, nullptr, work, work2, nullptr, bnd_idx};
     const MfFrontDev f = mf.lfronts[blockIdx.y];
-    const int m = f.m, k = f.k;
+    const int k = f.k, m = phase == 2 ? k : f.m;  // (m: end of this launch's columns)
     const int rb = blockIdx.x * (4 * R);
-    if (rb >= k) return;
+    if (rb >= k || (phase == 1 && f.m == k)) return;
+    const int safe = phase == 1 ? k : rb;  // a staged entry of vs (read, times zero, by lanes outside the range)
     extern __shared__ double vs[];  // [z (k) ; x_bnd (m-k)]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // row r of [U11^-1 , -U11^-1 U12] is physical row k + r: columns P (upper triangular: from r on) and,
@@ -1096,11 +1111,11 @@ __global__ void __launch_bounds__(256) bwd_level_kernel(const MfFrontDev* __rest
         r[q] = rb + wv * R + q;
         const bool live = r[q] < k;
         rowp[q] = mf.front_store + f.off + (int64_t)(k + (live ? r[q] : 0)) * f.ld;
-        cbeg[q] = r[q];
+        cbeg[q] = phase == 1 ? k : r[q];
         cend[q] = live ? m : 0;
         acc[q] = 0;
     }
-    const int c0 = rb + wv * R + lane;
+    const int c0 = (phase == 1 ? k : rb + wv * R) + lane;
     double a[U][R];
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -1112,12 +1127,12 @@ __global__ void __launch_bounds__(256) bwd_level_kernel(const MfFrontDev* __rest
             a[u][q] = ok ? v : 0.0;
         }
     const int32_t* bi = mf.bnd_idx + f.bnd_off;
-    for (int c = rb + tid; c < m; c += 256) vs[c] = c < k ? mf.work2[f.own_start + c] : mf.work[bi[c - k]];
+    for (int c = (phase == 1 ? k : rb) + tid; c < m; c += 256) vs[c] = c < k ? mf.work2[f.own_start + c] : mf.work[bi[c - k]];
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int c = c0 + 64 * u;
-        const double tv = vs[c < m ? c : rb];
+        const double tv = vs[c < m ? c : safe];
 #pragma unroll
         for (int q = 0; q < R; ++q) acc[q] = __builtin_fma(a[u][q], tv, acc[q]);
     }
@@ -1128,7 +1143,7 @@ __global__ void __launch_bounds__(256) bwd_level_kernel(const MfFrontDev* __rest
 #pragma unroll
             for (int u = 0; u < TAIL; ++u) {
                 const int cc = c + 64 * u;
-                tv[u] = vs[cc < m ? cc : rb];
+                tv[u] = vs[cc < m ? cc : safe];
 #pragma unroll
                 for (int q = 0; q < R; ++q) {
                     const bool ok = cc >= cbeg[q] && cc < cend[q];
@@ -1145,7 +1160,12 @@ __global__ void __launch_bounds__(256) bwd_level_kernel(const MfFrontDev* __rest
 #pragma unroll
     for (int q = 0; q < R; ++q) {
         const double v = wave_sum(acc[q]);
-        if (lane == 0 && r[q] < k) mf.work[f.own_start + r[q]] = v;
+        if (lane == 0 && r[q] < k) {
+            if (phase == 1)
+                mf.work2[f.own_start + r[q]] += v;
+            else
+                mf.work[f.own_start + r[q]] = v;
+        }
     }
 }
 
@@ -1177,14 +1197,14 @@ __device__ __forceinline__ double wave_dot_global(const double* __restrict__ row
     for (; c < cend; c += 64) a0 = __builtin_fma(row[c], v[c], a0);
     return wave_sum((a0 + a1) + (a2 + a3));
 }
-__global__ void __launch_bounds__(256) fwd_big_kernel(MfDev mf, int level_begin) {
+__global__ void __launch_bounds__(256) fwd_big_kernel(MfDev mf, int level_begin, int phase) {  // (phases: fwd_level_kernel)
     const MfFrontDev f = mf.lfronts[level_begin + blockIdx.y];
     const int m = f.m, k = f.k, lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= m) return;
+    if (r >= m || (phase == 1 && r >= k) || (phase == 2 && r < k)) return;
     const int pr = r < k ? r : r + k;
     const double* row = mf.front_store + f.off + (int64_t)pr * f.ld + k;
-    double acc = wave_dot_global(row, mf.work + f.own_start, 0, r < k ? r + 1 : k, lane);
+    double acc = wave_dot_global(row, (phase == 2 ? mf.work2 : mf.work) + f.own_start, 0, r < k ? r + 1 : k, lane);
     if (lane == 0) {
         if (r < k) {
             mf.work2[f.own_start + r] = acc;
@@ -1194,24 +1214,31 @@ __global__ void __launch_bounds__(256) fwd_big_kernel(MfDev mf, int level_begin)
         }
     }
 }
-__global__ void __launch_bounds__(256) bwd_big_kernel(MfDev mf, int level_begin) {
+__global__ void __launch_bounds__(256) bwd_big_kernel(MfDev mf, int level_begin, int phase) {  // (phases: bwd_level_kernel)
     const MfFrontDev f = mf.lfronts[level_begin + blockIdx.y];
     const int m = f.m, k = f.k, lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= k) return;
     const double* row = mf.front_store + f.off + (int64_t)(k + r) * f.ld;
-    double acc = wave_dot_global(row, mf.work2 + f.own_start, r, k, lane);
-    const double* rowb = row + 2 * k;
-    const int32_t* bi = mf.bnd_idx + f.bnd_off;
-    double a0 = 0, a1 = 0;
-    int c = lane;
-    for (; c + 64 < m - k; c += 128) {
-        a0 = __builtin_fma(rowb[c], mf.work[bi[c]], a0);
-        a1 = __builtin_fma(rowb[c + 64], mf.work[bi[c + 64]], a1);
+    double acc = phase == 1 ? 0.0 : wave_dot_global(row, mf.work2 + f.own_start, r, k, lane);
+    if (phase != 2) {
+        const double* rowb = row + 2 * k;
+        const int32_t* bi = mf.bnd_idx + f.bnd_off;
+        double a0 = 0, a1 = 0;
+        int c = lane;
+        for (; c + 64 < m - k; c += 128) {
+            a0 = __builtin_fma(rowb[c], mf.work[bi[c]], a0);
+            a1 = __builtin_fma(rowb[c + 64], mf.work[bi[c + 64]], a1);
+        }
+        if (c < m - k) a0 = __builtin_fma(rowb[c], mf.work[bi[c]], a0);
+        acc += wave_sum(a0 + a1);
     }
-    if (c < m - k) a0 = __builtin_fma(rowb[c], mf.work[bi[c]], a0);
-    acc += wave_sum(a0 + a1);
-    if (lane == 0) mf.work[f.own_start + r] = acc;
+    if (lane == 0) {
+        if (phase == 1)
+            mf.work2[f.own_start + r] += acc;
+        else
+            mf.work[f.own_start + r] = acc;
+    }
 }
 
 // ---- backward level kernel for fronts with long rows (round 4) --------------------------------------------------
@@ -1226,10 +1253,11 @@ __global__ void __launch_bounds__(256) bwd_big_kernel(MfDev mf, int level_begin)
 template <int R>
 __global__ void __launch_bounds__(256) bwd_wide_kernel(const MfFrontDev* __restrict__ lfronts,
                                                        const double* __restrict__ front_store, double* work,
-                                                       const double* __restrict__ work2,
-                                                       const int32_t* __restrict__ bnd_idx) {
+                                                       double* work2,
+                                                       const int32_t* __restrict__ bnd_idx, int phase) {
+    // (phases as in bwd_level_kernel: 1 = boundary columns only, added to z in work2; 2 = pivot columns only)
     const MfFrontDev f = lfronts[blockIdx.y];
-    const int m = f.m, k = f.k;
+    const int k = f.k, m = phase == 2 ? k : f.m;
     const int rb = blockIdx.x * R;
     if (rb >= k) return;
     __shared__ double part[4][R];
@@ -1246,7 +1274,7 @@ __global__ void __launch_bounds__(256) bwd_wide_kernel(const MfFrontDev* __restr
     const double* z = work2 + f.own_start;
     constexpr int TAIL = 8;
     // virtual column c of a row: physical column c (c < k: U11^-1, from the diagonal on) or c + k (boundary block)
-    for (int c = rb + 64 * wv + lane; c < m; c += 256 * TAIL) {
+    for (int c = (phase == 1 ? k : rb) + 64 * wv + lane; c < m; c += 256 * TAIL) {
         double av[TAIL][R], tv[TAIL];
 #pragma unroll
         for (int u = 0; u < TAIL; ++u) {
@@ -1272,8 +1300,13 @@ __global__ void __launch_bounds__(256) bwd_wide_kernel(const MfFrontDev* __restr
         if (lane == 0) part[wv][q] = v;
     }
     __syncthreads();
-    if (tid < R && rb + tid < k)
-        work[f.own_start + rb + tid] = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
+    if (tid < R && rb + tid < k) {
+        const double v = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
+        if (phase == 1)
+            work2[f.own_start + rb + tid] += v;
+        else
+            work[f.own_start + rb + tid] = v;
+    }
 }
 
 // ---- merged top of the tree (MfSchedule::Top) -----------------------------------------------------------

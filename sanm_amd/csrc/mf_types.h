@@ -88,6 +88,10 @@ struct MfSchedule {
         int32_t nr_panel;
         int32_t max_m, max_k, max_b;
         int64_t sum_m, sum_k;            // rows of the level's forward / backward solve
+        // Two-phase level (multifrontal.cpp): the fronts keep -L21 = -F[B,P] U11^-1 and -U12 = -L11^-1 F[P,B] in the
+        // F[B,A] / F[A,B] slots instead of the products with the pivot block's inverses (2 k^2 b flops per front not
+        // done); a solve sweep over the level is then two dependent launches (pivot block, then boundary block).
+        bool two_phase = false;
         std::vector<int32_t> panel_cnt;  // number of fronts with k > p*NB
         // extend-add rounds: round r holds the r-th child of every front of the
         // level; [begin,end) into ea_children

@@ -863,6 +863,36 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     }
     front_doubles = off;
 
+    // ---- two-phase levels (mf_types.h, Level::two_phase) -----------------------------------------------------------
+    // The boundary blocks of the solve operators, F[B,A] = -L21 L11^-1 and F[A,B] = -U11^-1 U12, cost k^2 b flops each;
+    // without them a sweep over the front is two dependent mat-vecs instead of one.  That pays where the products of a
+    // whole height of the tree (its fronts share their launches) outweigh two more launches in each of the ~2 x 20
+    // sweeps of a step: 8e9 flops, swept on the 32^3 / 40^3 / 48^3 blocks (3e9 ... 5e10: flat between 6e9 and
+    // 1.2e10) -- the upper half of a 32^3-vertex block's tree and beyond, never a BASELINE mesh
+    // (human ARAP, the largest: 11 GFLOP per factorisation in all).  SANM_MF_TWO_PHASE=1 / 0: every height / none; a
+    // value above 1: the threshold in flops.
+    std::vector<char> two_phase_h;
+    {
+        int32_t Hh = 0;
+        for (int32_t f = 0; f < F; ++f) Hh = std::max(Hh, height[f] + 1);
+        std::vector<double> h_k2b(Hh, 0.0);
+        for (int32_t f = 0; f < F; ++f) {
+            const double k = fr[f].k, bb = fr[f].m - fr[f].k;
+            h_k2b[height[f]] += 2 * k * k * bb;
+        }
+        const char* env = std::getenv("SANM_MF_TWO_PHASE");
+        two_phase_h.assign(Hh, 0);
+        const double env_v = env ? std::atof(env) : -1;  // (a value above 1: the threshold in flops, for sweeps)
+        for (int32_t h = 0; h < Hh; ++h)
+            two_phase_h[h] = env ? (env_v > 1 ? h_k2b[h] >= env_v : (env_v != 0 && h_k2b[h] > 0)) : h_k2b[h] >= 8e9;
+        for (int32_t f = 0; f < F; ++f)
+            if (two_phase_h[height[f]]) {
+                const double k = fr[f].k, bb = fr[f].m - fr[f].k;
+                front_flops[f] -= 2 * k * k * bb;
+                factor_flops -= 2 * k * k * bb;
+            }
+    }
+
     // ---- subtree-to-rank distribution (MfSchedule::Dist) ---------------------------------------------------------
     // The tree is cut from the root down: the subtree with the most factor work is replaced by its children (its
     // root joins the replicated top) until there are 4 subtrees per rank to balance with, or none can be split;
@@ -1053,6 +1083,7 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
         L.front_end = level_fronts.size();
         L.max_m = L.max_k = L.max_b = 0;
         L.sum_m = L.sum_k = 0;
+        L.two_phase = two_phase_h[height[fs[0]]] != 0;  // (a level's fronts share their height)
         size_t max_children = 0;
         for (int32_t f : fs) {
             L.max_m = std::max(L.max_m, fr[f].m);
@@ -1097,7 +1128,7 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
                 solve_elems += (int64_t)(f.m + f.k) * f.k;
                 const double k = f.k, bb = f.m - f.k;
                 fill += (int64_t)(k * k + 2 * k * bb);
-                fl += 2.0 / 3 * k * k * k + 2 * k * k * bb + 2 * k * bb * bb + 2 * k * k * (k + bb);
+                fl += 2.0 / 3 * k * k * k + 2 * k * k * bb + 2 * k * bb * bb + 2 * k * k * (k + (L.two_phase ? 0 : bb));
                 sk += f.k;
                 sb += f.m - f.k;
                 g_schur += 2 * k * bb * bb;
@@ -1105,9 +1136,9 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
             }
             const int nf = L.front_end - L.front_begin;
             std::fprintf(stderr, "mf level %d: fronts=%d max_k=%d max_m=%d max_b=%d panels=%d solve_MB=%.2f fill=%.2fM "
-                         "GF=%.2f avg_k=%.0f avg_b=%.0f schurGF=%.2f k2bGF=%.2f\n", h, nf, L.max_k, L.max_m, L.max_b,
+                         "GF=%.2f avg_k=%.0f avg_b=%.0f schurGF=%.2f k2bGF=%.2f%s\n", h, nf, L.max_k, L.max_m, L.max_b,
                          L.nr_panel, solve_elems * 8 / 1e6, fill / 1e6, fl / 1e9, (double)sk / nf, (double)sb / nf,
-                         g_schur / 1e9, g_k2b / 1e9);
+                         g_schur / 1e9, g_k2b / 1e9, L.two_phase ? " two-phase" : "");
         }
     }
 
@@ -1209,6 +1240,7 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
         auto& T = m_sched.top;
         const int32_t max_n = top_max_n;
         bool ok = max_n > 0 && !D.enabled && H >= 3 && m_sched.levels[H - 1].front_end - m_sched.levels[H - 1].front_begin == 1;
+        ok = ok && !m_sched.levels[H - 1].two_phase && !m_sched.levels[H - 2].two_phase;  // (needs the one-launch operators)
         std::vector<int32_t> tf;
         if (ok) {
             const auto& L = m_sched.levels[H - 2];

@@ -111,7 +111,7 @@ def test_singular_matrix_reports_bad_pivot(api):
     assert ds.factor(A) >= 1
 
 
-def test_grid3d_wide_separators(api):
+def _grid3d_wide_separators(api):
     """3-D 7-point stencil with unsymmetric values and the coordinate hint: the top
     separators have 200+ pivots, i.e. many 32-wide panels per front, partial last
     panels and workgroups that read panel tiles other workgroups of the same launch
@@ -129,6 +129,11 @@ def test_grid3d_wide_separators(api):
     ds = _check(api, A, coords=coords, nrhs=2)
     st = ds.stats()
     assert st["max_front"] >= 200 and st["nr_level"] >= 4
+    return st
+
+
+def test_grid3d_wide_separators(api):
+    _grid3d_wide_separators(api)
 
 
 @pytest.mark.parametrize("min_k", ["32", "96"])
@@ -178,6 +183,32 @@ def test_big_fronts_cut_into_chains_forced(api, monkeypatch, width):
     assert cut["flops"] < plain["flops"]
     assert cut["max_front"] <= plain["max_front"]
     test_random_block_unsymmetric(api)
+    test_tiny_and_diagonal(api)
+    test_fem_jacobian(api, True)
+
+
+@pytest.mark.parametrize("variant", ["staged", "wide", "beyond_lds", "chains"])
+def test_two_phase_levels_forced(api, monkeypatch, variant):
+    """heights of the tree whose boundary-operator products (2 k^2 b flops per front) outweigh two more launches per
+    sweep keep -L21 / -U12 in the F[B,A] / F[A,B] slots and are solved in two dependent launches per direction
+    (mf_types.h, Level::two_phase; the top of a 32^3 block and beyond).  SANM_MF_TWO_PHASE=1 forces every height
+    with a boundary, here through each family of level kernels: LDS-staged, the wide backward kernel, the kernels for
+    vectors beyond the LDS, and over chains of cut fronts.  (The host harness has its own solve: it only sees the
+    flop count change.)"""
+    monkeypatch.setenv("SANM_MF_TWO_PHASE", "0")
+    plain = _grid3d_wide_separators(api)
+    monkeypatch.setenv("SANM_MF_TWO_PHASE", "1")
+    if variant == "wide":
+        monkeypatch.setenv("SANM_MF_WIDE_MIN_M", "0")
+    elif variant == "beyond_lds":
+        monkeypatch.setenv("SANM_MF_LDS_MAX", "64")
+    elif variant == "chains":
+        monkeypatch.setenv("SANM_MF_SPLIT_K", "48")
+    forced = _grid3d_wide_separators(api)
+    if variant != "chains":
+        assert forced["flops"] < plain["flops"] and forced["nnz_factors"] == plain["nnz_factors"]
+    test_random_block_unsymmetric(api)
+    test_scalar_pattern_no_blocks(api)
     test_tiny_and_diagonal(api)
     test_fem_jacobian(api, True)
 
