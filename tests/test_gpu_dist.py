@@ -219,6 +219,20 @@ def test_subtree_distributed_solver_on_the_device_two_ranks_on_one_gpu():
     assert max(own) <= 0.65 * (total - top)
 
 
+def test_subtree_distributed_solver_over_chains_and_two_phase_levels_on_the_device():
+    """the same with the round-4 schedule features forced onto this mesh: fronts cut into chains (SANM_MF_SPLIT_K),
+    every height two-phase (SANM_MF_TWO_PHASE: boundary operators not multiplied out, two launches per sweep) and the
+    wide backward kernel (SANM_MF_WIDE_MIN_M) -- through mf_factor_piece / mf_solve_piece and the three exchanges.
+    The arithmetic of the solves differs from the default schedule's, so the comparison is with the golden equilibrium
+    (1e-9) and between the ranks (bit for bit), not with the default run's bits."""
+    res = _two_ranks_on_one_gpu("armadillo_small", {"SANM_DIST_SOLVER": "1", "SANM_MF_SPLIT_K": "96",
+                                                     "SANM_MF_TWO_PHASE": "1", "SANM_MF_WIDE_MIN_M": "512"})
+    for r in res:
+        assert r["steps"] == r["gold_steps"] == 2 and r["err"] < 1e-9 and r["rms"] < 1e-10
+        assert r["st"]["nr_subtree"] >= 2 and r["st"]["nr_level"] > 8
+    assert res[0]["vsum"] == res[1]["vsum"]
+
+
 def test_two_ranks_on_one_gpu_run_the_world_2_branch_of_the_sharded_hip_path():
     """World = 2 on the device.  RCCL refuses two ranks on one GPU and the test box has one, so the all-reduce goes
     through the C ABI's callback, staged through a gloo group (sanm_amd.dist.make_staged_allreduce) -- not a
