@@ -292,6 +292,123 @@ __global__ void __launch_bounds__(256) kernel(MatView A, MatView B, double* C, i
 }
 }  // namespace v3
 
+// ---------------------------------------------------------------- V4: 128 x 64 tile, K step KS (16 / 32 / 64) -----
+// half / a quarter of the barriers per flop; interior tiles only (no guards), as the product's fast path (= KS 16).
+// Round 4, 8192^2, K = 128 / 1024 / 4096: KS 16 41.7 / 67.1 / 69.4 TFLOP/s, KS 32 32.3 / 60.6 / 64.1 (fewer workgroups
+// per CU), double-buffered LDS with one barrier per step 41.7 / 64.4 / 65.9 (KS 32: 20.0 / 42.6 / 48.3): the fast path
+// as shipped is the best of them; 128 x 128 tiles 28.7 / 61.1 / 65.6.
+namespace v4 {
+constexpr int TM = 128, TN = 64;
+typedef double2 __attribute__((aligned(8))) double2_u;
+template <int KS>
+struct Stage { double2 a[KS / 4], b[KS / 8]; };
+template <int KS>
+__device__ __forceinline__ void stage_load(Stage<KS>& st, const MatView& A, const MatView& B, int ti, int tj, int kk) {
+    const int tid = threadIdx.x;
+    constexpr int APR = KS / 2;  // double2 per row of the A tile
+#pragma unroll
+    for (int s = 0; s < KS / 4; ++s) {  // A tile 128 x KS
+        const int idx = tid + 256 * s;
+        const int ar = idx / APR, ae = (idx % APR) * 2;
+        st.a[s] = *reinterpret_cast<const double2_u*>(A.p + (int64_t)(ti * TM + ar) * A.ld + kk + ae);
+    }
+#pragma unroll
+    for (int s = 0; s < KS / 8; ++s) {  // B tile KS x 64
+        const int idx = tid + 256 * s;
+        const int be = idx / 32, bc = (idx % 32) * 2;
+        st.b[s] = *reinterpret_cast<const double2_u*>(B.p + (int64_t)(kk + be) * B.ld + tj * TN + bc);
+    }
+}
+template <int KS>
+__device__ __forceinline__ void stage_store(const Stage<KS>& st, double (*As)[TM + 1], double (*Bs)[TN + 4]) {
+    const int tid = threadIdx.x;
+    constexpr int APR = KS / 2;
+#pragma unroll
+    for (int s = 0; s < KS / 4; ++s) {
+        const int idx = tid + 256 * s;
+        const int ar = idx / APR, ae = (idx % APR) * 2;
+        As[ae][ar] = st.a[s].x;
+        As[ae + 1][ar] = st.a[s].y;
+    }
+#pragma unroll
+    for (int s = 0; s < KS / 8; ++s) {
+        const int idx = tid + 256 * s;
+        const int be = idx / 32, bc = (idx % 32) * 2;
+        *reinterpret_cast<double2*>(&Bs[be][bc]) = st.b[s];
+    }
+}
+template <int KS>
+__global__ void __launch_bounds__(256) kernel(MatView A, MatView B, double* C, int ldc, int K) {
+    __shared__ double As[KS][TM + 1], Bs[KS][TN + 4];
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r0 = 64 * (wv >> 1) + (lane & 15), c0 = 32 * (wv & 1) + (lane & 15), kq = lane >> 4;
+    mfma_f64x4 acc[4][2];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = mfma_f64x4{0, 0, 0, 0};
+    Stage<KS> st;
+    stage_load<KS>(st, A, B, ti, tj, 0);
+    for (int kk = 0; kk < K; kk += KS) {
+        __syncthreads();
+        stage_store<KS>(st, As, Bs);
+        __syncthreads();
+        if (kk + KS < K) stage_load<KS>(st, A, B, ti, tj, kk + KS);
+#pragma unroll
+        for (int e = 0; e < KS; e += 4) {
+            double a[4], b[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[e + kq][r0 + 16 * i];
+            b[0] = Bs[e + kq][c0];
+            b[1] = Bs[e + kq][c0 + 16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    for (int mi = 0; mi < 4; ++mi) for (int ni = 0; ni < 2; ++ni) for (int g = 0; g < 4; ++g) {
+        const int r = ti * TM + 64 * (wv >> 1) + 16 * mi + (lane >> 4) + 4 * g, c = tj * TN + 32 * (wv & 1) + 16 * ni + (lane & 15);
+        C[(int64_t)r * ldc + c] -= acc[mi][ni][g];
+    }
+}
+// double-buffered LDS: one barrier per K step, the next step's tile stored while this one's MFMAs run
+template <int KS>
+__global__ void __launch_bounds__(256) kernel_db(MatView A, MatView B, double* C, int ldc, int K) {
+    __shared__ double As[2][KS][TM + 1], Bs[2][KS][TN + 4];
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r0 = 64 * (wv >> 1) + (lane & 15), c0 = 32 * (wv & 1) + (lane & 15), kq = lane >> 4;
+    mfma_f64x4 acc[4][2];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = mfma_f64x4{0, 0, 0, 0};
+    Stage<KS> st;
+    stage_load<KS>(st, A, B, ti, tj, 0);
+    stage_store<KS>(st, As[0], Bs[0]);
+    if (KS < K) stage_load<KS>(st, A, B, ti, tj, KS);
+    int cur = 0;
+    for (int kk = 0; kk < K; kk += KS) {
+        __syncthreads();  // buffer `cur` is complete; buffer `cur ^ 1` has been read by everyone (previous step)
+        if (kk + KS < K) stage_store<KS>(st, As[cur ^ 1], Bs[cur ^ 1]);
+        if (kk + 2 * KS < K) stage_load<KS>(st, A, B, ti, tj, kk + 2 * KS);
+#pragma unroll
+        for (int e = 0; e < KS; e += 4) {
+            double a[4], b[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[cur][e + kq][r0 + 16 * i];
+            b[0] = Bs[cur][e + kq][c0];
+            b[1] = Bs[cur][e + kq][c0 + 16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        cur ^= 1;
+    }
+    for (int mi = 0; mi < 4; ++mi) for (int ni = 0; ni < 2; ++ni) for (int g = 0; g < 4; ++g) {
+        const int r = ti * TM + 64 * (wv >> 1) + 16 * mi + (lane >> 4) + 4 * g, c = tj * TN + 32 * (wv & 1) + 16 * ni + (lane & 15);
+        C[(int64_t)r * ldc + c] -= acc[mi][ni][g];
+    }
+}
+}  // namespace v4
+
 template <class L>
 double bench(L&& launch, int reps, double flops) {
     hipEvent_t e0, e1;
@@ -309,7 +426,7 @@ double bench(L&& launch, int reps, double flops) {
 
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 8192, N = M;
-    for (int K : {128, 256, 4096}) {
+    for (int K : {128, 1024, 4096}) {
         const int ld = 8192 + 192;  // like a front: rows far apart
         std::vector<double> hA((size_t)M * K), hB((size_t)K * N), hC((size_t)M * N, 1.0);
         for (size_t i = 0; i < hA.size(); ++i) hA[i] = ((i * 2654435761u) % 1000) / 1000.0 - 0.5;
@@ -345,11 +462,19 @@ int main(int argc, char** argv) {
         reset(dC2); hipLaunchKernelGGL(v2::kernel, grid2, dim3(256), 0, 0, A, B, dC2, ld, K); check("v2");
         const dim3 grid3(N / 128, M / 128);
         reset(dC2); hipLaunchKernelGGL(v3::kernel, grid3, dim3(256), 0, 0, A, B, dC2, ld, K); check("v3");
+        reset(dC2); hipLaunchKernelGGL(v4::kernel<16>, grid2, dim3(256), 0, 0, A, B, dC2, ld, K); check("v4<16>");
+        reset(dC2); hipLaunchKernelGGL(v4::kernel<32>, grid2, dim3(256), 0, 0, A, B, dC2, ld, K); check("v4<32>");
+        reset(dC2); hipLaunchKernelGGL(v4::kernel_db<16>, grid2, dim3(256), 0, 0, A, B, dC2, ld, K); check("v4db<16>");
+        reset(dC2); hipLaunchKernelGGL(v4::kernel_db<32>, grid2, dim3(256), 0, 0, A, B, dC2, ld, K); check("v4db<32>");
         printf("  v0 (round 2)            %.1f TFLOP/s\n", bench([&] { hipLaunchKernelGGL(v0::kernel, grid, dim3(256), 0, 0, A, B, dC, ld, K); }, 5, flops));
         printf("  v1 branch-free, KS=16   %.1f TFLOP/s\n", bench([&] { hipLaunchKernelGGL(v1::kernel<16>, grid, dim3(256), 0, 0, A, B, dC2, ld, K); }, 5, flops));
         printf("  v1 branch-free, KS=32   %.1f TFLOP/s\n", bench([&] { hipLaunchKernelGGL(v1::kernel<32>, grid, dim3(256), 0, 0, A, B, dC2, ld, K); }, 5, flops));
         printf("  v3 128x128 tile         %.1f TFLOP/s\n", bench([&] { hipLaunchKernelGGL(v3::kernel, grid3, dim3(256), 0, 0, A, B, dC2, ld, K); }, 5, flops));
         printf("  v2 128x64 tile          %.1f TFLOP/s\n", bench([&] { hipLaunchKernelGGL(v2::kernel, grid2, dim3(256), 0, 0, A, B, dC2, ld, K); }, 5, flops));
+        printf("  v4 128x64 unguarded KS=16   %.1f TFLOP/s\n", bench([&] { hipLaunchKernelGGL(v4::kernel<16>, grid2, dim3(256), 0, 0, A, B, dC2, ld, K); }, 5, flops));
+        printf("  v4 128x64 unguarded KS=32   %.1f TFLOP/s\n", bench([&] { hipLaunchKernelGGL(v4::kernel<32>, grid2, dim3(256), 0, 0, A, B, dC2, ld, K); }, 5, flops));
+        printf("  v4 128x64 dbl-buf   KS=16   %.1f TFLOP/s\n", bench([&] { hipLaunchKernelGGL(v4::kernel_db<16>, grid2, dim3(256), 0, 0, A, B, dC2, ld, K); }, 5, flops));
+        printf("  v4 128x64 dbl-buf   KS=32   %.1f TFLOP/s\n", bench([&] { hipLaunchKernelGGL(v4::kernel_db<32>, grid2, dim3(256), 0, 0, A, B, dC2, ld, K); }, 5, flops));
         hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dC2);
     }
     return 0;
