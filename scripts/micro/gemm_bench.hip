@@ -426,6 +426,23 @@ double bench(L&& launch, int reps, double flops) {
 
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 8192, N = M;
+    if (argc > 5) {
+        // the product's operand layout: gemm_bench M K lda ldb ldc  (tmpL: lda = K; tmpU: ldb = N; C inside a front:
+        // ldc = N + 2 K) -- the 128 x 64 fast path only
+        const int K = atoi(argv[2]), lda = atoi(argv[3]), ldb = atoi(argv[4]), ldc = atoi(argv[5]);
+        double *dA, *dB, *dC;
+        CK(hipMalloc(&dA, (size_t)M * lda * 8));
+        CK(hipMalloc(&dB, (size_t)K * ldb * 8));
+        CK(hipMalloc(&dC, (size_t)M * ldc * 8));
+        CK(hipMemset(dA, 0, (size_t)M * lda * 8));
+        CK(hipMemset(dB, 0, (size_t)K * ldb * 8));
+        CK(hipMemset(dC, 0, (size_t)M * ldc * 8));
+        MatView A{dA, lda, M, K}, B{dB, ldb, K, N};
+        const dim3 grid2(N / 64, M / 128);
+        printf("M=N=%d K=%d lda=%d ldb=%d ldc=%d: 128x64 fast path %.1f TFLOP/s\n", M, K, lda, ldb, ldc,
+               bench([&] { hipLaunchKernelGGL(v4::kernel<16>, grid2, dim3(256), 0, 0, A, B, dC, ldc, K); }, 5, 2.0 * M * N * K));
+        return 0;
+    }
     for (int K : {128, 1024, 4096}) {
         const int ld = 8192 + 192;  // like a front: rows far apart
         std::vector<double> hA((size_t)M * K), hB((size_t)K * N), hC((size_t)M * N, 1.0);
