@@ -285,6 +285,7 @@ private:
                 for (int a = 0; a < 3; ++a)
                     for (int b = 0; b < 3; ++b) C[a][b] += c[a] * c[b];
             }
+            const double var_axis[3] = {C[0][0], C[1][1], C[2][2]};  // (C is diagonalised in place below)
             double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
             for (int sweep = 0; sweep < 30; ++sweep)
                 for (int p = 0; p < 2; ++p)
@@ -321,6 +322,24 @@ private:
                              (g.xyz[u * 3 + 2] - mean[2]) * V[2][d];
                 }
                 keys.push_back(std::move(key));
+            }
+            // A cloud with two (nearly) equal extents -- the halves of a cube, a plate -- has no principal directions
+            // in that plane: the eigenvectors come out at whatever angle the rounding of the covariance gives, and a
+            // DIAGONAL cut through a 60 x 60 x 30 half of a 60^3-vertex block has 3100 vertices where the cut across
+            // one of the long edges has 1800 (block:60: 35.3 TFLOP per factorisation where the n^6 law from block:48 /
+            // block:56 gives 19).  The coordinate axes join the candidates there -- for the big sets at the top of big
+            // trees only, where a cut decides teraflops: every set of a BASELINE mesh (at most 22 k supervariables)
+            // keeps the candidates, hence the ordering and the bits, it had.  Ties go to the principal directions
+            // (first in the list).  SANM_MF_AXIS_CUTS_MIN: the set size from which (0: never).
+            static const int64_t axis_min = std::getenv("SANM_MF_AXIS_CUTS_MIN") ? std::atoll(std::getenv("SANM_MF_AXIS_CUTS_MIN")) : 30000;
+            if (axis_min > 0 && (int64_t)ns >= axis_min) {
+                const double vmax = std::max(var_axis[0], std::max(var_axis[1], var_axis[2]));
+                for (int d = 0; d < 3; ++d) {
+                    if (!(var_axis[d] > 0.05 * vmax)) continue;
+                    std::vector<double> key(ns);
+                    for (size_t i = 0; i < ns; ++i) key[i] = g.xyz[set[i] * 3 + d];
+                    keys.push_back(std::move(key));
+                }
             }
         } else {
             // two far-apart sources s, t; key = d(s,.) - d(t,.)
