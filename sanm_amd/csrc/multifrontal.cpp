@@ -327,12 +327,14 @@ private:
             // in that plane: the eigenvectors come out at whatever angle the rounding of the covariance gives, and a
             // DIAGONAL cut through a 60 x 60 x 30 half of a 60^3-vertex block has 3100 vertices where the cut across
             // one of the long edges has 1800 (block:60: 35.3 TFLOP per factorisation where the n^6 law from block:48 /
-            // block:56 gives 19).  The coordinate axes join the candidates there -- for the big sets at the top of big
-            // trees only, where a cut decides teraflops: every set of a BASELINE mesh (at most 22 k supervariables)
-            // keeps the candidates, hence the ordering and the bits, it had.  Ties go to the principal directions
-            // (first in the list).  SANM_MF_AXIS_CUTS_MIN: the set size from which (0: never).
+            // block:56 gives 19).  The coordinate axes join the candidates -- in the trees of big problems (30 k+
+            // supervariables: there a cut decides teraflops), for sets of 1000+: every BASELINE mesh (at most 25.7 k
+            // supervariables) keeps the candidates, hence the ordering and the bits, it had.  Ties go to the principal
+            // directions (first in the list).  SANM_MF_AXIS_CUTS_MIN: the problem size from which (0: never),
+            // SANM_MF_AXIS_CUTS_SET: the set size.
             static const int64_t axis_min = std::getenv("SANM_MF_AXIS_CUTS_MIN") ? std::atoll(std::getenv("SANM_MF_AXIS_CUTS_MIN")) : 30000;
-            if (axis_min > 0 && (int64_t)ns >= axis_min) {
+            static const int64_t axis_set = std::getenv("SANM_MF_AXIS_CUTS_SET") ? std::atoll(std::getenv("SANM_MF_AXIS_CUTS_SET")) : 1000;
+            if (axis_min > 0 && (int64_t)g.nsv >= axis_min && (int64_t)ns >= axis_set) {
                 const double vmax = std::max(var_axis[0], std::max(var_axis[1], var_axis[2]));
                 for (int d = 0; d < 3; ++d) {
                     if (!(var_axis[d] > 0.05 * vmax)) continue;
