@@ -157,6 +157,17 @@ def load_workload(name):
                "boundary_thresh": 0.05, "boundary_proj_dir": [-1, 0, 0],
                "energy_model": "neohookean_c", "order": 12}
         return cfg, dfea.make_cuboid(nx, ny, nz, 0.025)
+    if name.startswith("refine:"):
+        # 'refine:<BASELINE config>:<levels>': its mesh with every tet cut into 8, `levels` times (an organic mesh at
+        # scale: refine:armadillo_small:1 = 338 k tets, :2 = 2.7 M)
+        _, base, levels = name.split(":")
+        cfg, mesh = dfea.load_named_config(base)
+        if "scale" in cfg:  # (scale before refining: setup_gravity scales a mesh object once)
+            mesh.V = mesh.V * float(cfg["scale"])
+            mesh._scaled = True
+        fine = dfea.refine_mesh(mesh, int(levels))
+        fine._scaled = True
+        return cfg, fine
     return dfea.load_named_config(name)
 
 

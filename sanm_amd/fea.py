@@ -44,6 +44,40 @@ def load_named_config(name):
     return cfg, mesh
 
 
+def refine_mesh(mesh, levels=1):
+    """Regular 1 -> 8 subdivision of every tet (edge midpoints; the inner octahedron cut along the 1-3 / 0-2 midpoint
+    diagonal), `levels` times: an organic mesh at scale from a BASELINE one (bench.py, workload `refine:<name>:<levels>`;
+    not a reference function -- the reference loads its big meshes from files that are not in the image).  Orientation
+    of the children follows the parent's."""
+    V, T = mesh.V, mesh.tets.astype(np.int64)
+    surf = np.zeros(V.shape[0], dtype=bool)
+    surf[mesh.surface_vtx] = True
+    for _ in range(levels):
+        nv = V.shape[0]
+        pairs = [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)]
+        e = np.concatenate([np.sort(T[:, list(pq)], axis=1) for pq in pairs], axis=0)
+        key = e[:, 0] * nv + e[:, 1]
+        uniq, inv = np.unique(key, return_inverse=True)
+        a, b = uniq // nv, uniq % nv
+        V = np.concatenate([V, 0.5 * (V[a] + V[b])], axis=0)
+        surf = np.concatenate([surf, surf[a] & surf[b]])  # (approximation: a midpoint of two surface vertices)
+        m = (nv + inv).reshape(6, -1).T  # per tet: midpoints of 01 02 03 12 13 23
+        m01, m02, m03, m12, m13, m23 = (m[:, i] for i in range(6))
+        v0, v1, v2, v3 = (T[:, i] for i in range(4))
+        T = np.concatenate([
+            np.stack([v0, m01, m02, m03], 1), np.stack([m01, v1, m12, m13], 1),
+            np.stack([m02, m12, v2, m23], 1), np.stack([m03, m13, m23, v3], 1),
+            np.stack([m01, m02, m03, m13], 1), np.stack([m01, m12, m02, m13], 1),
+            np.stack([m02, m03, m13, m23], 1), np.stack([m02, m12, m23, m13], 1)], axis=0)
+        # keep every child's orientation the parent's (positive signed volume stays positive)
+        d = V[T[:, 1:]] - V[T[:, :1]]
+        vol = np.einsum("ij,ij->i", np.cross(d[:, 0], d[:, 1]), d[:, 2])
+        parent_sign = np.sign(vol[: len(v0)])  # child 0 is similar to its parent
+        flip = np.sign(vol) != np.tile(parent_sign, 8)
+        T[flip] = T[flip][:, [0, 2, 1, 3]]
+    return Mesh(V, T, np.nonzero(surf)[0])
+
+
 def make_cuboid(nx, ny, nz, size):
     """TetrahedralMesh::make_cuboid, fea/tetrahedral_mesh.cpp:93-204 (5 tets / cell)."""
     ii, jj, kk = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")

@@ -134,3 +134,33 @@ def test_plain_command_two_ranks_with_the_distributed_direct_solver():
     # more collectives than the tet-sharded driver's alone: per step 1 + 1 + (order - 1) = 13 at order 12, plus two per
     # factorisation and two per solve
     assert d["roofline_families"]["collective"]["launches_per_step"] >= 0
+
+
+def test_refined_workload_mesh_is_a_conforming_subdivision():
+    """bench.py's `refine:<config>:<levels>` workloads (an organic mesh at scale: every tet of a BASELINE mesh cut into
+    8): volume conserved, every child oriented like its parent, the subdivision conforming (an interior face belongs
+    to exactly two tets, a boundary face to one, and the boundary faces are 4 x the parent's)."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from sanm_amd import fea as dfea
+
+    def faces(T):
+        f = np.concatenate([np.sort(T[:, list(c)], axis=1) for c in [(0, 1, 2), (0, 1, 3), (0, 2, 3), (1, 2, 3)]], axis=0)
+        _, cnt = np.unique(f, axis=0, return_counts=True)
+        return cnt
+
+    def volumes(m):
+        d = m.V[m.tets[:, 1:]] - m.V[m.tets[:, :1]]
+        return np.einsum("ij,ij->i", np.cross(d[:, 0], d[:, 1]), d[:, 2]) / 6
+
+    _, coarse = dfea.load_named_config("bob")
+    fine = dfea.refine_mesh(coarse, 1)
+    assert fine.nr_tet == 8 * coarse.nr_tet
+    v0, v1 = volumes(coarse), volumes(fine)
+    assert abs(v1.sum() - v0.sum()) <= 1e-12 * abs(v0.sum())
+    assert np.all(np.sign(v1) == np.tile(np.sign(v0), 8)) and np.all(np.abs(v1) > 0)
+    c0, c1 = faces(coarse.tets), faces(fine.tets)
+    assert set(np.unique(c1)) <= {1, 2}
+    assert (c1 == 1).sum() == 4 * (c0 == 1).sum()
+    twice = dfea.refine_mesh(dfea.make_cuboid(3, 3, 3, 0.1), 2)
+    assert twice.nr_tet == 64 * 5 * 8 and set(np.unique(faces(twice.tets))) <= {1, 2}
