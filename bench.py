@@ -55,6 +55,15 @@ def parse(argv=None):
                    help="N>1: one tet-sharded problem with an RCCL all-reduce of b_k per Taylor order (strong "
                         "scaling, the default: BASELINE config 4) or independent replicas (weak scaling)")
     p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL on ROCm) or gloo (CPU tests)")
+    p.add_argument("--at-scale-workload", default="auto",
+                   help="second leg of the line (`at_scale`): the same measurement on a mesh of the plausible size of the "
+                        "missing Armadillo.1; auto = refine:armadillo_small:1 (338 k tets) when the headline workload is "
+                        "the default, none otherwise; 'none' skips it")
+    p.add_argument("--at-scale-steps", type=int, default=5)
+    p.add_argument("--at-scale-warmup", type=int, default=1)
+    p.add_argument("--no-end-to-end", action="store_true",
+                   help="skip the `end_to_end` object (whole solves from solver construction to convergence: the "
+                        "reference's time_solve, fea/main.cpp:382, :418-425)")
     p.add_argument("--callback-allreduce", action="store_true",
                    help="shard mode: all-reduce through the C ABI's callback (torch.distributed) instead of the "
                         "library's own RCCL communicator")
@@ -100,6 +109,12 @@ def cpu_baseline(workload, budget_s=20.0, threads=None):
     setup_s = sum(setup.values())
     s = run.solver
     x0 = run.model.x0()
+    # the reference's own metric for this leg (fea/main.cpp:382, :418-425): construction -> convergence of the FIRST solve
+    while not s.converged() and time.perf_counter() - t0 < 20 * budget_s:
+        s.next_iter()
+    e2e = {"time_solve": time.perf_counter() - t0, "iter": int(s.get_nr_iter()), "converged": bool(s.converged()),
+           "setup_seconds": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in s.setup_profile().items()}}
+    e2e["steps_per_sec"] = e2e["iter"] / e2e["time_solve"]
     s.set_profile(1)  # clears what the constructor accumulated
     steps, t_step = 0, 0.0
     while t_step < budget_s:
@@ -124,7 +139,7 @@ def cpu_baseline(workload, budget_s=20.0, threads=None):
             "setup_seconds": {k: round(v, 2) for k, v in setup.items()},
             # the keys the reference's stats json carries (fea/main.cpp:425-431; render/gen_table_figs.py:60-66)
             "time_solve": t_step, "iter": steps, "threads": cores, "order": int(cfg.get("order", 20)),
-            "pade": not cfg.get("disable_pade", False),
+            "pade": not cfg.get("disable_pade", False), "end_to_end": e2e,
             "seconds_per_step": {k: round(prof.get(k, 0.0) / max(steps, 1), 4) for k in tags}}
 
 
@@ -298,25 +313,55 @@ def cpu_baseline_single_thread(workload, budget_s=8.0):
         return {"error": str(e)[:200]}
 
 
-def spawn_ranks(n, argv):
+def visible_gpu_count():
+    """GPUs this process could hand to its ranks, WITHOUT touching the GPU or importing torch: the entries of
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when set, else the kernel driver's topology
+    (/sys/class/kfd: the nodes with SIMDs).  None when nothing can be said (no kfd in sight: let the ranks find out)."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir(base):
+        return None
+    n = 0
+    for node in os.listdir(base):
+        try:
+            props = dict(ln.split()[:2] for ln in open(os.path.join(base, node, "properties")) if len(ln.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0 and int(props.get("gfx_target_version", "0")) > 0:
+            n += 1
+    return n
+
+
+def spawn_ranks(n, argv, dist_backend="nccl"):
     """`python bench.py --gpus N` as a plain command (no torchrun around it): this process becomes the launcher of N
     fresh rank processes, one per GPU -- the reference's scaling harness is likewise one command per thread count
-    (render/run_armadillo_exprs.sh:30-36).  The launcher makes NO GPU call and does not import torch (a process that
-    has touched the GPU must not start or replace programs on this pool); the ranks are ordinary children with
-    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, rank 0 prints the JSON line on the stdout they
-    inherit, and the launcher exits with the first non-zero child status (the other ranks are then ended by PID, so a
-    rank that died before a collective cannot leave the rest waiting for it)."""
-    import socket
+    (render/run_armadillo_exprs.sh:30-36).  The launcher itself makes no GPU call and does not import torch (it has
+    nothing to compute; what the pool forbids is REPLACING a process that has initialised the GPU by another program
+    -- fresh children like these ranks are fine either way).  The ranks are ordinary children with RANK / LOCAL_RANK /
+    WORLD_SIZE in their environment and rendezvous through a FILE store in a private temporary directory (no port to
+    pick, so no race for one: SANM_BENCH_RDZV_FILE); rank 0 prints the JSON line on the stdout they inherit, and the
+    launcher exits with the first non-zero child status (the other ranks are then ended by PID, so a rank that died
+    before or inside a collective cannot leave the rest waiting for it)."""
+    import shutil
     import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    import tempfile
+    if dist_backend == "nccl":
+        have = visible_gpu_count()
+        if have is not None and have < n:
+            print(f"bench.py launcher: --gpus {n} with the nccl (RCCL) backend needs {n} visible GPUs, this machine "
+                  f"shows {have}; nothing started", file=sys.stderr, flush=True)
+            return 2
+    tmp = tempfile.mkdtemp(prefix="sanm_bench_rdzv_")
     cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SANM_BENCH_SPAWNED="1")
+                   SANM_BENCH_RDZV_FILE=os.path.join(tmp, "store"), SANM_BENCH_SPAWNED="1")
+        for k in ("MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
         procs.append(subprocess.Popen(cmd, env=env, cwd=os.getcwd()))
     rc = 0
     try:
@@ -340,7 +385,205 @@ def spawn_ranks(n, argv):
         for p in procs:
             if p.poll() is None:
                 p.kill()
+        shutil.rmtree(tmp, ignore_errors=True)
     return rc
+
+
+def pmc_traffic(workload, order, family):
+    """HBM-side bytes per launch of a family's kernels from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE, separate passes, corrected per MI355X_MICROARCH.md) -- not collected live"""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        entries = [pmc] + list(pmc.get("workloads", {}).values())
+        for e in entries:
+            if e.get("workload") == workload and e.get("order") == order:
+                return e["families"][family]["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
+class Leg:
+    """One workload on this rank: the model, the solver (the FIRST solve timed from construction to convergence = the
+    reference's time_solve), then exactly W + K completed steps with restarts, then the family measurement."""
+
+    def __init__(self, api, workload, args, shard, dist, rank, world):
+        from sanm_amd import fea as dfea
+        self.api, self.workload, self.args, self.shard, self.dist = api, workload, args, shard, dist
+        self.rank, self.world = rank, world
+        self.cfg, mesh = load_workload(workload)
+        self.run = dfea.GravityRun(api, mesh, self.cfg, shard=shard, solver_rtol=args.solver_rtol,
+                                   solver_kind=args.solver_kind, profile=args.profile)
+        self.x0 = self.run.model.x0()
+        self.state = {"started": False, "solves": 0, "steps_per_solve": [], "cur": 0}
+        self.e2e = None
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        device_sync()
+
+    def max_over_ranks(self, v):
+        if self.dist is None:
+            return v
+        import torch
+        dev = "cuda" if self.args.dist_backend == "nccl" else "cpu"
+        tt = torch.tensor([v], dtype=torch.float64, device=dev)
+        self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    def one_step(self):
+        st, run = self.state, self.run
+        if not st["started"]:
+            run.construct()  # first step of the first solve
+            st["started"] = True
+            st["cur"] = 1
+            return
+        s = run.solver
+        if not s.converged():
+            before = s.get_nr_iter()
+            s.next_iter()
+            if s.get_nr_iter() > before:
+                st["cur"] += 1
+                return
+        # converged (the converged call only evaluates f(x0)): begin a new solve
+        st["solves"] += 1
+        st["steps_per_solve"].append(st["cur"])
+        s.restart(self.x0)
+        st["cur"] = 1
+
+    def first_solve(self):
+        """SURVEY 8(d) "Metric": ANM steps / wall time of the solve phase, from the solver's construction to convergence
+        (fea/main.cpp:382 starts the clock before the constructor, :418-425 stops it after run_anm).  Cold: the pass
+        kernels of the graph are compiled in this call unless the on-disk cache holds them."""
+        run = self.run
+        self.barrier()
+        t0 = time.perf_counter()
+        run.construct()
+        t_ctor = time.perf_counter() - t0
+        s = run.solver
+        guard = 0
+        while not s.converged() and guard < 10000:
+            s.next_iter()
+            guard += 1
+        device_sync()
+        dt = self.max_over_ranks(time.perf_counter() - t0)
+        self.state.update(started=True, cur=0)
+        it = int(s.get_nr_iter())
+        setup = s.setup_profile()
+        self.e2e = {"time_solve": dt, "iter": it, "steps_per_sec": it / dt if dt > 0 else 0.0,
+                    "converged": bool(s.converged()), "time_prep": run.time_prep, "constructor_seconds": t_ctor,
+                    "setup_seconds": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in setup.items()}}
+        self.state["steps_per_solve"].append(it)
+        self.state["solves"] += 1
+        s.restart(self.x0)  # (a completed step: the steady-state part below counts from here)
+        self.state["cur"] = 1
+        return self.e2e
+
+    def second_solve(self):
+        """the same from a second constructor on the same model with the in-process kernel cache dropped: the pass
+        kernels come from the on-disk cache, as in every later process"""
+        from sanm_amd import fea as dfea
+        lib = self.api.lib
+        if hasattr(lib, "sanm_rtc_cache_drop_memory"):
+            lib.sanm_rtc_cache_drop_memory()
+        run2 = dfea.GravityRun.__new__(dfea.GravityRun)
+        run2.__dict__.update(self.run.__dict__)  # same model, load and hyper-parameters; a solver of its own
+        run2.solver, run2.rms, run2.time_solve = None, [], 0.0
+        self.barrier()
+        t0 = time.perf_counter()
+        run2.construct()
+        s = run2.solver
+        guard = 0
+        while not s.converged() and guard < 10000:
+            s.next_iter()
+            guard += 1
+        device_sync()
+        dt = self.max_over_ranks(time.perf_counter() - t0)
+        it = int(s.get_nr_iter())
+        setup = s.setup_profile()
+        out = {"time_solve": dt, "iter": it, "steps_per_sec": it / dt if dt > 0 else 0.0,
+               "setup_seconds": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in setup.items()}}
+        del run2, s
+        return out
+
+    def timed(self, steps, warmup):
+        run, st = self.run, self.state
+        for _ in range(warmup):
+            self.one_step()
+        self.barrier()
+        t0 = time.perf_counter()
+        it0 = run.solver.get_nr_iter() if st["started"] else 0
+        if st["started"]:
+            # the K timed steps in one call (sanm_anm_run_steps: the same next_iter / restart sequence as one_step,
+            # driven from C++ like the reference's own loop, fea/main.cpp:172-190, without the interpreter in between)
+            st["solves"] += run.solver.run_steps(steps, self.x0)
+        else:
+            for _ in range(steps):
+                self.one_step()
+        self.barrier()
+        dt = time.perf_counter() - t0
+        assert run.solver.get_nr_iter() - it0 == steps
+        self.dt = self.max_over_ranks(dt)
+        self.steps, self.warmup = steps, warmup
+        self.stats = run.solver.stats()
+        # where the step goes: device-event brackets around the phases of two more steps.  Every rank runs them (the
+        # sharded solver's collectives need all ranks); rank 0 reports.
+        self.meas = measure_families(run, self.one_step, self.cfg, self.stats, self.args)
+        return self
+
+    def report(self, coll):
+        """the fields of the line that describe this leg (rank 0)"""
+        args, cfg, stats, meas, world, shard = self.args, self.cfg, self.stats, self.meas, self.world, self.shard
+        n, nnz, T = stats["nr_unknown"], stats["jacobian_nnz"], stats["nr_tet"]
+        N = int(cfg.get("order", 20))
+        ms_per_step = self.dt / self.steps * 1e3
+        fam = meas["families"]
+        dom = max((k for k in fam if fam[k]["bound"] == "hbm"), key=lambda k: fam[k]["ms_per_step"])
+        d = fam[dom]
+        whole = {"algorithmic_bytes_per_step": meas["bytes_step"],
+                 "achieved": meas["bytes_step"] / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
+                 "frac": meas["bytes_step"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        wl = self.workload
+        return {
+            "metric": metric_name(wl, cfg),
+            "value": (1 if shard else world) * self.steps / self.dt, "unit": "ANM steps/s", "n_gpus": world,
+            "steps": self.steps, "warmup": self.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong" if (shard or world == 1) else "weak", "vs_baseline": None,
+            "dtype": "f64", "backend": self.api.backend_name(),
+            # the ranks the data path's collective spans as the communication library reports them
+            # (ncclCommCount of the library communicator in the default tet-sharded mode)
+            "rccl_ranks": coll["ranks"], "collective_impl": coll["impl"],
+            "collective_ms_per_step": fam["collective"]["ms_per_step"] if "collective" in fam else 0.0,
+            "data": ("real mesh Armadillo-small.1 (stand-in for the missing Armadillo.1), rest state"
+                     if wl == "armadillo_small" else f"workload {wl}, rest state"),
+            "config": {"workload": (f"config/{wl}.json" if ":" not in wl
+                                    else f"synthetic {wl} (armadillo material, load and boundary rule)"
+                                    if not wl.startswith("refine:") else
+                                    f"{wl} (config/{wl.split(':')[1]}.json with every tet of its mesh cut into "
+                                    f"8, {wl.split(':')[2]} time(s))")
+                                   + f": {cfg['energy_model']}, order "
+                                   f"{N}, T={T}, n={n}, nnz={nnz}, pade on, sanity check on",
+                       "parallelism": ("tet-shard + all-reduce(b_k)/order" if shard else "replicas") if world > 1 else "single",
+                       "linear_solver": "jacobi-pcg" if args.solver_kind == 0 else "multifrontal-lu",
+                       "solver_stats": {k: stats[k] for k in ("factor_nnz", "factor_flops", "nr_front",
+                                                              "nr_level", "max_front")},
+                       # rank 0's share when the direct solver is distributed by subtrees (nr_subtree > 0; DESIGN 7)
+                       "dist_solver": {k: stats[k] for k in ("nr_subtree", "nr_subtree_own", "factor_flops_own",
+                                                             "factor_flops_top")},
+                       "steps_per_solve": self.state["steps_per_solve"]},
+            # the family of kernels the step spends most of its time in (HBM-bound families only; the
+            # factorisation is priced against the fp64 matrix-core peak in roofline_families)
+            "roofline": {"bound": "hbm", "kernel": d["kernels"], "family": dom, "achieved": d["achieved"],
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["achieved"] / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(wl, N, dom), "avg_launch_us": d["avg_launch_us"],
+                         "launches_per_step": d["launches_per_step"],
+                         "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
+                         "algorithmic_bytes_per_step": d["algorithmic_per_step"],
+                         "share_of_step": d["ms_per_step"] / max(meas["ms_step_measured"], 1e-9)},
+            "roofline_families": fam,
+            "roofline_whole_step": whole,
+        }
 
 
 def main(argv=None):
@@ -350,7 +593,7 @@ def main(argv=None):
         return None
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # a plain `python bench.py --gpus N`: start the N ranks ourselves (before anything touches the GPU)
-        sys.exit(spawn_ranks(args.gpus, sys.argv[1:] if argv is None else argv))
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:] if argv is None else argv, args.dist_backend))
     hook = os.environ.get("SANM_BENCH_TEST_HOOK")
     if hook:
         # tests only (tests/test_bench_multiproc.py): a module that replaces make_api / device_sync with the host
@@ -363,25 +606,32 @@ def main(argv=None):
     if world != args.gpus and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but the launcher created WORLD_SIZE={world} ranks; reporting "
               f"n_gpus={world}", file=sys.stderr, flush=True)
+    # end_to_end measures a COLD construction: the run-time compiled pass kernels go to a cache directory of this
+    # process's own (and come back from it for the `cached` figure) unless the caller chose one
+    jit_tmp = None
+    if "SANM_JIT_CACHE_DIR" not in os.environ and not os.environ.get("SANM_NO_JIT_CACHE"):
+        import tempfile
+        jit_tmp = tempfile.mkdtemp(prefix="sanm_jit_bench_")
+        os.environ["SANM_JIT_CACHE_DIR"] = jit_tmp
     dist = None
     # torch must load its HIP runtime before libsanm_hip.so pulls in the system one
     # (the other order leaves torch without visible devices)
     import torch  # noqa: F401
     if world > 1:
         import torch.distributed as dist
+        rdzv = os.environ.get("SANM_BENCH_RDZV_FILE")  # (ranks started by spawn_ranks: a file store, no port)
+        kw = dict(init_method=f"file://{rdzv}", rank=rank, world_size=world) if rdzv else {}
         if args.dist_backend == "nccl":
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), **kw)
         else:
-            dist.init_process_group(args.dist_backend)
+            dist.init_process_group(args.dist_backend, **kw)
 
-    from sanm_amd import fea as dfea
     if args.dist_backend != "nccl" and torch.cuda.device_count() > 0:
         # host-side process group with the HIP backend: ranks may share a GPU (tests on a single-GPU box)
         local_rank %= torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
     api = make_api(local_rank)
-    cfg, mesh = load_workload(args.workload)
     shard = None
     # which collective implementation the data path uses, and how many ranks IT says it spans
     coll = {"impl": "none (single rank)" if world == 1 else "none on the data path (independent replicas)",
@@ -411,129 +661,70 @@ def main(argv=None):
             coll = {"impl": f"C-ABI callback -> torch.distributed all_reduce ({dist.get_backend()})",
                     "ranks": dist.get_world_size()}
         shard = (rank, world, fn)
-    run = dfea.GravityRun(api, mesh, cfg, shard=shard, solver_rtol=args.solver_rtol,
-                          solver_kind=args.solver_kind, profile=args.profile)
-    x0 = run.model.x0()
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        device_sync()
+    # ---- headline leg: BASELINE's metric configuration -------------------------------------------------------------
+    leg = Leg(api, args.workload, args, shard, dist, rank, world)
+    e2e = None
+    if not args.no_end_to_end:
+        e2e = {"workload": args.workload,
+               "what": "one whole solve from the solver's constructor to convergence (the reference's time_solve, "
+                       "fea/main.cpp:382, :418-425; iter = get_nr_ieter); `cold`: the first constructor of the process, "
+                       "pass kernels compiled at run time unless setup_seconds.jit_source says otherwise; `cached`: a "
+                       "second constructor on the same model with the in-process kernel cache dropped (kernels from "
+                       "the on-disk cache, as in every later process)",
+               "cold": leg.first_solve()}
+    leg.timed(args.steps, args.warmup)
+    if e2e is not None:
+        e2e["cached"] = leg.second_solve()
+        c, w = e2e["cold"]["setup_seconds"], e2e["cached"]["setup_seconds"]
+        e2e["time_solve"], e2e["iter"] = e2e["cold"]["time_solve"], e2e["cold"]["iter"]
+        e2e["setup_seconds"] = {"analysis": c.get("analysis"), "tables": round(sum(
+            c.get(k, 0.0) for k in ("tet_order", "program", "remap_tables", "pattern")), 4),
+            "jit_cold": c.get("jit"), "jit_cold_source": c.get("jit_source"),
+            "jit_cached": w.get("jit"), "jit_cached_source": w.get("jit_source")}
+    out = leg.report(coll) if rank == 0 else None
+    if out is not None and e2e is not None:
+        out["end_to_end"] = e2e
 
-    # ---- continuation with restarts: exactly W + K completed steps ----------
-    state = {"started": False, "solves": 0, "steps_per_solve": []}
+    # ---- at-scale leg: the same measurement on a mesh of the plausible size of the missing Armadillo.1 -------------
+    wl2 = args.at_scale_workload
+    if wl2 == "auto":
+        wl2 = "refine:armadillo_small:1" if args.workload == "armadillo_small" else "none"
+    if wl2 and wl2 != "none":
+        # (the headline solver's device memory goes first)
+        del leg
+        import gc
+        gc.collect()
+        t0 = time.perf_counter()
+        leg2 = Leg(api, wl2, args, shard, dist, rank, world)
+        t_model = time.perf_counter() - t0
+        cold2 = leg2.first_solve() if not args.no_end_to_end else None
+        leg2.timed(args.at_scale_steps, args.at_scale_warmup)
+        if rank == 0:
+            r2 = leg2.report(coll)
+            for k in ("higher_is_better", "vs_baseline", "dtype", "backend", "n_gpus", "unit"):
+                r2.pop(k, None)
+            r2["model_build_seconds"] = t_model
+            if cold2 is not None:
+                r2["end_to_end"] = cold2
+            out["at_scale"] = r2
+        del leg2
 
-    def one_step():
-        if not state["started"]:
-            run.construct()  # first step of the first solve
-            state["started"] = True
-            state["cur"] = 1
-            return
-        s = run.solver
-        if not s.converged():
-            before = s.get_nr_iter()
-            s.next_iter()
-            if s.get_nr_iter() > before:
-                state["cur"] += 1
-                return
-        # converged (the converged call only evaluates f(x0)): begin a new solve
-        state["solves"] += 1
-        state["steps_per_solve"].append(state["cur"])
-        s.restart(x0)
-        state["cur"] = 1
-
-    for _ in range(args.warmup):
-        one_step()
-    barrier()
-    t0 = time.perf_counter()
-    it0 = run.solver.get_nr_iter() if state["started"] else 0
-    if state["started"]:
-        # the K timed steps in one call (sanm_anm_run_steps: the same next_iter / restart sequence as one_step,
-        # driven from C++ like the reference's own loop, fea/main.cpp:172-190, without the interpreter in between)
-        state["solves"] += run.solver.run_steps(args.steps, x0)
-    else:
-        for _ in range(args.steps):
-            one_step()
-    barrier()
-    dt = time.perf_counter() - t0
-    assert run.solver.get_nr_iter() - it0 == args.steps
-    if dist is not None:
-        import torch
-        dev = "cuda" if args.dist_backend == "nccl" else "cpu"
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    stats = run.solver.stats()
-    out = None
-
-    # ---- where the step goes: device-event brackets around the phases of two more steps ----------------
-    # Every rank runs them (the sharded solver's collectives need all ranks); rank 0 reports.
-    meas = measure_families(run, one_step, cfg, stats, args)
-    if rank == 0:
-        n, nnz, T = stats["nr_unknown"], stats["jacobian_nnz"], stats["nr_tet"]
-        N = int(cfg.get("order", 20))
-        ms_per_step = dt / args.steps * 1e3
-        fam = meas["families"]
-        dom = max((k for k in fam if fam[k]["bound"] == "hbm"), key=lambda k: fam[k]["ms_per_step"])
-        d = fam[dom]
-        # HBM-side bytes per launch of the dominant family's kernels from the committed PMC profile
-        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, corrected per MI355X_MICROARCH.md) --
-        # not collected live
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pmc.get("workload") == args.workload and pmc.get("order") == N:
-                traffic = pmc["families"][dom]["traffic_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
-        whole = {"algorithmic_bytes_per_step": meas["bytes_step"],
-                 "achieved": meas["bytes_step"] / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
-                 "frac": meas["bytes_step"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        out = {
-            "metric": metric_name(args.workload, cfg),
-            "value": (1 if shard else world) * args.steps / dt, "unit": "ANM steps/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong" if (shard or world == 1) else "weak", "vs_baseline": None,
-            "dtype": "f64", "backend": api.backend_name(),
-            # the ranks the data path's collective spans as the communication library reports them
-            # (ncclCommCount of the library communicator in the default tet-sharded mode)
-            "rccl_ranks": coll["ranks"], "collective_impl": coll["impl"],
-            "collective_ms_per_step": fam["collective"]["ms_per_step"] if "collective" in fam else 0.0,
-            "data": ("real mesh Armadillo-small.1 (stand-in for the missing Armadillo.1), rest state"
-                     if args.workload == "armadillo_small" else f"workload {args.workload}, rest state"),
-            "config": {"workload": (f"config/{args.workload}.json" if ":" not in args.workload
-                                    else f"synthetic {args.workload} (armadillo material, load and boundary rule)")
-                                   + f": {cfg['energy_model']}, order "
-                                   f"{N}, T={T}, n={n}, nnz={nnz}, pade on, sanity check on",
-                       "parallelism": ("tet-shard + all-reduce(b_k)/order" if shard else "replicas") if world > 1 else "single",
-                       "linear_solver": "jacobi-pcg" if args.solver_kind == 0 else "multifrontal-lu",
-                       "solver_stats": {k: stats[k] for k in ("factor_nnz", "factor_flops", "nr_front",
-                                                              "nr_level", "max_front")},
-                       # rank 0's share when the direct solver is distributed by subtrees (nr_subtree > 0)
-                       "dist_solver": {k: stats[k] for k in ("nr_subtree", "nr_subtree_own", "factor_flops_own",
-                                                             "factor_flops_top")},
-                       "steps_per_solve": state["steps_per_solve"]},
-            # the family of kernels the step spends most of its time in (HBM-bound families only; the
-            # factorisation is priced against the fp64 matrix-core peak in roofline_families)
-            "roofline": {"bound": "hbm", "kernel": d["kernels"], "family": dom, "achieved": d["achieved"],
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["achieved"] / HBM_PEAK_GBS,
-                         "traffic": traffic, "avg_launch_us": d["avg_launch_us"],
-                         "launches_per_step": d["launches_per_step"],
-                         "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
-                         "algorithmic_bytes_per_step": d["algorithmic_per_step"],
-                         "share_of_step": d["ms_per_step"] / max(meas["ms_step_measured"], 1e-9)},
-            "roofline_families": fam,
-            "roofline_whole_step": whole,
-        }
+    if out is not None:
         if not args.no_cpu_baseline and world == 1 and not args.workload.startswith("block:"):
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds, args.cpu_threads)
             cb = out["cpu_baseline"]
             cb["gpu_over_cpu"] = out["value"] / cb["value"] if cb["value"] > 0 else None
             cb["single_thread"] = cpu_baseline_single_thread(args.workload)
+            if "end_to_end" in out and cb.get("end_to_end"):
+                out["end_to_end"]["cpu"] = cb["end_to_end"]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if jit_tmp:
+        import shutil
+        shutil.rmtree(jit_tmp, ignore_errors=True)
     return out
 
 

@@ -45,6 +45,12 @@ typedef struct sanm_fea_model sanm_fea_model;       /* ElasticForceModel, fea/me
 int sanm_hip_init(int device);
 const char* sanm_hip_last_error(void);
 const char* sanm_hip_backend_name(void);
+/* Version of this interface: bumped whenever a record a caller allocates (sanm_hyper_param, sanm_anm_stats) grows or
+ * an entry point changes meaning.  A consumer compiled against this header checks
+ * sanm_hip_abi_version() == SANM_HIP_ABI_VERSION once after loading the library (adapter/anm_hip.h does), or uses
+ * the *_sized calls, which write no more than the caller's own record holds. */
+#define SANM_HIP_ABI_VERSION 5
+int sanm_hip_abi_version(void);
 
 /* ---- operator API: libsanm/oprs.h:14-103, oprs.cpp:16-102 --------------- */
 /* variables are int ids local to the graph (VarNode*, symbolic.h:222-251) */
@@ -264,6 +270,15 @@ typedef struct sanm_anm_stats {
     int64_t nr_subtree, nr_subtree_own;
 } sanm_anm_stats;
 int sanm_anm_get_stats(const sanm_anm_solver* s, sanm_anm_stats* st);
+/* the same for a caller whose sanm_anm_stats may be older (shorter) than the library's: at most st_bytes are written */
+int sanm_anm_get_stats_sized(const sanm_anm_solver* s, void* st, size_t st_bytes);
+/* Host-clock seconds of the phases of the solver's construction, in order; returns the number of phases (names /
+ * seconds may be NULL).  The reference's time_solve (fea/main.cpp:382, :418-425) runs from the solver's constructor
+ * to convergence, so these are part of its metric: "tet_order", "program" (graph -> device program), "jit" (the pass
+ * kernels of the graph: seconds; the next entry names their source -- "jit_compiled", "jit_disk_hit",
+ * "jit_memory_hit" or "jit_none" -- with the value 1), "remap_tables", "pattern" (the symbolic product
+ * remap_out J remap_in), "analysis" (ordering and symbolic factorisation of the direct solver + its device tables). */
+int sanm_anm_setup_profile(const sanm_anm_solver* s, int max_tags, const char** names, double* seconds);
 /* profile tags: returns the number of tags (or minus an error code: the call reads device events);
  * names/seconds may be NULL */
 int sanm_anm_profile(const sanm_anm_solver* s, int max_tags, const char** names, double* seconds);

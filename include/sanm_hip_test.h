@@ -23,6 +23,9 @@ int sanm_rtc_compile_check(const char* source, char* log, size_t log_cap, size_t
 /* how the code objects of the run-time compiled pass kernels were obtained in this process so far: compilations,
  * hits of the in-process cache, hits of the on-disk cache (rtc.cpp) */
 int sanm_rtc_cache_stats(int64_t* compiled, int64_t* memory_hits, int64_t* disk_hits);
+/* forget the in-process cache of code objects (the on-disk cache stays): the next solver for a known graph loads its
+ * kernels from the disk like a fresh process would (bench.py measures that as end_to_end.setup_seconds.jit_cached) */
+int sanm_rtc_cache_drop_memory(void);
 /* obtains the code object of `source` through the caches exactly like a solver under construction does; 0 = ok */
 int sanm_rtc_cache_probe(const char* source);
 

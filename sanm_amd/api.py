@@ -646,8 +646,26 @@ class _ANMSolver:
 
     def stats(self):
         st = StatsC()
-        self.api.check(self.api.lib.sanm_anm_get_stats(self.h, C.byref(st)))
+        self.api.check(self.api.lib.sanm_anm_get_stats_sized(self.h, C.byref(st), C.c_size_t(C.sizeof(st))))
         return {k: getattr(st, k) for k, _ in StatsC._fields_}
+
+    def setup_profile(self):
+        """host seconds of the constructor's phases (sanm_anm_setup_profile): {"tet_order", "program", "jit",
+        "remap_tables", "pattern", "analysis"} plus "jit_source" in {"compiled", "disk_hit", "memory_hit", "none"}"""
+        lib = self.api.lib
+        lib.sanm_anm_setup_profile.restype = C.c_int
+        n = lib.sanm_anm_setup_profile(self.h, C.c_int(0), None, None)
+        names = (C.c_char_p * max(n, 1))()
+        secs = (C.c_double * max(n, 1))()
+        n = lib.sanm_anm_setup_profile(self.h, C.c_int(n), names, secs)
+        out = {}
+        for i in range(n):
+            k = names[i].decode()
+            if k.startswith("jit_"):
+                out["jit_source"] = k[4:]
+            else:
+                out[k] = secs[i]
+        return out
 
     def profile(self):
         n = self.api.lib.sanm_anm_profile(self.h, C.c_int(0), None, None)

@@ -1,6 +1,7 @@
 #include "anm.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -194,6 +195,10 @@ class DirectSolver final : public LinearSolver {
         const auto& D = sch.dist;
         const int nl = (int)sch.levels.size();
         m_be->mf_factor_piece(mf, sch, m_pat.csr(), 0, D.cut, true);
+        // perturbed pivots: every rank counts those of its own subtrees, rank 0 also those of the replicated top (which
+        // every rank factors and would otherwise be counted `world` times: the sum must equal the single-rank count)
+        if (m_dist_status.empty()) m_dist_status = DVec{m_be, 1};
+        if (D.rank != 0) m_be->mf_factor_status(mf, m_dist_status.p());
         if (D.schur_doubles > 0) {
             // the Schur complements of all cut roots: own ones packed into the staging buffer, the rest of it zero
             m_be->zero(D.stage, (size_t)D.schur_doubles * 8);
@@ -203,8 +208,7 @@ class DirectSolver final : public LinearSolver {
         }
         m_be->mf_factor_piece(mf, sch, m_pat.csr(), D.cut, nl, false);
         // perturbed pivots anywhere decide for everybody (the refinement they switch on contains collectives)
-        if (m_dist_status.empty()) m_dist_status = DVec{m_be, 1};
-        m_be->mf_factor_status(mf, m_dist_status.p());
+        if (D.rank == 0) m_be->mf_factor_status(mf, m_dist_status.p());
         m_coll(m_dist_status.p(), 1);
         m_be->d2h_async(status, m_dist_status.p(), 8);
     }
@@ -891,6 +895,13 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
     sanm_check(remap_inp_in.out_size % 9 == 0, "remap_inp must produce a (T,3,3) tensor");
     if (hp.xcoeff_l2_penalty != 0 && hp.solver_kind != 1)
         sanm_throw(SANM_ERR_UNSUPPORTED, "xcoeff_l2_penalty (Tikhonov path) needs the direct solver (solver_kind 1)");
+    auto clk = [] { return std::chrono::steady_clock::now(); };
+    auto lap = [&](const char* name, std::chrono::steady_clock::time_point& t0) {
+        const auto t1 = clk();
+        m_setup.emplace_back(name, std::chrono::duration<double>(t1 - t0).count());
+        t0 = t1;
+    };
+    auto t_setup = clk();
     Graph g_perm;
     SparseDesc inp_perm, out_perm;
     const bool reorder = remap_out_in.out_coords.size() == (size_t)m_n * 3 &&
@@ -901,6 +912,7 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
         inp_perm = permute_rows_by_tet(remap_inp_in, order);
         out_perm = permute_inputs_by_tet(remap_out_in, order);
     }
+    lap("tet_order", t_setup);
     const Graph& g = reorder ? g_perm : g_in;
     const SparseDesc& remap_inp = reorder ? inp_perm : remap_inp_in;
     const SparseDesc& remap_out = reorder ? out_perm : remap_out_in;
@@ -920,14 +932,23 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
         te = (int64_t)(m_shard.rank + 1) * T / m_shard.world;
         sanm_check(te > tb, "more ranks than tets");
     }
+    t_setup = clk();
     m_prog = std::make_unique<Program>(be, g, out_var, te - tb, hp.order, tb, T, /*full_history=*/false);
+    lap("program", t_setup);
+    m_setup.back().second -= m_prog->jit_seconds;
+    m_setup.emplace_back("jit", m_prog->jit_seconds);
+    m_setup.emplace_back(m_prog->jit_source == 3 ? "jit_compiled" : m_prog->jit_source == 2 ? "jit_disk_hit"
+                         : m_prog->jit_source == 1 ? "jit_memory_hit" : "jit_none", 1.0);
     sanm_check(m_prog->dev().odim == 9, "the ANM solvers take a graph whose output is a batched 3x3 matrix");
     m_prog->set_remap_in(remap_inp.in_size, remap_inp.rowptr.data(), remap_inp.idx.data(),
                          remap_inp.coef.data());
     m_remap_out = std::make_unique<DeviceRows>(be, remap_out, te - tb, m_prog->Tpad(), tb, te);
+    lap("remap_tables", t_setup);
     m_pattern = std::make_unique<JacobianPattern>(be, remap_out, remap_inp, m_n, T, m_prog->Tpad(),
                                                   m_prog->dev().odim, tb, te);
+    lap("pattern", t_setup);
     construct_solver_and_vectors(remap_out.out_coords.size() == (size_t)m_n * 3 ? remap_out.out_coords.data() : nullptr);
+    lap("analysis", t_setup);
 }
 
 void AnmDriver::construct_on_vector_interpreter(const Graph& g, int out_var, const SparseDesc& remap_inp,

@@ -244,6 +244,12 @@ public:
     }
     const LinearSolver& linear_solver() const { return *m_solver; }
     const JacobianPattern& pattern() const { return *m_pattern; }
+    //! host-clock seconds of the constructor's phases, in order (what the reference's time_solve contains beside the
+    //! continuation steps, fea/main.cpp:382, :418-425): "tet_order", "program", "jit" (+ "jit_compiled" /
+    //! "jit_disk_hit" / "jit_memory_hit": 1 for the source the code object came from), "remap_tables", "pattern"
+    //! (symbolic product remap_out J remap_in), "analysis" (ordering + symbolic factorisation of the direct solver,
+    //! its device tables and the work vectors)
+    const std::vector<std::pair<std::string, double>>& setup_profile() const { return m_setup; }
     //! the per-tet program of a (T,3,3) graph; graphs on the vector interpreter have none
     Program& program() {
         if (!m_prog) sanm_throw(SANM_ERR_UNSUPPORTED, "this solver runs its graph on the vector interpreter");
@@ -322,6 +328,7 @@ protected:
     bool m_force_order1_host = false;  // an expansion taken again after perturbed pivots
     double* m_host_scalars = nullptr;  // pinned, per order: t_i, sanity excess, sanity x-dot
     std::map<std::string, double> m_profile, m_profile_cnt, m_profile_launches;
+    std::vector<std::pair<std::string, double>> m_setup;
 
     void init_xt0(const double* x_host, double t);
     void solve_expansion_coeffs();

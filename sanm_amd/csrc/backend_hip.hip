@@ -1447,7 +1447,12 @@ public:
     int specialize(const char* source) override {
         std::vector<char> code;
         std::string log;
-        if (!rtc_compile(source, code, log)) {
+        const RtcStats before = rtc_stats();
+        const bool compiled_ok = rtc_compile(source, code, log);
+        const RtcStats after = rtc_stats();
+        m_last_spec_source = after.compiled > before.compiled ? 3 : after.disk_hits > before.disk_hits ? 2
+                             : after.memory_hits > before.memory_hits ? 1 : 0;
+        if (!compiled_ok) {
             std::fprintf(stderr, "sanm_hip: run-time compilation of the pass kernels failed, using the interpreter kernels\n%s\n",
                          log.c_str());
             return -1;
@@ -1472,6 +1477,8 @@ public:
         m_spec.push_back(k);
         return (int)m_spec.size() - 1;
     }
+    int m_last_spec_source = 0;
+    int last_specialize_source() const override { return m_last_spec_source; }
     void release_specialized(int id) override {
         if (id < 0 || id >= (int)m_spec.size() || !m_spec[id].mod) return;
         (void)hipStreamSynchronize(m_stream);

@@ -118,6 +118,7 @@ int sanm_hip_init(int device) {
 }
 const char* sanm_hip_last_error(void) { return g_last_error.c_str(); }
 const char* sanm_hip_backend_name(void) { return g_backend ? g_backend->name() : "uninitialised"; }
+int sanm_hip_abi_version(void) { return SANM_HIP_ABI_VERSION; }
 
 // ---- graph ---------------------------------------------------------------
 int sanm_graph_create(sanm_graph** g) {
@@ -268,6 +269,7 @@ void sanm_direct_solver_destroy(sanm_direct_solver* s) {
 int sanm_direct_solver_factor(sanm_direct_solver* s, const double* val, int* nr_bad_pivot) {
     return guard([&] {
         Backend* be = backend();
+        sanm_check(!s->mf->schedule().dist.enabled, "plan-only handle (SANM_MF_PLAN_WORLD): factor is not offered");
         be->h2d(s->val.p(), val, s->col.size() * 8);
         int bad = be->mf_factor(s->mf->dev(), s->mf->schedule(), s->csr);
         if (nr_bad_pivot) *nr_bad_pivot = bad;
@@ -276,6 +278,7 @@ int sanm_direct_solver_factor(sanm_direct_solver* s, const double* val, int* nr_
 int sanm_direct_solver_solve(sanm_direct_solver* s, const double* b, double* x) {
     return guard([&] {
         Backend* be = backend();
+        sanm_check(!s->mf->schedule().dist.enabled, "plan-only handle (SANM_MF_PLAN_WORLD): solve is not offered");
         be->h2d(s->b.p(), b, s->csr.n * 8);
         be->mf_solve(s->mf->dev(), s->mf->schedule(), s->b.p(), s->x.p());
         be->d2h(x, s->x.p(), s->csr.n * 8);
@@ -667,6 +670,23 @@ int sanm_anm_xt_coeff(const sanm_anm_solver* s, int i, double* xt) {
 }
 int sanm_anm_has_pade(const sanm_anm_solver* s, int* flag) {
     return guard([&] { *flag = s->drv->has_pade(); });
+}
+int sanm_anm_get_stats_sized(const sanm_anm_solver* s, void* st, size_t st_bytes) {
+    // (a caller built against an older header has a shorter record: it gets the prefix it knows)
+    sanm_anm_stats full;
+    std::memset(&full, 0, sizeof full);
+    const int rc = sanm_anm_get_stats(s, &full);
+    if (rc == 0 && st) std::memcpy(st, &full, std::min(st_bytes, sizeof full));
+    return rc;
+}
+int sanm_anm_setup_profile(const sanm_anm_solver* s, int max_tags, const char** names, double* seconds) {
+    const auto& sp = s->drv->setup_profile();
+    const int k = (int)sp.size();
+    for (int i = 0; i < k && i < max_tags; ++i) {
+        if (names) names[i] = sp[i].first.c_str();
+        if (seconds) seconds[i] = sp[i].second;
+    }
+    return k;
 }
 int sanm_anm_get_stats(const sanm_anm_solver* s, sanm_anm_stats* st) {
     return guard([&] {

@@ -1,6 +1,7 @@
 #include "graph.h"
 #include "vecprog_host.h"
 
+#include <chrono>
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -623,7 +624,12 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
     // tests -- stay on the interpreter kernels.
     const char* env_min = std::getenv("SANM_JIT_MIN_T");
     const int64_t jit_min_t = env_min ? std::atoll(env_min) : 2048;
-    if (!std::getenv("SANM_NO_JIT") && T >= jit_min_t) m_dev.spec_id = be->specialize(spec_source().c_str());
+    if (!std::getenv("SANM_NO_JIT") && T >= jit_min_t) {
+        const auto t0 = std::chrono::steady_clock::now();
+        m_dev.spec_id = be->specialize(spec_source().c_str());
+        jit_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        jit_source = m_dev.spec_id >= 0 ? be->last_specialize_source() : 0;
+    }
 }
 
 std::string Program::spec_source() const {

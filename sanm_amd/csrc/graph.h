@@ -149,6 +149,10 @@ public:
     };
     const std::vector<PowFlag>& pow_flags() const { return m_pow_flags; }
     double* arena_dev() const { return m_dev.arena; }
+    //! run-time specialisation of the pass kernels (constructor): host seconds it took and where the code object came
+    //! from -- 0: not specialised, 1: the process-wide cache, 2: the on-disk cache, 3: compiled now
+    double jit_seconds = 0;
+    int jit_source = 0;
 
 private:
     Backend* m_be;

@@ -12,4 +12,5 @@ struct RtcStats {
 //! and the on-disk cache are consulted first and filled afterwards
 bool rtc_compile(const char* source, std::vector<char>& code, std::string& log, bool use_cache = true);
 RtcStats rtc_stats();
+void rtc_drop_memory_cache();
 }  // namespace sanm_hip

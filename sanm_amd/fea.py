@@ -48,10 +48,18 @@ def refine_mesh(mesh, levels=1):
     """Regular 1 -> 8 subdivision of every tet (edge midpoints; the inner octahedron cut along the 1-3 / 0-2 midpoint
     diagonal), `levels` times: an organic mesh at scale from a BASELINE one (bench.py, workload `refine:<name>:<levels>`;
     not a reference function -- the reference loads its big meshes from files that are not in the image).  Orientation
-    of the children follows the parent's."""
+    of the children follows the parent's.  The surface is carried along as FACES (the parent's faces that belong to one
+    tet only and join three of its surface vertices; each splits into four): a midpoint is a surface vertex iff its edge
+    lies in a surface face -- interior edges that join two surface vertices (thin parts) do not make one."""
     V, T = mesh.V, mesh.tets.astype(np.int64)
-    surf = np.zeros(V.shape[0], dtype=bool)
+    nv = V.shape[0]
+    surf = np.zeros(nv, dtype=bool)
     surf[mesh.surface_vtx] = True
+    faces = np.sort(np.concatenate([T[:, [1, 2, 3]], T[:, [0, 2, 3]], T[:, [0, 1, 3]], T[:, [0, 1, 2]]], axis=0), axis=1)
+    fkey = (faces[:, 0] * nv + faces[:, 1]) * nv + faces[:, 2]
+    _, first, cnt = np.unique(fkey, return_index=True, return_counts=True)
+    sf = faces[first[cnt == 1]]
+    sf = sf[surf[sf].all(axis=1)]
     for _ in range(levels):
         nv = V.shape[0]
         pairs = [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)]
@@ -60,7 +68,14 @@ def refine_mesh(mesh, levels=1):
         uniq, inv = np.unique(key, return_inverse=True)
         a, b = uniq // nv, uniq % nv
         V = np.concatenate([V, 0.5 * (V[a] + V[b])], axis=0)
-        surf = np.concatenate([surf, surf[a] & surf[b]])  # (approximation: a midpoint of two surface vertices)
+
+        def mid(p, q, nv=nv, uniq=uniq):  # midpoint vertex of the edges (p, q)
+            lo, hi = np.minimum(p, q), np.maximum(p, q)
+            return nv + np.searchsorted(uniq, lo * nv + hi)
+        fa, fb, fc = sf[:, 0], sf[:, 1], sf[:, 2]
+        mab, mbc, mac = mid(fa, fb), mid(fb, fc), mid(fa, fc)
+        sf = np.concatenate([np.stack([fa, mab, mac], 1), np.stack([fb, mab, mbc], 1), np.stack([fc, mac, mbc], 1),
+                             np.stack([mab, mbc, mac], 1)], axis=0)
         m = (nv + inv).reshape(6, -1).T  # per tet: midpoints of 01 02 03 12 13 23
         m01, m02, m03, m12, m13, m23 = (m[:, i] for i in range(6))
         v0, v1, v2, v3 = (T[:, i] for i in range(4))
@@ -75,7 +90,10 @@ def refine_mesh(mesh, levels=1):
         parent_sign = np.sign(vol[: len(v0)])  # child 0 is similar to its parent
         flip = np.sign(vol) != np.tile(parent_sign, 8)
         T[flip] = T[flip][:, [0, 2, 1, 3]]
-    return Mesh(V, T, np.nonzero(surf)[0])
+    out = np.zeros(V.shape[0], dtype=bool)
+    out[mesh.surface_vtx] = True
+    out[sf.ravel()] = True
+    return Mesh(V, T, np.nonzero(out)[0])
 
 
 def make_cuboid(nx, ny, nz, size):

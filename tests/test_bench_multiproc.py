@@ -17,7 +17,8 @@ from tests.hostsim import get_hostsim_api
 bench.make_api = lambda local_rank: get_hostsim_api()
 bench.device_sync = lambda: None
 out = bench.main(["--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "cuboid:5,3,3",
-                  "--no-cpu-baseline", "--dist-backend", "gloo"] + {extra!r})
+                  "--no-cpu-baseline", "--dist-backend", "gloo", "--at-scale-workload", "cuboid:6,3,3",
+                  "--at-scale-steps", "2"] + {extra!r})
 if os.environ["RANK"] == "0":
     assert out is not None
 else:
@@ -65,6 +66,19 @@ def _check_common(d):
     assert d["roofline"]["family"] in fam and d["roofline"]["bound"] == "hbm"
     assert abs(sum(f["share_of_step"] for f in fam.values()) - 1) < 1e-6
     assert d["roofline_whole_step"]["algorithmic_bytes_per_step"] > 0
+    # the reference's own metric (one whole solve, construction -> convergence) and the at-scale leg
+    # ride in the same line, for every N
+    e = d["end_to_end"]
+    assert e["iter"] >= 1 and e["time_solve"] > 0 and e["cold"]["converged"]
+    assert set(e["setup_seconds"]) == {"analysis", "tables", "jit_cold", "jit_cold_source", "jit_cached", "jit_cached_source"}
+    assert e["cached"]["iter"] == e["cold"]["iter"]
+    a = d["at_scale"]
+    assert a["steps"] == 2 and a["value"] > 0 and a["rccl_ranks"] == d["rccl_ranks"]
+    assert a["roofline"]["family"] in a["roofline_families"] and a["roofline"]["bound"] == "hbm"
+    assert "cuboid:6,3,3" in a["config"]["workload"] and "dist_solver" in a["config"]
+    assert a["end_to_end"]["iter"] >= 1
+    if d["config"]["parallelism"].startswith("tet-shard"):
+        assert a["config"]["parallelism"].startswith("tet-shard") and a["collective_ms_per_step"] > 0
 
 
 def test_two_rank_replicas_gloo():
@@ -94,7 +108,8 @@ def test_plain_command_with_gpus_2_starts_two_ranks_itself():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["SANM_BENCH_TEST_HOOK"] = "tests.hostsim.bench_hook"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--workload", "cuboid:5,3,3", "--no-cpu-baseline", "--dist-backend", "gloo"],
+                        "--workload", "cuboid:5,3,3", "--no-cpu-baseline", "--dist-backend", "gloo",
+                        "--at-scale-workload", "cuboid:6,3,3", "--at-scale-steps", "2"],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -125,7 +140,8 @@ def test_plain_command_two_ranks_with_the_distributed_direct_solver():
     env["SANM_BENCH_TEST_HOOK"] = "tests.hostsim.bench_hook"
     env["SANM_DIST_SOLVER"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--workload", "cuboid:10,5,5", "--no-cpu-baseline", "--dist-backend", "gloo"],
+                        "--workload", "cuboid:10,5,5", "--no-cpu-baseline", "--dist-backend", "gloo",
+                        "--at-scale-workload", "cuboid:6,3,3", "--at-scale-steps", "2"],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
@@ -162,5 +178,10 @@ def test_refined_workload_mesh_is_a_conforming_subdivision():
     c0, c1 = faces(coarse.tets), faces(fine.tets)
     assert set(np.unique(c1)) <= {1, 2}
     assert (c1 == 1).sum() == 4 * (c0 == 1).sum()
+    # the refined surface is the set of vertices of the faces that belong to one tet only (not every
+    # midpoint of two surface vertices -- interior edges join surface vertices in thin parts)
+    f = np.concatenate([np.sort(fine.tets[:, list(c)], axis=1) for c in [(0, 1, 2), (0, 1, 3), (0, 2, 3), (1, 2, 3)]], axis=0)
+    uf, cnt = np.unique(f, axis=0, return_counts=True)
+    assert set(uf[cnt == 1].ravel().tolist()) == set(np.asarray(fine.surface_vtx).tolist())
     twice = dfea.refine_mesh(dfea.make_cuboid(3, 3, 3, 0.1), 2)
     assert twice.nr_tet == 64 * 5 * 8 and set(np.unique(faces(twice.tets))) <= {1, 2}

@@ -253,7 +253,8 @@ def test_two_ranks_on_one_gpu_run_the_world_2_branch_of_the_sharded_hip_path():
     assert res[0]["vsum"] == res[1]["vsum"]
     # the launcher
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "3",
-                        "--workload", "armadillo_small", "--no-cpu-baseline", "--dist-backend", "gloo"],
+                        "--workload", "armadillo_small", "--no-cpu-baseline", "--dist-backend", "gloo",
+                        "--at-scale-workload", "none"],
                        env=base_env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
@@ -261,3 +262,7 @@ def test_two_ranks_on_one_gpu_run_the_world_2_branch_of_the_sharded_hip_path():
     assert d["config"]["parallelism"].startswith("tet-shard") and d["collective_ms_per_step"] > 0
     # warm-up = construct (step 1), step 2, converged -> restart: the first whole solve took the oracle's 2 steps
     assert d["config"]["steps_per_solve"][0] == 2, d["config"]["steps_per_solve"]
+    # ... which is what the line's end_to_end object timed from the constructor on (the reference's time_solve)
+    assert d["end_to_end"]["iter"] == 2 and d["end_to_end"]["cold"]["converged"]
+    assert d["end_to_end"]["setup_seconds"]["jit_cold_source"] in ("compiled", "disk_hit")
+    assert d["end_to_end"]["setup_seconds"]["jit_cached_source"] == "disk_hit"
