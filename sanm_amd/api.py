@@ -67,7 +67,7 @@ ENERGY = {"neohookean_i": 0, "neohookean_c": 1, "arap": 2, "stvk_stretch": 3}
 
 # every symbol include/sanm_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "sanm_hip_init", "sanm_hip_last_error", "sanm_hip_backend_name",
+    "sanm_hip_init", "sanm_hip_last_error", "sanm_hip_backend_name", "sanm_hip_abi_version",
     "sanm_hip_comm_available", "sanm_hip_comm_unique_id", "sanm_hip_comm_init", "sanm_hip_comm_destroy", "sanm_hip_comm_query",
     "sanm_graph_create", "sanm_graph_destroy", "sanm_graph_placeholder", "sanm_graph_constant", "sanm_graph_placeholder_vector", "sanm_graph_placeholder_matrix", "sanm_graph_constant_matrix", "sanm_graph_slice", "sanm_graph_concat",
     "sanm_graph_linear_combine", "sanm_graph_multiply", "sanm_graph_pow", "sanm_graph_log",
@@ -86,7 +86,7 @@ SYMBOLS = [
     "sanm_anm_update_approx", "sanm_anm_restart", "sanm_anm_run_steps", "sanm_anm_spec_source", "sanm_rtc_compile_check", "sanm_rtc_cache_stats", "sanm_rtc_cache_probe", "sanm_direct_solver_dist_plan", "sanm_anm_time_kernel", "sanm_anm_pass_timing", "sanm_anm_converged", "sanm_anm_residual_rms", "sanm_anm_get_x",
     "sanm_anm_get_t_upper", "sanm_anm_get_t_max_a", "sanm_anm_solve_a", "sanm_anm_eval",
     "sanm_anm_nr_iter", "sanm_anm_nr_xt_coeffs", "sanm_anm_xt_coeff", "sanm_anm_has_pade",
-    "sanm_anm_get_stats", "sanm_anm_profile", "sanm_anm_profile_counts", "sanm_anm_profile_launches", "sanm_anm_set_profile", "sanm_anm_debug_inject", "sanm_anm_trace", "sanm_anm_pade_diag", "sanm_anm_verbose_text", "sanm_anm_jacobian_csr",
+    "sanm_anm_get_stats", "sanm_anm_get_stats_sized", "sanm_anm_setup_profile", "sanm_rtc_cache_drop_memory", "sanm_anm_profile", "sanm_anm_profile_counts", "sanm_anm_profile_launches", "sanm_anm_set_profile", "sanm_anm_debug_inject", "sanm_anm_trace", "sanm_anm_pade_diag", "sanm_anm_verbose_text", "sanm_anm_jacobian_csr",
     "sanm_fea_model_create", "sanm_fea_model_destroy", "sanm_fea_model_nr_unknown",
     "sanm_fea_model_graph", "sanm_fea_model_output_var", "sanm_fea_model_F_var",
     "sanm_fea_model_remap_inp", "sanm_fea_model_remap_out", "sanm_fea_model_x0",
