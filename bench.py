@@ -712,12 +712,17 @@ def main(argv=None):
 
     if out is not None:
         if not args.no_cpu_baseline and world == 1 and not args.workload.startswith("block:"):
-            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds, args.cpu_threads)
-            cb = out["cpu_baseline"]
-            cb["gpu_over_cpu"] = out["value"] / cb["value"] if cb["value"] > 0 else None
-            cb["single_thread"] = cpu_baseline_single_thread(args.workload)
-            if "end_to_end" in out and cb.get("end_to_end"):
-                out["end_to_end"]["cpu"] = cb["end_to_end"]
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds, args.cpu_threads)
+                cb = out["cpu_baseline"]
+                cb["gpu_over_cpu"] = out["value"] / cb["value"] if cb["value"] > 0 else None
+                cb["single_thread"] = cpu_baseline_single_thread(args.workload)
+                if "end_to_end" in out and cb.get("end_to_end"):
+                    out["end_to_end"]["cpu"] = cb["end_to_end"]
+            except Exception as e:  # noqa: BLE001 -- a failing baseline leg must not cost the measured line
+                import traceback
+                traceback.print_exc()
+                out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -6,9 +6,10 @@
 //
 //   driver nx ny nz spacing young poisson density gx gy gz thresh px py pz order use_pade
 //
-// The graph is built HERE with sanm_graph_* (the compressible Neo-Hookean first Piola-Kirchhoff stress of
-// fea/material.cpp:72-82: P = mu F - mu F^-T + lambda log(det F) F^-T), not taken from sanm_fea_model_graph; the
-// remaps, the rest state and the load come from the fea entry points (mesh_template.h:174-219, fea/main.cpp:921-1036).
+// The graph is built HERE with sanm_graph_* -- F = (placeholder + fixed-vertex constant) Dm^-1 (fea/mesh_template.h:
+// 191-219) and the compressible Neo-Hookean first Piola-Kirchhoff stress P = mu F - mu F^-T + lambda log(det F) F^-T
+// (fea/material.cpp:72-82) --, not taken from sanm_fea_model_graph; the remaps, the rest state and the load come from
+// the fea entry points (mesh_template.h:20-161, fea/main.cpp:921-1036).
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -96,10 +97,38 @@ int main(int argc, char** argv) {
 
     // the material side, built by this program: pk1() of fea/material.cpp:72-82 with the operator API
     const double mu = young / (2 * (1 + poisson)), lambda = young * poisson / ((1 + poisson) * (1 - 2 * poisson));
+    // DeformableBody::make_forward, fea/mesh_template.h:191-219: the placeholder receives the free vertices' part of the
+    // deformed shape matrix Ds = [x1 - x0, x2 - x0, x3 - x0] through remap_inp, the fixed vertices' part is a per-tet
+    // constant, and F = Ds Dm^-1 with Dm the rest shape matrix
+    std::vector<double> bias((size_t)nt * 9), dminv((size_t)nt * 9);
+    for (int64_t e = 0; e < nt; ++e) {
+        const int32_t* t = &T[e * 4];
+        double dm[9];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) {
+                dm[r * 3 + c] = V[t[c + 1] * 3 + r] - V[t[0] * 3 + r];
+                bias[e * 9 + r * 3 + c] = (fixed[t[c + 1] * 3 + r] ? V[t[c + 1] * 3 + r] : 0.0) -
+                                          (fixed[t[0] * 3 + r] ? V[t[0] * 3 + r] : 0.0);
+            }
+        const double det = dm[0] * (dm[4] * dm[8] - dm[5] * dm[7]) - dm[1] * (dm[3] * dm[8] - dm[5] * dm[6]) +
+                           dm[2] * (dm[3] * dm[7] - dm[4] * dm[6]);
+        double* o = &dminv[e * 9];
+        o[0] = (dm[4] * dm[8] - dm[5] * dm[7]) / det, o[1] = (dm[2] * dm[7] - dm[1] * dm[8]) / det, o[2] = (dm[1] * dm[5] - dm[2] * dm[4]) / det;
+        o[3] = (dm[5] * dm[6] - dm[3] * dm[8]) / det, o[4] = (dm[0] * dm[8] - dm[2] * dm[6]) / det, o[5] = (dm[2] * dm[3] - dm[0] * dm[5]) / det;
+        o[6] = (dm[3] * dm[7] - dm[4] * dm[6]) / det, o[7] = (dm[1] * dm[6] - dm[0] * dm[7]) / det, o[8] = (dm[0] * dm[4] - dm[1] * dm[3]) / det;
+    }
     sanm_graph* gr = nullptr;
     CHECK(sanm_graph_create(&gr));
-    int F, Finv, FTinv, J, logJ, lF, P;
-    CHECK(sanm_graph_placeholder(gr, &F));
+    int X, Cb, Ds, Cd, F, Finv, FTinv, J, logJ, lF, P;
+    CHECK(sanm_graph_placeholder(gr, &X));
+    CHECK(sanm_graph_constant(gr, bias.data(), nt, 9, &Cb));
+    {
+        const double one[2] = {1.0, 1.0};
+        const int v[2] = {X, Cb};
+        CHECK(sanm_graph_linear_combine(gr, 2, one, v, 0.0, &Ds));
+    }
+    CHECK(sanm_graph_constant(gr, dminv.data(), nt, 9, &Cd));
+    CHECK(sanm_graph_batched_matmul(gr, Ds, Cd, &F));
     CHECK(sanm_graph_batched_mat_inv_mul(gr, F, -1, 1, &Finv));
     CHECK(sanm_graph_batched_transpose(gr, Finv, &FTinv));
     CHECK(sanm_graph_batched_det(gr, F, &J));

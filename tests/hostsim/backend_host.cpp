@@ -493,3 +493,4 @@ extern "C" int sanm_rtc_cache_stats(int64_t* compiled, int64_t* memory_hits, int
     return 0;
 }
 extern "C" int sanm_rtc_cache_probe(const char*) { return 2; }
+extern "C" int sanm_rtc_cache_drop_memory(void) { return 0; }
