@@ -23,6 +23,18 @@ int sanm_rtc_compile_check(const char* source, char* log, size_t log_cap, size_t
 /* how the code objects of the run-time compiled pass kernels were obtained in this process so far: compilations,
  * hits of the in-process cache, hits of the on-disk cache (rtc.cpp) */
 int sanm_rtc_cache_stats(int64_t* compiled, int64_t* memory_hits, int64_t* disk_hits);
+/* Code objects built ahead of time (sanm_amd/build.py).  The source of the pass kernels depends on the structure of
+ * the graph and on the order only -- not on the mesh or the material --, so the build compiles the sources of the fea
+ * models' own graphs (fea/material.cpp:20-115 through fea/mesh_template.h:174-219) at the usual orders and embeds the
+ * code objects in the library; a solver whose generated source matches one takes it from there (setup profile:
+ * "jit_embedded").  sanm_fea_spec_source: that source, from a one-cell mesh, no device needed;
+ * sanm_rtc_source_key: the key a source is looked up under (33 bytes incl. the terminator);
+ * sanm_rtc_compile_to_file: compile without any cache and write the code object; sanm_rtc_embedded_hits: how many
+ * solvers of this process were served from the embedded set. */
+int64_t sanm_fea_spec_source(int energy_model, int inverse, int order, char* buf, int64_t cap);
+int sanm_rtc_source_key(const char* source, char* key33);
+int sanm_rtc_compile_to_file(const char* source, const char* path, char* log, size_t log_cap);
+int sanm_rtc_embedded_hits(int64_t* hits);
 /* forget the in-process cache of code objects (the on-disk cache stays): the next solver for a known graph loads its
  * kernels from the disk like a fresh process would (bench.py measures that as end_to_end.setup_seconds.jit_cached) */
 int sanm_rtc_cache_drop_memory(void);

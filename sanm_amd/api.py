@@ -86,7 +86,7 @@ SYMBOLS = [
     "sanm_anm_update_approx", "sanm_anm_restart", "sanm_anm_run_steps", "sanm_anm_spec_source", "sanm_rtc_compile_check", "sanm_rtc_cache_stats", "sanm_rtc_cache_probe", "sanm_direct_solver_dist_plan", "sanm_anm_time_kernel", "sanm_anm_pass_timing", "sanm_anm_converged", "sanm_anm_residual_rms", "sanm_anm_get_x",
     "sanm_anm_get_t_upper", "sanm_anm_get_t_max_a", "sanm_anm_solve_a", "sanm_anm_eval",
     "sanm_anm_nr_iter", "sanm_anm_nr_xt_coeffs", "sanm_anm_xt_coeff", "sanm_anm_has_pade",
-    "sanm_anm_get_stats", "sanm_anm_get_stats_sized", "sanm_anm_setup_profile", "sanm_rtc_cache_drop_memory", "sanm_anm_profile", "sanm_anm_profile_counts", "sanm_anm_profile_launches", "sanm_anm_set_profile", "sanm_anm_debug_inject", "sanm_anm_trace", "sanm_anm_pade_diag", "sanm_anm_verbose_text", "sanm_anm_jacobian_csr",
+    "sanm_anm_get_stats", "sanm_anm_get_stats_sized", "sanm_anm_setup_profile", "sanm_rtc_cache_drop_memory", "sanm_fea_spec_source", "sanm_rtc_source_key", "sanm_rtc_compile_to_file", "sanm_rtc_embedded_hits", "sanm_anm_profile", "sanm_anm_profile_counts", "sanm_anm_profile_launches", "sanm_anm_set_profile", "sanm_anm_debug_inject", "sanm_anm_trace", "sanm_anm_pade_diag", "sanm_anm_verbose_text", "sanm_anm_jacobian_csr",
     "sanm_fea_model_create", "sanm_fea_model_destroy", "sanm_fea_model_nr_unknown",
     "sanm_fea_model_graph", "sanm_fea_model_output_var", "sanm_fea_model_F_var",
     "sanm_fea_model_remap_inp", "sanm_fea_model_remap_out", "sanm_fea_model_x0",
@@ -651,7 +651,7 @@ class _ANMSolver:
 
     def setup_profile(self):
         """host seconds of the constructor's phases (sanm_anm_setup_profile): {"tet_order", "program", "jit",
-        "remap_tables", "pattern", "analysis"} plus "jit_source" in {"compiled", "disk_hit", "memory_hit", "none"}"""
+        "remap_tables", "pattern", "analysis"} plus "jit_source" in {"embedded", "compiled", "disk_hit", "memory_hit", "none"}"""
         lib = self.api.lib
         lib.sanm_anm_setup_profile.restype = C.c_int
         n = lib.sanm_anm_setup_profile(self.h, C.c_int(0), None, None)

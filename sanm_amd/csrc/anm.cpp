@@ -937,7 +937,7 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
     lap("program", t_setup);
     m_setup.back().second -= m_prog->jit_seconds;
     m_setup.emplace_back("jit", m_prog->jit_seconds);
-    m_setup.emplace_back(m_prog->jit_source == 3 ? "jit_compiled" : m_prog->jit_source == 2 ? "jit_disk_hit"
+    m_setup.emplace_back(m_prog->jit_source == 4 ? "jit_embedded" : m_prog->jit_source == 3 ? "jit_compiled" : m_prog->jit_source == 2 ? "jit_disk_hit"
                          : m_prog->jit_source == 1 ? "jit_memory_hit" : "jit_none", 1.0);
     sanm_check(m_prog->dev().odim == 9, "the ANM solvers take a graph whose output is a batched 3x3 matrix");
     m_prog->set_remap_in(remap_inp.in_size, remap_inp.rowptr.data(), remap_inp.idx.data(),

@@ -151,7 +151,7 @@ public:
     virtual int specialize(const char* source) { (void)source; return -1; }
     virtual void release_specialized(int id) { (void)id; }
     //! where the code object of the last successful specialize() came from: 1 the process-wide cache, 2 the on-disk
-    //! cache, 3 a compilation (0: unknown)
+    //! cache, 3 a compilation, 4 the code objects built ahead of time into the library (0: unknown)
     virtual int last_specialize_source() const { return 0; }
     //! remap_out apply (SparseLinearDesc::apply, libsanm/anm.cpp:55-75)
     //! dst = R * src; with `perm`, additionally dst2[perm[i]] = dst[i] (the right-hand side where the direct

@@ -1450,8 +1450,8 @@ public:
         const RtcStats before = rtc_stats();
         const bool compiled_ok = rtc_compile(source, code, log);
         const RtcStats after = rtc_stats();
-        m_last_spec_source = after.compiled > before.compiled ? 3 : after.disk_hits > before.disk_hits ? 2
-                             : after.memory_hits > before.memory_hits ? 1 : 0;
+        m_last_spec_source = after.embedded_hits > before.embedded_hits ? 4 : after.compiled > before.compiled ? 3
+                             : after.disk_hits > before.disk_hits ? 2 : after.memory_hits > before.memory_hits ? 1 : 0;
         if (!compiled_ok) {
             std::fprintf(stderr, "sanm_hip: run-time compilation of the pass kernels failed, using the interpreter kernels\n%s\n",
                          log.c_str());
@@ -1494,11 +1494,12 @@ public:
             const uint32_t* rin_idx;
             const double* rin_coef;
             const double* xvec;
-            long long T;
+            const double* lc_params;
+            long long T, Tpad;
             int order, max_order, rin_nslot;
         };
         struct Args4 {  // ... and what spec_pass4 takes behind them
-            Args a;  // (56 bytes with its tail padding: the first pointer behind it is 8-aligned in the kernel's list too)
+            Args a;  // (72 bytes with its tail padding: the first pointer behind it is 8-aligned in the kernel's list too)
             const double* nc_xg;
             const double* nc_num;
             double nc_scale;
@@ -1515,10 +1516,11 @@ public:
             double* g_host;
             unsigned own, nc_blocks, rd_nblk;
         };
-        static_assert(offsetof(Args4, nc_xg) == 56, "kernel argument layout");
+        static_assert(offsetof(Args4, nc_xg) == 72, "kernel argument layout");
         const unsigned own = nblk(P.T, 64);
         Args4 a4{};
-        a4.a = Args{P.arena, P.rin.idx, P.rin.coef, xvec, (long long)P.T, order, P.max_order, P.rin.nslot};
+        a4.a = Args{P.arena, P.rin.idx, P.rin.coef, xvec, P.lc_params, (long long)P.T, (long long)P.Tpad, order, P.max_order,
+                    P.rin.nslot};
         a4.own = own;
         unsigned extra = 0;
         if (nc) {

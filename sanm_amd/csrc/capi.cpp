@@ -588,6 +588,36 @@ int sanm_anm_restart(sanm_anm_solver* s, const double* x0) {
         s->eqn->restart(x0);
     });
 }
+// The HIP source of the pass kernels of an fea model's graph at `order` -- it depends on the structure of the graph
+// and on the order only (graph.cpp: Program::spec_source), so it is produced here from a one-cell mesh, without a
+// device: sanm_amd/build.py compiles these sources ahead of time and embeds the code objects in the library.
+int64_t sanm_fea_spec_source(int energy_model, int inverse, int order, char* buf, int64_t cap) {
+    int64_t len = -1;
+    guard([&] {
+        // one cell of TetrahedralMesh::make_cuboid (fea/tetrahedral_mesh.cpp:93-204)
+        const double V[24] = {0, 0, 0, 0, 0, 1, 0, 1, 0, 0, 1, 1, 1, 0, 0, 1, 0, 1, 1, 1, 0, 1, 1, 1};
+        // (vertex (x, y, z) at index (x * 2 + y) * 2 + z; the cell's corners h0..h7 in make_cuboid's order)
+        const int32_t h[8] = {0, 4, 6, 2, 1, 5, 7, 3};
+        const int pat[5][4] = {{0, 2, 1, 5}, {0, 4, 7, 5}, {0, 2, 5, 7}, {2, 6, 5, 7}, {0, 7, 3, 2}};
+        int32_t tets[20];
+        for (int t = 0; t < 5; ++t)
+            for (int q = 0; q < 4; ++q) tets[t * 4 + q] = h[pat[t][q]];
+        uint8_t fixed[24] = {1, 1, 1};
+        ElasticForceModel m;
+        const Material mat = Material::from_young_poisson(1.0, 0.3);
+        if (inverse) make_inverse(m, 8, V, 5, tets, fixed, (EnergyModel)energy_model, mat);
+        else make_forward(m, 8, V, 5, tets, fixed, (EnergyModel)energy_model, mat, nullptr, nullptr);
+        Program prog(nullptr, m.graph, m.y, 5, order, 0, 5, /*full_history=*/false);
+        const std::string src = prog.spec_source();
+        len = src.size();
+        if (buf && cap > 0) {
+            const int64_t n = std::min<int64_t>(len, cap - 1);
+            std::memcpy(buf, src.data(), n);
+            buf[n] = 0;
+        }
+    });
+    return len;
+}
 int64_t sanm_anm_spec_source(sanm_anm_solver* s, char* buf, int64_t cap) {
     int64_t len = -1;
     guard([&] {

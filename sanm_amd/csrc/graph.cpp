@@ -507,7 +507,8 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
                 if (op.exponent != 2.0) {
                     // one double shared by all tets: set when an order-0 value is a zero (|x| < 1e-3) that the power
                     // recurrence cannot divide by (analytic_unary.cpp:43, :112-131; Program::pow_flags)
-                    if (m_pow_flags.empty()) m_pow_flag_off = take(64);
+                    // (a whole [Tpad] plane: every region of the arena is a multiple of Tpad, Program::spec_source)
+                    if (m_pow_flags.empty()) m_pow_flag_off = take(Tpad);
                     o.aux[2] = m_pow_flag_off;
                     m_pow_flags.push_back({o.aux[2], op.exponent});
                 }
@@ -571,6 +572,21 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
     }
     m_arena_doubles = off;
 
+    if (!be) {
+        // layout only (no device): what Program::spec_source needs -- the build uses it to compile the pass kernels of
+        // the fea models' graphs ahead of time (capi.cpp: sanm_fea_spec_source)
+        m_dev.nops = m_ops.size();
+        m_dev.out_var = lout;
+        m_dev.odim = odim;
+        m_dev.max_order = N;
+        m_dev.cur_size = cur_size;
+        m_dev.conv_total = conv_total;
+        m_dev.T = T;
+        m_dev.Tpad = Tpad;
+        m_dev.out_aos = out_aos;
+        m_dev.spec_id = -1;
+        return;
+    }
     // device buffers
     double* arena = static_cast<double*>(be->alloc(off * sizeof(double)));
     be->zero(arena, off * sizeof(double));
@@ -603,6 +619,17 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
         be->h2d(arena + d.coef, soa.data(), soa.size() * sizeof(double));
     }
 
+    // coefficients and bias of the linear combinations as a table of their own, for the kernels compiled per graph
+    // (which read them at run time: the material constants stay out of the generated source)
+    {
+        std::vector<double> lcp;
+        for (const OpDesc& o : m_ops)
+            if (o.type == OP_LINCOMB) lcp.insert(lcp.end(), o.p, o.p + MAX_OP_IN + 2);
+        if (lcp.empty()) lcp.push_back(0.0);
+        m_d_lc_params = be->alloc(lcp.size() * sizeof(double));
+        be->h2d(m_d_lc_params, lcp.data(), lcp.size() * sizeof(double));
+    }
+    m_dev.lc_params = static_cast<const double*>(m_d_lc_params);
     m_dev.ops = static_cast<const OpDesc*>(m_d_ops);
     m_dev.vars = static_cast<const VarDesc*>(m_d_vars);
     m_dev.arena = arena;
@@ -641,24 +668,39 @@ std::string Program::spec_source() const {
     };
     // SANM_NO_CONV_FUSION: every operator walks the history itself, as in the interpreter kernels
     const int conv_total = std::getenv("SANM_NO_CONV_FUSION") ? 0 : m_dev.conv_total;
-    add("#define SANM_CONV_MAX %d\n", std::max(conv_total, 1));
+    // The source depends on the STRUCTURE of the graph and on the order only -- not on the number of tets (arena
+    // offsets are written in units of Tpad, a run-time argument: tet_ops.h, SANM_SPEC_UNITS) and not on the material
+    // (the linear combinations read their coefficients from Program's lc_params table) --, so one code object serves
+    // every mesh and every material of an energy model: it is found in the caches (rtc.cpp), or among the code
+    // objects built ahead of time for the fea models' own graphs (sanm_amd/build.py: rtc_embedded.inc).
+    const int64_t U = m_dev.Tpad;
+    auto units = [&](int64_t off) -> long long {
+        if (off < 0) return -1;
+        sanm_check(off % U == 0, "arena offset %lld is not a multiple of Tpad", (long long)off);
+        return off / U;
+    };
+    add("#define SANM_CONV_MAX %d\n#define SANM_SPEC_UNITS 1\n", std::max(conv_total, 1));
     src += "#include \"tet_ops.h\"\n#include \"red_ops.h\"\nusing namespace sanm_hip;\nnamespace {\n";
-    add("constexpr int kNops = %zu, kCurSize = %d, kOutVar = %d, kConvTotal = %d;\nconstexpr long long kTpad = %lld, "
-        "kOutAos = %lld;\nconstexpr bool kNoOverlap = %s;\n",
-        m_ops.size(), (int)m_dev.cur_size, (int)m_dev.out_var, conv_total, (long long)m_dev.Tpad,
-        (long long)m_dev.out_aos, std::getenv("SANM_NO_COEFF_OVERLAP") ? "true" : "false");
+    add("constexpr int kNops = %zu, kCurSize = %d, kOutVar = %d, kConvTotal = %d;\nconstexpr long long "
+        "kOutAosUnits = %lld;\nconstexpr bool kNoOverlap = %s;\n",
+        m_ops.size(), (int)m_dev.cur_size, (int)m_dev.out_var, conv_total, units(m_dev.out_aos),
+        std::getenv("SANM_NO_COEFF_OVERLAP") ? "true" : "false");
     src += "#define SPEC_OPS { \\\n";
+    int lc_base = 0;
     for (const OpDesc& o : m_ops) {
         add("  {%d, %d, %d, %d, {%d, %d, %d, %d}, {%d, %d, %d}, %d, {", o.type, o.nin, o.nout, o.flags, o.in[0], o.in[1],
             o.in[2], o.in[3], o.out[0], o.out[1], o.out[2], o.grad_zero);
-        for (int i = 0; i < MAX_OP_IN + 2; ++i) add("%a%s", o.p[i], i + 1 < MAX_OP_IN + 2 ? ", " : "}, {");
-        add("%lldLL, %lldLL, %lldLL, %lldLL}, %d, %d}, \\\n", (long long)o.aux[0], (long long)o.aux[1],
-            (long long)o.aux[2], (long long)o.aux[3], o.conv_off, o.conv_n);
+        // (a linear combination's p[] comes from the table at run time; aux[3] = its first entry there)
+        const bool lc = o.type == OP_LINCOMB;
+        for (int i = 0; i < MAX_OP_IN + 2; ++i) add("%a%s", lc ? 0.0 : o.p[i], i + 1 < MAX_OP_IN + 2 ? ", " : "}, {");
+        add("%lldLL, %lldLL, %lldLL, %lldLL}, %d, %d}, \\\n", units(o.aux[0]), units(o.aux[1]), units(o.aux[2]),
+            lc ? (long long)lc_base : units(o.aux[3]), o.conv_off, o.conv_n);
+        if (lc) lc_base += MAX_OP_IN + 2;
     }
     src += "}\n#define SPEC_VARS { \\\n";
     for (const VarDesc& d : m_vars)
-        add("  {%lldLL, %lldLL, %lldLL, %d, %d, %d, %d, %d, 0}, \\\n", (long long)d.coef, (long long)d.bias,
-            (long long)d.jac, d.size, d.is_const, d.cur, d.hist, d.alias);
+        add("  {%lldLL, %lldLL, %lldLL, %d, %d, %d, %d, %d, 0}, \\\n", units(d.coef), units(d.bias), units(d.jac), d.size,
+            d.is_const, d.cur, d.hist, d.alias);
     src += "}\n#define SPEC_CONV_TERMS(I, J) { \\\n";
     for (size_t i = 0; i < m_ops.size(); ++i)
         if (m_ops[i].conv_n) add("  conv_term(c, kOps[%zu], I, J, conv); \\\n", i);
@@ -680,10 +722,11 @@ __device__ __forceinline__ void spec_body(const ProgramDev& P, int order, const 
     const int64_t tet = (int64_t)blockIdx.x * 64 + lane;
     if (tet >= P.T) return;
     double* cur = cur_lds + lane;
-    TetCtx c{P.arena, kVars, kTpad, tet, MODE == PASS_GRAD ? (int)blockIdx.y : order, kVars[kOutVar].size, cur, 64, kOutVar, part, nparts,
+    TetCtx c{P.arena, kVars, P.Tpad, tet, MODE == PASS_GRAD ? (int)blockIdx.y : order, kVars[kOutVar].size, cur, 64, kOutVar, part, nparts,
              cur_lds + (int64_t)kCurSize * 64 + lane};
-    c.out = P.arena + kOutAos;
+    c.out = P.arena + kOutAosUnits * P.Tpad;
     c.max_order = P.max_order;
+    c.params = P.lc_params;
     if (MODE == PASS_GRAD) {
         c.grow = blockIdx.y;
         for (int e = 0; e < kVars[kOutVar].size; ++e) cur[(int64_t)(kVars[kOutVar].cur + e) * 64] = (e == c.grow) ? 1.0 : 0.0;
@@ -732,7 +775,7 @@ __device__ __forceinline__ void spec_body(const ProgramDev& P, int order, const 
     for (size_t i = 0; i < m_ops.size(); ++i) add("        exec_op(c, kOps[%zu], MODE, P.rin, xvec);\n", i);
     src += R"SRC(        if (MODE == PASS_EVAL0) {
             double Y[9];
-            ld(p_coef(c, kOutVar, 0), kTpad, kVars[kOutVar].size, Y);
+            ld(p_coef(c, kOutVar, 0), P.Tpad, kVars[kOutVar].size, Y);
             st_out(c, kVars[kOutVar].size, Y);
         }
     }
@@ -741,25 +784,34 @@ __device__ __forceinline__ void spec_body(const ProgramDev& P, int order, const 
 // (scalar arguments, pointers first: with -amdgpu-kernarg-preload-count they are in SGPRs when a wavefront starts)
 #define SPEC_PARAMS                                                                                              \
     double *arena, const uint32_t *__restrict__ rin_idx, const double *__restrict__ rin_coef, const double *xvec, \
-        long long T, int order, int max_order, int rin_nslot
+        const double *__restrict__ lc_params, long long T, long long Tpad, int order, int max_order, int rin_nslot
 #define SPEC_P             \
     ProgramDev P{};        \
     P.arena = arena;       \
+    P.lc_params = lc_params; \
     P.T = T;               \
+    P.Tpad = Tpad;         \
     P.max_order = max_order; \
     P.rin = {rin_idx, rin_coef, rin_nslot};
+#if !defined(SPEC_ONLY) || SPEC_ONLY == 0
 extern "C" __global__ void __launch_bounds__(256, 1) spec_pass0(SPEC_PARAMS) {
     SPEC_P
     spec_body<PASS_EVAL0>(P, order, xvec);
 }
+#endif
+#if !defined(SPEC_ONLY) || SPEC_ONLY == 1
 extern "C" __global__ void __launch_bounds__(256, 1) spec_pass1(SPEC_PARAMS) {
     SPEC_P
     spec_body<PASS_GRAD>(P, order, xvec);
 }
+#endif
+#if !defined(SPEC_ONLY) || SPEC_ONLY == 2
 extern "C" __global__ void __launch_bounds__(256, 3) spec_pass2(SPEC_PARAMS) {
     SPEC_P
     spec_body<PASS_BIAS>(P, order, xvec);
 }
+#endif
+#if !defined(SPEC_ONLY) || SPEC_ONLY == 4
 // COEFF(order) by wavefront 0 of every workgroup, then BIAS(order + 1) by all of them (PASS_COEFF_BIAS).
 // With nc_xg set the launch also stands for the order loop's next_coeff (Backend::run_pass_next_coeff): the gather of
 // the placeholder forms x_order = -t xg - xvec on the way (t = *nc_num * nc_scale, a device scalar), and the
@@ -809,18 +861,23 @@ extern "C" __global__ void __launch_bounds__(256, 3) spec_pass4(SPEC_PARAMS, con
         spec_body<PASS_BIAS>(P, order + 1, xvec);
     }
 }
+#endif
+#if !defined(SPEC_ONLY) || SPEC_ONLY == 3
 extern "C" __global__ void __launch_bounds__(256, 1) spec_pass3(SPEC_PARAMS) {
     SPEC_P
     spec_body<PASS_COEFF>(P, order, xvec);
 }
+#endif
 )SRC";
     return src;
 }
 
 Program::~Program() {
+    if (!m_be) return;
     if (m_dev.spec_id >= 0) m_be->release_specialized(m_dev.spec_id);
     m_be->free(m_dev.arena);
     m_be->free(m_d_ops);  // the variable records live in the same block
+    if (m_d_lc_params) m_be->free(m_d_lc_params);
     if (m_d_rin_idx) m_be->free(m_d_rin_idx);
     if (m_d_rin_coef) m_be->free(m_d_rin_coef);
 }

@@ -150,7 +150,7 @@ public:
     const std::vector<PowFlag>& pow_flags() const { return m_pow_flags; }
     double* arena_dev() const { return m_dev.arena; }
     //! run-time specialisation of the pass kernels (constructor): host seconds it took and where the code object came
-    //! from -- 0: not specialised, 1: the process-wide cache, 2: the on-disk cache, 3: compiled now
+    //! from -- 0: not specialised, 1: the process-wide cache, 2: the on-disk cache, 3: compiled now, 4: built ahead of time (embedded)
     double jit_seconds = 0;
     int jit_source = 0;
 
@@ -168,6 +168,7 @@ private:
     int64_t m_tet_begin = 0;
     void* m_d_ops = nullptr;
     void* m_d_vars = nullptr;
+    void* m_d_lc_params = nullptr;
     void* m_d_rin_idx = nullptr;
     void* m_d_rin_coef = nullptr;
 };

@@ -701,6 +701,35 @@ __device__ __forceinline__ void gemm_tile_foreach(const mfma_f64x4 acc[2][2], F&
                   acc[mi][ni][g]);
 }
 
+// C[r, c] -= acc over the part of the tile inside (rows, cols): the 16 old values of a lane are requested TOGETHER,
+// then subtracted and stored.  (`*dst = *dst - v` element by element made every store wait for its own load and every
+// load for the store before it -- the compiler cannot tell that the addresses differ --: 16 dependent round trips per
+// lane, the whole run time of a tile with a short K loop, i.e. of every product of the fronts of the lower levels.)
+__device__ __forceinline__ void gemm_tile_sub_from(const mfma_f64x4 acc[2][2], double* __restrict__ C, int64_t ldc, int ti,
+                                                   int tj, int rows, int cols) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int rb = ti * GT + 32 * (wv >> 1) + (lane >> 4), cb = tj * GT + 32 * (wv & 1) + (lane & 15);
+    double old[2][2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = rb + 16 * mi + 4 * g, c = cb + 16 * ni;
+                old[mi][ni][g] = (r < rows && c < cols) ? C[(int64_t)r * ldc + c] : 0.0;
+            }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = rb + 16 * mi + 4 * g, c = cb + 16 * ni;
+                if (r < rows && c < cols) C[(int64_t)r * ldc + c] = old[mi][ni][g] - acc[mi][ni][g];
+            }
+}
+
 // step 2:  which = 0: tmpU (k x b) = L11^-1 F[P,B]     (L11^-1 lower: K tiles 0..ti)
 //          which = 1: tmpL (b x k) = F[B,P] U11^-1     (U11^-1 upper: K tiles 0..tj)
 // two_phase (Level::two_phase): the negated results are also the front's boundary operators, -U12 in the F[A,B] slot and
@@ -762,16 +791,21 @@ __global__ void __launch_bounds__(256) gemm2_tall_kernel(MF_FACTOR_PARAMS) {
     mfma_f64x4 acc4[4][2];
     gemm_tile_tall(A, B, ti >> 1, tj, 0, k, As, Bs, acc4);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // (old values requested together, see gemm_tile_sub_from; the tile is interior: no guards)
+    double* __restrict__ Cw = C + (int64_t)((ti >> 1) * GT2 + 64 * (wv >> 1) + (lane >> 4)) * ld + tj * GT + 32 * (wv & 1) + (lane & 15);
+    double old[4][2][4];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int r = (ti >> 1) * GT2 + 64 * (wv >> 1) + 16 * mi + (lane >> 4) + 4 * g;
-                const int c = tj * GT + 32 * (wv & 1) + 16 * ni + (lane & 15);
-                C[(int64_t)r * ld + c] -= acc4[mi][ni][g];
-            }
+            for (int g = 0; g < 4; ++g) old[mi][ni][g] = Cw[(int64_t)(16 * mi + 4 * g) * ld + 16 * ni];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) Cw[(int64_t)(16 * mi + 4 * g) * ld + 16 * ni] = old[mi][ni][g] - acc4[mi][ni][g];
 }
 
 // step 3:  which = 0: F[B,B] -= tmpL tmpU                        (b x b, K = k)
@@ -814,12 +848,13 @@ __global__ void __launch_bounds__(256) gemm2_kernel(MF_FACTOR_PARAMS, int nwhich
     }
     mfma_f64x4 acc[2][2];
     gemm_tile(A, B, ti, tj, k0, k, As, Bs, acc);
+    if (which == 0) {
+        gemm_tile_sub_from(acc, C, ld, ti, tj, rows, cols);
+        return;
+    }
     gemm_tile_foreach(acc, [&](int i, int j, double v) {
         const int r = ti * GT + i, c = tj * GT + j;
-        if (r < rows && c < cols) {
-            double* dst = C + (int64_t)r * ld + c;
-            *dst = (which == 0) ? *dst - v : -v;
-        }
+        if (r < rows && c < cols) C[(int64_t)r * ld + c] = -v;
     });
 }
 
@@ -842,10 +877,7 @@ __global__ void __launch_bounds__(256) block_gemm_kernel(MF_FACTOR_PARAMS, int p
     mfma_f64x4 acc[2][2];
     gemm_tile(A, B, ti, tj, p0 * NB, min(p1 * NB, k), As, Bs, acc);
     double* C = F + (int64_t)r0 * ld + r0;
-    gemm_tile_foreach(acc, [&](int i, int j, double v) {
-        const int r = ti * GT + i, c = tj * GT + j;
-        if (r < ext && c < ext) C[(int64_t)r * ld + c] -= v;
-    });
+    gemm_tile_sub_from(acc, C, ld, ti, tj, ext, ext);
 }
 
 // ---------------------------------------------------------------- solve --

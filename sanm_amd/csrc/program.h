@@ -117,6 +117,9 @@ struct ProgramDev {
     // tet-major they share cache lines, component-major every entry sits in a line of its own.
     int64_t out_aos;
     RemapInDev rin;
+    // coefficients and bias of the linear combinations, MAX_OP_IN + 2 doubles per LINCOMB operator in operator order:
+    // what the kernels compiled per graph read in place of OpDesc::p (tet_ops.h, SANM_LC_PARAM)
+    const double* lc_params;
     // host side only: handle of the kernels compiled for this very program (Backend::specialize), -1 = none
     int32_t spec_id;
 };

@@ -74,7 +74,23 @@ struct TetCtx {
     // the accumulators must end up in registers, and a pointer kept in the context defeats that.)
     bool has_conv = false;
     double conv[SANM_CONV_MAX];
+    // kernels compiled per graph (SANM_SPEC_UNITS): coefficients and bias of the linear combinations, which carry the
+    // material constants -- read at run time so that the generated source depends on the graph's structure only
+    const double* params = nullptr;
 };
+
+// Arena offsets.  The interpreter kernels take them from the operator / variable records as absolute offsets in
+// doubles.  The kernels compiled per graph (SANM_SPEC_UNITS, graph.cpp: Program::spec_source) carry them in UNITS OF
+// Tpad -- every region of the arena is a whole number of [component][Tpad] planes -- and multiply by the run-time
+// Tpad: their source, and with it the compiled code object, then does not depend on the size of the mesh (a scalar
+// multiplication per address).
+#ifdef SANM_SPEC_UNITS
+#define SANM_OFF(c, off) ((int64_t)(off) * (c).Tpad)
+#define SANM_LC_PARAM(c, o, k) ((c).params[(o).aux[3] + (k)])
+#else
+#define SANM_OFF(c, off) ((int64_t)(off))
+#define SANM_LC_PARAM(c, o, k) ((o).p[k])
+#endif
 
 // slice [lo, hi) of the convolution index range 1 .. order-1 taken by this part
 SANM_HD void conv_range(const TetCtx& c, int& lo, int& hi) {
@@ -106,10 +122,10 @@ SANM_HD void conv_reduce(const TetCtx& c, double* v, int n) {
 // ---------------------------------------------------------------- access --
 SANM_HD double* p_coef(const TetCtx& c, int v, int k) {
     const VarDesc& d = c.vars[v];
-    return c.arena + d.coef + (int64_t)k * d.size * c.Tpad + c.tet;
+    return c.arena + SANM_OFF(c, d.coef) + (int64_t)k * d.size * c.Tpad + c.tet;
 }
-SANM_HD double* p_bias(const TetCtx& c, int v) { return c.arena + c.vars[v].bias + c.tet; }
-SANM_HD double* p_aux(const TetCtx& c, int64_t off) { return c.arena + off + c.tet; }
+SANM_HD double* p_bias(const TetCtx& c, int v) { return c.arena + SANM_OFF(c, c.vars[v].bias) + c.tet; }
+SANM_HD double* p_aux(const TetCtx& c, int64_t off) { return c.arena + SANM_OFF(c, off) + c.tet; }
 // value pointer of the "current" term: bias buffer (BIAS pass) or coef[k]
 SANM_HD double* p_cur(const TetCtx& c, int v, bool in_coeff) {
     return in_coeff ? p_coef(c, v, c.order) : p_bias(c, v);
@@ -429,7 +445,7 @@ SANM_HD void op_lincomb_t(const TetCtx& c, const OpDesc& o, int mode) {
         for (int k = 0; k < o.nin; ++k) {
             int iv = o.in[k], isz = c.vars[iv].size;
             if (c.vars[iv].is_const) continue;
-            double ck = o.p[k];
+            double ck = SANM_LC_PARAM(c, o, k);
             for (int r = c.grow; r <= c.grow; ++r) {
                 if (isz == osz) {
                     for (int e = 0; e < osz; ++e) jfma(c, iv, r, e, ck, jget(c, ov, r, e));
@@ -444,11 +460,11 @@ SANM_HD void op_lincomb_t(const TetCtx& c, const OpDesc& o, int mode) {
     }
     double acc[9];
     if (mode == PASS_EVAL0) {
-        for (int e = 0; e < osz; ++e) acc[e] = o.p[MAX_OP_IN];
+        for (int e = 0; e < osz; ++e) acc[e] = SANM_LC_PARAM(c, o, MAX_OP_IN);
         for (int k = 0; k < o.nin; ++k) {
             int iv = o.in[k], isz = c.vars[iv].size;
             const double* p = p_coef(c, iv, 0);
-            for (int e = 0; e < osz; ++e) acc[e] = __builtin_fma(o.p[k], bval(p, s, isz, e), acc[e]);
+            for (int e = 0; e < osz; ++e) acc[e] = __builtin_fma(SANM_LC_PARAM(c, o, k), bval(p, s, isz, e), acc[e]);
         }
         st(p_coef(c, ov, 0), s, osz, acc);
         return;
@@ -457,7 +473,7 @@ SANM_HD void op_lincomb_t(const TetCtx& c, const OpDesc& o, int mode) {
     for (int k = 0; k < o.nin; ++k) {
         int iv = o.in[k], isz = c.vars[iv].size;
         if (c.vars[iv].is_const) continue;
-        for (int e = 0; e < osz; ++e) acc[e] = __builtin_fma(o.p[k], cur_bval(c, iv, isz, e), acc[e]);
+        for (int e = 0; e < osz; ++e) acc[e] = __builtin_fma(SANM_LC_PARAM(c, o, k), cur_bval(c, iv, isz, e), acc[e]);
     }
     st_cur(c, ov, osz, acc, mode == PASS_COEFF);
 }
@@ -606,8 +622,8 @@ SANM_HD void op_unary_t(const TetCtx& c, const OpDesc& o, int mode) {
                     // non-integer p", word 1 = "integer p beyond POW_INT_MAX_ORDER".  All pow operators of a graph
                     // share them, and every lane that stores a word stores the same value, so no operator and no
                     // tet can hide another one's report.
-                    if (!integer) c.arena[o.aux[2]] = 1.0;
-                    else if (c.max_order > POW_INT_MAX_ORDER) c.arena[o.aux[2] + 1] = 2.0;
+                    if (!integer) c.arena[SANM_OFF(c, o.aux[2])] = 1.0;
+                    else if (c.max_order > POW_INT_MAX_ORDER) c.arena[SANM_OFF(c, o.aux[2]) + 1] = 2.0;
                 }
             }
         }
@@ -1423,7 +1439,7 @@ SANM_HD void op_placeholder(const TetCtx& c, const OpDesc& o, int mode, const Re
         // the end of the reverse sweep: row grow of d(out)/d(placeholder), what the assembly gathers
         // (tet-major [T][9][9]: the contributions to one Jacobian entry come from a few tets and from up to 9
         // entries of each; tet-major those share cache lines)
-        double* j = c.arena + c.vars[ov].jac + c.tet * (c.odim * 9) + c.grow * 9;
+        double* j = c.arena + SANM_OFF(c, c.vars[ov].jac) + c.tet * (c.odim * 9) + c.grow * 9;
         for (int e = 0; e < 9; ++e) j[e] = jget(c, ov, c.grow, e);
         return;
     }

@@ -494,3 +494,6 @@ extern "C" int sanm_rtc_cache_stats(int64_t* compiled, int64_t* memory_hits, int
 }
 extern "C" int sanm_rtc_cache_probe(const char*) { return 2; }
 extern "C" int sanm_rtc_cache_drop_memory(void) { return 0; }
+extern "C" int sanm_rtc_source_key(const char*, char* key33) { key33[0] = 0; return 2; }
+extern "C" int sanm_rtc_compile_to_file(const char*, const char*, char*, size_t) { return 2; }
+extern "C" int sanm_rtc_embedded_hits(int64_t* hits) { *hits = 0; return 0; }

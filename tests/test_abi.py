@@ -24,7 +24,9 @@ def test_the_interface_header_declares_no_test_hook():
     assert "sanm_anm_debug_inject" not in iface and "sanm_rtc_compile_check" not in iface
     assert set(_declared_symbols(("sanm_hip_test.h",))) == {"sanm_anm_debug_inject", "sanm_rtc_compile_check",
                                                             "sanm_rtc_cache_stats", "sanm_rtc_cache_probe",
-                                                            "sanm_rtc_cache_drop_memory", "sanm_direct_solver_dist_plan"}
+                                                            "sanm_rtc_cache_drop_memory", "sanm_direct_solver_dist_plan",
+                                                            "sanm_fea_spec_source", "sanm_rtc_source_key",
+                                                            "sanm_rtc_compile_to_file", "sanm_rtc_embedded_hits"}
 
 
 def test_header_symbols_are_exported():

@@ -416,3 +416,30 @@ def test_anm_solver_at_order_30(api):
     print("order 30: steps", ls.nr_steps, "oracle", ofree.get_nr_iter(), "events", len(ls.events))
     if not ls.events:
         assert ls.nr_steps == ofree.get_nr_iter()
+
+
+@pytest.mark.gpu
+def test_kernels_built_ahead_of_time_equal_the_ones_compiled_at_run_time(monkeypatch):
+    """The pass kernels of the fea models' graphs are compiled when the library is built (sanm_amd/build.py:
+    rtc_embedded.bin, found by the key of the generated source, which depends on the graph's structure and the order
+    only) -- by the build's compiler, possibly another version than the process's run-time compiler.  Both must give
+    the same bits (everything is built with -ffp-contract=off and says fma where it wants one): the same cuboid
+    continuation with the embedded set and with SANM_NO_JIT_EMBEDDED=1 (compiled now), vertex for vertex."""
+    import ctypes
+    import sanm_amd
+    api = sanm_amd.get_api(0)
+    gold = json.load(open(os.path.join(GOLD, "anm_cuboid_nc.json")))
+    monkeypatch.setenv("SANM_JIT_MIN_T", "1")
+    monkeypatch.setenv("SANM_NO_JIT_CACHE", "1")
+    hits = ctypes.c_int64()
+    api.lib.sanm_rtc_embedded_hits(ctypes.byref(hits))
+    h0 = hits.value
+    run = _run_device(api, gold["dims"], gold["spacing"], gold["config"])
+    api.lib.sanm_rtc_embedded_hits(ctypes.byref(hits))
+    assert hits.value == h0 + 1 and run.solver.setup_profile()["jit_source"] == "embedded"
+    monkeypatch.setenv("SANM_NO_JIT_EMBEDDED", "1")
+    api.lib.sanm_rtc_cache_drop_memory()
+    ref = _run_device(api, gold["dims"], gold["spacing"], gold["config"])
+    assert ref.solver.setup_profile()["jit_source"] == "compiled"
+    assert run.solver.get_nr_iter() == ref.solver.get_nr_iter()
+    assert np.array_equal(run.vertices(), ref.vertices())

@@ -264,5 +264,7 @@ def test_two_ranks_on_one_gpu_run_the_world_2_branch_of_the_sharded_hip_path():
     assert d["config"]["steps_per_solve"][0] == 2, d["config"]["steps_per_solve"]
     # ... which is what the line's end_to_end object timed from the constructor on (the reference's time_solve)
     assert d["end_to_end"]["iter"] == 2 and d["end_to_end"]["cold"]["converged"]
-    assert d["end_to_end"]["setup_seconds"]["jit_cold_source"] in ("compiled", "disk_hit")
-    assert d["end_to_end"]["setup_seconds"]["jit_cached_source"] == "disk_hit"
+    # (armadillo's Neo-Hookean graph at order 20 is in the set compiled ahead of time into the library: no run-time
+    # compilation in either constructor)
+    assert d["end_to_end"]["setup_seconds"]["jit_cold_source"] == "embedded"
+    assert d["end_to_end"]["setup_seconds"]["jit_cached_source"] == "embedded"
