@@ -1169,6 +1169,8 @@ class HipBackend final : public Backend {
 #endif
     static constexpr int kOuterPanels = SANM_MF_OUTER_PANELS;
     static constexpr int kOuterMinK = 512;
+    // levels with at least this many fronts of at most SF_KMAX pivots take small_front_kernel
+    static constexpr int kSmallMinFronts = 1024;
     int m_conv_parts = std::getenv("SANM_CONV_PARTS") ? std::atoi(std::getenv("SANM_CONV_PARTS")) : 4;
     int m_conv_split_order = std::getenv("SANM_CONV_SPLIT_ORDER") ? std::atoi(std::getenv("SANM_CONV_SPLIT_ORDER")) : 4;
     PcgScalars* m_pcg_sc_host = nullptr;
@@ -1880,8 +1882,22 @@ public:
                                    m_stream, mf.fronts, mf.front_store, mf.rel,
                                    sch.ea_children + L.ea_rounds[r].first);
             }
-            const int nt = (2 * L.max_k + NB - 1) / NB;  // pivot + augmentation block
             const int nfront = L.front_end - L.front_begin;
+            // levels of many small fronts: the whole factorisation of a front in one workgroup (mf_kernels.h,
+            // small_front_kernel) instead of the panel chain and the two GEMM passes.  SANM_MF_SMALL_MIN_FRONTS: from how
+            // many fronts a level takes it (tests: 1; 0: never)
+            const char* env_small = std::getenv("SANM_MF_SMALL_MIN_FRONTS");
+            const int small_min = env_small ? std::atoi(env_small) : kSmallMinFronts;
+            if (small_min > 0 && nfront >= small_min && L.max_k <= SF_KMAX && !L.two_phase) {
+                const int ks = L.max_k | 1;
+                const size_t lds = std::max<size_t>(((size_t)ks * ks + 4 * (size_t)ks) * sizeof(double),
+                                                    (size_t)GK * (2 * GT + 5) * sizeof(double));
+                if (lds > 48 * 1024)
+                    HIP_CHECK(hipFuncSetAttribute((const void*)small_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                SANM_LAUNCH(small_front_kernel, dim3(nfront), dim3(256), lds, m_stream, MF_FACTOR_ARGS(mf, L.front_begin), ks);
+                continue;
+            }
+            const int nt = (2 * L.max_k + NB - 1) / NB;  // pivot + augmentation block
             // augmentation tiles of a panel: at most ceil(k / NB) + 1 per side
             const int atiles = (L.max_k + NB - 1) / NB + 1;
             if (L.max_k < outer_min_k) {

@@ -734,15 +734,10 @@ __device__ __forceinline__ void gemm_tile_sub_from(const mfma_f64x4 acc[2][2], d
 //          which = 1: tmpL (b x k) = F[B,P] U11^-1     (U11^-1 upper: K tiles 0..tj)
 // two_phase (Level::two_phase): the negated results are also the front's boundary operators, -U12 in the F[A,B] slot and
 // -L21 in the F[B,A] slot (gemm2_kernel then leaves its products 1 and 2 out)
-__global__ void __launch_bounds__(256) gemm1_kernel(MF_FACTOR_PARAMS, int two_phase) {
-    MF_FACTOR_INIT
-    const MfFrontDev f = mf.lfronts[level_begin + blockIdx.z / 2];
-    const int which = blockIdx.z & 1;
+__device__ __forceinline__ void gemm1_tile(const FactorArgs& mf, const MfFrontDev& f, int which, int ti, int tj,
+                                           double (*As)[GT + 1], double (*Bs)[GT + 4], int two_phase) {
     const int k = f.k, b = f.m - f.k, ld = f.ld;
     const int rows = which ? b : k, cols = which ? k : b;
-    const int ti = blockIdx.y, tj = blockIdx.x;
-    if (ti * GT >= rows || tj * GT >= cols) return;
-    __shared__ double As[GK][GT + 1], Bs[GK][GT + 4];
     const double* F = mf.front_store + f.off;
     double* tmp = mf.tmp_store + f.tmp_off;
     MatView A, B;
@@ -768,6 +763,17 @@ __global__ void __launch_bounds__(256) gemm1_kernel(MF_FACTOR_PARAMS, int two_ph
             if (two_phase) slot[(int64_t)r * ld + c] = -v;
         }
     });
+}
+__global__ void __launch_bounds__(256) gemm1_kernel(MF_FACTOR_PARAMS, int two_phase) {
+    MF_FACTOR_INIT
+    const MfFrontDev f = mf.lfronts[level_begin + blockIdx.z / 2];
+    const int which = blockIdx.z & 1;
+    const int k = f.k, b = f.m - f.k;
+    const int rows = which ? b : k, cols = which ? k : b;
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (ti * GT >= rows || tj * GT >= cols) return;
+    __shared__ double As[GK][GT + 1], Bs[GK][GT + 4];
+    gemm1_tile(mf, f, which, ti, tj, As, Bs, two_phase);
 }
 
 // F[B,B] -= tmpL tmpU of a big front: its interior 128 x 64 tiles go to gemm2_tall_kernel (a kernel of its own: the
@@ -812,15 +818,10 @@ __global__ void __launch_bounds__(256) gemm2_tall_kernel(MF_FACTOR_PARAMS) {
 //          which = 1: F[B,A]  = -tmpL L11^-1   (b x k; L11^-1 lower: K tiles tj..)
 //          which = 2: F[A,B]  = -U11^-1 tmpU   (k x b; U11^-1 upper: K tiles ti..)
 //          nwhich = 1 (two-phase levels): product 0 only
-__global__ void __launch_bounds__(256) gemm2_kernel(MF_FACTOR_PARAMS, int nwhich) {
-    MF_FACTOR_INIT
-    const MfFrontDev f = mf.lfronts[level_begin + blockIdx.z / nwhich];
-    const int which = blockIdx.z % nwhich;
+__device__ __forceinline__ void gemm2_tile(const FactorArgs& mf, const MfFrontDev& f, int which, int ti, int tj,
+                                           double (*As)[GT + 1], double (*Bs)[GT + 4]) {
     const int k = f.k, b = f.m - f.k, ld = f.ld;
     const int rows = which == 2 ? k : b, cols = which == 1 ? k : b;
-    const int ti = blockIdx.y, tj = blockIdx.x;
-    if (ti * GT >= rows || tj * GT >= cols) return;
-    __shared__ double As[GK][GT + 1], Bs[GK][GT + 4];
     double* F = mf.front_store + f.off;
     const double* tmpU = mf.tmp_store + f.tmp_off;
     const double* tmpL = tmpU + (int64_t)k * b;
@@ -831,10 +832,6 @@ __global__ void __launch_bounds__(256) gemm2_kernel(MF_FACTOR_PARAMS, int nwhich
         A = {tmpL, k, b, k};
         B = {tmpU, b, k, b};
         C = F + (int64_t)2 * k * ld + 2 * k;
-#ifndef SANM_MF_OLD_STAGING
-        // (the interior of the Schur complement of a big front belongs to gemm2_tall_kernel)
-        if (gemm2_is_tall(k, b, rows, cols, ti, tj)) return;
-#endif
     } else if (which == 1) {
         A = {tmpL, k, b, k};
         B = {F + k, ld, k, k};  // L11^-1 (lower): rows >= column
@@ -856,6 +853,142 @@ __global__ void __launch_bounds__(256) gemm2_kernel(MF_FACTOR_PARAMS, int nwhich
         const int r = ti * GT + i, c = tj * GT + j;
         if (r < rows && c < cols) C[(int64_t)r * ld + c] = -v;
     });
+}
+__global__ void __launch_bounds__(256) gemm2_kernel(MF_FACTOR_PARAMS, int nwhich) {
+    MF_FACTOR_INIT
+    const MfFrontDev f = mf.lfronts[level_begin + blockIdx.z / nwhich];
+    const int which = blockIdx.z % nwhich;
+    const int k = f.k, b = f.m - f.k;
+    const int rows = which == 2 ? k : b, cols = which == 1 ? k : b;
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (ti * GT >= rows || tj * GT >= cols) return;
+#ifndef SANM_MF_OLD_STAGING
+    // (the interior of the Schur complement of a big front belongs to gemm2_tall_kernel)
+    if (which == 0 && gemm2_is_tall(k, b, rows, cols, ti, tj)) return;
+#endif
+    __shared__ double As[GK][GT + 1], Bs[GK][GT + 4];
+    gemm2_tile(mf, f, which, ti, tj, As, Bs);
+}
+
+// ---- small fronts: the whole factorisation of a front in ONE workgroup (round 5) --------------------------------
+// On the lower levels of a big tree a front has a few dozen pivots and a boundary of a few hundred rows, and there
+// are thousands of them: every tile task of the panel / GEMM launches above is then a handful of dependent memory
+// round trips around 32 x 32 x 32 flops -- 10-40 us per task, two to four tasks in flight per compute unit (their LDS),
+// three quarters of the workgroups of a GEMM launch empty because the grid is sized for the level's largest front.
+// Measured on armadillo with every tet cut into 8 (338 k tets): the leaf level's 2572 fronts (54 pivots, 89 boundary
+// rows on average) took 3.2 ms of a 14.6 ms factorisation in seven launches, 8.4 GFLOP at 2.6 TFLOP/s.
+// Here a workgroup owns a front (k <= 96 pivots):
+//   A. its k x k pivot block goes to LDS once; LU without pivoting (pivots below the threshold perturbed and counted
+//      like tile_factor does), then L and U are inverted IN PLACE -- column by column, L from its last column
+//      backwards, U from its first forwards, both in the same sweep of k barriers --: no identity blocks carried
+//      through a panel loop, no global memory between the steps;
+//   B. L11^-1 / U11^-1 are stored where the solve kernels read them (F[P,A], F[A,P]) and the products of steps 2 and
+//      3 above run as a loop over their 64 x 64 tiles in this workgroup (gemm1_tile / gemm2_tile: the same arithmetic
+//      as the separate launches), operands from L2.
+// The pivot block's own factors are not written back: nothing reads F[P,P] after the factorisation.
+constexpr int SF_KMAX = 96;
+__global__ void __launch_bounds__(256) small_front_kernel(MF_FACTOR_PARAMS, int ks) {
+    MF_FACTOR_INIT
+    const MfFrontDev f = mf.lfronts[level_begin + blockIdx.x];
+    const int k = f.k, b = f.m - f.k, ld = f.ld;
+    extern __shared__ __attribute__((aligned(16))) double sdyn[];
+    double* S = sdyn;                       // S[r * ks + c], ks odd >= the level's largest k
+    double* vbuf = sdyn + (int64_t)ks * ks;  // 2 x 2 x ks: columns saved ahead of their in-place inversion
+    double* F = mf.front_store + f.off;
+    const int tid = threadIdx.x;
+    const double thr = MF_PIVOT_EPS * *mf.piv_amax;
+    for (int r = tid >> 5; r < k; r += 8)
+        for (int c = tid & 31; c < k; c += 32) S[r * ks + c] = F[(int64_t)r * ld + c];
+    __syncthreads();
+    // ---- LU, right-looking, one pivot per step
+    int nbad = 0;
+    const int ty = tid >> 4, tx = tid & 15;
+    for (int j = 0; j < k; ++j) {
+        double piv = S[j * ks + j];
+        const bool bad = !(fabs(piv) > thr);
+        if (bad) piv = thr > 0 ? copysign(thr, piv) : 1.0;
+        const double inv = 1.0 / piv;
+        // (a thread that reads the pivot after thread 0 has replaced it finds +-thr, replaces it by itself again and
+        // gets the same reciprocal: no barrier needed around the replacement)
+        if (tid == 0 && bad) {
+            ++nbad;
+            S[j * ks + j] = piv;
+        }
+        for (int i = j + 1 + tid; i < k; i += 256) S[i * ks + j] *= inv;
+        __syncthreads();
+        for (int i = j + 1 + ty; i < k; i += 16) {
+            const double l = S[i * ks + j];
+            for (int c = j + 1 + tx; c < k; c += 16) S[i * ks + c] = __builtin_fma(-l, S[j * ks + c], S[i * ks + c]);
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && nbad) atomicAdd(mf.status, nbad);
+    // ---- in-place inverses: step s finishes column k-2-s of L^-1 (threads 0..127) and column s of U^-1 (128..255).
+    // A column's ORIGINAL entries are needed while its new ones are written: they are copied one step ahead into vbuf.
+    double* vl = vbuf;           // [2][ks]
+    double* vu = vbuf + 2 * ks;  // [2][ks]
+    {
+        const int jl0 = k - 2, ju0 = 0;
+        if (tid < 128) {
+            if (jl0 >= 0)
+                for (int i = tid; i < k; i += 128) vl[i] = S[i * ks + jl0];
+        } else {
+            for (int i = tid - 128; i < k; i += 128) vu[i] = S[i * ks + ju0];
+        }
+    }
+    __syncthreads();
+    for (int s2 = 0; s2 < k; ++s2) {
+        const int cur = s2 & 1, nxt = cur ^ 1;
+        if (tid < 128) {
+            const int jl = k - 2 - s2;
+            if (jl >= 0) {
+                const double* v = vl + cur * ks;
+                for (int i = jl + 1 + tid; i < k; i += 128) {
+                    double acc = v[i];
+                    for (int t = jl + 1; t < i; ++t) acc = __builtin_fma(S[i * ks + t], v[t], acc);
+                    S[i * ks + jl] = -acc;
+                }
+                if (jl >= 1)
+                    for (int i = tid; i < k; i += 128) vl[nxt * ks + i] = S[i * ks + jl - 1];
+            }
+        } else {
+            const int u = tid - 128, ju = s2;
+            const double* v = vu + cur * ks;
+            const double d = 1.0 / v[ju];
+            for (int i = u; i < ju; i += 128) {
+                double acc = 0.0;
+                for (int t = i; t < ju; ++t) acc = __builtin_fma(S[i * ks + t], v[t], acc);
+                S[i * ks + ju] = -acc * d;
+            }
+            if (u == 0) S[ju * ks + ju] = d;
+            if (ju + 1 < k)
+                for (int i = u; i < k; i += 128) vu[nxt * ks + i] = S[i * ks + ju + 1];
+        }
+        __syncthreads();
+    }
+    // ---- L11^-1 (strictly lower part; its unit diagonal is the identity block's) -> F[P,A], U11^-1 -> F[A,P]
+    for (int r = tid >> 5; r < k; r += 8)
+        for (int c = tid & 31; c < k; c += 32) {
+            const double v = S[r * ks + c];
+            if (c < r) F[(int64_t)r * ld + k + c] = v;
+            else F[(int64_t)(k + r) * ld + c] = v;
+        }
+    if (b == 0) return;
+    __syncthreads();  // (also: S is dead from here on, the GEMM staging below takes its place)
+    auto As = reinterpret_cast<double(*)[GT + 1]>(sdyn);
+    auto Bs = reinterpret_cast<double(*)[GT + 4]>(sdyn + GK * (GT + 1));
+    const int tk = (k + GT - 1) / GT, tb = (b + GT - 1) / GT;
+    for (int tj = 0; tj < tb; ++tj)
+        for (int ti = 0; ti < tk; ++ti) gemm1_tile(mf, f, 0, ti, tj, As, Bs, 0);  // tmpU (k x b)
+    for (int ti = 0; ti < tb; ++ti)
+        for (int tj = 0; tj < tk; ++tj) gemm1_tile(mf, f, 1, ti, tj, As, Bs, 0);  // tmpL (b x k)
+    __syncthreads();
+    for (int ti = 0; ti < tb; ++ti)
+        for (int tj = 0; tj < tb; ++tj) gemm2_tile(mf, f, 0, ti, tj, As, Bs);
+    for (int ti = 0; ti < tb; ++ti)
+        for (int tj = 0; tj < tk; ++tj) gemm2_tile(mf, f, 1, ti, tj, As, Bs);
+    for (int ti = 0; ti < tk; ++ti)
+        for (int tj = 0; tj < tb; ++tj) gemm2_tile(mf, f, 2, ti, tj, As, Bs);
 }
 
 // Two blocking levels: after the panels [p0, p1) of an outer block the trailing matrix beyond it,

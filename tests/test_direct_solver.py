@@ -231,3 +231,29 @@ def test_reference_sparse_solver_case(api, seed):
     x = ds.solve(b)
     assert np.allclose(A @ x, b, rtol=1.2e-5, atol=1e-12)
     assert np.abs(x - np.linalg.solve(A, b)).max() <= 1e-9 * np.abs(x).max()
+
+
+@pytest.mark.parametrize("leaf", ["8", "20", "32"])
+def test_small_fronts_in_one_workgroup_forced(api, monkeypatch, leaf):
+    """levels of a thousand or more fronts of at most 96 pivots are factored by small_front_kernel (mf_kernels.h, round
+    5: pivot block in LDS, unblocked LU, L and U inverted in place, the boundary products as a tile loop in the same
+    workgroup) instead of the panel chain and the GEMM passes.  SANM_MF_SMALL_MIN_FRONTS=1 forces it on every level of
+    the small test systems whose fronts fit; the leaf size varies the pivot counts (1 ... 96: partial 32-panels, an odd /
+    even LDS stride, fronts without a boundary, single-pivot fronts) and SANM_MF_MERGE=none keeps the lower levels
+    small.  Perturbed pivots must still be counted.  (The host harness ignores the switch.)"""
+    monkeypatch.setenv("SANM_MF_SMALL_MIN_FRONTS", "1")
+    monkeypatch.setenv("SANM_MF_LEAF", leaf)
+    monkeypatch.setenv("SANM_MF_MERGE", "none")
+    test_random_block_unsymmetric(api)
+    test_scalar_pattern_no_blocks(api)
+    test_tiny_and_diagonal(api)
+    test_fem_jacobian(api, True)
+    test_fem_jacobian(api, False)
+    test_grid3d_wide_separators(api)
+    for seed in range(4):
+        test_reference_sparse_solver_case(api, seed)
+    # a singular pivot block in a leaf: the perturbation is counted and the refined solve still works
+    A = sp.block_diag([sp.csr_matrix(np.array([[1e-30, 1.0], [1.0, 1.0]])), sp.diags([2.0, 3.0, 4.0])]).tocsr()
+    A.sort_indices()
+    ds = DirectSolver(api, A)
+    assert ds.factor(A) >= 1
