@@ -1248,10 +1248,8 @@ void AnmDriver::solve_expansion_coeffs() {
         if (i == 1) {
             {
                 ScopedTimer t{this, "build_sparse_coeff"};
-                be->assemble(m_pattern->assembly(), jacobian_blocks(), m_pattern->csr().val);
-                if (m_pattern->has_t())
-                    be->assemble(m_pattern->assembly_grad_t(), jacobian_blocks(),
-                                 m_grad_t_buf.p());
+                be->assemble(m_pattern->assembly(), jacobian_blocks(), m_pattern->csr().val,
+                             m_pattern->has_t() ? m_grad_t_buf.p() : nullptr);
                 allreduce(m_pattern->csr().val, m_pattern->nnz());
                 if (m_pattern->has_t()) allreduce(m_grad_t_buf.p(), n);
                 if (m_inject.kind == 3) apply_injection(m_pattern->csr().val, m_pattern->nnz());

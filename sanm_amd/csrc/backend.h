@@ -43,13 +43,28 @@ struct CsrDev {
     int64_t n, nnz;
 };
 
-// value assembly: val[s] = sum_{p in [ptr[s], ptr[s+1])} drop(coef[p] * jac[jidx[p]])
-// where drop(c) = |c| < 1e-9 ? 0 : c   (libsanm/sparse_solver.cpp:291-293)
+// Value assembly of the Jacobian A = remap_out . blockdiag(J_e) . remap_in (libsanm/anm.cpp:362-438, :520-608):
+//   A[i, c] = sum over the triples (p, m, q) -- p an entry of row i of remap_out (output element e = b * odim + o of
+//   batch item b, coefficient c_out), m < idim, q an entry of row b * idim + m of remap_in with column c -- of
+//   drop((c_out * c_in) * J_b[o][m]),   drop(t) = |t| < 1e-9 ? 0 : t   (libsanm/sparse_solver.cpp:291-293),
+// summed in the order (p, m, q).  The triples are enumerated AT ASSEMBLY TIME from the two remap tables (round 5):
+// rounds 1-4 kept a gather list per non-zero -- 31 M (index, coefficient) pairs = 372 MB for armadillo_small, 3 GB for
+// the 338 k-tet mesh, built on the host at set-up (the largest part of the solver's construction) and streamed from
+// HBM at every assembly.  Column n of remap_in (the continuation parameter t of ANMImplicitSolver) goes to grad_t.
 struct AssemblyDev {
-    const uint32_t* ptr;  // nslots+1
-    const uint32_t* jidx;
-    const double* coef;
-    int64_t nslots;
+    const uint32_t* ro_ptr;  // remap_out by unknown: n + 1
+    const uint32_t* ro_idx;  // output element b * odim + o (global batch index b)
+    const double* ro_coef;
+    const uint32_t* ri_ptr;  // remap_in by placeholder element b * idim + m: T * idim + 1
+    const uint32_t* ri_idx;  // unknown (or n: the t column)
+    const double* ri_coef;
+    const uint32_t* rowptr;  // CSR pattern of A (columns ascending in a row)
+    const uint32_t* col;
+    int64_t n;
+    int32_t odim, idim;
+    int64_t tet_begin, tet_end;  // batch items whose blocks `jac` holds ([b - tet_begin][odim][idim]); the others'
+                                 // contributions are another rank's
+    int32_t has_t;
 };
 
 // One phase of a classical Gram-Schmidt step of the Pade basis (pade.cpp:36-70), as a value the backend may run at
@@ -159,7 +174,8 @@ public:
     virtual void gather_rows(const SparseRowsDev& R, const double* src, double* dst, const int32_t* perm = nullptr,
                              double* dst2 = nullptr) = 0;
     //! Jacobian values into a fixed CSR pattern (anm.cpp:362-438 + sparse_solver.cpp:250-305)
-    virtual void assemble(const AssemblyDev& A, const double* jac, double* val) = 0;
+    //! val: the CSR values; grad_t: n doubles (the t column), with A.has_t only
+    virtual void assemble(const AssemblyDev& A, const double* jac, double* val, double* grad_t) = 0;
     //! y = A x  (SparseSolver::apply, sparse_solver.cpp:202-215)
     virtual void spmv(const CsrDev& A, const double* x, double* y) = 0;
 

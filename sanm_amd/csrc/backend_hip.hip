@@ -134,35 +134,109 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(SparseRowsDev R, const
     }
 }
 
-// CSR assembly: ROW_LANES lanes per non-zero (~25 contributions each)
-__global__ void __launch_bounds__(256) assemble_kernel(AssemblyDev A, const double* __restrict__ jac,
-                                                       double* __restrict__ val) {
-    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t s = gid / ROW_LANES;
-    int sub = gid % ROW_LANES;
-    double v = 0;
-    if (s < A.nslots) {
-        const uint32_t p0 = A.ptr[s], e = A.ptr[s + 1];
-        for (uint32_t base = p0; base < e; base += 4 * ROW_LANES) {  // 4 index -> value chains in flight
-            uint32_t j[4];
-            double c[4];
+// CSR assembly (backend.h: AssemblyDev): one workgroup per row of A.  The row's triples (p, m, q) are enumerated in
+// order from the two remap tables into LDS -- column and value (c_out * c_in) * J --, then every non-zero of the row
+// (one thread each, plus one for the t column) walks the staged triples and adds up the ones with its column, in
+// order: the sum of a non-zero is the sequential one of row_ops.h (the host harness's), whatever the launch shape.
+// No gather list exists any more; what the kernel reads is the tables (a few bytes per tet) and the Jacobian blocks.
+constexpr int ASM_THREADS = 128;
+constexpr int ASM_PAIRS = 1024;  // (entry of the remap_out row, m) pairs per block
+constexpr int ASM_CHUNK = 1024;  // staged triples per pass
+constexpr int ASM_NZT = 2;       // non-zeros per thread and sweep
+__global__ void __launch_bounds__(ASM_THREADS) assemble_kernel(AssemblyDev A, const double* __restrict__ jac,
+                                                               double* __restrict__ val, double* __restrict__ grad_t) {
+    const int64_t i = blockIdx.x;
+    __shared__ uint32_t tcol[ASM_CHUNK];
+    __shared__ double tprod[ASM_CHUNK];
+    __shared__ uint32_t poff[ASM_PAIRS + 1];
+    const int tid = threadIdx.x;
+    const uint32_t p0 = A.ro_ptr[i];
+    const int64_t npairs = (int64_t)(A.ro_ptr[i + 1] - p0) * A.idim;
+    const uint32_t c0row = A.rowptr[i];
+    const int nnz_row = (int)(A.rowptr[i + 1] - c0row);
+    const int ntarget = nnz_row + (A.has_t ? 1 : 0);  // (the last target is the t column)
+    for (int nz0 = 0; nz0 < ntarget; nz0 += ASM_THREADS * ASM_NZT) {
+        double acc[ASM_NZT];
+        uint32_t target[ASM_NZT];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t q = base + sub + u * ROW_LANES;
-                const uint32_t qq = q < e ? q : p0;
-                j[u] = A.jidx[qq];
-                const double cv = A.coef[qq];
-                c[u] = q < e ? cv : 0.0;
+        for (int z = 0; z < ASM_NZT; ++z) {
+            acc[z] = 0.0;
+            const int t = nz0 + tid + ASM_THREADS * z;
+            target[z] = t < nnz_row ? A.col[c0row + t] : (t < ntarget ? (uint32_t)A.n : 0xffffffffu);
+        }
+        for (int64_t pb = 0; pb < npairs; pb += ASM_PAIRS) {
+            const int np = (int)min((int64_t)ASM_PAIRS, npairs - pb);
+            // triples per pair (own batch items only), then their offsets
+            for (int q = tid; q < np; q += ASM_THREADS) {
+                const int64_t pair = pb + q;
+                const uint32_t e = A.ro_idx[p0 + pair / A.idim];
+                const int64_t b = e / A.odim;
+                const int64_t irow = b * A.idim + pair % A.idim;
+                const bool mine = b >= A.tet_begin && b < A.tet_end;
+                poff[q] = mine ? A.ri_ptr[irow + 1] - A.ri_ptr[irow] : 0u;
             }
+            __syncthreads();
+            if (tid < 64) {  // exclusive scan by one wavefront, 64 pairs at a time
+                uint32_t carry = 0;
+                for (int base = 0; base < np; base += 64) {
+                    const int q = base + tid;
+                    const uint32_t v = q < np ? poff[q] : 0u;
+                    uint32_t incl = v;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const double t = c[u] * jac[j[u]];
-                if (fabs(t) >= 1e-9) v += t;  // libsanm/sparse_solver.cpp:291-293
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const uint32_t o = __shfl_up(incl, off, 64);
+                        if (tid >= off) incl += o;
+                    }
+                    if (q < np) poff[q] = carry + incl - v;
+                    carry += __shfl(incl, 63, 64);
+                }
+                if (tid == 0) poff[np] = carry;
+            }
+            __syncthreads();
+            const uint32_t total = poff[np];
+            for (uint32_t cb = 0; cb < total; cb += ASM_CHUNK) {
+                for (int q = tid; q < np; q += ASM_THREADS) {
+                    const uint32_t off = poff[q], cnt = poff[q + 1] - off;
+                    if (cnt == 0 || off + cnt <= cb || off >= cb + ASM_CHUNK) continue;
+                    const int64_t pair = pb + q;
+                    const uint32_t pe = p0 + (uint32_t)(pair / A.idim);
+                    const int m = (int)(pair % A.idim);
+                    const uint32_t e = A.ro_idx[pe];
+                    const int64_t b = e / A.odim;
+                    const int o = (int)(e % A.odim);
+                    const double c_out = A.ro_coef[pe];
+                    const double J = jac[((b - A.tet_begin) * A.odim + o) * A.idim + m];
+                    const uint32_t r0 = A.ri_ptr[b * A.idim + m];
+                    for (uint32_t r = 0; r < cnt; ++r) {
+                        const uint32_t kk = off + r;
+                        if (kk < cb || kk >= cb + ASM_CHUNK) continue;
+                        tcol[kk - cb] = A.ri_idx[r0 + r];
+                        tprod[kk - cb] = (c_out * A.ri_coef[r0 + r]) * J;
+                    }
+                }
+                __syncthreads();
+                const int nn = (int)min((uint32_t)ASM_CHUNK, total - cb);
+#pragma unroll
+                for (int z = 0; z < ASM_NZT; ++z) {
+                    if (target[z] == 0xffffffffu) continue;
+                    double a = acc[z];
+                    for (int kk = 0; kk < nn; ++kk)
+                        if (tcol[kk] == target[z]) {
+                            const double t = tprod[kk];
+                            if (fabs(t) >= 1e-9) a += t;  // libsanm/sparse_solver.cpp:291-293
+                        }
+                    acc[z] = a;
+                }
+                __syncthreads();
             }
         }
+#pragma unroll
+        for (int z = 0; z < ASM_NZT; ++z) {
+            const int t = nz0 + tid + ASM_THREADS * z;
+            if (t < nnz_row) val[c0row + t] = acc[z];
+            else if (t < ntarget) grad_t[i] = acc[z];
+        }
     }
-    for (int off = ROW_LANES / 2; off > 0; off >>= 1) v += __shfl_down(v, off, ROW_LANES);
-    if (s < A.nslots && sub == 0) val[s] = v;
 }
 
 __global__ void gather_kernel(size_t n, const double* __restrict__ src, const uint32_t* __restrict__ idx,
@@ -1742,9 +1816,9 @@ public:
                                m_stream, R, src, dst, perm, dst2);
         HIP_CHECK(hipGetLastError());
     }
-    void assemble(const AssemblyDev& A, const double* jac, double* val) override {
-        SANM_LAUNCH(assemble_kernel, dim3(nblk((size_t)A.nslots * ROW_LANES, 256)), dim3(256), 0,
-                           m_stream, A, jac, val);
+    void assemble(const AssemblyDev& A, const double* jac, double* val, double* grad_t) override {
+        sanm_check(!A.has_t || grad_t, "assembly with a t column needs grad_t");
+        SANM_LAUNCH(assemble_kernel, dim3((unsigned)A.n), dim3(ASM_THREADS), 0, m_stream, A, jac, val, grad_t);
         HIP_CHECK(hipGetLastError());
     }
     void gather(size_t n, const double* src, const uint32_t* idx, double* dst) override {
@@ -1889,12 +1963,27 @@ public:
             const char* env_small = std::getenv("SANM_MF_SMALL_MIN_FRONTS");
             const int small_min = env_small ? std::atoi(env_small) : kSmallMinFronts;
             if (small_min > 0 && nfront >= small_min && L.max_k <= SF_KMAX && !L.two_phase) {
-                const int ks = L.max_k | 1;
-                const size_t lds = std::max<size_t>(((size_t)ks * ks + 4 * (size_t)ks) * sizeof(double),
-                                                    (size_t)GK * (2 * GT + 5) * sizeof(double));
-                if (lds > 48 * 1024)
-                    HIP_CHECK(hipFuncSetAttribute((const void*)small_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-                SANM_LAUNCH(small_front_kernel, dim3(nfront), dim3(256), lds, m_stream, MF_FACTOR_ARGS(mf, L.front_begin), ks);
+                // The pivot block's LDS decides how many fronts a compute unit works on at a time: the level's fronts
+                // are sorted by decreasing pivot count (MfSchedule), so they go out in up to three launches by size
+                // class -- k <= 96 (78 KB: two workgroups per unit), k <= 64 (34 KB: four), k <= 44 (the GEMM
+                // staging's 17 KB)
+                const int cls[3] = {SF_KMAX, 64, 44};
+                int begin = 0;
+                for (int c = 0; c < 3 && begin < nfront; ++c) {
+                    const int kmax = std::min(cls[c], c == 0 ? L.max_k : cls[c]);
+                    const int lower = c + 1 < 3 ? cls[c + 1] : 0;
+                    int end = begin;
+                    while (end < nfront && L.front_k[end] > lower) ++end;
+                    if (end == begin) continue;
+                    const int ks = std::min(kmax, (int)L.front_k[begin]) | 1;
+                    const size_t lds = std::max<size_t>(((size_t)ks * ks + 4 * (size_t)ks) * sizeof(double),
+                                                        (size_t)GK * (2 * GT + 5) * sizeof(double));
+                    if (lds > 48 * 1024)
+                        HIP_CHECK(hipFuncSetAttribute((const void*)small_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                    SANM_LAUNCH(small_front_kernel, dim3(end - begin), dim3(256), lds, m_stream,
+                                MF_FACTOR_ARGS(mf, L.front_begin + begin), ks);
+                    begin = end;
+                }
                 continue;
             }
             const int nt = (2 * L.max_k + NB - 1) / NB;  // pivot + augmentation block

@@ -93,6 +93,7 @@ struct MfSchedule {
         // done); a solve sweep over the level is then two dependent launches (pivot block, then boundary block).
         bool two_phase = false;
         std::vector<int32_t> panel_cnt;  // number of fronts with k > p*NB
+        std::vector<int32_t> front_k;    // pivot counts of the level's fronts in launch order (decreasing)
         // extend-add rounds: round r holds the r-th child of every front of the
         // level; [begin,end) into ea_children
         std::vector<std::pair<int32_t, int32_t>> ea_rounds;

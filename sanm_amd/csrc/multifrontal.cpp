@@ -1122,6 +1122,7 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
             }
             tmp_doubles = std::max(tmp_doubles, t);
         }
+        for (int32_t f : fs) L.front_k.push_back(fr[f].k);
         L.nr_panel = (L.max_k + MF_NB - 1) / MF_NB;
         L.panel_cnt.assign(L.nr_panel, 0);
         for (int32_t f : fs)

@@ -15,15 +15,37 @@ SANM_HD double gather_row(const SparseRowsDev& R, const double* src, int64_t i) 
     return s;
 }
 
-// One CSR value: sum of its contributions, each dropped if |c| < 1e-9
-// (SparseMatBuilder::add_constraint, libsanm/sparse_solver.cpp:286-305)
-SANM_HD double assemble_slot(const AssemblyDev& A, const double* jac, int64_t s) {
-    double v = 0;
-    for (uint32_t p = A.ptr[s], e = A.ptr[s + 1]; p < e; ++p) {
-        double c = A.coef[p] * jac[A.jidx[p]];
-        if (fabs(c) >= 1e-9) v += c;
+// One row of the Jacobian's values (backend.h: AssemblyDev): the triples (p, m, q) in order, each product dropped if
+// |c| < 1e-9 (SparseMatBuilder::add_constraint, libsanm/sparse_solver.cpp:286-305), added to the non-zero of its column.
+// pos: scratch of n + 1 entries, all -1 on entry and on exit.  Host harness only (the device kernel stages the triples
+// in LDS: backend_hip.hip, assemble_kernel); both add a non-zero's contributions in the same order.
+inline void assemble_row(const AssemblyDev& A, const double* jac, int64_t i, double* val, double* grad_t, int32_t* pos) {
+    const uint32_t c0 = A.rowptr[i], c1 = A.rowptr[i + 1];
+    for (uint32_t p = c0; p < c1; ++p) {
+        pos[A.col[p]] = (int32_t)(p - c0);
+        val[p] = 0.0;
     }
-    return v;
+    double gt = 0.0;
+    for (uint32_t p = A.ro_ptr[i]; p < A.ro_ptr[i + 1]; ++p) {
+        const uint32_t e = A.ro_idx[p];
+        const int64_t b = e / A.odim;
+        if (b < A.tet_begin || b >= A.tet_end) continue;
+        const int o = (int)(e % A.odim);
+        const double c_out = A.ro_coef[p];
+        for (int m = 0; m < A.idim; ++m) {
+            const double J = jac[((b - A.tet_begin) * A.odim + o) * A.idim + m];
+            const int64_t irow = b * A.idim + m;
+            for (uint32_t q = A.ri_ptr[irow]; q < A.ri_ptr[irow + 1]; ++q) {
+                const double t = (c_out * A.ri_coef[q]) * J;
+                if (!(fabs(t) >= 1e-9)) continue;
+                const uint32_t c = A.ri_idx[q];
+                if ((int64_t)c == A.n) gt += t;
+                else val[c0 + pos[c]] += t;
+            }
+        }
+    }
+    for (uint32_t p = c0; p < c1; ++p) pos[A.col[p]] = -1;
+    if (A.has_t && grad_t) grad_t[i] = gt;
 }
 
 SANM_HD double spmv_row(const CsrDev& A, const double* x, int64_t i) {

@@ -119,20 +119,18 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
     sanm_check(ri.in_size == n || ri.in_size == n + 1, "remap_in must take n or n+1 inputs");
     m_has_t = ri.in_size == n + 1;
 
-    // Row i of remap_out . blockdiag(J_e) . remap_in: every (output entry, Jacobian entry, input entry)
-    // triple is one contribution to CSR entry (i, col); contributions of one entry keep the order in which
-    // the triples are enumerated (that fixes the summation order of the assembly kernel).  ~1500
-    // contributions per row and n rows: the rows are independent, so they are built by several host threads
-    // (this is the largest part of the setup of a large mesh) and grouped by a stable counting sort over the
-    // ~100 distinct columns of a row instead of a comparison sort.
-    struct Contrib {
-        uint32_t col, jidx;
-        double coef;
-        bool mine;  // the tet belongs to this rank's shard
-    };
+    // The pattern: row i of remap_out . blockdiag(J_e) . remap_in holds the columns of the remap_in rows of the batch
+    // items row i of remap_out touches.  Only the pattern is built here; the values are assembled from the two remap
+    // tables on the device (backend.h: AssemblyDev).  Rows are independent: several host threads, each with a dense
+    // marker over the columns.
+    sanm_check(ro.idx.size() < std::numeric_limits<uint32_t>::max() && ri.idx.size() < std::numeric_limits<uint32_t>::max() &&
+                       (uint64_t)T * std::max(odim, idim) < std::numeric_limits<uint32_t>::max(),
+               "remap tables too large for 32-bit indices");
+    sanm_check((uint64_t)(tet_end - tet_begin) * odim * idim < std::numeric_limits<uint32_t>::max(),
+               "mesh too large for 32-bit Jacobian block indices");
     struct Part {
-        std::vector<uint32_t> row_nnz, col, acnt, ajidx, tcnt, tjidx;  // acnt: contributions per CSR entry
-        std::vector<double> acoef, tcoef;
+        std::vector<uint32_t> row_nnz, col;
+        int64_t contrib = 0;
         std::string error;
     };
     const int nthread = (int)std::max<int64_t>(
@@ -141,68 +139,36 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
     auto build = [&](int t) {
         Part& P = parts[t];
         const int64_t r0 = n * t / nthread, r1 = n * (t + 1) / nthread;
-        std::vector<Contrib> row, sorted;
-        std::vector<uint32_t> ucol, rank, start;
+        std::vector<uint8_t> mark(n + 1, 0);
+        std::vector<uint32_t> ucol;
         try {
             for (int64_t i = r0; i < r1; ++i) {
-                row.clear();
-                for (uint64_t p = ro.rowptr[i]; p < ro.rowptr[i + 1]; ++p) {
-                    uint64_t b = ro.idx[p] / odim, o = ro.idx[p] % odim;
-                    double c_out = ro.coef[p];
-                    for (int m = 0; m < idim; ++m) {
-                        uint64_t irow = b * idim + m;
-                        const bool mine = (int64_t)b >= tet_begin && (int64_t)b < tet_end;
-                        // (index into the placeholder's Jacobian, tet-major [T][odim][idim])
-                        uint64_t jidx = mine ? (uint64_t)(b - tet_begin) * odim * idim + o * idim + m : 0;
-                        sanm_check(jidx < std::numeric_limits<uint32_t>::max(), "mesh too large for u32 jidx");
-                        for (uint64_t q = ri.rowptr[irow]; q < ri.rowptr[irow + 1]; ++q)
-                            row.push_back({(uint32_t)ri.idx[q], (uint32_t)jidx, c_out * ri.coef[q], mine});
-                    }
-                }
-                // distinct columns, ascending; stable counting sort of the contributions by column
                 ucol.clear();
-                for (const Contrib& c : row) ucol.push_back(c.col);
-                std::sort(ucol.begin(), ucol.end());
-                ucol.erase(std::unique(ucol.begin(), ucol.end()), ucol.end());
-                rank.resize(row.size());
-                start.assign(ucol.size() + 1, 0);
-                for (size_t k = 0; k < row.size(); ++k) {
-                    rank[k] = std::lower_bound(ucol.begin(), ucol.end(), row[k].col) - ucol.begin();
-                    start[rank[k] + 1]++;
-                }
-                for (size_t u = 0; u < ucol.size(); ++u) start[u + 1] += start[u];
-                sorted.resize(row.size());
-                {
-                    std::vector<uint32_t>& fill = rank;  // reuse: position counters per column
-                    std::vector<uint32_t> pos(start.begin(), start.end() - 1);
-                    for (size_t k = 0; k < row.size(); ++k) sorted[pos[fill[k]]++] = row[k];
-                }
-                uint32_t nnz_row = 0, tcount = 0;
-                for (size_t u = 0; u < ucol.size(); ++u) {
-                    const uint32_t c = ucol[u];
-                    if ((int64_t)c == n) {  // the t column -> grad_t
-                        for (uint32_t k = start[u]; k < start[u + 1]; ++k) {
-                            if (!sorted[k].mine) continue;
-                            P.tjidx.push_back(sorted[k].jidx);
-                            P.tcoef.push_back(sorted[k].coef);
-                            ++tcount;
+                for (uint64_t p = ro.rowptr[i]; p < ro.rowptr[i + 1]; ++p) {
+                    const uint64_t b = ro.idx[p] / odim;
+                    const bool mine = (int64_t)b >= tet_begin && (int64_t)b < tet_end;
+                    for (int m = 0; m < idim; ++m) {
+                        const uint64_t irow = b * idim + m;
+                        for (uint64_t q = ri.rowptr[irow]; q < ri.rowptr[irow + 1]; ++q) {
+                            const uint32_t c = (uint32_t)ri.idx[q];
+                            if (!mark[c]) {
+                                mark[c] = 1;
+                                ucol.push_back(c);
+                            }
                         }
-                        continue;
+                        if (mine) P.contrib += (int64_t)(ri.rowptr[irow + 1] - ri.rowptr[irow]);
                     }
+                }
+                std::sort(ucol.begin(), ucol.end());
+                uint32_t nnz_row = 0;
+                for (uint32_t c : ucol) {
+                    mark[c] = 0;
+                    if ((int64_t)c == n) continue;  // the t column -> grad_t
                     P.col.push_back(c);
                     ++nnz_row;
-                    uint32_t cnt = 0;
-                    for (uint32_t k = start[u]; k < start[u + 1]; ++k) {
-                        if (!sorted[k].mine) continue;
-                        P.ajidx.push_back(sorted[k].jidx);
-                        P.acoef.push_back(sorted[k].coef);
-                        ++cnt;
-                    }
-                    P.acnt.push_back(cnt);
                 }
                 sanm_check(nnz_row > 0, "empty row %ld", (long)i);  // sparse_solver.cpp:251-252
                 P.row_nnz.push_back(nnz_row);
-                P.tcnt.push_back(tcount);
             }
         } catch (const SanmError& e) {
             P.error = e.msg;
@@ -216,39 +182,18 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
     }
     for (const Part& P : parts) sanm_check(P.error.empty(), "%s", P.error.c_str());
     std::vector<uint32_t> rowptr(n + 1, 0), col;
-    std::vector<uint32_t> aptr{0}, ajidx;
-    std::vector<double> acoef;
-    std::vector<uint32_t> tptr(n + 1, 0), tjidx;
-    std::vector<double> tcoef;
     {
-        size_t ncol = 0, ncon = 0, nt = 0;
-        for (const Part& P : parts) {
-            ncol += P.col.size();
-            ncon += P.ajidx.size();
-            nt += P.tjidx.size();
-        }
-        sanm_check(ncon < std::numeric_limits<uint32_t>::max(), "assembly list too large");
+        size_t ncol = 0;
+        for (const Part& P : parts) ncol += P.col.size();
+        sanm_check(ncol < std::numeric_limits<uint32_t>::max(), "Jacobian pattern too large");
         col.reserve(ncol);
-        aptr.reserve(ncol + 1);
-        ajidx.reserve(ncon);
-        acoef.reserve(ncon);
-        tjidx.reserve(nt);
-        tcoef.reserve(nt);
         int64_t i = 0;
         for (const Part& P : parts) {
-            for (size_t r = 0; r < P.row_nnz.size(); ++r, ++i) {
-                rowptr[i + 1] = rowptr[i] + P.row_nnz[r];
-                tptr[i + 1] = tptr[i] + P.tcnt[r];
-            }
+            for (size_t r = 0; r < P.row_nnz.size(); ++r, ++i) rowptr[i + 1] = rowptr[i] + P.row_nnz[r];
             col.insert(col.end(), P.col.begin(), P.col.end());
-            for (uint32_t c : P.acnt) aptr.push_back(aptr.back() + c);
-            ajidx.insert(ajidx.end(), P.ajidx.begin(), P.ajidx.end());
-            acoef.insert(acoef.end(), P.acoef.begin(), P.acoef.end());
-            tjidx.insert(tjidx.end(), P.tjidx.begin(), P.tjidx.end());
-            tcoef.insert(tcoef.end(), P.tcoef.begin(), P.tcoef.end());
+            m_nr_contrib += P.contrib;
         }
     }
-    m_nr_contrib = ajidx.size();
     m_h_rowptr = rowptr;
     m_h_col = col;
 
@@ -258,8 +203,22 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
     m_csr.col = upload(col);
     std::vector<double> zeros(col.size(), 0.0);
     m_csr.val = upload(zeros);
-    m_asm = {upload(aptr), upload(ajidx), upload(acoef), (int64_t)col.size()};
-    if (m_has_t) m_asm_t = {upload(tptr), upload(tjidx), upload(tcoef), n};
+    // the remap tables as the assembly reads them
+    auto narrow = [](const std::vector<uint64_t>& v) { return std::vector<uint32_t>(v.begin(), v.end()); };
+    m_asm.ro_ptr = upload(narrow(ro.rowptr));
+    m_asm.ro_idx = upload(narrow(ro.idx));
+    m_asm.ro_coef = upload(ro.coef);
+    m_asm.ri_ptr = upload(narrow(ri.rowptr));
+    m_asm.ri_idx = upload(narrow(ri.idx));
+    m_asm.ri_coef = upload(ri.coef);
+    m_asm.rowptr = m_csr.rowptr;
+    m_asm.col = m_csr.col;
+    m_asm.n = n;
+    m_asm.odim = odim;
+    m_asm.idim = idim;
+    m_asm.tet_begin = tet_begin;
+    m_asm.tet_end = tet_end;
+    m_asm.has_t = m_has_t ? 1 : 0;
 }
 
 JacobianPattern::~JacobianPattern() {

@@ -65,7 +65,6 @@ public:
     CsrDev csr() const { return m_csr; }
     AssemblyDev assembly() const { return m_asm; }
     bool has_t() const { return m_has_t; }
-    AssemblyDev assembly_grad_t() const { return m_asm_t; }
     int64_t n() const { return m_csr.n; }
     int64_t nnz() const { return m_csr.nnz; }
     int64_t nr_contrib() const { return m_nr_contrib; }
@@ -75,7 +74,7 @@ public:
 private:
     Backend* m_be;
     CsrDev m_csr{};
-    AssemblyDev m_asm{}, m_asm_t{};
+    AssemblyDev m_asm{};
     bool m_has_t = false;
     int64_t m_nr_contrib = 0;
     std::vector<uint32_t> m_h_rowptr, m_h_col;

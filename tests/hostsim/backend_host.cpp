@@ -220,10 +220,11 @@ public:
             if (perm) dst2[perm[i]] = dst[i];
         }
     }
-    void assemble(const AssemblyDev& A, const double* jac, double* val) override {
+    void assemble(const AssemblyDev& A, const double* jac, double* val, double* grad_t) override {
         // worker-parallel by rows in the reference (anm.cpp:384-390)
-        m_pool.run(A.nslots, [&](int64_t sb, int64_t se) {
-            for (int64_t s = sb; s < se; ++s) val[s] = assemble_slot(A, jac, s);
+        m_pool.run(A.n, [&](int64_t sb, int64_t se) {
+            std::vector<int32_t> pos(A.n + 1, -1);
+            for (int64_t i = sb; i < se; ++i) assemble_row(A, jac, i, val, grad_t, pos.data());
         });
     }
     void gather(size_t n, const double* src, const uint32_t* idx, double* dst) override {
