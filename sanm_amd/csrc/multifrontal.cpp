@@ -1,11 +1,15 @@
 #include "multifrontal.h"
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
+#include <future>
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <string>
 
 namespace sanm_hip {
 
@@ -23,6 +27,23 @@ struct SvGraph {
     std::vector<double> xyz;         // nsv*3 centroid coordinates (empty if unknown)
     int32_t size(int32_t s) const { return sv_ptr[s + 1] - sv_ptr[s]; }
 };
+
+// contiguous ranges of [0, n) on a few host threads (the analysis is part of the solver's construction, i.e. of the
+// reference's time_solve: its loops over the rows of a big pattern are worth the threads)
+template <class F>
+void parallel_ranges(int64_t n, int64_t min_per_thread, F&& fn) {
+    const char* env_thr = std::getenv("SANM_MF_ND_THREADS");
+    const int64_t cap = env_thr ? std::atoi(env_thr) : (int64_t)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(cap, n / std::max<int64_t>(min_per_thread, 1)));
+    if (nt <= 1) {
+        fn(0, n, 0);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back([&, t] { fn(n * t / nt, n * (t + 1) / nt, t); });
+    fn(0, n / nt, 0);
+    for (auto& x : th) x.join();
+}
 
 SvGraph build_sv_graph(int64_t n, const std::vector<uint32_t>& rowptr,
                        const std::vector<uint32_t>& col, const double* coords) {
@@ -51,21 +72,27 @@ SvGraph build_sv_graph(int64_t n, const std::vector<uint32_t>& rowptr,
                 }
             }
     }
-    // sort + unique every list, hash it
+    // sort + unique every list, hash it (rows in parallel, in place), then close the gaps
     std::vector<int32_t> uptr(n + 1, 0);
     std::vector<uint64_t> hash(n);
     {
+        std::vector<int32_t> ulen(n);
+        parallel_ranges(n, 8192, [&](int64_t r0, int64_t r1, int) {
+            for (int64_t i = r0; i < r1; ++i) {
+                int32_t b = deg[i], e = deg[i + 1];
+                std::sort(nb.begin() + b, nb.begin() + e);
+                int32_t ne = std::unique(nb.begin() + b, nb.begin() + e) - nb.begin();
+                uint64_t h = 1469598103934665603ull;
+                for (int32_t q = b; q < ne; ++q) h = (h ^ (uint64_t)nb[q]) * 1099511628211ull;
+                hash[i] = h;
+                ulen[i] = ne - b;
+            }
+        });
         int32_t w = 0;
         for (int64_t i = 0; i < n; ++i) {
-            int32_t b = deg[i], e = deg[i + 1];
-            std::sort(nb.begin() + b, nb.begin() + e);
-            int32_t ne = std::unique(nb.begin() + b, nb.begin() + e) - nb.begin();
-            uint64_t h = 1469598103934665603ull;
-            for (int32_t q = b; q < ne; ++q) {
-                h = (h ^ (uint64_t)nb[q]) * 1099511628211ull;
-                nb[w++] = nb[q];
-            }
-            hash[i] = h;
+            const int32_t b = deg[i];
+            if (w != b) std::memmove(nb.data() + w, nb.data() + b, (size_t)ulen[i] * sizeof(int32_t));
+            w += ulen[i];
             uptr[i + 1] = w;
         }
         nb.resize(w);
@@ -194,6 +221,59 @@ public:
     std::vector<int32_t> in_set;  // set id of every supervariable (-1: none)
     int32_t next_set = 0;
 
+    // Subtrees of the dissection are independent of each other -- bisect() looks at its set and at the graph only --,
+    // so the top of the tree hands its parts to threads (round 5: the analysis is part of the reference's time_solve;
+    // 1.0 of the 1.8 s of a 235 k-unknown analysis was this loop).  Every thread works in a NestedDissection of its
+    // own (private marks and queues); the nodes are then numbered exactly as the sequential loop below numbers them --
+    // a node when it is popped, the parts of a set in the reverse of the order they were pushed --, so the tree, the
+    // elimination order and with them every bit of the factorisation are those of one thread
+    // (tests/test_direct_solver.py).  SANM_MF_ND_THREADS: the thread budget (1: sequential).
+    static std::vector<NdNode> dissect(const SvGraph& g, std::vector<int32_t> set, int budget) {
+        NestedDissection nd{g};
+        nd.in_set.assign(g.nsv, -1);
+        {
+            const int32_t mark = nd.next_set++;
+            for (int32_t u : set) nd.in_set[u] = mark;
+        }
+        if (budget <= 1 || (int)set.size() < 4096) {
+            std::vector<std::pair<std::vector<int32_t>, int32_t>> work;
+            work.emplace_back(std::move(set), -1);
+            nd.drain(work);
+            return std::move(nd.nodes);
+        }
+        std::vector<NdNode> out(1);
+        std::vector<int32_t> sep, pa, pb;
+        nd.bisect(set, sep, pa, pb);
+        if (pa.empty() || pb.empty()) {
+            out[0].vars = std::move(set);
+            return out;
+        }
+        out[0].vars = std::move(sep);
+        std::vector<std::pair<std::vector<int32_t>, int32_t>> parts;
+        nd.split_components(pa, 0, parts);
+        nd.split_components(pb, 0, parts);
+        // the sequential loop pops the part pushed last first
+        std::reverse(parts.begin(), parts.end());
+        size_t total = 0;
+        for (const auto& p : parts) total += p.first.size();
+        std::vector<std::future<std::vector<NdNode>>> subs;
+        for (auto& p : parts) {
+            const int share = std::max<int>(1, (int)std::lround((double)budget * p.first.size() / std::max<size_t>(total, 1)));
+            subs.push_back(std::async(std::launch::async, &NestedDissection::dissect, std::cref(g), std::move(p.first), share));
+        }
+        for (auto& f : subs) {
+            std::vector<NdNode> sub = f.get();
+            const int32_t off = (int32_t)out.size();
+            out[0].children.push_back(off);
+            for (auto& nd2 : sub) {
+                nd2.parent = nd2.parent < 0 ? 0 : nd2.parent + off;
+                for (auto& c : nd2.children) c += off;
+                out.push_back(std::move(nd2));
+            }
+        }
+        return out;
+    }
+
     void run() {
         in_set.assign(g.nsv, -1);
         // connected components of the whole graph are independent roots
@@ -201,6 +281,25 @@ public:
         std::iota(all.begin(), all.end(), 0);
         std::vector<std::pair<std::vector<int32_t>, int32_t>> work;  // (connected set, parent)
         split_components(all, -1, work);
+        const char* env_thr = std::getenv("SANM_MF_ND_THREADS");
+        const int budget = env_thr ? std::atoi(env_thr) : (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+        if (budget > 1 && g.nsv >= 8192) {
+            // (the roots in the order the loop below pops them)
+            for (size_t w = work.size(); w-- > 0;) {
+                std::vector<NdNode> sub = dissect(g, std::move(work[w].first), budget);
+                const int32_t off = (int32_t)nodes.size();
+                for (auto& nd2 : sub) {
+                    if (nd2.parent >= 0) nd2.parent += off;
+                    for (auto& c : nd2.children) c += off;
+                    nodes.push_back(std::move(nd2));
+                }
+            }
+            return;
+        }
+        drain(work);
+    }
+
+    void drain(std::vector<std::pair<std::vector<int32_t>, int32_t>>& work) {
         while (!work.empty()) {
             auto [set, parent] = std::move(work.back());
             work.pop_back();
@@ -224,7 +323,6 @@ public:
         }
     }
 
-private:
     void split_components(const std::vector<int32_t>& set, int32_t parent,
                           std::vector<std::pair<std::vector<int32_t>, int32_t>>& out) {
         int32_t mark = next_set++;
@@ -749,11 +847,21 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     sanm_check(world >= 1 && rank >= 0 && rank < world, "multifrontal: rank %d of %d", rank, world);
     sanm_check(n > 0 && (int64_t)rowptr.size() == n + 1, "bad CSR pattern");
     sanm_check(n < INT32_MAX / 2, "system too large for 32-bit indices");
+    const bool dbg_clock = std::getenv("SANM_MF_DEBUG") != nullptr;
+    auto t_clock = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!dbg_clock) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "mf analysis: %-28s %.3f s\n", what, std::chrono::duration<double>(t1 - t_clock).count());
+        t_clock = t1;
+    };
     SvGraph g = build_sv_graph(n, rowptr, col, coords);
+    lap("supervariable graph");
     nr_supervar = g.nsv;
     used_coords = coords != nullptr;
     NestedDissection nd{g};
     nd.run();
+    lap("nested dissection");
     amalgamate_levels(nd.nodes, g);
     int32_t F = 0;
     std::vector<int32_t> post, fid, parent, height, sv_front, sv_start, own_start, kf, perm;
@@ -856,6 +964,7 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
         }
     }
     nr_front = F;
+    lap("tree order, boundaries");
 
     std::vector<MfFrontDev> fr(F);
     std::vector<double> front_flops(F, 0.0);
@@ -1060,6 +1169,7 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
             }
     }
 
+    lap("fronts, rel, inboxes");
     // owner front of every new index
     std::vector<int32_t> owner(n);
     for (int32_t f = 0; f < F; ++f)
@@ -1068,13 +1178,24 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     // scatter map of A
     const int64_t nnzA = col.size();
     std::vector<int64_t> a_dst(nnzA);
-    for (int64_t i = 0; i < n; ++i)
-        for (uint32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
-            int32_t pi = perm[i], pj = perm[col[p]];
-            int32_t f = owner[std::min(pi, pj)];
-            a_dst[p] = fr[f].off + (int64_t)pos_in_front(f, pi) * fr[f].ld + pos_in_front(f, pj);
-        }
+    {
+        std::vector<std::string> errs(64);
+        parallel_ranges(n, 8192, [&](int64_t r0, int64_t r1, int t) {
+            try {
+                for (int64_t i = r0; i < r1; ++i)
+                    for (uint32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+                        int32_t pi = perm[i], pj = perm[col[p]];
+                        int32_t f = owner[std::min(pi, pj)];
+                        a_dst[p] = fr[f].off + (int64_t)pos_in_front(f, pi) * fr[f].ld + pos_in_front(f, pj);
+                    }
+            } catch (const SanmError& e) {
+                errs[t % 64] = e.msg;
+            }
+        });
+        for (const auto& e : errs) sanm_check(e.empty(), "%s", e.c_str());
+    }
 
+    lap("scatter map of A");
     // levels: fronts by height, by decreasing k inside a level.  Distributed: this rank's own subtrees first (part 0),
     // then the replicated top (part 1); fronts of other ranks' subtrees are in no level of this schedule.
     int32_t H = 0;
@@ -1164,6 +1285,7 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
         }
     }
 
+    lap("levels");
     // device copies
     m_dev.n = n;
     m_dev.nnzA = nnzA;
@@ -1204,6 +1326,7 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     m_bufs.push_back(m_dev.work);
     m_bufs.push_back(m_dev.status);
 
+    lap("device tables");
     // ---- exchange tables of the distributed schedule (MfSchedule::Dist) -----------------------------------------
     if (D.enabled) {
         std::vector<MfCopy2D> sp, su, ip, iu;

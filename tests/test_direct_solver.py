@@ -257,3 +257,34 @@ def test_small_fronts_in_one_workgroup_forced(api, monkeypatch, leaf):
     A.sort_indices()
     ds = DirectSolver(api, A)
     assert ds.factor(A) >= 1
+
+
+def test_parallel_analysis_gives_the_sequential_ordering(api, monkeypatch):
+    """the nested dissection hands the subtrees at the top of its tree to host threads and numbers the nodes as the
+    sequential loop does (multifrontal.cpp, NestedDissection::dissect; the row loops of the supervariable graph and of
+    the scatter map run on threads too): same tree, same elimination order, hence the same factorisation -- the
+    statistics of the analysis and the bits of a solve with 1 and with 8 threads."""
+    mesh = ofea.make_cuboid(32, 20, 16, 0.02)
+    nv = mesh.nr_vertices
+    T = mesh.tets
+    rows = np.repeat(T, 4, axis=1).ravel()
+    cols = np.tile(T, (1, 4)).ravel()
+    G = sp.csr_matrix((np.ones(rows.size), (rows, cols)), shape=(nv, nv))
+    G.sum_duplicates()
+    G.data[:] = 1.0
+    rng = np.random.default_rng(5)
+    A = sp.kron(G, np.ones((3, 3)), format="csr")
+    A.data = rng.standard_normal(A.nnz) * 0.1
+    A = sp.csr_matrix(A + sp.diags(np.full(3 * nv, 40.0)))
+    A.sort_indices()
+    coords = np.repeat(mesh.V, 3, axis=0)
+    b = rng.standard_normal(A.shape[0])
+    out = []
+    for threads in ("1", "8"):
+        monkeypatch.setenv("SANM_MF_ND_THREADS", threads)
+        ds = DirectSolver(api, A, coords)
+        assert ds.factor(A) == 0
+        out.append((ds.stats(), ds.solve(b)))
+    assert out[0][0] == out[1][0] and out[0][0]["nr_supervar"] == nv >= 8192
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.abs(A @ out[0][1] - b).max() < 1e-9
