@@ -65,6 +65,18 @@ struct AssemblyDev {
     int64_t tet_begin, tet_end;  // batch items whose blocks `jac` holds ([b - tet_begin][odim][idim]); the others'
                                  // contributions are another rank's
     int32_t has_t;
+    // Device back end: the triples of every non-zero as a gather list (index into jac, c_out * c_in) in enumeration
+    // order, BUILT ON THE DEVICE from the tables above when the pattern is created (Backend::prepare_assembly: two
+    // passes of one workgroup per row, ~25 ms for 235 k unknowns where the host loop of rounds 1-4 took 1.7 s).
+    // Enumerating the triples at every assembly instead was measured (round 5): 14x slower than streaming the list.
+    // nullptr on the host harness, which assembles from the tables (row_ops.h: assemble_row).
+    const uint32_t* aptr = nullptr;   // nnz + 1
+    const uint32_t* ajidx = nullptr;
+    const double* acoef = nullptr;
+    const uint32_t* tptr = nullptr;   // n + 1 (the t column's triples by row), with has_t
+    const uint32_t* tjidx = nullptr;
+    const double* tcoef = nullptr;
+    int64_t nnz = 0;
 };
 
 // One phase of a classical Gram-Schmidt step of the Pade basis (pade.cpp:36-70), as a value the backend may run at
@@ -176,6 +188,12 @@ public:
     //! Jacobian values into a fixed CSR pattern (anm.cpp:362-438 + sparse_solver.cpp:250-305)
     //! val: the CSR values; grad_t: n doubles (the t column), with A.has_t only
     virtual void assemble(const AssemblyDev& A, const double* jac, double* val, double* grad_t) = 0;
+    //! once per pattern: whatever the back end wants beside the tables (the device builds its gather lists); buffers
+    //! it allocates go to `owned` (the pattern frees them)
+    virtual void prepare_assembly(AssemblyDev& A, std::vector<void*>& owned) {
+        (void)A;
+        (void)owned;
+    }
     //! y = A x  (SparseSolver::apply, sparse_solver.cpp:202-215)
     virtual void spmv(const CsrDev& A, const double* x, double* y) = 0;
 

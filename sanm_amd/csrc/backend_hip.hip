@@ -134,20 +134,23 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(SparseRowsDev R, const
     }
 }
 
-// CSR assembly (backend.h: AssemblyDev): one workgroup per row of A.  The row's triples (p, m, q) are enumerated in
-// order from the two remap tables into LDS -- column and value (c_out * c_in) * J --, then every non-zero of the row
-// (one thread each, plus one for the t column) walks the staged triples and adds up the ones with its column, in
-// order: the sum of a non-zero is the sequential one of row_ops.h (the host harness's), whatever the launch shape.
-// No gather list exists any more; what the kernel reads is the tables (a few bytes per tet) and the Jacobian blocks.
+// Gather lists of the assembly, built on the device (backend.h: AssemblyDev): one workgroup per row of A.  The row's
+// triples (p, m, q) are enumerated in order from the two remap tables into LDS -- column, index into the Jacobian
+// blocks, c_out * c_in --, then every non-zero of the row (one thread each, plus one for the t column) walks the staged
+// triples: MODE 0 counts the ones with its column, MODE 1 writes them to its slice of the list, in order.
 constexpr int ASM_THREADS = 128;
 constexpr int ASM_PAIRS = 1024;  // (entry of the remap_out row, m) pairs per block
 constexpr int ASM_CHUNK = 1024;  // staged triples per pass
 constexpr int ASM_NZT = 2;       // non-zeros per thread and sweep
-__global__ void __launch_bounds__(ASM_THREADS) assemble_kernel(AssemblyDev A, const double* __restrict__ jac,
-                                                               double* __restrict__ val, double* __restrict__ grad_t) {
+template <int MODE>
+__global__ void __launch_bounds__(ASM_THREADS) asm_list_kernel(AssemblyDev A, uint32_t* __restrict__ cnt,
+                                                               uint32_t* __restrict__ tcnt, uint32_t* __restrict__ out_jidx,
+                                                               double* __restrict__ out_coef, uint32_t* __restrict__ out_tjidx,
+                                                               double* __restrict__ out_tcoef) {
     const int64_t i = blockIdx.x;
     __shared__ uint32_t tcol[ASM_CHUNK];
-    __shared__ double tprod[ASM_CHUNK];
+    __shared__ uint32_t tjx[ASM_CHUNK];
+    __shared__ double tcf[ASM_CHUNK];
     __shared__ uint32_t poff[ASM_PAIRS + 1];
     const int tid = threadIdx.x;
     const uint32_t p0 = A.ro_ptr[i];
@@ -156,13 +159,14 @@ __global__ void __launch_bounds__(ASM_THREADS) assemble_kernel(AssemblyDev A, co
     const int nnz_row = (int)(A.rowptr[i + 1] - c0row);
     const int ntarget = nnz_row + (A.has_t ? 1 : 0);  // (the last target is the t column)
     for (int nz0 = 0; nz0 < ntarget; nz0 += ASM_THREADS * ASM_NZT) {
-        double acc[ASM_NZT];
-        uint32_t target[ASM_NZT];
+        uint32_t seen[ASM_NZT], target[ASM_NZT], base[ASM_NZT];
 #pragma unroll
         for (int z = 0; z < ASM_NZT; ++z) {
-            acc[z] = 0.0;
+            seen[z] = 0;
             const int t = nz0 + tid + ASM_THREADS * z;
             target[z] = t < nnz_row ? A.col[c0row + t] : (t < ntarget ? (uint32_t)A.n : 0xffffffffu);
+            base[z] = 0;
+            if (MODE == 1) base[z] = t < nnz_row ? A.aptr[c0row + t] : (t < ntarget ? A.tptr[i] : 0u);
         }
         for (int64_t pb = 0; pb < npairs; pb += ASM_PAIRS) {
             const int np = (int)min((int64_t)ASM_PAIRS, npairs - pb);
@@ -178,8 +182,8 @@ __global__ void __launch_bounds__(ASM_THREADS) assemble_kernel(AssemblyDev A, co
             __syncthreads();
             if (tid < 64) {  // exclusive scan by one wavefront, 64 pairs at a time
                 uint32_t carry = 0;
-                for (int base = 0; base < np; base += 64) {
-                    const int q = base + tid;
+                for (int b0 = 0; b0 < np; b0 += 64) {
+                    const int q = b0 + tid;
                     const uint32_t v = q < np ? poff[q] : 0u;
                     uint32_t incl = v;
 #pragma unroll
@@ -196,8 +200,8 @@ __global__ void __launch_bounds__(ASM_THREADS) assemble_kernel(AssemblyDev A, co
             const uint32_t total = poff[np];
             for (uint32_t cb = 0; cb < total; cb += ASM_CHUNK) {
                 for (int q = tid; q < np; q += ASM_THREADS) {
-                    const uint32_t off = poff[q], cnt = poff[q + 1] - off;
-                    if (cnt == 0 || off + cnt <= cb || off >= cb + ASM_CHUNK) continue;
+                    const uint32_t off = poff[q], cn = poff[q + 1] - off;
+                    if (cn == 0 || off + cn <= cb || off >= cb + ASM_CHUNK) continue;
                     const int64_t pair = pb + q;
                     const uint32_t pe = p0 + (uint32_t)(pair / A.idim);
                     const int m = (int)(pair % A.idim);
@@ -205,13 +209,16 @@ __global__ void __launch_bounds__(ASM_THREADS) assemble_kernel(AssemblyDev A, co
                     const int64_t b = e / A.odim;
                     const int o = (int)(e % A.odim);
                     const double c_out = A.ro_coef[pe];
-                    const double J = jac[((b - A.tet_begin) * A.odim + o) * A.idim + m];
+                    const uint32_t jx = (uint32_t)(((b - A.tet_begin) * A.odim + o) * A.idim + m);
                     const uint32_t r0 = A.ri_ptr[b * A.idim + m];
-                    for (uint32_t r = 0; r < cnt; ++r) {
+                    for (uint32_t r = 0; r < cn; ++r) {
                         const uint32_t kk = off + r;
                         if (kk < cb || kk >= cb + ASM_CHUNK) continue;
                         tcol[kk - cb] = A.ri_idx[r0 + r];
-                        tprod[kk - cb] = (c_out * A.ri_coef[r0 + r]) * J;
+                        if (MODE == 1) {
+                            tjx[kk - cb] = jx;
+                            tcf[kk - cb] = c_out * A.ri_coef[r0 + r];
+                        }
                     }
                 }
                 __syncthreads();
@@ -219,24 +226,67 @@ __global__ void __launch_bounds__(ASM_THREADS) assemble_kernel(AssemblyDev A, co
 #pragma unroll
                 for (int z = 0; z < ASM_NZT; ++z) {
                     if (target[z] == 0xffffffffu) continue;
-                    double a = acc[z];
+                    const bool is_t = target[z] == (uint32_t)A.n;
                     for (int kk = 0; kk < nn; ++kk)
                         if (tcol[kk] == target[z]) {
-                            const double t = tprod[kk];
-                            if (fabs(t) >= 1e-9) a += t;  // libsanm/sparse_solver.cpp:291-293
+                            if (MODE == 1) {
+                                const uint32_t w = base[z] + seen[z];
+                                (is_t ? out_tjidx : out_jidx)[w] = tjx[kk];
+                                (is_t ? out_tcoef : out_coef)[w] = tcf[kk];
+                            }
+                            ++seen[z];
                         }
-                    acc[z] = a;
                 }
                 __syncthreads();
             }
         }
+        if (MODE == 0) {
 #pragma unroll
-        for (int z = 0; z < ASM_NZT; ++z) {
-            const int t = nz0 + tid + ASM_THREADS * z;
-            if (t < nnz_row) val[c0row + t] = acc[z];
-            else if (t < ntarget) grad_t[i] = acc[z];
+            for (int z = 0; z < ASM_NZT; ++z) {
+                const int t = nz0 + tid + ASM_THREADS * z;
+                if (t < nnz_row) cnt[c0row + t] = seen[z];
+                else if (t < ntarget) tcnt[i] = seen[z];
+            }
         }
     }
+}
+
+
+// CSR assembly: ROW_LANES lanes per non-zero (~25 contributions each)
+struct AsmList {
+    const uint32_t* ptr;
+    const uint32_t* jidx;
+    const double* coef;
+    int64_t nslots;
+};
+__global__ void __launch_bounds__(256) assemble_kernel(AsmList A, const double* __restrict__ jac,
+                                                       double* __restrict__ val) {
+    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t s = gid / ROW_LANES;
+    int sub = gid % ROW_LANES;
+    double v = 0;
+    if (s < A.nslots) {
+        const uint32_t p0 = A.ptr[s], e = A.ptr[s + 1];
+        for (uint32_t base = p0; base < e; base += 4 * ROW_LANES) {  // 4 index -> value chains in flight
+            uint32_t j[4];
+            double c[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t q = base + sub + u * ROW_LANES;
+                const uint32_t qq = q < e ? q : p0;
+                j[u] = A.jidx[qq];
+                const double cv = A.coef[qq];
+                c[u] = q < e ? cv : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double t = c[u] * jac[j[u]];
+                if (fabs(t) >= 1e-9) v += t;  // libsanm/sparse_solver.cpp:291-293
+            }
+        }
+    }
+    for (int off = ROW_LANES / 2; off > 0; off >>= 1) v += __shfl_down(v, off, ROW_LANES);
+    if (s < A.nslots && sub == 0) val[s] = v;
 }
 
 __global__ void gather_kernel(size_t n, const double* __restrict__ src, const uint32_t* __restrict__ idx,
@@ -1817,9 +1867,60 @@ public:
         HIP_CHECK(hipGetLastError());
     }
     void assemble(const AssemblyDev& A, const double* jac, double* val, double* grad_t) override {
+        sanm_check(A.aptr, "assembly lists were not prepared");
         sanm_check(!A.has_t || grad_t, "assembly with a t column needs grad_t");
-        SANM_LAUNCH(assemble_kernel, dim3((unsigned)A.n), dim3(ASM_THREADS), 0, m_stream, A, jac, val, grad_t);
+        const AsmList L{A.aptr, A.ajidx, A.acoef, A.nnz};
+        SANM_LAUNCH(assemble_kernel, dim3(nblk(L.nslots * ROW_LANES, 256)), dim3(256), 0, m_stream, L, jac, val);
+        if (A.has_t) {
+            const AsmList Lt{A.tptr, A.tjidx, A.tcoef, A.n};
+            SANM_LAUNCH(assemble_kernel, dim3(nblk(Lt.nslots * ROW_LANES, 256)), dim3(256), 0, m_stream, Lt, jac, grad_t);
+        }
         HIP_CHECK(hipGetLastError());
+    }
+    void prepare_assembly(AssemblyDev& A, std::vector<void*>& owned) override {
+        // counts per non-zero (and per row for the t column), offsets on the host, then the lists themselves
+        const size_t nnz = (size_t)A.nnz, n = (size_t)A.n;
+        uint32_t* cnt = static_cast<uint32_t*>(alloc((nnz + 1) * 4));
+        uint32_t* tcnt = static_cast<uint32_t*>(alloc((n + 1) * 4));
+        owned.push_back(cnt);
+        owned.push_back(tcnt);
+        zero(tcnt, (n + 1) * 4);
+        SANM_LAUNCH(asm_list_kernel<0>, dim3((unsigned)n), dim3(ASM_THREADS), 0, m_stream, A, cnt, tcnt, nullptr, nullptr,
+                    nullptr, nullptr);
+        HIP_CHECK(hipGetLastError());
+        std::vector<uint32_t> h(nnz + 1), ht(n + 1);
+        d2h(h.data(), cnt, nnz * 4);
+        d2h(ht.data(), tcnt, n * 4);
+        auto scan = [](std::vector<uint32_t>& v, size_t m, const char* what) {
+            uint64_t run = 0;
+            for (size_t q = 0; q < m; ++q) {
+                const uint32_t c = v[q];
+                v[q] = (uint32_t)run;
+                run += c;
+            }
+            sanm_check(run < std::numeric_limits<uint32_t>::max(), "%s list too large", what);
+            v[m] = (uint32_t)run;
+            return (size_t)run;
+        };
+        const size_t tot = scan(h, nnz, "assembly"), ttot = scan(ht, n, "grad_t");
+        h2d(cnt, h.data(), (nnz + 1) * 4);
+        h2d(tcnt, ht.data(), (n + 1) * 4);
+        uint32_t* jx = static_cast<uint32_t*>(alloc(std::max<size_t>(tot, 1) * 4));
+        double* cf = static_cast<double*>(alloc(std::max<size_t>(tot, 1) * 8));
+        uint32_t* tjx = static_cast<uint32_t*>(alloc(std::max<size_t>(ttot, 1) * 4));
+        double* tcf = static_cast<double*>(alloc(std::max<size_t>(ttot, 1) * 8));
+        owned.push_back(jx);
+        owned.push_back(cf);
+        owned.push_back(tjx);
+        owned.push_back(tcf);
+        A.aptr = cnt;
+        A.tptr = tcnt;
+        SANM_LAUNCH(asm_list_kernel<1>, dim3((unsigned)n), dim3(ASM_THREADS), 0, m_stream, A, nullptr, nullptr, jx, cf, tjx, tcf);
+        HIP_CHECK(hipGetLastError());
+        A.ajidx = jx;
+        A.acoef = cf;
+        A.tjidx = tjx;
+        A.tcoef = tcf;
     }
     void gather(size_t n, const double* src, const uint32_t* idx, double* dst) override {
         SANM_LAUNCH(gather_kernel, dim3(nblk(n, 256)), dim3(256), 0, m_stream, n, src, idx, dst);

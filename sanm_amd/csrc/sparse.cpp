@@ -219,6 +219,8 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
     m_asm.tet_begin = tet_begin;
     m_asm.tet_end = tet_end;
     m_asm.has_t = m_has_t ? 1 : 0;
+    m_asm.nnz = m_csr.nnz;
+    be->prepare_assembly(m_asm, m_bufs);
 }
 
 JacobianPattern::~JacobianPattern() {
