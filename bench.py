@@ -418,7 +418,13 @@ class Leg:
         self.state = {"started": False, "solves": 0, "steps_per_solve": [], "cur": 0}
         self.e2e = None
 
+    _barriers = 0
+
     def barrier(self):
+        Leg._barriers += 1
+        die = os.environ.get("SANM_BENCH_TEST_DIE_AT")  # tests only: "<rank>:<n>" -- that rank exits hard at its n-th barrier
+        if die and die == f"{self.rank}:{Leg._barriers}":
+            os._exit(17)
         if self.dist is not None:
             self.dist.barrier()
         device_sync()
@@ -527,6 +533,13 @@ class Leg:
         self.dt = self.max_over_ranks(dt)
         self.steps, self.warmup = steps, warmup
         self.stats = run.solver.stats()
+        # what every rank factors (the direct solver distributed by subtrees): rank 0 reports the table
+        self.rank_stats = None
+        if self.dist is not None:
+            mine = {k: self.stats[k] for k in ("factor_flops_own", "factor_flops_top", "nr_subtree_own")}
+            gathered = [None] * self.world
+            self.dist.all_gather_object(gathered, mine)
+            self.rank_stats = gathered
         # where the step goes: device-event brackets around the phases of two more steps.  Every rank runs them (the
         # sharded solver's collectives need all ranks); rank 0 reports.
         self.meas = measure_families(run, self.one_step, self.cfg, self.stats, self.args)
@@ -569,8 +582,12 @@ class Leg:
                        "solver_stats": {k: stats[k] for k in ("factor_nnz", "factor_flops", "nr_front",
                                                               "nr_level", "max_front")},
                        # rank 0's share when the direct solver is distributed by subtrees (nr_subtree > 0)
-                       "dist_solver": {k: stats[k] for k in ("nr_subtree", "nr_subtree_own", "factor_flops_own",
-                                                             "factor_flops_top")},
+                       "dist_solver": dict({k: stats[k] for k in ("nr_subtree", "nr_subtree_own", "factor_flops_own",
+                                                                  "factor_flops_top")},
+                                           exchange_bytes={"schur_per_factorisation": 8 * stats["dist_schur_doubles"],
+                                                           "inbox_per_solve": 8 * stats["dist_inbox_doubles"],
+                                                           "solution_per_solve": 8 * n if stats["nr_subtree"] else 0},
+                                           per_rank=self.rank_stats),
                        "steps_per_solve": self.state["steps_per_solve"]},
             # the family of kernels the step spends most of its time in (HBM-bound families only; the
             # factorisation is priced against the fp64 matrix-core peak in roofline_families)

@@ -268,6 +268,9 @@ typedef struct sanm_anm_stats {
      * replicated top of the elimination tree -- in the units of factor_flops; nr_subtree == 0: replicated solver */
     double factor_flops_own, factor_flops_top;
     int64_t nr_subtree, nr_subtree_own;
+    /* ... and what its exchanges move, in doubles: the Schur complements of the cut roots once per factorisation, their
+     * update rows once per solve (the third exchange, the solution, is nr_unknown doubles per solve) */
+    int64_t dist_schur_doubles, dist_inbox_doubles;
 } sanm_anm_stats;
 int sanm_anm_get_stats(const sanm_anm_solver* s, sanm_anm_stats* st);
 /* the same for a caller whose sanm_anm_stats may be older (shorter) than the library's: at most st_bytes are written */

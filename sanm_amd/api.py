@@ -60,7 +60,8 @@ class StatsC(C.Structure):
                 ("factor_nnz", C.c_int64), ("nr_front", C.c_int64), ("nr_level", C.c_int64),
                 ("max_front", C.c_int64), ("factor_flops", C.c_double),
                 ("factor_flops_own", C.c_double), ("factor_flops_top", C.c_double),
-                ("nr_subtree", C.c_int64), ("nr_subtree_own", C.c_int64)]
+                ("nr_subtree", C.c_int64), ("nr_subtree_own", C.c_int64),
+                ("dist_schur_doubles", C.c_int64), ("dist_inbox_doubles", C.c_int64)]
 
 
 ENERGY = {"neohookean_i": 0, "neohookean_c": 1, "arap": 2, "stvk_stretch": 3}

@@ -254,6 +254,8 @@ public:
         factor_flops_top = D.flops_top;
         nr_subtree = D.nr_subtree;
         nr_subtree_own = D.nr_subtree_own;
+        dist_schur_doubles = D.schur_doubles;
+        dist_inbox_doubles = D.inbox_doubles;
         m_refine = m_refine_always;
     }
     void prepare() override {

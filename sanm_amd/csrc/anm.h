@@ -118,6 +118,7 @@ public:
     // distributed direct solver (subtree-to-rank, MfSchedule::Dist): what THIS rank factors
     double factor_flops_own = 0, factor_flops_top = 0;
     int64_t nr_subtree = 0, nr_subtree_own = 0;
+    int64_t dist_schur_doubles = 0, dist_inbox_doubles = 0;
 };
 //! sum over the ranks of `count` doubles at a device pointer, in place (the driver's all-reduce: RCCL on the solver's
 //! stream or the C ABI's callback)

@@ -739,6 +739,8 @@ int sanm_anm_get_stats(const sanm_anm_solver* s, sanm_anm_stats* st) {
         st->factor_flops_top = d.linear_solver().factor_flops_top;
         st->nr_subtree = d.linear_solver().nr_subtree;
         st->nr_subtree_own = d.linear_solver().nr_subtree_own;
+        st->dist_schur_doubles = d.linear_solver().dist_schur_doubles;
+        st->dist_inbox_doubles = d.linear_solver().dist_inbox_doubles;
     });
 }
 int sanm_anm_debug_inject(sanm_anm_solver* s, int kind, int order, int64_t index, double value, int scale) {

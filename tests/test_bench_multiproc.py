@@ -185,3 +185,22 @@ def test_refined_workload_mesh_is_a_conforming_subdivision():
     assert set(uf[cnt == 1].ravel().tolist()) == set(np.asarray(fine.surface_vtx).tolist())
     twice = dfea.refine_mesh(dfea.make_cuboid(3, 3, 3, 0.1), 2)
     assert twice.nr_tet == 64 * 5 * 8 and set(np.unique(faces(twice.tets))) <= {1, 2}
+
+
+def test_launcher_ends_the_ranks_when_one_dies_inside_a_collective():
+    """a rank that is killed while the others wait for it in a collective (SANM_BENCH_TEST_DIE_AT: rank 1 exits hard
+    before its second barrier) must not leave the launcher hanging: it reports the dead rank's status, ends the rest by
+    PID and exits non-zero well within the test's time limit"""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["SANM_BENCH_TEST_HOOK"] = "tests.hostsim.bench_hook"
+    env["SANM_BENCH_TEST_DIE_AT"] = "1:2"  # rank 1, at its 2nd barrier
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--workload", "cuboid:5,3,3", "--no-cpu-baseline", "--dist-backend", "gloo",
+                        "--at-scale-workload", "none"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "launcher: rank 1 exited with status" in r.stderr, r.stderr[-2000:]
+    assert time.time() - t0 < 120
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")], "no line from a job that lost a rank"

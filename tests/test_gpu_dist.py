@@ -268,3 +268,72 @@ def test_two_ranks_on_one_gpu_run_the_world_2_branch_of_the_sharded_hip_path():
     # compilation in either constructor)
     assert d["end_to_end"]["setup_seconds"]["jit_cold_source"] == "embedded"
     assert d["end_to_end"]["setup_seconds"]["jit_cached_source"] == "embedded"
+
+
+_TWO_DEVICE_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, {root!r})
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import numpy as np
+import torch
+import torch.distributed as dist
+rank = int(os.environ["RANK"])
+torch.cuda.set_device(rank)
+dist.init_process_group("nccl", init_method="file://" + os.environ["RDZV"], rank=rank, world_size=2,
+                        device_id=torch.device("cuda", rank))
+import sanm_amd
+from sanm_amd import dist as sdist
+from sanm_amd import fea as dfea
+api = sanm_amd.get_api(rank)
+ok = sdist.init_native_comm(api, rank, 2)
+assert ok, "the library communicator did not come up on both ranks"
+world, r = api.comm_query()
+assert (world, r) == (2, rank), (world, r)
+cfg = {{"material": {{"young": 3e3, "poisson": 0.45, "density": 1000.0}}, "g": [0, -9.81, 0], "boundary_thresh": 0.05,
+       "boundary_proj_dir": [-1, 0, 0], "energy_model": "neohookean_c", "order": 12, "disable_pade": True}}
+mesh = lambda: dfea.make_cuboid(12, 5, 5, 0.025)
+ref = dfea.GravityRun(api, mesh(), dict(cfg), solver_rtol=1e-15).run()
+run = dfea.GravityRun(api, mesh(), dict(cfg), shard=(rank, 2, None), solver_rtol=1e-15).run()
+V, Vr = run.vertices(), ref.vertices()
+print(json.dumps({{"rank": rank, "steps": int(run.solver.get_nr_iter()), "ref_steps": int(ref.solver.get_nr_iter()),
+                  "err": float(np.abs(V - Vr).max() / np.abs(Vr).max()), "vsum": float(V.sum()), "rms": float(run.rms[-1])}}), flush=True)
+api.comm_destroy()
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_native_rccl_allreduce_between_two_devices(tmp_path):
+    """ncclAllReduce of the library communicator ACROSS TWO DEVICES: sanm_amd.dist.init_native_comm (identifier
+    broadcast, ncclCommInitRank on both ranks), ncclCommCount == 2, a tet-sharded solve whose nodal sums really are
+    partial on each rank, compared with the unsharded solve on the same devices.  The pool's test boxes have ONE GPU:
+    there the test skips and says so -- it is here so that the first box with two devices runs the collective before
+    the scaling bench does."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev < 2:
+        pytest.skip(f"{ndev} GPU visible: ncclAllReduce between two devices cannot run on this box (the world = 2 branch "
+                    "of the library runs on one GPU through a staged gloo all-reduce in the tests above)")
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["RDZV"] = str(tmp_path / "store")
+    procs = [subprocess.Popen([sys.executable, "-c", _TWO_DEVICE_WORKER.format(root=root)], env=dict(env, RANK=str(r)),
+                              cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=900))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    res = []
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+        res.append(json.loads([l for l in so.splitlines() if l.startswith("{")][-1]))
+    for r in res:
+        assert r["steps"] == r["ref_steps"] and r["err"] < 1e-9 and r["rms"] < 1e-10
+    assert res[0]["vsum"] == res[1]["vsum"]
