@@ -14,6 +14,8 @@ import sys
 
 tag = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # 0: counted below from the trace (one assembly per expansion)
+workload = sys.argv[3] if len(sys.argv) > 3 else "armadillo_small"
+order = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
@@ -42,9 +44,9 @@ tot = sum(v[1] for v in fam.values())
 with open(os.path.join(dst, f"{tag}_kernel_stats.md"), "w") as fo:
     if not steps:
         steps = next((c for k, (c, t) in fam.items() if k == "assemble_kernel"), 14)
-    fo.write(f"# rocprofv3 --kernel-trace --stats of `bench.py --steps 12 --warmup 2` ({tag})\n\n")
-    fo.write("armadillo_small, Neo-Hookean compressible, order 20, 1 MI355X.  Template instantiations of one kernel are\n"
-             f"summed.  {steps} ANM steps in the run (12 timed + 2 warm-up + the bench's 2 family-measurement steps: one\n"
+    fo.write(f"# rocprofv3 --kernel-trace --stats of `bench.py --workload {workload} --no-end-to-end --at-scale-workload none` ({tag})\n\n")
+    fo.write(f"{workload}, order {order}, 1 MI355X.  Template instantiations of one kernel are\n"
+             f"summed.  {steps} ANM steps in the run (timed + warm-up + the bench's 2 family-measurement steps: one\n"
              f"`assemble_kernel` launch each) -> per-step column = total / {steps}.  Full per-instantiation table: `{tag}_kernel_stats.csv`.\n\n")
     fo.write(f"Total kernel time {tot / 1e6:.1f} ms.\n\n")
     fo.write("| kernel | calls | total ms | avg us | ms/step | % |\n|---|---|---|---|---|---|\n")
@@ -66,12 +68,12 @@ def counter(path, name):
 
 fetch = counter(src + "/fetch", "FETCH_SIZE")
 write = counter(src + "/write", "WRITE_SIZE")
-out = {"workload": "armadillo_small", "order": 20,
+out = {"workload": workload, "order": order,
        "note": f"rocprofv3 PMC, FETCH_SIZE doubled per MI355X_MICROARCH.md; see {tag}_pmc_traffic.md", "kernels": {}}
 with open(os.path.join(dst, f"{tag}_pmc_traffic.md"), "w") as fo:
     fo.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, --kernel-trace only)\n\n")
     fo.write("Command: `rocprofv3 --kernel-trace --pmc <COUNTER> --output-format csv -- python3 bench.py --steps 4 "
-             "--warmup 1 --no-cpu-baseline`\n(armadillo_small, order 20, 1 MI355X; scripts/collect_profiles.sh). "
+             f"--warmup 1 --workload {workload} --no-cpu-baseline --no-end-to-end --at-scale-workload none`\n({workload}, order {order}, 1 MI355X; scripts/collect_profiles.sh). "
              "Counter unit: KiB per dispatch. Correction per\nMI355X_MICROARCH.md (HBM): FETCH_SIZE reports 1/2 of the "
              "bytes of a coalesced stream on gfx950 -> doubled; WRITE_SIZE is\nexact (calibrated on axpby_kernel, which "
              "writes n+1 = 38,047 doubles = 297.2 KiB per launch).\n\n")
@@ -97,5 +99,16 @@ for k, (c, v) in fetch.items():
     a[0] += c
     a[1] += out["kernels"][k]["traffic_bytes_per_launch"] * c
 out["families"] = {k: {"dispatches": c, "traffic_bytes_per_launch": v / c} for k, (c, v) in famacc.items()}
-json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+# profiles/pmc_traffic.json: the headline workload at the top level (as before), every other one under "workloads"
+path = os.path.join(dst, "pmc_traffic.json")
+try:
+    cur = json.load(open(path))
+except (OSError, ValueError):
+    cur = {}
+if workload == "armadillo_small":
+    out["workloads"] = cur.get("workloads", {})
+    cur = out
+else:
+    cur.setdefault("workloads", {})[workload] = out
+json.dump(cur, open(path, "w"), indent=1)
 print(open(os.path.join(dst, f"{tag}_pmc_traffic.md")).read())
