@@ -2140,10 +2140,20 @@ public:
                 const int tmax = std::max(tb, tk);
                 // (two-phase levels: the triangular products are the boundary operators, products 1 and 2 left out)
                 const int nwhich = L.two_phase ? 1 : 3;
+                static const bool no_lists = std::getenv("SANM_MF_NO_TILE_LISTS") != nullptr;  // (A/B: the box grids)
+                if (!no_lists && L.g1_tiles) {
+                    if (L.n_g1 > 0)
+                        SANM_LAUNCH(gemm1_list_kernel, dim3(L.n_g1), dim3(256), 0, m_stream, MF_FACTOR_ARGS(mf, L.front_begin),
+                                    L.g1_tiles, (int)L.two_phase);
+                    if (L.n_g2 > 0)
+                        SANM_LAUNCH(gemm2_list_kernel, dim3(L.n_g2), dim3(256), 0, m_stream, MF_FACTOR_ARGS(mf, L.front_begin),
+                                    L.g2_tiles);
+                } else {
                 SANM_LAUNCH(gemm1_kernel, dim3(tmax, tmax, 2 * nfr), dim3(256), 0, m_stream,
                                    MF_FACTOR_ARGS(mf, L.front_begin), (int)L.two_phase);
                 SANM_LAUNCH(gemm2_kernel, dim3(tmax, tmax, nwhich * nfr), dim3(256), 0, m_stream,
                                    MF_FACTOR_ARGS(mf, L.front_begin), nwhich);
+                }
 #ifndef SANM_MF_OLD_STAGING
                 if (L.max_k >= mfk::kTallMinK && L.max_b >= mfk::kTallMinB)  // big fronts: interior of the Schur complement
                     SANM_LAUNCH(gemm2_tall_kernel, dim3(tmax, (tmax + 1) / 2, nfr), dim3(256), 0, m_stream,

@@ -870,6 +870,22 @@ __global__ void __launch_bounds__(256) gemm2_kernel(MF_FACTOR_PARAMS, int nwhich
     gemm2_tile(mf, f, which, ti, tj, As, Bs);
 }
 
+// The same two passes over flat tile lists (mf_types.h, Level::g1_tiles / g2_tiles): blockIdx.x is a tile that exists.
+__global__ void __launch_bounds__(256) gemm1_list_kernel(MF_FACTOR_PARAMS, const uint32_t* __restrict__ tiles, int two_phase) {
+    MF_FACTOR_INIT
+    const uint32_t w0 = tiles[2 * blockIdx.x], w1 = tiles[2 * blockIdx.x + 1];
+    const MfFrontDev f = mf.lfronts[level_begin + w0];
+    __shared__ double As[GK][GT + 1], Bs[GK][GT + 4];
+    gemm1_tile(mf, f, (int)(w1 >> 30), (int)((w1 >> 15) & 32767), (int)(w1 & 32767), As, Bs, two_phase);
+}
+__global__ void __launch_bounds__(256) gemm2_list_kernel(MF_FACTOR_PARAMS, const uint32_t* __restrict__ tiles) {
+    MF_FACTOR_INIT
+    const uint32_t w0 = tiles[2 * blockIdx.x], w1 = tiles[2 * blockIdx.x + 1];
+    const MfFrontDev f = mf.lfronts[level_begin + w0];
+    __shared__ double As[GK][GT + 1], Bs[GK][GT + 4];
+    gemm2_tile(mf, f, (int)(w1 >> 30), (int)((w1 >> 15) & 32767), (int)(w1 & 32767), As, Bs);
+}
+
 // ---- small fronts: the whole factorisation of a front in ONE workgroup (round 5) --------------------------------
 // On the lower levels of a big tree a front has a few dozen pivots and a boundary of a few hundred rows, and there
 // are thousands of them: every tile task of the panel / GEMM launches above is then a handful of dependent memory

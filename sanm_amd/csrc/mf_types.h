@@ -94,6 +94,14 @@ struct MfSchedule {
         bool two_phase = false;
         std::vector<int32_t> panel_cnt;  // number of fronts with k > p*NB
         std::vector<int32_t> front_k;    // pivot counts of the level's fronts in launch order (decreasing)
+        // The 64 x 64 tiles of the level's two GEMM passes as flat lists (device; two words per tile: the front's
+        // position in the level, which << 30 | ti << 15 | tj): a launch of exactly the tiles that exist.  The grids of
+        // rounds 1-4 were boxes (largest tile count of the level)^2 x fronts x products -- on the middle levels of a
+        // big tree 90-95 % of their workgroups found nothing to do, and there were enough of them to BE the launch
+        // time (mf_kernels.h, gemm1_list_kernel).
+        const uint32_t* g1_tiles = nullptr;
+        const uint32_t* g2_tiles = nullptr;
+        int32_t n_g1 = 0, n_g2 = 0;
         // extend-add rounds: round r holds the r-th child of every front of the
         // level; [begin,end) into ea_children
         std::vector<std::pair<int32_t, int32_t>> ea_rounds;

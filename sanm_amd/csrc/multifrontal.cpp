@@ -1261,6 +1261,47 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
         }
     }
 
+    // tile lists of the GEMM passes (mf_types.h, Level::g1_tiles / g2_tiles)
+    for (int32_t h = 0; h < H; ++h) {
+        auto& L = m_sched.levels[h];
+        std::vector<uint32_t> t1, t2;
+        constexpr int GT = 64;
+        for (int32_t i = L.front_begin; i < L.front_end; ++i) {
+            const auto& f = fr[level_fronts[i]];
+            const uint32_t loc = (uint32_t)(i - L.front_begin);
+            const int k = f.k, b = f.m - f.k;
+            if (b == 0) continue;
+            const int tk = (k + GT - 1) / GT, tb = (b + GT - 1) / GT;
+            sanm_check(tk < 32768 && tb < 32768, "front too large for the tile lists");
+            auto push = [](std::vector<uint32_t>& v, uint32_t front, int which, int ti, int tj) {
+                v.push_back(front);
+                v.push_back((uint32_t)which << 30 | (uint32_t)ti << 15 | (uint32_t)tj);
+            };
+            for (int ti = 0; ti < tk; ++ti)
+                for (int tj = 0; tj < tb; ++tj) push(t1, loc, 0, ti, tj);  // tmpU (k x b)
+            for (int ti = 0; ti < tb; ++ti)
+                for (int tj = 0; tj < tk; ++tj) push(t1, loc, 1, ti, tj);  // tmpL (b x k)
+            // (the interior of the Schur complement of a big front belongs to gemm2_tall_kernel: mf_kernels.h,
+            // gemm2_is_tall)
+            auto is_tall = [&](int ti, int tj) {
+                return k >= 512 && b >= 1024 && ((ti & ~1) + 2) * GT <= b && (tj + 1) * GT <= b;
+            };
+            for (int ti = 0; ti < tb; ++ti)
+                for (int tj = 0; tj < tb; ++tj)
+                    if (!is_tall(ti, tj)) push(t2, loc, 0, ti, tj);
+            if (!L.two_phase) {
+                for (int ti = 0; ti < tb; ++ti)
+                    for (int tj = 0; tj < tk; ++tj) push(t2, loc, 1, ti, tj);
+                for (int ti = 0; ti < tk; ++ti)
+                    for (int tj = 0; tj < tb; ++tj) push(t2, loc, 2, ti, tj);
+            }
+        }
+        L.n_g1 = (int32_t)(t1.size() / 2);
+        L.n_g2 = (int32_t)(t2.size() / 2);
+        L.g1_tiles = upload(t1);
+        L.g2_tiles = upload(t2);
+    }
+
     if (std::getenv("SANM_MF_DEBUG")) {
         for (int32_t h = 0; h < H; ++h) {
             const auto& L = m_sched.levels[h];
