@@ -483,11 +483,55 @@ void PadeWorkspace::ensure(Backend* be_, int nx, size_t len) {
     orth.resize(nx);
     for (int i = 1; i < nx; ++i) orth[i] = DVec{be, len};
     acoef = DVec{be, (size_t)nx * nx + nx};
+    tmp_row = DVec{be, (size_t)nx + 1};
     host_acoef = be->alloc_host((size_t)nx * nx);
 }
 
+// SANM_PADE_ORTH=cgs2 (opt-in, round 5): the Pade basis by classical Gram-Schmidt WITH RE-ORTHOGONALISATION ("twice is
+// enough") instead of the reference's single classical sweep (libsanm/pade.cpp:30-55), whose loss of orthogonality --
+// kappa^2 eps on the nearly parallel series vectors -- is what makes the fp64 range decisions of the reference's
+// algorithm differ from their rounding-free outcome (profiles/r05_pade_arbiter_cgs2.json).  The
+// default stays the reference's algorithm: the contract is parity with it.
+int pade_orth_mode() {
+    static const int mode = [] {
+        const char* e = std::getenv("SANM_PADE_ORTH");
+        if (!e || !*e || !std::strcmp(e, "cgs")) return 0;
+        if (!std::strcmp(e, "cgs2")) return 1;
+        sanm_throw(SANM_ERR_ASSERT, "SANM_PADE_ORTH=%s: cgs (the reference's) or cgs2", e);
+    }();
+    return mode;
+}
+
 void PadeWorkspace::step(const std::vector<DVec>& xs, int i, bool anm_cond) {
-    for (int k = 1; k <= 3; ++k) phase(xs, i, k, anm_cond, false);
+    if (pade_orth_mode() == 0 || i < 2) {
+        for (int k = 1; k <= 3; ++k) phase(xs, i, k, anm_cond, false);
+        return;
+    }
+    // u = x_i - sum_j (x_i . q_j) q_j as the reference does, then once more on the result: u -= sum_j (u . q_j) q_j;
+    // the coefficients of the Pade system are the sums of both passes' projections
+    phase(xs, i, 1, anm_cond, false);
+    phase(xs, i, 2, anm_cond, false);
+    const int nx = orth.size();
+    double* row = acoef.p() + (size_t)i * nx;
+    GsPhase p1;
+    p1.kind = 1;
+    p1.n = orth[1].size();
+    p1.x = orth[i].p();
+    p1.nvec = i - 1;
+    p1.vecs.resize(p1.nvec);
+    for (int j = 1; j < i; ++j) p1.vecs[j - 1] = orth[j].p();
+    p1.eps = std::numeric_limits<double>::epsilon();
+    p1.red_out = tmp_row.p() + 1;
+    be->run_gs_phase(p1);
+    GsPhase p2 = p1;
+    p2.kind = 2;
+    p2.coefs = tmp_row.p() + 1;
+    p2.first = anm_cond ? 1 : 0;
+    p2.out = orth[i].p();
+    p2.red_out = row + i;
+    be->run_gs_phase(p2);
+    be->axpby((size_t)(i - 1), 1.0, row + 1, 1.0, tmp_row.p() + 1, row + 1);
+    phase(xs, i, 3, anm_cond, false);
 }
 
 void PadeWorkspace::phase(const std::vector<DVec>& xs, int i, int k, bool anm_cond, bool defer) {
@@ -1192,6 +1236,8 @@ void AnmDriver::solve_expansion_coeffs() {
     static const bool env_pade = getenv("SANM_PADE") != nullptr;
     static const int gs_mode = [] {
         const char* e = getenv("SANM_GS_MODE");
+        // (the re-orthogonalised basis is built step by step behind the order loop: no riders)
+        if (pade_orth_mode() != 0) return 0;
         return !e ? 2 : (!strcmp(e, "tail") ? 0 : (!strcmp(e, "side") ? 1 : 2));
     }();
     const bool anm_cond = !m_hp.xcoeff_l2_penalty;

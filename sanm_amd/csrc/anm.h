@@ -142,6 +142,7 @@ struct PadeWorkspace {
     Backend* be = nullptr;
     std::vector<DVec> orth;
     DVec acoef;
+    DVec tmp_row;  // projections of the re-orthogonalisation pass (SANM_PADE_ORTH=cgs2)
     void* graph = nullptr;
     //! Gram-Schmidt steps 1 .. done of the current series are queued (the driver queues step i on the side
     //! queue as soon as x_i exists: PadeApproximation then finds the basis ready); -1: steps not in use

@@ -1106,6 +1106,155 @@ __global__ void __launch_bounds__(DLU_THREADS) dense_lu_kernel(int64_t n, double
         status[1] = pmax;
     }
 }
+// The same factorisation for systems beyond a few hundred unknowns (round 5: the single workgroup above was the only
+// factorisation path of vector-graph systems up to 4096 unknowns): 32-column panels -- the panel by one workgroup
+// (pivot search over the whole column, interchanges inside the panel), then the interchanges of the rest of the rows and
+// the rows of U beside the panel (a thread per column), then the trailing matrix by 64 x 64 tiles over the chip.  Every
+// element receives the updates of the unblocked loop in the unblocked order, one fma per pivot, so the factors are
+// the single workgroup's bit for bit; columns whose pivot search finds nothing but zeros are skipped like there
+// (`flags`).  acc3 = {smallest pivot, largest pivot, saw a column without a comparable entry}.
+constexpr int DLU_NB = 32;
+__global__ void __launch_bounds__(DLU_THREADS) dense_lu_panel_kernel(int64_t n, double* lu, int32_t* piv, int32_t* flags,
+                                                                     double* acc3, double* status, int64_t c0, int w,
+                                                                     int first, int last) {
+    __shared__ double s_val[DLU_THREADS];
+    __shared__ int s_idx[DLU_THREADS];
+    __shared__ double s_piv;
+    const int t = threadIdx.x;
+    const int lane = t & 63, wv = t >> 6;
+    constexpr int kWaves = DLU_THREADS / 64;
+    double pmin = first ? INFINITY : acc3[0], pmax = first ? 0.0 : acc3[1];
+    bool bad = first ? false : acc3[2] != 0.0;
+    const int64_t ce = c0 + w;
+    for (int64_t c = c0; c < ce; ++c) {
+        double best = -1.0;
+        int bi = 0x7fffffff;
+        for (int64_t r = c + t; r < n; r += DLU_THREADS) {
+            const double v = fabs(lu[r * n + c]);
+            if (v > best) {
+                best = v;
+                bi = (int)r;
+            }
+        }
+        s_val[t] = best;
+        s_idx[t] = bi;
+        __syncthreads();
+        for (int ww = DLU_THREADS / 2; ww > 0; ww >>= 1) {
+            if (t < ww) {
+                const double ov = s_val[t + ww];
+                const int oi = s_idx[t + ww];
+                if (ov > s_val[t] || (ov == s_val[t] && oi < s_idx[t])) {
+                    s_val[t] = ov;
+                    s_idx[t] = oi;
+                }
+            }
+            __syncthreads();
+        }
+        int p = s_idx[0];
+        double pabs = s_val[0];
+        __syncthreads();
+        if (p >= n) {
+            p = (int)c;
+            pabs = 0.0;
+            bad = true;
+        }
+        if (t == 0) {
+            piv[c] = p;
+            flags[c] = pabs == 0.0;
+        }
+        pmin = fmin(pmin, pabs);
+        pmax = fmax(pmax, pabs);
+        if (p != (int)c)
+            for (int64_t j = c0 + t; j < ce; j += DLU_THREADS) {  // (the other columns: dense_lu_rowops_kernel)
+                const double a = lu[c * n + j];
+                lu[c * n + j] = lu[(int64_t)p * n + j];
+                lu[(int64_t)p * n + j] = a;
+            }
+        __syncthreads();
+        if (pabs == 0.0) continue;
+        if (t == 0) s_piv = lu[c * n + c];
+        __syncthreads();
+        const double pv = s_piv;
+        for (int64_t r = c + 1 + t; r < n; r += DLU_THREADS) lu[r * n + c] = lu[r * n + c] / pv;
+        __syncthreads();
+        for (int64_t r = c + 1 + wv; r < n; r += kWaves) {
+            const double l = lu[r * n + c];
+            for (int64_t j = c + 1 + lane; j < ce; j += 64) lu[r * n + j] = __builtin_fma(-l, lu[c * n + j], lu[r * n + j]);
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        acc3[0] = pmin;
+        acc3[1] = pmax;
+        acc3[2] = bad ? 1.0 : 0.0;
+        if (last) {
+            status[0] = bad ? NAN : pmin;
+            status[1] = pmax;
+        }
+    }
+}
+__global__ void __launch_bounds__(256) dense_lu_rowops_kernel(int64_t n, double* lu, const int32_t* __restrict__ piv,
+                                                              const int32_t* __restrict__ flags, int64_t c0, int w) {
+    // a thread per column outside the panel: the panel's interchanges in order, then -- right of the panel -- the
+    // panel rows of U: row r takes the updates of the pivots c < r of the panel
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= c0) j += w;
+    if (j >= n) return;
+    const int64_t ce = c0 + w;
+    for (int64_t c = c0; c < ce; ++c) {
+        const int p = piv[c];
+        if (p != (int)c) {
+            const double a = lu[c * n + j];
+            lu[c * n + j] = lu[(int64_t)p * n + j];
+            lu[(int64_t)p * n + j] = a;
+        }
+    }
+    if (j < ce) return;
+    for (int64_t c = c0; c < ce; ++c) {
+        if (flags[c]) continue;
+        const double u = lu[c * n + j];
+        for (int64_t r = c + 1; r < ce; ++r) lu[r * n + j] = __builtin_fma(-lu[r * n + c], u, lu[r * n + j]);
+    }
+}
+__global__ void __launch_bounds__(256) dense_lu_trailing_kernel(int64_t n, double* lu, const int32_t* __restrict__ flags,
+                                                                int64_t c0, int w) {
+    // 64 x 64 tile of the trailing matrix, 4 x 4 elements per thread; per element one fma per pivot of the panel, in order
+    __shared__ double Lp[64][DLU_NB + 1], Up[DLU_NB][64 + 1];
+    __shared__ int fl[DLU_NB];
+    const int64_t ce = c0 + w, r0 = ce + (int64_t)blockIdx.y * 64, j0 = ce + (int64_t)blockIdx.x * 64;
+    const int t = threadIdx.x;
+    for (int q = t; q < 64 * DLU_NB; q += 256) {
+        const int rr = q / DLU_NB, cc = q % DLU_NB;
+        Lp[rr][cc] = (r0 + rr < n && cc < w) ? lu[(r0 + rr) * n + c0 + cc] : 0.0;
+        const int uc = q / 64, uj = q % 64;
+        Up[uc][uj] = (uc < w && j0 + uj < n) ? lu[(c0 + uc) * n + j0 + uj] : 0.0;
+    }
+    if (t < DLU_NB) fl[t] = t < w ? flags[c0 + t] : 1;
+    __syncthreads();
+    const int ty = t / 16, tx = t % 16;
+    double a[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t r = r0 + ty * 4 + i, j = j0 + tx + 16 * k;
+            a[i][k] = (r < n && j < n) ? lu[r * n + j] : 0.0;
+        }
+    for (int c = 0; c < w; ++c) {
+        if (fl[c]) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[i][k] = __builtin_fma(-Lp[ty * 4 + i][c], Up[c][tx + 16 * k], a[i][k]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t r = r0 + ty * 4 + i, j = j0 + tx + 16 * k;
+            if (r < n && j < n) lu[r * n + j] = a[i][k];
+        }
+}
 __global__ void __launch_bounds__(DLU_THREADS) dense_lu_solve_kernel(int64_t n, const double* lu, const int32_t* piv,
                                                                      const double* b, double* x, double* work) {
     const int t = threadIdx.x;
@@ -1388,9 +1537,39 @@ public:
     int64_t launch_count() const override { return m_launch_count; }
     void dense_lu_factor(const CsrDev& A, double* lu, int32_t* piv, double* status) override {
         SANM_LAUNCH(dense_from_csr_kernel, dim3((unsigned)std::min<int64_t>(A.n, 1024)), dim3(256), 0, m_stream, A, lu);
-        SANM_LAUNCH(dense_lu_kernel, dim3(1), dim3(DLU_THREADS), 0, m_stream, A.n, lu, piv, status);
+        // small systems: the single workgroup; beyond: panels + trailing tiles over the chip (same factors bit for bit).
+        // SANM_DENSE_BLOCKED_MIN_N: from how many unknowns (tests: 0)
+        const char* env = std::getenv("SANM_DENSE_BLOCKED_MIN_N");
+        const int64_t blocked_min = env ? std::atoll(env) : 384;
+        const int64_t n = A.n;
+        if (n < blocked_min) {
+            SANM_LAUNCH(dense_lu_kernel, dim3(1), dim3(DLU_THREADS), 0, m_stream, n, lu, piv, status);
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
+        if ((int64_t)m_dlu_flags_n < n) {
+            if (m_dlu_flags) HIP_CHECK(hipFree(m_dlu_flags));
+            HIP_CHECK(hipMalloc(&m_dlu_flags, n * sizeof(int32_t) + 3 * sizeof(double) + 8));
+            m_dlu_flags_n = n;
+        }
+        int32_t* flags = static_cast<int32_t*>(m_dlu_flags);
+        double* acc3 = reinterpret_cast<double*>(static_cast<char*>(m_dlu_flags) + (n * sizeof(int32_t) + 7) / 8 * 8);
+        for (int64_t c0 = 0; c0 < n; c0 += DLU_NB) {
+            const int w = (int)std::min<int64_t>(DLU_NB, n - c0);
+            SANM_LAUNCH(dense_lu_panel_kernel, dim3(1), dim3(DLU_THREADS), 0, m_stream, n, lu, piv, flags, acc3, status, c0, w,
+                        (int)(c0 == 0), (int)(c0 + w >= n));
+            if (n - w > 0)
+                SANM_LAUNCH(dense_lu_rowops_kernel, dim3(nblk(n - w, 256)), dim3(256), 0, m_stream, n, lu, piv, flags, c0, w);
+            const int64_t rest = n - c0 - w;
+            if (rest > 0) {
+                const unsigned tiles = (unsigned)((rest + 63) / 64);
+                SANM_LAUNCH(dense_lu_trailing_kernel, dim3(tiles, tiles), dim3(256), 0, m_stream, n, lu, flags, c0, w);
+            }
+        }
         HIP_CHECK(hipGetLastError());
     }
+    void* m_dlu_flags = nullptr;
+    size_t m_dlu_flags_n = 0;
     void dense_lu_solve(int64_t n, const double* lu, const int32_t* piv, const double* b, double* x) override {
         if ((int64_t)m_dlu_work_n < n) {
             if (m_dlu_work) HIP_CHECK(hipFree(m_dlu_work));

@@ -139,7 +139,10 @@ class _LockStepBase:
                   "device_roots_valid": bool(dd.get("roots_valid")), "oracle_roots_valid": bool(od.get("roots_valid")),
                   "draws": sorted(set(draws)), "certified": ok}
             self.events.append(ev)
-            assert ok, f"step {k}: outcome {dev} vs the oracle's {own} is not an ill-conditioned decision: {ev}"
+            # (strict=False: a device that runs another algorithm on purpose -- SANM_PADE_ORTH=cgs2 under
+            # scripts/pade_arbiter.py -- is recorded, not judged, and the oracle follows it)
+            assert ok or not getattr(self, "strict", True), \
+                f"step {k}: outcome {dev} vs the oracle's {own} is not an ill-conditioned decision: {ev}"
             rec["forced"] = True
             # the oracle continues with the device's outcome
             if dev[0]:

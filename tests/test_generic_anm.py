@@ -464,3 +464,45 @@ def test_sharded_solver_rejects_vector_graphs(api):
     ident = A.SparseLinearDesc(api, sp.identity(16, format="csr"))
     with pytest.raises(A.SanmUnsupportedError):
         A.ANMEqnSolver(api, y, ident, ident, np.ones(16), -np.ones(16), api.default_hyper(order=4), shard=(0, 2, None))
+
+
+@pytest.mark.gpu
+def test_dense_lu_by_panels_gives_the_single_workgroups_factors(monkeypatch):
+    """systems of graphs on the vector interpreter are solved by a dense LU with partial pivoting; from 384 unknowns on
+    it runs by 32-column panels with the trailing matrix over the whole chip (backend_hip.hip, round 5: the single
+    workgroup was the only path up to 4096 unknowns).  Every element receives the unblocked loop's updates in the
+    unblocked order, so the factors -- and with them the whole continuation -- are the single workgroup's bit for
+    bit: SANM_DENSE_BLOCKED_MIN_N = 0 (panels always) against a huge value (never), on a (12, 5, 5) matrix graph (300
+    unknowns: ten panels, a partial last one) and on random sparse remaps with zero diagonal entries (row interchanges
+    in every panel) of 120 and of 400 unknowns (the latter beyond the default threshold)."""
+    import sanm_amd
+    api = sanm_amd.get_api(0)
+
+    def remap_case(seed, nx, midshp):
+        rng = np.random.default_rng(seed)
+        nmid = int(np.prod(midshp))
+        for _ in range(50):
+            rin, e_in, i_in = _rand_sparse(rng, nx, nmid)
+            rout, e_out, i_out = _rand_sparse(rng, nmid, nx)
+            x1 = rng.uniform(-1, 1, (nx,))
+            J = rout.tocsr() @ sp.diags(2 * (rin.tocsr() @ x1.ravel())) @ rin.tocsr()
+            if not e_out and np.linalg.cond(J.toarray()) < 1e5:
+                break
+        else:
+            pytest.skip("no well-conditioned draw")
+        rin_csr, rout_csr = sp.csr_matrix(rin), sp.csr_matrix(rout)
+        g = lambda x: (rout_csr @ (rin_csr @ x.ravel()) ** 2).reshape((nx,))
+        return lambda: _solve(api, lambda x, M: x.pow(2), x1, g(x1), 1.5, remap_in=rin_csr, remap_out=rout_csr, mid=midshp,
+                              oracle=False)
+
+    x0 = _x0_diag(5, -1, 1, batch=12, m=5)
+    cases = [lambda: _solve(api, lambda x, M: M.batched_mat_inv_mul(x, None, True), x0, np.linalg.inv(x0), 1.5, oracle=False),
+             remap_case(11, 120, (1, 150)), remap_case(12, 400, (2, 225))]
+    monkeypatch.setenv("SANM_DENSE_BLOCKED_MIN_N", "1000000")
+    ref = [c() for c in cases]
+    monkeypatch.setenv("SANM_DENSE_BLOCKED_MIN_N", "0")
+    got = [c() for c in cases]
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)
+    monkeypatch.delenv("SANM_DENSE_BLOCKED_MIN_N")
+    assert np.array_equal(cases[2](), ref[2])
