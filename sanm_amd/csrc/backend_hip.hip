@@ -2261,7 +2261,7 @@ public:
                     if (lds > 48 * 1024)
                         HIP_CHECK(hipFuncSetAttribute((const void*)small_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
                     SANM_LAUNCH(small_front_kernel, dim3(end - begin), dim3(256), lds, m_stream,
-                                MF_FACTOR_ARGS(mf, L.front_begin + begin), ks);
+                                MF_FACTOR_ARGS(mf, L.front_begin + begin), ks, (int)L.fwd_t);
                     begin = end;
                 }
                 continue;
@@ -2326,12 +2326,12 @@ public:
                                     L.g1_tiles, (int)L.two_phase);
                     if (L.n_g2 > 0)
                         SANM_LAUNCH(gemm2_list_kernel, dim3(L.n_g2), dim3(256), 0, m_stream, MF_FACTOR_ARGS(mf, L.front_begin),
-                                    L.g2_tiles);
+                                    L.g2_tiles, (int)L.fwd_t);
                 } else {
                 SANM_LAUNCH(gemm1_kernel, dim3(tmax, tmax, 2 * nfr), dim3(256), 0, m_stream,
                                    MF_FACTOR_ARGS(mf, L.front_begin), (int)L.two_phase);
                 SANM_LAUNCH(gemm2_kernel, dim3(tmax, tmax, nwhich * nfr), dim3(256), 0, m_stream,
-                                   MF_FACTOR_ARGS(mf, L.front_begin), nwhich);
+                                   MF_FACTOR_ARGS(mf, L.front_begin), nwhich, (int)L.fwd_t);
                 }
 #ifndef SANM_MF_OLD_STAGING
                 if (L.max_k >= mfk::kTallMinK && L.max_b >= mfk::kTallMinB)  // big fronts: interior of the Schur complement
@@ -2419,6 +2419,23 @@ public:
                 SANM_LAUNCH((bwd_wide_kernel<4>), dim3((L.max_k + 3) / 4, cnt), dim3(256), 0, m_stream,
                             mf.lfronts + L.front_begin, mf.front_store, mf.work, mf.work2, mf.bnd_idx, phase);
             return;
+        }
+        if (fwd && phase == 0 && L.fwd_t) {
+            // boundary operator stored transposed (Level::fwd_t): pivot rows by lane groups, boundary rows by threads
+            sanm_check(width <= 128, "transposed forward operator on a level of %d-pivot fronts", width);
+            const int cnt = L.front_end - L.front_begin;
+            const size_t lds = ((size_t)L.max_k + 256) * sizeof(double);
+            const int g = width <= 32 ? 8 : (width <= 64 ? 16 : 32);
+            const int nbb = (L.max_b + 63) / 64;
+#define SANM_FT(G)                                                                                                  \
+    if (g == G) {                                                                                                   \
+        const int nzb = (L.max_k + 256 / G * 2 - 1) / (256 / G * 2);                                                \
+        SANM_LAUNCH((fwd_level_tr_kernel<G, 2>), dim3(nzb + nbb, cnt), dim3(256), lds, m_stream,                     \
+                    mf.lfronts + L.front_begin, mf.front_store, mf.inbox_store, mf.work, mf.work2, mf.upd_dst, nzb); \
+        return;                                                                                                     \
+    }
+            SANM_FT(8) SANM_FT(16) SANM_FT(32)
+#undef SANM_FT
         }
         if ((size_t)(fwd || phase == 2 ? L.max_k : L.max_m) * sizeof(double) > lds_max) {
             // vectors beyond the LDS: plain mat-vec kernels on operands in HBM (bandwidth-bound levels)

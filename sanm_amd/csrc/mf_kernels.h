@@ -819,7 +819,7 @@ __global__ void __launch_bounds__(256) gemm2_tall_kernel(MF_FACTOR_PARAMS) {
 //          which = 2: F[A,B]  = -U11^-1 tmpU   (k x b; U11^-1 upper: K tiles ti..)
 //          nwhich = 1 (two-phase levels): product 0 only
 __device__ __forceinline__ void gemm2_tile(const FactorArgs& mf, const MfFrontDev& f, int which, int ti, int tj,
-                                           double (*As)[GT + 1], double (*Bs)[GT + 4]) {
+                                           double (*As)[GT + 1], double (*Bs)[GT + 4], int tr = 0) {
     const int k = f.k, b = f.m - f.k, ld = f.ld;
     const int rows = which == 2 ? k : b, cols = which == 1 ? k : b;
     double* F = mf.front_store + f.off;
@@ -849,12 +849,21 @@ __device__ __forceinline__ void gemm2_tile(const FactorArgs& mf, const MfFrontDe
         gemm_tile_sub_from(acc, C, ld, ti, tj, rows, cols);
         return;
     }
+    if (which == 1 && tr) {
+        // Level::fwd_t: F[B,A] transposed into the dead F[P,B] slot (k rows of b entries)
+        double* CT = F + 2 * k;
+        gemm_tile_foreach(acc, [&](int i, int j, double v) {
+            const int r = ti * GT + i, c = tj * GT + j;
+            if (r < rows && c < cols) CT[(int64_t)c * ld + r] = -v;
+        });
+        return;
+    }
     gemm_tile_foreach(acc, [&](int i, int j, double v) {
         const int r = ti * GT + i, c = tj * GT + j;
         if (r < rows && c < cols) C[(int64_t)r * ld + c] = -v;
     });
 }
-__global__ void __launch_bounds__(256) gemm2_kernel(MF_FACTOR_PARAMS, int nwhich) {
+__global__ void __launch_bounds__(256) gemm2_kernel(MF_FACTOR_PARAMS, int nwhich, int tr) {
     MF_FACTOR_INIT
     const MfFrontDev f = mf.lfronts[level_begin + blockIdx.z / nwhich];
     const int which = blockIdx.z % nwhich;
@@ -867,7 +876,7 @@ __global__ void __launch_bounds__(256) gemm2_kernel(MF_FACTOR_PARAMS, int nwhich
     if (which == 0 && gemm2_is_tall(k, b, rows, cols, ti, tj)) return;
 #endif
     __shared__ double As[GK][GT + 1], Bs[GK][GT + 4];
-    gemm2_tile(mf, f, which, ti, tj, As, Bs);
+    gemm2_tile(mf, f, which, ti, tj, As, Bs, tr);
 }
 
 // The same two passes over flat tile lists (mf_types.h, Level::g1_tiles / g2_tiles): blockIdx.x is a tile that exists.
@@ -878,12 +887,12 @@ __global__ void __launch_bounds__(256) gemm1_list_kernel(MF_FACTOR_PARAMS, const
     __shared__ double As[GK][GT + 1], Bs[GK][GT + 4];
     gemm1_tile(mf, f, (int)(w1 >> 30), (int)((w1 >> 15) & 32767), (int)(w1 & 32767), As, Bs, two_phase);
 }
-__global__ void __launch_bounds__(256) gemm2_list_kernel(MF_FACTOR_PARAMS, const uint32_t* __restrict__ tiles) {
+__global__ void __launch_bounds__(256) gemm2_list_kernel(MF_FACTOR_PARAMS, const uint32_t* __restrict__ tiles, int tr) {
     MF_FACTOR_INIT
     const uint32_t w0 = tiles[2 * blockIdx.x], w1 = tiles[2 * blockIdx.x + 1];
     const MfFrontDev f = mf.lfronts[level_begin + w0];
     __shared__ double As[GK][GT + 1], Bs[GK][GT + 4];
-    gemm2_tile(mf, f, (int)(w1 >> 30), (int)((w1 >> 15) & 32767), (int)(w1 & 32767), As, Bs);
+    gemm2_tile(mf, f, (int)(w1 >> 30), (int)((w1 >> 15) & 32767), (int)(w1 & 32767), As, Bs, tr);
 }
 
 // ---- small fronts: the whole factorisation of a front in ONE workgroup (round 5) --------------------------------
@@ -903,7 +912,7 @@ __global__ void __launch_bounds__(256) gemm2_list_kernel(MF_FACTOR_PARAMS, const
 //      as the separate launches), operands from L2.
 // The pivot block's own factors are not written back: nothing reads F[P,P] after the factorisation.
 constexpr int SF_KMAX = 96;
-__global__ void __launch_bounds__(256) small_front_kernel(MF_FACTOR_PARAMS, int ks) {
+__global__ void __launch_bounds__(256) small_front_kernel(MF_FACTOR_PARAMS, int ks, int tr) {
     MF_FACTOR_INIT
     const MfFrontDev f = mf.lfronts[level_begin + blockIdx.x];
     const int k = f.k, b = f.m - f.k, ld = f.ld;
@@ -1002,7 +1011,7 @@ __global__ void __launch_bounds__(256) small_front_kernel(MF_FACTOR_PARAMS, int 
     for (int ti = 0; ti < tb; ++ti)
         for (int tj = 0; tj < tb; ++tj) gemm2_tile(mf, f, 0, ti, tj, As, Bs);
     for (int ti = 0; ti < tb; ++ti)
-        for (int tj = 0; tj < tk; ++tj) gemm2_tile(mf, f, 1, ti, tj, As, Bs);
+        for (int tj = 0; tj < tk; ++tj) gemm2_tile(mf, f, 1, ti, tj, As, Bs, tr);
     for (int ti = 0; ti < tk; ++ti)
         for (int tj = 0; tj < tb; ++tj) gemm2_tile(mf, f, 2, ti, tj, As, Bs);
 }
@@ -1264,6 +1273,94 @@ __global__ void __launch_bounds__(256) fwd_level_sub_kernel(const MfFrontDev* __
             else mf.inbox_store[dst[q]] = acc + pre[q];
         }
     }
+}
+
+// Forward level kernel for levels whose boundary operator is stored transposed (Level::fwd_t): the first `nzb` blocks
+// of a front take its pivot rows, z = L11^-1 t, G lanes per row like fwd_level_sub_kernel; the others take 64 boundary
+// rows each, a THREAD per row: upd_j = sum_i FT[i][j] t[i] with FT = (F[B,A])' in the F[P,B] slot -- every load of a
+// wavefront is 512 contiguous bytes of one of the k long rows, no reduction across lanes --, the k terms dealt to the
+// four wavefronts in contiguous quarters whose partial sums wavefront 0 adds in order.
+template <int G, int R>
+__global__ void __launch_bounds__(256) fwd_level_tr_kernel(const MfFrontDev* __restrict__ lfronts,
+                                                           const double* __restrict__ front_store, double* inbox_store,
+                                                           double* work, double* work2,
+                                                           const int32_t* __restrict__ upd_dst, int nzb) {
+    const MfFrontDev f = lfronts[blockIdx.y];
+    const int m = f.m, k = f.k, b = m - k;
+    extern __shared__ double vs[];  // t (k entries), then the partial sums [4][64]
+    const int tid = threadIdx.x;
+    const double* inbox = inbox_store + f.inbox_off;
+    if ((int)blockIdx.x < nzb) {
+        constexpr int RPB = 256 / G * R;
+        const int rb = blockIdx.x * RPB;
+        if (rb >= k) return;
+        const int sub = tid % G, r0 = rb + tid / G * R;
+        const double* rowp[R];
+        int cend[R];
+        double a[R][4];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int r = r0 + q;
+            const bool live = r < k;
+            rowp[q] = front_store + f.off + (int64_t)(live ? r : 0) * f.ld + k;
+            cend[q] = live ? r + 1 : 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = sub + G * u;
+                const double v = rowp[q][min(c, k - 1)];
+                a[q][u] = c < cend[q] ? v : 0.0;
+            }
+        }
+        const int kneed = min(k, rb + RPB);
+        for (int c = tid; c < kneed; c += 256) vs[c] = work[f.own_start + c] + inbox_sum(inbox, f.nch, m, c);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            double acc = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_fma(a[q][u], vs[min(sub + G * u, kneed - 1)], acc);
+            for (int c = sub + 4 * G; c < cend[q]; c += G) acc = __builtin_fma(rowp[q][c], vs[c], acc);
+#pragma unroll
+            for (int off = G / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, G);
+            const int r = r0 + q;
+            if (sub == 0 && r < k) work2[f.own_start + r] = acc;
+        }
+        return;
+    }
+    const int jb = ((int)blockIdx.x - nzb) * 64;
+    if (jb >= b) return;
+    const int lane = tid & 63, w = tid >> 6;
+    const int j = jb + lane, jc = min(j, b - 1);
+    // the row's own loads first: destination slot and the children's entries of this boundary row
+    int dst = -1;
+    double pre = 0;
+    if (w == 0 && j < b) {
+        dst = upd_dst[f.bnd_off + j];
+        pre = inbox_sum(inbox, f.nch, m, k + j);
+    }
+    const int i0 = (int)((int64_t)k * w / 4), i1 = (int)((int64_t)k * (w + 1) / 4);
+    const double* col = front_store + f.off + 2 * k + jc;  // FT[i][j] at col[i * ld]
+    constexpr int UN = 8;
+    double av[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) av[u] = col[(int64_t)min(i0 + u, k - 1) * f.ld];  // (in flight across the staging)
+    for (int c = tid; c < k; c += 256) vs[c] = work[f.own_start + c] + inbox_sum(inbox, f.nch, m, c);
+    __syncthreads();
+    double acc = 0;
+    for (int i = i0; i < i1; i += UN) {
+        double nx[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) nx[u] = col[(int64_t)min(i + UN + u, k - 1) * f.ld];
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+            if (i + u < i1) acc = __builtin_fma(av[u], vs[i + u], acc);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) av[u] = nx[u];
+    }
+    double* part = vs + k;
+    part[w * 64 + lane] = acc;
+    __syncthreads();
+    if (w == 0 && j < b) inbox_store[dst] = (((part[lane] + part[64 + lane]) + part[128 + lane]) + part[192 + lane]) + pre;
 }
 
 template <int R, int U>

@@ -92,6 +92,12 @@ struct MfSchedule {
         // F[B,A] / F[A,B] slots instead of the products with the pivot block's inverses (2 k^2 b flops per front not
         // done); a solve sweep over the level is then two dependent launches (pivot block, then boundary block).
         bool two_phase = false;
+        // Transposed forward operator (round 5): the boundary block of the forward sweep, F[B,A] = -L21 L11^-1 (b rows of
+        // k entries at a stride of 2k + b), is written TRANSPOSED into the F[P,B] slot, which is dead once the
+        // triangular products have read it: k long rows of b entries.  The forward kernel then gives a boundary row to
+        // a thread (coalesced loads down the columns, no cross-lane reduction) instead of a row of a few dozen entries to
+        // a lane group.  Levels of short pivot blocks (max_k <= 128) that are not two-phase.
+        bool fwd_t = false;
         std::vector<int32_t> panel_cnt;  // number of fronts with k > p*NB
         std::vector<int32_t> front_k;    // pivot counts of the level's fronts in launch order (decreasing)
         // The 64 x 64 tiles of the level's two GEMM passes as flat lists (device; two words per tile: the front's

@@ -1236,6 +1236,12 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
             max_children = std::max(max_children, children[f].size());
         }
         {
+            // (SANM_MF_FWD_T=0: never; the merged top block reads F[B,A] itself: not together with SANM_MF_TOP)
+            const char* env_ft = std::getenv("SANM_MF_FWD_T");
+            const bool want = env_ft ? std::atoi(env_ft) != 0 : true;
+            L.fwd_t = want && !L.two_phase && L.max_k <= 128 && L.max_b > 0 && !std::getenv("SANM_MF_TOP");
+        }
+        {
             int64_t t = 0;
             for (int32_t f : fs) {
                 fr[f].tmp_off = t;

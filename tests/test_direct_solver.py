@@ -288,3 +288,23 @@ def test_parallel_analysis_gives_the_sequential_ordering(api, monkeypatch):
     assert out[0][0] == out[1][0] and out[0][0]["nr_supervar"] == nv >= 8192
     assert np.array_equal(out[0][1], out[1][1])
     assert np.abs(A @ out[0][1] - b).max() < 1e-9
+
+
+@pytest.mark.parametrize("leaf", ["8", "32"])
+def test_forward_operator_not_transposed(api, monkeypatch, leaf):
+    """levels of fronts of at most 128 pivots keep the boundary block of their forward operator TRANSPOSED in the dead
+    F[P,B] slot and sweep it with a thread per boundary row (mf_types.h, Level::fwd_t; round 5) -- the default, so every
+    other test of this file runs it; SANM_MF_FWD_T=0 is the row-wise form of rounds 1-4 on the same systems, with the
+    small-front kernel forced on and off (it writes the same slot).  (The host harness has its own solve.)"""
+    monkeypatch.setenv("SANM_MF_FWD_T", "0")
+    monkeypatch.setenv("SANM_MF_LEAF", leaf)
+    for small in ("1", "0"):
+        monkeypatch.setenv("SANM_MF_SMALL_MIN_FRONTS", small)
+        test_random_block_unsymmetric(api)
+        test_scalar_pattern_no_blocks(api)
+        test_fem_jacobian(api, True)
+        test_grid3d_wide_separators(api)
+    monkeypatch.setenv("SANM_MF_FWD_T", "1")
+    monkeypatch.setenv("SANM_MF_SMALL_MIN_FRONTS", "1")
+    test_fem_jacobian(api, True)
+    test_grid3d_wide_separators(api)
