@@ -11,6 +11,7 @@
 #include <limits>
 
 #include "multifrontal.h"
+#include "host_parallel.h"
 #include "vecprog_host.h"
 #include "poly.h"
 #include "tet_ops.h"
@@ -840,22 +841,32 @@ std::vector<int64_t> spatial_tet_order(const SparseDesc& remap_inp, const std::v
                                        int64_t n) {
     const int64_t T = remap_inp.out_size / 9;
     std::vector<double> cen((size_t)T * 3, 0.0);
+    constexpr int kMaxThr = 64;
+    double tlo[kMaxThr][3], thi[kMaxThr][3];
+    for (int t = 0; t < kMaxThr; ++t)
+        for (int d = 0; d < 3; ++d) tlo[t][d] = 1e300, thi[t][d] = -1e300;
+    parallel_ranges(T, 16384, [&](int64_t e0, int64_t e1, int t) {
+        double* lo = tlo[t % kMaxThr];  // min / max are exact: any grouping gives the same box
+        double* hi = thi[t % kMaxThr];
+        for (int64_t e = e0; e < e1; ++e) {
+            double acc[3] = {0, 0, 0};
+            int64_t cnt = 0;
+            for (uint64_t q = remap_inp.rowptr[e * 9]; q < remap_inp.rowptr[e * 9 + 9]; ++q) {
+                const int64_t u = remap_inp.idx[q];
+                if (u >= n) continue;  // the t column of the implicit solver
+                for (int d = 0; d < 3; ++d) acc[d] += coords[u * 3 + d];
+                ++cnt;
+            }
+            for (int d = 0; d < 3; ++d) {
+                cen[e * 3 + d] = cnt ? acc[d] / cnt : 0.0;
+                lo[d] = std::min(lo[d], cen[e * 3 + d]);
+                hi[d] = std::max(hi[d], cen[e * 3 + d]);
+            }
+        }
+    });
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (int64_t e = 0; e < T; ++e) {
-        double acc[3] = {0, 0, 0};
-        int64_t cnt = 0;
-        for (uint64_t q = remap_inp.rowptr[e * 9]; q < remap_inp.rowptr[e * 9 + 9]; ++q) {
-            const int64_t u = remap_inp.idx[q];
-            if (u >= n) continue;  // the t column of the implicit solver
-            for (int d = 0; d < 3; ++d) acc[d] += coords[u * 3 + d];
-            ++cnt;
-        }
-        for (int d = 0; d < 3; ++d) {
-            cen[e * 3 + d] = cnt ? acc[d] / cnt : 0.0;
-            lo[d] = std::min(lo[d], cen[e * 3 + d]);
-            hi[d] = std::max(hi[d], cen[e * 3 + d]);
-        }
-    }
+    for (int t = 0; t < kMaxThr; ++t)
+        for (int d = 0; d < 3; ++d) lo[d] = std::min(lo[d], tlo[t][d]), hi[d] = std::max(hi[d], thi[t][d]);
     auto spread = [](uint64_t v) {  // 21 bits -> every third bit
         v &= 0x1fffff;
         v = (v | v << 32) & 0x1f00000000ffffULL;
@@ -866,16 +877,36 @@ std::vector<int64_t> spatial_tet_order(const SparseDesc& remap_inp, const std::v
         return v;
     };
     std::vector<std::pair<uint64_t, int64_t>> key(T);
-    for (int64_t e = 0; e < T; ++e) {
-        uint64_t k = 0;
-        for (int d = 0; d < 3; ++d) {
-            const double ext = hi[d] - lo[d];
-            const double f = ext > 0 ? (cen[e * 3 + d] - lo[d]) / ext : 0.0;
-            k |= spread((uint64_t)(f * 2097151.0)) << d;
+    // sorted pieces merged pairwise: the keys carry the tet number, so the order is total and the result is the
+    // sequential sort's whatever the number of pieces
+    std::vector<int64_t> cut{0};
+    parallel_ranges(T, 16384, [&](int64_t e0, int64_t e1, int) {
+        for (int64_t e = e0; e < e1; ++e) {
+            uint64_t k = 0;
+            for (int d = 0; d < 3; ++d) {
+                const double ext = hi[d] - lo[d];
+                const double f = ext > 0 ? (cen[e * 3 + d] - lo[d]) / ext : 0.0;
+                k |= spread((uint64_t)(f * 2097151.0)) << d;
+            }
+            key[e] = {k, e};
         }
-        key[e] = {k, e};
+        std::sort(key.begin() + e0, key.begin() + e1);
+    });
+    {
+        const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(host_thread_cap(), T / 16384));
+        for (int t = 1; t <= nt; ++t) cut.push_back(T * t / nt);  // the ranges parallel_ranges made
+        while (cut.size() > 2) {
+            const int64_t pairs = (int64_t)(cut.size() - 1) / 2;
+            parallel_ranges(pairs, 1, [&](int64_t p0, int64_t p1, int) {
+                for (int64_t p = p0; p < p1; ++p)
+                    std::inplace_merge(key.begin() + cut[2 * p], key.begin() + cut[2 * p + 1], key.begin() + cut[2 * p + 2]);
+            });
+            std::vector<int64_t> next;
+            for (size_t i = 0; i < cut.size(); i += 2) next.push_back(cut[i]);
+            if (next.back() != T) next.push_back(T);
+            cut.swap(next);
+        }
     }
-    std::sort(key.begin(), key.end());
     std::vector<int64_t> order(T);
     for (int64_t e = 0; e < T; ++e) order[e] = key[e].second;  // new tet e = old tet order[e]
     return order;
@@ -887,18 +918,24 @@ SparseDesc permute_rows_by_tet(const SparseDesc& d, const std::vector<int64_t>& 
     r.out_size = d.out_size;
     r.in_size = d.in_size;
     r.out_coords = d.out_coords;
+    const int64_t T = order.size();
     r.rowptr.assign(d.out_size + 1, 0);
-    r.idx.reserve(d.idx.size());
-    r.coef.reserve(d.coef.size());
-    for (int64_t e = 0; e < (int64_t)order.size(); ++e)
+    for (int64_t e = 0; e < T; ++e)
         for (int c = 0; c < 9; ++c) {
             const int64_t src = order[e] * 9 + c;
-            for (uint64_t q = d.rowptr[src]; q < d.rowptr[src + 1]; ++q) {
-                r.idx.push_back(d.idx[q]);
-                r.coef.push_back(d.coef[q]);
-            }
-            r.rowptr[e * 9 + c + 1] = r.idx.size();
+            r.rowptr[e * 9 + c + 1] = r.rowptr[e * 9 + c] + (d.rowptr[src + 1] - d.rowptr[src]);
         }
+    r.idx.resize(d.idx.size());
+    r.coef.resize(d.coef.size());
+    parallel_ranges(T, 16384, [&](int64_t e0, int64_t e1, int) {
+        for (int64_t e = e0; e < e1; ++e)
+            for (int c = 0; c < 9; ++c) {
+                const int64_t src = order[e] * 9 + c;
+                const uint64_t len = d.rowptr[src + 1] - d.rowptr[src];
+                std::copy_n(d.idx.begin() + d.rowptr[src], len, r.idx.begin() + r.rowptr[e * 9 + c]);
+                std::copy_n(d.coef.begin() + d.rowptr[src], len, r.coef.begin() + r.rowptr[e * 9 + c]);
+            }
+    });
     return r;
 }
 
@@ -906,23 +943,37 @@ SparseDesc permute_rows_by_tet(const SparseDesc& d, const std::vector<int64_t>& 
 SparseDesc permute_inputs_by_tet(const SparseDesc& d, const std::vector<int64_t>& order) {
     std::vector<int64_t> inv(order.size());
     for (size_t e = 0; e < order.size(); ++e) inv[order[e]] = e;
-    SparseDesc r = d;
-    for (auto& i : r.idx) i = (uint64_t)(inv[i / 9] * 9 + i % 9);
+    SparseDesc r;
+    r.out_size = d.out_size;
+    r.in_size = d.in_size;
+    r.out_coords = d.out_coords;
+    r.rowptr = d.rowptr;
+    r.coef = d.coef;
+    r.idx.resize(d.idx.size());
+    parallel_ranges((int64_t)d.idx.size(), 1 << 18, [&](int64_t q0, int64_t q1, int) {
+        for (int64_t q = q0; q < q1; ++q) r.idx[q] = (uint64_t)(inv[d.idx[q] / 9] * 9 + d.idx[q] % 9);
+    });
     return r;
 }
 
 //! the graph with its per-tet constants permuted
 Graph permute_constants_by_tet(const Graph& g, const std::vector<int64_t>& order) {
-    Graph r = g;
     const int64_t T = order.size();
-    for (auto& op : r.ops) {
-        if (op.type != OP_CONSTANT || op.batch != T) continue;
-        const size_t sz = op.value.size() / T;
-        std::vector<double> v(op.value.size());
-        for (int64_t e = 0; e < T; ++e)
-            std::copy(op.value.begin() + order[e] * sz, op.value.begin() + (order[e] + 1) * sz,
-                      v.begin() + e * sz);
-        op.value.swap(v);
+    Graph r;
+    r.vars = g.vars;
+    r.ops.reserve(g.ops.size());
+    for (const auto& src : g.ops) {
+        if (src.type != OP_CONSTANT || src.batch != T) {
+            r.ops.push_back(src);
+            continue;
+        }
+        auto op = src;  // the value is replaced below; nothing else of a constant is per tet
+        const size_t sz = src.value.size() / T;
+        parallel_ranges(T, 16384, [&](int64_t e0, int64_t e1, int) {
+            for (int64_t e = e0; e < e1; ++e)
+                std::copy_n(src.value.begin() + order[e] * sz, sz, op.value.begin() + e * sz);
+        });
+        r.ops.push_back(std::move(op));
     }
     return r;
 }

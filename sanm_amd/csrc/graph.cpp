@@ -1,5 +1,6 @@
 #include "graph.h"
 #include "vecprog_host.h"
+#include "host_parallel.h"
 
 #include <chrono>
 #include <algorithm>
@@ -895,17 +896,23 @@ void Program::set_remap_in(int64_t n_in, const uint64_t* rowptr, const uint64_t*
     nslot = std::max(nslot, 1);
     std::vector<uint32_t> hidx((size_t)nslot * 9 * Tpad, 0);
     std::vector<double> hcoef((size_t)nslot * 9 * Tpad, 0.0);
-    for (int64_t e = 0; e < T; ++e)
-        for (int c = 0; c < 9; ++c) {
-            int64_t o = (m_tet_begin + e) * 9 + c;
-            int s = 0;
-            for (uint64_t p = rowptr[o]; p < rowptr[o + 1]; ++p, ++s) {
-                sanm_check((int64_t)idx[p] < n_in, "remap_in: index %lu out of range",
-                           (unsigned long)idx[p]);
-                hidx[((size_t)s * 9 + c) * Tpad + e] = idx[p];
-                hcoef[((size_t)s * 9 + c) * Tpad + e] = coef[p];
+    std::vector<int64_t> bad(64, -1);
+    parallel_ranges(T, 16384, [&](int64_t e0, int64_t e1, int t) {
+        for (int64_t e = e0; e < e1; ++e)
+            for (int c = 0; c < 9; ++c) {
+                int64_t o = (m_tet_begin + e) * 9 + c;
+                int s = 0;
+                for (uint64_t p = rowptr[o]; p < rowptr[o + 1]; ++p, ++s) {
+                    if ((int64_t)idx[p] >= n_in) {
+                        bad[t % 64] = (int64_t)idx[p];
+                        continue;
+                    }
+                    hidx[((size_t)s * 9 + c) * Tpad + e] = idx[p];
+                    hcoef[((size_t)s * 9 + c) * Tpad + e] = coef[p];
+                }
             }
-        }
+    });
+    for (int64_t b : bad) sanm_check(b < 0, "remap_in: index %lu out of range", (unsigned long)b);
     if (m_d_rin_idx) m_be->free(m_d_rin_idx);
     if (m_d_rin_coef) m_be->free(m_d_rin_coef);
     m_d_rin_idx = m_be->alloc(hidx.size() * sizeof(uint32_t));

@@ -1,4 +1,5 @@
 #include "multifrontal.h"
+#include "host_parallel.h"
 
 #include <algorithm>
 #include <chrono>
@@ -27,23 +28,6 @@ struct SvGraph {
     std::vector<double> xyz;         // nsv*3 centroid coordinates (empty if unknown)
     int32_t size(int32_t s) const { return sv_ptr[s + 1] - sv_ptr[s]; }
 };
-
-// contiguous ranges of [0, n) on a few host threads (the analysis is part of the solver's construction, i.e. of the
-// reference's time_solve: its loops over the rows of a big pattern are worth the threads)
-template <class F>
-void parallel_ranges(int64_t n, int64_t min_per_thread, F&& fn) {
-    const char* env_thr = std::getenv("SANM_MF_ND_THREADS");
-    const int64_t cap = env_thr ? std::atoi(env_thr) : (int64_t)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
-    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(cap, n / std::max<int64_t>(min_per_thread, 1)));
-    if (nt <= 1) {
-        fn(0, n, 0);
-        return;
-    }
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; ++t) th.emplace_back([&, t] { fn(n * t / nt, n * (t + 1) / nt, t); });
-    fn(0, n / nt, 0);
-    for (auto& x : th) x.join();
-}
 
 SvGraph build_sv_graph(int64_t n, const std::vector<uint32_t>& rowptr,
                        const std::vector<uint32_t>& col, const double* coords) {

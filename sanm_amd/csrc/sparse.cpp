@@ -1,4 +1,5 @@
 #include "sparse.h"
+#include "host_parallel.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -37,17 +38,34 @@ DeviceRows::DeviceRows(Backend* be, const SparseDesc& d, int64_t T, int64_t Tpad
     sanm_check(d.idx.size() < std::numeric_limits<uint32_t>::max(), "remap_out too large");
     std::vector<uint32_t> ptr(d.out_size + 1, 0), idx;
     std::vector<double> coef;
-    idx.reserve(d.idx.size());
-    coef.reserve(d.idx.size());
-    for (int64_t i = 0; i < d.out_size; ++i) {
-        for (uint64_t p = d.rowptr[i]; p < d.rowptr[i + 1]; ++p) {
-            int64_t e = d.idx[p] / block, c = d.idx[p] % block;
-            if (e < tet_begin || e >= tet_end) continue;
-            idx.push_back((e - tet_begin) * block + c);
-            coef.push_back(d.coef[p]);
+    const bool whole = tet_begin == 0 && tet_end * block == d.in_size;
+    parallel_ranges(d.out_size, 16384, [&](int64_t i0, int64_t i1, int) {
+        for (int64_t i = i0; i < i1; ++i) {
+            uint32_t cnt = 0;
+            if (whole)
+                cnt = (uint32_t)(d.rowptr[i + 1] - d.rowptr[i]);
+            else
+                for (uint64_t p = d.rowptr[i]; p < d.rowptr[i + 1]; ++p) {
+                    const int64_t e = d.idx[p] / block;
+                    cnt += e >= tet_begin && e < tet_end;
+                }
+            ptr[i + 1] = cnt;
         }
-        ptr[i + 1] = idx.size();
-    }
+    });
+    for (int64_t i = 0; i < d.out_size; ++i) ptr[i + 1] += ptr[i];
+    idx.resize(ptr[d.out_size]);
+    coef.resize(ptr[d.out_size]);
+    parallel_ranges(d.out_size, 16384, [&](int64_t i0, int64_t i1, int) {
+        for (int64_t i = i0; i < i1; ++i) {
+            uint32_t w = ptr[i];
+            for (uint64_t p = d.rowptr[i]; p < d.rowptr[i + 1]; ++p) {
+                int64_t e = d.idx[p] / block, c = d.idx[p] % block;
+                if (e < tet_begin || e >= tet_end) continue;
+                idx[w] = (uint32_t)((e - tet_begin) * block + c);
+                coef[w++] = d.coef[p];
+            }
+        }
+    });
     m_ptr = be->alloc(ptr.size() * 4);
     m_idx = be->alloc(std::max<size_t>(idx.size(), 1) * 4);
     m_coef = be->alloc(std::max<size_t>(idx.size(), 1) * 8);
@@ -59,14 +77,22 @@ DeviceRows::DeviceRows(Backend* be, const SparseDesc& d, int64_t T, int64_t Tpad
     // rows in triples?  (SparseRowsDev: same coefficients, indices shifted by 0 / 3 / 6 inside one tet's block)
     const int64_t nr = d.out_size;
     bool triples = nr > 0 && nr % 3 == 0 && block == 9;
-    for (int64_t u = 0; triples && u < nr / 3; ++u) {
-        const uint32_t p0 = ptr[3 * u], len = ptr[3 * u + 1] - p0;
-        for (int c = 1; triples && c < 3; ++c) {
-            const uint32_t pc = ptr[3 * u + c];
-            triples = ptr[3 * u + c + 1] - pc == len;
-            for (uint32_t q = 0; triples && q < len; ++q)
-                triples = idx[pc + q] == idx[p0 + q] + 3u * c && coef[pc + q] == coef[p0 + q] && idx[p0 + q] % 9 < 3;
-        }
+    if (triples) {
+        std::vector<char> ok(64, 1);
+        parallel_ranges(nr / 3, 16384, [&](int64_t u0, int64_t u1, int t) {
+            bool good = true;
+            for (int64_t u = u0; good && u < u1; ++u) {
+                const uint32_t p0 = ptr[3 * u], len = ptr[3 * u + 1] - p0;
+                for (int c = 1; good && c < 3; ++c) {
+                    const uint32_t pc = ptr[3 * u + c];
+                    good = ptr[3 * u + c + 1] - pc == len;
+                    for (uint32_t q = 0; good && q < len; ++q)
+                        good = idx[pc + q] == idx[p0 + q] + 3u * c && coef[pc + q] == coef[p0 + q] && idx[p0 + q] % 9 < 3;
+                }
+            }
+            if (!good) ok[t % 64] = 0;
+        });
+        for (char c : ok) triples = triples && c;
     }
     if (std::getenv("SANM_DEBUG"))
         std::fprintf(stderr, "remap_out: %ld rows, %zu entries, rows in triples: %s\n", (long)nr, idx.size(), triples ? "yes" : "no");

@@ -334,6 +334,25 @@ def test_jacobian_of_a_mesh_built_by_several_host_threads(api):
     assert run.rms[-1] == pytest.approx(osolver.residual_rms, rel=1e-6, abs=1e-14)
 
 
+def test_setup_loops_on_host_threads_are_deterministic(api, monkeypatch):
+    """tet order (piecewise sort + merges), permuted remap tables and ELL tables are filled by several host threads
+    above 16384 tets per thread (host_parallel.h; they are inside the reference's time_solve): the Jacobian and the
+    first iteration must be bit-identical to the single-threaded build."""
+    cfg = {"material": {"young": 3e4, "poisson": 0.45, "density": 900.0}, "g": [0, -9.81, 0],
+           "boundary_thresh": 0.05, "boundary_proj_dir": [-1, 0, 0], "energy_model": "neohookean_c", "order": 4}
+    dims, sp = (20, 20, 20), 0.01
+    out = []
+    for threads in ("1", "8"):
+        monkeypatch.setenv("SANM_HOST_THREADS", threads)
+        mesh = dfea.make_cuboid(*dims, sp)
+        assert mesh.nr_tet >= 2 * 16384
+        run = dfea.GravityRun(api, mesh, dict(cfg)).construct()
+        J = run.solver.jacobian_csr()
+        out.append((J.indptr.copy(), J.indices.copy(), J.data.copy(), run.rms[-1], run.solver.get_x().copy()))
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
+
+
 def test_pade_approx_on_its_own(api):
     """tests/pade.cpp:64-110 (Pade.Approx) through the C ABI: a stand-alone PadeApproximation over nine coefficient
     vectors of 500 entries (the last entry is t), its range accepted from range0 / 10, eval against the plain
