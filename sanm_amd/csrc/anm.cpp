@@ -912,71 +912,6 @@ std::vector<int64_t> spatial_tet_order(const SparseDesc& remap_inp, const std::v
     return order;
 }
 
-//! remap_inp with its (tet, component) rows permuted
-SparseDesc permute_rows_by_tet(const SparseDesc& d, const std::vector<int64_t>& order) {
-    SparseDesc r;
-    r.out_size = d.out_size;
-    r.in_size = d.in_size;
-    r.out_coords = d.out_coords;
-    const int64_t T = order.size();
-    r.rowptr.assign(d.out_size + 1, 0);
-    for (int64_t e = 0; e < T; ++e)
-        for (int c = 0; c < 9; ++c) {
-            const int64_t src = order[e] * 9 + c;
-            r.rowptr[e * 9 + c + 1] = r.rowptr[e * 9 + c] + (d.rowptr[src + 1] - d.rowptr[src]);
-        }
-    r.idx.resize(d.idx.size());
-    r.coef.resize(d.coef.size());
-    parallel_ranges(T, 16384, [&](int64_t e0, int64_t e1, int) {
-        for (int64_t e = e0; e < e1; ++e)
-            for (int c = 0; c < 9; ++c) {
-                const int64_t src = order[e] * 9 + c;
-                const uint64_t len = d.rowptr[src + 1] - d.rowptr[src];
-                std::copy_n(d.idx.begin() + d.rowptr[src], len, r.idx.begin() + r.rowptr[e * 9 + c]);
-                std::copy_n(d.coef.begin() + d.rowptr[src], len, r.coef.begin() + r.rowptr[e * 9 + c]);
-            }
-    });
-    return r;
-}
-
-//! remap_out with its (tet, component) input indices renumbered
-SparseDesc permute_inputs_by_tet(const SparseDesc& d, const std::vector<int64_t>& order) {
-    std::vector<int64_t> inv(order.size());
-    for (size_t e = 0; e < order.size(); ++e) inv[order[e]] = e;
-    SparseDesc r;
-    r.out_size = d.out_size;
-    r.in_size = d.in_size;
-    r.out_coords = d.out_coords;
-    r.rowptr = d.rowptr;
-    r.coef = d.coef;
-    r.idx.resize(d.idx.size());
-    parallel_ranges((int64_t)d.idx.size(), 1 << 18, [&](int64_t q0, int64_t q1, int) {
-        for (int64_t q = q0; q < q1; ++q) r.idx[q] = (uint64_t)(inv[d.idx[q] / 9] * 9 + d.idx[q] % 9);
-    });
-    return r;
-}
-
-//! the graph with its per-tet constants permuted
-Graph permute_constants_by_tet(const Graph& g, const std::vector<int64_t>& order) {
-    const int64_t T = order.size();
-    Graph r;
-    r.vars = g.vars;
-    r.ops.reserve(g.ops.size());
-    for (const auto& src : g.ops) {
-        if (src.type != OP_CONSTANT || src.batch != T) {
-            r.ops.push_back(src);
-            continue;
-        }
-        auto op = src;  // the value is replaced below; nothing else of a constant is per tet
-        const size_t sz = src.value.size() / T;
-        parallel_ranges(T, 16384, [&](int64_t e0, int64_t e1, int) {
-            for (int64_t e = e0; e < e1; ++e)
-                std::copy_n(src.value.begin() + order[e] * sz, sz, op.value.begin() + e * sz);
-        });
-        r.ops.push_back(std::move(op));
-    }
-    return r;
-}
 }  // namespace
 
 AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDesc& remap_inp_in,
@@ -999,20 +934,22 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
         t0 = t1;
     };
     auto t_setup = clk();
-    Graph g_perm;
-    SparseDesc inp_perm, out_perm;
+    // the renumbering is applied while the device tables are built (Program, DeviceRows, JacobianPattern read the
+    // caller's graph constants and remap tables through it): no permuted copies of either
+    std::vector<int64_t> order, inv;
     const bool reorder = remap_out_in.out_coords.size() == (size_t)m_n * 3 &&
                          remap_out_in.in_size == remap_inp_in.out_size && !std::getenv("SANM_NO_TET_ORDER");
     if (reorder) {
-        const std::vector<int64_t> order = spatial_tet_order(remap_inp_in, remap_out_in.out_coords, m_n);
-        g_perm = permute_constants_by_tet(g_in, order);
-        inp_perm = permute_rows_by_tet(remap_inp_in, order);
-        out_perm = permute_inputs_by_tet(remap_out_in, order);
+        order = spatial_tet_order(remap_inp_in, remap_out_in.out_coords, m_n);
+        inv.resize(order.size());
+        for (size_t e = 0; e < order.size(); ++e) inv[order[e]] = (int64_t)e;
     }
     lap("tet_order", t_setup);
-    const Graph& g = reorder ? g_perm : g_in;
-    const SparseDesc& remap_inp = reorder ? inp_perm : remap_inp_in;
-    const SparseDesc& remap_out = reorder ? out_perm : remap_out_in;
+    const Graph& g = g_in;
+    const SparseDesc& remap_inp = remap_inp_in;
+    const SparseDesc& remap_out = remap_out_in;
+    const int64_t* tet_order = reorder ? order.data() : nullptr;
+    const int64_t* tet_inv = reorder ? inv.data() : nullptr;
     const int64_t T = remap_inp.out_size / 9;
     // this rank's tets: contiguous ranges like the reference's worker shards
     // (libsanm/symbolic.cpp:525-536)
@@ -1030,7 +967,7 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
         sanm_check(te > tb, "more ranks than tets");
     }
     t_setup = clk();
-    m_prog = std::make_unique<Program>(be, g, out_var, te - tb, hp.order, tb, T, /*full_history=*/false);
+    m_prog = std::make_unique<Program>(be, g, out_var, te - tb, hp.order, tb, T, /*full_history=*/false, tet_order);
     lap("program", t_setup);
     m_setup.back().second -= m_prog->jit_seconds;
     m_setup.emplace_back("jit", m_prog->jit_seconds);
@@ -1039,13 +976,15 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
     sanm_check(m_prog->dev().odim == 9, "the ANM solvers take a graph whose output is a batched 3x3 matrix");
     m_prog->set_remap_in(remap_inp.in_size, remap_inp.rowptr.data(), remap_inp.idx.data(),
                          remap_inp.coef.data());
-    m_remap_out = std::make_unique<DeviceRows>(be, remap_out, te - tb, m_prog->Tpad(), tb, te);
+    m_remap_out = std::make_unique<DeviceRows>(be, remap_out, te - tb, m_prog->Tpad(), tb, te, 9, tet_inv);
     lap("remap_tables", t_setup);
     m_pattern = std::make_unique<JacobianPattern>(be, remap_out, remap_inp, m_n, T, m_prog->Tpad(),
-                                                  m_prog->dev().odim, tb, te);
+                                                  m_prog->dev().odim, tb, te, 9, tet_order, tet_inv);
     lap("pattern", t_setup);
     construct_solver_and_vectors(remap_out.out_coords.size() == (size_t)m_n * 3 ? remap_out.out_coords.data() : nullptr);
     lap("analysis", t_setup);
+    if (std::getenv("SANM_DEBUG_SETUP"))
+        for (const auto& kv : m_setup) std::fprintf(stderr, "[setup] %s %.4f\n", kv.first.c_str(), kv.second);
 }
 
 void AnmDriver::construct_on_vector_interpreter(const Graph& g, int out_var, const SparseDesc& remap_inp,

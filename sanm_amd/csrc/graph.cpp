@@ -280,9 +280,10 @@ void Graph::batched_svd_w(int x, bool require_rotation, int out[3]) {
 
 // ---------------------------------------------------------------- Program --
 Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_order,
-                 int64_t tet_begin, int64_t T_global, bool full_history)
+                 int64_t tet_begin, int64_t T_global, bool full_history, const int64_t* tet_order)
         : m_be{be}, m_tet_begin{tet_begin} {
     if (T_global < 0) T_global = T;
+    if (tet_order) m_tet_order.assign(tet_order + tet_begin, tet_order + tet_begin + T);
     sanm_check(out_var >= 0 && out_var < (int)g.vars.size(), "invalid output var");
     if (graph_is_vector(g, out_var))
         sanm_throw(SANM_ERR_UNSUPPORTED,
@@ -611,9 +612,12 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
                    "ConstantOprMeta shape mismatch in data parallel: tot_batch=%ld value_shape=%ld",
                    (long)T_global, (long)op.batch);
         soa.assign((size_t)d.size * Tpad, 0.0);
-        for (int64_t e = 0; e < T; ++e)
-            for (int c = 0; c < d.size; ++c)
-                soa[c * Tpad + e] = op.value[(op.batch == 1 ? 0 : tet_begin + e) * d.size + c];
+        parallel_ranges(T, 16384, [&](int64_t e0, int64_t e1, int) {
+            for (int64_t e = e0; e < e1; ++e) {
+                const int64_t src = op.batch == 1 ? 0 : (tet_order ? tet_order[tet_begin + e] : tet_begin + e);
+                for (int c = 0; c < d.size; ++c) soa[c * Tpad + e] = op.value[src * d.size + c];
+            }
+        });
         // pad lanes replicate tet 0 so that padded lanes stay finite
         for (int64_t e = T; e < Tpad; ++e)
             for (int c = 0; c < d.size; ++c) soa[c * Tpad + e] = soa[c * Tpad];
@@ -887,10 +891,13 @@ void Program::set_remap_in(int64_t n_in, const uint64_t* rowptr, const uint64_t*
                            const double* coef) {
     const int64_t T = m_dev.T, Tpad = m_dev.Tpad;
     int nslot = 0;
-    const int64_t o0 = m_tet_begin * 9;
-    for (int64_t o = o0; o < o0 + T * 9; ++o) {
-        sanm_check(rowptr[o + 1] >= rowptr[o], "remap_in: rowptr not monotone");
-        nslot = std::max<int>(nslot, rowptr[o + 1] - rowptr[o]);
+    const int64_t* ord = m_tet_order.empty() ? nullptr : m_tet_order.data();
+    for (int64_t e = 0; e < T; ++e) {
+        const int64_t o0 = (ord ? ord[e] : m_tet_begin + e) * 9;
+        for (int64_t o = o0; o < o0 + 9; ++o) {
+            sanm_check(rowptr[o + 1] >= rowptr[o], "remap_in: rowptr not monotone");
+            nslot = std::max<int>(nslot, rowptr[o + 1] - rowptr[o]);
+        }
     }
     sanm_check(nslot <= 64, "remap_in: %d entries for one output element", nslot);
     nslot = std::max(nslot, 1);
@@ -900,7 +907,7 @@ void Program::set_remap_in(int64_t n_in, const uint64_t* rowptr, const uint64_t*
     parallel_ranges(T, 16384, [&](int64_t e0, int64_t e1, int t) {
         for (int64_t e = e0; e < e1; ++e)
             for (int c = 0; c < 9; ++c) {
-                int64_t o = (m_tet_begin + e) * 9 + c;
+                int64_t o = (ord ? ord[e] : m_tet_begin + e) * 9 + c;
                 int s = 0;
                 for (uint64_t p = rowptr[o]; p < rowptr[o + 1]; ++p, ++s) {
                     if ((int64_t)idx[p] >= n_in) {

@@ -108,17 +108,20 @@ public:
     //! tet-sharded run) the program covers tets [tet_begin, tet_begin + T) of
     //! T_global and batched constants are sliced accordingly (ConstantOprMeta
     //! under ParallelTaylorCoeffProp, libsanm/oprs/misc.cpp:51-72).
+    //! tet_order (T_global entries, optional): the program's tet e is the caller's tet tet_order[e] -- batched
+    //! constants and the rows of remap_in are read through it (the driver's spatial renumbering, anm.cpp)
     //! full_history: keep the series of every variable (what sanm_taylor_get_var exposes, like
     //! VarNodeExeCtx::coeffs of the reference); otherwise only the series some convolution reads back
     Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_order,
-            int64_t tet_begin = 0, int64_t T_global = -1, bool full_history = true);
+            int64_t tet_begin = 0, int64_t T_global = -1, bool full_history = true,
+            const int64_t* tet_order = nullptr);
     ~Program();
     Program(const Program&) = delete;
 
     //! attach the remap_in table (ELL), converting flattened AoS output
     //! indices e*9+c (fea/mesh_template.h:73-110) to the SoA layout
     void set_remap_in(int64_t n_in, const uint64_t* rowptr, const uint64_t* idx,
-                      const double* coef);  // rowptr indexed by GLOBAL output element
+                      const double* coef);  // rowptr indexed by GLOBAL output element (of the caller's numbering)
 
     ProgramDev dev() const { return m_dev; }
     //! HIP source of the four pass kernels with this program's records as compile-time constants
@@ -166,6 +169,7 @@ private:
     int64_t m_arena_doubles = 0, m_jac_begin = 0, m_jac_end = 0;
     int64_t m_n_in = 0;
     int64_t m_tet_begin = 0;
+    std::vector<int64_t> m_tet_order;  // this program's tets in the caller's numbering (empty: tet_begin + e)
     void* m_d_ops = nullptr;
     void* m_d_vars = nullptr;
     void* m_d_lc_params = nullptr;

@@ -11,6 +11,11 @@ namespace sanm_hip {
 // dst[i] = sum coef*src[idx]   (SparseLinearDesc::apply, libsanm/anm.cpp:55-75)
 SANM_HD double gather_row(const SparseRowsDev& R, const double* src, int64_t i) {
     double s = 0;
+    if (R.bptr) {  // rows in triples: the list of row 3u with its indices shifted by 3 (i - 3u)
+        const uint32_t sh = 3u * (uint32_t)(i % 3);
+        for (uint32_t p = R.bptr[i / 3], e = R.bptr[i / 3 + 1]; p < e; ++p) s += R.bcoef[p] * src[R.bidx[p] + sh];
+        return s;
+    }
     for (uint32_t p = R.ptr[i], e = R.ptr[i + 1]; p < e; ++p) s += R.coef[p] * src[R.idx[p]];
     return s;
 }

@@ -29,65 +29,53 @@ SparseDesc::SparseDesc(int64_t out_size_, int64_t in_size_, const uint64_t* rp, 
 }
 
 DeviceRows::DeviceRows(Backend* be, const SparseDesc& d, int64_t T, int64_t Tpad, int64_t tet_begin,
-                       int64_t tet_end, int64_t block)
+                       int64_t tet_end, int64_t block, const int64_t* tet_inv)
         : m_be{be} {
     sanm_check(block >= 1 && d.in_size % block == 0, "sparse map over a (T,%ld) tensor: got %ld input elements",
                (long)block, (long)d.in_size);
     if (tet_end < 0) tet_end = d.in_size / block;
     sanm_check(tet_end - tet_begin == T, "remap_out: shard size mismatch");
     sanm_check(d.idx.size() < std::numeric_limits<uint32_t>::max(), "remap_out too large");
-    std::vector<uint32_t> ptr(d.out_size + 1, 0), idx;
-    std::vector<double> coef;
+    (void)Tpad;
     const bool whole = tet_begin == 0 && tet_end * block == d.in_size;
-    parallel_ranges(d.out_size, 16384, [&](int64_t i0, int64_t i1, int) {
+    // entry p of the source as this rank sees it: (kept?, index into the local (T, block) tensor)
+    auto local = [&](uint64_t p, uint32_t& li) {
+        int64_t e = d.idx[p] / block;
+        const int64_t c = d.idx[p] % block;
+        if (tet_inv) e = tet_inv[e];
+        li = (uint32_t)((e - tet_begin) * block + c);
+        return e >= tet_begin && e < tet_end;
+    };
+    const int64_t nr = d.out_size;
+    std::vector<uint32_t> ptr(nr + 1, 0);
+    parallel_ranges(nr, 16384, [&](int64_t i0, int64_t i1, int) {
         for (int64_t i = i0; i < i1; ++i) {
-            uint32_t cnt = 0;
+            uint32_t cnt = 0, li;
             if (whole)
                 cnt = (uint32_t)(d.rowptr[i + 1] - d.rowptr[i]);
             else
-                for (uint64_t p = d.rowptr[i]; p < d.rowptr[i + 1]; ++p) {
-                    const int64_t e = d.idx[p] / block;
-                    cnt += e >= tet_begin && e < tet_end;
-                }
+                for (uint64_t p = d.rowptr[i]; p < d.rowptr[i + 1]; ++p) cnt += local(p, li);
             ptr[i + 1] = cnt;
         }
     });
-    for (int64_t i = 0; i < d.out_size; ++i) ptr[i + 1] += ptr[i];
-    idx.resize(ptr[d.out_size]);
-    coef.resize(ptr[d.out_size]);
-    parallel_ranges(d.out_size, 16384, [&](int64_t i0, int64_t i1, int) {
-        for (int64_t i = i0; i < i1; ++i) {
-            uint32_t w = ptr[i];
-            for (uint64_t p = d.rowptr[i]; p < d.rowptr[i + 1]; ++p) {
-                int64_t e = d.idx[p] / block, c = d.idx[p] % block;
-                if (e < tet_begin || e >= tet_end) continue;
-                idx[w] = (uint32_t)((e - tet_begin) * block + c);
-                coef[w++] = d.coef[p];
-            }
-        }
-    });
-    m_ptr = be->alloc(ptr.size() * 4);
-    m_idx = be->alloc(std::max<size_t>(idx.size(), 1) * 4);
-    m_coef = be->alloc(std::max<size_t>(idx.size(), 1) * 8);
-    be->h2d(m_ptr, ptr.data(), ptr.size() * 4);
-    be->h2d(m_idx, idx.data(), idx.size() * 4);
-    be->h2d(m_coef, coef.data(), idx.size() * 8);
-    m_dev = {static_cast<uint32_t*>(m_ptr), static_cast<uint32_t*>(m_idx),
-             static_cast<double*>(m_coef), d.out_size, nullptr, nullptr, nullptr};
+    for (int64_t i = 0; i < nr; ++i) ptr[i + 1] += ptr[i];
     // rows in triples?  (SparseRowsDev: same coefficients, indices shifted by 0 / 3 / 6 inside one tet's block)
-    const int64_t nr = d.out_size;
     bool triples = nr > 0 && nr % 3 == 0 && block == 9;
     if (triples) {
         std::vector<char> ok(64, 1);
         parallel_ranges(nr / 3, 16384, [&](int64_t u0, int64_t u1, int t) {
             bool good = true;
             for (int64_t u = u0; good && u < u1; ++u) {
-                const uint32_t p0 = ptr[3 * u], len = ptr[3 * u + 1] - p0;
+                const uint32_t len = ptr[3 * u + 1] - ptr[3 * u];
                 for (int c = 1; good && c < 3; ++c) {
-                    const uint32_t pc = ptr[3 * u + c];
-                    good = ptr[3 * u + c + 1] - pc == len;
-                    for (uint32_t q = 0; good && q < len; ++q)
-                        good = idx[pc + q] == idx[p0 + q] + 3u * c && coef[pc + q] == coef[p0 + q] && idx[p0 + q] % 9 < 3;
+                    good = ptr[3 * u + c + 1] - ptr[3 * u + c] == len;
+                    uint64_t p0 = d.rowptr[3 * u], pc = d.rowptr[3 * u + c];
+                    for (uint32_t q = 0; good && q < len; ++q, ++p0, ++pc) {
+                        uint32_t i0, ic;
+                        while (!local(p0, i0)) ++p0;  // (len kept entries are known to follow)
+                        while (!local(pc, ic)) ++pc;
+                        good = ic == i0 + 3u * c && d.coef[pc] == d.coef[p0] && i0 % 9 < 3;
+                    }
                 }
             }
             if (!good) ok[t % 64] = 0;
@@ -95,31 +83,52 @@ DeviceRows::DeviceRows(Backend* be, const SparseDesc& d, int64_t T, int64_t Tpad
         for (char c : ok) triples = triples && c;
     }
     if (std::getenv("SANM_DEBUG"))
-        std::fprintf(stderr, "remap_out: %ld rows, %zu entries, rows in triples: %s\n", (long)nr, idx.size(), triples ? "yes" : "no");
+        std::fprintf(stderr, "remap_out: %ld rows, %u entries, rows in triples: %s\n", (long)nr, ptr[nr], triples ? "yes" : "no");
+    // rows [r0 .. ) of the source, every `step`-th one, packed: the whole table (step 1) or the first row of each triple
+    auto pack = [&](int step, std::vector<uint32_t>& optr, std::vector<uint32_t>& oidx, std::vector<double>& ocoef) {
+        const int64_t rows = nr / step;
+        optr.assign(rows + 1, 0);
+        for (int64_t u = 0; u < rows; ++u) optr[u + 1] = optr[u] + (ptr[step * u + 1] - ptr[step * u]);
+        oidx.resize(optr[rows]);
+        ocoef.resize(optr[rows]);
+        parallel_ranges(rows, 16384, [&](int64_t u0, int64_t u1, int) {
+            for (int64_t u = u0; u < u1; ++u) {
+                uint32_t w = optr[u], li;
+                for (uint64_t p = d.rowptr[step * u]; p < d.rowptr[step * u + 1]; ++p) {
+                    if (!local(p, li)) continue;
+                    oidx[w] = li;
+                    ocoef[w++] = d.coef[p];
+                }
+            }
+        });
+    };
+    std::vector<uint32_t> optr, oidx;
+    std::vector<double> ocoef;
+    pack(triples ? 3 : 1, optr, oidx, ocoef);
+    void* dptr = be->alloc(optr.size() * 4);
+    void* didx = be->alloc(std::max<size_t>(oidx.size(), 1) * 4);
+    void* dcoef = be->alloc(std::max<size_t>(oidx.size(), 1) * 8);
+    be->h2d(dptr, optr.data(), optr.size() * 4);
+    be->h2d(didx, oidx.data(), oidx.size() * 4);
+    be->h2d(dcoef, ocoef.data(), oidx.size() * 8);
     if (triples) {
-        std::vector<uint32_t> bptr(nr / 3 + 1, 0), bidx;
-        std::vector<double> bcoef;
-        for (int64_t u = 0; u < nr / 3; ++u) {
-            bidx.insert(bidx.end(), idx.begin() + ptr[3 * u], idx.begin() + ptr[3 * u + 1]);
-            bcoef.insert(bcoef.end(), coef.begin() + ptr[3 * u], coef.begin() + ptr[3 * u + 1]);
-            bptr[u + 1] = bidx.size();
-        }
-        m_bptr = be->alloc(bptr.size() * 4);
-        m_bidx = be->alloc(std::max<size_t>(bidx.size(), 1) * 4);
-        m_bcoef = be->alloc(std::max<size_t>(bidx.size(), 1) * 8);
-        be->h2d(m_bptr, bptr.data(), bptr.size() * 4);
-        be->h2d(m_bidx, bidx.data(), bidx.size() * 4);
-        be->h2d(m_bcoef, bcoef.data(), bidx.size() * 8);
-        m_dev.bptr = static_cast<uint32_t*>(m_bptr);
-        m_dev.bidx = static_cast<uint32_t*>(m_bidx);
-        m_dev.bcoef = static_cast<double*>(m_bcoef);
+        // only the list of the first row of each triple is kept (row_ops.h: gather_row reads rows 3u+1, 3u+2 through it)
+        m_bptr = dptr, m_bidx = didx, m_bcoef = dcoef;
+        m_dev = {nullptr, nullptr, nullptr, nr, static_cast<uint32_t*>(dptr), static_cast<uint32_t*>(didx),
+                 static_cast<double*>(dcoef)};
+    } else {
+        m_ptr = dptr, m_idx = didx, m_coef = dcoef;
+        m_dev = {static_cast<uint32_t*>(dptr), static_cast<uint32_t*>(didx), static_cast<double*>(dcoef), nr,
+                 nullptr, nullptr, nullptr};
     }
 }
 
 DeviceRows::~DeviceRows() {
-    m_be->free(m_ptr);
-    m_be->free(m_idx);
-    m_be->free(m_coef);
+    if (m_ptr) {
+        m_be->free(m_ptr);
+        m_be->free(m_idx);
+        m_be->free(m_coef);
+    }
     if (m_bptr) {
         m_be->free(m_bptr);
         m_be->free(m_bidx);
@@ -136,8 +145,10 @@ T* JacobianPattern::upload(const std::vector<T>& v) {
 }
 
 JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const SparseDesc& ri, int64_t n,
-                                 int64_t T, int64_t Tpad, int odim, int64_t tet_begin, int64_t tet_end, int idim)
+                                 int64_t T, int64_t Tpad, int odim, int64_t tet_begin, int64_t tet_end, int idim,
+                                 const int64_t* tet_order, const int64_t* tet_inv)
         : m_be{be} {
+    sanm_check(!tet_order == !tet_inv, "a renumbering of the batch items comes with its inverse");
     if (tet_end < 0) tet_end = T;
     sanm_check(ro.out_size == n, "remap_out must produce %ld unknowns, got %ld", (long)n,
                (long)ro.out_size);
@@ -171,8 +182,9 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
             for (int64_t i = r0; i < r1; ++i) {
                 ucol.clear();
                 for (uint64_t p = ro.rowptr[i]; p < ro.rowptr[i + 1]; ++p) {
-                    const uint64_t b = ro.idx[p] / odim;
-                    const bool mine = (int64_t)b >= tet_begin && (int64_t)b < tet_end;
+                    const uint64_t b = ro.idx[p] / odim;  // (the caller's numbering, like the rows of ri)
+                    const int64_t bn = tet_inv ? tet_inv[b] : (int64_t)b;
+                    const bool mine = bn >= tet_begin && bn < tet_end;
                     for (int m = 0; m < idim; ++m) {
                         const uint64_t irow = b * idim + m;
                         for (uint64_t q = ri.rowptr[irow]; q < ri.rowptr[irow + 1]; ++q) {
@@ -227,16 +239,49 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
     m_csr.nnz = col.size();
     m_csr.rowptr = upload(rowptr);
     m_csr.col = upload(col);
-    std::vector<double> zeros(col.size(), 0.0);
-    m_csr.val = upload(zeros);
-    // the remap tables as the assembly reads them
-    auto narrow = [](const std::vector<uint64_t>& v) { return std::vector<uint32_t>(v.begin(), v.end()); };
-    m_asm.ro_ptr = upload(narrow(ro.rowptr));
-    m_asm.ro_idx = upload(narrow(ro.idx));
-    m_asm.ro_coef = upload(ro.coef);
-    m_asm.ri_ptr = upload(narrow(ri.rowptr));
-    m_asm.ri_idx = upload(narrow(ri.idx));
-    m_asm.ri_coef = upload(ri.coef);
+    {
+        void* val = m_be->alloc(std::max<size_t>(col.size(), 1) * sizeof(double));
+        m_be->zero(val, col.size() * sizeof(double));
+        m_bufs.push_back(val);
+        m_csr.val = static_cast<double*>(val);
+    }
+    // the remap tables as the assembly reads them: 32-bit, in the renumbered batch order
+    {
+        std::vector<uint32_t> v32(ro.rowptr.begin(), ro.rowptr.end());
+        m_asm.ro_ptr = upload(v32);
+        v32.resize(ro.idx.size());
+        parallel_ranges((int64_t)ro.idx.size(), 1 << 18, [&](int64_t q0, int64_t q1, int) {
+            for (int64_t q = q0; q < q1; ++q)
+                v32[q] = (uint32_t)(tet_inv ? tet_inv[ro.idx[q] / odim] * odim + ro.idx[q] % odim : ro.idx[q]);
+        });
+        m_asm.ro_idx = upload(v32);
+        m_asm.ro_coef = upload(ro.coef);
+        // rows of ri: batch item e of the table is the caller's item tet_order[e]
+        const int64_t nrow = ri.out_size;
+        v32.assign(nrow + 1, 0);
+        for (int64_t e = 0; e < T; ++e) {
+            const int64_t src = (tet_order ? tet_order[e] : e) * idim;
+            for (int m = 0; m < idim; ++m)
+                v32[e * idim + m + 1] = v32[e * idim + m] + (uint32_t)(ri.rowptr[src + m + 1] - ri.rowptr[src + m]);
+        }
+        m_asm.ri_ptr = upload(v32);
+        std::vector<uint32_t> i32(ri.idx.size());
+        std::vector<double> c64;
+        if (tet_order) c64.resize(ri.coef.size());
+        parallel_ranges(T, 16384, [&](int64_t e0, int64_t e1, int) {
+            for (int64_t e = e0; e < e1; ++e) {
+                const int64_t src = (tet_order ? tet_order[e] : e) * idim;
+                uint32_t w = v32[e * idim];
+                for (uint64_t q = ri.rowptr[src]; q < ri.rowptr[src + idim]; ++q, ++w) {
+                    i32[w] = (uint32_t)ri.idx[q];
+                    if (tet_order) c64[w] = ri.coef[q];
+                }
+            }
+        });
+        m_asm.ri_idx = upload(i32);
+        const std::vector<double>* rc = tet_order ? &c64 : &ri.coef;
+        m_asm.ri_coef = upload(*rc);
+    }
     m_asm.rowptr = m_csr.rowptr;
     m_asm.col = m_csr.col;
     m_asm.n = n;

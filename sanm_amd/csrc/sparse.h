@@ -38,8 +38,9 @@ public:
     //! only the entries whose input tet lies in [tet_begin, tet_end) are kept (all of
     //! them by default); T / Tpad describe the local SoA tensor
     //! block: elements per batch item of the input tensor (9 for the (T,3,3) output of a tet program)
+    //! tet_inv (optional): batch item b of the map's inputs is item tet_inv[b] of the tensor (the driver's renumbering)
     DeviceRows(Backend* be, const SparseDesc& d, int64_t T, int64_t Tpad, int64_t tet_begin = 0,
-               int64_t tet_end = -1, int64_t block = 9);
+               int64_t tet_end = -1, int64_t block = 9, const int64_t* tet_inv = nullptr);
     ~DeviceRows();
     SparseRowsDev dev() const { return m_dev; }
 
@@ -58,8 +59,11 @@ public:
     //! are left to the other ranks (the CSR pattern itself is always the global one)
     //! odim / idim: elements per batch item of the graph's output / placeholder (the blocks of the Jacobian are
     //! batch-major [T][odim][idim])
+    //! tet_order / tet_inv (optional, both or none): the device's batch item e is the maps' item tet_order[e]; the
+    //! shard [tet_begin, tet_end) and the Jacobian blocks are in the device's numbering
     JacobianPattern(Backend* be, const SparseDesc& remap_out, const SparseDesc& remap_in, int64_t n,
-                    int64_t T, int64_t Tpad, int odim, int64_t tet_begin = 0, int64_t tet_end = -1, int idim = 9);
+                    int64_t T, int64_t Tpad, int odim, int64_t tet_begin = 0, int64_t tet_end = -1, int idim = 9,
+                    const int64_t* tet_order = nullptr, const int64_t* tet_inv = nullptr);
     ~JacobianPattern();
 
     CsrDev csr() const { return m_csr; }

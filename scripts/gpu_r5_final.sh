@@ -1,0 +1,18 @@
+#!/bin/bash
+# round-end validation: full GPU suite, then the default bench line      usage: gpu_r5_final.sh <tag>
+set -u
+TAG=$1
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd $ROOT
+timeout 2400 python -m pytest tests -q -m gpu -x > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
+tail -5 $OUT/pytest_gpu.log
+timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
+python - <<PY
+import json
+d=json.loads(open("$OUT/bench.json").read().strip().splitlines()[-1])
+print("value", d["value"], "ms", d["ms_per_step"], "roofline", d["roofline"])
+print("e2e", d["end_to_end"])
+a=d["at_scale"]; print("at_scale", a["value"], a["ms_per_step"], a.get("roofline"), a["end_to_end"])
+PY
