@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <exception>
+#include <functional>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -877,9 +878,6 @@ std::vector<int64_t> spatial_tet_order(const SparseDesc& remap_inp, const std::v
         return v;
     };
     std::vector<std::pair<uint64_t, int64_t>> key(T);
-    // sorted pieces merged pairwise: the keys carry the tet number, so the order is total and the result is the
-    // sequential sort's whatever the number of pieces
-    std::vector<int64_t> cut{0};
     parallel_ranges(T, 16384, [&](int64_t e0, int64_t e1, int) {
         for (int64_t e = e0; e < e1; ++e) {
             uint64_t k = 0;
@@ -890,23 +888,9 @@ std::vector<int64_t> spatial_tet_order(const SparseDesc& remap_inp, const std::v
             }
             key[e] = {k, e};
         }
-        std::sort(key.begin() + e0, key.begin() + e1);
     });
-    {
-        const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(host_thread_cap(), T / 16384));
-        for (int t = 1; t <= nt; ++t) cut.push_back(T * t / nt);  // the ranges parallel_ranges made
-        while (cut.size() > 2) {
-            const int64_t pairs = (int64_t)(cut.size() - 1) / 2;
-            parallel_ranges(pairs, 1, [&](int64_t p0, int64_t p1, int) {
-                for (int64_t p = p0; p < p1; ++p)
-                    std::inplace_merge(key.begin() + cut[2 * p], key.begin() + cut[2 * p + 1], key.begin() + cut[2 * p + 2]);
-            });
-            std::vector<int64_t> next;
-            for (size_t i = 0; i < cut.size(); i += 2) next.push_back(cut[i]);
-            if (next.back() != T) next.push_back(T);
-            cut.swap(next);
-        }
-    }
+    // (the keys carry the tet number: a total order)
+    parallel_sort(key.begin(), key.end(), std::less<std::pair<uint64_t, int64_t>>{});
     std::vector<int64_t> order(T);
     for (int64_t e = 0; e < T; ++e) order[e] = key[e].second;  // new tet e = old tet order[e]
     return order;

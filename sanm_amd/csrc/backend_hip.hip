@@ -33,6 +33,7 @@
 #include "mf_kernels.h"
 #include "red_ops.h"
 #include "row_ops.h"
+#include "host_parallel.h"
 #include "rtc.h"
 #include "tet_ops.h"
 #include "vecprog.h"
@@ -2059,6 +2060,8 @@ public:
     void prepare_assembly(AssemblyDev& A, std::vector<void*>& owned) override {
         // counts per non-zero (and per row for the t column), offsets on the host, then the lists themselves
         const size_t nnz = (size_t)A.nnz, n = (size_t)A.n;
+        SetupLaps laps("assembly lists");
+        const bool dbg = std::getenv("SANM_DEBUG_SETUP") != nullptr;
         uint32_t* cnt = static_cast<uint32_t*>(alloc((nnz + 1) * 4));
         uint32_t* tcnt = static_cast<uint32_t*>(alloc((n + 1) * 4));
         owned.push_back(cnt);
@@ -2067,6 +2070,8 @@ public:
         SANM_LAUNCH(asm_list_kernel<0>, dim3((unsigned)n), dim3(ASM_THREADS), 0, m_stream, A, cnt, tcnt, nullptr, nullptr,
                     nullptr, nullptr);
         HIP_CHECK(hipGetLastError());
+        if (dbg) sync();
+        laps.lap("count kernel");
         std::vector<uint32_t> h(nnz + 1), ht(n + 1);
         d2h(h.data(), cnt, nnz * 4);
         d2h(ht.data(), tcnt, n * 4);
@@ -2081,9 +2086,12 @@ public:
             v[m] = (uint32_t)run;
             return (size_t)run;
         };
+        laps.lap("d2h");
         const size_t tot = scan(h, nnz, "assembly"), ttot = scan(ht, n, "grad_t");
+        laps.lap("scan");
         h2d(cnt, h.data(), (nnz + 1) * 4);
         h2d(tcnt, ht.data(), (n + 1) * 4);
+        laps.lap("h2d");
         uint32_t* jx = static_cast<uint32_t*>(alloc(std::max<size_t>(tot, 1) * 4));
         double* cf = static_cast<double*>(alloc(std::max<size_t>(tot, 1) * 8));
         uint32_t* tjx = static_cast<uint32_t*>(alloc(std::max<size_t>(ttot, 1) * 4));
@@ -2092,10 +2100,13 @@ public:
         owned.push_back(cf);
         owned.push_back(tjx);
         owned.push_back(tcf);
+        laps.lap("alloc lists");
         A.aptr = cnt;
         A.tptr = tcnt;
         SANM_LAUNCH(asm_list_kernel<1>, dim3((unsigned)n), dim3(ASM_THREADS), 0, m_stream, A, nullptr, nullptr, jx, cf, tjx, tcf);
         HIP_CHECK(hipGetLastError());
+        if (dbg) sync();
+        laps.lap("fill kernel");
         A.ajidx = jx;
         A.acoef = cf;
         A.tjidx = tjx;

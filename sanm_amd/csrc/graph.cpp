@@ -901,31 +901,39 @@ void Program::set_remap_in(int64_t n_in, const uint64_t* rowptr, const uint64_t*
     }
     sanm_check(nslot <= 64, "remap_in: %d entries for one output element", nslot);
     nslot = std::max(nslot, 1);
-    std::vector<uint32_t> hidx((size_t)nslot * 9 * Tpad, 0);
-    std::vector<double> hcoef((size_t)nslot * 9 * Tpad, 0.0);
+    SetupLaps laps("remap_in table");
+    const size_t tab = (size_t)nslot * 9 * Tpad;
+    auto hidx = raw_array<uint32_t>(tab);   // every entry written below: the workers touch their own pages
+    auto hcoef = raw_array<double>(tab);
     std::vector<int64_t> bad(64, -1);
-    parallel_ranges(T, 16384, [&](int64_t e0, int64_t e1, int t) {
+    parallel_ranges(Tpad, 16384, [&](int64_t e0, int64_t e1, int t) {
         for (int64_t e = e0; e < e1; ++e)
             for (int c = 0; c < 9; ++c) {
-                int64_t o = (ord ? ord[e] : m_tet_begin + e) * 9 + c;
                 int s = 0;
-                for (uint64_t p = rowptr[o]; p < rowptr[o + 1]; ++p, ++s) {
-                    if ((int64_t)idx[p] >= n_in) {
-                        bad[t % 64] = (int64_t)idx[p];
-                        continue;
+                if (e < T) {
+                    const int64_t o = (ord ? ord[e] : m_tet_begin + e) * 9 + c;
+                    for (uint64_t p = rowptr[o]; p < rowptr[o + 1]; ++p, ++s) {
+                        const bool ok = (int64_t)idx[p] < n_in;
+                        if (!ok) bad[t % 64] = (int64_t)idx[p];
+                        hidx[((size_t)s * 9 + c) * Tpad + e] = ok ? (uint32_t)idx[p] : 0u;
+                        hcoef[((size_t)s * 9 + c) * Tpad + e] = ok ? coef[p] : 0.0;
                     }
-                    hidx[((size_t)s * 9 + c) * Tpad + e] = idx[p];
-                    hcoef[((size_t)s * 9 + c) * Tpad + e] = coef[p];
+                }
+                for (; s < nslot; ++s) {  // unused slots and the pad lanes: index 0, coefficient 0
+                    hidx[((size_t)s * 9 + c) * Tpad + e] = 0;
+                    hcoef[((size_t)s * 9 + c) * Tpad + e] = 0.0;
                 }
             }
     });
     for (int64_t b : bad) sanm_check(b < 0, "remap_in: index %lu out of range", (unsigned long)b);
+    laps.lap("fill");
     if (m_d_rin_idx) m_be->free(m_d_rin_idx);
     if (m_d_rin_coef) m_be->free(m_d_rin_coef);
-    m_d_rin_idx = m_be->alloc(hidx.size() * sizeof(uint32_t));
-    m_d_rin_coef = m_be->alloc(hcoef.size() * sizeof(double));
-    m_be->h2d(m_d_rin_idx, hidx.data(), hidx.size() * sizeof(uint32_t));
-    m_be->h2d(m_d_rin_coef, hcoef.data(), hcoef.size() * sizeof(double));
+    m_d_rin_idx = m_be->alloc(tab * sizeof(uint32_t));
+    m_d_rin_coef = m_be->alloc(tab * sizeof(double));
+    m_be->h2d(m_d_rin_idx, hidx.get(), tab * sizeof(uint32_t));
+    m_be->h2d(m_d_rin_coef, hcoef.get(), tab * sizeof(double));
+    laps.lap("upload");
     m_dev.rin = {static_cast<const uint32_t*>(m_d_rin_idx),
                  static_cast<const double*>(m_d_rin_coef), nslot};
     m_n_in = n_in;

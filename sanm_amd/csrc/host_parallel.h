@@ -3,8 +3,11 @@
 // is constructed), so its loops over the rows of a big mesh are worth the threads.
 #pragma once
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdint>
 #include <cstdlib>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -12,7 +15,7 @@ namespace sanm_hip {
 inline int host_thread_cap() {
     const char* env_thr = std::getenv("SANM_HOST_THREADS");
     if (!env_thr) env_thr = std::getenv("SANM_MF_ND_THREADS");  // the name of round 5's first version
-    if (env_thr) return std::max(1, std::atoi(env_thr));
+    if (env_thr) return std::min(64, std::max(1, std::atoi(env_thr)));
     return (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
 }
 
@@ -29,4 +32,59 @@ void parallel_ranges(int64_t n, int64_t min_per_thread, F&& fn) {
     fn(0, n / nt, 0);
     for (auto& x : th) x.join();
 }
+
+//! std::sort by pieces on the threads of parallel_ranges, merged pairwise.  cmp must be a strict TOTAL order (break
+//! ties by index): then the result is the sequential sort's whatever the number of pieces.
+template <class It, class Cmp>
+void parallel_sort(It first, It last, Cmp cmp, int64_t min_per_thread = 16384) {
+    const int64_t n = last - first;
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(host_thread_cap(), n / std::max<int64_t>(min_per_thread, 1)));
+    if (nt <= 1) {
+        std::sort(first, last, cmp);
+        return;
+    }
+    std::vector<int64_t> cut(nt + 1);
+    for (int t = 0; t <= nt; ++t) cut[t] = n * t / nt;
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back([&, t] { std::sort(first + cut[t], first + cut[t + 1], cmp); });
+        std::sort(first + cut[0], first + cut[1], cmp);
+        for (auto& x : th) x.join();
+    }
+    while (cut.size() > 2) {
+        const int64_t pairs = (int64_t)(cut.size() - 1) / 2;
+        std::vector<std::thread> th;
+        for (int64_t p = 1; p < pairs; ++p)
+            th.emplace_back([&, p] { std::inplace_merge(first + cut[2 * p], first + cut[2 * p + 1], first + cut[2 * p + 2], cmp); });
+        std::inplace_merge(first + cut[0], first + cut[1], first + cut[2], cmp);
+        for (auto& x : th) x.join();
+        std::vector<int64_t> next;
+        for (size_t i = 0; i < cut.size(); i += 2) next.push_back(cut[i]);
+        if (next.back() != n) next.push_back(n);
+        cut.swap(next);
+    }
+}
+
+//! n elements left uninitialised (a std::vector would zero them on one thread before the workers fill them)
+template <class T>
+std::unique_ptr<T[]> raw_array(size_t n) {
+    return std::unique_ptr<T[]>(new T[std::max<size_t>(n, 1)]);
+}
+
+//! wall-clock laps of a setup phase on stderr when SANM_DEBUG_SETUP is set
+class SetupLaps {
+    const char* m_phase;
+    bool m_on;
+    std::chrono::steady_clock::time_point m_t;
+
+public:
+    explicit SetupLaps(const char* phase)
+            : m_phase{phase}, m_on{std::getenv("SANM_DEBUG_SETUP") != nullptr}, m_t{std::chrono::steady_clock::now()} {}
+    void lap(const char* what) {
+        if (!m_on) return;
+        const auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[setup] %s.%s %.4f\n", m_phase, what, std::chrono::duration<double>(t - m_t).count());
+        m_t = t;
+    }
+};
 }  // namespace sanm_hip

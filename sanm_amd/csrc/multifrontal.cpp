@@ -2,6 +2,8 @@
 #include "host_parallel.h"
 
 #include <algorithm>
+#include <atomic>
+#include <memory>
 #include <chrono>
 #include <thread>
 #include <future>
@@ -31,60 +33,77 @@ struct SvGraph {
 
 SvGraph build_sv_graph(int64_t n, const std::vector<uint32_t>& rowptr,
                        const std::vector<uint32_t>& col, const double* coords) {
-    // symmetrised adjacency including the diagonal
+    // symmetrised adjacency including the diagonal.  Rows on several threads: the counters are bumped atomically and
+    // the lists come out in whatever order the threads reached them -- every list is sorted below, so the graph does
+    // not depend on that order.
     std::vector<int32_t> deg(n + 1, 0);
-    for (int64_t i = 0; i < n; ++i)
-        for (uint32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
-            int64_t j = col[p];
-            sanm_check(j < n, "column index out of range");
-            if (j != i) {
-                deg[i + 1]++;
-                deg[j + 1]++;
-            }
-        }
-    for (int64_t i = 0; i < n; ++i) deg[i + 1] += deg[i] + 1;  // +1: self
-    std::vector<int32_t> nb(deg[n]);
-    {
-        std::vector<int32_t> fill(deg.begin(), deg.end() - 1);
-        for (int64_t i = 0; i < n; ++i) nb[fill[i]++] = i;
-        for (int64_t i = 0; i < n; ++i)
+    std::vector<std::string> errs(64);
+    parallel_ranges(n, 8192, [&](int64_t r0, int64_t r1, int t) {
+        for (int64_t i = r0; i < r1; ++i) {
+            int32_t own = 0;
             for (uint32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
-                int64_t j = col[p];
+                const int64_t j = col[p];
+                if (j >= n) {
+                    errs[t % 64] = "column index out of range";
+                    return;
+                }
                 if (j != i) {
-                    nb[fill[i]++] = j;
-                    nb[fill[j]++] = i;
+                    ++own;
+                    std::atomic_ref<int32_t>(deg[j + 1]).fetch_add(1, std::memory_order_relaxed);
                 }
             }
+            std::atomic_ref<int32_t>(deg[i + 1]).fetch_add(own, std::memory_order_relaxed);
+        }
+    });
+    for (const auto& e : errs) sanm_check(e.empty(), "%s", e.c_str());
+    for (int64_t i = 0; i < n; ++i) deg[i + 1] += deg[i] + 1;  // +1: self
+    auto nb_raw = raw_array<int32_t>(deg[n]);
+    int32_t* nb = nb_raw.get();
+    {
+        std::vector<int32_t> fill(deg.begin(), deg.end() - 1);
+        parallel_ranges(n, 8192, [&](int64_t r0, int64_t r1, int) {
+            for (int64_t i = r0; i < r1; ++i) {
+                nb[std::atomic_ref<int32_t>(fill[i]).fetch_add(1, std::memory_order_relaxed)] = (int32_t)i;
+                for (uint32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+                    const int64_t j = col[p];
+                    if (j != i) {
+                        nb[std::atomic_ref<int32_t>(fill[i]).fetch_add(1, std::memory_order_relaxed)] = (int32_t)j;
+                        nb[std::atomic_ref<int32_t>(fill[j]).fetch_add(1, std::memory_order_relaxed)] = (int32_t)i;
+                    }
+                }
+            }
+        });
     }
-    // sort + unique every list, hash it (rows in parallel, in place), then close the gaps
+    // sort + unique every list, hash it (rows in parallel, in place), then pack the lists
     std::vector<int32_t> uptr(n + 1, 0);
     std::vector<uint64_t> hash(n);
+    std::unique_ptr<int32_t[]> unb_raw;
     {
         std::vector<int32_t> ulen(n);
         parallel_ranges(n, 8192, [&](int64_t r0, int64_t r1, int) {
             for (int64_t i = r0; i < r1; ++i) {
                 int32_t b = deg[i], e = deg[i + 1];
-                std::sort(nb.begin() + b, nb.begin() + e);
-                int32_t ne = std::unique(nb.begin() + b, nb.begin() + e) - nb.begin();
+                std::sort(nb + b, nb + e);
+                int32_t ne = std::unique(nb + b, nb + e) - nb;
                 uint64_t h = 1469598103934665603ull;
                 for (int32_t q = b; q < ne; ++q) h = (h ^ (uint64_t)nb[q]) * 1099511628211ull;
                 hash[i] = h;
                 ulen[i] = ne - b;
             }
         });
-        int32_t w = 0;
-        for (int64_t i = 0; i < n; ++i) {
-            const int32_t b = deg[i];
-            if (w != b) std::memmove(nb.data() + w, nb.data() + b, (size_t)ulen[i] * sizeof(int32_t));
-            w += ulen[i];
-            uptr[i + 1] = w;
-        }
-        nb.resize(w);
+        for (int64_t i = 0; i < n; ++i) uptr[i + 1] = uptr[i] + ulen[i];
+        unb_raw = raw_array<int32_t>(uptr[n]);
+        int32_t* dst = unb_raw.get();
+        parallel_ranges(n, 8192, [&](int64_t r0, int64_t r1, int) {
+            for (int64_t i = r0; i < r1; ++i) std::memcpy(dst + uptr[i], nb + deg[i], (size_t)ulen[i] * sizeof(int32_t));
+        });
+        nb_raw.reset();
+        nb = dst;
     }
     // group indistinguishable unknowns (same closed neighbourhood)
     std::vector<int32_t> order(n);
     std::iota(order.begin(), order.end(), 0);
-    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+    parallel_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
         if (hash[a] != hash[b]) return hash[a] < hash[b];
         return a < b;
     });
@@ -92,7 +111,7 @@ SvGraph build_sv_graph(int64_t n, const std::vector<uint32_t>& rowptr,
     g.sv_of.assign(n, -1);
     auto same = [&](int32_t a, int32_t b) {
         int32_t la = uptr[a + 1] - uptr[a], lb = uptr[b + 1] - uptr[b];
-        return la == lb && std::equal(nb.begin() + uptr[a], nb.begin() + uptr[a + 1], nb.begin() + uptr[b]);
+        return la == lb && std::equal(nb + uptr[a], nb + uptr[a + 1], nb + uptr[b]);
     };
     std::vector<int32_t> rep;  // representative unknown of each supervariable
     for (int64_t q = 0; q < n;) {
@@ -136,20 +155,33 @@ SvGraph build_sv_graph(int64_t n, const std::vector<uint32_t>& rowptr,
         std::vector<int32_t> fill(g.sv_ptr.begin(), g.sv_ptr.end() - 1);
         for (int64_t i = 0; i < n; ++i) g.sv_members[fill[g.sv_of[i]]++] = i;
     }
-    // compressed adjacency from the first member of each supervariable
+    // compressed adjacency from the first member of each supervariable (lists by ranges of supervariables, then
+    // joined in order)
     g.adj_ptr.assign(g.nsv + 1, 0);
-    std::vector<int32_t> tmp;
-    for (int32_t s = 0; s < g.nsv; ++s) {
-        int32_t u = g.sv_members[g.sv_ptr[s]];
-        tmp.clear();
-        for (int32_t q = uptr[u]; q < uptr[u + 1]; ++q) {
-            int32_t t = g.sv_of[nb[q]];
-            if (t != s) tmp.push_back(t);
-        }
-        std::sort(tmp.begin(), tmp.end());
-        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-        g.adj.insert(g.adj.end(), tmp.begin(), tmp.end());
-        g.adj_ptr[s + 1] = g.adj.size();
+    {
+        std::vector<std::vector<int32_t>> piece(64);
+        std::vector<std::pair<int32_t, int32_t>> piece_range(64, {0, 0});
+        parallel_ranges(g.nsv, 4096, [&](int64_t s0, int64_t s1, int t) {
+            std::vector<int32_t>& out = piece[t];
+            piece_range[t] = {(int32_t)s0, (int32_t)s1};
+            std::vector<int32_t> tmp;
+            for (int32_t s = (int32_t)s0; s < (int32_t)s1; ++s) {
+                const int32_t u = g.sv_members[g.sv_ptr[s]];
+                tmp.clear();
+                for (int32_t q = uptr[u]; q < uptr[u + 1]; ++q) {
+                    const int32_t v = g.sv_of[nb[q]];
+                    if (v != s) tmp.push_back(v);
+                }
+                std::sort(tmp.begin(), tmp.end());
+                tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+                out.insert(out.end(), tmp.begin(), tmp.end());
+                g.adj_ptr[s + 1] = (int32_t)tmp.size();
+            }
+        });
+        for (int32_t s = 0; s < g.nsv; ++s) g.adj_ptr[s + 1] += g.adj_ptr[s];
+        g.adj.resize(g.adj_ptr[g.nsv]);
+        for (int t = 0; t < 64; ++t)
+            if (!piece[t].empty()) std::copy(piece[t].begin(), piece[t].end(), g.adj.begin() + g.adj_ptr[piece_range[t].first]);
     }
     if (coords) {
         g.xyz.assign((size_t)g.nsv * 3, 0.0);
@@ -175,6 +207,7 @@ class NestedDissection {
     const SvGraph& g;
     std::vector<int32_t> stamp, dist, queue;
     int32_t cur_stamp = 0;
+    int threads = 1;  // host threads bisect() may use for its candidate cuts
     const int LEAF = std::getenv("SANM_MF_LEAF") ? std::atoi(std::getenv("SANM_MF_LEAF")) : 32;
 
 public:
@@ -227,7 +260,9 @@ public:
         }
         std::vector<NdNode> out(1);
         std::vector<int32_t> sep, pa, pb;
+        nd.threads = budget;
         nd.bisect(set, sep, pa, pb);
+        nd.threads = 1;
         if (pa.empty() || pb.empty()) {
             out[0].vars = std::move(set);
             return out;
@@ -325,15 +360,22 @@ public:
 
     // candidate cut: the first `cut` entries of `ord` (positions into `set`) form side A.  Returns the
     // weight of the smaller of the two boundary layers, an upper bound of the separator it yields.
+    // Reads shared state only (in_set == mark for the members of the set, dist = position in the set): candidates
+    // are weighed concurrently.
     int64_t boundary_weight(const std::vector<int32_t>& set, const std::vector<int32_t>& ord, size_t cut,
-                            int32_t markA, int32_t markB) {
-        for (size_t i = 0; i < ord.size(); ++i) in_set[set[ord[i]]] = i < cut ? markA : markB;
+                            int32_t mark) const {
+        std::vector<uint8_t> side(set.size());
+        for (size_t i = 0; i < ord.size(); ++i) side[ord[i]] = i < cut;
         int64_t wA = 0, wB = 0;
-        for (int32_t u : set) {
-            const int32_t other = in_set[u] == markA ? markB : markA;
+        for (size_t i = 0; i < set.size(); ++i) {
+            const int32_t u = set[i];
+            const uint8_t sa = side[i];
             bool touch = false;
-            for (int32_t q = g.adj_ptr[u]; q < g.adj_ptr[u + 1] && !touch; ++q) touch = in_set[g.adj[q]] == other;
-            if (touch) (in_set[u] == markA ? wA : wB) += g.size(u);
+            for (int32_t q = g.adj_ptr[u]; q < g.adj_ptr[u + 1] && !touch; ++q) {
+                const int32_t v = g.adj[q];
+                touch = in_set[v] == mark && side[dist[v]] != sa;
+            }
+            if (touch) (sa ? wA : wB) += g.size(u);
         }
         return std::min(wA, wB);
     }
@@ -444,30 +486,55 @@ public:
         // lighter separators but deepen the tree by a level, and every level costs two launches per solve
         // (measured on the three BASELINE meshes: 45..55 % is best or within 2 % of best)
         static const double fracs[] = {0.5, 0.45, 0.55};
-        std::vector<int32_t> best_ord;
-        size_t best_cut = 0;
-        double best_score = 1e300;
-        for (const auto& key : keys) {
-            std::vector<int32_t> ord(ns);
+        const int nf = ns < 200 ? 1 : 3;  // small sets: the median only
+        const int nk = (int)keys.size();
+        // The candidates read the graph, the set and its position map only (each writes a side array of its own):
+        // the cuts near the root -- up to 6 orderings x 3 positions over the whole graph, 0.09 of the 0.17 s of
+        // a 78 k-supervariable dissection -- are sorted and weighed by the threads the subtrees below will get.
+        for (size_t i = 0; i < ns; ++i) dist[set[i]] = (int32_t)i;
+        std::vector<std::vector<int32_t>> ords(nk);
+        std::vector<int64_t> weight((size_t)nk * nf, 0);
+        auto sort_key = [&](int k) {
+            const auto& key = keys[k];
+            std::vector<int32_t>& ord = ords[k];
+            ord.resize(ns);
             std::iota(ord.begin(), ord.end(), 0);
             std::sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) {
                 if (key[a] != key[b]) return key[a] < key[b];
                 if (key2[a] != key2[b]) return key2[a] < key2[b];
                 return set[a] < set[b];
             });
-            for (double f : fracs) {
-                const size_t cut = std::min(ns - 1, std::max<size_t>(1, (size_t)(f * ns)));
+        };
+        auto cut_of = [&](int f) { return std::min(ns - 1, std::max<size_t>(1, (size_t)(fracs[f] * ns))); };
+        auto weigh = [&](int c) { weight[c] = boundary_weight(set, ords[c / nf], cut_of(c % nf), mark); };
+        auto spread = [&](int count, auto&& fn) {
+            const int nt = ns >= 4096 ? std::min(threads, count) : 1;
+            if (nt <= 1) {
+                for (int i = 0; i < count; ++i) fn(i);
+                return;
+            }
+            std::vector<std::thread> th;
+            for (int t = 1; t < nt; ++t)
+                th.emplace_back([&, t] { for (int i = t; i < count; i += nt) fn(i); });
+            for (int i = 0; i < count; i += nt) fn(i);
+            for (auto& x : th) x.join();
+        };
+        spread(nk, sort_key);
+        spread(nk * nf, weigh);
+        int best_k = 0;
+        size_t best_cut = 0;
+        double best_score = 1e300;
+        for (int k = 0; k < nk; ++k)
+            for (int f = 0; f < nf; ++f) {
                 // an unbalanced cut must pay for itself: the larger part is dissected one level deeper
-                const double score = (double)boundary_weight(set, ord, cut, markA, markB) *
-                                     (1.0 + 2.0 * std::fabs(f - 0.5));
+                const double score = (double)weight[k * nf + f] * (1.0 + 2.0 * std::fabs(fracs[f] - 0.5));
                 if (score < best_score) {
                     best_score = score;
-                    best_cut = cut;
-                    best_ord = ord;
+                    best_cut = cut_of(f);
+                    best_k = k;
                 }
-                if (ns < 200) break;  // small sets: the median only
             }
-        }
+        const std::vector<int32_t>& best_ord = ords[best_k];
         for (size_t i = 0; i < ns; ++i) in_set[set[best_ord[i]]] = i < best_cut ? markA : markB;
 
         // boundary layers and the bipartite graph of the cut edges
@@ -1340,8 +1407,10 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     m_dev.own_front = upload(owner);
     m_dev.a_dst = upload(a_dst);
     m_sched.ea_children = upload(ea_children);
+    lap("device tables: uploads");
     m_dev.front_store_size = off;
     m_dev.front_store = static_cast<double*>(be->alloc(off * sizeof(double)));
+    lap("device tables: front store");
     // (n doubles, and room behind them for the solution of the merged top block, MfSchedule::Top)
     const char* env_top = std::getenv("SANM_MF_TOP");
     const int32_t top_max_n = env_top ? std::atoi(env_top) : 0;

@@ -47,6 +47,7 @@ DeviceRows::DeviceRows(Backend* be, const SparseDesc& d, int64_t T, int64_t Tpad
         return e >= tet_begin && e < tet_end;
     };
     const int64_t nr = d.out_size;
+    SetupLaps laps("remap_out rows");
     std::vector<uint32_t> ptr(nr + 1, 0);
     parallel_ranges(nr, 16384, [&](int64_t i0, int64_t i1, int) {
         for (int64_t i = i0; i < i1; ++i) {
@@ -102,15 +103,18 @@ DeviceRows::DeviceRows(Backend* be, const SparseDesc& d, int64_t T, int64_t Tpad
             }
         });
     };
+    laps.lap("counts, triples");
     std::vector<uint32_t> optr, oidx;
     std::vector<double> ocoef;
     pack(triples ? 3 : 1, optr, oidx, ocoef);
+    laps.lap("pack");
     void* dptr = be->alloc(optr.size() * 4);
     void* didx = be->alloc(std::max<size_t>(oidx.size(), 1) * 4);
     void* dcoef = be->alloc(std::max<size_t>(oidx.size(), 1) * 8);
     be->h2d(dptr, optr.data(), optr.size() * 4);
     be->h2d(didx, oidx.data(), oidx.size() * 4);
     be->h2d(dcoef, ocoef.data(), oidx.size() * 8);
+    laps.lap("upload");
     if (triples) {
         // only the list of the first row of each triple is kept (row_ops.h: gather_row reads rows 3u+1, 3u+2 through it)
         m_bptr = dptr, m_bidx = didx, m_bcoef = dcoef;
@@ -137,11 +141,15 @@ DeviceRows::~DeviceRows() {
 }
 
 template <class T>
-T* JacobianPattern::upload(const std::vector<T>& v) {
-    void* p = m_be->alloc(std::max<size_t>(v.size(), 1) * sizeof(T));
-    if (!v.empty()) m_be->h2d(p, v.data(), v.size() * sizeof(T));
+T* JacobianPattern::upload(const T* v, size_t count) {
+    void* p = m_be->alloc(std::max<size_t>(count, 1) * sizeof(T));
+    if (count) m_be->h2d(p, v, count * sizeof(T));
     m_bufs.push_back(p);
     return static_cast<T*>(p);
+}
+template <class T>
+T* JacobianPattern::upload(const std::vector<T>& v) {
+    return upload(v.data(), v.size());
 }
 
 JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const SparseDesc& ri, int64_t n,
@@ -165,6 +173,7 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
                "remap tables too large for 32-bit indices");
     sanm_check((uint64_t)(tet_end - tet_begin) * odim * idim < std::numeric_limits<uint32_t>::max(),
                "mesh too large for 32-bit Jacobian block indices");
+    SetupLaps laps("pattern");
     struct Part {
         std::vector<uint32_t> row_nnz, col;
         int64_t contrib = 0;
@@ -181,20 +190,20 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
         try {
             for (int64_t i = r0; i < r1; ++i) {
                 ucol.clear();
+                uint64_t last_b = ~0ull;  // (a row lists the elements of one batch item side by side: its columns once)
                 for (uint64_t p = ro.rowptr[i]; p < ro.rowptr[i + 1]; ++p) {
                     const uint64_t b = ro.idx[p] / odim;  // (the caller's numbering, like the rows of ri)
                     const int64_t bn = tet_inv ? tet_inv[b] : (int64_t)b;
                     const bool mine = bn >= tet_begin && bn < tet_end;
-                    for (int m = 0; m < idim; ++m) {
-                        const uint64_t irow = b * idim + m;
-                        for (uint64_t q = ri.rowptr[irow]; q < ri.rowptr[irow + 1]; ++q) {
-                            const uint32_t c = (uint32_t)ri.idx[q];
-                            if (!mark[c]) {
-                                mark[c] = 1;
-                                ucol.push_back(c);
-                            }
+                    if (mine) P.contrib += (int64_t)(ri.rowptr[(b + 1) * idim] - ri.rowptr[b * idim]);
+                    if (b == last_b) continue;
+                    last_b = b;
+                    for (uint64_t q = ri.rowptr[b * idim]; q < ri.rowptr[(b + 1) * idim]; ++q) {
+                        const uint32_t c = (uint32_t)ri.idx[q];
+                        if (!mark[c]) {
+                            mark[c] = 1;
+                            ucol.push_back(c);
                         }
-                        if (mine) P.contrib += (int64_t)(ri.rowptr[irow + 1] - ri.rowptr[irow]);
                     }
                 }
                 std::sort(ucol.begin(), ucol.end());
@@ -219,21 +228,31 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
         for (auto& x : th) x.join();
     }
     for (const Part& P : parts) sanm_check(P.error.empty(), "%s", P.error.c_str());
-    std::vector<uint32_t> rowptr(n + 1, 0), col;
+    laps.lap("rows");
+    std::vector<uint32_t>& rowptr = m_h_rowptr;
+    std::vector<uint32_t>& col = m_h_col;
+    rowptr.assign(n + 1, 0);
     {
         size_t ncol = 0;
-        for (const Part& P : parts) ncol += P.col.size();
+        std::vector<size_t> part_off;
+        for (const Part& P : parts) {
+            part_off.push_back(ncol);
+            ncol += P.col.size();
+        }
         sanm_check(ncol < std::numeric_limits<uint32_t>::max(), "Jacobian pattern too large");
-        col.reserve(ncol);
+        col.resize(ncol);
         int64_t i = 0;
         for (const Part& P : parts) {
             for (size_t r = 0; r < P.row_nnz.size(); ++r, ++i) rowptr[i + 1] = rowptr[i] + P.row_nnz[r];
-            col.insert(col.end(), P.col.begin(), P.col.end());
             m_nr_contrib += P.contrib;
         }
+        std::vector<std::thread> th;
+        for (int t = 1; t < nthread; ++t)
+            th.emplace_back([&, t] { std::copy(parts[t].col.begin(), parts[t].col.end(), col.begin() + part_off[t]); });
+        std::copy(parts[0].col.begin(), parts[0].col.end(), col.begin());
+        for (auto& x : th) x.join();
     }
-    m_h_rowptr = rowptr;
-    m_h_col = col;
+    laps.lap("merge");
 
     m_csr.n = n;
     m_csr.nnz = col.size();
@@ -245,17 +264,20 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
         m_bufs.push_back(val);
         m_csr.val = static_cast<double*>(val);
     }
+    laps.lap("csr upload");
     // the remap tables as the assembly reads them: 32-bit, in the renumbered batch order
     {
         std::vector<uint32_t> v32(ro.rowptr.begin(), ro.rowptr.end());
         m_asm.ro_ptr = upload(v32);
-        v32.resize(ro.idx.size());
+        auto o32 = raw_array<uint32_t>(ro.idx.size());
         parallel_ranges((int64_t)ro.idx.size(), 1 << 18, [&](int64_t q0, int64_t q1, int) {
             for (int64_t q = q0; q < q1; ++q)
-                v32[q] = (uint32_t)(tet_inv ? tet_inv[ro.idx[q] / odim] * odim + ro.idx[q] % odim : ro.idx[q]);
+                o32[q] = (uint32_t)(tet_inv ? tet_inv[ro.idx[q] / odim] * odim + ro.idx[q] % odim : ro.idx[q]);
         });
-        m_asm.ro_idx = upload(v32);
+        laps.lap("remap tables: ro convert");
+        m_asm.ro_idx = upload(o32.get(), ro.idx.size());
         m_asm.ro_coef = upload(ro.coef);
+        laps.lap("remap tables: ro upload");
         // rows of ri: batch item e of the table is the caller's item tet_order[e]
         const int64_t nrow = ri.out_size;
         v32.assign(nrow + 1, 0);
@@ -265,9 +287,8 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
                 v32[e * idim + m + 1] = v32[e * idim + m] + (uint32_t)(ri.rowptr[src + m + 1] - ri.rowptr[src + m]);
         }
         m_asm.ri_ptr = upload(v32);
-        std::vector<uint32_t> i32(ri.idx.size());
-        std::vector<double> c64;
-        if (tet_order) c64.resize(ri.coef.size());
+        auto i32 = raw_array<uint32_t>(ri.idx.size());
+        auto c64 = raw_array<double>(tet_order ? ri.coef.size() : 0);
         parallel_ranges(T, 16384, [&](int64_t e0, int64_t e1, int) {
             for (int64_t e = e0; e < e1; ++e) {
                 const int64_t src = (tet_order ? tet_order[e] : e) * idim;
@@ -278,10 +299,11 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
                 }
             }
         });
-        m_asm.ri_idx = upload(i32);
-        const std::vector<double>* rc = tet_order ? &c64 : &ri.coef;
-        m_asm.ri_coef = upload(*rc);
+        laps.lap("remap tables: ri convert");
+        m_asm.ri_idx = upload(i32.get(), ri.idx.size());
+        m_asm.ri_coef = upload(tet_order ? c64.get() : ri.coef.data(), ri.coef.size());
     }
+    laps.lap("remap tables");
     m_asm.rowptr = m_csr.rowptr;
     m_asm.col = m_csr.col;
     m_asm.n = n;
@@ -292,6 +314,7 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
     m_asm.has_t = m_has_t ? 1 : 0;
     m_asm.nnz = m_csr.nnz;
     be->prepare_assembly(m_asm, m_bufs);
+    laps.lap("assembly lists");
 }
 
 JacobianPattern::~JacobianPattern() {

@@ -85,6 +85,8 @@ private:
     std::vector<void*> m_bufs;
     template <class T>
     T* upload(const std::vector<T>& v);
+    template <class T>
+    T* upload(const T* v, size_t count);
 };
 
 }  // namespace sanm_hip
