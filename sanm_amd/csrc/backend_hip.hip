@@ -617,6 +617,75 @@ struct GsRider {
     GridRed g;
 };
 
+// Exclusive prefix sum of v[0 .. m) in place with the total in v[m] (prepare_assembly: list offsets from list lengths
+// without a round trip through the host): sums of blocks of 1024, their offsets by one workgroup, then each block again.
+constexpr int SCAN_BLOCK = 1024;
+__global__ void __launch_bounds__(256) scan_block_sums_kernel(const uint32_t* __restrict__ v, size_t m,
+                                                              uint64_t* __restrict__ bsum) {
+    __shared__ uint64_t red[256];
+    const size_t base = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x * 4;
+    uint64_t s = 0;
+    for (int k = 0; k < 4; ++k)
+        if (base + k < m) s += v[base + k];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bsum[blockIdx.x] = red[0];
+}
+__global__ void __launch_bounds__(256) scan_offsets_kernel(uint64_t* __restrict__ bsum, size_t nb) {
+    __shared__ uint64_t part[256];
+    const size_t per = (nb + 255) / 256, b0 = min(nb, threadIdx.x * per), b1 = min(nb, b0 + per);
+    uint64_t s = 0;
+    for (size_t b = b0; b < b1; ++b) s += bsum[b];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t run = 0;
+        for (int t = 0; t < 256; ++t) {
+            const uint64_t c = part[t];
+            part[t] = run;
+            run += c;
+        }
+        bsum[nb] = run;
+    }
+    __syncthreads();
+    uint64_t run = part[threadIdx.x];
+    for (size_t b = b0; b < b1; ++b) {
+        const uint64_t c = bsum[b];
+        bsum[b] = run;
+        run += c;
+    }
+}
+__global__ void __launch_bounds__(256) scan_apply_kernel(uint32_t* __restrict__ v, size_t m,
+                                                         const uint64_t* __restrict__ bsum, size_t nb) {
+    __shared__ uint32_t tsum[256];
+    const int tid = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * SCAN_BLOCK + tid * 4;
+    uint32_t x[4], s = 0;
+    for (int k = 0; k < 4; ++k) {
+        x[k] = base + k < m ? v[base + k] : 0u;
+        s += x[k];
+    }
+    tsum[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const uint32_t add = tid >= off ? tsum[tid - off] : 0u;
+        __syncthreads();
+        tsum[tid] += add;
+        __syncthreads();
+    }
+    uint32_t run = (uint32_t)bsum[blockIdx.x] + tsum[tid] - s;
+    for (int k = 0; k < 4; ++k)
+        if (base + k < m) {
+            v[base + k] = run;
+            run += x[k];
+        }
+    if (blockIdx.x == 0 && tid == 0) v[m] = (uint32_t)bsum[nb];
+}
+
 // remap_out with its rows in triples (SparseRowsDev::bptr): GATHER_LANES lanes per vertex, one list entry feeds the
 // three components (their values sit 3 doubles apart in the tet's block of the tet-major output buffer)
 template <int RIDE_NVT>
@@ -2072,26 +2141,21 @@ public:
         HIP_CHECK(hipGetLastError());
         if (dbg) sync();
         laps.lap("count kernel");
-        std::vector<uint32_t> h(nnz + 1), ht(n + 1);
-        d2h(h.data(), cnt, nnz * 4);
-        d2h(ht.data(), tcnt, n * 4);
-        auto scan = [](std::vector<uint32_t>& v, size_t m, const char* what) {
-            uint64_t run = 0;
-            for (size_t q = 0; q < m; ++q) {
-                const uint32_t c = v[q];
-                v[q] = (uint32_t)run;
-                run += c;
-            }
-            sanm_check(run < std::numeric_limits<uint32_t>::max(), "%s list too large", what);
-            v[m] = (uint32_t)run;
-            return (size_t)run;
+        auto scan = [&](uint32_t* v, size_t m, const char* what) {
+            const size_t nb = (m + SCAN_BLOCK - 1) / SCAN_BLOCK;
+            uint64_t* bsum = static_cast<uint64_t*>(alloc((nb + 1) * 8));
+            if (nb) SANM_LAUNCH(scan_block_sums_kernel, dim3((unsigned)nb), dim3(256), 0, m_stream, v, m, bsum);
+            SANM_LAUNCH(scan_offsets_kernel, dim3(1), dim3(256), 0, m_stream, bsum, nb);
+            SANM_LAUNCH(scan_apply_kernel, dim3((unsigned)std::max<size_t>(nb, 1)), dim3(256), 0, m_stream, v, m, bsum, nb);
+            HIP_CHECK(hipGetLastError());
+            uint64_t total = 0;
+            d2h(&total, bsum + nb, 8);
+            free(bsum);
+            sanm_check(total < std::numeric_limits<uint32_t>::max(), "%s list too large", what);
+            return (size_t)total;
         };
-        laps.lap("d2h");
-        const size_t tot = scan(h, nnz, "assembly"), ttot = scan(ht, n, "grad_t");
-        laps.lap("scan");
-        h2d(cnt, h.data(), (nnz + 1) * 4);
-        h2d(tcnt, ht.data(), (n + 1) * 4);
-        laps.lap("h2d");
+        const size_t tot = scan(cnt, nnz, "assembly"), ttot = scan(tcnt, n, "grad_t");
+        laps.lap("offsets");
         uint32_t* jx = static_cast<uint32_t*>(alloc(std::max<size_t>(tot, 1) * 4));
         double* cf = static_cast<double*>(alloc(std::max<size_t>(tot, 1) * 8));
         uint32_t* tjx = static_cast<uint32_t*>(alloc(std::max<size_t>(ttot, 1) * 4));

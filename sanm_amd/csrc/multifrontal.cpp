@@ -33,13 +33,14 @@ struct SvGraph {
 
 SvGraph build_sv_graph(int64_t n, const std::vector<uint32_t>& rowptr,
                        const std::vector<uint32_t>& col, const double* coords) {
-    // symmetrised adjacency including the diagonal.  Rows on several threads: the counters are bumped atomically and
-    // the lists come out in whatever order the threads reached them -- every list is sorted below, so the graph does
-    // not depend on that order.
+    // symmetrised adjacency including the diagonal.  Every thread scans ALL rows and keeps what lands in its own range
+    // of unknowns (the entries of its rows and the transposed entries pointing into them): no shared counters, and
+    // each list receives its entries in the order one thread would append them.
     std::vector<int32_t> deg(n + 1, 0);
     std::vector<std::string> errs(64);
     parallel_ranges(n, 8192, [&](int64_t r0, int64_t r1, int t) {
-        for (int64_t i = r0; i < r1; ++i) {
+        for (int64_t i = 0; i < n; ++i) {
+            const bool own_row = i >= r0 && i < r1;
             int32_t own = 0;
             for (uint32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
                 const int64_t j = col[p];
@@ -47,12 +48,11 @@ SvGraph build_sv_graph(int64_t n, const std::vector<uint32_t>& rowptr,
                     errs[t % 64] = "column index out of range";
                     return;
                 }
-                if (j != i) {
-                    ++own;
-                    std::atomic_ref<int32_t>(deg[j + 1]).fetch_add(1, std::memory_order_relaxed);
-                }
+                if (j == i) continue;
+                ++own;
+                if (j >= r0 && j < r1) deg[j + 1]++;
             }
-            std::atomic_ref<int32_t>(deg[i + 1]).fetch_add(own, std::memory_order_relaxed);
+            if (own_row) deg[i + 1] += own;
         }
     });
     for (const auto& e : errs) sanm_check(e.empty(), "%s", e.c_str());
@@ -62,14 +62,14 @@ SvGraph build_sv_graph(int64_t n, const std::vector<uint32_t>& rowptr,
     {
         std::vector<int32_t> fill(deg.begin(), deg.end() - 1);
         parallel_ranges(n, 8192, [&](int64_t r0, int64_t r1, int) {
-            for (int64_t i = r0; i < r1; ++i) {
-                nb[std::atomic_ref<int32_t>(fill[i]).fetch_add(1, std::memory_order_relaxed)] = (int32_t)i;
+            for (int64_t i = r0; i < r1; ++i) nb[fill[i]++] = (int32_t)i;
+            for (int64_t i = 0; i < n; ++i) {
+                const bool own_row = i >= r0 && i < r1;
                 for (uint32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
                     const int64_t j = col[p];
-                    if (j != i) {
-                        nb[std::atomic_ref<int32_t>(fill[i]).fetch_add(1, std::memory_order_relaxed)] = (int32_t)j;
-                        nb[std::atomic_ref<int32_t>(fill[j]).fetch_add(1, std::memory_order_relaxed)] = (int32_t)i;
-                    }
+                    if (j == i) continue;
+                    if (own_row) nb[fill[i]++] = (int32_t)j;
+                    if (j >= r0 && j < r1) nb[fill[j]++] = (int32_t)i;
                 }
             }
         });

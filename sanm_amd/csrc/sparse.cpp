@@ -174,6 +174,7 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
     sanm_check((uint64_t)(tet_end - tet_begin) * odim * idim < std::numeric_limits<uint32_t>::max(),
                "mesh too large for 32-bit Jacobian block indices");
     SetupLaps laps("pattern");
+    const bool sharded = tet_begin != 0 || tet_end != T;
     struct Part {
         std::vector<uint32_t> row_nnz, col;
         int64_t contrib = 0;
@@ -192,9 +193,13 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
                 ucol.clear();
                 uint64_t last_b = ~0ull;  // (a row lists the elements of one batch item side by side: its columns once)
                 for (uint64_t p = ro.rowptr[i]; p < ro.rowptr[i + 1]; ++p) {
-                    const uint64_t b = ro.idx[p] / odim;  // (the caller's numbering, like the rows of ri)
-                    const int64_t bn = tet_inv ? tet_inv[b] : (int64_t)b;
-                    const bool mine = bn >= tet_begin && bn < tet_end;
+                    // (the caller's numbering, like the rows of ri; 9: a division the compiler turns into a multiply)
+                    const uint64_t b = odim == 9 ? ro.idx[p] / 9 : ro.idx[p] / odim;
+                    bool mine = true;
+                    if (sharded) {
+                        const int64_t bn = tet_inv ? tet_inv[b] : (int64_t)b;
+                        mine = bn >= tet_begin && bn < tet_end;
+                    }
                     if (mine) P.contrib += (int64_t)(ri.rowptr[(b + 1) * idim] - ri.rowptr[b * idim]);
                     if (b == last_b) continue;
                     last_b = b;
