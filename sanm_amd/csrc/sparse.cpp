@@ -189,9 +189,11 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
         std::vector<uint8_t> mark(n + 1, 0);
         std::vector<uint32_t> ucol;
         try {
+            // a row whose batch items are those of the row before it (the three components of a vertex) has its columns
+            std::vector<uint64_t> items, prev_items;
+            uint32_t prev_nnz = 0;
             for (int64_t i = r0; i < r1; ++i) {
-                ucol.clear();
-                uint64_t last_b = ~0ull;  // (a row lists the elements of one batch item side by side: its columns once)
+                items.clear();
                 for (uint64_t p = ro.rowptr[i]; p < ro.rowptr[i + 1]; ++p) {
                     // (the caller's numbering, like the rows of ri; 9: a division the compiler turns into a multiply)
                     const uint64_t b = odim == 9 ? ro.idx[p] / 9 : ro.idx[p] / odim;
@@ -201,8 +203,19 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
                         mine = bn >= tet_begin && bn < tet_end;
                     }
                     if (mine) P.contrib += (int64_t)(ri.rowptr[(b + 1) * idim] - ri.rowptr[b * idim]);
-                    if (b == last_b) continue;
-                    last_b = b;
+                    if (items.empty() || items.back() != b) items.push_back(b);
+                }
+                if (i > r0 && items == prev_items) {
+                    const size_t from = P.col.size() - prev_nnz;
+                    for (uint32_t q = 0; q < prev_nnz; ++q) {
+                        const uint32_t c = P.col[from + q];  // (by value: push_back may move the storage)
+                        P.col.push_back(c);
+                    }
+                    P.row_nnz.push_back(prev_nnz);
+                    continue;
+                }
+                ucol.clear();
+                for (uint64_t b : items)
                     for (uint64_t q = ri.rowptr[b * idim]; q < ri.rowptr[(b + 1) * idim]; ++q) {
                         const uint32_t c = (uint32_t)ri.idx[q];
                         if (!mark[c]) {
@@ -210,7 +223,6 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
                             ucol.push_back(c);
                         }
                     }
-                }
                 std::sort(ucol.begin(), ucol.end());
                 uint32_t nnz_row = 0;
                 for (uint32_t c : ucol) {
@@ -221,6 +233,8 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
                 }
                 sanm_check(nnz_row > 0, "empty row %ld", (long)i);  // sparse_solver.cpp:251-252
                 P.row_nnz.push_back(nnz_row);
+                prev_nnz = nnz_row;
+                prev_items.swap(items);
             }
         } catch (const SanmError& e) {
             P.error = e.msg;
@@ -286,11 +300,13 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
         // rows of ri: batch item e of the table is the caller's item tet_order[e]
         const int64_t nrow = ri.out_size;
         v32.assign(nrow + 1, 0);
-        for (int64_t e = 0; e < T; ++e) {
-            const int64_t src = (tet_order ? tet_order[e] : e) * idim;
-            for (int m = 0; m < idim; ++m)
-                v32[e * idim + m + 1] = v32[e * idim + m] + (uint32_t)(ri.rowptr[src + m + 1] - ri.rowptr[src + m]);
-        }
+        parallel_ranges(T, 16384, [&](int64_t e0, int64_t e1, int) {
+            for (int64_t e = e0; e < e1; ++e) {
+                const int64_t src = (tet_order ? tet_order[e] : e) * idim;
+                for (int m = 0; m < idim; ++m) v32[e * idim + m + 1] = (uint32_t)(ri.rowptr[src + m + 1] - ri.rowptr[src + m]);
+            }
+        });
+        for (int64_t r = 0; r < nrow; ++r) v32[r + 1] += v32[r];
         m_asm.ri_ptr = upload(v32);
         auto i32 = raw_array<uint32_t>(ri.idx.size());
         auto c64 = raw_array<double>(tet_order ? ri.coef.size() : 0);
