@@ -2497,10 +2497,10 @@ public:
         }
         if (fwd && phase == 0 && L.fwd_t) {
             // boundary operator stored transposed (Level::fwd_t): pivot rows by lane groups, boundary rows by threads
-            sanm_check(width <= 128, "transposed forward operator on a level of %d-pivot fronts", width);
+            sanm_check(width <= kFwdTMaxK, "transposed forward operator on a level of %d-pivot fronts", width);
             const int cnt = L.front_end - L.front_begin;
             const size_t lds = ((size_t)L.max_k + 256) * sizeof(double);
-            const int g = width <= 32 ? 8 : (width <= 64 ? 16 : 32);
+            const int g = width <= 32 ? 8 : (width <= 64 ? 16 : (width <= 128 ? 32 : 64));
             const int nbb = (L.max_b + 63) / 64;
 #define SANM_FT(G)                                                                                                  \
     if (g == G) {                                                                                                   \
@@ -2509,7 +2509,7 @@ public:
                     mf.lfronts + L.front_begin, mf.front_store, mf.inbox_store, mf.work, mf.work2, mf.upd_dst, nzb); \
         return;                                                                                                     \
     }
-            SANM_FT(8) SANM_FT(16) SANM_FT(32)
+            SANM_FT(8) SANM_FT(16) SANM_FT(32) SANM_FT(64)
 #undef SANM_FT
         }
         if ((size_t)(fwd || phase == 2 ? L.max_k : L.max_m) * sizeof(double) > lds_max) {

@@ -7,6 +7,8 @@
 namespace sanm_hip {
 
 constexpr int MF_NB = 32;  // panel / tile width
+// widest pivot block of a level whose forward boundary operator is kept transposed (Level::fwd_t; SANM_MF_FWD_T_MAX_K)
+constexpr int kFwdTMaxK = 256;
 // Static pivot perturbation, as PARDISO does for unsymmetric matrices (iparm[9] = 13, the setting the reference's
 // pardisoinit leaves in place, libsanm/sparse_solver.cpp:107-127): a pivot smaller in magnitude than
 // MF_PIVOT_EPS * max|a_ij| is replaced by that value with the pivot's sign and counted; a factorisation with
@@ -96,7 +98,7 @@ struct MfSchedule {
         // k entries at a stride of 2k + b), is written TRANSPOSED into the F[P,B] slot, which is dead once the
         // triangular products have read it: k long rows of b entries.  The forward kernel then gives a boundary row to
         // a thread (coalesced loads down the columns, no cross-lane reduction) instead of a row of a few dozen entries to
-        // a lane group.  Levels of short pivot blocks (max_k <= 128) that are not two-phase.
+        // a lane group.  Levels of short pivot blocks (max_k <= kFwdTMaxK) that are not two-phase.
         bool fwd_t = false;
         std::vector<int32_t> panel_cnt;  // number of fronts with k > p*NB
         std::vector<int32_t> front_k;    // pivot counts of the level's fronts in launch order (decreasing)

@@ -33,6 +33,7 @@ struct SvGraph {
 
 SvGraph build_sv_graph(int64_t n, const std::vector<uint32_t>& rowptr,
                        const std::vector<uint32_t>& col, const double* coords) {
+    SetupLaps laps("svgraph");
     // symmetrised adjacency including the diagonal.  Every thread scans ALL rows and keeps what lands in its own range
     // of unknowns (the entries of its rows and the transposed entries pointing into them): no shared counters, and
     // each list receives its entries in the order one thread would append them.
@@ -74,6 +75,7 @@ SvGraph build_sv_graph(int64_t n, const std::vector<uint32_t>& rowptr,
             }
         });
     }
+    laps.lap("symmetrise");
     // sort + unique every list, hash it (rows in parallel, in place), then pack the lists
     std::vector<int32_t> uptr(n + 1, 0);
     std::vector<uint64_t> hash(n);
@@ -100,6 +102,7 @@ SvGraph build_sv_graph(int64_t n, const std::vector<uint32_t>& rowptr,
         nb_raw.reset();
         nb = dst;
     }
+    laps.lap("sort lists, pack");
     // group indistinguishable unknowns (same closed neighbourhood)
     std::vector<int32_t> order(n);
     std::iota(order.begin(), order.end(), 0);
@@ -107,6 +110,7 @@ SvGraph build_sv_graph(int64_t n, const std::vector<uint32_t>& rowptr,
         if (hash[a] != hash[b]) return hash[a] < hash[b];
         return a < b;
     });
+    laps.lap("sort by hash");
     SvGraph g;
     g.sv_of.assign(n, -1);
     auto same = [&](int32_t a, int32_t b) {
@@ -135,6 +139,7 @@ SvGraph build_sv_graph(int64_t n, const std::vector<uint32_t>& rowptr,
         }
         q = e;
     }
+    laps.lap("group");
     // renumber supervariables by their smallest member to keep locality
     g.nsv = rep.size();
     {
@@ -155,6 +160,7 @@ SvGraph build_sv_graph(int64_t n, const std::vector<uint32_t>& rowptr,
         std::vector<int32_t> fill(g.sv_ptr.begin(), g.sv_ptr.end() - 1);
         for (int64_t i = 0; i < n; ++i) g.sv_members[fill[g.sv_of[i]]++] = i;
     }
+    laps.lap("renumber, members");
     // compressed adjacency from the first member of each supervariable (lists by ranges of supervariables, then
     // joined in order)
     g.adj_ptr.assign(g.nsv + 1, 0);
@@ -183,6 +189,7 @@ SvGraph build_sv_graph(int64_t n, const std::vector<uint32_t>& rowptr,
         for (int t = 0; t < 64; ++t)
             if (!piece[t].empty()) std::copy(piece[t].begin(), piece[t].end(), g.adj.begin() + g.adj_ptr[piece_range[t].first]);
     }
+    laps.lap("adjacency");
     if (coords) {
         g.xyz.assign((size_t)g.nsv * 3, 0.0);
         for (int32_t s = 0; s < g.nsv; ++s) {
@@ -1290,7 +1297,13 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
             // (SANM_MF_FWD_T=0: never; the merged top block reads F[B,A] itself: not together with SANM_MF_TOP)
             const char* env_ft = std::getenv("SANM_MF_FWD_T");
             const bool want = env_ft ? std::atoi(env_ft) != 0 : true;
-            L.fwd_t = want && !L.two_phase && L.max_k <= 128 && L.max_b > 0 && !std::getenv("SANM_MF_TOP");
+            static const int fwd_t_max_k = std::getenv("SANM_MF_FWD_T_MAX_K") ? std::min(kFwdTMaxK, std::atoi(std::getenv("SANM_MF_FWD_T_MAX_K"))) : kFwdTMaxK;
+            // (pivot blocks of 129 .. 256: a thread per boundary row walks a column of up to 64 entries per wavefront
+            // quarter -- it pays where the level has rows enough to fill the chip with such threads: refine:armadillo_
+            // small:1, levels of 152 / 80 / 47 fronts: solves 10.76 -> 10.12 ms per step; the 32-front level of
+            // armadillo_small, 13 k rows, lost 0.11 ms)
+            const bool rows_enough = L.max_k <= 128 || L.sum_m - L.sum_k >= 24576;
+            L.fwd_t = want && !L.two_phase && L.max_k <= fwd_t_max_k && rows_enough && L.max_b > 0 && !std::getenv("SANM_MF_TOP");
         }
         {
             int64_t t = 0;
