@@ -846,7 +846,7 @@ std::vector<int64_t> spatial_tet_order(const SparseDesc& remap_inp, const std::v
     double tlo[kMaxThr][3], thi[kMaxThr][3];
     for (int t = 0; t < kMaxThr; ++t)
         for (int d = 0; d < 3; ++d) tlo[t][d] = 1e300, thi[t][d] = -1e300;
-    parallel_ranges(T, 16384, [&](int64_t e0, int64_t e1, int t) {
+    parallel_ranges(T, 4096, [&](int64_t e0, int64_t e1, int t) {
         double* lo = tlo[t % kMaxThr];  // min / max are exact: any grouping gives the same box
         double* hi = thi[t % kMaxThr];
         for (int64_t e = e0; e < e1; ++e) {
@@ -878,7 +878,7 @@ std::vector<int64_t> spatial_tet_order(const SparseDesc& remap_inp, const std::v
         return v;
     };
     std::vector<std::pair<uint64_t, int64_t>> key(T);
-    parallel_ranges(T, 16384, [&](int64_t e0, int64_t e1, int) {
+    parallel_ranges(T, 4096, [&](int64_t e0, int64_t e1, int) {
         for (int64_t e = e0; e < e1; ++e) {
             uint64_t k = 0;
             for (int d = 0; d < 3; ++d) {

@@ -612,7 +612,7 @@ Program::Program(Backend* be, const Graph& g, int out_var, int64_t T, int max_or
                    "ConstantOprMeta shape mismatch in data parallel: tot_batch=%ld value_shape=%ld",
                    (long)T_global, (long)op.batch);
         soa.assign((size_t)d.size * Tpad, 0.0);
-        parallel_ranges(T, 16384, [&](int64_t e0, int64_t e1, int) {
+        parallel_ranges(T, 4096, [&](int64_t e0, int64_t e1, int) {
             for (int64_t e = e0; e < e1; ++e) {
                 const int64_t src = op.batch == 1 ? 0 : (tet_order ? tet_order[tet_begin + e] : tet_begin + e);
                 for (int c = 0; c < d.size; ++c) soa[c * Tpad + e] = op.value[src * d.size + c];
@@ -906,7 +906,7 @@ void Program::set_remap_in(int64_t n_in, const uint64_t* rowptr, const uint64_t*
     auto hidx = raw_array<uint32_t>(tab);   // every entry written below: the workers touch their own pages
     auto hcoef = raw_array<double>(tab);
     std::vector<int64_t> bad(64, -1);
-    parallel_ranges(Tpad, 16384, [&](int64_t e0, int64_t e1, int t) {
+    parallel_ranges(Tpad, 4096, [&](int64_t e0, int64_t e1, int t) {
         for (int64_t e = e0; e < e1; ++e)
             for (int c = 0; c < 9; ++c) {
                 int s = 0;

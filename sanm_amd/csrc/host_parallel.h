@@ -36,7 +36,7 @@ void parallel_ranges(int64_t n, int64_t min_per_thread, F&& fn) {
 //! std::sort by pieces on the threads of parallel_ranges, merged pairwise.  cmp must be a strict TOTAL order (break
 //! ties by index): then the result is the sequential sort's whatever the number of pieces.
 template <class It, class Cmp>
-void parallel_sort(It first, It last, Cmp cmp, int64_t min_per_thread = 16384) {
+void parallel_sort(It first, It last, Cmp cmp, int64_t min_per_thread = 4096) {
     const int64_t n = last - first;
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(host_thread_cap(), n / std::max<int64_t>(min_per_thread, 1)));
     if (nt <= 1) {

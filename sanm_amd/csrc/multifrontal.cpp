@@ -39,7 +39,7 @@ SvGraph build_sv_graph(int64_t n, const std::vector<uint32_t>& rowptr,
     // each list receives its entries in the order one thread would append them.
     std::vector<int32_t> deg(n + 1, 0);
     std::vector<std::string> errs(64);
-    parallel_ranges(n, 8192, [&](int64_t r0, int64_t r1, int t) {
+    parallel_ranges(n, 2048, [&](int64_t r0, int64_t r1, int t) {
         for (int64_t i = 0; i < n; ++i) {
             const bool own_row = i >= r0 && i < r1;
             int32_t own = 0;
@@ -62,7 +62,7 @@ SvGraph build_sv_graph(int64_t n, const std::vector<uint32_t>& rowptr,
     int32_t* nb = nb_raw.get();
     {
         std::vector<int32_t> fill(deg.begin(), deg.end() - 1);
-        parallel_ranges(n, 8192, [&](int64_t r0, int64_t r1, int) {
+        parallel_ranges(n, 2048, [&](int64_t r0, int64_t r1, int) {
             for (int64_t i = r0; i < r1; ++i) nb[fill[i]++] = (int32_t)i;
             for (int64_t i = 0; i < n; ++i) {
                 const bool own_row = i >= r0 && i < r1;
@@ -82,7 +82,7 @@ SvGraph build_sv_graph(int64_t n, const std::vector<uint32_t>& rowptr,
     std::unique_ptr<int32_t[]> unb_raw;
     {
         std::vector<int32_t> ulen(n);
-        parallel_ranges(n, 8192, [&](int64_t r0, int64_t r1, int) {
+        parallel_ranges(n, 2048, [&](int64_t r0, int64_t r1, int) {
             for (int64_t i = r0; i < r1; ++i) {
                 int32_t b = deg[i], e = deg[i + 1];
                 std::sort(nb + b, nb + e);
@@ -96,7 +96,7 @@ SvGraph build_sv_graph(int64_t n, const std::vector<uint32_t>& rowptr,
         for (int64_t i = 0; i < n; ++i) uptr[i + 1] = uptr[i] + ulen[i];
         unb_raw = raw_array<int32_t>(uptr[n]);
         int32_t* dst = unb_raw.get();
-        parallel_ranges(n, 8192, [&](int64_t r0, int64_t r1, int) {
+        parallel_ranges(n, 2048, [&](int64_t r0, int64_t r1, int) {
             for (int64_t i = r0; i < r1; ++i) std::memcpy(dst + uptr[i], nb + deg[i], (size_t)ulen[i] * sizeof(int32_t));
         });
         nb_raw.reset();
@@ -1238,7 +1238,7 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     std::vector<int64_t> a_dst(nnzA);
     {
         std::vector<std::string> errs(64);
-        parallel_ranges(n, 8192, [&](int64_t r0, int64_t r1, int t) {
+        parallel_ranges(n, 2048, [&](int64_t r0, int64_t r1, int t) {
             try {
                 for (int64_t i = r0; i < r1; ++i)
                     for (uint32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {

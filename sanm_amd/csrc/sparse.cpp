@@ -49,7 +49,7 @@ DeviceRows::DeviceRows(Backend* be, const SparseDesc& d, int64_t T, int64_t Tpad
     const int64_t nr = d.out_size;
     SetupLaps laps("remap_out rows");
     std::vector<uint32_t> ptr(nr + 1, 0);
-    parallel_ranges(nr, 16384, [&](int64_t i0, int64_t i1, int) {
+    parallel_ranges(nr, 4096, [&](int64_t i0, int64_t i1, int) {
         for (int64_t i = i0; i < i1; ++i) {
             uint32_t cnt = 0, li;
             if (whole)
@@ -64,7 +64,7 @@ DeviceRows::DeviceRows(Backend* be, const SparseDesc& d, int64_t T, int64_t Tpad
     bool triples = nr > 0 && nr % 3 == 0 && block == 9;
     if (triples) {
         std::vector<char> ok(64, 1);
-        parallel_ranges(nr / 3, 16384, [&](int64_t u0, int64_t u1, int t) {
+        parallel_ranges(nr / 3, 4096, [&](int64_t u0, int64_t u1, int t) {
             bool good = true;
             for (int64_t u = u0; good && u < u1; ++u) {
                 const uint32_t len = ptr[3 * u + 1] - ptr[3 * u];
@@ -92,7 +92,7 @@ DeviceRows::DeviceRows(Backend* be, const SparseDesc& d, int64_t T, int64_t Tpad
         for (int64_t u = 0; u < rows; ++u) optr[u + 1] = optr[u] + (ptr[step * u + 1] - ptr[step * u]);
         oidx.resize(optr[rows]);
         ocoef.resize(optr[rows]);
-        parallel_ranges(rows, 16384, [&](int64_t u0, int64_t u1, int) {
+        parallel_ranges(rows, 4096, [&](int64_t u0, int64_t u1, int) {
             for (int64_t u = u0; u < u1; ++u) {
                 uint32_t w = optr[u], li;
                 for (uint64_t p = d.rowptr[step * u]; p < d.rowptr[step * u + 1]; ++p) {
@@ -300,7 +300,7 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
         // rows of ri: batch item e of the table is the caller's item tet_order[e]
         const int64_t nrow = ri.out_size;
         v32.assign(nrow + 1, 0);
-        parallel_ranges(T, 16384, [&](int64_t e0, int64_t e1, int) {
+        parallel_ranges(T, 4096, [&](int64_t e0, int64_t e1, int) {
             for (int64_t e = e0; e < e1; ++e) {
                 const int64_t src = (tet_order ? tet_order[e] : e) * idim;
                 for (int m = 0; m < idim; ++m) v32[e * idim + m + 1] = (uint32_t)(ri.rowptr[src + m + 1] - ri.rowptr[src + m]);
@@ -310,7 +310,7 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
         m_asm.ri_ptr = upload(v32);
         auto i32 = raw_array<uint32_t>(ri.idx.size());
         auto c64 = raw_array<double>(tet_order ? ri.coef.size() : 0);
-        parallel_ranges(T, 16384, [&](int64_t e0, int64_t e1, int) {
+        parallel_ranges(T, 4096, [&](int64_t e0, int64_t e1, int) {
             for (int64_t e = e0; e < e1; ++e) {
                 const int64_t src = (tet_order ? tet_order[e] : e) * idim;
                 uint32_t w = v32[e * idim];
