@@ -259,7 +259,7 @@ public:
             const int32_t mark = nd.next_set++;
             for (int32_t u : set) nd.in_set[u] = mark;
         }
-        if (budget <= 1 || (int)set.size() < 4096) {
+        if (budget <= 1 || (int)set.size() < 1024) {
             std::vector<std::pair<std::vector<int32_t>, int32_t>> work;
             work.emplace_back(std::move(set), -1);
             nd.drain(work);
@@ -515,7 +515,7 @@ public:
         auto cut_of = [&](int f) { return std::min(ns - 1, std::max<size_t>(1, (size_t)(fracs[f] * ns))); };
         auto weigh = [&](int c) { weight[c] = boundary_weight(set, ords[c / nf], cut_of(c % nf), mark); };
         auto spread = [&](int count, auto&& fn) {
-            const int nt = ns >= 4096 ? std::min(threads, count) : 1;
+            const int nt = ns >= 2048 ? std::min(threads, count) : 1;
             if (nt <= 1) {
                 for (int i = 0; i < count; ++i) fn(i);
                 return;
