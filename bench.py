@@ -196,7 +196,7 @@ def metric_name(workload, cfg):
 
 # kernels of each family (names as rocprofv3 reports them; profiles/*_kernel_stats.md)
 FAMILY_KERNELS = {
-    "solve": "mfk::fwd_level_sub_kernel + mfk::fwd_level_kernel + mfk::bwd_level_kernel + permute_out_dot_kernel",
+    "solve": "mfk::fwd_level_tr_kernel + mfk::fwd_level_kernel + mfk::bwd_level_kernel + permute_out_dot_kernel",
     "factor": "mfk::update_kernel + gemm1/gemm2 + extend_add + panel_finalize + diag + scatter",
     "taylor": "spec_pass* (taylor_pass_kernel: EVAL0, GRAD, COEFF+BIAS per order)",
     "io": "gather_rows3_kernel (remap_out; remap_in is fused into the Taylor passes)",

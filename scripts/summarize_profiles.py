@@ -76,7 +76,7 @@ with open(os.path.join(dst, f"{tag}_pmc_traffic.md"), "w") as fo:
              f"--warmup 1 --workload {workload} --no-cpu-baseline --no-end-to-end --at-scale-workload none`\n({workload}, order {order}, 1 MI355X; scripts/collect_profiles.sh). "
              "Counter unit: KiB per dispatch. Correction per\nMI355X_MICROARCH.md (HBM): FETCH_SIZE reports 1/2 of the "
              "bytes of a coalesced stream on gfx950 -> doubled; WRITE_SIZE is\nexact (calibrated on axpby_kernel, which "
-             "writes n+1 = 38,047 doubles = 297.2 KiB per launch).\n\n")
+             "writes n+1 doubles per launch: armadillo_small 38,047 = 297.2 KiB, refine:armadillo_small:1 235,378 = 1838.9 KiB).\n\n")
     fo.write("| kernel | dispatches | FETCH_SIZE avg KiB | WRITE_SIZE avg KiB | corrected HBM-side MB per launch "
              "(2*FETCH + WRITE) |\n|---|---|---|---|---|\n")
     for k, (c, v) in sorted(fetch.items(), key=lambda kv: -kv[1][1]):
@@ -86,7 +86,7 @@ with open(os.path.join(dst, f"{tag}_pmc_traffic.md"), "w") as fo:
         out["kernels"][k] = {"fetch_kib": f_avg, "write_kib": w_avg, "traffic_bytes_per_launch": traffic}
         fo.write(f"| {k} | {c} | {f_avg:.1f} | {w_avg:.1f} | {traffic / 1e6:.2f} |\n")
 # kernel families as bench.py reports them (roofline_families); traffic per launch = dispatch-weighted mean
-FAMILY_OF = {"mfk::fwd_level_sub_kernel": "solve", "mfk::fwd_level_kernel": "solve", "mfk::bwd_level_kernel": "solve",
+FAMILY_OF = {"mfk::fwd_level_sub_kernel": "solve", "mfk::fwd_level_tr_kernel": "solve", "mfk::fwd_level_kernel": "solve", "mfk::bwd_level_kernel": "solve",
              "mfk::fwd_top_kernel": "solve", "mfk::bwd_top_kernel": "solve", "mfk::root_solve_kernel": "solve",
              "mfk::fwd_big_kernel": "solve", "mfk::bwd_big_kernel": "solve", "mfk::fwd_prep_kernel": "solve",
              "permute_out_dot_kernel": "solve", "mfk::permute_out_kernel": "solve", "mfk::permute_in_kernel": "solve",
