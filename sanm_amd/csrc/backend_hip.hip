@@ -1411,6 +1411,7 @@ struct Rccl {
 class HipBackend final : public Backend {
     hipStream_t m_stream = nullptr;  // the queue launches currently go to: m_main, or m_side between side_fork / side_end
     hipStream_t m_main = nullptr, m_side = nullptr;
+    hipStream_t m_sf_queue[3] = {nullptr, nullptr, nullptr};  // size classes of small_front_kernel beside each other (mf_factor)
     bool m_side_dirty = false;  // the side queue got work since the last join / sync
     bool m_side_detached = false;  // ... and nothing waits for it before side_wait()
     static constexpr int kForkEvents = 64;
@@ -1601,6 +1602,8 @@ public:
         if (m_red_side.ticket) (void)hipFree(m_red_side.ticket);
         if (m_red_side.host) (void)hipHostFree(m_red_side.host);
         if (m_side) (void)hipStreamDestroy(m_side);
+        for (hipStream_t q : m_sf_queue)
+            if (q) (void)hipStreamDestroy(q);
         (void)hipStreamDestroy(m_main);
     }
     const char* name() const override { return "hip"; }
@@ -2320,13 +2323,24 @@ public:
             if (small_min > 0 && nfront >= small_min && L.max_k <= SF_KMAX && !L.two_phase) {
                 // The pivot block's LDS decides how many fronts a compute unit works on at a time: the level's fronts
                 // are sorted by decreasing pivot count (MfSchedule), so they go out in up to three launches by size
-                // class -- k <= 96 (78 KB: two workgroups per unit), k <= 64 (34 KB: four), k <= 44 (the GEMM
-                // staging's 17 KB)
-                const int cls[3] = {SF_KMAX, 64, 44};
+                // class -- k <= 96 (77 KB: two workgroups per unit), k <= 64 (34 KB: four), k <= 44 (the GEMM
+                // staging's 17 KB; five by the kernel's 88 registers).  (Four classes by exact occupancy -- 96 / 80 /
+                // 69 / 62 pivots for 2 / 3 / 4 / 5 workgroups per unit -- measured the same beside each other, 12.9 ms,
+                // and worse one after the other, 13.5 against 13.2.)
+                constexpr int NCLS = 3;
+                const int cls[NCLS] = {SF_KMAX, 64, 44};
+                // The classes are independent of each other (different fronts of one level) and a unit that holds two
+                // 78 KB workgroups has room for nothing else while four of the small ones leave most of its LDS idle:
+                // the later classes go to queues of their own and fill the slots the big class leaves (its last round
+                // above all).  SANM_MF_SMALL_SERIAL=1: one queue, one class after the other.
+                static const bool serial = std::getenv("SANM_MF_SMALL_SERIAL") != nullptr;
+                hipStream_t home = m_stream;
+                hipEvent_t fork_ev = nullptr;
+                int forked = 0;
                 int begin = 0;
-                for (int c = 0; c < 3 && begin < nfront; ++c) {
+                for (int c = 0; c < NCLS && begin < nfront; ++c) {
                     const int kmax = std::min(cls[c], c == 0 ? L.max_k : cls[c]);
-                    const int lower = c + 1 < 3 ? cls[c + 1] : 0;
+                    const int lower = c + 1 < NCLS ? cls[c + 1] : 0;
                     int end = begin;
                     while (end < nfront && L.front_k[end] > lower) ++end;
                     if (end == begin) continue;
@@ -2335,9 +2349,24 @@ public:
                                                         (size_t)GK * (2 * GT + 5) * sizeof(double));
                     if (lds > 48 * 1024)
                         HIP_CHECK(hipFuncSetAttribute((const void*)small_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-                    SANM_LAUNCH(small_front_kernel, dim3(end - begin), dim3(256), lds, m_stream,
+                    hipStream_t q = home;
+                    if (!serial && end < nfront && forked < NCLS - 1) {  // more classes follow: this one beside them
+                        if (!m_sf_queue[forked]) HIP_CHECK(hipStreamCreateWithFlags(&m_sf_queue[forked], hipStreamNonBlocking));
+                        if (!fork_ev) {
+                            fork_ev = next_fork_event();
+                            HIP_CHECK(hipEventRecord(fork_ev, home));
+                        }
+                        q = m_sf_queue[forked++];
+                        HIP_CHECK(hipStreamWaitEvent(q, fork_ev, 0));
+                    }
+                    SANM_LAUNCH(small_front_kernel, dim3(end - begin), dim3(256), lds, q,
                                 MF_FACTOR_ARGS(mf, L.front_begin + begin), ks, (int)L.fwd_t);
                     begin = end;
+                }
+                for (int f = 0; f < forked; ++f) {
+                    hipEvent_t e = next_fork_event();
+                    HIP_CHECK(hipEventRecord(e, m_sf_queue[f]));
+                    HIP_CHECK(hipStreamWaitEvent(home, e, 0));
                 }
                 continue;
             }
