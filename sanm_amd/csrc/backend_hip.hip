@@ -2333,7 +2333,7 @@ public:
                 // 78 KB workgroups has room for nothing else while four of the small ones leave most of its LDS idle:
                 // the later classes go to queues of their own and fill the slots the big class leaves (its last round
                 // above all).  SANM_MF_SMALL_SERIAL=1: one queue, one class after the other.
-                static const bool serial = std::getenv("SANM_MF_SMALL_SERIAL") != nullptr;
+                const bool serial = std::getenv("SANM_MF_SMALL_SERIAL") != nullptr;  // (read per factorisation: tests switch it)
                 hipStream_t home = m_stream;
                 hipEvent_t fork_ev = nullptr;
                 int forked = 0;

@@ -259,6 +259,39 @@ def test_small_fronts_in_one_workgroup_forced(api, monkeypatch, leaf):
     assert ds.factor(A) >= 1
 
 
+def test_small_front_size_classes_beside_each_other(api, monkeypatch):
+    """the size classes of small_front_kernel on a level go to queues of their own (backend_hip.hip, mf_factor_levels):
+    the fronts are independent, so the solution is the one of the classes queued one after the other
+    (SANM_MF_SMALL_SERIAL=1), bit for bit.  (The host harness ignores both switches.)"""
+    monkeypatch.setenv("SANM_MF_SMALL_MIN_FRONTS", "1")
+    monkeypatch.setenv("SANM_MF_MERGE", "none")
+    if True:
+        n = 14
+        idx = np.arange(n ** 3).reshape(n, n, n)
+        rows, cols = [idx.ravel()], [idx.ravel()]
+        for ax in range(3):
+            a = np.take(idx, np.arange(n - 1), axis=ax).ravel()
+            b = np.take(idx, np.arange(1, n), axis=ax).ravel()
+            rows += [a, b]
+            cols += [b, a]
+        rows, cols = np.concatenate(rows), np.concatenate(cols)
+        rng = np.random.default_rng(11)
+        A = sp.csr_matrix((rng.standard_normal(rows.size) * 0.3, (rows, cols)), shape=(n ** 3, n ** 3))
+        A = sp.csr_matrix(A + sp.diags(np.full(n ** 3, 8.0)))
+        A.sort_indices()
+    g = np.stack(np.meshgrid(*[np.arange(14.0)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    b = np.random.default_rng(12).standard_normal(A.shape[0])
+    out = []
+    for serial in (None, "1"):
+        if serial:
+            monkeypatch.setenv("SANM_MF_SMALL_SERIAL", serial)
+        ds = DirectSolver(api, A, g)
+        assert ds.factor(A) == 0
+        out.append(ds.solve(b))
+    assert np.array_equal(out[0], out[1])
+    assert np.abs(A @ out[0] - b).max() < 1e-9
+
+
 def test_parallel_analysis_gives_the_sequential_ordering(api, monkeypatch):
     """the nested dissection hands the subtrees at the top of its tree to host threads and numbers the nodes as the
     sequential loop does (multifrontal.cpp, NestedDissection::dissect; the row loops of the supervariable graph and of
