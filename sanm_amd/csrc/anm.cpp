@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <exception>
 #include <functional>
+#include <future>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -150,7 +151,8 @@ namespace {
 class DirectSolver final : public LinearSolver {
     Backend* m_be;
     const JacobianPattern& m_pat;
-    Multifrontal m_mf;
+    std::unique_ptr<Multifrontal> m_mf_own;  // analysed here, or handed in (analysed beside the driver's other tables)
+    Multifrontal& m_mf;
     // Iterative refinement (x += A^-1 (b - A x), residual in double-double): `m_refine_always` steps per solve on
     // request (HyperParam::solver_refine / SANM_SOLVER_REFINE: brings the solution within ~1e-14 of the exact one
     // where the plain LU of an elasticity Jacobian of condition 5e8 is off by 4e-11 and PARDISO by 4e-13), and
@@ -240,8 +242,11 @@ class DirectSolver final : public LinearSolver {
 
 public:
     DirectSolver(Backend* be, const JacobianPattern& pat, const HyperParam& hp, const double* coords, int rank,
-                 int world, Collective coll)
-            : m_be{be}, m_pat{pat}, m_mf{be, pat.n(), pat.h_rowptr(), pat.h_col(), coords, rank, world},
+                 int world, Collective coll, std::unique_ptr<Multifrontal> analysed)
+            : m_be{be}, m_pat{pat},
+              m_mf_own{analysed ? std::move(analysed)
+                                : std::make_unique<Multifrontal>(be, pat.n(), pat.h_rowptr(), pat.h_col(), coords, rank, world)},
+              m_mf{*m_mf_own},
               m_refine_always{std::getenv("SANM_SOLVER_REFINE") ? std::atoi(std::getenv("SANM_SOLVER_REFINE"))
                                                                 : hp.solver_refine},
               m_coll{std::move(coll)} {
@@ -464,10 +469,10 @@ std::unique_ptr<LinearSolver> make_dense_solver(Backend* be, const JacobianPatte
 
 std::unique_ptr<LinearSolver> make_direct_solver(Backend* be, const JacobianPattern& pat,
                                                  const HyperParam& hp, const double* coords, int rank, int world,
-                                                 Collective coll) {
+                                                 Collective coll, std::unique_ptr<Multifrontal> analysed) {
     // (the regularised path factors A'A on every rank: replicated)
     if (hp.xcoeff_l2_penalty != 0) return std::make_unique<TikhonovSolver>(be, pat, hp.xcoeff_l2_penalty, coords);
-    return std::make_unique<DirectSolver>(be, pat, hp, coords, rank, world, std::move(coll));
+    return std::make_unique<DirectSolver>(be, pat, hp, coords, rank, world, std::move(coll), std::move(analysed));
 }
 
 std::unique_ptr<LinearSolver> make_pcg_solver(Backend* be, const JacobianPattern& pat,
@@ -914,8 +919,14 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
     auto clk = [] { return std::chrono::steady_clock::now(); };
     auto lap = [&](const char* name, std::chrono::steady_clock::time_point& t0) {
         const auto t1 = clk();
-        m_setup.emplace_back(name, std::chrono::duration<double>(t1 - t0).count());
+        const double sec = std::chrono::duration<double>(t1 - t0).count();
         t0 = t1;
+        for (auto& kv : m_setup)
+            if (kv.first == name) {  // (a phase in two pieces: one entry)
+                kv.second += sec;
+                return;
+            }
+        m_setup.emplace_back(name, sec);
     };
     auto t_setup = clk();
     // the renumbering is applied while the device tables are built (Program, DeviceRows, JacobianPattern read the
@@ -950,7 +961,31 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
         te = (int64_t)(m_shard.rank + 1) * T / m_shard.world;
         sanm_check(te > tb, "more ranks than tets");
     }
+    // The Jacobian's pattern first (host only), so that the direct solver's analysis -- host only as well, and the
+    // longest piece of the constructor -- runs on a thread of its own beside the program, the remap tables and the
+    // assembly lists; its device copies are made by this thread once the others are done.  SANM_SETUP_SERIAL=1: one
+    // thing after the other.
+    const double* coords = remap_out.out_coords.size() == (size_t)m_n * 3 ? remap_out.out_coords.data() : nullptr;
+    const bool beside = hp.solver_kind == 1 && hp.xcoeff_l2_penalty == 0 && !std::getenv("SANM_SETUP_SERIAL");
     t_setup = clk();
+    m_pattern = std::make_unique<JacobianPattern>(be, remap_out, remap_inp, m_n, T, 0, 9, tb, te, 9, tet_order, tet_inv,
+                                                  /*defer_device=*/true);
+    lap("pattern", t_setup);
+    std::future<std::unique_ptr<Multifrontal>> analysis;
+    if (beside) {
+        const bool dist = m_shard.active() && m_shard.world > 1;
+        analysis = std::async(std::launch::async, [this, be, coords, dist] {
+            return std::make_unique<Multifrontal>(be, m_n, m_pattern->h_rowptr(), m_pattern->h_col(), coords,
+                                                  dist ? m_shard.rank : 0, dist ? m_shard.world : 1, /*defer_device=*/true);
+        });
+    }
+    // (whatever fails below, the thread is joined before the pattern it reads goes away)
+    struct Join {
+        std::future<std::unique_ptr<Multifrontal>>& f;
+        ~Join() {
+            if (f.valid()) f.wait();
+        }
+    } join{analysis};
     m_prog = std::make_unique<Program>(be, g, out_var, te - tb, hp.order, tb, T, /*full_history=*/false, tet_order);
     lap("program", t_setup);
     m_setup.back().second -= m_prog->jit_seconds;
@@ -962,10 +997,15 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
                          remap_inp.coef.data());
     m_remap_out = std::make_unique<DeviceRows>(be, remap_out, te - tb, m_prog->Tpad(), tb, te, 9, tet_inv);
     lap("remap_tables", t_setup);
-    m_pattern = std::make_unique<JacobianPattern>(be, remap_out, remap_inp, m_n, T, m_prog->Tpad(),
-                                                  m_prog->dev().odim, tb, te, 9, tet_order, tet_inv);
+    m_pattern->finish_device(remap_out, remap_inp);
     lap("pattern", t_setup);
-    construct_solver_and_vectors(remap_out.out_coords.size() == (size_t)m_n * 3 ? remap_out.out_coords.data() : nullptr);
+    std::unique_ptr<Multifrontal> analysed;
+    if (analysis.valid()) {
+        analysed = analysis.get();  // (rethrows what the analysis threw)
+        m_setup.emplace_back("analysis_thread", analysed->analysis_seconds);  // its own clock; "analysis" is the wait for it
+        analysed->finish_device();
+    }
+    construct_solver_and_vectors(coords, std::move(analysed));
     lap("analysis", t_setup);
     if (std::getenv("SANM_DEBUG_SETUP"))
         for (const auto& kv : m_setup) std::fprintf(stderr, "[setup] %s %.4f\n", kv.first.c_str(), kv.second);
@@ -1000,7 +1040,7 @@ void AnmDriver::construct_on_vector_interpreter(const Graph& g, int out_var, con
     construct_solver_and_vectors(nullptr);
 }
 
-void AnmDriver::construct_solver_and_vectors(const double* coords) {
+void AnmDriver::construct_solver_and_vectors(const double* coords, std::unique_ptr<Multifrontal> analysed) {
     Backend* be = m_be;
     const HyperParam& hp = m_hp;
     // Graphs on the vector interpreter: general small systems (a transpose or a random sparse map puts zeros on
@@ -1014,9 +1054,9 @@ void AnmDriver::construct_solver_and_vectors(const double* coords) {
         // tet-sharded over several ranks: factorisation and solves by subtrees where that pays (multifrontal.cpp)
         if (m_shard.active() && m_shard.world > 1)
             m_solver = make_direct_solver(be, *m_pattern, hp, coords, m_shard.rank, m_shard.world,
-                                          [this](double* p, int64_t c) { allreduce(p, c); });
+                                          [this](double* p, int64_t c) { allreduce(p, c); }, std::move(analysed));
         else
-            m_solver = make_direct_solver(be, *m_pattern, hp, coords);
+            m_solver = make_direct_solver(be, *m_pattern, hp, coords, 0, 1, {}, std::move(analysed));
     } else if (hp.solver_kind == 0) {
         m_solver = make_pcg_solver(be, *m_pattern, hp);
     } else if (hp.solver_kind == 2) {

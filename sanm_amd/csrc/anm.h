@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 
+#include "multifrontal.h"
 #include "backend.h"
 #include "graph.h"
 #include "sparse.h"
@@ -128,9 +129,11 @@ std::unique_ptr<LinearSolver> make_pcg_solver(Backend* be, const JacobianPattern
 //! multifrontal LU (multifrontal.h); coords: (n,3) ordering hint or null
 //! world > 1: the factorisation and the solves distributed by subtrees over the ranks (multifrontal.h), `coll` for
 //! the exchanges
+//! analysed: the analysis of pat's pattern done beforehand (Multifrontal with defer_device, finished); null: done here
 std::unique_ptr<LinearSolver> make_direct_solver(Backend* be, const JacobianPattern& pat,
                                                  const HyperParam& hp, const double* coords, int rank = 0,
-                                                 int world = 1, Collective coll = {});
+                                                 int world = 1, Collective coll = {},
+                                                 std::unique_ptr<Multifrontal> analysed = nullptr);
 
 //! dense LU with partial pivoting: the small general systems of graphs on the vector interpreter
 std::unique_ptr<LinearSolver> make_dense_solver(Backend* be, const JacobianPattern& pat);
@@ -304,7 +307,7 @@ protected:
     std::string pow_exponent_list() const;
     void construct_on_vector_interpreter(const Graph& g, int out_var, const SparseDesc& remap_inp,
                                          const SparseDesc& remap_out);
-    void construct_solver_and_vectors(const double* coords);
+    void construct_solver_and_vectors(const double* coords, std::unique_ptr<Multifrontal> analysed = nullptr);
     std::unique_ptr<DeviceRows> m_remap_out;
     std::unique_ptr<JacobianPattern> m_pattern;
     std::unique_ptr<LinearSolver> m_solver;

@@ -887,11 +887,60 @@ bool split_big_fronts(std::vector<NdNode>& nodes, const SvGraph& g, const std::v
 
 // ---------------------------------------------------------------------------
 template <class T>
-T* Multifrontal::upload(const std::vector<T>& v) {
+T* Multifrontal::upload(const std::vector<T>& v) {  // (on the spot: the merged top block, never deferred)
     void* p = m_be->alloc(std::max<size_t>(v.size(), 1) * sizeof(T));
     if (!v.empty()) m_be->h2d(p, v.data(), v.size() * sizeof(T));
     m_bufs.push_back(p);
     return static_cast<T*>(p);
+}
+void Multifrontal::run_op(DeviceOp& op) {
+    void* p = m_be->alloc(std::max<size_t>(op.bytes, 1));
+    if (op.src && op.bytes) m_be->h2d(p, op.src, op.bytes);
+    if (op.zero) m_be->zero(p, op.bytes);
+    m_bufs.push_back(p);
+    op.set(p);
+}
+template <class P, class T>
+void Multifrontal::upload_to(P& target, std::vector<T>&& v) {
+    DeviceOp op;
+    op.bytes = v.size() * sizeof(T);
+    op.set = [&target](void* p) { target = static_cast<P>(p); };
+    if (m_defer) {
+        auto keep = std::make_shared<std::vector<T>>(std::move(v));
+        op.src = keep->data();
+        op.keep = keep;
+        m_pending.push_back(std::move(op));
+    } else {
+        op.src = v.data();
+        run_op(op);
+    }
+}
+template <class P, class T>
+void Multifrontal::upload_to(P& target, const std::vector<T>& v) {
+    if (m_defer) {
+        upload_to(target, std::vector<T>(v));
+        return;
+    }
+    DeviceOp op;
+    op.bytes = v.size() * sizeof(T);
+    op.src = v.data();
+    op.set = [&target](void* p) { target = static_cast<P>(p); };
+    run_op(op);
+}
+template <class P>
+void Multifrontal::alloc_to(P& target, size_t bytes, bool zero) {
+    DeviceOp op;
+    op.bytes = bytes;
+    op.zero = zero;
+    op.set = [&target](void* p) { target = static_cast<P>(p); };
+    if (m_defer) m_pending.push_back(std::move(op));
+    else run_op(op);
+}
+void Multifrontal::finish_device() {
+    for (DeviceOp& op : m_pending) run_op(op);
+    m_pending.clear();
+    m_pending.shrink_to_fit();
+    m_defer = false;
 }
 
 Multifrontal::~Multifrontal() {
@@ -900,8 +949,12 @@ Multifrontal::~Multifrontal() {
 }
 
 Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& rowptr,
-                           const std::vector<uint32_t>& col, const double* coords, int rank, int world)
-        : m_be{be} {
+                           const std::vector<uint32_t>& col, const double* coords, int rank, int world,
+                           bool defer_device)
+        : m_be{be},
+          // (the merged top block multiplies device blocks out while it is built: not deferred)
+          m_defer{defer_device && !(std::getenv("SANM_MF_TOP") && std::atoi(std::getenv("SANM_MF_TOP")) > 0)} {
+    const auto t_ctor = std::chrono::steady_clock::now();
     sanm_check(world >= 1 && rank >= 0 && rank < world, "multifrontal: rank %d of %d", rank, world);
     sanm_check(n > 0 && (int64_t)rowptr.size() == n + 1, "bad CSR pattern");
     sanm_check(n < INT32_MAX / 2, "system too large for 32-bit indices");
@@ -1368,8 +1421,8 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
         }
         L.n_g1 = (int32_t)(t1.size() / 2);
         L.n_g2 = (int32_t)(t2.size() / 2);
-        L.g1_tiles = upload(t1);
-        L.g2_tiles = upload(t2);
+        upload_to(L.g1_tiles, std::move(t1));
+        upload_to(L.g2_tiles, std::move(t2));
     }
 
     if (std::getenv("SANM_MF_DEBUG")) {
@@ -1402,42 +1455,44 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     m_dev.nnzA = nnzA;
     m_dev.nr_front = F;
     m_dev.nr_level = H;
-    m_dev.fronts = upload(fr);
-    m_dev.level_fronts = upload(level_fronts);
+    upload_to(m_dev.fronts, fr);
+    upload_to(m_dev.level_fronts, level_fronts);
     {
         std::vector<MfFrontDev> lf(level_fronts.size());
         for (size_t i = 0; i < lf.size(); ++i) lf[i] = fr[level_fronts[i]];
-        m_dev.lfronts = upload(lf);
+        upload_to(m_dev.lfronts, std::move(lf));
     }
-    m_dev.upd_dst = upload(upd_dst);
+    upload_to(m_dev.upd_dst, upd_dst);
     // (one more double at the end that nothing writes: the padding slot of the merged top block's lists)
-    m_dev.inbox_store = static_cast<double*>(be->alloc((inbox_doubles + 1) * sizeof(double)));
-    be->zero(m_dev.inbox_store, (inbox_doubles + 1) * sizeof(double));
-    m_bufs.push_back(m_dev.inbox_store);
-    m_dev.bnd_idx = upload(bnd_idx);
-    m_dev.rel = upload(rel);
-    m_dev.perm = upload(perm);
-    m_dev.own_front = upload(owner);
-    m_dev.a_dst = upload(a_dst);
-    m_sched.ea_children = upload(ea_children);
+    alloc_to(m_dev.inbox_store, (inbox_doubles + 1) * sizeof(double), true);
+    upload_to(m_dev.bnd_idx, bnd_idx);
+    upload_to(m_dev.rel, rel);
+    upload_to(m_dev.perm, perm);
+    upload_to(m_dev.own_front, owner);
+    upload_to(m_dev.a_dst, a_dst);
+    upload_to(m_sched.ea_children, ea_children);
     lap("device tables: uploads");
     m_dev.front_store_size = off;
-    m_dev.front_store = static_cast<double*>(be->alloc(off * sizeof(double)));
+    alloc_to(m_dev.front_store, off * sizeof(double), false);
     lap("device tables: front store");
     // (n doubles, and room behind them for the solution of the merged top block, MfSchedule::Top)
     const char* env_top = std::getenv("SANM_MF_TOP");
     const int32_t top_max_n = env_top ? std::atoi(env_top) : 0;
-    m_dev.work = static_cast<double*>(be->alloc((n + std::max(top_max_n, 0)) * sizeof(double)));
-    m_dev.work2 = static_cast<double*>(be->alloc(n * sizeof(double)));
-    m_bufs.push_back(m_dev.work2);
-    m_dev.tmp_store = static_cast<double*>(be->alloc(tmp_doubles * sizeof(double)));
-    m_bufs.push_back(m_dev.tmp_store);
-    m_dev.status = static_cast<int32_t*>(be->alloc(64));
-    be->zero(m_dev.status, 64);
-    m_dev.piv_amax = reinterpret_cast<double*>(m_dev.status) + 1;
-    m_bufs.push_back(m_dev.front_store);
-    m_bufs.push_back(m_dev.work);
-    m_bufs.push_back(m_dev.status);
+    alloc_to(m_dev.work, (n + std::max(top_max_n, 0)) * sizeof(double), false);
+    alloc_to(m_dev.work2, n * sizeof(double), false);
+    alloc_to(m_dev.tmp_store, tmp_doubles * sizeof(double), false);
+    {
+        // status word, and the largest |a_ij| behind it
+        DeviceOp op;
+        op.bytes = 64;
+        op.zero = true;
+        op.set = [this](void* p) {
+            m_dev.status = static_cast<int32_t*>(p);
+            m_dev.piv_amax = reinterpret_cast<double*>(m_dev.status) + 1;
+        };
+        if (m_defer) m_pending.push_back(std::move(op));
+        else run_op(op);
+    }
 
     lap("device tables");
     // ---- exchange tables of the distributed schedule (MfSchedule::Dist) -----------------------------------------
@@ -1468,12 +1523,11 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
         D.n_schur_unpack = su.size();
         D.n_inbox_pack = ip.size();
         D.n_inbox_unpack = iu.size();
-        D.schur_pack = upload(sp);
-        D.schur_unpack = upload(su);
-        D.inbox_pack = upload(ip);
-        D.inbox_unpack = upload(iu);
-        D.stage = static_cast<double*>(be->alloc(std::max<int64_t>(std::max(so, io), 1) * sizeof(double)));
-        m_bufs.push_back(D.stage);
+        upload_to(D.schur_pack, std::move(sp));
+        upload_to(D.schur_unpack, std::move(su));
+        upload_to(D.inbox_pack, std::move(ip));
+        upload_to(D.inbox_unpack, std::move(iu));
+        alloc_to(D.stage, std::max<int64_t>(std::max(so, io), 1) * sizeof(double), false);
         // entries of the permuted solution this rank must not contribute to the last exchange: the pivots of the
         // other ranks' subtrees, and -- except on rank 0 -- the replicated top's
         for (int32_t f = 0; f < F; ++f) {
@@ -1660,6 +1714,7 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
                 std::fprintf(stderr, "mf top block: %d fronts, %d pivots, %zu products\n", T.nf, T.n, g.size());
         }
     }
+    analysis_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_ctor).count();
 }
 
 }  // namespace sanm_hip

@@ -30,6 +30,8 @@
 // unpivoted LU is stable there; tiny pivots are detected and reported.
 #pragma once
 #include <cstdint>
+#include <functional>
+#include <memory>
 #include <vector>
 
 #include "backend.h"
@@ -43,9 +45,14 @@ public:
     //! pattern of the n x n matrix (CSR, original numbering); coords (n,3) or null.  world > 1: this rank's part of
     //! the subtree-to-rank distribution (MfSchedule::Dist): every rank runs the same analysis on the same pattern
     //! and keeps its own subtrees plus the replicated top of the tree in its schedule.
+    //! defer_device: the constructor does the host analysis only and touches no backend -- it may run on a thread of
+    //! its own beside the owner of the backend --; finish_device(), called by that owner, then makes the device copies.
     Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& rowptr,
-                 const std::vector<uint32_t>& col, const double* coords, int rank = 0, int world = 1);
+                 const std::vector<uint32_t>& col, const double* coords, int rank = 0, int world = 1,
+                 bool defer_device = false);
     ~Multifrontal();
+    void finish_device();
+    double analysis_seconds = 0;  // wall clock of the constructor
     Multifrontal(const Multifrontal&) = delete;
 
     const MfDev& dev() const { return m_dev; }
@@ -63,8 +70,26 @@ private:
     MfDev m_dev{};
     MfSchedule m_sched;
     std::vector<void*> m_bufs;
+    // device work of the constructor: done on the spot, or kept for finish_device()
+    bool m_defer = false;
+    struct DeviceOp {
+        std::shared_ptr<void> keep;  // the host copy of an upload
+        const void* src = nullptr;
+        size_t bytes = 0;
+        bool zero = false;
+        std::function<void(void*)> set;  // stores the device pointer where it belongs
+    };
+    std::vector<DeviceOp> m_pending;
+    void run_op(DeviceOp& op);
     template <class T>
     T* upload(const std::vector<T>& v);
+    //! device copy of v into `target` (v is left empty when the copy is deferred and v was given as an rvalue)
+    template <class P, class T>
+    void upload_to(P& target, const std::vector<T>& v);
+    template <class P, class T>
+    void upload_to(P& target, std::vector<T>&& v);
+    template <class P>
+    void alloc_to(P& target, size_t bytes, bool zero);
 };
 
 }  // namespace sanm_hip

@@ -154,7 +154,7 @@ T* JacobianPattern::upload(const std::vector<T>& v) {
 
 JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const SparseDesc& ri, int64_t n,
                                  int64_t T, int64_t Tpad, int odim, int64_t tet_begin, int64_t tet_end, int idim,
-                                 const int64_t* tet_order, const int64_t* tet_inv)
+                                 const int64_t* tet_order, const int64_t* tet_inv, bool defer_device)
         : m_be{be} {
     sanm_check(!tet_order == !tet_inv, "a renumbering of the batch items comes with its inverse");
     if (tet_end < 0) tet_end = T;
@@ -272,7 +272,20 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
         for (auto& x : th) x.join();
     }
     laps.lap("merge");
+    m_n = n, m_T = T, m_tet_begin = tet_begin, m_tet_end = tet_end, m_odim = odim, m_idim = idim;
+    m_tet_order = tet_order, m_tet_inv = tet_inv;
+    if (!defer_device) finish_device(ro, ri);
+}
 
+void JacobianPattern::finish_device(const SparseDesc& ro, const SparseDesc& ri) {
+    SetupLaps laps("pattern");
+    Backend* be = m_be;
+    const int64_t n = m_n, T = m_T, tet_begin = m_tet_begin, tet_end = m_tet_end;
+    const int odim = m_odim, idim = m_idim;
+    const int64_t *tet_order = m_tet_order, *tet_inv = m_tet_inv;
+    const std::vector<uint32_t>& rowptr = m_h_rowptr;
+    const std::vector<uint32_t>& col = m_h_col;
+    m_tet_order = m_tet_inv = nullptr;  // (the caller's arrays need not outlive this call)
     m_csr.n = n;
     m_csr.nnz = col.size();
     m_csr.rowptr = upload(rowptr);

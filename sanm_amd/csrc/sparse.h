@@ -63,8 +63,11 @@ public:
     //! shard [tet_begin, tet_end) and the Jacobian blocks are in the device's numbering
     JacobianPattern(Backend* be, const SparseDesc& remap_out, const SparseDesc& remap_in, int64_t n,
                     int64_t T, int64_t Tpad, int odim, int64_t tet_begin = 0, int64_t tet_end = -1, int idim = 9,
-                    const int64_t* tet_order = nullptr, const int64_t* tet_inv = nullptr);
+                    const int64_t* tet_order = nullptr, const int64_t* tet_inv = nullptr, bool defer_device = false);
     ~JacobianPattern();
+    //! defer_device: the constructor builds the host pattern only (h_rowptr / h_col are valid -- what the analysis of a
+    //! direct solver needs --, nothing else is); finish_device, with the constructor's maps, makes the device side
+    void finish_device(const SparseDesc& remap_out, const SparseDesc& remap_in);
 
     CsrDev csr() const { return m_csr; }
     AssemblyDev assembly() const { return m_asm; }
@@ -83,6 +86,10 @@ private:
     int64_t m_nr_contrib = 0;
     std::vector<uint32_t> m_h_rowptr, m_h_col;
     std::vector<void*> m_bufs;
+    // what finish_device needs of the constructor's arguments
+    int64_t m_n = 0, m_T = 0, m_tet_begin = 0, m_tet_end = 0;
+    int m_odim = 9, m_idim = 9;
+    const int64_t *m_tet_order = nullptr, *m_tet_inv = nullptr;
     template <class T>
     T* upload(const std::vector<T>& v);
     template <class T>
