@@ -499,6 +499,7 @@ class Leg:
         self.barrier()
         t0 = time.perf_counter()
         run2.construct()
+        t_ctor = time.perf_counter() - t0
         s = run2.solver
         guard = 0
         while not s.converged() and guard < 10000:
@@ -508,7 +509,7 @@ class Leg:
         dt = self.max_over_ranks(time.perf_counter() - t0)
         it = int(s.get_nr_iter())
         setup = s.setup_profile()
-        out = {"time_solve": dt, "iter": it, "steps_per_sec": it / dt if dt > 0 else 0.0,
+        out = {"time_solve": dt, "iter": it, "steps_per_sec": it / dt if dt > 0 else 0.0, "constructor_seconds": t_ctor,
                "setup_seconds": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in setup.items()}}
         del run2, s
         return out
