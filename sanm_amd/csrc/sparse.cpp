@@ -181,7 +181,7 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
         std::string error;
     };
     const int nthread = (int)std::max<int64_t>(
-            1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 16, n / 4096 + 1}));
+            1, std::min<int64_t>({(int64_t)host_thread_cap(), n / 2048 + 1}));
     std::vector<Part> parts(nthread);
     auto build = [&](int t) {
         Part& P = parts[t];
