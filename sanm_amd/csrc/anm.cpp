@@ -1007,8 +1007,11 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
     }
     construct_solver_and_vectors(coords, std::move(analysed));
     lap("analysis", t_setup);
-    if (std::getenv("SANM_DEBUG_SETUP"))
+    if (std::getenv("SANM_DEBUG_SETUP")) {
         for (const auto& kv : m_setup) std::fprintf(stderr, "[setup] %s %.4f\n", kv.first.c_str(), kv.second);
+        std::fprintf(stderr, "[setup] driver constructor, first member to here: %.4f\n",
+                     std::chrono::duration<double>(std::chrono::steady_clock::now() - m_ctor_begin).count());
+    }
 }
 
 void AnmDriver::construct_on_vector_interpreter(const Graph& g, int out_var, const SparseDesc& remap_inp,
@@ -1687,10 +1690,19 @@ AnmEqnSolver::AnmEqnSolver(Backend* be, const Graph& g, int out_var, const Spars
         : AnmSolverVecScale(be, g, out_var, remap_inp, remap_out, x0, n, 0, nullptr, hp, true, shard),
           m_converge_rms{hp.converge_rms} {
     // libsanm/anm.cpp:446-462: f(x) - f(x0) + t*(y + f(x0)) = 0, t from 0
+    SetupLaps dl("eqn solver");
     init_xt0(x0, 0);
+    dl.lap("init_xt0");
     m_eqn_y = DVec{be, (size_t)n};
     be->h2d(m_eqn_y.p(), y, n * 8);
+    dl.lap("y");
+    const auto t0 = std::chrono::steady_clock::now();
     solve_expansion_coeffs();
+    // (the first expansion belongs to the constructor like in the reference, anm.cpp:446-462: queued, not waited for)
+    m_setup.emplace_back("first_expansion", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    if (std::getenv("SANM_DEBUG_SETUP"))
+        std::fprintf(stderr, "[setup] constructor, first member to last statement: %.4f\n",
+                     std::chrono::duration<double>(std::chrono::steady_clock::now() - m_ctor_begin).count());
 }
 
 AnmEqnSolver& AnmEqnSolver::next_iter() {

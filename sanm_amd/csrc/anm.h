@@ -334,6 +334,7 @@ protected:
     double* m_host_scalars = nullptr;  // pinned, per order: t_i, sanity excess, sanity x-dot
     std::map<std::string, double> m_profile, m_profile_cnt, m_profile_launches;
     std::vector<std::pair<std::string, double>> m_setup;
+    std::chrono::steady_clock::time_point m_ctor_begin = std::chrono::steady_clock::now();
 
     void init_xt0(const double* x_host, double t);
     void solve_expansion_coeffs();

@@ -1602,6 +1602,10 @@ public:
         if (m_red_side.ticket) (void)hipFree(m_red_side.ticket);
         if (m_red_side.host) (void)hipHostFree(m_red_side.host);
         if (m_side) (void)hipStreamDestroy(m_side);
+        for (int b = 0; b < 2; ++b) {
+            if (m_stage[b]) (void)hipHostFree(m_stage[b]);
+            if (m_stage_ev[b]) (void)hipEventDestroy(m_stage_ev[b]);
+        }
         for (hipStream_t q : m_sf_queue)
             if (q) (void)hipStreamDestroy(q);
         (void)hipStreamDestroy(m_main);
@@ -1737,9 +1741,39 @@ public:
             (void)hipFree(p);
         }
     }
+    // Uploads go through two pinned staging buffers of our own.  hipMemcpy from pageable memory pins the caller's pages
+    // in place, and the tables a constructor uploads are temporaries: unmapping pages the driver has seen pinned stops
+    // the process's queues, ~20 ms at the next submission (scripts/ctor_sync_probe.py: a second solver's constructor
+    // 74 -> 53 ms just by keeping the analysis's upload buffers alive).  Staged, nothing of the caller's is ever pinned.
+    // SANM_H2D_DIRECT=1: the plain hipMemcpy.
+    static constexpr size_t kStageBytes = size_t(8) << 20;
+    void* m_stage[2] = {nullptr, nullptr};
+    hipEvent_t m_stage_ev[2] = {nullptr, nullptr};
     void h2d(void* dst, const void* src, size_t bytes) override {
         if (!bytes) return;
-        HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, m_stream));
+        static const bool direct = std::getenv("SANM_H2D_DIRECT") != nullptr;
+        if (direct) {
+            HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, m_stream));
+            HIP_CHECK(hipStreamSynchronize(m_stream));
+            return;
+        }
+        if (!m_stage[0])
+            for (int b = 0; b < 2; ++b) {
+                HIP_CHECK(hipHostMalloc(&m_stage[b], kStageBytes));
+                HIP_CHECK(hipEventCreateWithFlags(&m_stage_ev[b], hipEventDisableTiming));
+            }
+        int b = 0;
+        bool used[2] = {false, false};
+        for (size_t off = 0; off < bytes; off += kStageBytes, b ^= 1) {
+            const size_t len = std::min(kStageBytes, bytes - off);
+            if (used[b]) HIP_CHECK(hipEventSynchronize(m_stage_ev[b]));  // (the copy out of this buffer two chunks ago)
+            const char* from = static_cast<const char*>(src) + off;
+            char* stage = static_cast<char*>(m_stage[b]);
+            parallel_ranges((int64_t)len, 1 << 20, [&](int64_t r0, int64_t r1, int) { std::memcpy(stage + r0, from + r0, (size_t)(r1 - r0)); });
+            HIP_CHECK(hipMemcpyAsync(static_cast<char*>(dst) + off, stage, len, hipMemcpyHostToDevice, m_stream));
+            HIP_CHECK(hipEventRecord(m_stage_ev[b], m_stream));
+            used[b] = true;
+        }
         HIP_CHECK(hipStreamSynchronize(m_stream));
     }
     void d2h_async(void* dst_pinned, const void* src, size_t bytes) override {
