@@ -1749,6 +1749,13 @@ public:
     static constexpr size_t kStageBytes = size_t(8) << 20;
     void* m_stage[2] = {nullptr, nullptr};
     hipEvent_t m_stage_ev[2] = {nullptr, nullptr};
+    void ensure_stage() {
+        if (m_stage[0]) return;
+        for (int b = 0; b < 2; ++b) {
+            HIP_CHECK(hipHostMalloc(&m_stage[b], kStageBytes));
+            HIP_CHECK(hipEventCreateWithFlags(&m_stage_ev[b], hipEventDisableTiming));
+        }
+    }
     void h2d(void* dst, const void* src, size_t bytes) override {
         if (!bytes) return;
         static const bool direct = std::getenv("SANM_H2D_DIRECT") != nullptr;
@@ -1757,11 +1764,7 @@ public:
             HIP_CHECK(hipStreamSynchronize(m_stream));
             return;
         }
-        if (!m_stage[0])
-            for (int b = 0; b < 2; ++b) {
-                HIP_CHECK(hipHostMalloc(&m_stage[b], kStageBytes));
-                HIP_CHECK(hipEventCreateWithFlags(&m_stage_ev[b], hipEventDisableTiming));
-            }
+        ensure_stage();
         int b = 0;
         bool used[2] = {false, false};
         for (size_t off = 0; off < bytes; off += kStageBytes, b ^= 1) {
@@ -1788,8 +1791,20 @@ public:
             HIP_CHECK(hipStreamSynchronize(m_side));
             m_side_dirty = false;
         }
-        HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, m_stream));
-        HIP_CHECK(hipStreamSynchronize(m_stream));
+        static const bool direct = std::getenv("SANM_H2D_DIRECT") != nullptr;
+        if (direct || bytes <= 4096) {  // (scalars: the runtime stages those itself)
+            HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, m_stream));
+            HIP_CHECK(hipStreamSynchronize(m_stream));
+            return;
+        }
+        // through the staging buffers, like h2d: the caller's pages are never pinned
+        ensure_stage();
+        for (size_t off = 0; off < bytes; off += kStageBytes) {
+            const size_t len = std::min(kStageBytes, bytes - off);
+            HIP_CHECK(hipMemcpyAsync(m_stage[0], static_cast<const char*>(src) + off, len, hipMemcpyDeviceToHost, m_stream));
+            HIP_CHECK(hipStreamSynchronize(m_stream));
+            std::memcpy(static_cast<char*>(dst) + off, m_stage[0], len);
+        }
     }
     void d2d(void* dst, const void* src, size_t bytes) override {
         if (!bytes) return;
