@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import sys
 
 from . import api as _api
 from .api import (ANMEqnSolver, ANMImplicitSolver, ANMSolverVecScale, Api, SanmError,  # noqa: F401
@@ -26,6 +27,15 @@ def load_library() -> ctypes.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m sanm_amd.build` (needs hipcc). "
             "sanm_amd has no CPU fallback.")
+    # A process that uses PyTorch-ROCm as well (bench.py, the distributed tests) must end up with ONE HIP runtime: the
+    # wheel bundles its own libamdhip64 / libhsa-runtime64, and if this library pulls in the system's copies first, a later
+    # torch.cuda initialisation reports "No HIP GPUs are available" (seen on the MI355X boxes).  With torch loaded first
+    # both bind to its copies.  SANM_NO_TORCH_PRELOAD=1: leave the order to the caller.
+    if "torch" not in sys.modules and not os.environ.get("SANM_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except Exception:  # no torch in this environment: nothing to keep consistent
+            pass
     return ctypes.CDLL(LIB_PATH)
 
 

@@ -64,3 +64,17 @@ def test_package_does_not_import_oracle():
             if f.endswith((".py", ".cpp", ".h", ".hip")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+@pytest.mark.gpu
+def test_pytorch_initialised_after_the_product_library_still_finds_the_gpu():
+    """the torch wheel bundles its own HIP runtime: a process in which libsanm_hip.so pulled in the system's copy first
+    made a later torch.cuda initialisation report "No HIP GPUs are available" (seen on the MI355X boxes).  The package
+    loads torch's runtime first (sanm_amd.load_library); a fresh process checks the order a user may well choose."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import sanm_amd; sanm_amd.get_api(0); import torch; "
+            "torch.cuda.synchronize(); assert torch.cuda.is_available(); print('ok')" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
