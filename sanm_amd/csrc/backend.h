@@ -77,6 +77,17 @@ struct AssemblyDev {
     const uint32_t* tjidx = nullptr;
     const double* tcoef = nullptr;
     int64_t nnz = 0;
+    // Rows in triples (set by JacobianPattern when rows 3u, 3u+1, 3u+2 of remap_out have the same coefficients and
+    // output elements that differ by 0 / 3 / 6 inside one batch item's block -- the three components of a vertex -- and
+    // there is no t column): the three rows have the same columns, and the gather list of a non-zero of row 3u+c is
+    // that of the same non-zero of row 3u with its Jacobian indices shifted by 3 c idim.  The device keeps the lists of
+    // the rows 3u only -- a third of the bytes to build, to hold and to stream at every assembly -- and a slot table:
+    // tslot_p[t] = position of the t-th non-zero of the rows 3u in the CSR arrays, tslot_len[t] = its row's length
+    // (the same non-zero of rows 3u+1 / 3u+2 sits tslot_len / 2 tslot_len further on).
+    int32_t triples = 0;
+    const uint32_t* tslot_p = nullptr;
+    const uint32_t* tslot_len = nullptr;
+    int64_t ntslot = 0;
 };
 
 // One phase of a classical Gram-Schmidt step of the Pade basis (pade.cpp:36-70), as a value the backend may run at

@@ -147,8 +147,8 @@ template <int MODE>
 __global__ void __launch_bounds__(ASM_THREADS) asm_list_kernel(AssemblyDev A, uint32_t* __restrict__ cnt,
                                                                uint32_t* __restrict__ tcnt, uint32_t* __restrict__ out_jidx,
                                                                double* __restrict__ out_coef, uint32_t* __restrict__ out_tjidx,
-                                                               double* __restrict__ out_tcoef) {
-    const int64_t i = blockIdx.x;
+                                                               double* __restrict__ out_tcoef, int row_step) {
+    const int64_t i = (int64_t)blockIdx.x * row_step;  // (3: the first row of every triple only, AssemblyDev::triples)
     __shared__ uint32_t tcol[ASM_CHUNK];
     __shared__ uint32_t tjx[ASM_CHUNK];
     __shared__ double tcf[ASM_CHUNK];
@@ -288,6 +288,52 @@ __global__ void __launch_bounds__(256) assemble_kernel(AsmList A, const double* 
     }
     for (int off = ROW_LANES / 2; off > 0; off >>= 1) v += __shfl_down(v, off, ROW_LANES);
     if (s < A.nslots && sub == 0) val[s] = v;
+}
+
+// The same for rows in triples (AssemblyDev::triples): a slot is a non-zero of a row 3u; its list serves the same
+// non-zero of rows 3u+1 and 3u+2 with the Jacobian index shifted by `shift` and 2 `shift` -- every value is the sum it
+// is in assemble_kernel, term by term.
+__global__ void __launch_bounds__(256) assemble3_kernel(AsmList A, const uint32_t* __restrict__ tslot_p,
+                                                        const uint32_t* __restrict__ tslot_len, int shift,
+                                                        const double* __restrict__ jac, double* __restrict__ val) {
+    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t s = gid / ROW_LANES;
+    int sub = gid % ROW_LANES;
+    double v[3] = {0, 0, 0};
+    uint32_t p = 0, len = 0;
+    if (s < A.nslots) {
+        p = tslot_p[s];
+        len = tslot_len[s];
+        const uint32_t p0 = A.ptr[p], e = A.ptr[p + 1];
+        for (uint32_t base = p0; base < e; base += 4 * ROW_LANES) {  // 4 index -> value chains in flight
+            uint32_t j[4];
+            double c[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t q = base + sub + u * ROW_LANES;
+                const uint32_t qq = q < e ? q : p0;
+                j[u] = A.jidx[qq];
+                const double cv = A.coef[qq];
+                c[u] = q < e ? cv : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const double t = c[u] * jac[j[u] + r * shift];
+                    if (fabs(t) >= 1e-9) v[r] += t;  // libsanm/sparse_solver.cpp:291-293
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+        for (int off = ROW_LANES / 2; off > 0; off >>= 1) v[r] += __shfl_down(v[r], off, ROW_LANES);
+    if (s < A.nslots && sub == 0) {
+        val[p] = v[0];
+        val[p + len] = v[1];
+        val[p + 2 * len] = v[2];
+    }
 }
 
 __global__ void gather_kernel(size_t n, const double* __restrict__ src, const uint32_t* __restrict__ idx,
@@ -2170,6 +2216,13 @@ public:
     void assemble(const AssemblyDev& A, const double* jac, double* val, double* grad_t) override {
         sanm_check(A.aptr, "assembly lists were not prepared");
         sanm_check(!A.has_t || grad_t, "assembly with a t column needs grad_t");
+        if (A.triples) {
+            const AsmList L{A.aptr, A.ajidx, A.acoef, A.ntslot};
+            SANM_LAUNCH(assemble3_kernel, dim3(nblk(L.nslots * ROW_LANES, 256)), dim3(256), 0, m_stream, L, A.tslot_p, A.tslot_len,
+                        3 * A.idim, jac, val);
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
         const AsmList L{A.aptr, A.ajidx, A.acoef, A.nnz};
         SANM_LAUNCH(assemble_kernel, dim3(nblk(L.nslots * ROW_LANES, 256)), dim3(256), 0, m_stream, L, jac, val);
         if (A.has_t) {
@@ -2188,8 +2241,12 @@ public:
         owned.push_back(cnt);
         owned.push_back(tcnt);
         zero(tcnt, (n + 1) * 4);
-        SANM_LAUNCH(asm_list_kernel<0>, dim3((unsigned)n), dim3(ASM_THREADS), 0, m_stream, A, cnt, tcnt, nullptr, nullptr,
-                    nullptr, nullptr);
+        // (rows in triples: lists of the rows 3u only; the other rows' counts stay zero)
+        const int step = A.triples ? 3 : 1;
+        const unsigned rows = (unsigned)(n / step);
+        if (A.triples) zero(cnt, (nnz + 1) * 4);
+        SANM_LAUNCH(asm_list_kernel<0>, dim3(rows), dim3(ASM_THREADS), 0, m_stream, A, cnt, tcnt, nullptr, nullptr,
+                    nullptr, nullptr, step);
         HIP_CHECK(hipGetLastError());
         if (dbg) sync();
         laps.lap("count kernel");
@@ -2219,7 +2276,7 @@ public:
         laps.lap("alloc lists");
         A.aptr = cnt;
         A.tptr = tcnt;
-        SANM_LAUNCH(asm_list_kernel<1>, dim3((unsigned)n), dim3(ASM_THREADS), 0, m_stream, A, nullptr, nullptr, jx, cf, tjx, tcf);
+        SANM_LAUNCH(asm_list_kernel<1>, dim3(rows), dim3(ASM_THREADS), 0, m_stream, A, nullptr, nullptr, jx, cf, tjx, tcf, step);
         HIP_CHECK(hipGetLastError());
         if (dbg) sync();
         laps.lap("fill kernel");

@@ -347,6 +347,48 @@ void JacobianPattern::finish_device(const SparseDesc& ro, const SparseDesc& ri) 
     m_asm.tet_end = tet_end;
     m_asm.has_t = m_has_t ? 1 : 0;
     m_asm.nnz = m_csr.nnz;
+    // rows in triples?  (AssemblyDev::triples: the three components of a vertex share their columns and, up to a shift
+    // of the Jacobian index, their gather lists)
+    bool triples = n > 0 && n % 3 == 0 && odim == 9 && !m_has_t && !std::getenv("SANM_ASM_NO_TRIPLES");
+    if (triples) {
+        std::vector<char> ok(64, 1);
+        parallel_ranges(n / 3, 4096, [&](int64_t u0, int64_t u1, int t) {
+            bool good = true;
+            for (int64_t u = u0; good && u < u1; ++u) {
+                const uint64_t p0 = ro.rowptr[3 * u], len = ro.rowptr[3 * u + 1] - p0;
+                const uint32_t c0 = rowptr[3 * u], clen = rowptr[3 * u + 1] - c0;
+                for (int c = 1; good && c < 3; ++c) {
+                    const uint64_t pc = ro.rowptr[3 * u + c];
+                    good = ro.rowptr[3 * u + c + 1] - pc == len && rowptr[3 * u + c + 1] - rowptr[3 * u + c] == clen &&
+                           rowptr[3 * u + c] == c0 + c * clen &&
+                           std::equal(col.begin() + c0, col.begin() + c0 + clen, col.begin() + rowptr[3 * u + c]);
+                    for (uint64_t q = 0; good && q < len; ++q)
+                        good = ro.idx[pc + q] == ro.idx[p0 + q] + 3u * c && ro.coef[pc + q] == ro.coef[p0 + q] &&
+                               ro.idx[p0 + q] % 9 < 3;
+                }
+            }
+            if (!good) ok[t % 64] = 0;
+        });
+        for (char c : ok) triples = triples && c;
+    }
+    if (triples) {
+        const size_t nts = col.size() / 3;
+        auto tp = raw_array<uint32_t>(nts);
+        auto tl = raw_array<uint32_t>(nts);
+        parallel_ranges(n / 3, 4096, [&](int64_t u0, int64_t u1, int) {
+            for (int64_t u = u0; u < u1; ++u) {
+                const uint32_t c0 = rowptr[3 * u], clen = rowptr[3 * u + 1] - c0;
+                for (uint32_t k = 0; k < clen; ++k) {
+                    tp[c0 / 3 + k] = c0 + k;  // (rowptr[3u] = 3 x the lengths of the triples before u)
+                    tl[c0 / 3 + k] = clen;
+                }
+            }
+        });
+        m_asm.triples = 1;
+        m_asm.ntslot = (int64_t)nts;
+        m_asm.tslot_p = upload(tp.get(), nts);
+        m_asm.tslot_len = upload(tl.get(), nts);
+    }
     be->prepare_assembly(m_asm, m_bufs);
     laps.lap("assembly lists");
 }

@@ -353,6 +353,28 @@ def test_setup_loops_on_host_threads_are_deterministic(api, monkeypatch):
         assert np.array_equal(a, b)
 
 
+def test_assembly_lists_of_row_triples_give_the_same_jacobian(api, monkeypatch):
+    """the three rows of a vertex share their columns and, up to a shift of the Jacobian index, their gather lists
+    (backend.h, AssemblyDev::triples): the device keeps the lists of every third row only and assemble3_kernel forms the
+    three values from one pass over a list.  SANM_ASM_NO_TRIPLES=1 is the list per non-zero: same sums, term by term --
+    the Jacobian, the first expansion and the solution must be bit-identical.  (The host harness assembles from the
+    remap tables either way.)"""
+    cfg = {"material": {"young": 3e4, "poisson": 0.45, "density": 900.0}, "g": [0, -9.81, 0],
+           "boundary_thresh": 0.05, "boundary_proj_dir": [-1, 0, 0], "energy_model": "neohookean_c", "order": 6}
+    dims, sp = (11, 7, 6), 0.01
+    out = []
+    for flag in (None, "1"):
+        if flag:
+            monkeypatch.setenv("SANM_ASM_NO_TRIPLES", flag)
+        run = dfea.GravityRun(api, dfea.make_cuboid(*dims, sp), dict(cfg)).construct()
+        J = run.solver.jacobian_csr()
+        run.step()
+        out.append((J.indptr.copy(), J.indices.copy(), J.data.copy(), np.array(run.rms), run.solver.get_x().copy()))
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
+    assert np.abs(out[0][2]).max() > 0
+
+
 def test_pade_approx_on_its_own(api):
     """tests/pade.cpp:64-110 (Pade.Approx) through the C ABI: a stand-alone PadeApproximation over nine coefficient
     vectors of 500 entries (the last entry is t), its range accepted from range0 / 10, eval against the plain
