@@ -200,7 +200,7 @@ FAMILY_KERNELS = {
     "factor": "mfk::update_kernel + gemm1/gemm2 + extend_add + panel_finalize + diag + scatter",
     "taylor": "spec_pass* (taylor_pass_kernel: EVAL0, GRAD, COEFF+BIAS per order)",
     "io": "gather_rows3_kernel (remap_out; remap_in is fused into the Taylor passes)",
-    "asm": "assemble_kernel + nonfinite_kernel",
+    "asm": "assemble3_kernel (assemble_kernel without the row triples) + nonfinite_kernel",
     "collective": "ncclAllReduce of f(x0), the Jacobian values and b_k per order (tet-sharded mode)",
     "tail": "sanity_check_multi + Pade (multi_dot, gs_update, scale_rsqrt, lincomb2_diff_norms_multi) + "
             "next_coeff / dot / lincomb + host root finder",

@@ -43,11 +43,11 @@ for r in rows:
 tot = sum(v[1] for v in fam.values())
 with open(os.path.join(dst, f"{tag}_kernel_stats.md"), "w") as fo:
     if not steps:
-        steps = next((c for k, (c, t) in fam.items() if k == "assemble_kernel"), 14)
+        steps = next((c for k, (c, t) in fam.items() if k in ("assemble3_kernel", "assemble_kernel")), 14)
     fo.write(f"# rocprofv3 --kernel-trace --stats of `bench.py --workload {workload} --no-end-to-end --at-scale-workload none` ({tag})\n\n")
     fo.write(f"{workload}, order {order}, 1 MI355X.  Template instantiations of one kernel are\n"
              f"summed.  {steps} ANM steps in the run (timed + warm-up + the bench's 2 family-measurement steps: one\n"
-             f"`assemble_kernel` launch each) -> per-step column = total / {steps}.  Full per-instantiation table: `{tag}_kernel_stats.csv`.\n\n")
+             f"`assemble3_kernel` / `assemble_kernel` launch each) -> per-step column = total / {steps}.  Full per-instantiation table: `{tag}_kernel_stats.csv`.\n\n")
     fo.write(f"Total kernel time {tot / 1e6:.1f} ms.\n\n")
     fo.write("| kernel | calls | total ms | avg us | ms/step | % |\n|---|---|---|---|---|---|\n")
     for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
@@ -91,7 +91,7 @@ FAMILY_OF = {"mfk::fwd_level_sub_kernel": "solve", "mfk::fwd_level_tr_kernel": "
              "mfk::fwd_big_kernel": "solve", "mfk::bwd_big_kernel": "solve", "mfk::fwd_prep_kernel": "solve",
              "permute_out_dot_kernel": "solve", "mfk::permute_out_kernel": "solve", "mfk::permute_in_kernel": "solve",
              "taylor_pass_kernel": "taylor", "gather_rows3_kernel": "io", "gather_rows_kernel": "io",
-             "assemble_kernel": "asm", "nonfinite_kernel": "asm"}
+             "assemble_kernel": "asm", "assemble3_kernel": "asm", "nonfinite_kernel": "asm"}
 famacc = collections.OrderedDict()
 for k, (c, v) in fetch.items():
     name = FAMILY_OF.get(k, "factor" if k.startswith("mfk::") else "tail")
