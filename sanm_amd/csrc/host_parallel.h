@@ -16,7 +16,15 @@ inline int host_thread_cap() {
     const char* env_thr = std::getenv("SANM_HOST_THREADS");
     if (!env_thr) env_thr = std::getenv("SANM_MF_ND_THREADS");  // the name of round 5's first version
     if (env_thr) return std::min(64, std::max(1, std::atoi(env_thr)));
-    return (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+    // the host's threads are shared by the ranks of a node (torchrun's LOCAL_WORLD_SIZE, else WORLD_SIZE)
+    unsigned ranks = 1;
+    for (const char* name : {"LOCAL_WORLD_SIZE", "WORLD_SIZE"})
+        if (const char* v = std::getenv(name)) {
+            ranks = (unsigned)std::max(1, std::atoi(v));
+            break;
+        }
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    return (int)std::min(16u, std::max(1u, hw / ranks));
 }
 
 //! fn(begin, end, thread) over nt <= cap ranges of at least min_per_thread elements; fn must not throw

@@ -308,7 +308,7 @@ public:
         std::vector<std::pair<std::vector<int32_t>, int32_t>> work;  // (connected set, parent)
         split_components(all, -1, work);
         const char* env_thr = std::getenv("SANM_MF_ND_THREADS");
-        const int budget = env_thr ? std::atoi(env_thr) : (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+        const int budget = env_thr ? std::atoi(env_thr) : host_thread_cap();
         if (budget > 1 && g.nsv >= 8192) {
             // (the roots in the order the loop below pops them)
             for (size_t w = work.size(); w-- > 0;) {
