@@ -2,7 +2,6 @@
 #include "host_parallel.h"
 
 #include <algorithm>
-#include <atomic>
 #include <memory>
 #include <chrono>
 #include <thread>
