@@ -926,13 +926,40 @@ void Program::set_remap_in(int64_t n_in, const uint64_t* rowptr, const uint64_t*
             }
     });
     for (int64_t b : bad) sanm_check(b < 0, "remap_in: index %lu out of range", (unsigned long)b);
+    // Coefficients that are all +1, -1 or (the empty slots') +0 -- the edge vectors x_j - x_0 of a tet mesh -- go into
+    // the two top bits of their index words (program.h: RemapInDev): a third of the table's bytes in every pass, and
+    // the kernels form the same products.  SANM_RIN_NO_PACK=1: the table with its coefficients as doubles.
+    bool pack = n_in < (int64_t(1) << 30) && !std::getenv("SANM_RIN_NO_PACK");
+    if (pack) {
+        std::vector<char> ok(64, 1);
+        parallel_ranges((int64_t)tab, 1 << 18, [&](int64_t q0, int64_t q1, int t) {
+            for (int64_t q = q0; q < q1; ++q) {
+                const double cf = hcoef[q];
+                if (!(cf == 1.0 || cf == -1.0 || (cf == 0.0 && !std::signbit(cf)))) {
+                    ok[t % 64] = 0;
+                    return;
+                }
+            }
+        });
+        for (char c : ok) pack = pack && c;
+    }
+    if (pack)
+        parallel_ranges((int64_t)tab, 1 << 18, [&](int64_t q0, int64_t q1, int) {
+            for (int64_t q = q0; q < q1; ++q) {
+                const double cf = hcoef[q];
+                hidx[q] |= cf == 1.0 ? 0u : (cf == -1.0 ? 2u << 30 : 3u << 30);
+            }
+        });
     laps.lap("fill");
     if (m_d_rin_idx) m_be->free(m_d_rin_idx);
     if (m_d_rin_coef) m_be->free(m_d_rin_coef);
+    m_d_rin_coef = nullptr;
     m_d_rin_idx = m_be->alloc(tab * sizeof(uint32_t));
-    m_d_rin_coef = m_be->alloc(tab * sizeof(double));
     m_be->h2d(m_d_rin_idx, hidx.get(), tab * sizeof(uint32_t));
-    m_be->h2d(m_d_rin_coef, hcoef.get(), tab * sizeof(double));
+    if (!pack) {
+        m_d_rin_coef = m_be->alloc(tab * sizeof(double));
+        m_be->h2d(m_d_rin_coef, hcoef.get(), tab * sizeof(double));
+    }
     laps.lap("upload");
     m_dev.rin = {static_cast<const uint32_t*>(m_d_rin_idx),
                  static_cast<const double*>(m_d_rin_coef), nslot};

@@ -91,6 +91,9 @@ struct OpDesc {
 // idx/coef at [(s*9 + c)*Tpad + e]; unused slots carry coef 0.
 struct RemapInDev {
     const uint32_t* idx;
+    // null: every coefficient of the table is +1, -1 or 0 (the edge vectors of a tet: x_j - x_0) and sits in the two
+    // top bits of its index word -- 00: +1, 10: -1, 11: 0 (empty slot) --: 4 bytes per entry instead of 12
+    // (SANM_RIN_DECODE below; Program::set_remap_in packs when it can)
     const double* coef;
     int32_t nslot;
     // next_coeff fused into the gather (Backend::run_pass_next_coeff): with xg set, the gathered vector is not read
@@ -99,6 +102,10 @@ struct RemapInDev {
     const double* xg = nullptr;
     double t = 0;
 };
+
+// index and coefficient of a packed remap_in word (RemapInDev::coef == nullptr)
+#define SANM_RIN_INDEX(w) ((w) & 0x3fffffffu)
+#define SANM_RIN_COEF(w) (((w) >> 30) == 0u ? 1.0 : (((w) >> 30) == 2u ? -1.0 : 0.0))
 
 struct ProgramDev {
     const OpDesc* ops;

@@ -1401,9 +1401,17 @@ SANM_HD void gather_remap_in(const TetCtx& c, const RemapInDev& rin, const doubl
     if constexpr (NSLOT > 0) {
         uint32_t idx[9 * NSLOT];
         double coef[9 * NSLOT];
-        for (int i = 0; i < 9 * NSLOT; ++i) {  // slot sl of element e at i = sl * 9 + e
-            idx[i] = rin.idx[(int64_t)i * s + c.tet];
-            coef[i] = rin.coef[(int64_t)i * s + c.tet];
+        if (rin.coef) {
+            for (int i = 0; i < 9 * NSLOT; ++i) {  // slot sl of element e at i = sl * 9 + e
+                idx[i] = rin.idx[(int64_t)i * s + c.tet];
+                coef[i] = rin.coef[(int64_t)i * s + c.tet];
+            }
+        } else {  // (uniform) coefficients +-1 / 0 inside the index words: the same products and sums
+            for (int i = 0; i < 9 * NSLOT; ++i) {
+                const uint32_t w = rin.idx[(int64_t)i * s + c.tet];
+                idx[i] = SANM_RIN_INDEX(w);
+                coef[i] = SANM_RIN_COEF(w);
+            }
         }
         double v[9 * NSLOT];
         for (int i = 0; i < 9 * NSLOT; ++i) v[i] = xvec[idx[i]];
@@ -1423,9 +1431,12 @@ SANM_HD void gather_remap_in(const TetCtx& c, const RemapInDev& rin, const doubl
             double acc = 0;
             for (int sl = 0; sl < rin.nslot; ++sl) {
                 int64_t off = ((int64_t)sl * 9 + e) * s + c.tet;
-                double v = xvec[rin.idx[off]];
-                if (rin.xg) v = -rin.t * rin.xg[rin.idx[off]] - v;
-                acc = __builtin_fma(rin.coef[off], v, acc);
+                const uint32_t w = rin.idx[off];
+                const uint32_t ix = rin.coef ? w : SANM_RIN_INDEX(w);
+                const double cf = rin.coef ? rin.coef[off] : SANM_RIN_COEF(w);
+                double v = xvec[ix];
+                if (rin.xg) v = -rin.t * rin.xg[ix] - v;
+                acc = __builtin_fma(cf, v, acc);
             }
             X[e] = acc;
         }

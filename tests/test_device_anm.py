@@ -353,6 +353,23 @@ def test_setup_loops_on_host_threads_are_deterministic(api, monkeypatch):
         assert np.array_equal(a, b)
 
 
+def test_remap_in_coefficients_packed_into_the_index_words(api, monkeypatch):
+    """a remap_in table whose coefficients are all +1 / -1 / 0 (the edge vectors of a tet mesh) is kept as index words
+    with the coefficient in their two top bits (program.h, RemapInDev: 4 bytes per entry instead of 12 in every Taylor
+    pass); the kernels decode and form the same products: Jacobian, residuals and solution bit-identical with
+    SANM_RIN_NO_PACK=1, interpreter and compiled kernels alike."""
+    gold = json.load(open(os.path.join(GOLD, "anm_cuboid_nc.json")))
+    out = []
+    for flag in (None, "1"):
+        if flag:
+            monkeypatch.setenv("SANM_RIN_NO_PACK", flag)
+        run = _run_device(api, gold["dims"], gold["spacing"], gold["config"])
+        J = run.solver.jacobian_csr()
+        out.append((J.data.copy(), np.array(run.rms), run.solver.get_x().copy(), run.solver.get_nr_iter()))
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
+
+
 def test_assembly_lists_of_row_triples_give_the_same_jacobian(api, monkeypatch):
     """the three rows of a vertex share their columns and, up to a shift of the Jacobian index, their gather lists
     (backend.h, AssemblyDev::triples): the device keeps the lists of every third row only and assemble3_kernel forms the
