@@ -966,7 +966,10 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
     // assembly lists; its device copies are made by this thread once the others are done.  SANM_SETUP_SERIAL=1: one
     // thing after the other.
     const double* coords = remap_out.out_coords.size() == (size_t)m_n * 3 ? remap_out.out_coords.data() : nullptr;
-    const bool beside = hp.solver_kind == 1 && hp.xcoeff_l2_penalty == 0 && !std::getenv("SANM_SETUP_SERIAL");
+    // (the merged top block, SANM_MF_TOP > 0, multiplies device blocks out while the analysis builds it, i.e. it is
+    // not deferred: it must run on this thread, the owner of the backend, whose pool and staging buffers have no lock)
+    const bool mf_top = std::getenv("SANM_MF_TOP") && std::atoi(std::getenv("SANM_MF_TOP")) > 0;
+    const bool beside = hp.solver_kind == 1 && hp.xcoeff_l2_penalty == 0 && !std::getenv("SANM_SETUP_SERIAL") && !mf_top;
     t_setup = clk();
     m_pattern = std::make_unique<JacobianPattern>(be, remap_out, remap_inp, m_n, T, 0, 9, tb, te, 9, tet_order, tet_inv,
                                                   /*defer_device=*/true);

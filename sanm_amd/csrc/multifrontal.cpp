@@ -951,9 +951,12 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
                            const std::vector<uint32_t>& col, const double* coords, int rank, int world,
                            bool defer_device)
         : m_be{be},
-          // (the merged top block multiplies device blocks out while it is built: not deferred)
-          m_defer{defer_device && !(std::getenv("SANM_MF_TOP") && std::atoi(std::getenv("SANM_MF_TOP")) > 0)} {
+          m_defer{defer_device} {
     const auto t_ctor = std::chrono::steady_clock::now();
+    // (the merged top block multiplies device blocks out while it is built: it cannot be deferred, and a constructor
+    // that touches the backend must run on the backend's owner thread -- the caller's job, anm.cpp: `beside`)
+    sanm_check(!(defer_device && std::getenv("SANM_MF_TOP") && std::atoi(std::getenv("SANM_MF_TOP")) > 0),
+               "multifrontal: SANM_MF_TOP needs a constructor that is not deferred (owner thread of the backend)");
     sanm_check(world >= 1 && rank >= 0 && rank < world, "multifrontal: rank %d of %d", rank, world);
     sanm_check(n > 0 && (int64_t)rowptr.size() == n + 1, "bad CSR pattern");
     sanm_check(n < INT32_MAX / 2, "system too large for 32-bit indices");

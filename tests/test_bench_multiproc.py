@@ -18,7 +18,8 @@ bench.make_api = lambda local_rank: get_hostsim_api()
 bench.device_sync = lambda: None
 out = bench.main(["--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "cuboid:5,3,3",
                   "--no-cpu-baseline", "--dist-backend", "gloo", "--at-scale-workload", "cuboid:6,3,3",
-                  "--at-scale-steps", "2"] + {extra!r})
+                  "--at-scale-steps", "2", "--at-scale-large-workload", "cuboid:7,3,3", "--at-scale-large-steps", "2"]
+                 + {extra!r})
 if os.environ["RANK"] == "0":
     assert out is not None
 else:
@@ -77,6 +78,10 @@ def _check_common(d):
     assert a["roofline"]["family"] in a["roofline_families"] and a["roofline"]["bound"] == "hbm"
     assert "cuboid:6,3,3" in a["config"]["workload"] and "dist_solver" in a["config"]
     assert a["end_to_end"]["iter"] >= 1
+    # a third leg in the regime where the distributed direct solver acts, for every N
+    b = d["at_scale_large"]
+    assert b["steps"] == 2 and b["value"] > 0 and "cuboid:7,3,3" in b["config"]["workload"]
+    assert "dist_solver" in b["config"] and b["end_to_end"]["iter"] >= 1 and "factor" in b["roofline_families"]
     if d["config"]["parallelism"].startswith("tet-shard"):
         assert a["config"]["parallelism"].startswith("tet-shard") and a["collective_ms_per_step"] > 0
 
@@ -109,7 +114,8 @@ def test_plain_command_with_gpus_2_starts_two_ranks_itself():
     env["SANM_BENCH_TEST_HOOK"] = "tests.hostsim.bench_hook"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                         "--workload", "cuboid:5,3,3", "--no-cpu-baseline", "--dist-backend", "gloo",
-                        "--at-scale-workload", "cuboid:6,3,3", "--at-scale-steps", "2"],
+                        "--at-scale-workload", "cuboid:6,3,3", "--at-scale-steps", "2",
+                        "--at-scale-large-workload", "cuboid:7,3,3", "--at-scale-large-steps", "2"],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -141,7 +147,8 @@ def test_plain_command_two_ranks_with_the_distributed_direct_solver():
     env["SANM_DIST_SOLVER"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                         "--workload", "cuboid:10,5,5", "--no-cpu-baseline", "--dist-backend", "gloo",
-                        "--at-scale-workload", "cuboid:6,3,3", "--at-scale-steps", "2"],
+                        "--at-scale-workload", "cuboid:6,3,3", "--at-scale-steps", "2",
+                        "--at-scale-large-workload", "cuboid:7,3,3", "--at-scale-large-steps", "2"],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])

@@ -238,6 +238,35 @@ def test_inverse_single_tet(api):
         assert z == pytest.approx(want, rel=2e-8)
 
 
+def test_jacobi_pcg_solver_against_the_oracle(api):
+    """solver_kind 0, the Jacobi-preconditioned conjugate gradients north_star names first (pcg_init / pcg_spmv_dot /
+    pcg_update kernels; the reference's direct solve, sparse_solver.cpp:154-180, stands behind the oracle): the first
+    expansion's coefficients against the live oracle at 1e-8, then the whole continuation without Pade -- same step
+    count, same residuals, the oracle's equilibrium (golden file) at the north-star tolerance.  The iteration stops
+    at a relative residual of 1e-13: what the conditioning of the cuboid's Jacobian leaves of that in x is 1e-9."""
+    gold = json.load(open(os.path.join(GOLD, "anm_cuboid_nc_nopade_o8.json")))
+    cfg = gold["config"]
+    assert cfg.get("disable_pade")
+    run = dfea.GravityRun(api, dfea.make_cuboid(*gold["dims"], gold["spacing"]), dict(cfg), solver_kind=0,
+                          solver_rtol=1e-13, solver_maxit=20000, profile=1).construct()
+    _, osolver, _ = ofea.make_gravity_solver(ofea.make_cuboid(*gold["dims"], gold["spacing"]), cfg)
+    tr = run.solver.trace()
+    assert np.allclose(tr["t"], osolver.trace[0]["t"], rtol=1e-8)
+    assert np.allclose(tr["x_norm"], osolver.trace[0]["x_norm"], rtol=1e-8)
+    xc = run.solver.xt_coeffs()
+    for i in range(1, int(cfg["order"]) + 1):
+        assert np.abs(xc[i] - osolver.xt_coeffs[i]).max() <= 1e-8 * np.abs(osolver.xt_coeffs[i]).max(), i
+    st = run.solver.stats()
+    assert st["nr_linear_solve"] >= int(cfg["order"]) and 0 < st["linear_iters_last"] < 20000
+    while not run.solver.converged():
+        run.step()
+    assert run.solver.get_nr_iter() == gold["iter"]
+    assert np.allclose(run.rms[:-1], gold["residual_rms"][:-1], rtol=1e-5)
+    V, Vg = run.vertices(), np.array(gold["vertices"])
+    assert np.abs(V - Vg).max() <= VTX_RTOL * np.abs(Vg).max()
+    assert run.rms[-1] < 1e-10
+
+
 def test_error_paths(api):
     mesh = dfea.make_cuboid(3, 3, 3, 0.05)
     fixed = np.zeros((mesh.nr_vertices, 3), bool)
