@@ -560,7 +560,7 @@ class Leg:
         # what every rank factors (the direct solver distributed by subtrees): rank 0 reports the table
         self.rank_stats = None
         if self.dist is not None:
-            mine = {k: self.stats[k] for k in ("factor_flops_own", "factor_flops_top", "nr_subtree_own")}
+            mine = {k: self.stats[k] for k in ("factor_flops_own", "factor_flops_top_own", "nr_subtree_own")}
             gathered = [None] * self.world
             self.dist.all_gather_object(gathered, mine)
             self.rank_stats = gathered
@@ -605,9 +605,12 @@ class Leg:
                        "linear_solver": "jacobi-pcg" if args.solver_kind == 0 else "multifrontal-lu",
                        "solver_stats": {k: stats[k] for k in ("factor_nnz", "factor_flops", "nr_front",
                                                               "nr_level", "max_front")},
-                       # rank 0's share when the direct solver is distributed by subtrees (nr_subtree > 0)
+                       # rank 0's share when the direct solver is distributed over the tree (nr_subtree > 0):
+                       # its subtrees (own) and top fronts (top_own) of the whole top, the stages, and the critical path
+                       # of the factorisation in flops (factor_flops / factor_flops_critical = speed-up if flops-bound)
                        "dist_solver": dict({k: stats[k] for k in ("nr_subtree", "nr_subtree_own", "factor_flops_own",
-                                                                  "factor_flops_top")},
+                                                                  "factor_flops_top", "factor_flops_top_own",
+                                                                  "factor_flops_critical", "nr_dist_stage")},
                                            exchange_bytes={"schur_per_factorisation": 8 * stats["dist_schur_doubles"],
                                                            "inbox_per_solve": 8 * stats["dist_inbox_doubles"],
                                                            "solution_per_solve": 8 * n if stats["nr_subtree"] else 0},

@@ -49,7 +49,7 @@ const char* sanm_hip_backend_name(void);
  * an entry point changes meaning.  A consumer compiled against this header checks
  * sanm_hip_abi_version() == SANM_HIP_ABI_VERSION once after loading the library (adapter/anm_hip.h does), or uses
  * the *_sized calls, which write no more than the caller's own record holds. */
-#define SANM_HIP_ABI_VERSION 5
+#define SANM_HIP_ABI_VERSION 6
 int sanm_hip_abi_version(void);
 
 /* ---- operator API: libsanm/oprs.h:14-103, oprs.cpp:16-102 --------------- */
@@ -271,6 +271,12 @@ typedef struct sanm_anm_stats {
     /* ... and what its exchanges move, in doubles: the Schur complements of the cut roots once per factorisation, their
      * update rows once per solve (the third exchange, the solution, is nr_unknown doubles per solve) */
     int64_t dist_schur_doubles, dist_inbox_doubles;
+    /* (ABI 6) the distribution over the whole tree: every front has one owner, the fronts above the subtrees -- the top,
+     * factor_flops_top -- are mapped onto the ranks as well (factor_flops_top_own: this rank's) and run in nr_dist_stage
+     * - 1 stages with exchanges between them; factor_flops_critical: sum over the stages of the busiest rank's flops,
+     * i.e. the factorisation's critical path (factor_flops / factor_flops_critical = its speed-up if flops-bound) */
+    double factor_flops_top_own, factor_flops_critical;
+    int64_t nr_dist_stage;
 } sanm_anm_stats;
 int sanm_anm_get_stats(const sanm_anm_solver* s, sanm_anm_stats* st);
 /* the same for a caller whose sanm_anm_stats may be older (shorter) than the library's: at most st_bytes are written */

@@ -41,11 +41,14 @@ int sanm_rtc_cache_drop_memory(void);
 /* obtains the code object of `source` through the caches exactly like a solver under construction does; 0 = ok */
 int sanm_rtc_cache_probe(const char* source);
 
-/* the subtree-to-rank plan of a direct solver created with SANM_MF_PLAN_WORLD=G in the environment (analysis as rank 0
- * of G; scripts/dist_plan.py): rank_flops[r] = factor flops of rank r's subtrees, rank_flops[world_cap + r] = their
- * factor entries (2 * world_cap doubles), out8 = {world, total flops, flops of the replicated top, subtrees, doubles of
- * the Schur exchange, doubles of the inbox exchange, factor entries of the top, factor entries in all} */
-int sanm_direct_solver_dist_plan(const sanm_direct_solver* s, int world_cap, double* rank_flops, double* out8);
+/* the tree-to-ranks plan of a direct solver created with SANM_MF_PLAN_WORLD=G in the environment (analysis as rank 0
+ * of G; scripts/dist_plan.py).  out[0..11] = {world G, stages S, total flops, flops of the top, subtrees, doubles of all
+ * Schur exchanges, doubles of all inbox exchanges, factor entries of the top, factor entries in all, critical-path
+ * flops, subtree imbalance, 0}; then S * G flops (rank r in stage s at [s * G + r]), S * G factor entries, and per stage
+ * the doubles of its Schur exchange and the largest number of them one rank receives, then the number X of Schur
+ * transfers and {stage, src, dst, doubles, stage that produces it} for each.  Returns the number of doubles the plan has
+ * (12 + 2 S G + 2 S + 1 + 5 X) through *n_out; writes at most cap of them. */
+int sanm_direct_solver_dist_plan(const sanm_direct_solver* s, int64_t cap, double* out, int64_t* n_out);
 
 #ifdef __cplusplus
 }

@@ -61,7 +61,9 @@ class StatsC(C.Structure):
                 ("max_front", C.c_int64), ("factor_flops", C.c_double),
                 ("factor_flops_own", C.c_double), ("factor_flops_top", C.c_double),
                 ("nr_subtree", C.c_int64), ("nr_subtree_own", C.c_int64),
-                ("dist_schur_doubles", C.c_int64), ("dist_inbox_doubles", C.c_int64)]
+                ("dist_schur_doubles", C.c_int64), ("dist_inbox_doubles", C.c_int64),
+                ("factor_flops_top_own", C.c_double), ("factor_flops_critical", C.c_double),
+                ("nr_dist_stage", C.c_int64)]
 
 
 ENERGY = {"neohookean_i": 0, "neohookean_c": 1, "arap": 2, "stvk_stretch": 3}
@@ -450,16 +452,27 @@ class DirectSolver:
             self.api.lib.sanm_direct_solver_destroy(self.h)
             self.h = None
 
-    def dist_plan(self, world_cap=64):
-        """the subtree-to-rank plan of a solver created under SANM_MF_PLAN_WORLD (test hook, sanm_hip_test.h)"""
-        rf, out = np.zeros(2 * world_cap), np.zeros(8)
-        self.api.check(self.api.lib.sanm_direct_solver_dist_plan(self.h, C.c_int(world_cap), _dp(rf), _dp(out)))
-        w = int(out[0])
-        rfl = rf[:w].tolist()
-        return {"world": w, "total_flops": out[1], "top_flops": out[2], "nr_subtree": int(out[3]),
-                "schur_exchange_doubles": out[4], "inbox_exchange_doubles": out[5], "top_nnz": out[6],
-                "factor_nnz": out[7], "rank_flops": rfl, "rank_nnz": rf[world_cap:world_cap + w].tolist(),
-                "imbalance": (max(rfl) * w / sum(rfl)) if sum(rfl) > 0 else 1.0}
+    def dist_plan(self):
+        """the tree-to-ranks plan of a solver created under SANM_MF_PLAN_WORLD (test hook, sanm_hip_test.h)"""
+        out, n = np.zeros(1 << 14), C.c_int64()
+        self.api.check(self.api.lib.sanm_direct_solver_dist_plan(self.h, C.c_int64(out.size), _dp(out), C.byref(n)))
+        assert n.value <= out.size
+        G, S = int(out[0]), int(out[1])
+        p = 12
+        sf = out[p:p + S * G].reshape(S, G)
+        sn = out[p + S * G:p + 2 * S * G].reshape(S, G)
+        ex = out[p + 2 * S * G:p + 2 * S * G + 2 * S].reshape(S, 2)
+        rfl = sf[0].tolist()
+        q = p + 2 * S * G + 2 * S
+        nx = int(out[q])
+        xf = out[q + 1:q + 1 + 5 * nx].reshape(nx, 5)
+        return {"schur_transfers": [{"stage": int(r[0]), "src": int(r[1]), "dst": int(r[2]), "doubles": r[3],
+                                     "src_stage": int(r[4])} for r in xf],
+                "world": G, "nr_stage": S, "total_flops": out[2], "top_flops": out[3], "nr_subtree": int(out[4]),
+                "schur_exchange_doubles": out[5], "inbox_exchange_doubles": out[6], "top_nnz": out[7],
+                "factor_nnz": out[8], "critical_flops": out[9], "imbalance": out[10],
+                "rank_flops": rfl, "stage_flops": sf.tolist(), "stage_nnz": sn.tolist(),
+                "stage_schur_doubles": ex[:, 0].tolist(), "stage_schur_max_recv_doubles": ex[:, 1].tolist()}
 
     def factor(self, A):
         A = A.tocsr()

@@ -187,32 +187,38 @@ class DirectSolver final : public LinearSolver {
         }
     }
 
-    // ---- distributed by subtrees (MfSchedule::Dist): pieces of the factorisation / the sweeps with the exchanges
-    //      between them.  Every exchange is a sum over the ranks in which each entry has one non-zero contributor,
-    //      so the factors and solutions are those of the single-rank run bit for bit.
+    // ---- distributed over the ranks (MfSchedule::Dist, mf_types.h): every front has one owner, the rank's own levels
+    //      run stage by stage with the exchanges between them.  Every entry of every exchange has exactly one writer, so
+    //      the factors and solutions are those of the single-rank run bit for bit.  m_p2p (the backend's own
+    //      communicator): grouped send / receive pairs and broadcasts in place; else the C ABI's all-reduce callback
+    //      over a zeroed staging buffer.
     const Collective m_coll;
+    const PointToPoint m_p2p;
     DVec m_dist_status;
     bool dist() const { return m_mf.schedule().dist.enabled; }
+    //! one staged exchange: pack what this rank sends (src_base -> stage), move it, unpack what it receives
+    void exchange(const MfSchedule::Exchange& E, const double* src_base, double* dst_base) {
+        const auto& D = m_mf.schedule().dist;
+        if (E.doubles == 0) return;
+        if (!m_p2p) m_be->zero(D.stage, (size_t)E.doubles * 8);
+        m_be->copy2d_batch(E.pack, E.n_pack, E.max_rows, E.max_cols, src_base, D.stage);
+        if (m_p2p) m_p2p(D.stage, E.xfers.data(), (int)E.xfers.size());
+        else m_coll(D.stage, E.doubles);
+        m_be->copy2d_batch(E.unpack, E.n_unpack, E.max_rows, E.max_cols, D.stage, dst_base);
+    }
     void dist_factor(double* status) {
         const MfDev& mf = m_mf.dev();
         const MfSchedule& sch = m_mf.schedule();
         const auto& D = sch.dist;
-        const int nl = (int)sch.levels.size();
-        m_be->mf_factor_piece(mf, sch, m_pat.csr(), 0, D.cut, true);
-        // perturbed pivots: every rank counts those of its own subtrees, rank 0 also those of the replicated top (which
-        // every rank factors and would otherwise be counted `world` times: the sum must equal the single-rank count)
-        if (m_dist_status.empty()) m_dist_status = DVec{m_be, 1};
-        if (D.rank != 0) m_be->mf_factor_status(mf, m_dist_status.p());
-        if (D.schur_doubles > 0) {
-            // the Schur complements of all cut roots: own ones packed into the staging buffer, the rest of it zero
-            m_be->zero(D.stage, (size_t)D.schur_doubles * 8);
-            m_be->copy2d_batch(D.schur_pack, D.n_schur_pack, D.schur_max_b, D.schur_max_b, mf.front_store, D.stage);
-            m_coll(D.stage, D.schur_doubles);
-            m_be->copy2d_batch(D.schur_unpack, D.n_schur_unpack, D.schur_max_b, D.schur_max_b, D.stage, mf.front_store);
+        for (int st = 0; st < D.nr_stage; ++st) {
+            // the Schur complements of the children another rank factored
+            if (st > 0) exchange(D.schur[st], mf.front_store, mf.front_store);
+            m_be->mf_factor_piece(mf, sch, m_pat.csr(), D.stage_level[st], D.stage_level[st + 1], st == 0);
         }
-        m_be->mf_factor_piece(mf, sch, m_pat.csr(), D.cut, nl, false);
-        // perturbed pivots anywhere decide for everybody (the refinement they switch on contains collectives)
-        if (D.rank == 0) m_be->mf_factor_status(mf, m_dist_status.p());
+        // perturbed pivots: every rank counts those of its own fronts; anywhere decides for everybody (the refinement
+        // they switch on contains collectives)
+        if (m_dist_status.empty()) m_dist_status = DVec{m_be, 1};
+        m_be->mf_factor_status(mf, m_dist_status.p());
         m_coll(m_dist_status.p(), 1);
         m_be->d2h_async(status, m_dist_status.p(), 8);
     }
@@ -220,36 +226,41 @@ class DirectSolver final : public LinearSolver {
         const MfDev& mf = m_mf.dev();
         const MfSchedule& sch = m_mf.schedule();
         const auto& D = sch.dist;
-        const int nl = (int)sch.levels.size();
         m_be->mf_permute(mf, b, nullptr);
-        m_be->mf_solve_piece(mf, sch, true, 0, D.cut);
-        if (D.inbox_doubles > 0) {
-            // the cut roots' update rows in their parents' inboxes
-            m_be->zero(D.stage, (size_t)D.inbox_doubles * 8);
-            m_be->copy2d_batch(D.inbox_pack, D.n_inbox_pack, 1, D.inbox_max_m, mf.inbox_store, D.stage);
-            m_coll(D.stage, D.inbox_doubles);
-            m_be->copy2d_batch(D.inbox_unpack, D.n_inbox_unpack, 1, D.inbox_max_m, D.stage, mf.inbox_store);
+        for (int st = 0; st < D.nr_stage; ++st) {
+            // the update rows of those children in their parents' inboxes
+            if (st > 0) exchange(D.inbox[st], mf.inbox_store, mf.inbox_store);
+            m_be->mf_solve_piece(mf, sch, true, D.stage_level[st], D.stage_level[st + 1]);
         }
-        m_be->mf_solve_piece(mf, sch, true, D.cut, nl);
-        m_be->mf_solve_piece(mf, sch, false, D.cut, nl);
-        m_be->mf_solve_piece(mf, sch, false, 0, D.cut);
-        // every rank ends with the whole solution: each entry of the permuted vector from the one rank that speaks
-        // for it (the owner of its subtree; rank 0 for the replicated top)
-        for (const auto& r : D.zero_ranges) m_be->zero(mf.work + r.first, (size_t)(r.second - r.first) * 8);
-        m_coll(mf.work, mf.n);
+        for (int st = D.nr_stage - 1; st >= 0; --st) {
+            m_be->mf_solve_piece(mf, sch, false, D.stage_level[st], D.stage_level[st + 1]);
+            // the stage's pivots to everyone: the levels below read their boundary values there, and every rank ends
+            // with the whole solution
+            const auto& X = D.sol[st];
+            if (X.doubles == 0) continue;
+            if (m_p2p) {
+                m_p2p(mf.work, X.xfers.data(), (int)X.xfers.size());  // broadcasts in place
+            } else if (st > 0) {
+                exchange(X, mf.work, mf.work);
+            } else {
+                for (const auto& r : D.zero_ranges) m_be->zero(mf.work + r.first, (size_t)(r.second - r.first) * 8);
+                m_coll(mf.work, mf.n);
+            }
+        }
         m_be->mf_permute(mf, nullptr, x);
     }
 
 public:
     DirectSolver(Backend* be, const JacobianPattern& pat, const HyperParam& hp, const double* coords, int rank,
-                 int world, Collective coll, std::unique_ptr<Multifrontal> analysed)
+                 int world, Collective coll, PointToPoint p2p, std::unique_ptr<Multifrontal> analysed)
             : m_be{be}, m_pat{pat},
               m_mf_own{analysed ? std::move(analysed)
                                 : std::make_unique<Multifrontal>(be, pat.n(), pat.h_rowptr(), pat.h_col(), coords, rank, world)},
               m_mf{*m_mf_own},
               m_refine_always{std::getenv("SANM_SOLVER_REFINE") ? std::atoi(std::getenv("SANM_SOLVER_REFINE"))
                                                                 : hp.solver_refine},
-              m_coll{std::move(coll)} {
+              m_coll{std::move(coll)},
+              m_p2p{std::move(p2p)} {
         sanm_check(!dist() || m_coll, "distributed direct solver without a collective");
         nnz_factors = m_mf.nnz_factors;
         nr_front = m_mf.nr_front;
@@ -259,6 +270,9 @@ public:
         const auto& D = m_mf.schedule().dist;
         factor_flops_own = D.flops_own;
         factor_flops_top = D.flops_top;
+        factor_flops_top_own = D.flops_top_own;
+        factor_flops_critical = D.flops_critical;
+        nr_dist_stage = D.enabled ? D.nr_stage : 0;
         nr_subtree = D.nr_subtree;
         nr_subtree_own = D.nr_subtree_own;
         dist_schur_doubles = D.schur_doubles;
@@ -469,10 +483,12 @@ std::unique_ptr<LinearSolver> make_dense_solver(Backend* be, const JacobianPatte
 
 std::unique_ptr<LinearSolver> make_direct_solver(Backend* be, const JacobianPattern& pat,
                                                  const HyperParam& hp, const double* coords, int rank, int world,
-                                                 Collective coll, std::unique_ptr<Multifrontal> analysed) {
+                                                 Collective coll, PointToPoint p2p,
+                                                 std::unique_ptr<Multifrontal> analysed) {
     // (the regularised path factors A'A on every rank: replicated)
     if (hp.xcoeff_l2_penalty != 0) return std::make_unique<TikhonovSolver>(be, pat, hp.xcoeff_l2_penalty, coords);
-    return std::make_unique<DirectSolver>(be, pat, hp, coords, rank, world, std::move(coll), std::move(analysed));
+    return std::make_unique<DirectSolver>(be, pat, hp, coords, rank, world, std::move(coll), std::move(p2p),
+                                          std::move(analysed));
 }
 
 std::unique_ptr<LinearSolver> make_pcg_solver(Backend* be, const JacobianPattern& pat,
@@ -1058,11 +1074,19 @@ void AnmDriver::construct_solver_and_vectors(const double* coords, std::unique_p
         m_solver = make_dense_solver(be, *m_pattern);
     } else if (hp.solver_kind == 1) {
         // tet-sharded over several ranks: factorisation and solves by subtrees where that pays (multifrontal.cpp)
-        if (m_shard.active() && m_shard.world > 1)
+        if (m_shard.active() && m_shard.world > 1) {
+            // point-to-point transfers where the collective is the backend's own communicator (SANM_DIST_P2P=0: the
+            // all-reduce form of the exchanges there too); the callback of the C ABI offers the all-reduce only
+            PointToPoint p2p;
+            const char* env_p2p = std::getenv("SANM_DIST_P2P");
+            if (!m_shard.allreduce && be->comm_p2p_available() && !(env_p2p && std::atoi(env_p2p) == 0))
+                p2p = [this](double* base, const MfSchedule::Xfer* x, int n) { exchange_p2p(base, x, n); };
             m_solver = make_direct_solver(be, *m_pattern, hp, coords, m_shard.rank, m_shard.world,
-                                          [this](double* p, int64_t c) { allreduce(p, c); }, std::move(analysed));
-        else
-            m_solver = make_direct_solver(be, *m_pattern, hp, coords, 0, 1, {}, std::move(analysed));
+                                          [this](double* p, int64_t c) { allreduce(p, c); }, std::move(p2p),
+                                          std::move(analysed));
+        } else {
+            m_solver = make_direct_solver(be, *m_pattern, hp, coords, 0, 1, {}, {}, std::move(analysed));
+        }
     } else if (hp.solver_kind == 0) {
         m_solver = make_pcg_solver(be, *m_pattern, hp);
     } else if (hp.solver_kind == 2) {
@@ -1163,6 +1187,11 @@ void AnmDriver::allreduce(double* buf, int64_t count) {
     m_be->sync();  // the callback's collective runs outside this backend's stream
     int rc = m_shard.allreduce(m_shard.user, buf, count);
     if (rc != 0) sanm_throw(SANM_ERR_HIP, "all-reduce callback failed with code %d", rc);
+}
+
+void AnmDriver::exchange_p2p(double* base, const MfSchedule::Xfer* x, int n) {
+    ScopedTimer t{this, "allreduce"};  // (booked with the collectives)
+    m_be->comm_exchange(base, x, n);   // queued on the backend's stream
 }
 
 void AnmDriver::init_xt0(const double* x_host, double t) {

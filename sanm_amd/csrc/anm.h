@@ -116,14 +116,19 @@ public:
     // direct solver analysis (0 for iterative solvers)
     int64_t nnz_factors = 0, nr_front = 0, nr_level = 0, max_front = 0;
     double factor_flops = 0;
-    // distributed direct solver (subtree-to-rank, MfSchedule::Dist): what THIS rank factors
-    double factor_flops_own = 0, factor_flops_top = 0;
-    int64_t nr_subtree = 0, nr_subtree_own = 0;
+    // distributed direct solver (MfSchedule::Dist): what THIS rank factors -- its subtrees (own) and its fronts of the
+    // top (top_own) --, the whole top, and the critical path of the factorisation (sum over the stages of the busiest
+    // rank's flops)
+    double factor_flops_own = 0, factor_flops_top = 0, factor_flops_top_own = 0, factor_flops_critical = 0;
+    int64_t nr_subtree = 0, nr_subtree_own = 0, nr_dist_stage = 0;
     int64_t dist_schur_doubles = 0, dist_inbox_doubles = 0;
 };
 //! sum over the ranks of `count` doubles at a device pointer, in place (the driver's all-reduce: RCCL on the solver's
 //! stream or the C ABI's callback)
 using Collective = std::function<void(double*, int64_t)>;
+//! grouped point-to-point transfers / broadcasts of ranges of one device buffer (MfSchedule::Xfer; Backend::
+//! comm_exchange on the backend's own communicator); empty: the communicator at hand offers the all-reduce only
+using PointToPoint = std::function<void(double*, const MfSchedule::Xfer*, int)>;
 std::unique_ptr<LinearSolver> make_pcg_solver(Backend* be, const JacobianPattern& pat,
                                               const HyperParam& hp);
 //! multifrontal LU (multifrontal.h); coords: (n,3) ordering hint or null
@@ -132,7 +137,7 @@ std::unique_ptr<LinearSolver> make_pcg_solver(Backend* be, const JacobianPattern
 //! analysed: the analysis of pat's pattern done beforehand (Multifrontal with defer_device, finished); null: done here
 std::unique_ptr<LinearSolver> make_direct_solver(Backend* be, const JacobianPattern& pat,
                                                  const HyperParam& hp, const double* coords, int rank = 0,
-                                                 int world = 1, Collective coll = {},
+                                                 int world = 1, Collective coll = {}, PointToPoint p2p = {},
                                                  std::unique_ptr<Multifrontal> analysed = nullptr);
 
 //! dense LU with partial pivoting: the small general systems of graphs on the vector interpreter
@@ -292,6 +297,7 @@ protected:
     Injection m_inject;
     void apply_injection(double* vec, int64_t len);
     void allreduce(double* buf, int64_t count);
+    void exchange_p2p(double* base, const MfSchedule::Xfer* x, int n);
     std::unique_ptr<Program> m_prog;
     // Graphs over vectors or matrices of other sizes than 3 x 3 (vecprog.h): the same order loop with the vector
     // interpreter as its pass engine -- remap_inp as a device gather in front of it, the Jacobian's blocks

@@ -319,6 +319,12 @@ public:
     virtual void comm_query(int* world, int* rank) { *world = *rank = 0; }
     //! in-place sum of `count` doubles over all ranks, queued on the backend's stream (no host synchronisation)
     virtual void allreduce_sum(double* buf, int64_t count);
+    //! the live communicator offers grouped send / receive and broadcast (ncclSend / ncclRecv / ncclBroadcast bound)
+    virtual bool comm_p2p_available() { return false; }
+    //! n transfers of ranges of one device buffer as ONE group, queued on the backend's stream: x[i] with dst >= 0: rank
+    //! src sends base[off, off + cnt) and rank dst receives it at the same place; dst = -1: broadcast in place from
+    //! src to every rank.  The same list on every rank (MfSchedule::Xfer).
+    virtual void comm_exchange(double* base, const MfSchedule::Xfer* x, int n);
 
     //! HyperParam::solver_kind == 2: a linear solver supplied by the backend itself.  The HIP backend has none
     //! (nullptr: the driver rejects the setting); the CPU baseline harness (tests/hostsim) returns MKL PARDISO,

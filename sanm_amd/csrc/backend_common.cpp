@@ -13,6 +13,10 @@ void Backend::allreduce_sum(double*, int64_t) {
     sanm_throw(SANM_ERR_UNSUPPORTED, "backend %s has no native collective (pass an all-reduce callback)", name());
 }
 
+void Backend::comm_exchange(double*, const MfSchedule::Xfer*, int) {
+    sanm_throw(SANM_ERR_UNSUPPORTED, "backend %s has no native point-to-point transfers", name());
+}
+
 void Backend::residual(const CsrDev& A, const double* b, const double* x, double* r) {
     double* ax = static_cast<double*>(alloc(A.n * 8));
     spmv(A, x, ax);

@@ -1414,6 +1414,13 @@ struct Rccl {
     int (*GetUniqueId)(UniqueId*) = nullptr;
     int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+    // the exchanges of the distributed direct solver (MfSchedule::Dist): grouped send / receive pairs for the Schur
+    // complements and inbox rows, grouped broadcasts in place (a gather of ranges of unequal length) for the solution
+    int (*Send)(const void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     int (*CommDestroy)(Comm) = nullptr;
     int (*CommCount)(Comm, int*) = nullptr;
     int (*CommUserRank)(Comm, int*) = nullptr;
@@ -1428,6 +1435,11 @@ struct Rccl {
                 x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
                 x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
                 x.AllReduce = reinterpret_cast<decltype(x.AllReduce)>(dlsym(h, "ncclAllReduce"));
+                x.Send = reinterpret_cast<decltype(x.Send)>(dlsym(h, "ncclSend"));
+                x.Recv = reinterpret_cast<decltype(x.Recv)>(dlsym(h, "ncclRecv"));
+                x.Broadcast = reinterpret_cast<decltype(x.Broadcast)>(dlsym(h, "ncclBroadcast"));
+                x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(dlsym(h, "ncclGroupStart"));
+                x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
                 x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
                 x.CommCount = reinterpret_cast<decltype(x.CommCount)>(dlsym(h, "ncclCommCount"));
                 x.CommUserRank = reinterpret_cast<decltype(x.CommUserRank)>(dlsym(h, "ncclCommUserRank"));
@@ -1756,6 +1768,34 @@ public:
         r.check(r.AllReduce(buf, buf, (size_t)count, /*ncclFloat64*/ 8, /*ncclSum*/ 0, m_comm, m_stream), "ncclAllReduce");
     }
 
+    bool comm_p2p_available() override {
+        if (!m_comm) return false;
+        const Rccl& r = Rccl::get();
+        return r.Send && r.Recv && r.Broadcast && r.GroupStart && r.GroupEnd;
+    }
+    void comm_exchange(double* base, const MfSchedule::Xfer* x, int n) override {
+        if (!m_comm) sanm_throw(SANM_ERR_ASSERT, "exchange without a communicator (sanm_hip_comm_init first)");
+        const Rccl& r = Rccl::get();
+        if (!comm_p2p_available()) sanm_throw(SANM_ERR_UNSUPPORTED, "this RCCL has no ncclSend / ncclRecv / ncclBroadcast");
+        // (one group: the transfers of a stage are independent of each other and RCCL runs them together; a rank that
+        // takes part in none of them opens and closes an empty group)
+        r.check(r.GroupStart(), "ncclGroupStart");
+        int rc = 0;
+        for (int i = 0; i < n && rc == 0; ++i) {
+            double* p = base + x[i].off;
+            const size_t cnt = (size_t)x[i].cnt;
+            if (cnt == 0) continue;
+            if (x[i].dst < 0) {
+                rc = r.Broadcast(p, p, cnt, /*ncclFloat64*/ 8, x[i].src, m_comm, m_stream);
+            } else if (x[i].src != x[i].dst) {
+                if (m_comm_rank == x[i].src) rc = r.Send(p, cnt, 8, x[i].dst, m_comm, m_stream);
+                else if (m_comm_rank == x[i].dst) rc = r.Recv(p, cnt, 8, x[i].src, m_comm, m_stream);
+            }
+        }
+        const int rc_end = r.GroupEnd();
+        r.check(rc, "ncclSend / ncclRecv / ncclBroadcast");
+        r.check(rc_end, "ncclGroupEnd");
+    }
     // Work vectors come and go every continuation step (Pade basis, range checks); hipMalloc / hipFree
     // cost tens of microseconds each and hipFree synchronises the device, so freed blocks of up to
     // kPoolBlockMax bytes are kept and handed out again by exact size.  Everything runs on one stream, so a
@@ -2400,7 +2440,12 @@ public:
                           bool epilogue) {
         using namespace mfk;
         if (prologue) {
-        HIP_CHECK(hipMemsetAsync(mf.front_store, 0, mf.front_store_size * sizeof(double), m_stream));
+        if (sch.dist.enabled) {  // (only the fronts this rank factors: MfSchedule::Dist::own_store)
+            for (const auto& r : sch.dist.own_store)
+                HIP_CHECK(hipMemsetAsync(mf.front_store + r.first, 0, (size_t)(r.second - r.first) * sizeof(double), m_stream));
+        } else {
+            HIP_CHECK(hipMemsetAsync(mf.front_store, 0, mf.front_store_size * sizeof(double), m_stream));
+        }
         HIP_CHECK(hipMemsetAsync(mf.status, 0, sizeof(int32_t), m_stream));
         SANM_LAUNCH(absmax_kernel, dim3(red_grid(mf.nnzA)), dim3(256), 0, m_stream, (size_t)mf.nnzA, A.val,
                            red_to(mf.piv_amax));

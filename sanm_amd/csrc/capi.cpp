@@ -241,21 +241,41 @@ int sanm_direct_solver_create(int64_t n, const uint32_t* rowptr, const uint32_t*
         *out = s.release();
     });
 }
-int sanm_direct_solver_dist_plan(const sanm_direct_solver* s, int world_cap, double* rank_flops, double* out8) {
+int sanm_direct_solver_dist_plan(const sanm_direct_solver* s, int64_t cap, double* out, int64_t* n_out) {
     return guard([&] {
         const auto& D = s->mf->schedule().dist;
-        sanm_check(rank_flops && out8, "null output");
-        // rank_flops: 2 * world_cap doubles -- flops, then factor entries, of each rank's subtrees
-        for (int r = 0; r < world_cap; ++r) rank_flops[r] = r < (int)D.rank_flops.size() ? D.rank_flops[r] : 0.0;
-        for (int r = 0; r < world_cap; ++r) rank_flops[world_cap + r] = r < (int)D.rank_nnz.size() ? D.rank_nnz[r] : 0.0;
-        out8[0] = D.enabled ? D.world : 1;
-        out8[1] = s->mf->factor_flops;
-        out8[2] = D.flops_top;
-        out8[3] = D.nr_subtree;
-        out8[4] = (double)D.schur_doubles;
-        out8[5] = (double)D.inbox_doubles;
-        out8[6] = D.nnz_top;
-        out8[7] = (double)s->mf->nnz_factors;
+        sanm_check(out && n_out, "null output");
+        const int G = D.enabled ? D.world : 1, S = D.enabled ? D.nr_stage : 1;
+        std::vector<double> v{(double)G, (double)S, s->mf->factor_flops, D.flops_top, (double)D.nr_subtree,
+                              (double)D.schur_doubles, (double)D.inbox_doubles, D.nnz_top, (double)s->mf->nnz_factors,
+                              D.flops_critical, D.imbalance, 0.0};
+        if (D.enabled) {
+            v.insert(v.end(), D.stage_flops.begin(), D.stage_flops.end());
+            v.insert(v.end(), D.stage_nnz.begin(), D.stage_nnz.end());
+            for (int st = 0; st < S; ++st) {
+                std::vector<double> recv(G, 0.0);
+                for (const auto& x : D.schur[st].xfers) recv[x.dst] += (double)x.cnt;
+                v.push_back((double)D.schur[st].doubles);
+                v.push_back(*std::max_element(recv.begin(), recv.end()));
+            }
+            // the transfers themselves: {stage, src, dst, doubles, src_stage} each, behind their count
+            size_t nx = 0;
+            for (int st = 0; st < S; ++st) nx += D.schur[st].xfers.size();
+            v.push_back((double)nx);
+            for (int st = 0; st < S; ++st)
+                for (const auto& x : D.schur[st].xfers) {
+                    const double e[5] = {(double)st, (double)x.src, (double)x.dst, (double)x.cnt, (double)x.src_stage};
+                    v.insert(v.end(), e, e + 5);
+                }
+        } else {
+            v.push_back(s->mf->factor_flops);
+            v.push_back((double)s->mf->nnz_factors);
+            v.push_back(0.0);
+            v.push_back(0.0);
+            v.push_back(0.0);
+        }
+        *n_out = (int64_t)v.size();
+        for (int64_t i = 0; i < (int64_t)v.size() && i < cap; ++i) out[i] = v[i];
     });
 }
 void sanm_direct_solver_destroy(sanm_direct_solver* s) {
@@ -741,6 +761,9 @@ int sanm_anm_get_stats(const sanm_anm_solver* s, sanm_anm_stats* st) {
         st->nr_subtree_own = d.linear_solver().nr_subtree_own;
         st->dist_schur_doubles = d.linear_solver().dist_schur_doubles;
         st->dist_inbox_doubles = d.linear_solver().dist_inbox_doubles;
+        st->factor_flops_top_own = d.linear_solver().factor_flops_top_own;
+        st->factor_flops_critical = d.linear_solver().factor_flops_critical;
+        st->nr_dist_stage = d.linear_solver().nr_dist_stage;
     });
 }
 int sanm_anm_debug_inject(sanm_anm_solver* s, int kind, int order, int64_t index, double value, int scale) {

@@ -117,33 +117,61 @@ struct MfSchedule {
     };
     std::vector<Level> levels;
     const int32_t* ea_children = nullptr;  // device
-    // Subtree-to-rank distribution (stage 1 of DESIGN.md section 7; multifrontal.cpp).  The elimination tree is cut
-    // into subtrees, each owned by one rank; the fronts above the cut (`top`) are replicated.  This rank's level list
-    // holds its own subtrees' fronts first -- levels [0, cut) -- then the top fronts -- levels [cut, size) --, and
-    // three exchanges (sums over ranks in which every entry has exactly one non-zero contributor, i.e. gathers) tie
-    // the ranks together:
-    //   factor, between the two parts: the Schur complements F[B,B] of all cut roots (packed into `stage`);
-    //   forward solve, between the two parts: the cut roots' update rows in their parents' inboxes;
-    //   backward solve, at the end: the solution entries of the subtrees' pivots (the permuted vector `work`, the
-    //   ranges this rank does not speak for zeroed first).
+    // Tree-to-ranks distribution (multifrontal.cpp).  EVERY front has one owner.  The elimination
+    // tree is mapped from the root down onto sets of ranks (proportional mapping: a node with the rank set R gives its
+    // children disjoint slices of R in proportion to their subtree work); a subtree whose set is one rank belongs to it
+    // entirely -- stage 0 --, the fronts above -- the top -- belong to the first rank of their set, so a separator
+    // and the heaviest of its children share their owner and sibling separators are factored beside each other by
+    // different ranks.  Top fronts are grouped in stages: stage(f) = max over children c of stage(c) + (owner(c) !=
+    // owner(f)), at least 1; fronts of one stage on a path of the tree share their owner, so all communication sits
+    // BETWEEN stages.  A rank's level list holds its own fronts only, stage after stage (stage_level[s] .. stage_level[s
+    // + 1]), heights ascending inside a stage.  The exchanges (each entry of every buffer has exactly one writer, so the
+    // factors and solutions are the single-rank solver's bit for bit):
+    //   factor, before stage s >= 1:   the Schur complements F[B,B] of the children (of stage-s fronts) that another
+    //                                  rank owns: owner(child) -> owner(parent);
+    //   forward sweep, before stage s: those children's update rows in their parents' inboxes, the same way;
+    //   backward sweep, after stage s: the solution entries of the stage's pivots, owner -> everyone (the levels below
+    //                                  read their boundary values there);
+    //   backward sweep, at the end:    the pivots of the subtrees (stage 0), owner -> everyone.
+    // With a communicator that offers point-to-point transfers the first two are grouped send / receive pairs and the
+    // last two grouped broadcasts in place; through the all-reduce callback of the C ABI each is a sum over a zeroed
+    // staging buffer.
+    struct Xfer {
+        int32_t src, dst;   // ranks; dst = -1: to every rank
+        int64_t off, cnt;   // doubles: [off, off + cnt) of the staging buffer (Schur, inbox) or of `work` (solution)
+        int32_t src_stage;  // the stage in which src produces it (the plan's dependency model; not read by the transfer)
+    };
+    struct Exchange {
+        std::vector<Xfer> xfers;               // the same list on every rank
+        int64_t doubles = 0;                   // staging doubles (sum of cnt)
+        const MfCopy2D* pack = nullptr;        // device; what this rank sends: its source -> stage
+        const MfCopy2D* unpack = nullptr;      // device; what this rank receives: stage -> its destination
+        int32_t n_pack = 0, n_unpack = 0, max_rows = 0, max_cols = 0;
+    };
     struct Dist {
         bool enabled = false;
         int32_t rank = 0, world = 1;
-        int32_t cut = 0;
-        int64_t schur_doubles = 0, inbox_doubles = 0;
-        const MfCopy2D* schur_pack = nullptr;    // device; own cut roots: front_store -> stage
-        const MfCopy2D* schur_unpack = nullptr;  // the other ranks' cut roots: stage -> front_store
-        int32_t n_schur_pack = 0, n_schur_unpack = 0, schur_max_b = 0;
-        const MfCopy2D* inbox_pack = nullptr;    // inbox_store -> stage, one row per cut root
-        const MfCopy2D* inbox_unpack = nullptr;
-        int32_t n_inbox_pack = 0, n_inbox_unpack = 0, inbox_max_m = 0;
-        std::vector<std::pair<int32_t, int32_t>> zero_ranges;  // [begin, end) of `work` before the last exchange
-        double* stage = nullptr;                               // device: max(schur_doubles, inbox_doubles)
-        // what this rank factors: its subtrees and the replicated top (flops as Multifrontal::factor_flops counts them)
-        double flops_own = 0, flops_top = 0;
+        int32_t nr_stage = 1;                    // stages 0 .. nr_stage - 1
+        std::vector<int32_t> stage_level;        // nr_stage + 1 entries into this rank's levels
+        std::vector<Exchange> schur, inbox, sol; // per stage (entry 0 of schur / inbox unused; sol[0] = the subtrees' pivots)
+        int64_t schur_doubles = 0, inbox_doubles = 0;  // totals over the stages (statistics)
+        int64_t stage_doubles = 0;
+        double* stage = nullptr;                 // device: the largest exchange
+        // ranges of front_store this rank's fronts occupy (the factorisation zeroes these only) and of `work` it does
+        // not speak for at the end of a solve (the callback form of the last exchange zeroes them first)
+        std::vector<std::pair<int64_t, int64_t>> own_store;
+        std::vector<std::pair<int32_t, int32_t>> zero_ranges;
+        // what this rank factors: its subtrees and its fronts of the top (flops as Multifrontal::factor_flops counts
+        // them); flops_top: the whole top; flops_critical: the factorisation's critical path in flops -- a rank runs its
+        // stages one after the other and a stage starts when the stages that produce its incoming Schur complements are
+        // done (stage_finish_time with flops as the clock)
+        double flops_own = 0, flops_top = 0, flops_top_own = 0, flops_critical = 0;
         double imbalance = 1;  // largest subtree load of a rank over the mean
-        std::vector<double> rank_flops;  // subtree flops per rank (the same table on every rank)
-        std::vector<double> rank_nnz;    // factor entries of each rank's subtrees; nnz_top: of the replicated top
+        std::vector<double> rank_flops;      // subtree flops per rank (the same table on every rank)
+        std::vector<double> rank_top_flops;  // top flops per rank
+        std::vector<double> rank_nnz;        // factor entries of each rank's fronts (subtrees and top)
+        std::vector<double> stage_flops;     // nr_stage x world: flops of rank r in stage s at [s * world + r]
+        std::vector<double> stage_nnz;       // the same for factor entries (the solve's bytes)
         double nnz_top = 0;
         int32_t nr_front_own = 0, nr_front_top = 0, nr_subtree = 0, nr_subtree_own = 0;
     } dist;

@@ -1136,108 +1136,148 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
             }
     }
 
-    // ---- subtree-to-rank distribution (MfSchedule::Dist) ---------------------------------------------------------
-    // The tree is cut from the root down: the subtree with the most factor work is replaced by its children (its
-    // root joins the replicated top) until there are 4 subtrees per rank to balance with, or none can be split;
-    // the subtrees go to the ranks largest first, each to the rank with the least work so far.  owner[f] = rank of
-    // front f's subtree, -1 for the top.  One rank: everything is "top" and the schedule is the plain one.
-    std::vector<int32_t> f_owner(F, -1);
-    std::vector<int32_t> cut_roots;  // in front order (the same on every rank)
+    // ---- tree-to-ranks distribution (MfSchedule::Dist, mf_types.h) -----------------------------------------------
+    // Proportional mapping from the roots down: a node with the rank set R keeps R[0] as its owner and gives its
+    // children disjoint slices of R in proportion to the factor work of their subtrees (heaviest child first, so that it
+    // shares the node's owner and its Schur complement never travels); more children than ranks: each child to the rank
+    // of the set with the least work so far, largest first.  A subtree whose set is one rank is that rank's (stage 0);
+    // f_owner[f] = owner of every front, f_stage[f] >= 1 for the fronts above (the top).  One rank: no distribution.
+    std::vector<int32_t> f_owner(F, -1), f_stage(F, 0);
+    std::vector<int32_t> cut_roots;  // roots of the stage-0 subtrees, in front order (the same on every rank)
     auto& D = m_sched.dist;
     D.rank = rank;
     D.world = world;
-    // When it pays: the exchanges add two collectives to every solve, so small systems (a BASELINE-size mesh
-    // factors 6 GFLOP in 1.9 ms of launch latency) stay replicated; SANM_DIST_SOLVER=1 / 0 forces it on / off, the
-    // default takes it from 50 GFLOP per factorisation (block:24 and larger).
+    // When it pays: the exchanges add collectives to every solve, so small systems (a BASELINE-size mesh factors
+    // 6 GFLOP in 1.9 ms of launch latency) stay replicated; SANM_DIST_SOLVER=1 / 0 forces it on / off, the default
+    // takes it from 50 GFLOP per factorisation (block:24 and larger).
     const char* env_dist = std::getenv("SANM_DIST_SOLVER");
     const bool want_dist = world > 1 && (env_dist ? std::atoi(env_dist) != 0 : factor_flops >= 50e9);
     if (want_dist) {
         std::vector<double> sub_flops(front_flops);
         for (int32_t f = 0; f < F; ++f)
             if (parent[f] >= 0) sub_flops[parent[f]] += sub_flops[f];  // (postorder: children come first)
-        std::vector<int32_t> S;
+        // (a subtree lighter than a 64th of a rank's share is never spread over several ranks: latency, not work)
+        const double min_split = factor_flops / (64.0 * world);
+        struct Task {
+            int32_t f;                  // -1: the virtual root above the tree's roots
+            std::vector<int32_t> ranks;
+        };
+        std::vector<int32_t> tree_roots;
         for (int32_t f = 0; f < F; ++f)
-            if (parent[f] < 0) S.push_back(f);
-        // greedy assignment, largest first, each to the rank with the least work so far
-        auto assign = [&](const std::vector<int32_t>& set, std::vector<int32_t>* root_owner) {
-            std::vector<int32_t> by_work(set);
-            std::stable_sort(by_work.begin(), by_work.end(), [&](int32_t a, int32_t b) { return sub_flops[a] > sub_flops[b]; });
-            std::vector<double> load(world, 0.0);
-            for (int32_t c : by_work) {
-                int r = 0;
-                for (int q = 1; q < world; ++q)
-                    if (load[q] < load[r]) r = q;
-                load[r] += sub_flops[c];
-                if (root_owner) (*root_owner)[c] = r;
+            if (parent[f] < 0) tree_roots.push_back(f);
+        std::vector<Task> stack;
+        {
+            Task t{-1, {}};
+            for (int r = 0; r < world; ++r) t.ranks.push_back(r);
+            stack.push_back(std::move(t));
+        }
+        std::vector<char> is_cut_root(F, 0);
+        while (!stack.empty()) {
+            Task t = std::move(stack.back());
+            stack.pop_back();
+            const std::vector<int32_t>& ch = t.f < 0 ? tree_roots : children[t.f];
+            if (t.f >= 0) {
+                f_owner[t.f] = t.ranks[0];
+                if (t.ranks.size() == 1 || ch.empty() || sub_flops[t.f] < min_split) {
+                    is_cut_root[t.f] = 1;  // the whole subtree is this rank's
+                    continue;
+                }
+                f_stage[t.f] = 1;  // (a top front; its stage is computed below)
             }
+            std::vector<int32_t> by_work(ch);
+            std::stable_sort(by_work.begin(), by_work.end(), [&](int32_t a, int32_t b) { return sub_flops[a] > sub_flops[b]; });
+            const int nr = (int)t.ranks.size(), nc = (int)by_work.size();
+            if (nc >= nr) {
+                // each child to one rank: largest first, to the rank with the least work so far
+                std::vector<double> load(nr, 0.0);
+                for (int32_t c : by_work) {
+                    int q = 0;
+                    for (int r = 1; r < nr; ++r)
+                        if (load[r] < load[q]) q = r;
+                    load[q] += sub_flops[c];
+                    stack.push_back(Task{c, {t.ranks[q]}});
+                }
+            } else {
+                // slices of the set in proportion to the work, at least one rank each (largest remainders first)
+                double W = 0;
+                for (int32_t c : by_work) W += sub_flops[c];
+                std::vector<int> cnt(nc, 1);
+                int left = nr - nc;
+                std::vector<double> want(nc);
+                for (int i = 0; i < nc; ++i) want[i] = W > 0 ? sub_flops[by_work[i]] / W * nr : 1.0;
+                while (left > 0) {
+                    int q = 0;
+                    for (int i = 1; i < nc; ++i)
+                        if (want[i] - cnt[i] > want[q] - cnt[q]) q = i;
+                    ++cnt[q];
+                    --left;
+                }
+                int at = 0;
+                for (int i = 0; i < nc; ++i) {
+                    Task u{by_work[i], {}};
+                    u.ranks.assign(t.ranks.begin() + at, t.ranks.begin() + at + cnt[i]);
+                    at += cnt[i];
+                    stack.push_back(std::move(u));
+                }
+            }
+        }
+        // fronts below a cut root inherit its owner (parents have larger ids: walk down from the top)
+        for (int32_t f = F - 1; f >= 0; --f)
+            if (f_owner[f] < 0) {
+                sanm_check(parent[f] >= 0 && f_owner[parent[f]] >= 0, "front %d has no owner", f);
+                f_owner[f] = f_owner[parent[f]];
+            }
+        for (int32_t f = 0; f < F; ++f)
+            if (is_cut_root[f]) cut_roots.push_back(f);
+        // stages of the top fronts (children first)
+        int32_t nr_stage = 1;
+        for (int32_t f = 0; f < F; ++f) {
+            if (f_stage[f] == 0) continue;
+            int32_t st = 1;
+            for (int32_t c : children[f]) st = std::max(st, f_stage[c] + (f_owner[c] != f_owner[f] ? 1 : 0));
+            f_stage[f] = st;
+            nr_stage = std::max(nr_stage, st + 1);
+        }
+        D.enabled = true;
+        D.nr_stage = nr_stage;
+        D.nr_subtree = (int32_t)cut_roots.size();
+        for (int32_t c : cut_roots) D.nr_subtree_own += f_owner[c] == rank;
+        D.rank_flops.assign(world, 0.0);
+        D.rank_top_flops.assign(world, 0.0);
+        D.rank_nnz.assign(world, 0.0);
+        D.stage_flops.assign((size_t)nr_stage * world, 0.0);
+        D.stage_nnz.assign((size_t)nr_stage * world, 0.0);
+        for (int32_t f = 0; f < F; ++f) {
+            const double fk = fr[f].k, fb = fr[f].m - fr[f].k, fnnz = fk * fk + 2 * fk * fb;
+            const int o = f_owner[f], st = f_stage[f];
+            D.rank_nnz[o] += fnnz;
+            D.stage_flops[(size_t)st * world + o] += front_flops[f];
+            D.stage_nnz[(size_t)st * world + o] += fnnz;
+            if (st > 0) {
+                D.nnz_top += fnnz;
+                D.flops_top += front_flops[f];
+                D.rank_top_flops[o] += front_flops[f];
+                ++D.nr_front_top;
+                if (o == rank) D.flops_top_own += front_flops[f];
+            } else {
+                D.rank_flops[o] += front_flops[f];
+                if (o == rank) {
+                    D.flops_own += front_flops[f];
+                    ++D.nr_front_own;
+                }
+            }
+        }
+        {
             double mx = 0, sum = 0;
-            for (double l : load) {
+            for (double l : D.rank_flops) {
                 mx = std::max(mx, l);
                 sum += l;
             }
-            if (root_owner) m_sched.dist.rank_flops = load;
-            return sum > 0 ? mx * world / sum : 1.0;  // imbalance: largest load over the mean
-        };
-        // Every split moves a front into the replicated top and (usually) evens out the ranks' loads.  What a rank
-        // has to factor is the top plus its own subtrees, so the cut is the one -- among those the splitting sequence
-        // passes through, largest subtree first, up to 4 subtrees per rank -- with the smallest
-        // top + largest rank load.
-        auto makespan = [&](const std::vector<int32_t>& set) {
-            double below = 0;
-            for (int32_t c : set) below += sub_flops[c];
-            const double imb = assign(set, nullptr);
-            return (factor_flops - below) + imb * below / world;
-        };
-        std::vector<int32_t> best_S = S;
-        double best_cost = makespan(S);
-        for (;;) {
-            if (S.size() >= (size_t)world * 4) break;
-            int best = -1;
-            for (size_t i = 0; i < S.size(); ++i)
-                if (!children[S[i]].empty() && (best < 0 || sub_flops[S[i]] > sub_flops[S[best]])) best = (int)i;
-            if (best < 0) break;
-            // (never split a subtree that is already lighter than a 64th of a rank's share: latency, not work)
-            if (sub_flops[S[best]] * 64 * world < factor_flops) break;
-            const int32_t s0 = S[best];
-            S.erase(S.begin() + best);
-            S.insert(S.end(), children[s0].begin(), children[s0].end());
-            const double c = makespan(S);
-            if (c < best_cost) {
-                best_cost = c;
-                best_S = S;
-            }
-        }
-        S = best_S;
-        std::sort(S.begin(), S.end());
-        cut_roots = S;
-        std::vector<int32_t> root_owner(F, -1);
-        D.imbalance = assign(S, &root_owner);
-        // fronts inherit from the cut root above them (parents have larger ids: walk down from the top)
-        for (int32_t f = F - 1; f >= 0; --f) {
-            if (root_owner[f] >= 0) f_owner[f] = root_owner[f];
-            else if (parent[f] >= 0 && f_owner[parent[f]] >= 0) f_owner[f] = f_owner[parent[f]];
-        }
-        // (a tree root that could not be split is a subtree of its own: then there is no top at all)
-        D.enabled = true;
-        D.nr_subtree = (int32_t)cut_roots.size();
-        for (int32_t c : cut_roots) D.nr_subtree_own += f_owner[c] == rank;
-        D.rank_nnz.assign(world, 0.0);
-        for (int32_t f = 0; f < F; ++f) {
-            const double fk = fr[f].k, fb = fr[f].m - fr[f].k, fnnz = fk * fk + 2 * fk * fb;
-            if (f_owner[f] < 0) D.nnz_top += fnnz;
-            else D.rank_nnz[f_owner[f]] += fnnz;
-        }
-        for (int32_t f = 0; f < F; ++f) {
-            if (f_owner[f] < 0) {
-                D.flops_top += front_flops[f];
-                ++D.nr_front_top;
-            } else if (f_owner[f] == rank) {
-                D.flops_own += front_flops[f];
-                ++D.nr_front_own;
-            }
+            D.imbalance = sum > 0 ? mx * world / sum : 1.0;
         }
     } else {
         D.flops_top = factor_flops;
+        D.flops_critical = factor_flops;
         D.nr_front_top = F;
     }
 
@@ -1309,22 +1349,22 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     }
 
     lap("scatter map of A");
-    // levels: fronts by height, by decreasing k inside a level.  Distributed: this rank's own subtrees first (part 0),
-    // then the replicated top (part 1); fronts of other ranks' subtrees are in no level of this schedule.
+    // levels: fronts by height, by decreasing k inside a level.  Distributed: this rank's own fronts only, stage after
+    // stage (MfSchedule::Dist); fronts of other ranks are in no level of this schedule.
     int32_t H = 0;
     for (int32_t f = 0; f < F; ++f) H = std::max(H, height[f] + 1);
     std::vector<int32_t> level_fronts;
     std::vector<int32_t> ea_children;
     int64_t tmp_doubles = 1;
     std::vector<std::vector<int32_t>> level_lists;
-    for (int part = 0; part < 2; ++part) {
-        if (part == 1) D.cut = (int32_t)level_lists.size();
-        for (int32_t h = 0; h < H; ++h) {
-            std::vector<int32_t> fs;
-            for (int32_t f = 0; f < F; ++f)
-                if (height[f] == h && (part == 0 ? (f_owner[f] >= 0 && f_owner[f] == rank) : f_owner[f] < 0)) fs.push_back(f);
+    D.stage_level.assign(1, 0);
+    for (int32_t st = 0; st < D.nr_stage; ++st) {
+        std::vector<std::vector<int32_t>> by_h(H);
+        for (int32_t f = 0; f < F; ++f)
+            if (!D.enabled || (f_owner[f] == rank && f_stage[f] == st)) by_h[height[f]].push_back(f);
+        for (auto& fs : by_h)
             if (!fs.empty()) level_lists.push_back(std::move(fs));
-        }
+        D.stage_level.push_back((int32_t)level_lists.size());
     }
     H = (int32_t)level_lists.size();
     nr_level = H;
@@ -1499,51 +1539,118 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     lap("device tables");
     // ---- exchange tables of the distributed schedule (MfSchedule::Dist) -----------------------------------------
     if (D.enabled) {
-        std::vector<MfCopy2D> sp, su, ip, iu;
-        int64_t so = 0, io = 0;
-        for (int32_t c : cut_roots) {
-            const int32_t b = fr[c].m - fr[c].k, p = parent[c];
-            if (p < 0 || b == 0) continue;  // (a tree root that is a subtree of its own has nobody above it)
-            const bool mine = f_owner[c] == rank;
+        const int32_t S = D.nr_stage;
+        D.schur.resize(S);
+        D.inbox.resize(S);
+        D.sol.resize(S);
+        std::vector<std::vector<MfCopy2D>> sp(S), su(S), ip(S), iu(S), lp(S), lu(S);
+        // edges of the tree whose ends have different owners, by the parent's stage
+        for (int32_t c = 0; c < F; ++c) {
+            const int32_t p = parent[c];
+            if (p < 0 || f_owner[p] == f_owner[c]) continue;
+            const int32_t st = f_stage[p], b = fr[c].m - fr[c].k;
+            sanm_check(st >= 1 && f_stage[c] < st, "distributed schedule: edge %d -> %d does not cross a stage", c, p);
+            if (b == 0) continue;
+            const int src = f_owner[c], dst = f_owner[p];
+            auto& E = D.schur[st];
             const int64_t blk = fr[c].off + (int64_t)2 * fr[c].k * fr[c].ld + 2 * fr[c].k;  // F[B,B]
-            if (mine) sp.push_back({blk, so, b, b, fr[c].ld, b});
-            else su.push_back({so, blk, b, b, b, fr[c].ld});
-            so += (int64_t)b * b;
-            D.schur_max_b = std::max(D.schur_max_b, b);
-            // the cut root's slot row in its parent's inbox
+            E.xfers.push_back({src, dst, E.doubles, (int64_t)b * b, f_stage[c]});
+            if (rank == src) sp[st].push_back({blk, E.doubles, b, b, fr[c].ld, b});
+            if (rank == dst) su[st].push_back({E.doubles, blk, b, b, b, fr[c].ld});
+            E.doubles += (int64_t)b * b;
+            E.max_rows = E.max_cols = std::max(E.max_rows, b);
+            // the child's slot row in its parent's inbox
             const auto& ch = children[p];
             const int32_t j = (int32_t)(std::find(ch.begin(), ch.end(), c) - ch.begin());
             const int64_t row = fr[p].inbox_off + (int64_t)j * fr[p].m;
-            if (mine) ip.push_back({row, io, 1, fr[p].m, fr[p].m, fr[p].m});
-            else iu.push_back({io, row, 1, fr[p].m, fr[p].m, fr[p].m});
-            io += fr[p].m;
-            D.inbox_max_m = std::max(D.inbox_max_m, fr[p].m);
+            auto& I = D.inbox[st];
+            I.xfers.push_back({src, dst, I.doubles, fr[p].m, f_stage[c]});
+            if (rank == src) ip[st].push_back({row, I.doubles, 1, fr[p].m, fr[p].m, fr[p].m});
+            if (rank == dst) iu[st].push_back({I.doubles, row, 1, fr[p].m, fr[p].m, fr[p].m});
+            I.doubles += fr[p].m;
+            I.max_rows = 1;
+            I.max_cols = std::max(I.max_cols, fr[p].m);
         }
-        D.schur_doubles = so;
-        D.inbox_doubles = io;
-        D.n_schur_pack = sp.size();
-        D.n_schur_unpack = su.size();
-        D.n_inbox_pack = ip.size();
-        D.n_inbox_unpack = iu.size();
-        upload_to(D.schur_pack, std::move(sp));
-        upload_to(D.schur_unpack, std::move(su));
-        upload_to(D.inbox_pack, std::move(ip));
-        upload_to(D.inbox_unpack, std::move(iu));
-        alloc_to(D.stage, std::max<int64_t>(std::max(so, io), 1) * sizeof(double), false);
-        // entries of the permuted solution this rank must not contribute to the last exchange: the pivots of the
-        // other ranks' subtrees, and -- except on rank 0 -- the replicated top's
+        // solution entries: the pivots of every stage's fronts, owner -> everyone; runs of fronts with one owner are
+        // one range of the permuted vector (front order = order of the unknowns)
         for (int32_t f = 0; f < F; ++f) {
-            const bool speak = f_owner[f] >= 0 ? f_owner[f] == rank : rank == 0;
-            if (speak) continue;
+            auto& X = D.sol[f_stage[f]].xfers;
+            const int64_t b0 = fr[f].own_start, k = fr[f].k;
+            if (!X.empty() && X.back().src == f_owner[f] && X.back().off + X.back().cnt == b0) X.back().cnt += k;
+            else X.push_back({f_owner[f], -1, b0, k, f_stage[f]});
+        }
+        for (int32_t st = 0; st < S; ++st) {
+            // (through the all-reduce callback the ranges of the top stages travel packed; stage 0's -- most of the
+            // vector -- are summed in place, the ranges of others zeroed first: zero_ranges)
+            auto& X = D.sol[st];
+            for (const auto& x : X.xfers) {
+                if (st > 0) {
+                    if (rank == x.src) lp[st].push_back({x.off, X.doubles, 1, (int32_t)x.cnt, (int32_t)x.cnt, (int32_t)x.cnt});
+                    else lu[st].push_back({X.doubles, x.off, 1, (int32_t)x.cnt, (int32_t)x.cnt, (int32_t)x.cnt});
+                    X.max_rows = 1;
+                    X.max_cols = std::max<int32_t>(X.max_cols, (int32_t)x.cnt);
+                }
+                X.doubles += x.cnt;
+            }
+        }
+        int64_t stage_doubles = 1;
+        for (int32_t st = 0; st < S; ++st) {
+            auto fin = [&](MfSchedule::Exchange& E, std::vector<MfCopy2D>& pk, std::vector<MfCopy2D>& up, bool staged) {
+                E.n_pack = (int32_t)pk.size();
+                E.n_unpack = (int32_t)up.size();
+                upload_to(E.pack, std::move(pk));
+                upload_to(E.unpack, std::move(up));
+                if (staged) stage_doubles = std::max(stage_doubles, E.doubles);
+            };
+            fin(D.schur[st], sp[st], su[st], true);
+            fin(D.inbox[st], ip[st], iu[st], true);
+            fin(D.sol[st], lp[st], lu[st], st > 0);
+            D.schur_doubles += D.schur[st].doubles;
+            D.inbox_doubles += D.inbox[st].doubles;
+        }
+        D.stage_doubles = stage_doubles;
+        alloc_to(D.stage, stage_doubles * sizeof(double), false);
+        {
+            // critical path in flops: end(r, s) = max(end(r, s - 1), end of the stages that send to (r, s)) + flops(r, s)
+            std::vector<double> end((size_t)S * world, 0.0);
+            for (int32_t st = 0; st < S; ++st)
+                for (int r = 0; r < world; ++r) {
+                    double t0 = st > 0 ? end[(size_t)(st - 1) * world + r] : 0.0;
+                    for (const auto& x : D.schur[st].xfers)
+                        if (x.dst == r) t0 = std::max(t0, end[(size_t)x.src_stage * world + x.src]);
+                    end[(size_t)st * world + r] = t0 + D.stage_flops[(size_t)st * world + r];
+                    D.flops_critical = std::max(D.flops_critical, end[(size_t)st * world + r]);
+                }
+        }
+        // entries of the permuted solution this rank does not speak for in the last exchange (callback form: a sum in
+        // place over the whole vector): the pivots of every front it does not own
+        for (int32_t f = 0; f < F; ++f) {
+            if (f_owner[f] == rank) continue;
             const int32_t b0 = fr[f].own_start, e0 = b0 + fr[f].k;
             if (!D.zero_ranges.empty() && D.zero_ranges.back().second == b0) D.zero_ranges.back().second = e0;
             else D.zero_ranges.emplace_back(b0, e0);
         }
-        if (std::getenv("SANM_MF_DEBUG"))
-            std::fprintf(stderr, "mf dist: rank %d of %d: %d subtrees (%d own), fronts own %d top %d, GF own %.2f top %.2f of "
-                         "%.2f, levels %d (cut at %d), schur exchange %.2f MB, inbox %.1f KB, %zu zero ranges\n", rank,
-                         world, D.nr_subtree, D.nr_subtree_own, D.nr_front_own, D.nr_front_top, D.flops_own / 1e9,
-                         D.flops_top / 1e9, factor_flops / 1e9, H, D.cut, so * 8 / 1e6, io * 8 / 1e3, D.zero_ranges.size());
+        // the part of the front storage this rank factors in (and the children of its top fronts, whose Schur
+        // complements arrive whole): what the factorisation's prologue zeroes
+        for (int32_t f = 0; f < F; ++f) {
+            if (f_owner[f] != rank) continue;
+            const int64_t b0 = fr[f].off, e0 = b0 + (int64_t)fr[f].ld * fr[f].ld;
+            if (!D.own_store.empty() && D.own_store.back().second == b0) D.own_store.back().second = e0;
+            else D.own_store.emplace_back(b0, e0);
+        }
+        if (std::getenv("SANM_MF_DEBUG")) {
+            std::fprintf(stderr, "mf dist: rank %d of %d: %d subtrees (%d own), %d stages, fronts own %d top %d, GF own %.2f "
+                         "top %.2f (own %.2f) of %.2f, critical path %.2f GF, levels %d, schur exchange %.2f MB, inbox %.1f KB, "
+                         "%zu zero ranges, %zu own store ranges\n", rank, world, D.nr_subtree, D.nr_subtree_own, S,
+                         D.nr_front_own, D.nr_front_top, D.flops_own / 1e9, D.flops_top / 1e9, D.flops_top_own / 1e9,
+                         factor_flops / 1e9, D.flops_critical / 1e9, H, D.schur_doubles * 8 / 1e6, D.inbox_doubles * 8 / 1e3,
+                         D.zero_ranges.size(), D.own_store.size());
+            for (int32_t st = 0; st < S; ++st) {
+                std::fprintf(stderr, "mf dist:   stage %d: levels [%d, %d), GF per rank", st, D.stage_level[st], D.stage_level[st + 1]);
+                for (int r = 0; r < world; ++r) std::fprintf(stderr, " %.1f", D.stage_flops[(size_t)st * world + r] / 1e9);
+                std::fprintf(stderr, "; schur %.1f MB in %zu transfers\n", D.schur[st].doubles * 8 / 1e6, D.schur[st].xfers.size());
+            }
+        }
     }
 
     // ---- merged top block (mf_types.h, MfSchedule::Top): the root and the level below it ----------------------

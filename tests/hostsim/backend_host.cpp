@@ -369,7 +369,15 @@ struct HostMf {
     }
     static void factor_piece(const MfDev& mf, const MfSchedule& sch, const CsrDev& A, int l0, int l1, bool prologue) {
         if (prologue) {
-            std::memset(mf.front_store, 0, mf.front_store_size * sizeof(double));
+            if (sch.dist.enabled) {
+                // only the fronts this rank factors are zeroed (MfSchedule::Dist::own_store); the harness POISONS the
+                // rest, so that a read of another rank's front that no exchange delivered shows up as NaN
+                for (int64_t q = 0; q < mf.front_store_size; ++q) mf.front_store[q] = std::nan("");
+                for (const auto& r : sch.dist.own_store)
+                    std::memset(mf.front_store + r.first, 0, (size_t)(r.second - r.first) * sizeof(double));
+            } else {
+                std::memset(mf.front_store, 0, mf.front_store_size * sizeof(double));
+            }
             for (int64_t p = 0; p < mf.nnzA; ++p) mf.front_store[mf.a_dst[p]] += A.val[p];
             double amax = 0;
             for (int64_t p = 0; p < mf.nnzA; ++p) amax = std::fmax(amax, std::fabs(A.val[p]));

@@ -170,7 +170,7 @@ dist.destroy_process_group()
 """
 
 
-def _two_ranks_on_one_gpu(name, env_extra):
+def _two_ranks_on_one_gpu(name, env_extra, world=2):
     import json
     import subprocess
     import sys
@@ -182,8 +182,8 @@ def _two_ranks_on_one_gpu(name, env_extra):
     port = s.getsockname()[1]
     s.close()
     procs = []
-    for rank in range(2):
-        env = dict(base_env, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+    for rank in range(world):
+        env = dict(base_env, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, "-c", WORKER_2ON1.format(root=root, name=name)],
                                       env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
@@ -200,23 +200,45 @@ def _two_ranks_on_one_gpu(name, env_extra):
     return sorted(res, key=lambda r: r["rank"])
 
 
-def test_subtree_distributed_solver_on_the_device_two_ranks_on_one_gpu():
-    """Stage 1 of the distributed direct solver (multifrontal.cpp, MfSchedule::Dist) on the HIP backend: two ranks
-    share cuda:0 (staged gloo all-reduce), SANM_DIST_SOLVER=1 forces the subtree distribution on the BASELINE-size
-    mesh of config 4.  Each rank factors its own subtrees and the replicated top; the Schur complements of the cut,
-    the inbox rows and the solution entries are exchanged (copy2d_kernel, mf_factor_piece / mf_solve_piece).  Every
-    exchange is a gather, so the result must be the oracle's equilibrium in the oracle's 2 steps, identical on both
-    ranks, and the flops of the two ranks' subtrees must add up to the whole minus the top."""
-    res = _two_ranks_on_one_gpu("armadillo_small", {"SANM_DIST_SOLVER": "1"})
-    print([(r["rank"], r["steps"], r["err"], r["st"]["factor_flops_own"], r["st"]["factor_flops_top"]) for r in res])
+def _check_tree_distribution(res):
     for r in res:
         assert r["steps"] == r["gold_steps"] == 2 and r["err"] < 1e-9 and r["rms"] < 1e-10
-        assert r["st"]["nr_subtree"] >= 2 and r["st"]["nr_subtree_own"] >= 1
-    assert res[0]["vsum"] == res[1]["vsum"]
+        assert r["st"]["nr_subtree"] >= len(res) and r["st"]["nr_subtree_own"] >= 1  # every rank owns a subtree
+    assert len({r["vsum"] for r in res}) == 1
     total, top = res[0]["st"]["factor_flops"], res[0]["st"]["factor_flops_top"]
     own = [r["st"]["factor_flops_own"] for r in res]
-    assert abs(sum(own) + top - total) <= 1e-9 * total
-    assert max(own) <= 0.65 * (total - top)
+    top_own = [r["st"]["factor_flops_top_own"] for r in res]
+    # every front has one owner: subtrees and top fronts partition the work
+    assert abs(sum(own) + top - total) <= 1e-9 * total and abs(sum(top_own) - top) <= 1e-9 * total
+    crit = res[0]["st"]["factor_flops_critical"]
+    assert max(o + t for o, t in zip(own, top_own)) <= crit * (1 + 1e-9) and crit < total
+    return own, top_own, total, crit
+
+
+def test_subtree_distributed_solver_on_the_device_two_ranks_on_one_gpu():
+    """The distributed direct solver (multifrontal.cpp, MfSchedule::Dist: every front of the elimination tree one owner,
+    stages with exchanges between them) on the HIP backend: two ranks share cuda:0 (staged gloo all-reduce),
+    SANM_DIST_SOLVER=1 forces the distribution on the BASELINE-size mesh of config 4.  Each rank zeroes, factors and
+    solves its own fronts only; Schur complements, inbox rows and solution entries are exchanged (copy2d_kernel,
+    mf_factor_piece / mf_solve_piece).  Every entry of every exchange has one writer, so the result must be the oracle's
+    equilibrium in the oracle's 2 steps, identical on both ranks."""
+    res = _two_ranks_on_one_gpu("armadillo_small", {"SANM_DIST_SOLVER": "1"})
+    own, top_own, total, crit = _check_tree_distribution(res)
+    print([(r["rank"], r["steps"], r["err"]) for r in res], "own", own, "top own", top_own, "total", total, "critical", crit)
+    assert res[0]["st"]["nr_dist_stage"] == 2
+    assert max(own) <= 0.65 * sum(own)
+
+
+def test_tree_distributed_solver_three_stages_four_ranks_on_one_gpu():
+    """the same over FOUR ranks sharing cuda:0: the top of the tree is mapped onto rank sets -- the
+    root to rank 0, the two separators below it to ranks 0 and 2, beside each other --, three stages, exchanges before
+    the second and the third; every rank owns a subtree; equilibrium, step count and bits as above."""
+    res = _two_ranks_on_one_gpu("armadillo_small", {"SANM_DIST_SOLVER": "1"}, world=4)
+    own, top_own, total, crit = _check_tree_distribution(res)
+    print("4 ranks: own", own, "top own", top_own, "total", total, "critical", crit)
+    assert res[0]["st"]["nr_dist_stage"] >= 3
+    assert sum(t > 0 for t in top_own) >= 2  # sibling separators with different owners
+    assert crit <= 0.6 * total
 
 
 def test_subtree_distributed_solver_over_chains_and_two_phase_levels_on_the_device():
@@ -229,7 +251,8 @@ def test_subtree_distributed_solver_over_chains_and_two_phase_levels_on_the_devi
                                                      "SANM_MF_TWO_PHASE": "1", "SANM_MF_WIDE_MIN_M": "512"})
     for r in res:
         assert r["steps"] == r["gold_steps"] == 2 and r["err"] < 1e-9 and r["rms"] < 1e-10
-        assert r["st"]["nr_subtree"] >= 2 and r["st"]["nr_level"] > 8
+        assert r["st"]["nr_subtree"] >= 2
+    assert max(r["st"]["nr_level"] for r in res) > 8
     assert res[0]["vsum"] == res[1]["vsum"]
 
 

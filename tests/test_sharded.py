@@ -289,21 +289,27 @@ def _check_dist(res, world):
     total = res[0]["ref_st"]["factor_flops"]
     top = res[0]["st"]["factor_flops_top"]
     own = [r["st"]["factor_flops_own"] for r in res]
+    top_own = [r["st"]["factor_flops_top_own"] for r in res]
+    S = res[0]["st"]["nr_dist_stage"]
+    assert S >= 2
     for r in res:
         st = r["st"]
         assert st["nr_subtree"] >= world and st["factor_flops"] == total and st["factor_flops_top"] == top
-        # same continuation, same equilibrium: every exchange is a gather, so the factors are the single-rank ones
+        assert st["nr_dist_stage"] == S and st["nr_subtree_own"] >= 1  # every rank owns a subtree
+        # same continuation, same equilibrium: every entry of every exchange has one writer, so the factors are the
+        # single-rank ones
         assert r["steps"] == r["ref_steps"] and r["err"] < 1e-9 and r["rms"] < 1e-10
         assert r["vsum"] == res[0]["vsum"]
         # collectives: the tet-sharded driver's (f(x0), Jacobian values, b_k per order; f(x0) of the converged
-        # call) + per factorisation the Schur complements of the cut and the pivot status + per solve the inbox rows
-        # of the cut and the solution entries
+        # call) + per factorisation the Schur complements before every top stage and the pivot status + per solve the
+        # inbox rows before every top stage and the pivots after every stage
         steps, order, solves = r["steps"], 10, st["nr_linear_solve"]
-        assert r["ncall"] == steps * (1 + 1 + (order - 1)) + 1 + 2 * steps + 2 * solves
-    # the subtrees partition the work below the cut ...
-    assert abs(sum(own) + top - total) <= 1e-9 * total
-    # ... evenly enough that every rank factors clearly less than the whole (no 2-D LU of the top yet: the replicated
-    # top is what each rank still repeats)
+        assert r["ncall"] == steps * (1 + 1 + (order - 1)) + 1 + S * steps + (2 * S - 1) * solves
+    # every front has one owner: the subtrees and the top fronts partition the work ...
+    assert abs(sum(own) + top - total) <= 1e-9 * total and abs(sum(top_own) - top) <= 1e-9 * total
+    # ... and the critical path (sum over the stages of the busiest rank) is what a rank waits for
+    crit = res[0]["st"]["factor_flops_critical"]
+    assert max(o + t for o, t in zip(own, top_own)) <= crit * (1 + 1e-9) and crit < 0.8 * total
     sub = total - top
     assert sub > 0.3 * total
     for o in own:
@@ -312,11 +318,12 @@ def _check_dist(res, world):
 
 
 def test_subtree_distributed_factor_and_solve_two_ranks():
-    """Stage 1 of DESIGN.md section 7: the elimination tree cut into subtrees, each rank factors
-    and solves its own subtrees and the replicated top, the Schur complements of the cut / the inbox rows / the
-    solution entries exchanged.  Two ranks (gloo + host harness) on a 12 x 6 x 6 cantilever: the unsharded solve's
-    step count and vertices, the same result on both ranks bit for bit, flops per rank = top + about half of the
-    rest."""
+    """The direct solver distributed over the ranks: every front of the
+    elimination tree has one owner -- the subtrees below the cut and, mapped proportionally onto rank sets, the fronts
+    above it --, a rank factors and solves its own fronts stage by stage, Schur complements / inbox rows / solution
+    entries travel between the stages.  Two ranks (gloo + host harness, whose factorisation POISONS every front the
+    rank does not own) on a 12 x 6 x 6 cantilever: the unsharded solve's step count and vertices, the same result on
+    both ranks bit for bit, every rank with a subtree, flops per rank = its top fronts + about half of the rest."""
     res = _run_dist(2, (12, 6, 6))
     own, top, total = _check_dist(res, 2)
     print("2 ranks: own GF", [o / 1e9 for o in own], "top", top / 1e9, "total", total / 1e9)
@@ -329,7 +336,7 @@ def test_subtree_distributed_solver_over_chains_of_cut_fronts():
     solve's steps and vertices, both ranks bit for bit."""
     res = _run_dist(2, (12, 6, 6), env_extra={"SANM_MF_SPLIT_K": "48"})
     _check_dist(res, 2)
-    assert res[0]["st"]["nr_level"] > 6
+    assert res[0]["st"]["nr_level"] + res[1]["st"]["nr_level"] > 6
 
 
 def test_subtree_distributed_factor_and_solve_four_ranks_with_pade():
@@ -342,5 +349,45 @@ def test_subtree_distributed_factor_and_solve_four_ranks_with_pade():
     assert len({r["vsum"] for r in res}) == 1 and len({r["steps"] for r in res}) == 1
     top, total = res[0]["st"]["factor_flops_top"], res[0]["ref_st"]["factor_flops"]
     own = [r["st"]["factor_flops_own"] for r in res]
-    assert abs(sum(own) + top - total) <= 1e-9 * total
-    print("4 ranks: own GF", [o / 1e9 for o in own], "top", top / 1e9, "total", total / 1e9)
+    top_own = [r["st"]["factor_flops_top_own"] for r in res]
+    assert abs(sum(own) + top - total) <= 1e-9 * total and abs(sum(top_own) - top) <= 1e-9 * total
+    assert all(r["st"]["nr_subtree_own"] >= 1 for r in res) and res[0]["st"]["nr_dist_stage"] >= 3
+    print("4 ranks: own GF", [o / 1e9 for o in own], "top own", [t / 1e9 for t in top_own], "total", total / 1e9,
+          "critical", res[0]["st"]["factor_flops_critical"] / 1e9)
+
+
+def test_tree_mapping_gives_every_rank_a_subtree_at_world_8(monkeypatch):
+    """at world = 8 the old cut left four ranks without a subtree.  The proportional mapping of the
+    elimination tree onto rank sets (multifrontal.cpp) gives every rank one; the top fronts are mapped too (sibling
+    separators to different ranks), and the plan's tables are consistent: per stage and rank flops add up to the whole,
+    every Schur transfer crosses from an earlier stage into a later one between different ranks, and the critical path
+    (a rank runs its stages in order, a stage waits for what it receives) is less than half of the work."""
+    import numpy as np
+    import scipy.sparse as sp
+    from sanm_amd import api as A, fea as dfea
+    from tests.hostsim import get_hostsim_api
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from dist_plan import jacobian_pattern
+    api = get_hostsim_api()
+    mesh = dfea.make_cuboid(20, 10, 10, 0.025)
+    fixed = np.zeros((mesh.nr_vertices, 3), bool)
+    fixed[mesh.V[:, 0] < 0.01] = True
+    P, coords = jacobian_pattern(mesh, fixed)
+    monkeypatch.setenv("SANM_DIST_SOLVER", "1")
+    for world in (2, 3, 8):
+        monkeypatch.setenv("SANM_MF_PLAN_WORLD", str(world))
+        s = A.DirectSolver(api, P, coords)
+        plan = s.dist_plan()
+        del s
+        sf = np.array(plan["stage_flops"])
+        assert plan["world"] == world and sf.shape == (plan["nr_stage"], world)
+        assert np.all(sf[0] > 0), sf[0]  # every rank owns a subtree
+        assert abs(sf.sum() - plan["total_flops"]) <= 1e-9 * plan["total_flops"]
+        assert abs(sf[1:].sum() - plan["top_flops"]) <= 1e-9 * plan["total_flops"]
+        for x in plan["schur_transfers"]:
+            assert x["src"] != x["dst"] and x["src_stage"] < x["stage"] and x["doubles"] > 0
+        assert max(sf.sum(axis=0)) <= plan["critical_flops"] * (1 + 1e-9)
+        assert plan["critical_flops"] <= sf.max(axis=1).sum() * (1 + 1e-9)  # never worse than a barrier per stage
+        if world == 8:
+            assert plan["nr_stage"] >= 4 and plan["critical_flops"] < 0.5 * plan["total_flops"]
+            assert (sf[1:].sum(axis=0) > 0).sum() >= 4  # the top is spread over at least four owners
