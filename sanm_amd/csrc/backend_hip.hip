@@ -2440,11 +2440,23 @@ public:
                           bool epilogue) {
         using namespace mfk;
         if (prologue) {
-        if (sch.dist.enabled) {  // (only the fronts this rank factors: MfSchedule::Dist::own_store)
-            for (const auto& r : sch.dist.own_store)
-                HIP_CHECK(hipMemsetAsync(mf.front_store + r.first, 0, (size_t)(r.second - r.first) * sizeof(double), m_stream));
-        } else {
-            HIP_CHECK(hipMemsetAsync(mf.front_store, 0, mf.front_store_size * sizeof(double), m_stream));
+        // (read per factorisation: tests switch it) SANM_MF_FULL_ZERO=1: the whole storage of the rank's fronts, as
+        // rounds 1-5 did
+        if (std::getenv("SANM_MF_FULL_ZERO")) {
+            if (sch.dist.enabled) {  // (only the fronts this rank factors: MfSchedule::Dist::own_store)
+                for (const auto& r : sch.dist.own_store)
+                    HIP_CHECK(hipMemsetAsync(mf.front_store + r.first, 0, (size_t)(r.second - r.first) * sizeof(double), m_stream));
+            } else {
+                HIP_CHECK(hipMemsetAsync(mf.front_store, 0, mf.front_store_size * sizeof(double), m_stream));
+            }
+        } else if (sch.n_zero_blocks > 0) {
+            // (tests: SANM_MF_POISON=1 fills the whole storage with NaNs first -- whatever the factorisation reads
+            // without having written or zeroed it shows up in the factors)
+            if (std::getenv("SANM_MF_POISON"))
+                HIP_CHECK(hipMemsetAsync(mf.front_store, 0xFF, mf.front_store_size * sizeof(double), m_stream));
+            // what is accumulated into or read before it is written, of this rank's fronts (mf_kernels.h, zero_kernel)
+            SANM_LAUNCH(zero_kernel, dim3(sch.n_zero_blocks), dim3(256), 0, m_stream, mf.fronts, mf.front_store,
+                        sch.zero_blocks);
         }
         HIP_CHECK(hipMemsetAsync(mf.status, 0, sizeof(int32_t), m_stream));
         SANM_LAUNCH(absmax_kernel, dim3(red_grid(mf.nnzA)), dim3(256), 0, m_stream, (size_t)mf.nnzA, A.val,
@@ -2460,10 +2472,16 @@ public:
             for (size_t r = 0; r < L.ea_rounds.size(); ++r) {
                 int cnt = L.ea_rounds[r].second - L.ea_rounds[r].first;
                 int64_t mb = L.ea_max_b[r];
-                if (cnt == 0 || mb == 0) continue;
-                SANM_LAUNCH(extend_add_kernel, dim3((unsigned)((mb + EA_ROWS - 1) / EA_ROWS), cnt), dim3(256), 0,
-                                   m_stream, mf.fronts, mf.front_store, mf.rel,
-                                   sch.ea_children + L.ea_rounds[r].first);
+                if (cnt == 0) continue;
+                // round 0: the parents' F[B,B] blocks are ASSIGNED from their first children (every entry, so the block
+                // needs no zero-fill), what lands in their pivot rows and columns is added as in the later rounds
+                if (r == 0 && L.ea0_max_bp > 0)
+                    SANM_LAUNCH(schur_gather_kernel, dim3((unsigned)((L.ea0_max_bp + EA_ROWS - 1) / EA_ROWS), cnt), dim3(256),
+                                0, m_stream, mf.fronts, mf.front_store, sch.ea_inv, sch.ea_children + L.ea_rounds[r].first);
+                if (mb > 0)
+                    SANM_LAUNCH(extend_add_kernel, dim3((unsigned)((mb + EA_ROWS - 1) / EA_ROWS), cnt), dim3(256), 0,
+                                       m_stream, mf.fronts, mf.front_store, mf.rel,
+                                       sch.ea_children + L.ea_rounds[r].first, (int)(r == 0));
             }
             const int nfront = L.front_end - L.front_begin;
             // levels of many small fronts: the whole factorisation of a front in one workgroup (mf_kernels.h,

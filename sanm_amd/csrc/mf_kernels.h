@@ -16,6 +16,7 @@
 //   3. gemm2_kernel:  F[B,B] -= tmpL tmpU,  F[B,A] = -tmpL L11^-1,  F[A,B] = -U11^-1 tmpU
 // so the Schur complement is read and written once instead of once per panel.
 #pragma once
+#include <climits>
 #include <type_traits>
 #include <hip/hip_runtime.h>
 
@@ -62,15 +63,64 @@ __global__ void aug_identity_kernel(MfDev mf) {
     F[(int64_t)(f.k + r) * f.ld + r] = 1.0;
 }
 
+constexpr int EA_ROWS = 4;  // rows of a Schur complement per workgroup of the extend-add kernels
+
+// Prologue of a factorisation: the parts of every front that are accumulated into or read before they are written --
+// the rows P in full (matrix entries, children's contributions, the identity block of the augmentation), the columns P
+// and A of the rows A, the columns P of the rows B.  F[A,B] and F[B,A] are outputs of the GEMM passes, F[B,B] is
+// assigned by round 0 of the extend-add (schur_gather_kernel) or never read (fronts without children): not touched --
+// at 338 k tets 1.8 of the 4.1 GB a memset of the whole front storage wrote.  One workgroup per MF_ZERO_ROWS rows.
+__global__ void __launch_bounds__(256) zero_kernel(const MfFrontDev* __restrict__ fronts, double* __restrict__ store,
+                                                   const int32_t* __restrict__ blocks) {
+    const MfFrontDev f = fronts[blocks[2 * blockIdx.x]];
+    const int r0 = blocks[2 * blockIdx.x + 1], k = f.k, ld = f.ld;
+    double* F = store + f.off;
+    for (int r = r0 + (threadIdx.x >> 6); r < min(r0 + MF_ZERO_ROWS, ld); r += 4) {
+        const int len = r < k ? ld : (r < 2 * k ? 2 * k : k);
+        double* row = F + (int64_t)r * ld;
+        for (int c = threadIdx.x & 63; c < len; c += 64) row[c] = 0.0;
+    }
+}
+
+// Round 0 of the extend-add, the F[B,B] block of the parent: parent[2k + i, 2k + j] = schur of its first child at
+// (inv[i], inv[j]), 0 where the child has no such row or column (MfSchedule::ea_inv) -- every entry of the block is
+// written, so it needs no zero-fill and no read.  0.0 + v: the bits an addition to a zeroed block gave.
+__global__ void __launch_bounds__(256) schur_gather_kernel(const MfFrontDev* __restrict__ fronts_, double* front_store_,
+                                                           const int32_t* __restrict__ inv_,
+                                                           const int32_t* __restrict__ children) {
+    const MfFrontDev c = fronts_[children[blockIdx.y]];
+    const MfFrontDev p = fronts_[c.parent];
+    const int bp = p.m - p.k;
+    const int i0 = blockIdx.x * EA_ROWS;
+    if (i0 >= bp) return;
+    const int32_t* __restrict__ inv = inv_ + p.bnd_off;
+    const double* src = front_store_ + c.off + (int64_t)(2 * c.k) * c.ld + 2 * c.k;
+    double* dst = front_store_ + p.off + (int64_t)(2 * p.k) * p.ld + 2 * p.k;
+    int ci[EA_ROWS];
+#pragma unroll
+    for (int q = 0; q < EA_ROWS; ++q) ci[q] = i0 + q < bp ? inv[i0 + q] : -1;
+    for (int j = threadIdx.x; j < bp; j += 256) {
+        const int cj = inv[j];
+        double v[EA_ROWS];
+#pragma unroll
+        for (int q = 0; q < EA_ROWS; ++q) v[q] = (ci[q] >= 0 && cj >= 0) ? src[(int64_t)ci[q] * c.ld + cj] : 0.0;
+#pragma unroll
+        for (int q = 0; q < EA_ROWS; ++q)
+            if (i0 + q < bp) dst[(int64_t)(i0 + q) * p.ld + j] = 0.0 + v[q];
+    }
+}
+
 // parent[rel[i], rel[j]] += child_schur[i, j]; one child per blockIdx.y, EA_ROWS rows of its Schur complement per
 // workgroup, the threads along the columns.  (Round 2 gave every element a thread of its own: a 64-bit division per
 // element, one load in flight per lane and a grid sized for the largest child of the round -- 225 GB/s on the
 // 0.5 M-tet block, 16 of the 255 ms of a step.  Here a thread keeps EA_ROWS independent read-modify-writes per
 // column in flight and rel[j] is read once per column for all of them.)
-constexpr int EA_ROWS = 4;
+// skip_bb (round 0): the entries that land in the parent's F[B,B] are left to schur_gather_kernel -- rel is ascending,
+// so those are the rows and columns from the first one at or beyond the parent's 2k on: a row block wholly there only
+// walks the columns before it.
 __global__ void __launch_bounds__(256) extend_add_kernel(const MfFrontDev* __restrict__ fronts_, double* front_store_,
                                                          const int32_t* __restrict__ rel_,
-                                                         const int32_t* __restrict__ children) {
+                                                         const int32_t* __restrict__ children, int skip_bb) {
     const MfFrontDev c = fronts_[children[blockIdx.y]];
     const int nb = c.m - c.k;
     const int i0 = blockIdx.x * EA_ROWS;
@@ -79,11 +129,20 @@ __global__ void __launch_bounds__(256) extend_add_kernel(const MfFrontDev* __res
     const int32_t* __restrict__ rel = rel_ + c.rel_off;
     const double* src = front_store_ + c.off + (int64_t)(2 * c.k) * c.ld + 2 * c.k;
     double* dst = front_store_ + p.off;
+    const int pb = skip_bb ? 2 * p.k : INT_MAX;  // first physical row / column of the parent's boundary block
     int64_t drow[EA_ROWS];
+    bool rb[EA_ROWS], all_b = true;
 #pragma unroll
-    for (int q = 0; q < EA_ROWS; ++q) drow[q] = (int64_t)rel[min(i0 + q, nb - 1)] * p.ld;
+    for (int q = 0; q < EA_ROWS; ++q) {
+        const int rr = rel[min(i0 + q, nb - 1)];
+        drow[q] = (int64_t)rr * p.ld;
+        rb[q] = rr >= pb;
+        all_b = all_b && rb[q];
+    }
     for (int j = threadIdx.x; j < nb; j += 256) {
         const int rj = rel[j];
+        const bool cb = rj >= pb;
+        if (cb && all_b) break;  // (ascending: every later column is in the boundary block as well)
         double v[EA_ROWS], d[EA_ROWS];
 #pragma unroll
         for (int q = 0; q < EA_ROWS; ++q) {
@@ -92,7 +151,7 @@ __global__ void __launch_bounds__(256) extend_add_kernel(const MfFrontDev* __res
         }
 #pragma unroll
         for (int q = 0; q < EA_ROWS; ++q)
-            if (i0 + q < nb) dst[drow[q] + rj] = d[q] + v[q];
+            if (i0 + q < nb && !(cb && rb[q])) dst[drow[q] + rj] = d[q] + v[q];
     }
 }
 
@@ -800,12 +859,13 @@ __global__ void __launch_bounds__(256) gemm2_tall_kernel(MF_FACTOR_PARAMS) {
     // (old values requested together, see gemm_tile_sub_from; the tile is interior: no guards)
     double* __restrict__ Cw = C + (int64_t)((ti >> 1) * GT2 + 64 * (wv >> 1) + (lane >> 4)) * ld + tj * GT + 32 * (wv & 1) + (lane & 15);
     double old[4][2][4];
+    const bool leaf = f.nch == 0;  // (no children: F[B,B] holds nothing yet and was not zeroed, see gemm2_tile)
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) old[mi][ni][g] = Cw[(int64_t)(16 * mi + 4 * g) * ld + 16 * ni];
+            for (int g = 0; g < 4; ++g) old[mi][ni][g] = leaf ? 0.0 : Cw[(int64_t)(16 * mi + 4 * g) * ld + 16 * ni];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -846,6 +906,15 @@ __device__ __forceinline__ void gemm2_tile(const FactorArgs& mf, const MfFrontDe
     mfma_f64x4 acc[2][2];
     gemm_tile(A, B, ti, tj, k0, k, As, Bs, acc);
     if (which == 0) {
+        if (f.nch == 0) {
+            // a front without children: nothing was added to its F[B,B], which the prologue no longer zeroes either
+            // (zero_kernel) -- the block is written, 0.0 - v being the bits `old - v` gave on a zeroed block
+            gemm_tile_foreach(acc, [&](int i, int j, double v) {
+                const int r = ti * GT + i, c = tj * GT + j;
+                if (r < rows && c < cols) C[(int64_t)r * ld + c] = 0.0 - v;
+            });
+            return;
+        }
         gemm_tile_sub_from(acc, C, ld, ti, tj, rows, cols);
         return;
     }

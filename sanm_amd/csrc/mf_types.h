@@ -7,6 +7,7 @@
 namespace sanm_hip {
 
 constexpr int MF_NB = 32;  // panel / tile width
+constexpr int MF_ZERO_ROWS = 16;  // rows of a front per workgroup of zero_kernel
 // widest pivot block of a level whose forward boundary operator is kept transposed (Level::fwd_t; SANM_MF_FWD_T_MAX_K)
 constexpr int kFwdTMaxK = 256;
 // Static pivot perturbation, as PARDISO does for unsymmetric matrices (iparm[9] = 13, the setting the reference's
@@ -114,9 +115,22 @@ struct MfSchedule {
         // level; [begin,end) into ea_children
         std::vector<std::pair<int32_t, int32_t>> ea_rounds;
         std::vector<int32_t> ea_max_b;   // max boundary size of the children of a round
+        int32_t ea0_max_bp = 0;          // largest boundary of a front of the level that has children (round 0's gather)
     };
     std::vector<Level> levels;
     const int32_t* ea_children = nullptr;  // device
+    // Round 0 of the extend-add ASSIGNS the parent's F[B,B] instead of adding to a zeroed block (round 6): for boundary
+    // position i of a front with children, ea_inv[bnd_off + i] = the boundary position of its FIRST child that lands there,
+    // -1 for none -- a parent-side gather, so every entry of the block is written once and the block needs no zero-fill
+    // (the fronts without children never read theirs: mf_kernels.h, gemm2_tile).  The rest of the first child's Schur
+    // complement -- what lands in the parent's pivot rows and columns -- is added like the other children's.
+    const int32_t* ea_inv = nullptr;       // device; parallel to bnd_idx
+    // What the factorisation's prologue zeroes instead of the whole front storage: per front the rows P in full, the
+    // columns P and A of the rows A, the columns P of the rows B (zero_kernel); flat list of (front, first row) blocks
+    // of ZERO_ROWS rows each
+    const int32_t* zero_blocks = nullptr;  // device; 2 words per block
+    int32_t n_zero_blocks = 0;
+    int64_t zero_doubles = 0;              // what that writes (statistics)
     // Tree-to-ranks distribution (multifrontal.cpp).  EVERY front has one owner.  The elimination
     // tree is mapped from the root down onto sets of ranks (proportional mapping: a node with the rank set R gives its
     // children disjoint slices of R in proportion to their subtree work); a subtree whose set is one rank belongs to it

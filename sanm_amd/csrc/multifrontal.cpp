@@ -1187,38 +1187,44 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
             std::vector<int32_t> by_work(ch);
             std::stable_sort(by_work.begin(), by_work.end(), [&](int32_t a, int32_t b) { return sub_flops[a] > sub_flops[b]; });
             const int nr = (int)t.ranks.size(), nc = (int)by_work.size();
-            if (nc >= nr) {
-                // each child to one rank: largest first, to the rank with the least work so far
-                std::vector<double> load(nr, 0.0);
-                for (int32_t c : by_work) {
-                    int q = 0;
-                    for (int r = 1; r < nr; ++r)
-                        if (load[r] < load[q]) q = r;
-                    load[q] += sub_flops[c];
-                    stack.push_back(Task{c, {t.ranks[q]}});
-                }
-            } else {
-                // slices of the set in proportion to the work, at least one rank each (largest remainders first)
-                double W = 0;
-                for (int32_t c : by_work) W += sub_flops[c];
-                std::vector<int> cnt(nc, 1);
-                int left = nr - nc;
-                std::vector<double> want(nc);
-                for (int i = 0; i < nc; ++i) want[i] = W > 0 ? sub_flops[by_work[i]] / W * nr : 1.0;
-                while (left > 0) {
-                    int q = 0;
-                    for (int i = 1; i < nc; ++i)
-                        if (want[i] - cnt[i] > want[q] - cnt[q]) q = i;
-                    ++cnt[q];
-                    --left;
-                }
-                int at = 0;
-                for (int i = 0; i < nc; ++i) {
-                    Task u{by_work[i], {}};
-                    u.ranks.assign(t.ranks.begin() + at, t.ranks.begin() + at + cnt[i]);
-                    at += cnt[i];
-                    stack.push_back(std::move(u));
-                }
+            // Every child gets the whole number of ranks in its share of the set (possibly none), the ranks left over
+            // go by largest remainder; the children left without a rank of their own -- a share below half a rank or so:
+            // the light side of a lopsided node, the small components of a forest -- ride with the least loaded rank of
+            // the set, largest first.
+            double W = 0;
+            for (int32_t c : by_work) W += sub_flops[c];
+            std::vector<int> cnt(nc, 0);
+            std::vector<double> want(nc);
+            int left = nr;
+            for (int i = 0; i < nc; ++i) {
+                want[i] = W > 0 ? sub_flops[by_work[i]] / W * nr : 0.0;
+                cnt[i] = std::min((int)want[i], left);
+                left -= cnt[i];
+            }
+            while (left > 0) {
+                int q = 0;
+                for (int i = 1; i < nc; ++i)
+                    if (want[i] - cnt[i] > want[q] - cnt[q]) q = i;
+                ++cnt[q];
+                --left;
+            }
+            std::vector<double> load(nr, 0.0);
+            int at = 0;
+            for (int i = 0; i < nc; ++i) {
+                if (cnt[i] == 0) continue;
+                Task u{by_work[i], {}};
+                u.ranks.assign(t.ranks.begin() + at, t.ranks.begin() + at + cnt[i]);
+                for (int r = at; r < at + cnt[i]; ++r) load[r] = sub_flops[by_work[i]] / cnt[i];
+                at += cnt[i];
+                stack.push_back(std::move(u));
+            }
+            for (int i = 0; i < nc; ++i) {
+                if (cnt[i] != 0) continue;
+                int q = 0;
+                for (int r = 1; r < nr; ++r)
+                    if (load[r] < load[q]) q = r;
+                load[q] += sub_flops[by_work[i]];
+                stack.push_back(Task{by_work[i], {t.ranks[q]}});
             }
         }
         // fronts below a cut root inherit its owner (parents have larger ids: walk down from the top)
@@ -1424,6 +1430,8 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
             L.ea_rounds.emplace_back(b, (int32_t)ea_children.size());
             L.ea_max_b.push_back(mb);
         }
+        for (int32_t f : fs)
+            if (!children[f].empty()) L.ea0_max_bp = std::max(L.ea0_max_bp, fr[f].m - fr[f].k);
     }
 
     // tile lists of the GEMM passes (mf_types.h, Level::g1_tiles / g2_tiles)
@@ -1513,6 +1521,34 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     upload_to(m_dev.own_front, owner);
     upload_to(m_dev.a_dst, a_dst);
     upload_to(m_sched.ea_children, ea_children);
+    {
+        // the parent-side map of round 0 (mf_types.h, MfSchedule::ea_inv)
+        std::vector<int32_t> ea_inv(bnd_idx.size(), -1);
+        for (int32_t f = 0; f < F; ++f) {
+            if (children[f].empty()) continue;
+            const int32_t c = children[f][0], bc = fr[c].m - fr[c].k;
+            for (int32_t i = 0; i < bc; ++i) {
+                const int32_t pos = rel[fr[c].rel_off + i];
+                if (pos >= 2 * fr[f].k) ea_inv[fr[f].bnd_off + pos - 2 * fr[f].k] = i;
+            }
+        }
+        upload_to(m_sched.ea_inv, std::move(ea_inv));
+        // blocks of rows the prologue zeroes (this rank's fronts when the tree is distributed)
+        std::vector<int32_t> zb;
+        int64_t zd = 0;
+        for (int32_t f = 0; f < F; ++f) {
+            if (D.enabled && f_owner[f] != rank) continue;
+            for (int32_t r0 = 0; r0 < fr[f].ld; r0 += MF_ZERO_ROWS) {
+                zb.push_back(f);
+                zb.push_back(r0);
+            }
+            const int64_t k = fr[f].k, b = fr[f].m - fr[f].k;
+            zd += 4 * k * k + 2 * k * b;
+        }
+        m_sched.n_zero_blocks = (int32_t)(zb.size() / 2);
+        m_sched.zero_doubles = zd;
+        upload_to(m_sched.zero_blocks, std::move(zb));
+    }
     lap("device tables: uploads");
     m_dev.front_store_size = off;
     alloc_to(m_dev.front_store, off * sizeof(double), false);

@@ -11,7 +11,7 @@ i=0
 for v in "base" "$@"; do
   i=$((i+1))
   if [ "$v" = "base" ]; then envs=""; else envs="$v"; fi
-  env $envs timeout 600 python bench.py --workload $WL --steps 5 --warmup 2 --no-cpu-baseline --no-end-to-end --at-scale-workload none > $OUT/b_$i.json 2> $OUT/b_$i.err
+  env $envs timeout 600 python bench.py --workload $WL --steps 5 --warmup 2 --no-cpu-baseline --no-end-to-end --at-scale-workload none --at-scale-large-workload none > $OUT/b_$i.json 2> $OUT/b_$i.err
   python - "$OUT/b_$i.json" "$v" <<'PY'
 import json, sys
 try:

@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd $ROOT
 for K in off on off on off on; do
   if [ $K = on ]; then export $VAR=$VAL; else unset $VAR; fi
-  timeout 300 python bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --at-scale-workload none > $OUT/e2e_$K.json 2> $OUT/e2e_$K.err
+  timeout 300 python bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --at-scale-workload none --at-scale-large-workload none > $OUT/e2e_$K.json 2> $OUT/e2e_$K.err
   python - <<PY
 import json
 d=json.loads(open("$OUT/e2e_$K.json").read().strip().splitlines()[-1])

@@ -11,7 +11,7 @@ for WL in $WLS; do
   N=$(echo $WL | tr ':' '_')
   for K in off on off on; do
     if [ $K = on ]; then export $VAR=$VAL; else unset $VAR; fi
-    timeout 300 python bench.py --workload $WL --steps 8 --warmup 2 --no-cpu-baseline --no-end-to-end --at-scale-workload none > $OUT/${N}_$K.json 2> $OUT/${N}_$K.err
+    timeout 300 python bench.py --workload $WL --steps 8 --warmup 2 --no-cpu-baseline --no-end-to-end --at-scale-workload none --at-scale-large-workload none > $OUT/${N}_$K.json 2> $OUT/${N}_$K.err
     python - <<PY
 import json
 d=json.loads(open("$OUT/${N}_$K.json").read().strip().splitlines()[-1])

@@ -10,7 +10,7 @@ run() {
   local name=$1; shift
   for WL in armadillo_small refine:armadillo_small:1; do
     N=$(echo $WL | tr ':' '_')
-    env "$@" timeout 300 python bench.py --workload $WL --steps 8 --warmup 2 --no-cpu-baseline --no-end-to-end --at-scale-workload none > $OUT/${N}_$name.json 2> $OUT/${N}_$name.err
+    env "$@" timeout 300 python bench.py --workload $WL --steps 8 --warmup 2 --no-cpu-baseline --no-end-to-end --at-scale-workload none --at-scale-large-workload none > $OUT/${N}_$name.json 2> $OUT/${N}_$name.err
     python - <<PY
 import json
 try:

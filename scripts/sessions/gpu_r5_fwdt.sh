@@ -10,7 +10,7 @@ timeout 900 python -m pytest tests/test_direct_solver.py -q -m gpu -x 2>&1 | tai
 for WL in refine:armadillo_small:1 armadillo_small; do
   N=$(echo $WL | tr ':' '_')
   for K in 128 256 128 256; do
-    SANM_MF_FWD_T_MAX_K=$K timeout 300 python bench.py --workload $WL --steps 8 --warmup 2 --no-cpu-baseline --no-end-to-end --at-scale-workload none > $OUT/${N}_$K.json 2> $OUT/${N}_$K.err
+    SANM_MF_FWD_T_MAX_K=$K timeout 300 python bench.py --workload $WL --steps 8 --warmup 2 --no-cpu-baseline --no-end-to-end --at-scale-workload none --at-scale-large-workload none > $OUT/${N}_$K.json 2> $OUT/${N}_$K.err
     python - <<PY
 import json
 d=json.loads(open("$OUT/${N}_$K.json").read().strip().splitlines()[-1])

@@ -9,7 +9,7 @@ cd $ROOT
 for WL in bob human_arap16 block:32 block:48 refine:armadillo_small:2; do
   N=$(echo $WL | tr ':' '_')
   ST=8; [ $WL = block:48 ] && ST=3; [ $WL = refine:armadillo_small:2 ] && ST=2
-  timeout 900 python bench.py --workload $WL --steps $ST --warmup 1 --no-cpu-baseline --at-scale-workload none > $OUT/bench_$N.json 2> $OUT/bench_$N.err
+  timeout 900 python bench.py --workload $WL --steps $ST --warmup 1 --no-cpu-baseline --at-scale-workload none --at-scale-large-workload none > $OUT/bench_$N.json 2> $OUT/bench_$N.err
   python - <<PY
 import json
 try:

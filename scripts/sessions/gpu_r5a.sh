@@ -14,7 +14,7 @@ fi
 ( time timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err ) 2> $OUT/bench.time; echo "bench rc=$?"; tail -3 $OUT/bench.time
 cut -c1-400 $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_x8 -o run -- python3 $ROOT/bench.py --workload refine:armadillo_small:1 --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --at-scale-workload none > $OUT/stats_x8.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_x8 -o run -- python3 $ROOT/bench.py --workload refine:armadillo_small:1 --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --at-scale-workload none --at-scale-large-workload none > $OUT/stats_x8.log 2>&1
 ls $OUT/stats_x8/ | head
 cd $ROOT
 python scripts/prof_summary.py $OUT/stats_x8 > $OUT/kernel_stats_x8.md 2>/dev/null || true

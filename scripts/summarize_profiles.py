@@ -44,7 +44,7 @@ tot = sum(v[1] for v in fam.values())
 with open(os.path.join(dst, f"{tag}_kernel_stats.md"), "w") as fo:
     if not steps:
         steps = next((c for k, (c, t) in fam.items() if k in ("assemble3_kernel", "assemble_kernel")), 14)
-    fo.write(f"# rocprofv3 --kernel-trace --stats of `bench.py --workload {workload} --no-end-to-end --at-scale-workload none` ({tag})\n\n")
+    fo.write(f"# rocprofv3 --kernel-trace --stats of `bench.py --workload {workload} --no-end-to-end --at-scale-workload none --at-scale-large-workload none` ({tag})\n\n")
     fo.write(f"{workload}, order {order}, 1 MI355X.  Template instantiations of one kernel are\n"
              f"summed.  {steps} ANM steps in the run (timed + warm-up + the bench's 2 family-measurement steps: one\n"
              f"`assemble3_kernel` / `assemble_kernel` launch each) -> per-step column = total / {steps}.  Full per-instantiation table: `{tag}_kernel_stats.csv`.\n\n")
@@ -73,7 +73,7 @@ out = {"workload": workload, "order": order,
 with open(os.path.join(dst, f"{tag}_pmc_traffic.md"), "w") as fo:
     fo.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, --kernel-trace only)\n\n")
     fo.write("Command: `rocprofv3 --kernel-trace --pmc <COUNTER> --output-format csv -- python3 bench.py --steps 4 "
-             f"--warmup 1 --workload {workload} --no-cpu-baseline --no-end-to-end --at-scale-workload none`\n({workload}, order {order}, 1 MI355X; scripts/collect_profiles.sh). "
+             f"--warmup 1 --workload {workload} --no-cpu-baseline --no-end-to-end --at-scale-workload none --at-scale-large-workload none`\n({workload}, order {order}, 1 MI355X; scripts/collect_profiles.sh). "
              "Counter unit: KiB per dispatch. Correction per\nMI355X_MICROARCH.md (HBM): FETCH_SIZE reports 1/2 of the "
              "bytes of a coalesced stream on gfx950 -> doubled; WRITE_SIZE is\nexact (calibrated on axpby_kernel, which "
              "writes n+1 doubles per launch: armadillo_small 38,047 = 297.2 KiB, refine:armadillo_small:1 235,378 = 1838.9 KiB).\n\n")

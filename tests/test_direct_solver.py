@@ -341,3 +341,51 @@ def test_forward_operator_not_transposed(api, monkeypatch, leaf):
     monkeypatch.setenv("SANM_MF_SMALL_MIN_FRONTS", "1")
     test_fem_jacobian(api, True)
     test_grid3d_wide_separators(api)
+
+
+@pytest.mark.parametrize("leaf", ["8", "32"])
+def test_selective_zero_fill_and_assigned_schur_blocks(api, monkeypatch, leaf):
+    """Round 6: the factorisation's prologue zeroes only what is accumulated into (zero_kernel: rows P, the P / A columns
+    of rows A, the P columns of rows B -- not F[A,B], F[B,A], F[B,B]); the F[B,B] block of a front with children is
+    ASSIGNED by round 0 of the extend-add (schur_gather_kernel), a front without children writes its Schur complement
+    without reading the block.  Same bits as the memset of the whole storage (SANM_MF_FULL_ZERO=1), also when the
+    storage is filled with NaNs first (SANM_MF_POISON=1: nothing unwritten is read), with the small-front kernel, the
+    panel chain, two-phase levels and chains of cut fronts, over two factorisations on the same storage.  (The host
+    harness zeroes everything and adds: its own results are the reference the other tests hold the device to.)"""
+    mesh = ofea.make_cuboid(9, 5, 4, 0.02)
+    fixed = np.zeros((mesh.nr_vertices, 3), bool)
+    fixed[mesh.V[:, 0] < 0.01] = True
+    om = ofea.make_forward(mesh, ofea.Material(1e4, 0.45), fixed, "neohookean_c")
+    prop = S.TaylorCoeffProp(om.y)
+    prop.push_xi([(om.lt_inp.mat @ om.lt_inp.x0).reshape(-1, 3, 3)])
+    A, _ = build_jacobian_csr(om.lt_out, prop.get_jacobian(), om.lt_inp.mat, om.lt_inp.n)
+    A = A.tocsr()
+    A.sort_indices()
+    coords = mesh.V[om.lt_inp.vertex_loc[:, 0]]
+    rng = np.random.default_rng(3)
+    b = rng.standard_normal(A.shape[0])
+    A2 = A.copy()
+    A2.data = A.data * (1 + 0.05 * rng.standard_normal(A.nnz))
+    monkeypatch.setenv("SANM_MF_LEAF", leaf)
+    for extra in ({}, {"SANM_MF_SMALL_MIN_FRONTS": "0"}, {"SANM_MF_TWO_PHASE": "1"}, {"SANM_MF_SPLIT_K": "48"},
+                  {"SANM_MF_OUTER_MIN_K": "32"}):
+        for k, v in extra.items():
+            monkeypatch.setenv(k, v)
+        sols = []
+        for mode in ({"SANM_MF_FULL_ZERO": "1"}, {}, {"SANM_MF_POISON": "1"}):
+            for k, v in mode.items():
+                monkeypatch.setenv(k, v)
+            ds = DirectSolver(api, A, coords)
+            assert ds.factor(A) == 0
+            x1 = ds.solve(b)
+            assert ds.factor(A2) == 0  # (a second factorisation on the storage the first one left behind)
+            x2 = ds.solve(b)
+            sols.append((x1, x2))
+            for k in mode:
+                monkeypatch.delenv(k)
+        assert np.all(np.isfinite(sols[2][0])) and np.all(np.isfinite(sols[2][1]))
+        for s in sols[1:]:
+            assert np.array_equal(s[0], sols[0][0]) and np.array_equal(s[1], sols[0][1])
+        assert np.abs(A @ sols[0][0] - b).max() <= 1e-8 * np.abs(b).max()
+        for k in extra:
+            monkeypatch.delenv(k)
