@@ -2439,17 +2439,25 @@ public:
     void mf_factor_levels(const MfDev& mf, const MfSchedule& sch, const CsrDev& A, int l0, int l1, bool prologue,
                           bool epilogue) {
         using namespace mfk;
+        // Selective zero-fill + assigned F[B,B] blocks (mf_kernels.h: zero_kernel, schur_gather_kernel) from 16 GB of
+        // front storage on: there the bytes not written and not read back pay (2.7 M tets: factor -1 %, 26 instead of
+        // 60 GB of fill per step); below, the memset of everything and one extend-add launch per round are faster
+        // (338 k tets: 13.1 against 13.4 ms per factorisation).  SANM_MF_FULL_ZERO=1 / SANM_MF_SELECTIVE_ZERO=1 force
+        // one or the other; same bits either way (tests/test_direct_solver.py).
+        const bool selective = !std::getenv("SANM_MF_FULL_ZERO") && sch.n_zero_blocks > 0 &&
+                               (std::getenv("SANM_MF_SELECTIVE_ZERO") || std::getenv("SANM_MF_POISON") ||
+                                mf.front_store_size >= (int64_t(2) << 30));
         if (prologue) {
         // (read per factorisation: tests switch it) SANM_MF_FULL_ZERO=1: the whole storage of the rank's fronts, as
         // rounds 1-5 did
-        if (std::getenv("SANM_MF_FULL_ZERO")) {
+        if (!selective) {
             if (sch.dist.enabled) {  // (only the fronts this rank factors: MfSchedule::Dist::own_store)
                 for (const auto& r : sch.dist.own_store)
                     HIP_CHECK(hipMemsetAsync(mf.front_store + r.first, 0, (size_t)(r.second - r.first) * sizeof(double), m_stream));
             } else {
                 HIP_CHECK(hipMemsetAsync(mf.front_store, 0, mf.front_store_size * sizeof(double), m_stream));
             }
-        } else if (sch.n_zero_blocks > 0) {
+        } else {
             // (tests: SANM_MF_POISON=1 fills the whole storage with NaNs first -- whatever the factorisation reads
             // without having written or zeroed it shows up in the factors)
             if (std::getenv("SANM_MF_POISON"))
@@ -2475,13 +2483,25 @@ public:
                 if (cnt == 0) continue;
                 // round 0: the parents' F[B,B] blocks are ASSIGNED from their first children (every entry, so the block
                 // needs no zero-fill), what lands in their pivot rows and columns is added as in the later rounds
-                if (r == 0 && L.ea0_max_bp > 0)
-                    SANM_LAUNCH(schur_gather_kernel, dim3((unsigned)((L.ea0_max_bp + EA_ROWS - 1) / EA_ROWS), cnt), dim3(256),
-                                0, m_stream, mf.fronts, mf.front_store, sch.ea_inv, sch.ea_children + L.ea_rounds[r].first);
-                if (mb > 0)
-                    SANM_LAUNCH(extend_add_kernel, dim3((unsigned)((mb + EA_ROWS - 1) / EA_ROWS), cnt), dim3(256), 0,
-                                       m_stream, mf.fronts, mf.front_store, mf.rel,
-                                       sch.ea_children + L.ea_rounds[r].first, (int)(r == 0));
+                const bool assign0 = r == 0 && selective;
+                // rows of a Schur complement per workgroup: EA_ROWS at a time, as many times as keeps the launch at
+                // 8 k workgroups or more (SANM_MF_EA_ROWS: fixed)
+                static const int env_ea_rows = std::getenv("SANM_MF_EA_ROWS") ? std::atoi(std::getenv("SANM_MF_EA_ROWS")) : 0;
+                auto rows_per_wg = [&](int64_t max_rows) {
+                    if (env_ea_rows > 0) return (env_ea_rows + EA_ROWS - 1) / EA_ROWS * EA_ROWS;
+                    const int64_t blocks4 = (max_rows + EA_ROWS - 1) / EA_ROWS * cnt;
+                    return EA_ROWS * (int)std::clamp<int64_t>(blocks4 / 8192, 1, 16);
+                };
+                if (assign0 && L.ea0_max_bp > 0) {
+                    const int rw = rows_per_wg(L.ea0_max_bp);
+                    SANM_LAUNCH(schur_gather_kernel, dim3((unsigned)((L.ea0_max_bp + rw - 1) / rw), cnt), dim3(256), 0, m_stream,
+                                mf.fronts, mf.front_store, sch.ea_inv, sch.ea_children + L.ea_rounds[r].first, rw);
+                }
+                if (mb > 0) {
+                    const int rw = rows_per_wg(mb);
+                    SANM_LAUNCH(extend_add_kernel, dim3((unsigned)((mb + rw - 1) / rw), cnt), dim3(256), 0, m_stream, mf.fronts,
+                                mf.front_store, mf.rel, sch.ea_children + L.ea_rounds[r].first, (int)assign0, rw);
+                }
             }
             const int nfront = L.front_end - L.front_begin;
             // levels of many small fronts: the whole factorisation of a front in one workgroup (mf_kernels.h,
@@ -2607,9 +2627,16 @@ public:
                                    MF_FACTOR_ARGS(mf, L.front_begin), nwhich, (int)L.fwd_t);
                 }
 #ifndef SANM_MF_OLD_STAGING
-                if (L.max_k >= mfk::kTallMinK && L.max_b >= mfk::kTallMinB)  // big fronts: interior of the Schur complement
+                // big fronts: the interior of the Schur complement in 128 x 64 tiles, a flat list of the tiles that exist
+                // in an order that keeps an XCD's workgroups on shared panels (mf_types.h, MF_ST_R)
+                if (!no_lists && L.gt_tiles) {
+                    if (L.n_gt > 0)
+                        SANM_LAUNCH(gemm2_tall_list_kernel, dim3(L.n_gt), dim3(256), 0, m_stream,
+                                    MF_FACTOR_ARGS(mf, L.front_begin), L.gt_tiles);
+                } else if (L.max_k >= mfk::kTallMinK && L.max_b >= mfk::kTallMinB) {
                     SANM_LAUNCH(gemm2_tall_kernel, dim3(tmax, (tmax + 1) / 2, nfr), dim3(256), 0, m_stream,
                                 MF_FACTOR_ARGS(mf, L.front_begin));
+                }
 #endif
             }
         }

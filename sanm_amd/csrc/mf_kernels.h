@@ -87,26 +87,30 @@ __global__ void __launch_bounds__(256) zero_kernel(const MfFrontDev* __restrict_
 // written, so it needs no zero-fill and no read.  0.0 + v: the bits an addition to a zeroed block gave.
 __global__ void __launch_bounds__(256) schur_gather_kernel(const MfFrontDev* __restrict__ fronts_, double* front_store_,
                                                            const int32_t* __restrict__ inv_,
-                                                           const int32_t* __restrict__ children) {
+                                                           const int32_t* __restrict__ children, int rows_per_wg) {
     const MfFrontDev c = fronts_[children[blockIdx.y]];
     const MfFrontDev p = fronts_[c.parent];
     const int bp = p.m - p.k;
-    const int i0 = blockIdx.x * EA_ROWS;
-    if (i0 >= bp) return;
+    const int ib = blockIdx.x * rows_per_wg;
+    if (ib >= bp) return;
     const int32_t* __restrict__ inv = inv_ + p.bnd_off;
     const double* src = front_store_ + c.off + (int64_t)(2 * c.k) * c.ld + 2 * c.k;
     double* dst = front_store_ + p.off + (int64_t)(2 * p.k) * p.ld + 2 * p.k;
-    int ci[EA_ROWS];
+    // (rows_per_wg: the levels of thousands of small fronts were bound by the NUMBER of four-row workgroups -- 880 k of
+    // them, a microsecond of work each, on the second level of a 2.7 M-tet tree; ea_rows_per_wg in backend_hip.hip)
+    for (int i0 = ib; i0 < min(ib + rows_per_wg, bp); i0 += EA_ROWS) {
+        int ci[EA_ROWS];
 #pragma unroll
-    for (int q = 0; q < EA_ROWS; ++q) ci[q] = i0 + q < bp ? inv[i0 + q] : -1;
-    for (int j = threadIdx.x; j < bp; j += 256) {
-        const int cj = inv[j];
-        double v[EA_ROWS];
+        for (int q = 0; q < EA_ROWS; ++q) ci[q] = i0 + q < bp ? inv[i0 + q] : -1;
+        for (int j = threadIdx.x; j < bp; j += 256) {
+            const int cj = inv[j];
+            double v[EA_ROWS];
 #pragma unroll
-        for (int q = 0; q < EA_ROWS; ++q) v[q] = (ci[q] >= 0 && cj >= 0) ? src[(int64_t)ci[q] * c.ld + cj] : 0.0;
+            for (int q = 0; q < EA_ROWS; ++q) v[q] = (ci[q] >= 0 && cj >= 0) ? src[(int64_t)ci[q] * c.ld + cj] : 0.0;
 #pragma unroll
-        for (int q = 0; q < EA_ROWS; ++q)
-            if (i0 + q < bp) dst[(int64_t)(i0 + q) * p.ld + j] = 0.0 + v[q];
+            for (int q = 0; q < EA_ROWS; ++q)
+                if (i0 + q < bp) dst[(int64_t)(i0 + q) * p.ld + j] = 0.0 + v[q];
+        }
     }
 }
 
@@ -120,38 +124,41 @@ __global__ void __launch_bounds__(256) schur_gather_kernel(const MfFrontDev* __r
 // walks the columns before it.
 __global__ void __launch_bounds__(256) extend_add_kernel(const MfFrontDev* __restrict__ fronts_, double* front_store_,
                                                          const int32_t* __restrict__ rel_,
-                                                         const int32_t* __restrict__ children, int skip_bb) {
+                                                         const int32_t* __restrict__ children, int skip_bb,
+                                                         int rows_per_wg) {
     const MfFrontDev c = fronts_[children[blockIdx.y]];
     const int nb = c.m - c.k;
-    const int i0 = blockIdx.x * EA_ROWS;
-    if (i0 >= nb) return;
+    const int ib = blockIdx.x * rows_per_wg;
+    if (ib >= nb) return;
     const MfFrontDev p = fronts_[c.parent];
     const int32_t* __restrict__ rel = rel_ + c.rel_off;
     const double* src = front_store_ + c.off + (int64_t)(2 * c.k) * c.ld + 2 * c.k;
     double* dst = front_store_ + p.off;
     const int pb = skip_bb ? 2 * p.k : INT_MAX;  // first physical row / column of the parent's boundary block
-    int64_t drow[EA_ROWS];
-    bool rb[EA_ROWS], all_b = true;
-#pragma unroll
-    for (int q = 0; q < EA_ROWS; ++q) {
-        const int rr = rel[min(i0 + q, nb - 1)];
-        drow[q] = (int64_t)rr * p.ld;
-        rb[q] = rr >= pb;
-        all_b = all_b && rb[q];
-    }
-    for (int j = threadIdx.x; j < nb; j += 256) {
-        const int rj = rel[j];
-        const bool cb = rj >= pb;
-        if (cb && all_b) break;  // (ascending: every later column is in the boundary block as well)
-        double v[EA_ROWS], d[EA_ROWS];
+    for (int i0 = ib; i0 < min(ib + rows_per_wg, nb); i0 += EA_ROWS) {
+        int64_t drow[EA_ROWS];
+        bool rb[EA_ROWS], all_b = true;
 #pragma unroll
         for (int q = 0; q < EA_ROWS; ++q) {
-            v[q] = src[(int64_t)min(i0 + q, nb - 1) * c.ld + j];
-            d[q] = dst[drow[q] + rj];
+            const int rr = rel[min(i0 + q, nb - 1)];
+            drow[q] = (int64_t)rr * p.ld;
+            rb[q] = rr >= pb;
+            all_b = all_b && rb[q];
         }
+        for (int j = threadIdx.x; j < nb; j += 256) {
+            const int rj = rel[j];
+            const bool cb = rj >= pb;
+            if (cb && all_b) break;  // (ascending: every later column is in the boundary block as well)
+            double v[EA_ROWS], d[EA_ROWS];
 #pragma unroll
-        for (int q = 0; q < EA_ROWS; ++q)
-            if (i0 + q < nb && !(cb && rb[q])) dst[drow[q] + rj] = d[q] + v[q];
+            for (int q = 0; q < EA_ROWS; ++q) {
+                v[q] = src[(int64_t)min(i0 + q, nb - 1) * c.ld + j];
+                d[q] = dst[drow[q] + rj];
+            }
+#pragma unroll
+            for (int q = 0; q < EA_ROWS; ++q)
+                if (i0 + q < nb && !(cb && rb[q])) dst[drow[q] + rj] = d[q] + v[q];
+        }
     }
 }
 
@@ -535,7 +542,7 @@ __global__ void __launch_bounds__(256) panel_finalize_kernel(MF_FACTOR_PARAMS, i
 // C/D: register g of lane l is C[(l>>4) + 4g][l&15]).  K advances in steps of 16 through LDS; the next
 // step's global loads are issued before the current step's MFMAs (register prefetch).  Element (i,j) of
 // an operand is p[i*ld + j] inside (rows, cols), else 0.  K range [k0, k1) in elements.
-constexpr int GT = 64;   // GEMM tile edge
+constexpr int GT = MF_GT;  // GEMM tile edge
 constexpr int GK = 16;   // GEMM K step
 
 struct GemmStage {
@@ -691,7 +698,7 @@ __device__ __forceinline__ void gemm_tile(const MatView& A, const MatView& B, in
 // the B traffic per flop.  For the Schur complements of big fronts (long K).  acc[mi][ni]: rows 64*(wave>>1) +
 // 16*mi, columns 32*(wave&1) + 16*ni.  K range [k0, k1).
 constexpr int GT2 = 128;
-constexpr int kTallMinK = 512, kTallMinB = 1024;  // fronts from this size on take the tall tile for F[B,B] -= L U
+constexpr int kTallMinK = MF_TALL_MIN_K, kTallMinB = MF_TALL_MIN_B;  // fronts from this size on take the tall tile for F[B,B] -= L U
 __device__ __forceinline__ void gemm_tile_tall(const MatView& A, const MatView& B, int ti, int tj, int k0, int k1,
                                                double (*As)[GT2 + 1], double (*Bs)[GT + 4], mfma_f64x4 acc[4][2]) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -839,15 +846,34 @@ __global__ void __launch_bounds__(256) gemm1_kernel(MF_FACTOR_PARAMS, int two_ph
 // eight accumulator tiles per wavefront cost 136 VGPRs, which would take a wavefront per SIMD from every other
 // product of gemm2_kernel), the tile rows at the lower edge and everything on smaller fronts stay here
 __device__ __forceinline__ bool gemm2_is_tall(int k, int b, int rows, int cols, int ti, int tj) {
-    return k >= kTallMinK && b >= kTallMinB && ((ti & ~1) + 2) * GT <= rows && (tj + 1) * GT <= cols;
+    return rows == b && cols == b && mf_gemm2_is_tall(k, b, ti, tj);
 }
-__global__ void __launch_bounds__(256) gemm2_tall_kernel(MF_FACTOR_PARAMS) {
+// one tall tile: rows [64 ti, 64 ti + 128) x columns [64 tj, 64 tj + 64) of F[B,B], ti even
+__device__ __forceinline__ void gemm2_tall_tile(const FactorArgs& mf, const MfFrontDev& f, int ti, int tj,
+                                                double (*As)[GT2 + 1], double (*Bs)[GT + 4]);
+__global__ void __launch_bounds__(256) gemm2_tall_kernel(MF_FACTOR_PARAMS) {  // (the box grid: SANM_MF_NO_TILE_LISTS)
     MF_FACTOR_INIT
     const MfFrontDev f = mf.lfronts[level_begin + blockIdx.z];
-    const int k = f.k, b = f.m - f.k, ld = f.ld;
+    const int k = f.k, b = f.m - f.k;
     const int ti = 2 * blockIdx.y, tj = blockIdx.x;
     if (!gemm2_is_tall(k, b, b, b, ti, tj)) return;
     __shared__ double As[GK][GT2 + 1], Bs[GK][GT + 4];
+    gemm2_tall_tile(mf, f, ti, tj, As, Bs);
+}
+// the same over the level's flat list of tall tiles, ordered for the eight L2s (mf_types.h, MF_ST_R): a launch of the
+// tiles that exist -- the box grid (widest front's tiles x fronts of the level) spent 45 of the 73 ms of the tall
+// tiles of a 2.7 M-tet factorisation on workgroups that found nothing to do
+__global__ void __launch_bounds__(256) gemm2_tall_list_kernel(MF_FACTOR_PARAMS, const uint32_t* __restrict__ tiles) {
+    MF_FACTOR_INIT
+    const uint32_t w0 = tiles[2 * blockIdx.x], w1 = tiles[2 * blockIdx.x + 1];
+    if (w0 == ~0u) return;  // (padding of the shorter queues)
+    const MfFrontDev f = mf.lfronts[level_begin + w0];
+    __shared__ double As[GK][GT2 + 1], Bs[GK][GT + 4];
+    gemm2_tall_tile(mf, f, 2 * (int)(w1 >> 15), (int)(w1 & 32767), As, Bs);
+}
+__device__ __forceinline__ void gemm2_tall_tile(const FactorArgs& mf, const MfFrontDev& f, int ti, int tj,
+                                                double (*As)[GT2 + 1], double (*Bs)[GT + 4]) {
+    const int k = f.k, b = f.m - f.k, ld = f.ld;
     double* F = mf.front_store + f.off;
     const double* tmpU = mf.tmp_store + f.tmp_off;
     const double* tmpL = tmpU + (int64_t)k * b;

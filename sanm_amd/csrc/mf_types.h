@@ -8,6 +8,25 @@ namespace sanm_hip {
 
 constexpr int MF_NB = 32;  // panel / tile width
 constexpr int MF_ZERO_ROWS = 16;  // rows of a front per workgroup of zero_kernel
+// F[B,B] -= tmpL tmpU of a big front: the interior of the block is computed in 128 x 64 tiles (mf_kernels.h,
+// gemm2_tall_list_kernel), the 64 x 64 tile rows at its lower / right edge and everything on smaller fronts by the
+// GEMM-2 pass.  One predicate for the host's tile lists and the kernels: is the 64 x 64 tile (ti, tj) of a b x b
+// Schur complement with k pivots part of a tall tile?
+constexpr int MF_GT = 64;  // GEMM tile edge
+constexpr int MF_TALL_MIN_K = 512, MF_TALL_MIN_B = 1024;
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define SANM_HD __host__ __device__
+#else
+#define SANM_HD
+#endif
+SANM_HD inline bool mf_gemm2_is_tall(int k, int b, int ti, int tj) {
+    return k >= MF_TALL_MIN_K && b >= MF_TALL_MIN_B && ((ti & ~1) + 2) * MF_GT <= b && (tj + 1) * MF_GT <= b;
+}
+// The tall tiles of a level go out as a flat list ordered for the eight L2s: workgroup n runs on the XCD n % 8 (observed
+// round-robin placement: speed only), so the list interleaves eight queues, each a sequence of SUPERTILES of
+// MF_ST_R x MF_ST_C tall tiles -- the ~96 workgroups an XCD holds at a time then share 8 row panels of tmpL and 12
+// column panels of tmpU instead of one row panel and 96 column panels.
+constexpr int MF_ST_R = 8, MF_ST_C = 12;
 // widest pivot block of a level whose forward boundary operator is kept transposed (Level::fwd_t; SANM_MF_FWD_T_MAX_K)
 constexpr int kFwdTMaxK = 256;
 // Static pivot perturbation, as PARDISO does for unsymmetric matrices (iparm[9] = 13, the setting the reference's
@@ -110,7 +129,8 @@ struct MfSchedule {
         // time (mf_kernels.h, gemm1_list_kernel).
         const uint32_t* g1_tiles = nullptr;
         const uint32_t* g2_tiles = nullptr;
-        int32_t n_g1 = 0, n_g2 = 0;
+        const uint32_t* gt_tiles = nullptr;  // tall tiles (front or ~0u for a padding entry, tp << 15 | tj)
+        int32_t n_g1 = 0, n_g2 = 0, n_gt = 0;
         // extend-add rounds: round r holds the r-th child of every front of the
         // level; [begin,end) into ea_children
         std::vector<std::pair<int32_t, int32_t>> ea_rounds;

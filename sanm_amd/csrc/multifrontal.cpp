@@ -1438,7 +1438,9 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     for (int32_t h = 0; h < H; ++h) {
         auto& L = m_sched.levels[h];
         std::vector<uint32_t> t1, t2;
-        constexpr int GT = 64;
+        std::vector<uint32_t> tall_q[8];
+        size_t tall_next = 0;
+        constexpr int GT = MF_GT;
         for (int32_t i = L.front_begin; i < L.front_end; ++i) {
             const auto& f = fr[level_fronts[i]];
             const uint32_t loc = (uint32_t)(i - L.front_begin);
@@ -1454,14 +1456,28 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
                 for (int tj = 0; tj < tb; ++tj) push(t1, loc, 0, ti, tj);  // tmpU (k x b)
             for (int ti = 0; ti < tb; ++ti)
                 for (int tj = 0; tj < tk; ++tj) push(t1, loc, 1, ti, tj);  // tmpL (b x k)
-            // (the interior of the Schur complement of a big front belongs to gemm2_tall_kernel: mf_kernels.h,
-            // gemm2_is_tall)
-            auto is_tall = [&](int ti, int tj) {
-                return k >= 512 && b >= 1024 && ((ti & ~1) + 2) * GT <= b && (tj + 1) * GT <= b;
-            };
+            // (the interior of the Schur complement of a big front goes out in tall tiles: mf_types.h)
+#ifdef SANM_MF_OLD_STAGING  // (A/B build without the tall tiles: every tile of the Schur complement in the GEMM-2 pass)
+            const bool tall_tiles = false;
+#else
+            const bool tall_tiles = true;
+#endif
             for (int ti = 0; ti < tb; ++ti)
                 for (int tj = 0; tj < tb; ++tj)
-                    if (!is_tall(ti, tj)) push(t2, loc, 0, ti, tj);
+                    if (!(tall_tiles && mf_gemm2_is_tall(k, b, ti, tj))) push(t2, loc, 0, ti, tj);
+            if (tall_tiles && mf_gemm2_is_tall(k, b, 0, 0)) {
+                // supertiles of tall tiles, dealt to the eight queues in turn
+                const int TR = b / (2 * GT), TC = b / GT;
+                for (int sr = 0; sr < TR; sr += MF_ST_R)
+                    for (int sc = 0; sc < TC; sc += MF_ST_C) {
+                        auto& q = tall_q[tall_next++ % 8];
+                        for (int tp = sr; tp < std::min(sr + MF_ST_R, TR); ++tp)
+                            for (int tj = sc; tj < std::min(sc + MF_ST_C, TC); ++tj) {
+                                q.push_back(loc);
+                                q.push_back((uint32_t)tp << 15 | (uint32_t)tj);
+                            }
+                    }
+            }
             if (!L.two_phase) {
                 for (int ti = 0; ti < tb; ++ti)
                     for (int tj = 0; tj < tk; ++tj) push(t2, loc, 1, ti, tj);
@@ -1473,6 +1489,22 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
         L.n_g2 = (int32_t)(t2.size() / 2);
         upload_to(L.g1_tiles, std::move(t1));
         upload_to(L.g2_tiles, std::move(t2));
+        {
+            // the eight queues interleaved: entry n of the list is entry n / 8 of queue n % 8 (a padding entry where
+            // that queue has run out)
+            size_t longest = 0;
+            for (const auto& q : tall_q) longest = std::max(longest, q.size() / 2);
+            std::vector<uint32_t> t3;
+            t3.reserve(longest * 16);
+            for (size_t i = 0; i < longest; ++i)
+                for (const auto& q : tall_q) {
+                    const bool have = 2 * i < q.size();
+                    t3.push_back(have ? q[2 * i] : ~0u);
+                    t3.push_back(have ? q[2 * i + 1] : 0u);
+                }
+            L.n_gt = (int32_t)(t3.size() / 2);
+            upload_to(L.gt_tiles, std::move(t3));
+        }
     }
 
     if (std::getenv("SANM_MF_DEBUG")) {

@@ -1,0 +1,30 @@
+#!/bin/bash
+# tall-tile lists + A/B of the zero-fill / assigned Schur blocks on one box     usage: gpu_r6e.sh <tag>
+set -u
+TAG=$1
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd $ROOT
+timeout 1200 python -m pytest tests/test_direct_solver.py -q -m gpu -x > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
+tail -3 $OUT/pytest_gpu.log
+run() {  # name, workload, steps, env...
+  local name=$1 wl=$2 steps=$3; shift 3
+  env "$@" timeout 600 python bench.py --workload $wl --steps $steps --warmup 1 --no-cpu-baseline --no-end-to-end --at-scale-workload none --at-scale-large-workload none > $OUT/$name.json 2> $OUT/$name.err
+  python - <<PY
+import json
+d=json.loads(open("$OUT/$name.json").read().strip().splitlines()[-1]); f=d["roofline_families"]
+print("$name", round(d["value"],3), round(d["ms_per_step"],2), {k: round(v["ms_per_step"],2) for k,v in f.items()}, "factor TF", round(f["factor"]["achieved_tflops"],2))
+PY
+}
+for rep in 1 2; do
+  run x8_new_$rep refine:armadillo_small:1 10 A=1
+  run x8_selective_$rep refine:armadillo_small:1 10 SANM_MF_SELECTIVE_ZERO=1
+  run x8_earows4_$rep refine:armadillo_small:1 10 SANM_MF_EA_ROWS=4
+done
+run x64_new refine:armadillo_small:2 3 A=1
+run x64_fullzero refine:armadillo_small:2 3 SANM_MF_FULL_ZERO=1
+run b48_new block:48 3 A=1
+run x64_earows4 refine:armadillo_small:2 3 SANM_MF_EA_ROWS=4
+run small_new armadillo_small 20 A=1
+run small_new2 armadillo_small 20 A=1

@@ -372,7 +372,9 @@ def test_selective_zero_fill_and_assigned_schur_blocks(api, monkeypatch, leaf):
         for k, v in extra.items():
             monkeypatch.setenv(k, v)
         sols = []
-        for mode in ({"SANM_MF_FULL_ZERO": "1"}, {}, {"SANM_MF_POISON": "1"}):
+        # (the selective path is the default from 16 GB of front storage on; forced here)
+        for mode in ({"SANM_MF_FULL_ZERO": "1"}, {"SANM_MF_SELECTIVE_ZERO": "1"}, {"SANM_MF_POISON": "1"},
+                     {"SANM_MF_SELECTIVE_ZERO": "1", "SANM_MF_EA_ROWS": "16"}):
             for k, v in mode.items():
                 monkeypatch.setenv(k, v)
             ds = DirectSolver(api, A, coords)
@@ -383,7 +385,7 @@ def test_selective_zero_fill_and_assigned_schur_blocks(api, monkeypatch, leaf):
             sols.append((x1, x2))
             for k in mode:
                 monkeypatch.delenv(k)
-        assert np.all(np.isfinite(sols[2][0])) and np.all(np.isfinite(sols[2][1]))
+        assert all(np.all(np.isfinite(x)) for s in sols for x in s)
         for s in sols[1:]:
             assert np.array_equal(s[0], sols[0][0]) and np.array_equal(s[1], sols[0][1])
         assert np.abs(A @ sols[0][0] - b).max() <= 1e-8 * np.abs(b).max()
