@@ -1470,9 +1470,6 @@ class HipBackend final : public Backend {
     hipStream_t m_stream = nullptr;  // the queue launches currently go to: m_main, or m_side between side_fork / side_end
     hipStream_t m_main = nullptr, m_side = nullptr;
     hipStream_t m_sf_queue[3] = {nullptr, nullptr, nullptr};  // size classes of small_front_kernel beside each other (mf_factor)
-    hipStream_t m_la_queue = nullptr;  // the tails of a level's Schur tiles beside the next level's panel chain (look-ahead)
-    hipEvent_t m_la_done = nullptr;
-    bool m_la_pending = false;
     bool m_side_dirty = false;  // the side queue got work since the last join / sync
     bool m_side_detached = false;  // ... and nothing waits for it before side_wait()
     static constexpr int kForkEvents = 64;
@@ -1669,8 +1666,6 @@ public:
         }
         for (hipStream_t q : m_sf_queue)
             if (q) (void)hipStreamDestroy(q);
-        if (m_la_queue) (void)hipStreamDestroy(m_la_queue);
-        if (m_la_done) (void)hipEventDestroy(m_la_done);
         (void)hipStreamDestroy(m_main);
     }
     const char* name() const override { return "hip"; }
@@ -2482,41 +2477,29 @@ public:
         const int outer_min_k = env_min_k ? std::atoi(env_min_k) : kOuterMinK;
         for (int li = l0; li < l1; ++li) {
             const auto& L = sch.levels[li];
-            // extend-add of the level's children, round by round (round r: the r-th child of every front).  what: 0 =
-            // everything; 1 = the HEADS only (what lands in the fronts' pivot rows and columns); 2 = the F[B,B] blocks
-            // only.  With the selective zero-fill round 0 ASSIGNS the F[B,B] blocks from the first children (every entry,
-            // so the block needs no zero-fill: schur_gather_kernel) and adds only the heads.
-            auto extend_add = [&](int what) {
+            for (size_t r = 0; r < L.ea_rounds.size(); ++r) {
+                int cnt = L.ea_rounds[r].second - L.ea_rounds[r].first;
+                int64_t mb = L.ea_max_b[r];
+                if (cnt == 0) continue;
+                // round 0: the parents' F[B,B] blocks are ASSIGNED from their first children (every entry, so the block
+                // needs no zero-fill), what lands in their pivot rows and columns is added as in the later rounds
+                const bool assign0 = r == 0 && selective;
                 // (rows of a Schur complement per workgroup: EA_ROWS.  More rows per workgroup on the levels of thousands of
                 // small fronts -- fewer, longer workgroups -- measured slower, 13.24 against 13.10 ms per factorisation at
                 // 338 k tets, 222.8 against 220.7 at 2.7 M: SANM_MF_EA_ROWS for the experiment)
                 static const int env_ea_rows = std::getenv("SANM_MF_EA_ROWS") ? std::atoi(std::getenv("SANM_MF_EA_ROWS")) : 0;
-                const int rw = env_ea_rows > 0 ? (env_ea_rows + EA_ROWS - 1) / EA_ROWS * EA_ROWS : EA_ROWS;
-                for (size_t r = 0; r < L.ea_rounds.size(); ++r) {
-                    const int cnt = L.ea_rounds[r].second - L.ea_rounds[r].first;
-                    const int64_t mb = L.ea_max_b[r];
-                    if (cnt == 0) continue;
-                    const int32_t* ch = sch.ea_children + L.ea_rounds[r].first;
-                    const bool assign0 = r == 0 && selective;
-                    if (assign0 && what != 1 && L.ea0_max_bp > 0)
-                        SANM_LAUNCH(schur_gather_kernel, dim3((unsigned)((L.ea0_max_bp + rw - 1) / rw), cnt), dim3(256), 0, m_stream,
-                                    mf.fronts, mf.front_store, sch.ea_inv, ch, rw);
-                    // which part of the round the adding kernel takes: the heads when the blocks are assigned or left to
-                    // a later call, the blocks alone, or all of it
-                    int part = what;
-                    if (assign0) part = what == 2 ? -1 : 1;
-                    if (part >= 0 && mb > 0)
-                        SANM_LAUNCH(extend_add_kernel, dim3((unsigned)((mb + rw - 1) / rw), cnt), dim3(256), 0, m_stream, mf.fronts,
-                                    mf.front_store, mf.rel, ch, part, rw);
+                auto rows_per_wg = [&](int64_t) { return env_ea_rows > 0 ? (env_ea_rows + EA_ROWS - 1) / EA_ROWS * EA_ROWS : EA_ROWS; };
+                if (assign0 && L.ea0_max_bp > 0) {
+                    const int rw = rows_per_wg(L.ea0_max_bp);
+                    SANM_LAUNCH(schur_gather_kernel, dim3((unsigned)((L.ea0_max_bp + rw - 1) / rw), cnt), dim3(256), 0, m_stream,
+                                mf.fronts, mf.front_store, sch.ea_inv, sch.ea_children + L.ea_rounds[r].first, rw);
                 }
-            };
-            // LOOK-AHEAD (mf_types.h, Level::n_g2_head): the tails of the previous level's Schur tiles may still be running
-            // on the side queue; only this level's F[B,B] blocks need them (tails_join).
-            auto tails_join = [&] {
-                if (!m_la_pending) return;
-                HIP_CHECK(hipStreamWaitEvent(m_stream, m_la_done, 0));
-                m_la_pending = false;
-            };
+                if (mb > 0) {
+                    const int rw = rows_per_wg(mb);
+                    SANM_LAUNCH(extend_add_kernel, dim3((unsigned)((mb + rw - 1) / rw), cnt), dim3(256), 0, m_stream, mf.fronts,
+                                mf.front_store, mf.rel, sch.ea_children + L.ea_rounds[r].first, (int)assign0, rw);
+                }
+            }
             const int nfront = L.front_end - L.front_begin;
             // levels of many small fronts: the whole factorisation of a front in one workgroup (mf_kernels.h,
             // small_front_kernel) instead of the panel chain and the two GEMM passes.  SANM_MF_SMALL_MIN_FRONTS: from how
@@ -2524,8 +2507,6 @@ public:
             const char* env_small = std::getenv("SANM_MF_SMALL_MIN_FRONTS");
             const int small_min = env_small ? std::atoi(env_small) : kSmallMinFronts;
             if (small_min > 0 && nfront >= small_min && L.max_k <= SF_KMAX && !L.two_phase) {
-                tails_join();
-                extend_add(0);
                 // The pivot block's LDS decides how many fronts a compute unit works on at a time: the level's fronts
                 // are sorted by decreasing pivot count (MfSchedule), so they go out in up to three launches by size
                 // class -- k <= 96 (77 KB: two workgroups per unit), k <= 64 (34 KB: four), k <= 44 (the GEMM
@@ -2574,17 +2555,6 @@ public:
                     HIP_CHECK(hipStreamWaitEvent(home, e, 0));
                 }
                 continue;
-            }
-            static const bool no_lists = std::getenv("SANM_MF_NO_TILE_LISTS") != nullptr;  // (A/B: the box grids)
-            // (read per factorisation: tests switch it)
-            const bool lookahead = !no_lists && L.g2_tiles && !std::getenv("SANM_MF_NO_LOOKAHEAD");
-            // (the extend-add is split only while tails are in flight: two launches per round instead of one)
-            const bool split_ea = lookahead && m_la_pending;
-            if (split_ea) {
-                extend_add(1);  // the heads: all the pivot block, the panel chain and the triangular products need
-            } else {
-                tails_join();
-                extend_add(0);
             }
             const int nt = (2 * L.max_k + NB - 1) / NB;  // pivot + augmentation block
             // augmentation tiles of a panel: at most ceil(k / NB) + 1 per side
@@ -2639,75 +2609,33 @@ public:
                 const int tmax = std::max(tb, tk);
                 // (two-phase levels: the triangular products are the boundary operators, products 1 and 2 left out)
                 const int nwhich = L.two_phase ? 1 : 3;
+                static const bool no_lists = std::getenv("SANM_MF_NO_TILE_LISTS") != nullptr;  // (A/B: the box grids)
                 if (!no_lists && L.g1_tiles) {
                     if (L.n_g1 > 0)
                         SANM_LAUNCH(gemm1_list_kernel, dim3(L.n_g1), dim3(256), 0, m_stream, MF_FACTOR_ARGS(mf, L.front_begin),
                                     L.g1_tiles, (int)L.two_phase);
-                    if (split_ea) {
-                        // the children's tails, then this level's F[B,B] blocks
-                        tails_join();
-                        extend_add(2);
-                    }
-                    // Fork?  The tails (and the boundary operators of the solve) go to the side queue beside the next
-                    // level's extend-add of the heads, panel chain and triangular products when they are work enough to pay
-                    // for the split launches (mf_types.h, Level::tail_flops)
-                    const char* env_la = std::getenv("SANM_MF_LOOKAHEAD_MIN_GF");  // (read per factorisation: tests switch it)
-                    const double la_min_flops = (env_la ? std::atof(env_la) : 20.0) * 1e9;
-                    const bool fork = lookahead && li + 1 < l1 && L.tail_flops >= la_min_flops && L.n_g2 + L.n_gt > L.n_g2_head + L.n_gt_head;
-                    // the HEAD tiles of the Schur complements on this queue (everything when there is no fork): the next
-                    // level's pivot blocks wait for them.  Big fronts in 128 x 64 tiles, a flat list in an order that keeps
-                    // an XCD's workgroups on shared panels (mf_types.h, MF_ST_R)
-                    const int n2h = fork ? L.n_g2_head : L.n_g2, nth = fork ? L.n_gt_head : L.n_gt;
-#ifndef SANM_MF_OLD_STAGING
-                    if (nth > 0)
-                        SANM_LAUNCH(gemm2_tall_list_kernel, dim3(nth), dim3(256), 0, m_stream,
-                                    MF_FACTOR_ARGS(mf, L.front_begin), L.gt_tiles);
-#endif
-                    if (n2h > 0)
-                        SANM_LAUNCH(gemm2_list_kernel, dim3(n2h), dim3(256), 0, m_stream, MF_FACTOR_ARGS(mf, L.front_begin),
+                    if (L.n_g2 > 0)
+                        SANM_LAUNCH(gemm2_list_kernel, dim3(L.n_g2), dim3(256), 0, m_stream, MF_FACTOR_ARGS(mf, L.front_begin),
                                     L.g2_tiles, (int)L.fwd_t);
-                    const int n2t = L.n_g2 - n2h, ntt = L.n_gt - nth;
-                    hipStream_t home = m_stream;
-                    if (fork) {
-                        if (!m_la_queue) HIP_CHECK(hipStreamCreateWithFlags(&m_la_queue, hipStreamNonBlocking));
-                        hipEvent_t e = next_fork_event();
-                        HIP_CHECK(hipEventRecord(e, home));
-                        HIP_CHECK(hipStreamWaitEvent(m_la_queue, e, 0));
-                        m_stream = m_la_queue;
-                    }
-#ifndef SANM_MF_OLD_STAGING
-                    if (ntt > 0)
-                        SANM_LAUNCH(gemm2_tall_list_kernel, dim3(ntt), dim3(256), 0, m_stream, MF_FACTOR_ARGS(mf, L.front_begin),
-                                    L.gt_tiles + 2 * (size_t)nth);
-#endif
-                    if (n2t > 0)
-                        SANM_LAUNCH(gemm2_list_kernel, dim3(n2t), dim3(256), 0, m_stream, MF_FACTOR_ARGS(mf, L.front_begin),
-                                    L.g2_tiles + 2 * (size_t)n2h, (int)L.fwd_t);
-                    if (fork) {
-                        if (!m_la_done) HIP_CHECK(hipEventCreateWithFlags(&m_la_done, hipEventDisableTiming));
-                        HIP_CHECK(hipEventRecord(m_la_done, m_la_queue));
-                        m_la_pending = true;
-                        m_stream = home;
-                    }
                 } else {
-                    SANM_LAUNCH(gemm1_kernel, dim3(tmax, tmax, 2 * nfr), dim3(256), 0, m_stream,
-                                       MF_FACTOR_ARGS(mf, L.front_begin), (int)L.two_phase);
-                    SANM_LAUNCH(gemm2_kernel, dim3(tmax, tmax, nwhich * nfr), dim3(256), 0, m_stream,
-                                       MF_FACTOR_ARGS(mf, L.front_begin), nwhich, (int)L.fwd_t);
-#ifndef SANM_MF_OLD_STAGING
-                    if (L.max_k >= mfk::kTallMinK && L.max_b >= mfk::kTallMinB)
-                        SANM_LAUNCH(gemm2_tall_kernel, dim3(tmax, (tmax + 1) / 2, nfr), dim3(256), 0, m_stream,
-                                    MF_FACTOR_ARGS(mf, L.front_begin));
-#endif
+                SANM_LAUNCH(gemm1_kernel, dim3(tmax, tmax, 2 * nfr), dim3(256), 0, m_stream,
+                                   MF_FACTOR_ARGS(mf, L.front_begin), (int)L.two_phase);
+                SANM_LAUNCH(gemm2_kernel, dim3(tmax, tmax, nwhich * nfr), dim3(256), 0, m_stream,
+                                   MF_FACTOR_ARGS(mf, L.front_begin), nwhich, (int)L.fwd_t);
                 }
-            } else if (split_ea) {
-                tails_join();  // (a level without boundaries: roots; nothing of it reads the children's tails, but whoever
-                extend_add(2); //  comes next expects them done)
+#ifndef SANM_MF_OLD_STAGING
+                // big fronts: the interior of the Schur complement in 128 x 64 tiles, a flat list of the tiles that exist
+                // in an order that keeps an XCD's workgroups on shared panels (mf_types.h, MF_ST_R)
+                if (!no_lists && L.gt_tiles) {
+                    if (L.n_gt > 0)
+                        SANM_LAUNCH(gemm2_tall_list_kernel, dim3(L.n_gt), dim3(256), 0, m_stream,
+                                    MF_FACTOR_ARGS(mf, L.front_begin), L.gt_tiles);
+                } else if (L.max_k >= mfk::kTallMinK && L.max_b >= mfk::kTallMinB) {
+                    SANM_LAUNCH(gemm2_tall_kernel, dim3(tmax, (tmax + 1) / 2, nfr), dim3(256), 0, m_stream,
+                                MF_FACTOR_ARGS(mf, L.front_begin));
+                }
+#endif
             }
-        }
-        if (m_la_pending) {  // (the last level's tails: whoever comes next -- an exchange, the solve -- expects them done)
-            HIP_CHECK(hipStreamWaitEvent(m_stream, m_la_done, 0));
-            m_la_pending = false;
         }
         if (epilogue && sch.top.enabled) {  // the top of the tree as one dense operator (mf_kernels.h)
             const auto& T = sch.top;

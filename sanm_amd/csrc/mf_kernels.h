@@ -118,14 +118,12 @@ __global__ void __launch_bounds__(256) schur_gather_kernel(const MfFrontDev* __r
 // element, one load in flight per lane and a grid sized for the largest child of the round -- 225 GB/s on the
 // 0.5 M-tet block, 16 of the 255 ms of a step.  Here a thread keeps EA_ROWS independent read-modify-writes per
 // column in flight and rel[j] is read once per column for all of them.)
-// part: 0 = every entry; 1 = only what lands in the parent's pivot rows or columns (the HEAD of the child's Schur
-// complement: all the parent's panel chain waits for); 2 = only what lands in the parent's F[B,B].  rel is ascending, so
-// the parent's boundary block starts at the first row / column at or beyond its 2k: part 1 stops a row block that lies
-// wholly there at that column, part 2 skips row blocks and columns before it.  The parts of one round touch disjoint
-// entries: splitting a round changes no sum.
+// skip_bb (round 0): the entries that land in the parent's F[B,B] are left to schur_gather_kernel -- rel is ascending,
+// so those are the rows and columns from the first one at or beyond the parent's 2k on: a row block wholly there only
+// walks the columns before it.
 __global__ void __launch_bounds__(256) extend_add_kernel(const MfFrontDev* __restrict__ fronts_, double* front_store_,
                                                          const int32_t* __restrict__ rel_,
-                                                         const int32_t* __restrict__ children, int part,
+                                                         const int32_t* __restrict__ children, int skip_bb,
                                                          int rows_per_wg) {
     const MfFrontDev c = fronts_[children[blockIdx.y]];
     const int nb = c.m - c.k;
@@ -135,24 +133,21 @@ __global__ void __launch_bounds__(256) extend_add_kernel(const MfFrontDev* __res
     const int32_t* __restrict__ rel = rel_ + c.rel_off;
     const double* src = front_store_ + c.off + (int64_t)(2 * c.k) * c.ld + 2 * c.k;
     double* dst = front_store_ + p.off;
-    const int pb = part ? 2 * p.k : INT_MAX;  // first physical row / column of the parent's boundary block
+    const int pb = skip_bb ? 2 * p.k : INT_MAX;  // first physical row / column of the parent's boundary block
     for (int i0 = ib; i0 < min(ib + rows_per_wg, nb); i0 += EA_ROWS) {
         int64_t drow[EA_ROWS];
-        bool rb[EA_ROWS], all_b = true, any_b = false;
+        bool rb[EA_ROWS], all_b = true;
 #pragma unroll
         for (int q = 0; q < EA_ROWS; ++q) {
             const int rr = rel[min(i0 + q, nb - 1)];
             drow[q] = (int64_t)rr * p.ld;
             rb[q] = rr >= pb;
             all_b = all_b && rb[q];
-            any_b = any_b || rb[q];
         }
-        if (part == 2 && !any_b) continue;
         for (int j = threadIdx.x; j < nb; j += 256) {
             const int rj = rel[j];
             const bool cb = rj >= pb;
-            if (part == 1 && cb && all_b) break;  // (ascending: every later column is in the boundary block as well)
-            if (part == 2 && !cb) continue;
+            if (cb && all_b) break;  // (ascending: every later column is in the boundary block as well)
             double v[EA_ROWS], d[EA_ROWS];
 #pragma unroll
             for (int q = 0; q < EA_ROWS; ++q) {
@@ -160,10 +155,8 @@ __global__ void __launch_bounds__(256) extend_add_kernel(const MfFrontDev* __res
                 d[q] = dst[drow[q] + rj];
             }
 #pragma unroll
-            for (int q = 0; q < EA_ROWS; ++q) {
-                const bool in_bb = cb && rb[q];
-                if (i0 + q < nb && (part == 0 || (part == 1) != in_bb)) dst[drow[q] + rj] = d[q] + v[q];
-            }
+            for (int q = 0; q < EA_ROWS; ++q)
+                if (i0 + q < nb && !(cb && rb[q])) dst[drow[q] + rj] = d[q] + v[q];
         }
     }
 }

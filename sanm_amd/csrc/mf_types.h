@@ -131,17 +131,6 @@ struct MfSchedule {
         const uint32_t* g2_tiles = nullptr;
         const uint32_t* gt_tiles = nullptr;  // tall tiles (front or ~0u for a padding entry, tp << 15 | tj)
         int32_t n_g1 = 0, n_g2 = 0, n_gt = 0;
-        // LOOK-AHEAD (round 6): the first n_g2_head / n_gt_head entries of g2_tiles / gt_tiles are the tiles of the Schur
-        // complements' HEADS -- rows or columns that are pivots of the front's parent; the parent's pivot block, panel
-        // chain and triangular products need nothing else of its children.  The rest (the tails, and the boundary
-        // operators of the solve) runs on a queue of its own beside the next level's extend-add of the heads, its panel
-        // chain and its triangular products, and is waited for before that level's F[B,B] blocks are assembled
-        // (backend_hip.hip, mf_factor_levels; SANM_MF_NO_LOOKAHEAD=1: one queue, same order, same bits).  Measured on one
-        // box: 2.7 M tets 231.4 -> 227.0 ms per factorisation, block:48 134.1 -> 129.7; the split costs launches, so
-        // levels with less than 20 GFLOP of tails keep one queue (338 k tets 13.54 -> 13.72, armadillo_small 1.89 -> 2.08
-        // ms with every level forked; SANM_MF_LOOKAHEAD_MIN_GF moves the threshold, 0: every level).
-        int32_t n_g2_head = 0, n_gt_head = 0;
-        double tail_flops = 0;  // of the tails' Schur tiles: the look-ahead pays from ~20 GFLOP per level on
         // extend-add rounds: round r holds the r-th child of every front of the
         // level; [begin,end) into ea_children
         std::vector<std::pair<int32_t, int32_t>> ea_rounds;

@@ -1407,9 +1407,6 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
             L.fwd_t = want && !L.two_phase && L.max_k <= fwd_t_max_k && rows_enough && L.max_b > 0 && !std::getenv("SANM_MF_TOP");
         }
         {
-            // (offsets inside the level's half of the workspace: consecutive levels alternate between two halves, because
-            // the tail of a level's Schur tiles still reads its products while the next level forms its own -- the
-            // look-ahead of mf_types.h; the halves' offset is added below, once their size is known)
             int64_t t = 0;
             for (int32_t f : fs) {
                 fr[f].tmp_off = t;
@@ -1437,27 +1434,12 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
             if (!children[f].empty()) L.ea0_max_bp = std::max(L.ea0_max_bp, fr[f].m - fr[f].k);
     }
 
-    for (int32_t h = 1; h < H; h += 2)
-        for (int32_t i = m_sched.levels[h].front_begin; i < m_sched.levels[h].front_end; ++i)
-            fr[level_fronts[i]].tmp_off += tmp_doubles;
-    tmp_doubles *= 2;
-    // head of a front's Schur complement: its first head_b[f] boundary rows / columns are pivots of its parent (the
-    // boundary is in elimination order and the parent's own variables come first) -- what the parent's pivot block, its
-    // panel chain and triangular products wait for
-    std::vector<int32_t> head_b(F, 0);
-    for (int32_t f = 0; f < F; ++f) {
-        if (parent[f] < 0) continue;
-        const int32_t kp = fr[parent[f]].k, b = fr[f].m - fr[f].k;
-        int32_t hcount = 0;
-        while (hcount < b && rel[fr[f].rel_off + hcount] < kp) ++hcount;
-        head_b[f] = hcount;
-    }
     // tile lists of the GEMM passes (mf_types.h, Level::g1_tiles / g2_tiles)
     for (int32_t h = 0; h < H; ++h) {
         auto& L = m_sched.levels[h];
-        std::vector<uint32_t> t1, t2, t2_tail;
-        std::vector<uint32_t> tall_q[2][8];  // [head / tail][queue]
-        size_t tall_next[2] = {0, 0};
+        std::vector<uint32_t> t1, t2;
+        std::vector<uint32_t> tall_q[8];
+        size_t tall_next = 0;
         constexpr int GT = MF_GT;
         for (int32_t i = L.front_begin; i < L.front_end; ++i) {
             const auto& f = fr[level_fronts[i]];
@@ -1480,61 +1462,46 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
 #else
             const bool tall_tiles = true;
 #endif
-            // head tiles (what the parent's pivot rows and columns receive) first, the tail behind them: the tail may run
-            // on a queue of its own beside the next level's panel chain (mf_types.h, Level::n_g2_head)
-            const int hb = head_b[level_fronts[i]];
-            auto is_head = [&](int r0, int c0) { return r0 < hb || c0 < hb; };
             for (int ti = 0; ti < tb; ++ti)
                 for (int tj = 0; tj < tb; ++tj)
-                    if (!(tall_tiles && mf_gemm2_is_tall(k, b, ti, tj))) {
-                        const bool hd = is_head(ti * GT, tj * GT);
-                        push(hd ? t2 : t2_tail, loc, 0, ti, tj);
-                        if (!hd) L.tail_flops += 2.0 * GT * GT * k;
-                    }
+                    if (!(tall_tiles && mf_gemm2_is_tall(k, b, ti, tj))) push(t2, loc, 0, ti, tj);
             if (tall_tiles && mf_gemm2_is_tall(k, b, 0, 0)) {
-                // supertiles of tall tiles, dealt to the eight queues in turn (head and tail tiles to queues of their own)
+                // supertiles of tall tiles, dealt to the eight queues in turn
                 const int TR = b / (2 * GT), TC = b / GT;
                 for (int sr = 0; sr < TR; sr += MF_ST_R)
                     for (int sc = 0; sc < TC; sc += MF_ST_C) {
-                        const size_t q0 = tall_next[0]++ % 8, q1 = tall_next[1]++ % 8;
+                        auto& q = tall_q[tall_next++ % 8];
                         for (int tp = sr; tp < std::min(sr + MF_ST_R, TR); ++tp)
                             for (int tj = sc; tj < std::min(sc + MF_ST_C, TC); ++tj) {
-                                const bool hd = is_head(tp * 2 * GT, tj * GT);
-                                auto& q = hd ? tall_q[0][q0] : tall_q[1][q1];
-                                if (!hd) L.tail_flops += 4.0 * GT * GT * k;
                                 q.push_back(loc);
                                 q.push_back((uint32_t)tp << 15 | (uint32_t)tj);
                             }
                     }
             }
-            if (!L.two_phase) {  // (the boundary operators of the solve: nobody waits for them before the solve)
+            if (!L.two_phase) {
                 for (int ti = 0; ti < tb; ++ti)
-                    for (int tj = 0; tj < tk; ++tj) push(t2_tail, loc, 1, ti, tj);
+                    for (int tj = 0; tj < tk; ++tj) push(t2, loc, 1, ti, tj);
                 for (int ti = 0; ti < tk; ++ti)
-                    for (int tj = 0; tj < tb; ++tj) push(t2_tail, loc, 2, ti, tj);
+                    for (int tj = 0; tj < tb; ++tj) push(t2, loc, 2, ti, tj);
             }
         }
         L.n_g1 = (int32_t)(t1.size() / 2);
-        L.n_g2_head = (int32_t)(t2.size() / 2);
-        t2.insert(t2.end(), t2_tail.begin(), t2_tail.end());
         L.n_g2 = (int32_t)(t2.size() / 2);
         upload_to(L.g1_tiles, std::move(t1));
         upload_to(L.g2_tiles, std::move(t2));
         {
-            // the eight queues interleaved: entry n of a part is entry n / 8 of queue n % 8 (a padding entry where that
-            // queue has run out); the head part first
+            // the eight queues interleaved: entry n of the list is entry n / 8 of queue n % 8 (a padding entry where
+            // that queue has run out)
+            size_t longest = 0;
+            for (const auto& q : tall_q) longest = std::max(longest, q.size() / 2);
             std::vector<uint32_t> t3;
-            for (int part = 0; part < 2; ++part) {
-                size_t longest = 0;
-                for (const auto& q : tall_q[part]) longest = std::max(longest, q.size() / 2);
-                for (size_t i = 0; i < longest; ++i)
-                    for (const auto& q : tall_q[part]) {
-                        const bool have = 2 * i < q.size();
-                        t3.push_back(have ? q[2 * i] : ~0u);
-                        t3.push_back(have ? q[2 * i + 1] : 0u);
-                    }
-                if (part == 0) L.n_gt_head = (int32_t)(t3.size() / 2);
-            }
+            t3.reserve(longest * 16);
+            for (size_t i = 0; i < longest; ++i)
+                for (const auto& q : tall_q) {
+                    const bool have = 2 * i < q.size();
+                    t3.push_back(have ? q[2 * i] : ~0u);
+                    t3.push_back(have ? q[2 * i + 1] : 0u);
+                }
             L.n_gt = (int32_t)(t3.size() / 2);
             upload_to(L.gt_tiles, std::move(t3));
         }

@@ -350,9 +350,7 @@ def test_selective_zero_fill_and_assigned_schur_blocks(api, monkeypatch, leaf):
     ASSIGNED by round 0 of the extend-add (schur_gather_kernel), a front without children writes its Schur complement
     without reading the block.  Same bits as the memset of the whole storage (SANM_MF_FULL_ZERO=1), also when the
     storage is filled with NaNs first (SANM_MF_POISON=1: nothing unwritten is read), with the small-front kernel, the
-    panel chain, two-phase levels and chains of cut fronts, over two factorisations on the same storage -- and with the
-    LOOK-AHEAD of the factorisation (the tails of a level's Schur tiles on a side queue beside the next level's panel
-    chain, the extend-add split into heads and F[B,B] blocks) forced onto every level and switched off.  (The host
+    panel chain, two-phase levels and chains of cut fronts, over two factorisations on the same storage.  (The host
     harness zeroes everything and adds: its own results are the reference the other tests hold the device to.)"""
     mesh = ofea.make_cuboid(9, 5, 4, 0.02)
     fixed = np.zeros((mesh.nr_vertices, 3), bool)
@@ -376,10 +374,7 @@ def test_selective_zero_fill_and_assigned_schur_blocks(api, monkeypatch, leaf):
         sols = []
         # (the selective path is the default from 16 GB of front storage on; forced here)
         for mode in ({"SANM_MF_FULL_ZERO": "1"}, {"SANM_MF_SELECTIVE_ZERO": "1"}, {"SANM_MF_POISON": "1"},
-                     {"SANM_MF_SELECTIVE_ZERO": "1", "SANM_MF_EA_ROWS": "16"},
-                     # the look-ahead at every level (by default from 20 GFLOP of tails per level on): same bits
-                     {"SANM_MF_LOOKAHEAD_MIN_GF": "0"}, {"SANM_MF_LOOKAHEAD_MIN_GF": "0", "SANM_MF_SELECTIVE_ZERO": "1"},
-                     {"SANM_MF_NO_LOOKAHEAD": "1"}):
+                     {"SANM_MF_SELECTIVE_ZERO": "1", "SANM_MF_EA_ROWS": "16"}):
             for k, v in mode.items():
                 monkeypatch.setenv(k, v)
             ds = DirectSolver(api, A, coords)
