@@ -1845,7 +1845,7 @@ public:
     void h2d(void* dst, const void* src, size_t bytes) override {
         if (!bytes) return;
         static const bool direct = std::getenv("SANM_H2D_DIRECT") != nullptr;
-        if (direct) {
+        if (direct || bytes <= 4096) {  // (scalars and short tables: the runtime stages those itself, as in d2h)
             HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, m_stream));
             HIP_CHECK(hipStreamSynchronize(m_stream));
             return;
@@ -2769,8 +2769,18 @@ public:
             SANM_FS(8, 4) SANM_FS(16, 4) SANM_FS(32, 4)
 #undef SANM_FS
         }
+        // U preloaded chunks per row: enough for the level's TYPICAL row, not its longest (the chunks beyond run in the
+        // kernels' tail loop, same sums in the same order) -- on a leaf level of 2572 fronts whose rows average 143 entries
+        // and peak at 303, U = 8 for the longest row issued 16 loads per lane of which 5 were in range and left R = 2 rows
+        // per wavefront.  Alternating runs on one box (profiles/r06_ab_solve.md): solves 10.16 -> 9.63 ms per step at 338 k
+        // tets, 106.8 -> 100.3 at 2.7 M, 2.12 -> 2.07 on armadillo_small.  SANM_MF_LS_WIDTH: the factor on the average row
+        // (default 1.25; 0: the longest row, as rounds 1-5).
+        static const double ls_wf = std::getenv("SANM_MF_LS_WIDTH") ? std::atof(std::getenv("SANM_MF_LS_WIDTH")) : 1.25;
+        const int cntf = L.front_end - L.front_begin;
+        const double avg_w = fwd ? (double)L.sum_k / cntf : (phase == 0 ? (double)L.sum_m / cntf : (phase == 1 ? (double)(L.sum_m - L.sum_k) / cntf : (double)L.sum_k / cntf));
+        const int wsel = ls_wf > 0 ? std::min(width, std::max(64, (int)(ls_wf * avg_w))) : width;
         int u = 1;
-        while (u < 16 && 64 * u < width) u *= 2;
+        while (u < 16 && 64 * u < wsel) u *= 2;
         // R * U <= 16 row chunks in registers, and enough workgroups to fill the chip (measured: more than
         // 4 rows per wavefront never paid, even on the leaf level)
         int r = rows >= 16 * 2048 ? 4 : (rows >= 8 * 2048 ? 2 : 1);

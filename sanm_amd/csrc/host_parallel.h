@@ -8,13 +8,14 @@
 #include <cstdint>
 #include <cstdlib>
 #include <memory>
+#include <system_error>
 #include <thread>
 #include <vector>
 
 namespace sanm_hip {
 inline int host_thread_cap() {
+    // (SANM_MF_ND_THREADS is the dissection's own budget, multifrontal.cpp: it no longer caps every setup loop)
     const char* env_thr = std::getenv("SANM_HOST_THREADS");
-    if (!env_thr) env_thr = std::getenv("SANM_MF_ND_THREADS");  // the name of round 5's first version
     if (env_thr) return std::min(64, std::max(1, std::atoi(env_thr)));
     // the host's threads are shared by the ranks of a node (torchrun's LOCAL_WORLD_SIZE, else WORLD_SIZE)
     unsigned ranks = 1;
@@ -27,6 +28,26 @@ inline int host_thread_cap() {
     return (int)std::min(16u, std::max(1u, hw / ranks));
 }
 
+//! threads that are joined when the scope ends, whatever ends it (a std::thread that is still joinable when it is
+//! destroyed terminates the process: a throwing emplace_back -- thread limits of a container -- or a throwing piece of
+//! work on the calling thread would otherwise do that inside a library constructor)
+struct JoinedThreads {
+    std::vector<std::thread> th;
+    ~JoinedThreads() {
+        for (auto& x : th)
+            if (x.joinable()) x.join();
+    }
+    //! start fn on a thread of its own; when the system refuses one, run it here
+    template <class F>
+    void run(F&& fn) {
+        try {
+            th.emplace_back(fn);
+        } catch (const std::system_error&) {
+            fn();
+        }
+    }
+};
+
 //! fn(begin, end, thread) over nt <= cap ranges of at least min_per_thread elements; fn must not throw
 template <class F>
 void parallel_ranges(int64_t n, int64_t min_per_thread, F&& fn) {
@@ -35,10 +56,9 @@ void parallel_ranges(int64_t n, int64_t min_per_thread, F&& fn) {
         fn(0, n, 0);
         return;
     }
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; ++t) th.emplace_back([&, t] { fn(n * t / nt, n * (t + 1) / nt, t); });
+    JoinedThreads jt;
+    for (int t = 1; t < nt; ++t) jt.run([&, t] { fn(n * t / nt, n * (t + 1) / nt, t); });
     fn(0, n / nt, 0);
-    for (auto& x : th) x.join();
 }
 
 //! std::sort by pieces on the threads of parallel_ranges, merged pairwise.  cmp must be a strict TOTAL order (break
@@ -54,18 +74,18 @@ void parallel_sort(It first, It last, Cmp cmp, int64_t min_per_thread = 4096) {
     std::vector<int64_t> cut(nt + 1);
     for (int t = 0; t <= nt; ++t) cut[t] = n * t / nt;
     {
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t) th.emplace_back([&, t] { std::sort(first + cut[t], first + cut[t + 1], cmp); });
+        JoinedThreads jt;
+        for (int t = 1; t < nt; ++t) jt.run([&, t] { std::sort(first + cut[t], first + cut[t + 1], cmp); });
         std::sort(first + cut[0], first + cut[1], cmp);
-        for (auto& x : th) x.join();
     }
     while (cut.size() > 2) {
         const int64_t pairs = (int64_t)(cut.size() - 1) / 2;
-        std::vector<std::thread> th;
-        for (int64_t p = 1; p < pairs; ++p)
-            th.emplace_back([&, p] { std::inplace_merge(first + cut[2 * p], first + cut[2 * p + 1], first + cut[2 * p + 2], cmp); });
-        std::inplace_merge(first + cut[0], first + cut[1], first + cut[2], cmp);
-        for (auto& x : th) x.join();
+        {
+            JoinedThreads jt;
+            for (int64_t p = 1; p < pairs; ++p)
+                jt.run([&, p] { std::inplace_merge(first + cut[2 * p], first + cut[2 * p + 1], first + cut[2 * p + 2], cmp); });
+            std::inplace_merge(first + cut[0], first + cut[1], first + cut[2], cmp);
+        }
         std::vector<int64_t> next;
         for (size_t i = 0; i < cut.size(); i += 2) next.push_back(cut[i]);
         if (next.back() != n) next.push_back(n);

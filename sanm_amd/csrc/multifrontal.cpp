@@ -519,11 +519,10 @@ public:
                 for (int i = 0; i < count; ++i) fn(i);
                 return;
             }
-            std::vector<std::thread> th;
+            JoinedThreads jt;
             for (int t = 1; t < nt; ++t)
-                th.emplace_back([&, t] { for (int i = t; i < count; i += nt) fn(i); });
+                jt.run([&, t] { for (int i = t; i < count; i += nt) fn(i); });
             for (int i = 0; i < count; i += nt) fn(i);
-            for (auto& x : th) x.join();
         };
         spread(nk, sort_key);
         spread(nk * nf, weigh);

@@ -241,10 +241,9 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
         }
     };
     {
-        std::vector<std::thread> th;
-        for (int t = 1; t < nthread; ++t) th.emplace_back(build, t);
+        JoinedThreads jt;
+        for (int t = 1; t < nthread; ++t) jt.run([&, t] { build(t); });
         build(0);
-        for (auto& x : th) x.join();
     }
     for (const Part& P : parts) sanm_check(P.error.empty(), "%s", P.error.c_str());
     laps.lap("rows");
@@ -265,11 +264,10 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
             for (size_t r = 0; r < P.row_nnz.size(); ++r, ++i) rowptr[i + 1] = rowptr[i] + P.row_nnz[r];
             m_nr_contrib += P.contrib;
         }
-        std::vector<std::thread> th;
+        JoinedThreads jt;
         for (int t = 1; t < nthread; ++t)
-            th.emplace_back([&, t] { std::copy(parts[t].col.begin(), parts[t].col.end(), col.begin() + part_off[t]); });
+            jt.run([&, t] { std::copy(parts[t].col.begin(), parts[t].col.end(), col.begin() + part_off[t]); });
         std::copy(parts[0].col.begin(), parts[0].col.end(), col.begin());
-        for (auto& x : th) x.join();
     }
     laps.lap("merge");
     m_n = n, m_T = T, m_tet_begin = tet_begin, m_tet_end = tet_end, m_odim = odim, m_idim = idim;
