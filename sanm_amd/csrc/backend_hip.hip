@@ -1616,6 +1616,8 @@ public:
         HIP_CHECK(hipHostMalloc(&m_scalar_host, 64));
     }
     void forget_chains(const void* key) override {
+        m_cur_sch = nullptr;
+        forget_solve_blocks(key);
         for (auto it = m_chains.begin(); it != m_chains.end();) {
             if (it->first.first == key) {
                 if (it->second.exec) {
@@ -2656,6 +2658,56 @@ public:
 
     // Level solve kernels are instantiated for R rows per wave and U preloaded 64-column chunks per row
     // with R * U == 16: U covers the level's widest row where it can, R takes what is left.
+    // ---- flat block lists of the solve launches (mf_types.h, MfSolveBlock): made on first use from the schedule's host
+    //      copy of the level's descriptors, kept until the solver goes (forget_chains)
+    struct SolveBlocks {
+        const void* owner;  // MfDev::front_store of the solver the level belongs to
+        MfSolveBlock* dev;
+        int count;
+    };
+    std::map<std::tuple<const void*, int, int>, SolveBlocks> m_solve_blocks;  // (level, kind, parameter)
+    const MfSchedule* m_cur_sch = nullptr;  // the schedule whose levels are being swept (mf_solve_piece / mf_solve_fused)
+    // levels of at least this many fronts take the lists (SANM_MF_SOLVE_LISTS: the threshold; 0: never)
+    int solve_lists_min() const {
+        static const int v = std::getenv("SANM_MF_SOLVE_LISTS") ? std::atoi(std::getenv("SANM_MF_SOLVE_LISTS")) : 64;
+        return v;
+    }
+    //! kind 0: `param` rows per workgroup, blocks over the k pivot rows (backward sweep; forward phase 1);
+    //! kind 1: transposed forward sweep, `param` pivot rows per workgroup (nzb blocks of the level's largest front come
+    //!         first in the numbering), then blocks of 64 boundary rows;
+    //! kind 2 / 3: `param` rows per workgroup, blocks over all m rows / over the b boundary rows (forward phases 0 / 2)
+    const SolveBlocks* solve_blocks(const MfDev& mf, const MfSchedule::Level& L, int kind, int param, int nzb) {
+        if (!m_cur_sch || m_cur_sch->h_lfronts.empty()) return nullptr;
+        const auto key = std::make_tuple((const void*)&L, kind, param);
+        auto it = m_solve_blocks.find(key);
+        if (it != m_solve_blocks.end()) return &it->second;
+        if (m_capturing) return nullptr;  // (no allocation or copy while a launch chain is being captured: the box grid)
+        std::vector<MfSolveBlock> v;
+        for (int32_t i = L.front_begin; i < L.front_end; ++i) {
+            const MfFrontDev& f = m_cur_sch->h_lfronts[i];
+            const int rows_f = kind == 2 ? f.m : (kind == 3 ? f.m - f.k : f.k);
+            const int nb = (rows_f + param - 1) / param;
+            for (int b = 0; b < nb; ++b) v.push_back({f, b, 0});
+            if (kind == 1)
+                for (int b = 0; b < (f.m - f.k + 63) / 64; ++b) v.push_back({f, nzb + b, 0});
+        }
+        SolveBlocks sb{mf.front_store, nullptr, (int)v.size()};
+        if (!v.empty()) {
+            sb.dev = static_cast<MfSolveBlock*>(alloc(v.size() * sizeof(MfSolveBlock)));
+            h2d(sb.dev, v.data(), v.size() * sizeof(MfSolveBlock));
+        }
+        return &(m_solve_blocks[key] = sb);
+    }
+    void forget_solve_blocks(const void* owner) {
+        for (auto it = m_solve_blocks.begin(); it != m_solve_blocks.end();)
+            if (it->second.owner == owner) {
+                if (it->second.dev) free(it->second.dev);
+                it = m_solve_blocks.erase(it);
+            } else {
+                ++it;
+            }
+    }
+
     template <int R, int U>
     void launch_level_solve(bool fwd, const MfDev& mf, const MfSchedule::Level& L, int phase) {
         using namespace mfk;
@@ -2673,6 +2725,21 @@ public:
         }
         const dim3 grid((rows + 4 * R - 1) / (4 * R), cnt);
         const MfFrontDev* lf = mf.lfronts + L.front_begin;
+        if (solve_lists_min() > 0 && cnt >= solve_lists_min()) {
+            // the (front, row block) pairs that exist instead of the box grid; the rows of a front in this launch: its
+            // pivot rows (backward sweep, forward phase 1), all of them (forward phase 0), its boundary rows (phase 2)
+            const int kind = !fwd || phase == 1 ? 0 : (phase == 0 ? 2 : 3);
+            if (const SolveBlocks* sb = solve_blocks(mf, L, kind, 4 * R, 0)) {
+                const MfFrontDev* bl = reinterpret_cast<const MfFrontDev*>(sb->dev);
+                if (sb->count > 0 && fwd)
+                    SANM_LAUNCH((fwd_level_kernel<R, U, true>), dim3(sb->count), dim3(256), lds, m_stream, bl, mf.front_store,
+                                mf.inbox_store, mf.work, mf.work2, mf.upd_dst, phase);
+                else if (sb->count > 0)
+                    SANM_LAUNCH((bwd_level_kernel<R, U, true>), dim3(sb->count), dim3(256), lds, m_stream, bl, mf.front_store,
+                                mf.work, mf.work2, mf.bnd_idx, phase);
+                return;
+            }
+        }
         if (fwd)
             SANM_LAUNCH((fwd_level_kernel<R, U>), grid, dim3(256), lds, m_stream, lf, mf.front_store,
                                mf.inbox_store, mf.work, mf.work2, mf.upd_dst, phase);
@@ -2727,6 +2794,14 @@ public:
 #define SANM_FT(G)                                                                                                  \
     if (g == G) {                                                                                                   \
         const int nzb = (L.max_k + 256 / G * 2 - 1) / (256 / G * 2);                                                \
+        const SolveBlocks* sb = solve_lists_min() > 0 && cnt >= solve_lists_min() ? solve_blocks(mf, L, 1, 256 / G * 2, nzb) : nullptr; \
+        if (sb) {                                                                                                   \
+            if (sb->count > 0)                                                                                      \
+                SANM_LAUNCH((fwd_level_tr_kernel<G, 2, true>), dim3(sb->count), dim3(256), lds, m_stream,           \
+                            reinterpret_cast<const MfFrontDev*>(sb->dev), mf.front_store, mf.inbox_store, mf.work, \
+                            mf.work2, mf.upd_dst, nzb);                                                             \
+            return;                                                                                                 \
+        }                                                                                                           \
         SANM_LAUNCH((fwd_level_tr_kernel<G, 2>), dim3(nzb + nbb, cnt), dim3(256), lds, m_stream,                     \
                     mf.lfronts + L.front_begin, mf.front_store, mf.inbox_store, mf.work, mf.work2, mf.upd_dst, nzb); \
         return;                                                                                                     \
@@ -2803,6 +2878,7 @@ public:
         mf_solve_fused(mf, sch, b, x, nullptr, nullptr);
     }
     void mf_solve_piece(const MfDev& mf, const MfSchedule& sch, bool fwd, int l0, int l1) override {
+        m_cur_sch = &sch;
         if (fwd)
             for (int li = l0; li < l1; ++li) level_solve(true, mf, sch.levels[li]);
         else
@@ -2829,6 +2905,7 @@ public:
             SANM_LAUNCH(permute_in_kernel, dim3(nblk(mf.n, 256)), dim3(256), 0, m_stream, mf.n,
                                mf.perm, b, mf.work);
         const int nl = (int)sch.levels.size(), below = sch.top.enabled ? nl - 2 : nl;
+        m_cur_sch = &sch;
         MfDev mb = mf;
         if (sch.top.enabled) mb.bnd_idx = sch.top.bnd_x;
         const int32_t* perm_out = sch.top.enabled ? sch.top.perm_x : mf.perm;

@@ -1242,7 +1242,7 @@ struct SolveArgs {  // what the bodies below call mf.*
     const int32_t* upd_dst;
     const int32_t* bnd_idx;
 };
-template <int R, int U>
+template <int R, int U, bool LIST = false>  // (LIST: as in bwd_level_kernel)
 __global__ void __launch_bounds__(256) fwd_level_kernel(const MfFrontDev* __restrict__ lfronts,
                                                         const double* __restrict__ front_store, double* inbox_store,
                                                         double* work, double* work2,
@@ -1250,9 +1250,10 @@ __global__ void __launch_bounds__(256) fwd_level_kernel(const MfFrontDev* __rest
     // phase 0: the whole sweep, [z; upd] = [L11^-1; F[B,A]] t.  Two-phase levels (Level::two_phase: F[B,A] holds -L21):
     // phase 1: z = L11^-1 t (rows < k), phase 2, a launch later: upd = F[B,A] z (rows >= k, the vector is z)
     const SolveArgs mf{lfronts, front_store, inbox_store, work, work2, upd_dst, nullptr};
-    const MfFrontDev f = mf.lfronts[blockIdx.y];
+    const MfSolveBlock* blocks = reinterpret_cast<const MfSolveBlock*>(lfronts);
+    const MfFrontDev f = LIST ? blocks[blockIdx.x].f : mf.lfronts[blockIdx.y];
     const int k = f.k, m = phase == 1 ? k : f.m;  // (m: end of this launch's rows)
-    const int rb = (phase == 2 ? k : 0) + blockIdx.x * (4 * R);
+    const int rb = (phase == 2 ? k : 0) + (LIST ? blocks[blockIdx.x].bx : (int)blockIdx.x) * (4 * R);
     if (rb >= m) return;
     extern __shared__ double vs[];  // t = w_own + children's contributions (k entries); phase 2: z
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1374,19 +1375,21 @@ __global__ void __launch_bounds__(256) fwd_level_sub_kernel(const MfFrontDev* __
 // rows each, a THREAD per row: upd_j = sum_i FT[i][j] t[i] with FT = (F[B,A])' in the F[P,B] slot -- every load of a
 // wavefront is 512 contiguous bytes of one of the k long rows, no reduction across lanes --, the k terms dealt to the
 // four wavefronts in contiguous quarters whose partial sums wavefront 0 adds in order.
-template <int G, int R>
+template <int G, int R, bool LIST = false>
 __global__ void __launch_bounds__(256) fwd_level_tr_kernel(const MfFrontDev* __restrict__ lfronts,
                                                            const double* __restrict__ front_store, double* inbox_store,
                                                            double* work, double* work2,
                                                            const int32_t* __restrict__ upd_dst, int nzb) {
-    const MfFrontDev f = lfronts[blockIdx.y];
+    const MfSolveBlock* blocks = reinterpret_cast<const MfSolveBlock*>(lfronts);  // (LIST: bx < nzb pivot rows, else boundary)
+    const MfFrontDev f = LIST ? blocks[blockIdx.x].f : lfronts[blockIdx.y];
+    const int bx = LIST ? blocks[blockIdx.x].bx : (int)blockIdx.x;
     const int m = f.m, k = f.k, b = m - k;
     extern __shared__ double vs[];  // t (k entries), then the partial sums [4][64]
     const int tid = threadIdx.x;
     const double* inbox = inbox_store + f.inbox_off;
-    if ((int)blockIdx.x < nzb) {
+    if (bx < nzb) {
         constexpr int RPB = 256 / G * R;
-        const int rb = blockIdx.x * RPB;
+        const int rb = bx * RPB;
         if (rb >= k) return;
         const int sub = tid % G, r0 = rb + tid / G * R;
         const double* rowp[R];
@@ -1421,7 +1424,7 @@ __global__ void __launch_bounds__(256) fwd_level_tr_kernel(const MfFrontDev* __r
         }
         return;
     }
-    const int jb = ((int)blockIdx.x - nzb) * 64;
+    const int jb = (bx - nzb) * 64;
     if (jb >= b) return;
     const int lane = tid & 63, w = tid >> 6;
     const int j = jb + lane, jc = min(j, b - 1);
@@ -1457,7 +1460,8 @@ __global__ void __launch_bounds__(256) fwd_level_tr_kernel(const MfFrontDev* __r
     if (w == 0 && j < b) inbox_store[dst] = (((part[lane] + part[64 + lane]) + part[128 + lane]) + part[192 + lane]) + pre;
 }
 
-template <int R, int U>
+// LIST: blockIdx.x indexes a flat list of the (front, row block) pairs that exist (MfSolveBlock) instead of the box grid
+template <int R, int U, bool LIST = false>
 __global__ void __launch_bounds__(256) bwd_level_kernel(const MfFrontDev* __restrict__ lfronts,
                                                         const double* __restrict__ front_store, double* work,
                                                         double* work2,
@@ -1465,9 +1469,10 @@ __global__ void __launch_bounds__(256) bwd_level_kernel(const MfFrontDev* __rest
     // phase 0: the whole sweep, x_own = [U11^-1, F[A,B]] [z; x_bnd].  Two-phase levels (F[A,B] holds -U12):
     // phase 1: z += F[A,B] x_bnd (in work2), phase 2, a launch later: x_own = U11^-1 z
     const SolveArgs mf{lfronts, front_store, nullptr, work, work2, nullptr, bnd_idx};
-    const MfFrontDev f = mf.lfronts[blockIdx.y];
+    const MfSolveBlock* blocks = reinterpret_cast<const MfSolveBlock*>(lfronts);
+    const MfFrontDev f = LIST ? blocks[blockIdx.x].f : mf.lfronts[blockIdx.y];
     const int k = f.k, m = phase == 2 ? k : f.m;  // (m: end of this launch's columns)
-    const int rb = blockIdx.x * (4 * R);
+    const int rb = (LIST ? blocks[blockIdx.x].bx : (int)blockIdx.x) * (4 * R);
     if (rb >= k || (phase == 1 && f.m == k)) return;
     const int safe = phase == 1 ? k : rb;  // a staged entry of vs (read, times zero, by lanes outside the range)
     extern __shared__ double vs[];  // [z (k) ; x_bnd (m-k)]

@@ -78,6 +78,15 @@ struct MfDev {
     int64_t front_store_size;
 };
 
+// One workgroup of a level's solve launch: the front's descriptor and which block of its rows.  The box grids of the
+// sweeps -- (row blocks of the level's LARGEST front) x fronts -- leave 40-60 % of the workgroups of the lower levels
+// without rows (a leaf level's fronts average 54 pivots and peak at 96); a flat list of the blocks that exist, the
+// descriptor inside the entry (no extra dependent load), launches exactly those (backend_hip.hip, solve_blocks).
+struct MfSolveBlock {
+    MfFrontDev f;
+    int32_t bx, pad;
+};
+
 // Operand of the device GEMMs: element (i, j) at p[i*ld + j] inside (rows, cols), else 0.  The index maps are read
 // by the GEMMs of the merged top block only: column j of an A operand at cidx[j], row i of a B operand at ridx[i].
 struct MatView {
@@ -138,6 +147,7 @@ struct MfSchedule {
         int32_t ea0_max_bp = 0;          // largest boundary of a front of the level that has children (round 0's gather)
     };
     std::vector<Level> levels;
+    std::vector<MfFrontDev> h_lfronts;     // host copy of MfDev::lfronts (the solve's block lists are made from it)
     const int32_t* ea_children = nullptr;  // device
     // Round 0 of the extend-add ASSIGNS the parent's F[B,B] instead of adding to a zeroed block (round 6): for boundary
     // position i of a front with children, ea_inv[bnd_off + i] = the boundary position of its FIRST child that lands there,

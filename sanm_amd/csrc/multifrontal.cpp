@@ -1541,6 +1541,7 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     {
         std::vector<MfFrontDev> lf(level_fronts.size());
         for (size_t i = 0; i < lf.size(); ++i) lf[i] = fr[level_fronts[i]];
+        m_sched.h_lfronts = lf;
         upload_to(m_dev.lfronts, std::move(lf));
     }
     upload_to(m_dev.upd_dst, upd_dst);
