@@ -1109,8 +1109,8 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     // The boundary blocks of the solve operators, F[B,A] = -L21 L11^-1 and F[A,B] = -U11^-1 U12, cost k^2 b flops each;
     // without them a sweep over the front is two dependent mat-vecs instead of one.  That pays where the products of a
     // whole height of the tree (its fronts share their launches) outweigh two more launches in each of the ~2 x 20
-    // sweeps of a step: 8e9 flops, swept on the 32^3 / 40^3 / 48^3 blocks (3e9 ... 5e10: flat between 6e9 and
-    // 1.2e10) -- the upper half of a 32^3-vertex block's tree and beyond, never a BASELINE mesh
+    // sweeps of a step: 2e10 flops (rounds 4-5: 8e9, swept on the 32^3 / 40^3 / 48^3 blocks, 3e9 ... 5e10: flat between
+    // 6e9 and 1.2e10, HISTORY.md section 5; round 6 below) -- the upper half of a 32^3-vertex block's tree and beyond, never a BASELINE mesh
     // (human ARAP, the largest: 11 GFLOP per factorisation in all).  SANM_MF_TWO_PHASE=1 / 0: every height / none; a
     // value above 1: the threshold in flops.
     std::vector<char> two_phase_h;
@@ -1118,15 +1118,23 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
         int32_t Hh = 0;
         for (int32_t f = 0; f < F; ++f) Hh = std::max(Hh, height[f] + 1);
         std::vector<double> h_k2b(Hh, 0.0);
+        std::vector<int32_t> h_max_k(Hh, 0);
         for (int32_t f = 0; f < F; ++f) {
             const double k = fr[f].k, bb = fr[f].m - fr[f].k;
             h_k2b[height[f]] += 2 * k * k * bb;
+            h_max_k[height[f]] = std::max(h_max_k[height[f]], fr[f].k);
         }
         const char* env = std::getenv("SANM_MF_TWO_PHASE");
         two_phase_h.assign(Hh, 0);
         const double env_v = env ? std::atof(env) : -1;  // (a value above 1: the threshold in flops, for sweeps)
         for (int32_t h = 0; h < Hh; ++h)
-            two_phase_h[h] = env ? (env_v > 1 ? h_k2b[h] >= env_v : (env_v != 0 && h_k2b[h] > 0)) : h_k2b[h] >= 8e9;
+            // (round 6: 2e10, and never a height of small fronts.  The sum over a height crosses any threshold once the
+            // height has fronts enough -- the leaf level of a 2.7 M-tet mesh, 14062 fronts of 57 pivots, sums to 15 GFLOP --
+            // and a two-phase level loses the one-workgroup small-front kernel, the transposed forward operator and one
+            // launch per sweep: 2.7 M tets, thresholds 8e9 / 2e10 / 4e10 / 8e10: solves 96.0 / 84.5 / 83.3 / 82.9, factor
+            // 215.6 / 217.3 / 220.0 / 224.2 ms per step; block:48 172.1 / 172.0 / 174.7 / 179.3 ms per step)
+            two_phase_h[h] = env ? (env_v > 1 ? h_k2b[h] >= env_v : (env_v != 0 && h_k2b[h] > 0))
+                                 : (h_k2b[h] >= 2e10 && h_max_k[h] > 96);
         for (int32_t f = 0; f < F; ++f)
             if (two_phase_h[height[f]]) {
                 const double k = fr[f].k, bb = fr[f].m - fr[f].k;
