@@ -1847,7 +1847,7 @@ public:
     void h2d(void* dst, const void* src, size_t bytes) override {
         if (!bytes) return;
         static const bool direct = std::getenv("SANM_H2D_DIRECT") != nullptr;
-        if (direct || bytes <= 4096) {  // (scalars and short tables: the runtime stages those itself, as in d2h)
+        if (direct) {  // (small copies take the staging buffers too: nothing of the caller's is ever pinned in place)
             HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, m_stream));
             HIP_CHECK(hipStreamSynchronize(m_stream));
             return;
