@@ -1172,32 +1172,39 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
         std::vector<int32_t> tree_roots;
         for (int32_t f = 0; f < F; ++f)
             if (parent[f] < 0) tree_roots.push_back(f);
+        // The mapping in two variants -- a child always gets at least one rank of its own (`ride` false), or the light side
+        // of a lopsided node rides with the least loaded rank of the set (true) --; kept is the one with the shorter
+        // critical path (a rank takes its fronts in elimination order, a front waits for its children).  Neither wins
+        // everywhere: armadillo x64 at 8 ranks 32.7 % against 37.7 % of the flops on the path, the forest of a mesh with a
+        // one-vertex component the other way round (one rank would own nothing but that vertex).
+        auto map_tree = [&](bool ride, std::vector<int32_t>& owner, std::vector<int32_t>& top, std::vector<char>& is_cut_root) {
+        owner.assign(F, -1);
+        top.assign(F, 0);
+        is_cut_root.assign(F, 0);
         std::vector<Task> stack;
         {
             Task t{-1, {}};
             for (int r = 0; r < world; ++r) t.ranks.push_back(r);
             stack.push_back(std::move(t));
         }
-        std::vector<char> is_cut_root(F, 0);
         while (!stack.empty()) {
             Task t = std::move(stack.back());
             stack.pop_back();
             const std::vector<int32_t>& ch = t.f < 0 ? tree_roots : children[t.f];
             if (t.f >= 0) {
-                f_owner[t.f] = t.ranks[0];
+                owner[t.f] = t.ranks[0];
                 if (t.ranks.size() == 1 || ch.empty() || sub_flops[t.f] < min_split) {
                     is_cut_root[t.f] = 1;  // the whole subtree is this rank's
                     continue;
                 }
-                f_stage[t.f] = 1;  // (a top front; its stage is computed below)
+                top[t.f] = 1;  // (a top front; its stage is computed below)
             }
             std::vector<int32_t> by_work(ch);
             std::stable_sort(by_work.begin(), by_work.end(), [&](int32_t a, int32_t b) { return sub_flops[a] > sub_flops[b]; });
             const int nr = (int)t.ranks.size(), nc = (int)by_work.size();
-            // Every child gets the whole number of ranks in its share of the set (possibly none), the ranks left over
-            // go by largest remainder; the children left without a rank of their own -- a share below half a rank or so:
-            // the light side of a lopsided node, the small components of a forest -- ride with the least loaded rank of
-            // the set, largest first.
+            // Every child gets the whole number of ranks in its share of the set (`ride`: possibly none; else at least one
+            // while ranks last), the ranks left over go by largest remainder; the children left without a rank of their
+            // own ride with the least loaded rank of the set, largest first.
             double W = 0;
             for (int32_t c : by_work) W += sub_flops[c];
             std::vector<int> cnt(nc, 0);
@@ -1205,7 +1212,7 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
             int left = nr;
             for (int i = 0; i < nc; ++i) {
                 want[i] = W > 0 ? sub_flops[by_work[i]] / W * nr : 0.0;
-                cnt[i] = std::min((int)want[i], left);
+                cnt[i] = std::min(std::max((int)want[i], ride ? 0 : 1), left);
                 left -= cnt[i];
             }
             while (left > 0) {
@@ -1236,10 +1243,37 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
         }
         // fronts below a cut root inherit its owner (parents have larger ids: walk down from the top)
         for (int32_t f = F - 1; f >= 0; --f)
-            if (f_owner[f] < 0) {
-                sanm_check(parent[f] >= 0 && f_owner[parent[f]] >= 0, "front %d has no owner", f);
-                f_owner[f] = f_owner[parent[f]];
+            if (owner[f] < 0) {
+                sanm_check(parent[f] >= 0 && owner[parent[f]] >= 0, "front %d has no owner", f);
+                owner[f] = owner[parent[f]];
             }
+        // the critical path in flops
+        std::vector<double> finish(F, 0.0), rank_time(world, 0.0);
+        double crit = 0;
+        for (int32_t f = 0; f < F; ++f) {
+            double t0 = rank_time[owner[f]];
+            for (int32_t c : children[f]) t0 = std::max(t0, finish[c]);
+            finish[f] = t0 + front_flops[f];
+            rank_time[owner[f]] = finish[f];
+            crit = std::max(crit, finish[f]);
+        }
+        return crit;
+        };
+        std::vector<char> is_cut_root;
+        {
+            std::vector<int32_t> o2, t2;
+            std::vector<char> c2;
+            const double crit_own = map_tree(false, f_owner, f_stage, is_cut_root);
+            const double crit_ride = map_tree(true, o2, t2, c2);
+            if (crit_ride < crit_own) {
+                f_owner.swap(o2);
+                f_stage.swap(t2);
+                is_cut_root.swap(c2);
+            }
+            if (std::getenv("SANM_MF_DEBUG"))
+                std::fprintf(stderr, "mf dist: critical path %.2f GF with a rank for every child, %.2f with riders\n",
+                             crit_own / 1e9, crit_ride / 1e9);
+        }
         for (int32_t f = 0; f < F; ++f)
             if (is_cut_root[f]) cut_roots.push_back(f);
         // stages of the top fronts (children first)
