@@ -19,6 +19,13 @@ timed.  For N > 1 the default is ONE problem whose tets are sharded over the
 ranks (BASELINE config 4: strong scaling, one all-reduce of b_k per Taylor order,
 value = K / max-over-ranks time); `--parallelism replicas` runs N independent
 copies instead (weak scaling, value = N*K / time).  See DESIGN.md "Multi-GPU".
+
+Beside the headline the line carries, for every N, the same measurement on two
+refinements of the same mesh (`at_scale`: every tet cut into 8, 338 k tets -- the
+plausible size of the missing Armadillo.1; `at_scale_large`: into 64, 2.7 M tets --
+the regime where factorisation and solves are the step and the distributed direct
+solver acts) and `end_to_end`: one whole solve from the solver's constructor to
+convergence, the reference's own time_solve (fea/main.cpp:382, :418-425).
 """
 from __future__ import annotations
 
