@@ -2668,9 +2668,9 @@ public:
     std::map<std::tuple<const void*, int, int>, SolveBlocks> m_solve_blocks;  // (level, kind, parameter)
     const MfSchedule* m_cur_sch = nullptr;  // the schedule whose levels are being swept (mf_solve_piece / mf_solve_fused)
     // levels of at least this many fronts take the lists (SANM_MF_SOLVE_LISTS: the threshold; 0: never)
-    int solve_lists_min() const {
-        static const int v = std::getenv("SANM_MF_SOLVE_LISTS") ? std::atoi(std::getenv("SANM_MF_SOLVE_LISTS")) : 64;
-        return v;
+    int solve_lists_min() const {  // (read per launch: tests switch it)
+        const char* e = std::getenv("SANM_MF_SOLVE_LISTS");
+        return e ? std::atoi(e) : 64;
     }
     //! kind 0: `param` rows per workgroup, blocks over the k pivot rows (backward sweep; forward phase 1);
     //! kind 1: transposed forward sweep, `param` pivot rows per workgroup (nzb blocks of the level's largest front come
@@ -2850,7 +2850,8 @@ public:
         // per wavefront.  Alternating runs on one box (profiles/r06_ab_solve.md): solves 10.16 -> 9.63 ms per step at 338 k
         // tets, 106.8 -> 100.3 at 2.7 M, 2.12 -> 2.07 on armadillo_small.  SANM_MF_LS_WIDTH: the factor on the average row
         // (default 1.25; 0: the longest row, as rounds 1-5).
-        static const double ls_wf = std::getenv("SANM_MF_LS_WIDTH") ? std::atof(std::getenv("SANM_MF_LS_WIDTH")) : 1.25;
+        const char* env_wf = std::getenv("SANM_MF_LS_WIDTH");  // (read per launch: tests switch it)
+        const double ls_wf = env_wf ? std::atof(env_wf) : 1.25;
         const int cntf = L.front_end - L.front_begin;
         const double avg_w = fwd ? (double)L.sum_k / cntf : (phase == 0 ? (double)L.sum_m / cntf : (phase == 1 ? (double)(L.sum_m - L.sum_k) / cntf : (double)L.sum_k / cntf));
         const int wsel = ls_wf > 0 ? std::min(width, std::max(64, (int)(ls_wf * avg_w))) : width;

@@ -391,3 +391,45 @@ def test_selective_zero_fill_and_assigned_schur_blocks(api, monkeypatch, leaf):
         assert np.abs(A @ sols[0][0] - b).max() <= 1e-8 * np.abs(b).max()
         for k in extra:
             monkeypatch.delenv(k)
+
+
+def test_solve_launch_forms_give_the_same_bits(api, monkeypatch):
+    """Round 6: the sweeps' launches go out over flat lists of the (front, row block) pairs that exist (levels of 64+
+    fronts; MfSolveBlock) and preload the row chunks of the level's TYPICAL row, the rest of a longer row in the tail
+    loop.  Neither changes a sum: the box grids (SANM_MF_SOLVE_LISTS=0), lists forced onto every level (=1) and chunks
+    for the longest row (SANM_MF_LS_WIDTH=0) or far too few (=0.3) give the same solutions bit for bit, with the
+    transposed forward operator and without, one-phase and two-phase levels, several right-hand sides in a row."""
+    mesh = ofea.make_cuboid(12, 6, 5, 0.02)
+    fixed = np.zeros((mesh.nr_vertices, 3), bool)
+    fixed[mesh.V[:, 0] < 0.01] = True
+    om = ofea.make_forward(mesh, ofea.Material(1e4, 0.45), fixed, "neohookean_c")
+    prop = S.TaylorCoeffProp(om.y)
+    prop.push_xi([(om.lt_inp.mat @ om.lt_inp.x0).reshape(-1, 3, 3)])
+    A, _ = build_jacobian_csr(om.lt_out, prop.get_jacobian(), om.lt_inp.mat, om.lt_inp.n)
+    A = A.tocsr()
+    A.sort_indices()
+    coords = mesh.V[om.lt_inp.vertex_loc[:, 0]]
+    rng = np.random.default_rng(5)
+    bs = [rng.standard_normal(A.shape[0]) for _ in range(3)]
+    monkeypatch.setenv("SANM_MF_LEAF", "8")  # (many small fronts: levels of 64+ fronts exist on this small mesh)
+    for extra in ({}, {"SANM_MF_FWD_T": "0"}, {"SANM_MF_TWO_PHASE": "1"}):
+        for k, v in extra.items():
+            monkeypatch.setenv(k, v)
+        ref = None
+        for mode in ({"SANM_MF_SOLVE_LISTS": "0", "SANM_MF_LS_WIDTH": "0"}, {"SANM_MF_SOLVE_LISTS": "0"}, {},
+                     {"SANM_MF_SOLVE_LISTS": "1"}, {"SANM_MF_SOLVE_LISTS": "1", "SANM_MF_LS_WIDTH": "0.3"}):
+            for k, v in mode.items():
+                monkeypatch.setenv(k, v)
+            ds = DirectSolver(api, A, coords)
+            assert ds.factor(A) == 0
+            xs = [ds.solve(b) for b in bs]
+            del ds
+            for k in mode:
+                monkeypatch.delenv(k)
+            if ref is None:
+                ref = xs
+                assert max(np.abs(A @ x - b).max() for x, b in zip(xs, bs)) <= 1e-8
+            else:
+                assert all(np.array_equal(x, r) for x, r in zip(xs, ref)), mode
+        for k in extra:
+            monkeypatch.delenv(k)
