@@ -80,11 +80,19 @@ def predict(plan, fam, n, nnz, order):
     solve = nsolve * one_solve
     ring = 2.0 * (G - 1) / G
     allred = ((order + 1) * n * 8 + nnz * 8) * ring / (P2P_GBS * 1e9) * 1e3 + (order + 2) * COLL_US * 1e-3
-    sharded = (fam["taylor"] + fam["io"] + fam["asm"]) / G + allred
+    # the same all-reduces done directly over the G - 1 links of the full mesh (reduce-scatter + all-gather, a chunk of
+    # 1 / G per peer and direction at a time) instead of a ring through one link: what RCCL can do on xGMI, not charged
+    # in `step_ms`
+    allred_mesh = ((order + 1) * n * 8 + nnz * 8) * 2.0 / G / (P2P_GBS * 1e9) * 1e3 + 2 * (order + 2) * COLL_US * 1e-3
+    compute_sharded = (fam["taylor"] + fam["io"] + fam["asm"]) / G
+    sharded = compute_sharded + allred
     step1 = sum(fam.values())
     step = factor + solve + sharded + fam["tail"]
+    step_mesh = factor + solve + compute_sharded + allred_mesh + fam["tail"]
     return {"factor_ms": factor, "factor_ms_without_transfers": no_xfer, "solve_ms": solve,
-            "taylor_io_asm_ms": sharded, "tail_ms": fam["tail"],
+            "taylor_io_asm_ms": sharded, "allreduce_ms_ring_one_link": allred, "allreduce_ms_full_mesh": allred_mesh,
+            "step_ms_with_full_mesh_allreduce": step_mesh, "speedup_with_full_mesh_allreduce": step1 / step_mesh,
+            "tail_ms": fam["tail"],
             "step_ms": step, "step_ms_one_gpu": step1, "speedup": step1 / step,
             "factor_speedup": fam["factor"] / factor, "solve_speedup": fam["solve"] / solve,
             "factor_plus_solves_speedup": (fam["factor"] + fam["solve"]) / (factor + solve)}
@@ -140,7 +148,9 @@ def main():
                   f"without the transfers), solves {fam['solve']:.1f} -> {p['solve_ms']:.1f}, Taylor/io/asm -> "
                   f"{p['taylor_io_asm_ms']:.1f}, step "
                   f"{p['step_ms_one_gpu']:.1f} -> {p['step_ms']:.1f} ms: x{p['speedup']:.2f} (factor + solves x"
-                  f"{p['factor_plus_solves_speedup']:.2f})", flush=True)
+                  f"{p['factor_plus_solves_speedup']:.2f}); with the all-reduces over the full mesh instead of a ring "
+                  f"through one link ({p['allreduce_ms_ring_one_link']:.1f} -> {p['allreduce_ms_full_mesh']:.1f} ms): "
+                  f"{p['step_ms_with_full_mesh_allreduce']:.1f} ms, x{p['speedup_with_full_mesh_allreduce']:.2f}", flush=True)
     os.environ.pop("SANM_MF_PLAN_WORLD", None)
     if args.out:
         json.dump(rec, open(args.out, "w"), indent=1)
