@@ -2402,6 +2402,20 @@ public:
 
 
     // ---- multifrontal LU (mf_kernels.h) ---------------------------------------
+#ifdef SANM_SF_PHASES
+    void sf_print_phases() {
+        unsigned long long ph[8];
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(mfk::g_sf_phase), sizeof(ph)));
+        if (!ph[7]) return;
+        std::fprintf(stderr, "small_front_kernel, per workgroup, 10 ns ticks: load %.0f  LU %.0f  inverses %.0f  store %.0f  gemm1 %.0f  "
+                     "gemm2 %.0f  (%.1f gemm1 tiles per front, %llu fronts)\n", (double)ph[0] / ph[7], (double)ph[1] / ph[7],
+                     (double)ph[2] / ph[7], (double)ph[3] / ph[7], (double)ph[4] / ph[7], (double)ph[5] / ph[7],
+                     (double)ph[6] / ph[7], ph[7]);
+        unsigned long long zero[8] = {};
+        HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(mfk::g_sf_phase), zero, sizeof(zero)));
+    }
+#endif
     int mf_factor(const MfDev& mf, const MfSchedule& sch, const CsrDev& A) override {
         mf_factor_launch(mf, sch, A);
         int32_t* hs = reinterpret_cast<int32_t*>(m_scalar_host);
@@ -2418,6 +2432,9 @@ public:
             SANM_LAUNCH(status_to_double_kernel, dim3(1), dim3(1), 0, m_stream, mf.status, status);
         });
         HIP_CHECK(hipGetLastError());
+#ifdef SANM_SF_PHASES
+        sf_print_phases();
+#endif
     }
 #ifdef SANM_MF_PHASES
     void mf_print_phases() {

@@ -1006,6 +1006,9 @@ __global__ void __launch_bounds__(256) gemm2_list_kernel(MF_FACTOR_PARAMS, const
 //      as the separate launches), operands from L2.
 // The pivot block's own factors are not written back: nothing reads F[P,P] after the factorisation.
 constexpr int SF_KMAX = 96;
+#ifdef SANM_SF_PHASES
+__device__ unsigned long long g_sf_phase[8];
+#endif
 __global__ void __launch_bounds__(256) small_front_kernel(MF_FACTOR_PARAMS, int ks, int tr) {
     MF_FACTOR_INIT
     const MfFrontDev f = mf.lfronts[level_begin + blockIdx.x];
@@ -1016,9 +1019,15 @@ __global__ void __launch_bounds__(256) small_front_kernel(MF_FACTOR_PARAMS, int 
     double* F = mf.front_store + f.off;
     const int tid = threadIdx.x;
     const double thr = MF_PIVOT_EPS * *mf.piv_amax;
+#ifdef SANM_SF_PHASES  // (-DSANM_SF_PHASES: wall clock of this kernel's phases, summed over the workgroups; 10 ns ticks)
+    const unsigned long long sf0 = wall_clock64();
+#endif
     for (int r = tid >> 5; r < k; r += 8)
         for (int c = tid & 31; c < k; c += 32) S[r * ks + c] = F[(int64_t)r * ld + c];
     __syncthreads();
+#ifdef SANM_SF_PHASES
+    const unsigned long long sf1 = wall_clock64();
+#endif
     // ---- LU, right-looking, one pivot per step
     int nbad = 0;
     const int ty = tid >> 4, tx = tid & 15;
@@ -1042,6 +1051,9 @@ __global__ void __launch_bounds__(256) small_front_kernel(MF_FACTOR_PARAMS, int 
         __syncthreads();
     }
     if (tid == 0 && nbad) atomicAdd(mf.status, nbad);
+#ifdef SANM_SF_PHASES
+    const unsigned long long sf2 = wall_clock64();
+#endif
     // ---- in-place inverses: step s finishes column k-2-s of L^-1 (threads 0..127) and column s of U^-1 (128..255).
     // A column's ORIGINAL entries are needed while its new ones are written: they are copied one step ahead into vbuf.
     double* vl = vbuf;           // [2][ks]
@@ -1085,6 +1097,9 @@ __global__ void __launch_bounds__(256) small_front_kernel(MF_FACTOR_PARAMS, int 
         }
         __syncthreads();
     }
+#ifdef SANM_SF_PHASES
+    const unsigned long long sf3 = wall_clock64();
+#endif
     // ---- L11^-1 (strictly lower part; its unit diagonal is the identity block's) -> F[P,A], U11^-1 -> F[A,P]
     for (int r = tid >> 5; r < k; r += 8)
         for (int c = tid & 31; c < k; c += 32) {
@@ -1097,17 +1112,35 @@ __global__ void __launch_bounds__(256) small_front_kernel(MF_FACTOR_PARAMS, int 
     auto As = reinterpret_cast<double(*)[GT + 1]>(sdyn);
     auto Bs = reinterpret_cast<double(*)[GT + 4]>(sdyn + GK * (GT + 1));
     const int tk = (k + GT - 1) / GT, tb = (b + GT - 1) / GT;
+#ifdef SANM_SF_PHASES
+    const unsigned long long sf4 = wall_clock64();
+#endif
     for (int tj = 0; tj < tb; ++tj)
         for (int ti = 0; ti < tk; ++ti) gemm1_tile(mf, f, 0, ti, tj, As, Bs, 0);  // tmpU (k x b)
     for (int ti = 0; ti < tb; ++ti)
         for (int tj = 0; tj < tk; ++tj) gemm1_tile(mf, f, 1, ti, tj, As, Bs, 0);  // tmpL (b x k)
     __syncthreads();
+#ifdef SANM_SF_PHASES
+    const unsigned long long sf5 = wall_clock64();
+#endif
     for (int ti = 0; ti < tb; ++ti)
         for (int tj = 0; tj < tb; ++tj) gemm2_tile(mf, f, 0, ti, tj, As, Bs);
     for (int ti = 0; ti < tb; ++ti)
         for (int tj = 0; tj < tk; ++tj) gemm2_tile(mf, f, 1, ti, tj, As, Bs, tr);
     for (int ti = 0; ti < tk; ++ti)
         for (int tj = 0; tj < tb; ++tj) gemm2_tile(mf, f, 2, ti, tj, As, Bs);
+#ifdef SANM_SF_PHASES
+    if (tid == 0) {
+        atomicAdd(&g_sf_phase[0], sf1 - sf0);
+        atomicAdd(&g_sf_phase[1], sf2 - sf1);
+        atomicAdd(&g_sf_phase[2], sf3 - sf2);
+        atomicAdd(&g_sf_phase[3], sf4 - sf3);
+        atomicAdd(&g_sf_phase[4], sf5 - sf4);
+        atomicAdd(&g_sf_phase[5], wall_clock64() - sf5);
+        atomicAdd(&g_sf_phase[6], (unsigned long long)(2 * tk * tb));
+        atomicAdd(&g_sf_phase[7], 1ull);
+    }
+#endif
 }
 
 // Two blocking levels: after the panels [p0, p1) of an outer block the trailing matrix beyond it,
