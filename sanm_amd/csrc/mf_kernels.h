@@ -1006,6 +1006,25 @@ __global__ void __launch_bounds__(256) gemm2_list_kernel(MF_FACTOR_PARAMS, const
 //      as the separate launches), operands from L2.
 // The pivot block's own factors are not written back: nothing reads F[P,P] after the factorisation.
 constexpr int SF_KMAX = 96;
+// acc + sum_{t = t0}^{t1 - 1} row[t] * v[t], ONE accumulation chain in ascending t (the sums the plain loop formed, bit for
+// bit) with the LDS operands of eight terms requested together: the plain loop waited for an LDS round trip per term,
+// and these dot products are the k barrier-separated steps of the in-place inverses -- 77 of the 208 us a front of the
+// 338 k-tet mesh spends in small_front_kernel
+__device__ __forceinline__ double sf_dot(const double* row, const double* v, int t0, int t1, double acc) {
+    int t = t0;
+    for (; t + 8 <= t1; t += 8) {
+        double a[8], b[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            a[q] = row[t + q];
+            b[q] = v[t + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = __builtin_fma(a[q], b[q], acc);
+    }
+    for (; t < t1; ++t) acc = __builtin_fma(row[t], v[t], acc);
+    return acc;
+}
 #ifdef SANM_SF_PHASES
 __device__ unsigned long long g_sf_phase[8];
 #endif
@@ -1074,26 +1093,19 @@ __global__ void __launch_bounds__(256) small_front_kernel(MF_FACTOR_PARAMS, int 
             const int jl = k - 2 - s2;
             if (jl >= 0) {
                 const double* v = vl + cur * ks;
-                for (int i = jl + 1 + tid; i < k; i += 128) {
-                    double acc = v[i];
-                    for (int t = jl + 1; t < i; ++t) acc = __builtin_fma(S[i * ks + t], v[t], acc);
-                    S[i * ks + jl] = -acc;
-                }
+                // (the next step's column first: its copy does not wait for the dot products)
                 if (jl >= 1)
                     for (int i = tid; i < k; i += 128) vl[nxt * ks + i] = S[i * ks + jl - 1];
+                for (int i = jl + 1 + tid; i < k; i += 128) S[i * ks + jl] = -sf_dot(S + i * ks, v, jl + 1, i, v[i]);
             }
         } else {
             const int u = tid - 128, ju = s2;
             const double* v = vu + cur * ks;
             const double d = 1.0 / v[ju];
-            for (int i = u; i < ju; i += 128) {
-                double acc = 0.0;
-                for (int t = i; t < ju; ++t) acc = __builtin_fma(S[i * ks + t], v[t], acc);
-                S[i * ks + ju] = -acc * d;
-            }
-            if (u == 0) S[ju * ks + ju] = d;
             if (ju + 1 < k)
                 for (int i = u; i < k; i += 128) vu[nxt * ks + i] = S[i * ks + ju + 1];
+            for (int i = u; i < ju; i += 128) S[i * ks + ju] = -sf_dot(S + i * ks, v, i, ju, 0.0) * d;
+            if (u == 0) S[ju * ks + ju] = d;
         }
         __syncthreads();
     }
