@@ -88,6 +88,9 @@ private:
     void upload_to(P& target, const std::vector<T>& v);
     template <class P, class T>
     void upload_to(P& target, std::vector<T>&& v);
+    //! device copy of count elements that `keep` holds alive (no host copy when deferred)
+    template <class P, class T>
+    void upload_kept(P& target, std::shared_ptr<void> keep, const T* src, size_t count);
     template <class P>
     void alloc_to(P& target, size_t bytes, bool zero);
 };

@@ -323,6 +323,60 @@ def test_parallel_analysis_gives_the_sequential_ordering(api, monkeypatch):
     assert np.abs(A @ out[0][1] - b).max() < 1e-9
 
 
+def test_supervariables_from_runs_of_equal_rows(api, monkeypatch):
+    """the supervariables come from runs of consecutive rows with one column list (the 3 x 3 blocks of a mesh Jacobian),
+    the pattern of the runs then goes through the hashing of closed neighbourhoods (multifrontal.cpp, build_sv_graph;
+    round 6).  On a symmetric pattern that is the partition, the numbering and the ordering the hashing of the whole
+    pattern gives (SANM_MF_SV_RUNS=0) -- same statistics, same bits of a solve; SANM_MF_DEBUG makes the analysis check
+    its scatter map and its parent positions entry by entry against a search of their own.  In an unsymmetric pattern
+    rows of a run may differ in their COLUMNS: the run is then a supervariable with explicit zeros, and the system is
+    still solved."""
+    monkeypatch.setenv("SANM_MF_DEBUG", "1")
+    mesh = ofea.make_cuboid(14, 9, 7, 0.05)
+    nv = mesh.nr_vertices
+    T = mesh.tets
+    rows = np.repeat(T, 4, axis=1).ravel()
+    cols = np.tile(T, (1, 4)).ravel()
+    G = sp.csr_matrix((np.ones(rows.size), (rows, cols)), shape=(nv, nv))
+    G.sum_duplicates()
+    rng = np.random.default_rng(11)
+    A = sp.kron(G, np.ones((3, 3)), format="csr")
+    A.data = rng.standard_normal(A.nnz) * 0.1
+    A = sp.csr_matrix(A + sp.diags(np.full(3 * nv, 30.0)))
+    A.sort_indices()
+    coords = np.repeat(mesh.V, 3, axis=0)
+    b = rng.standard_normal(A.shape[0])
+    out = []
+    for runs in ("0", "1"):
+        monkeypatch.setenv("SANM_MF_SV_RUNS", runs)
+        for c in (coords, None):
+            ds = DirectSolver(api, A, c)
+            assert ds.factor(A) == 0
+            out.append((ds.stats(), ds.solve(b)))
+    for i in (0, 1):
+        assert out[i][0] == out[2 + i][0] and out[i][0]["nr_supervar"] == nv
+        assert np.array_equal(out[i][1], out[2 + i][1])
+        assert np.abs(A @ out[i][1] - b).max() < 1e-9
+    # unsymmetric: pairs of rows with one column list, columns that differ inside a pair
+    n = 600
+    P = sp.random(n // 2, n, density=0.02, random_state=5, format="csr")
+    P = sp.vstack([P[i // 2] for i in range(n)]).tocsr()  # row 2i+1 lists the columns of row 2i
+    P = (P + sp.kron(sp.eye(n // 2), np.ones((2, 2)))).tocsr()  # both diagonals in both rows
+    P.data = rng.standard_normal(P.nnz) * 0.05
+    P = sp.csr_matrix(P + sp.diags(np.full(n, 4.0)))
+    P.sort_indices()
+    assert (P != P.T).nnz > 0 and np.array_equal(P[0].indices, P[1].indices)
+    bu = rng.standard_normal(n)
+    xs = []
+    for runs in ("0", "1"):
+        monkeypatch.setenv("SANM_MF_SV_RUNS", runs)
+        ds = DirectSolver(api, P, None)
+        assert ds.factor(P) == 0
+        xs.append((ds.stats()["nr_supervar"], ds.solve(bu)))
+        assert np.abs(P @ xs[-1][1] - bu).max() < 1e-10
+    assert xs[1][0] <= n // 2 < xs[0][0]  # (the hashing of A + A' tells the rows of a pair apart)
+
+
 @pytest.mark.parametrize("leaf", ["8", "32"])
 def test_forward_operator_not_transposed(api, monkeypatch, leaf):
     """levels of fronts of at most 128 pivots keep the boundary block of their forward operator TRANSPOSED in the dead
