@@ -731,7 +731,8 @@ def main(argv=None):
         e2e["time_solve"], e2e["iter"] = e2e["cold"]["time_solve"], e2e["cold"]["iter"]
         # (analysis: what the constructor WAITS for the direct solver's analysis, which runs on a thread of its own beside
         # the tables -- analysis_thread is that thread's own clock)
-        e2e["setup_seconds"] = {"analysis": c.get("analysis"), "analysis_thread": c.get("analysis_thread"), "tables": round(sum(
+        e2e["setup_seconds"] = {"analysis": c.get("analysis"), "analysis_thread": c.get("analysis_thread"),
+                                "analysis_device": c.get("analysis_device"), "solver_vectors": c.get("solver_vectors"), "tables": round(sum(
             c.get(k, 0.0) for k in ("tet_order", "program", "remap_tables", "pattern")), 4),
             "jit_cold": c.get("jit"), "jit_cold_source": c.get("jit_source"),
             "jit_cached": w.get("jit"), "jit_cached_source": w.get("jit_source")}

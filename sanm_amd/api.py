@@ -665,7 +665,7 @@ class _ANMSolver:
 
     def setup_profile(self):
         """host seconds of the constructor's phases (sanm_anm_setup_profile): {"tet_order", "program", "jit",
-        "remap_tables", "pattern", "analysis"} plus "jit_source" in {"embedded", "compiled", "disk_hit", "memory_hit", "none"}"""
+        "remap_tables", "pattern", "analysis", "analysis_thread", "analysis_device", "solver_vectors"} plus "jit_source" in {"embedded", "compiled", "disk_hit", "memory_hit", "none"}"""
         lib = self.api.lib
         lib.sanm_anm_setup_profile.restype = C.c_int
         n = lib.sanm_anm_setup_profile(self.h, C.c_int(0), None, None)

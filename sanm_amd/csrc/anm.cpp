@@ -945,22 +945,9 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
         m_setup.emplace_back(name, sec);
     };
     auto t_setup = clk();
-    // the renumbering is applied while the device tables are built (Program, DeviceRows, JacobianPattern read the
-    // caller's graph constants and remap tables through it): no permuted copies of either
-    std::vector<int64_t> order, inv;
-    const bool reorder = remap_out_in.out_coords.size() == (size_t)m_n * 3 &&
-                         remap_out_in.in_size == remap_inp_in.out_size && !std::getenv("SANM_NO_TET_ORDER");
-    if (reorder) {
-        order = spatial_tet_order(remap_inp_in, remap_out_in.out_coords, m_n);
-        inv.resize(order.size());
-        for (size_t e = 0; e < order.size(); ++e) inv[order[e]] = (int64_t)e;
-    }
-    lap("tet_order", t_setup);
     const Graph& g = g_in;
     const SparseDesc& remap_inp = remap_inp_in;
     const SparseDesc& remap_out = remap_out_in;
-    const int64_t* tet_order = reorder ? order.data() : nullptr;
-    const int64_t* tet_inv = reorder ? inv.data() : nullptr;
     const int64_t T = remap_inp.out_size / 9;
     // this rank's tets: contiguous ranges like the reference's worker shards
     // (libsanm/symbolic.cpp:525-536)
@@ -977,18 +964,42 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
         te = (int64_t)(m_shard.rank + 1) * T / m_shard.world;
         sanm_check(te > tb, "more ranks than tets");
     }
+    // the renumbering is applied while the device tables are built (Program, DeviceRows, JacobianPattern read the
+    // caller's graph constants and remap tables through it): no permuted copies of either
+    std::vector<int64_t> order, inv;
+    const bool reorder = remap_out_in.out_coords.size() == (size_t)m_n * 3 &&
+                         remap_out_in.in_size == remap_inp_in.out_size && !std::getenv("SANM_NO_TET_ORDER");
     // The Jacobian's pattern first (host only), so that the direct solver's analysis -- host only as well, and the
     // longest piece of the constructor -- runs on a thread of its own beside the program, the remap tables and the
-    // assembly lists; its device copies are made by this thread once the others are done.  SANM_SETUP_SERIAL=1: one
-    // thing after the other.
+    // assembly lists; its device copies are made by this thread once the others are done.  The host pattern of ALL tets
+    // does not depend on their numbering: it is built beside the renumbering (round 6; a shard's pattern needs the
+    // numbering first).  SANM_SETUP_SERIAL=1: one thing after the other.
+    const bool serial = std::getenv("SANM_SETUP_SERIAL") != nullptr;
+    auto make_pattern = [&](const int64_t* tet_order, const int64_t* tet_inv) {
+        m_pattern = std::make_unique<JacobianPattern>(be, remap_out, remap_inp, m_n, T, 0, 9, tb, te, 9, tet_order, tet_inv,
+                                                      /*defer_device=*/true);
+    };
+    const bool pattern_beside = reorder && !serial && tb == 0 && te == T;
+    {
+        std::future<void> pattern_job;  // (joined when the scope ends, whatever ends it)
+        if (pattern_beside) pattern_job = std::async(std::launch::async, [&] { make_pattern(nullptr, nullptr); });
+        if (reorder) {
+            order = spatial_tet_order(remap_inp_in, remap_out_in.out_coords, m_n);
+            inv.resize(order.size());
+            for (size_t e = 0; e < order.size(); ++e) inv[order[e]] = (int64_t)e;
+        }
+        lap("tet_order", t_setup);
+        if (pattern_job.valid()) pattern_job.get();  // (rethrows)
+    }
+    const int64_t* tet_order = reorder ? order.data() : nullptr;
+    const int64_t* tet_inv = reorder ? inv.data() : nullptr;
     const double* coords = remap_out.out_coords.size() == (size_t)m_n * 3 ? remap_out.out_coords.data() : nullptr;
     // (the merged top block, SANM_MF_TOP > 0, multiplies device blocks out while the analysis builds it, i.e. it is
     // not deferred: it must run on this thread, the owner of the backend, whose pool and staging buffers have no lock)
     const bool mf_top = std::getenv("SANM_MF_TOP") && std::atoi(std::getenv("SANM_MF_TOP")) > 0;
-    const bool beside = hp.solver_kind == 1 && hp.xcoeff_l2_penalty == 0 && !std::getenv("SANM_SETUP_SERIAL") && !mf_top;
-    t_setup = clk();
-    m_pattern = std::make_unique<JacobianPattern>(be, remap_out, remap_inp, m_n, T, 0, 9, tb, te, 9, tet_order, tet_inv,
-                                                  /*defer_device=*/true);
+    const bool beside = hp.solver_kind == 1 && hp.xcoeff_l2_penalty == 0 && !serial && !mf_top;
+    if (pattern_beside) m_pattern->set_tet_order(tet_order, tet_inv);
+    else make_pattern(tet_order, tet_inv);
     lap("pattern", t_setup);
     std::future<std::unique_ptr<Multifrontal>> analysis;
     if (beside) {
@@ -1022,10 +1033,12 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
     if (analysis.valid()) {
         analysed = analysis.get();  // (rethrows what the analysis threw)
         m_setup.emplace_back("analysis_thread", analysed->analysis_seconds);  // its own clock; "analysis" is the wait for it
+        lap("analysis", t_setup);
         analysed->finish_device();
+        lap("analysis_device", t_setup);  // the queued uploads and allocations, the front store among them
     }
     construct_solver_and_vectors(coords, std::move(analysed));
-    lap("analysis", t_setup);
+    lap(beside ? "solver_vectors" : "analysis", t_setup);
     if (std::getenv("SANM_DEBUG_SETUP")) {
         for (const auto& kv : m_setup) std::fprintf(stderr, "[setup] %s %.4f\n", kv.first.c_str(), kv.second);
         std::fprintf(stderr, "[setup] driver constructor, first member to here: %.4f\n",

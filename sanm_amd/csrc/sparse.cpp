@@ -183,6 +183,23 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
     const int nthread = (int)std::max<int64_t>(
             1, std::min<int64_t>({(int64_t)host_thread_cap(), n / 2048 + 1}));
     std::vector<Part> parts(nthread);
+    // the distinct columns of every batch item, once (a tet's 9 remap_in rows list its 12 unknowns three times over, and
+    // every one of the ~24 tets around a vertex was walked in full for each of that vertex's rows: round 6); the list of
+    // item b starts where its remap_in rows start
+    auto item_col_raw = raw_array<uint32_t>(ri.rowptr[(size_t)T * idim]);
+    uint32_t* const item_col = item_col_raw.get();
+    std::vector<uint32_t> item_nr(T);
+    parallel_ranges(T, 4096, [&](int64_t b0, int64_t b1, int) {
+        for (int64_t b = b0; b < b1; ++b) {
+            const uint64_t q0 = ri.rowptr[b * idim], q1 = ri.rowptr[(b + 1) * idim];
+            uint32_t* out = item_col + q0;
+            uint32_t m = 0;
+            for (uint64_t q = q0; q < q1; ++q) out[m++] = (uint32_t)ri.idx[q];
+            std::sort(out, out + m);
+            item_nr[b] = (uint32_t)(std::unique(out, out + m) - out);
+        }
+    });
+    laps.lap("columns of the items");
     auto build = [&](int t) {
         Part& P = parts[t];
         const int64_t r0 = n * t / nthread, r1 = n * (t + 1) / nthread;
@@ -215,14 +232,16 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
                     continue;
                 }
                 ucol.clear();
-                for (uint64_t b : items)
-                    for (uint64_t q = ri.rowptr[b * idim]; q < ri.rowptr[(b + 1) * idim]; ++q) {
-                        const uint32_t c = (uint32_t)ri.idx[q];
+                for (uint64_t b : items) {
+                    const uint32_t* lc = item_col + ri.rowptr[b * idim];
+                    for (uint32_t q = 0; q < item_nr[b]; ++q) {
+                        const uint32_t c = lc[q];
                         if (!mark[c]) {
                             mark[c] = 1;
                             ucol.push_back(c);
                         }
                     }
+                }
                 std::sort(ucol.begin(), ucol.end());
                 uint32_t nnz_row = 0;
                 for (uint32_t c : ucol) {

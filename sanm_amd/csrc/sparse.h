@@ -68,6 +68,13 @@ public:
     //! defer_device: the constructor builds the host pattern only (h_rowptr / h_col are valid -- what the analysis of a
     //! direct solver needs --, nothing else is); finish_device, with the constructor's maps, makes the device side
     void finish_device(const SparseDesc& remap_out, const SparseDesc& remap_in);
+    //! a deferred pattern of ALL batch items (no shard: the host pattern does not depend on the numbering) built before
+    //! the renumbering was known: hand it in before finish_device
+    void set_tet_order(const int64_t* tet_order, const int64_t* tet_inv) {
+        sanm_check(!tet_order == !tet_inv, "a renumbering of the batch items comes with its inverse");
+        sanm_check(m_tet_begin == 0 && m_tet_end == m_T, "set_tet_order: the pattern of a shard was built in a numbering");
+        m_tet_order = tet_order, m_tet_inv = tet_inv;
+    }
 
     CsrDev csr() const { return m_csr; }
     AssemblyDev assembly() const { return m_asm; }

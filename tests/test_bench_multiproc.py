@@ -71,7 +71,7 @@ def _check_common(d):
     # ride in the same line, for every N
     e = d["end_to_end"]
     assert e["iter"] >= 1 and e["time_solve"] > 0 and e["cold"]["converged"]
-    assert set(e["setup_seconds"]) == {"analysis", "analysis_thread", "tables", "jit_cold", "jit_cold_source", "jit_cached", "jit_cached_source"}
+    assert set(e["setup_seconds"]) == {"analysis", "analysis_thread", "analysis_device", "solver_vectors", "tables", "jit_cold", "jit_cold_source", "jit_cached", "jit_cached_source"}
     assert e["cached"]["iter"] == e["cold"]["iter"]
     a = d["at_scale"]
     assert a["steps"] == 2 and a["value"] > 0 and a["rccl_ranks"] == d["rccl_ranks"]
