@@ -133,6 +133,14 @@ public:
 
     virtual void* alloc(size_t bytes) = 0;
     virtual void free(void* p) = 0;
+    //! Device memory asked for from ANY host thread while the owner thread works (the direct solver's analysis asks for
+    //! its front store -- tens of GB whose mapping takes 0.1-1 s -- as soon as it knows the size, beside the rest of the
+    //! constructor): nothing of the backend's own state is touched.  nullptr: not offered (or no memory: the owner then
+    //! asks again through alloc and reports).  adopt() on the owner thread makes the block one of alloc()'s; a block
+    //! that is never adopted goes back through free_detached().
+    virtual void* alloc_detached(size_t) { return nullptr; }
+    virtual void free_detached(void*) {}
+    virtual void adopt(void*, size_t) {}
     virtual void h2d(void* dst, const void* src, size_t bytes) = 0;
     virtual void d2h(void* dst, const void* src, size_t bytes) = 0;
     //! queue a copy to pinned host memory (alloc_host) without waiting: valid after the next sync()

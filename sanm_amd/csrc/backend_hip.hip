@@ -1600,7 +1600,8 @@ class HipBackend final : public Backend {
     }
 
 public:
-    explicit HipBackend(int device) {
+    int m_device_id = 0;
+    explicit HipBackend(int device) : m_device_id{device} {
         int count = 0;
         hipError_t e = hipGetDeviceCount(&count);
         if (e != hipSuccess || count <= 0) {
@@ -1817,6 +1818,20 @@ public:
         m_live[p] = bytes;
         return p;
     }
+    void* alloc_detached(size_t bytes) override {
+        static const bool off = std::getenv("SANM_NO_DETACHED_ALLOC") != nullptr;
+        if (off || !bytes) return nullptr;
+        void* p = nullptr;
+        if (hipSetDevice(m_device_id) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        return p;
+    }
+    void free_detached(void* p) override {
+        if (p) (void)hipFree(p);
+    }
+    void adopt(void* p, size_t bytes) override { m_live[p] = bytes ? bytes : 8; }
     void free(void* p) override {
         if (!p) return;
         auto it = m_live.find(p);

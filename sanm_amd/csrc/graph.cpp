@@ -892,16 +892,27 @@ void Program::set_remap_in(int64_t n_in, const uint64_t* rowptr, const uint64_t*
     const int64_t T = m_dev.T, Tpad = m_dev.Tpad;
     int nslot = 0;
     const int64_t* ord = m_tet_order.empty() ? nullptr : m_tet_order.data();
-    for (int64_t e = 0; e < T; ++e) {
-        const int64_t o0 = (ord ? ord[e] : m_tet_begin + e) * 9;
-        for (int64_t o = o0; o < o0 + 9; ++o) {
-            sanm_check(rowptr[o + 1] >= rowptr[o], "remap_in: rowptr not monotone");
-            nslot = std::max<int>(nslot, rowptr[o + 1] - rowptr[o]);
-        }
+    SetupLaps laps("remap_in table");
+    {
+        std::vector<int> part_max(64, 0);
+        std::vector<char> part_bad(64, 0);
+        parallel_ranges(T, 1 << 16, [&](int64_t e0, int64_t e1, int t) {
+            int mx = 0;
+            for (int64_t e = e0; e < e1; ++e) {
+                const int64_t o0 = (ord ? ord[e] : m_tet_begin + e) * 9;
+                for (int64_t o = o0; o < o0 + 9; ++o) {
+                    if (rowptr[o + 1] < rowptr[o]) part_bad[t % 64] = 1;
+                    else mx = std::max<int>(mx, (int)std::min<uint64_t>(rowptr[o + 1] - rowptr[o], 1u << 20));
+                }
+            }
+            part_max[t % 64] = std::max(part_max[t % 64], mx);
+        });
+        for (char b : part_bad) sanm_check(!b, "remap_in: rowptr not monotone");
+        for (int m : part_max) nslot = std::max(nslot, m);
     }
     sanm_check(nslot <= 64, "remap_in: %d entries for one output element", nslot);
     nslot = std::max(nslot, 1);
-    SetupLaps laps("remap_in table");
+    laps.lap("slots");
     const size_t tab = (size_t)nslot * 9 * Tpad;
     auto hidx = raw_array<uint32_t>(tab);   // every entry written below: the workers touch their own pages
     auto hcoef = raw_array<double>(tab);

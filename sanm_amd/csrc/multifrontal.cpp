@@ -1049,7 +1049,12 @@ T* Multifrontal::upload(const std::vector<T>& v) {  // (on the spot: the merged 
     return static_cast<T*>(p);
 }
 void Multifrontal::run_op(DeviceOp& op) {
-    void* p = m_be->alloc(std::max<size_t>(op.bytes, 1));
+    void* p = nullptr;
+    if (op.detached && m_front_job.job.valid()) {
+        p = m_front_job.job.get();
+        if (p) m_be->adopt(p, op.bytes);
+    }
+    if (!p) p = m_be->alloc(std::max<size_t>(op.bytes, 1));
     if (op.src && op.bytes) m_be->h2d(p, op.src, op.bytes);
     if (op.zero) m_be->zero(p, op.bytes);
     m_bufs.push_back(p);
@@ -1310,6 +1315,12 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
         factor_flops += front_flops[f];
     }
     front_doubles = off;
+    // the front store's memory, asked for now on a thread of its own (deferred constructors only: the owner thread is
+    // busy with the driver's tables, and mapping tens of GB takes the device 0.1-1 s)
+    if (m_defer && off * sizeof(double) >= (size_t(1) << 28)) {
+        m_front_job.be = m_be;
+        m_front_job.job = std::async(std::launch::async, [be = m_be, bytes = (size_t)off * sizeof(double)] { return be->alloc_detached(bytes); });
+    }
 
     // ---- two-phase levels (mf_types.h, Level::two_phase) -----------------------------------------------------------
     // The boundary blocks of the solve operators, F[B,A] = -L21 L11^-1 and F[A,B] = -U11^-1 U12, cost k^2 b flops each;
@@ -1905,7 +1916,14 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     }
     lap("device tables: uploads");
     m_dev.front_store_size = off;
-    alloc_to(m_dev.front_store, off * sizeof(double), false);
+    {
+        DeviceOp op;
+        op.bytes = off * sizeof(double);
+        op.detached = true;
+        op.set = [this](void* p) { m_dev.front_store = static_cast<double*>(p); };
+        if (m_defer) m_pending.push_back(std::move(op));
+        else run_op(op);
+    }
     lap("device tables: front store");
     // (n doubles, and room behind them for the solution of the merged top block, MfSchedule::Top)
     const char* env_top = std::getenv("SANM_MF_TOP");

@@ -31,6 +31,7 @@
 #pragma once
 #include <cstdint>
 #include <functional>
+#include <future>
 #include <memory>
 #include <vector>
 
@@ -78,7 +79,17 @@ private:
         size_t bytes = 0;
         bool zero = false;
         std::function<void(void*)> set;  // stores the device pointer where it belongs
+        bool detached = false;           // the block m_front_job asked for, if it got one
     };
+    //! the front store asked for beside the analysis (Backend::alloc_detached); given back if nobody adopts it
+    struct DetachedAlloc {
+        Backend* be = nullptr;
+        std::future<void*> job;
+        ~DetachedAlloc() {
+            if (job.valid())
+                if (void* p = job.get()) be->free_detached(p);
+        }
+    } m_front_job;
     std::vector<DeviceOp> m_pending;
     void run_op(DeviceOp& op);
     template <class T>

@@ -86,12 +86,12 @@ DeviceRows::DeviceRows(Backend* be, const SparseDesc& d, int64_t T, int64_t Tpad
     if (std::getenv("SANM_DEBUG"))
         std::fprintf(stderr, "remap_out: %ld rows, %u entries, rows in triples: %s\n", (long)nr, ptr[nr], triples ? "yes" : "no");
     // rows [r0 .. ) of the source, every `step`-th one, packed: the whole table (step 1) or the first row of each triple
-    auto pack = [&](int step, std::vector<uint32_t>& optr, std::vector<uint32_t>& oidx, std::vector<double>& ocoef) {
+    auto pack = [&](int step, std::vector<uint32_t>& optr, std::unique_ptr<uint32_t[]>& oidx, std::unique_ptr<double[]>& ocoef) {
         const int64_t rows = nr / step;
         optr.assign(rows + 1, 0);
         for (int64_t u = 0; u < rows; ++u) optr[u + 1] = optr[u] + (ptr[step * u + 1] - ptr[step * u]);
-        oidx.resize(optr[rows]);
-        ocoef.resize(optr[rows]);
+        oidx = raw_array<uint32_t>(optr[rows]);  // (the workers touch their own pages first)
+        ocoef = raw_array<double>(optr[rows]);
         parallel_ranges(rows, 4096, [&](int64_t u0, int64_t u1, int) {
             for (int64_t u = u0; u < u1; ++u) {
                 uint32_t w = optr[u], li;
@@ -104,16 +104,18 @@ DeviceRows::DeviceRows(Backend* be, const SparseDesc& d, int64_t T, int64_t Tpad
         });
     };
     laps.lap("counts, triples");
-    std::vector<uint32_t> optr, oidx;
-    std::vector<double> ocoef;
+    std::vector<uint32_t> optr;
+    std::unique_ptr<uint32_t[]> oidx;
+    std::unique_ptr<double[]> ocoef;
     pack(triples ? 3 : 1, optr, oidx, ocoef);
+    const size_t nent = optr.back();
     laps.lap("pack");
     void* dptr = be->alloc(optr.size() * 4);
-    void* didx = be->alloc(std::max<size_t>(oidx.size(), 1) * 4);
-    void* dcoef = be->alloc(std::max<size_t>(oidx.size(), 1) * 8);
+    void* didx = be->alloc(std::max<size_t>(nent, 1) * 4);
+    void* dcoef = be->alloc(std::max<size_t>(nent, 1) * 8);
     be->h2d(dptr, optr.data(), optr.size() * 4);
-    be->h2d(didx, oidx.data(), oidx.size() * 4);
-    be->h2d(dcoef, ocoef.data(), oidx.size() * 8);
+    be->h2d(didx, oidx.get(), nent * 4);
+    be->h2d(dcoef, ocoef.get(), nent * 8);
     laps.lap("upload");
     if (triples) {
         // only the list of the first row of each triple is kept (row_ops.h: gather_row reads rows 3u+1, 3u+2 through it)
