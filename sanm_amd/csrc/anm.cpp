@@ -1023,12 +1023,28 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
     m_setup.emplace_back(m_prog->jit_source == 4 ? "jit_embedded" : m_prog->jit_source == 3 ? "jit_compiled" : m_prog->jit_source == 2 ? "jit_disk_hit"
                          : m_prog->jit_source == 1 ? "jit_memory_hit" : "jit_none", 1.0);
     sanm_check(m_prog->dev().odim == 9, "the ANM solvers take a graph whose output is a batched 3x3 matrix");
-    m_prog->set_remap_in(remap_inp.in_size, remap_inp.rowptr.data(), remap_inp.idx.data(),
-                         remap_inp.coef.data());
-    m_remap_out = std::make_unique<DeviceRows>(be, remap_out, te - tb, m_prog->Tpad(), tb, te, 9, tet_inv);
-    lap("remap_tables", t_setup);
-    m_pattern->finish_device(remap_out, remap_inp);
-    lap("pattern", t_setup);
+    if (serial) {
+        m_prog->set_remap_in(remap_inp.in_size, remap_inp.rowptr.data(), remap_inp.idx.data(),
+                             remap_inp.coef.data());
+        m_remap_out = std::make_unique<DeviceRows>(be, remap_out, te - tb, m_prog->Tpad(), tb, te, 9, tet_inv);
+        lap("remap_tables", t_setup);
+        m_pattern->finish_device(remap_out, remap_inp);
+        lap("pattern", t_setup);
+    } else {
+        // the host halves of the two remap tables on a thread beside the device side of the pattern (round 6); their
+        // uploads follow on this thread
+        auto tables = std::async(std::launch::async, [&] {
+            return std::make_pair(m_prog->prepare_remap_in(remap_inp.in_size, remap_inp.rowptr.data(), remap_inp.idx.data(),
+                                                           remap_inp.coef.data()),
+                                  DeviceRows::pack_host(remap_out, te - tb, m_prog->Tpad(), tb, te, 9, tet_inv));
+        });
+        m_pattern->finish_device(remap_out, remap_inp);
+        lap("pattern", t_setup);
+        auto host = tables.get();  // (rethrows)
+        m_prog->set_remap_in(std::move(host.first));
+        m_remap_out = std::make_unique<DeviceRows>(be, std::move(host.second));
+        lap("remap_tables", t_setup);
+    }
     std::unique_ptr<Multifrontal> analysed;
     if (analysis.valid()) {
         analysed = analysis.get();  // (rethrows what the analysis threw)

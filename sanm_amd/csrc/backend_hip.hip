@@ -2503,6 +2503,11 @@ public:
         HIP_CHECK(hipMemsetAsync(mf.status, 0, sizeof(int32_t), m_stream));
         SANM_LAUNCH(absmax_kernel, dim3(red_grid(mf.nnzA)), dim3(256), 0, m_stream, (size_t)mf.nnzA, A.val,
                            red_to(mf.piv_amax));
+        if (!sch.a_dst_ready) {  // (the first factorisation of this solver: where the entries of A go)
+            sanm_check(A.rowptr && A.col && A.nnz == mf.nnzA, "multifrontal: the matrix to factor is not the analysed pattern");
+            SANM_LAUNCH(scatter_map_kernel, dim3(nblk(mf.n, 4)), dim3(256), 0, m_stream, mf, A.rowptr, A.col);
+            sch.a_dst_ready = true;
+        }
         SANM_LAUNCH(scatter_kernel, dim3(nblk(mf.nnzA, 256)), dim3(256), 0, m_stream, mf.nnzA,
                            mf.a_dst, A.val, mf.front_store);
         SANM_LAUNCH(aug_identity_kernel, dim3(nblk(mf.n, 256)), dim3(256), 0, m_stream, mf);

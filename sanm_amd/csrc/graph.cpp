@@ -889,6 +889,11 @@ Program::~Program() {
 
 void Program::set_remap_in(int64_t n_in, const uint64_t* rowptr, const uint64_t* idx,
                            const double* coef) {
+    set_remap_in(prepare_remap_in(n_in, rowptr, idx, coef));
+}
+
+Program::RemapInHost Program::prepare_remap_in(int64_t n_in, const uint64_t* rowptr, const uint64_t* idx,
+                                               const double* coef) const {
     const int64_t T = m_dev.T, Tpad = m_dev.Tpad;
     int nslot = 0;
     const int64_t* ord = m_tet_order.empty() ? nullptr : m_tet_order.data();
@@ -962,19 +967,31 @@ void Program::set_remap_in(int64_t n_in, const uint64_t* rowptr, const uint64_t*
             }
         });
     laps.lap("fill");
+    RemapInHost out;
+    out.idx = std::move(hidx);
+    out.coef = std::move(hcoef);
+    out.tab = tab;
+    out.nslot = nslot;
+    out.packed = pack;
+    out.n_in = n_in;
+    return out;
+}
+
+void Program::set_remap_in(RemapInHost&& t) {
+    SetupLaps laps("remap_in table");
     if (m_d_rin_idx) m_be->free(m_d_rin_idx);
     if (m_d_rin_coef) m_be->free(m_d_rin_coef);
     m_d_rin_coef = nullptr;
-    m_d_rin_idx = m_be->alloc(tab * sizeof(uint32_t));
-    m_be->h2d(m_d_rin_idx, hidx.get(), tab * sizeof(uint32_t));
-    if (!pack) {
-        m_d_rin_coef = m_be->alloc(tab * sizeof(double));
-        m_be->h2d(m_d_rin_coef, hcoef.get(), tab * sizeof(double));
+    m_d_rin_idx = m_be->alloc(t.tab * sizeof(uint32_t));
+    m_be->h2d(m_d_rin_idx, t.idx.get(), t.tab * sizeof(uint32_t));
+    if (!t.packed) {
+        m_d_rin_coef = m_be->alloc(t.tab * sizeof(double));
+        m_be->h2d(m_d_rin_coef, t.coef.get(), t.tab * sizeof(double));
     }
     laps.lap("upload");
     m_dev.rin = {static_cast<const uint32_t*>(m_d_rin_idx),
-                 static_cast<const double*>(m_d_rin_coef), nslot};
-    m_n_in = n_in;
+                 static_cast<const double*>(m_d_rin_coef), t.nslot};
+    m_n_in = t.n_in;
 }
 
 void Program::download_var(int graph_var, int order, double* dst) const {

@@ -121,7 +121,18 @@ public:
     //! attach the remap_in table (ELL), converting flattened AoS output
     //! indices e*9+c (fea/mesh_template.h:73-110) to the SoA layout
     void set_remap_in(int64_t n_in, const uint64_t* rowptr, const uint64_t* idx,
-                      const double* coef);  // rowptr indexed by GLOBAL output element (of the caller's numbering)
+                      const double* coef);
+    //! the host half of set_remap_in (no backend: any thread) and the device half (the backend's owner thread)
+    struct RemapInHost {
+        std::unique_ptr<uint32_t[]> idx;
+        std::unique_ptr<double[]> coef;
+        size_t tab = 0;
+        int nslot = 1;
+        bool packed = false;
+        int64_t n_in = 0;
+    };
+    RemapInHost prepare_remap_in(int64_t n_in, const uint64_t* rowptr, const uint64_t* idx, const double* coef) const;
+    void set_remap_in(RemapInHost&& table);  // rowptr indexed by GLOBAL output element (of the caller's numbering)
 
     ProgramDev dev() const { return m_dev; }
     //! HIP source of the four pass kernels with this program's records as compile-time constants

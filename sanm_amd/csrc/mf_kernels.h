@@ -52,6 +52,16 @@ __global__ void scatter_kernel(int64_t nnz, const int64_t* __restrict__ a_dst,
     if (p < nnz) store[a_dst[p]] = val[p];
 }
 
+// a_dst of every entry of A (mf_types.h, mf_scatter_slot), once per solver: a wavefront per row of A
+__global__ void __launch_bounds__(256) scatter_map_kernel(MfDev mf, const uint32_t* __restrict__ rowptr,
+                                                          const uint32_t* __restrict__ col) {
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= mf.n) return;
+    const int32_t pi = mf.perm[i];
+    for (uint32_t p = rowptr[i] + (threadIdx.x & 63); p < rowptr[i + 1]; p += 64)
+        mf.a_dst[p] = mf_scatter_slot(mf.fronts, mf.own_front, mf.bnd_idx, pi, mf.perm[col[p]]);
+}
+
 // identity blocks of the augmentation: F[r, k + r] = F[k + r, r] = 1 for r < k
 __global__ void aug_identity_kernel(MfDev mf) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -65,8 +65,10 @@ struct MfDev {
     const int32_t* rel;
     const int32_t* perm;          // original -> new numbering
     const int32_t* own_front;     // new index -> owning front (identity init of the augmentation)
-    // scatter of A: front_store[a_dst[p]] = A.val[p]
-    const int64_t* a_dst;
+    // scatter of A: front_store[a_dst[p]] = A.val[p].  Filled by the backend from the matrix's pattern when the first
+    // factorisation runs (mf_scatter_slot below; MfSchedule::a_dst_ready) -- 8 bytes per entry that the analysis neither
+    // computes on the host nor uploads (round 6)
+    int64_t* a_dst;
     // extend-add: child lists per level and round
     double* front_store;          // sum of m*m
     double* work;                 // n doubles (permuted rhs / solution)
@@ -77,6 +79,30 @@ struct MfDev {
                                   // perturbed (MF_PIVOT_EPS)
     int64_t front_store_size;
 };
+
+//! where entry (i, j) of the matrix (new numbering: pi, pj) sits in the front storage: in the front that owns the smaller
+//! of the two, at the positions of both among its [pivots | augmentation | boundary]
+MF_HD inline int64_t mf_scatter_slot(const MfFrontDev* fronts, const int32_t* own_front, const int32_t* bnd_idx, int32_t pi,
+                                     int32_t pj) {
+    const MfFrontDev& f = fronts[own_front[pi < pj ? pi : pj]];
+    int32_t pos[2];
+    for (int w = 0; w < 2; ++w) {
+        const int32_t x = w == 0 ? pi : pj;
+        if (x >= f.own_start && x < f.own_start + f.k) {
+            pos[w] = x - f.own_start;
+            continue;
+        }
+        const int32_t* b = bnd_idx + f.bnd_off;
+        int32_t lo = 0, hi = f.m - f.k;  // first boundary entry >= x (the analysis made sure it is x)
+        while (lo < hi) {
+            const int32_t mid = (lo + hi) >> 1;
+            if (b[mid] < x) lo = mid + 1;
+            else hi = mid;
+        }
+        pos[w] = 2 * f.k + lo;
+    }
+    return f.off + (int64_t)pos[0] * f.ld + pos[1];
+}
 
 // One workgroup of a level's solve launch: the front's descriptor and which block of its rows.  The box grids of the
 // sweeps -- (row blocks of the level's LARGEST front) x fronts -- leave 40-60 % of the workgroups of the lower levels
@@ -148,6 +174,7 @@ struct MfSchedule {
     };
     std::vector<Level> levels;
     std::vector<MfFrontDev> h_lfronts;     // host copy of MfDev::lfronts (the solve's block lists are made from it)
+    mutable bool a_dst_ready = false;      // MfDev::a_dst has been filled (by the first factorisation)
     const int32_t* ea_children = nullptr;  // device
     // Round 0 of the extend-add ASSIGNS the parent's F[B,B] instead of adding to a zeroed block (round 6): for boundary
     // position i of a front with children, ea_inv[bnd_off + i] = the boundary position of its FIRST child that lands there,

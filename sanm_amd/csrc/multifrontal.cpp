@@ -308,6 +308,20 @@ class NestedDissection {
     std::vector<int32_t> stamp, dist, queue;
     int32_t cur_stamp = 0;
     int threads = 1;  // host threads bisect() may use for its candidate cuts
+    // fn(begin, end, piece) over pieces of [0, n) whose bounds are multiples of `align`, on this dissection's threads when
+    // the set is big (the cuts at the top of the tree of a 2.7 M-tet mesh are the critical path of the constructor)
+    template <class F>
+    void over_pieces(size_t n, size_t align, F&& fn) const {
+        const int nt = n >= 65536 ? std::max(1, std::min(threads, 16)) : 1;
+        if (nt <= 1) {
+            fn((size_t)0, n, 0);
+            return;
+        }
+        auto bound = [&](int t) { return t >= nt ? n : std::min(n, (n * t / nt) / align * align); };
+        JoinedThreads jt;
+        for (int t = 1; t < nt; ++t) jt.run([&, t] { fn(bound(t), bound(t + 1), t); });
+        fn(bound(0), bound(1), 0);
+    }
     const int LEAF = std::getenv("SANM_MF_LEAF") ? std::atoi(std::getenv("SANM_MF_LEAF")) : 32;
 
 public:
@@ -369,8 +383,23 @@ public:
         }
         out[0].vars = std::move(sep);
         std::vector<std::pair<std::vector<int32_t>, int32_t>> parts;
-        nd.split_components(pa, 0, parts);
-        nd.split_components(pb, 0, parts);
+        if (set.size() >= 65536) {
+            // (the components of the second side on a thread and a dissection object of its own: the sides share no vertex)
+            std::vector<std::pair<std::vector<int32_t>, int32_t>> parts_b;
+            {
+                JoinedThreads jt;
+                jt.run([&] {
+                    NestedDissection other{g};
+                    other.in_set.assign(g.nsv, -1);
+                    other.split_components(pb, 0, parts_b);
+                });
+                nd.split_components(pa, 0, parts);
+            }
+            for (auto& pr : parts_b) parts.push_back(std::move(pr));
+        } else {
+            nd.split_components(pa, 0, parts);
+            nd.split_components(pb, 0, parts);
+        }
         // the sequential loop pops the part pushed last first
         std::reverse(parts.begin(), parts.end());
         size_t total = 0;
@@ -518,11 +547,13 @@ public:
                 const int d = dirs[t];
                 if (t > 0 && !(C[d][d] > 0.05 * C[dirs[0]][dirs[0]])) break;
                 std::vector<double> key(ns);
-                for (size_t i = 0; i < ns; ++i) {
-                    const int32_t u = set[i];
-                    key[i] = (g.xyz[u * 3] - mean[0]) * V[0][d] + (g.xyz[u * 3 + 1] - mean[1]) * V[1][d] +
-                             (g.xyz[u * 3 + 2] - mean[2]) * V[2][d];
-                }
+                over_pieces(ns, 1, [&](size_t i0, size_t i1, int) {
+                    for (size_t i = i0; i < i1; ++i) {
+                        const int32_t u = set[i];
+                        key[i] = (g.xyz[u * 3] - mean[0]) * V[0][d] + (g.xyz[u * 3 + 1] - mean[1]) * V[1][d] +
+                                 (g.xyz[u * 3 + 2] - mean[2]) * V[2][d];
+                    }
+                });
                 keys.push_back(std::move(key));
             }
             // A cloud with two (nearly) equal extents -- the halves of a cube, a plate -- has no principal directions
@@ -541,7 +572,9 @@ public:
                 for (int d = 0; d < 3; ++d) {
                     if (!(var_axis[d] > 0.05 * vmax)) continue;
                     std::vector<double> key(ns);
-                    for (size_t i = 0; i < ns; ++i) key[i] = g.xyz[set[i] * 3 + d];
+                    over_pieces(ns, 1, [&](size_t i0, size_t i1, int) {
+                        for (size_t i = i0; i < i1; ++i) key[i] = g.xyz[set[i] * 3 + d];
+                    });
                     keys.push_back(std::move(key));
                 }
             }
@@ -663,15 +696,27 @@ public:
                 }
             }
         const std::vector<int32_t>& best_ord = ords[best_k];
-        for (size_t i = 0; i < ns; ++i) in_set[set[best_ord[i]]] = i < best_cut ? markA : markB;
+        over_pieces(ns, 1, [&](size_t i0, size_t i1, int) {
+            for (size_t i = i0; i < i1; ++i) in_set[set[best_ord[i]]] = i < best_cut ? markA : markB;
+        });
 
-        // boundary layers and the bipartite graph of the cut edges
+        // boundary layers and the bipartite graph of the cut edges (found by pieces of the set, joined in their order)
         std::vector<int32_t> bA, bB;
-        for (int32_t u : set) {
-            const int32_t other = in_set[u] == markA ? markB : markA;
-            bool touch = false;
-            for (int32_t q = g.adj_ptr[u]; q < g.adj_ptr[u + 1] && !touch; ++q) touch = in_set[g.adj[q]] == other;
-            if (touch) (in_set[u] == markA ? bA : bB).push_back(u);
+        {
+            std::vector<std::vector<int32_t>> pA(16), pB(16);
+            over_pieces(ns, 1, [&](size_t i0, size_t i1, int t) {
+                for (size_t i = i0; i < i1; ++i) {
+                    const int32_t u = set[i];
+                    const int32_t other = in_set[u] == markA ? markB : markA;
+                    bool touch = false;
+                    for (int32_t q = g.adj_ptr[u]; q < g.adj_ptr[u + 1] && !touch; ++q) touch = in_set[g.adj[q]] == other;
+                    if (touch) (in_set[u] == markA ? pA : pB)[t].push_back(u);
+                }
+            });
+            for (int t = 0; t < 16; ++t) {
+                bA.insert(bA.end(), pA[t].begin(), pA[t].end());
+                bB.insert(bB.end(), pB[t].begin(), pB[t].end());
+            }
         }
         // maximum matching by augmenting paths (boundary layers have hundreds of vertices)
         std::vector<int32_t>& loc = dist;  // position of a boundary vertex in bA / bB
@@ -785,23 +830,34 @@ public:
         const size_t ns = set.size();
         int64_t w[3] = {0, 0, 0};  // A, B, S
         auto side_of = [&](int32_t u) { return in_set[u] == markA ? 0 : (in_set[u] == markB ? 1 : (in_set[u] == markS ? 2 : 3)); };
-        for (int32_t u : set) w[side_of(u)] += g.size(u);
+        {
+            int64_t pw[16][3] = {};
+            over_pieces(ns, 1, [&](size_t i0, size_t i1, int t) {
+                for (size_t i = i0; i < i1; ++i) pw[t][side_of(set[i])] += g.size(set[i]);
+            });
+            for (int t = 0; t < 16; ++t)
+                for (int d = 0; d < 3; ++d) w[d] += pw[t][d];
+        }
         const int64_t wTot = w[0] + w[1] + w[2];
         const int64_t wMax = std::max<int64_t>((int64_t)(0.58 * wTot), std::max(w[0], w[1]));
         std::vector<int32_t>& locked = stamp;  // stamp[v] == cur_stamp: moved in this pass
         std::vector<int32_t>& pos = dist;      // position of a member in the set
         std::vector<int32_t> nA(ns, 0), nB(ns, 0);
         std::vector<uint64_t> sep_bits((ns + 63) / 64, 0);
-        for (size_t i = 0; i < ns; ++i) pos[set[i]] = (int32_t)i;
-        for (size_t i = 0; i < ns; ++i) {
-            const int32_t u = set[i];
-            if (in_set[u] == markS) sep_bits[i >> 6] |= 1ull << (i & 63);
-            for (int32_t q = g.adj_ptr[u]; q < g.adj_ptr[u + 1]; ++q) {
-                const int32_t v = g.adj[q];
-                if (in_set[v] == markA) nA[i] += g.size(v);
-                else if (in_set[v] == markB) nB[i] += g.size(v);
+        over_pieces(ns, 64, [&](size_t i0, size_t i1, int) {
+            for (size_t i = i0; i < i1; ++i) pos[set[i]] = (int32_t)i;
+        });
+        over_pieces(ns, 64, [&](size_t i0, size_t i1, int) {  // (pieces of whole bitmap words)
+            for (size_t i = i0; i < i1; ++i) {
+                const int32_t u = set[i];
+                if (in_set[u] == markS) sep_bits[i >> 6] |= 1ull << (i & 63);
+                for (int32_t q = g.adj_ptr[u]; q < g.adj_ptr[u + 1]; ++q) {
+                    const int32_t v = g.adj[q];
+                    if (in_set[v] == markA) nA[i] += g.size(v);
+                    else if (in_set[v] == markB) nB[i] += g.size(v);
+                }
             }
-        }
+        });
         std::vector<std::pair<int32_t, int32_t>> undo;  // (vertex, mark it had) since the best state of the pass
         auto set_state = [&](int32_t u, int32_t to) {
             const int32_t from = in_set[u];
@@ -826,6 +882,7 @@ public:
             int64_t best_imb = std::llabs(w[0] - w[1]);
             undo.clear();
             int64_t wa = w[0], wb = w[1];
+            int64_t best_wa = wa, best_wb = wb;  // (the sides' weights in the best state: exact integer bookkeeping)
             int since_best = 0;
             for (int step = 0; step < (int)ns && since_best < 60; ++step) {
                 // best admissible move
@@ -874,6 +931,8 @@ public:
                 if (cur_w < best_w || (cur_w == best_w && imb < best_imb)) {
                     best_w = cur_w;
                     best_imb = imb;
+                    best_wa = wa;
+                    best_wb = wb;
                     undo.clear();
                     since_best = 0;
                 } else {
@@ -882,8 +941,7 @@ public:
             }
             for (size_t i = undo.size(); i-- > 0;) set_state(undo[i].first, undo[i].second);
             const int64_t before = w[2];
-            w[0] = w[1] = w[2] = 0;
-            for (int32_t u : set) w[side_of(u)] += g.size(u);
+            w[0] = best_wa, w[1] = best_wb, w[2] = best_w;  // (what a count over the set would find)
             if (w[2] >= before) break;
         }
     }
@@ -1623,68 +1681,28 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     for (int32_t f = 0; f < F; ++f)
         for (int32_t q = 0; q < fr[f].k; ++q) owner[fr[f].own_start + q] = f;
 
-    // scatter map of A
+    // The scatter map of A -- front_store[a_dst[p]] = val[p] -- is the backend's to fill when the first factorisation
+    // runs (mf_types.h, mf_scatter_slot: a search of a boundary list per entry, nothing on a device and 8 bytes per entry
+    // that are neither computed here nor uploaded; round 6).  Every entry has its place because the supervariable graph
+    // was built from these very rows; SANM_MF_DEBUG looks every one of them up.
     const int64_t nnzA = col.size();
-    // (left uninitialised: the threads below touch its pages first, each its own)
-    std::shared_ptr<int64_t[]> a_dst_keep(new int64_t[std::max<int64_t>(nnzA, 1)]);
-    int64_t* const a_dst = a_dst_keep.get();
-    {
+    if (dbg_clock) {
         std::vector<std::string> errs(64);
         parallel_ranges(n, 2048, [&](int64_t r0, int64_t r1, int t) {
-            try {
-                // The members of a supervariable are neighbours in the new numbering and in every front they are part
-                // of: an entry whose column follows the previous entry's inside one supervariable sits one place to its
-                // right, and a row that follows the row above inside one supervariable with the same column list sits
-                // one front row lower -- a binary search of a boundary list for one entry in nine of a 3 x 3-block
-                // pattern instead of for every entry (round 6: 0.07 of the 0.5 s of a 235 k-unknown analysis).
-                for (int64_t i = r0; i < r1; ++i) {
-                    const uint32_t b = rowptr[i], e = rowptr[i + 1];
-                    const int32_t pi = perm[i];
-                    if (i > 0 && g.sv_of[i] == g.sv_of[i - 1] && pi == perm[i - 1] + 1 && e - b == b - rowptr[i - 1] &&
-                        std::memcmp(&col[b], &col[rowptr[i - 1]], (size_t)(e - b) * sizeof(uint32_t)) == 0) {
-                        const uint32_t up = rowptr[i - 1];
-                        // (the rows above may belong to another thread's range: their fronts are looked up again)
-                        for (uint32_t p = b; p < e; ++p) {
-                            const int32_t pj = perm[col[p]];
-                            const int32_t f = owner[std::min(pi - 1, pj)];
-                            if (i - 1 >= r0) {
-                                a_dst[p] = a_dst[up + (p - b)] + fr[f].ld;
-                            } else {
-                                a_dst[p] = fr[f].off + (int64_t)pos_in_front(f, pi) * fr[f].ld + pos_in_front(f, pj);
-                            }
-                        }
-                        continue;
-                    }
-                    for (uint32_t p = b; p < e; ++p) {
-                        const int32_t pj = perm[col[p]];
-                        if (p > b && g.sv_of[col[p]] == g.sv_of[col[p - 1]] && pj == perm[col[p - 1]] + 1) {
-                            a_dst[p] = a_dst[p - 1] + 1;
-                            continue;
-                        }
-                        const int32_t f = owner[std::min(pi, pj)];
-                        a_dst[p] = fr[f].off + (int64_t)pos_in_front(f, pi) * fr[f].ld + pos_in_front(f, pj);
+            for (int64_t i = r0; i < r1; ++i)
+                for (uint32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+                    const int32_t pi = perm[i], pj = perm[col[p]];
+                    const MfFrontDev& f = fr[owner[std::min(pi, pj)]];
+                    for (int32_t x : {pi, pj}) {
+                        if (x >= f.own_start && x < f.own_start + f.k) continue;
+                        const int32_t* bb = bnd_idx.data() + f.bnd_off;
+                        if (!std::binary_search(bb, bb + (f.m - f.k), x)) errs[t % 64] = "an entry of A has no place in its front";
                     }
                 }
-            } catch (const SanmError& e) {
-                errs[t % 64] = e.msg;
-            }
         });
         for (const auto& e : errs) sanm_check(e.empty(), "%s", e.c_str());
-        lap("scatter map of A");
-        if (dbg_clock) {  // every entry once more, looked up on its own
-            parallel_ranges(n, 2048, [&](int64_t r0, int64_t r1, int t) {
-                for (int64_t i = r0; i < r1; ++i)
-                    for (uint32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
-                        const int32_t pi = perm[i], pj = perm[col[p]];
-                        const int32_t f = owner[std::min(pi, pj)];
-                        if (a_dst[p] != fr[f].off + (int64_t)pos_in_front(f, pi) * fr[f].ld + pos_in_front(f, pj))
-                            errs[t % 64] = "scatter map: a shortcut entry differs from its own lookup";
-                    }
-            });
-            for (const auto& e : errs) sanm_check(e.empty(), "%s", e.c_str());
-            std::fprintf(stderr, "mf analysis: scatter map checked entry by entry\n");
-            lap("(debug: that check)");
-        }
+        std::fprintf(stderr, "mf analysis: every entry of A has its place\n");
+        lap("(debug: places of A's entries)");
     }
 
     // levels: fronts by height, by decreasing k inside a level.  Distributed: this rank's own fronts only, stage after
@@ -1884,7 +1902,7 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     upload_kept(m_dev.rel, rel_keep, rel.data(), rel.size());
     upload_to(m_dev.perm, perm);
     upload_to(m_dev.own_front, std::move(owner));
-    upload_kept(m_dev.a_dst, a_dst_keep, a_dst, (size_t)nnzA);
+    alloc_to(m_dev.a_dst, (size_t)std::max<int64_t>(nnzA, 1) * sizeof(int64_t), false);
     upload_to(m_sched.ea_children, ea_children);
     {
         // the parent-side map of round 0 (mf_types.h, MfSchedule::ea_inv)

@@ -30,7 +30,10 @@ SparseDesc::SparseDesc(int64_t out_size_, int64_t in_size_, const uint64_t* rp, 
 
 DeviceRows::DeviceRows(Backend* be, const SparseDesc& d, int64_t T, int64_t Tpad, int64_t tet_begin,
                        int64_t tet_end, int64_t block, const int64_t* tet_inv)
-        : m_be{be} {
+        : DeviceRows(be, pack_host(d, T, Tpad, tet_begin, tet_end, block, tet_inv)) {}
+
+DeviceRows::Packed DeviceRows::pack_host(const SparseDesc& d, int64_t T, int64_t Tpad, int64_t tet_begin,
+                                         int64_t tet_end, int64_t block, const int64_t* tet_inv) {
     sanm_check(block >= 1 && d.in_size % block == 0, "sparse map over a (T,%ld) tensor: got %ld input elements",
                (long)block, (long)d.in_size);
     if (tet_end < 0) tet_end = d.in_size / block;
@@ -104,20 +107,26 @@ DeviceRows::DeviceRows(Backend* be, const SparseDesc& d, int64_t T, int64_t Tpad
         });
     };
     laps.lap("counts, triples");
-    std::vector<uint32_t> optr;
-    std::unique_ptr<uint32_t[]> oidx;
-    std::unique_ptr<double[]> ocoef;
-    pack(triples ? 3 : 1, optr, oidx, ocoef);
-    const size_t nent = optr.back();
+    Packed out;
+    out.nr = nr;
+    out.triples = triples;
+    pack(triples ? 3 : 1, out.ptr, out.idx, out.coef);
     laps.lap("pack");
-    void* dptr = be->alloc(optr.size() * 4);
+    return out;
+}
+
+DeviceRows::DeviceRows(Backend* be, Packed&& rows) : m_be{be} {
+    SetupLaps laps("remap_out rows");
+    const size_t nent = rows.ptr.empty() ? 0 : rows.ptr.back();
+    const int64_t nr = rows.nr;
+    void* dptr = be->alloc(std::max<size_t>(rows.ptr.size(), 1) * 4);
     void* didx = be->alloc(std::max<size_t>(nent, 1) * 4);
     void* dcoef = be->alloc(std::max<size_t>(nent, 1) * 8);
-    be->h2d(dptr, optr.data(), optr.size() * 4);
-    be->h2d(didx, oidx.get(), nent * 4);
-    be->h2d(dcoef, ocoef.get(), nent * 8);
+    be->h2d(dptr, rows.ptr.data(), rows.ptr.size() * 4);
+    be->h2d(didx, rows.idx.get(), nent * 4);
+    be->h2d(dcoef, rows.coef.get(), nent * 8);
     laps.lap("upload");
-    if (triples) {
+    if (rows.triples) {
         // only the list of the first row of each triple is kept (row_ops.h: gather_row reads rows 3u+1, 3u+2 through it)
         m_bptr = dptr, m_bidx = didx, m_bcoef = dcoef;
         m_dev = {nullptr, nullptr, nullptr, nr, static_cast<uint32_t*>(dptr), static_cast<uint32_t*>(didx),

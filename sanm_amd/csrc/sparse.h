@@ -10,6 +10,7 @@
 // per non-zero that a HIP kernel evaluates every step.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <vector>
 
 #include "backend.h"
@@ -41,6 +42,17 @@ public:
     //! tet_inv (optional): batch item b of the map's inputs is item tet_inv[b] of the tensor (the driver's renumbering)
     DeviceRows(Backend* be, const SparseDesc& d, int64_t T, int64_t Tpad, int64_t tet_begin = 0,
                int64_t tet_end = -1, int64_t block = 9, const int64_t* tet_inv = nullptr);
+    //! the host half of the constructor above (no backend: any thread) and the device half (the backend's owner thread)
+    struct Packed {
+        std::vector<uint32_t> ptr;
+        std::unique_ptr<uint32_t[]> idx;
+        std::unique_ptr<double[]> coef;
+        int64_t nr = 0;
+        bool triples = false;
+    };
+    static Packed pack_host(const SparseDesc& d, int64_t T, int64_t Tpad, int64_t tet_begin = 0, int64_t tet_end = -1,
+                            int64_t block = 9, const int64_t* tet_inv = nullptr);
+    DeviceRows(Backend* be, Packed&& rows);
     ~DeviceRows();
     SparseRowsDev dev() const { return m_dev; }
 

@@ -328,7 +328,7 @@ def test_supervariables_from_runs_of_equal_rows(api, monkeypatch):
     the pattern of the runs then goes through the hashing of closed neighbourhoods (multifrontal.cpp, build_sv_graph;
     round 6).  On a symmetric pattern that is the partition, the numbering and the ordering the hashing of the whole
     pattern gives (SANM_MF_SV_RUNS=0) -- same statistics, same bits of a solve; SANM_MF_DEBUG makes the analysis check
-    its scatter map and its parent positions entry by entry against a search of their own.  In an unsymmetric pattern
+    its parent positions entry by entry against a search of their own and look up the place of every entry of A.  In an unsymmetric pattern
     rows of a run may differ in their COLUMNS: the run is then a supervariable with explicit zeros, and the system is
     still solved."""
     monkeypatch.setenv("SANM_MF_DEBUG", "1")
