@@ -312,7 +312,11 @@ class NestedDissection {
     // the set is big (the cuts at the top of the tree of a 2.7 M-tet mesh are the critical path of the constructor)
     template <class F>
     void over_pieces(size_t n, size_t align, F&& fn) const {
-        const int nt = n >= 65536 ? std::max(1, std::min(threads, 16)) : 1;
+        // (from 256 k supervariables: on the GPU box's cores the threads cost a 78 k-supervariable root cut 0.02 s more than
+        // they saved, session r6ab1, and a 538 k one breaks even, r6ab2; on 8 slower cores the dissection of the latter went
+        // from 1.19 to 0.99 s.  SANM_MF_ND_TOP_SERIAL: never)
+        static const bool serial = std::getenv("SANM_MF_ND_TOP_SERIAL") != nullptr;
+        const int nt = n >= 262144 && !serial ? std::max(1, std::min(threads, 16)) : 1;
         if (nt <= 1) {
             fn((size_t)0, n, 0);
             return;
@@ -383,7 +387,7 @@ public:
         }
         out[0].vars = std::move(sep);
         std::vector<std::pair<std::vector<int32_t>, int32_t>> parts;
-        if (set.size() >= 65536) {
+        if (set.size() >= 262144) {
             // (the components of the second side on a thread and a dissection object of its own: the sides share no vertex)
             std::vector<std::pair<std::vector<int32_t>, int32_t>> parts_b;
             {
