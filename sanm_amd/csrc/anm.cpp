@@ -975,9 +975,33 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
     // does not depend on their numbering: it is built beside the renumbering (round 6; a shard's pattern needs the
     // numbering first).  SANM_SETUP_SERIAL=1: one thing after the other.
     const bool serial = std::getenv("SANM_SETUP_SERIAL") != nullptr;
+    const double* coords = remap_out.out_coords.size() == (size_t)m_n * 3 ? remap_out.out_coords.data() : nullptr;
+    // (the merged top block, SANM_MF_TOP > 0, multiplies device blocks out while the analysis builds it, i.e. it is
+    // not deferred: it must run on this thread, the owner of the backend, whose pool and staging buffers have no lock)
+    const bool mf_top = std::getenv("SANM_MF_TOP") && std::atoi(std::getenv("SANM_MF_TOP")) > 0;
+    const bool beside = hp.solver_kind == 1 && hp.xcoeff_l2_penalty == 0 && !serial && !mf_top;
+    const bool dist = m_shard.active() && m_shard.world > 1;
+    // The analysis starts as soon as the pattern's BLOCK rows exist (sparse.h, on_blocks: the Jacobian of a mesh with three
+    // unknowns per vertex), i.e. while the rows of the unknowns are still being written out and the tets renumbered
+    // (round 6); a pattern without that structure hands the analysis its rows when they are complete.
+    std::future<std::unique_ptr<Multifrontal>> analysis;
+    // (whatever fails below, the thread is joined before what it reads goes away)
+    struct Join {
+        std::future<std::unique_ptr<Multifrontal>>& f;
+        ~Join() {
+            if (f.valid()) f.wait();
+        }
+    } join{analysis};
+    auto on_blocks = [&](JacobianPattern::BlockRows qptr, JacobianPattern::BlockRows qcol) {
+        if (!beside || std::getenv("SANM_ANALYSIS_FROM_ROWS")) return;
+        analysis = std::async(std::launch::async, [this, be, coords, dist, qptr, qcol] {
+            return std::make_unique<Multifrontal>(be, m_n, Multifrontal::BlockPattern{3, qptr, qcol}, coords,
+                                                  dist ? m_shard.rank : 0, dist ? m_shard.world : 1, /*defer_device=*/true);
+        });
+    };
     auto make_pattern = [&](const int64_t* tet_order, const int64_t* tet_inv) {
         m_pattern = std::make_unique<JacobianPattern>(be, remap_out, remap_inp, m_n, T, 0, 9, tb, te, 9, tet_order, tet_inv,
-                                                      /*defer_device=*/true);
+                                                      /*defer_device=*/true, on_blocks);
     };
     const bool pattern_beside = reorder && !serial && tb == 0 && te == T;
     {
@@ -993,29 +1017,15 @@ AnmDriver::AnmDriver(Backend* be, const Graph& g_in, int out_var, const SparseDe
     }
     const int64_t* tet_order = reorder ? order.data() : nullptr;
     const int64_t* tet_inv = reorder ? inv.data() : nullptr;
-    const double* coords = remap_out.out_coords.size() == (size_t)m_n * 3 ? remap_out.out_coords.data() : nullptr;
-    // (the merged top block, SANM_MF_TOP > 0, multiplies device blocks out while the analysis builds it, i.e. it is
-    // not deferred: it must run on this thread, the owner of the backend, whose pool and staging buffers have no lock)
-    const bool mf_top = std::getenv("SANM_MF_TOP") && std::atoi(std::getenv("SANM_MF_TOP")) > 0;
-    const bool beside = hp.solver_kind == 1 && hp.xcoeff_l2_penalty == 0 && !serial && !mf_top;
     if (pattern_beside) m_pattern->set_tet_order(tet_order, tet_inv);
     else make_pattern(tet_order, tet_inv);
     lap("pattern", t_setup);
-    std::future<std::unique_ptr<Multifrontal>> analysis;
-    if (beside) {
-        const bool dist = m_shard.active() && m_shard.world > 1;
+    if (beside && !analysis.valid()) {
         analysis = std::async(std::launch::async, [this, be, coords, dist] {
             return std::make_unique<Multifrontal>(be, m_n, m_pattern->h_rowptr(), m_pattern->h_col(), coords,
                                                   dist ? m_shard.rank : 0, dist ? m_shard.world : 1, /*defer_device=*/true);
         });
     }
-    // (whatever fails below, the thread is joined before the pattern it reads goes away)
-    struct Join {
-        std::future<std::unique_ptr<Multifrontal>>& f;
-        ~Join() {
-            if (f.valid()) f.wait();
-        }
-    } join{analysis};
     m_prog = std::make_unique<Program>(be, g, out_var, te - tb, hp.order, tb, T, /*full_history=*/false, tet_order);
     lap("program", t_setup);
     m_setup.back().second -= m_prog->jit_seconds;

@@ -294,6 +294,40 @@ SvGraph build_sv_graph(int64_t n, const std::vector<uint32_t>& rowptr,
     return g;
 }
 
+//! the same graph from the pattern of the BLOCKS (Multifrontal::BlockPattern): what build_sv_graph finds from the expanded
+//! rows -- there the runs of equal rows are the blocks (or runs of blocks with one neighbourhood, which the hashing of the
+//! blocks' pattern joins just as well), the numbering goes by the smallest member either way
+SvGraph build_sv_graph_of_blocks(int64_t n, int block, const std::vector<uint32_t>& qptr, const std::vector<uint32_t>& qcol,
+                                 const double* coords) {
+    const int64_t nq = n / block;
+    SvGraph q = sv_graph_by_hash(nq, qptr, qcol);
+    SvGraph g;
+    g.nsv = q.nsv;
+    g.adj_ptr = std::move(q.adj_ptr);
+    g.adj = std::move(q.adj);
+    g.sv_of.resize(n);
+    parallel_ranges(n, 8192, [&](int64_t r0, int64_t r1, int) {
+        for (int64_t i = r0; i < r1; ++i) g.sv_of[i] = q.sv_of[i / block];
+    });
+    g.sv_ptr.assign(g.nsv + 1, 0);
+    for (int64_t i = 0; i < n; ++i) g.sv_ptr[g.sv_of[i] + 1]++;
+    for (int32_t s2 = 0; s2 < g.nsv; ++s2) g.sv_ptr[s2 + 1] += g.sv_ptr[s2];
+    g.sv_members.resize(n);
+    {
+        std::vector<int32_t> fill(g.sv_ptr.begin(), g.sv_ptr.end() - 1);
+        for (int64_t i = 0; i < n; ++i) g.sv_members[fill[g.sv_of[i]]++] = (int32_t)i;
+    }
+    if (coords) {
+        g.xyz.assign((size_t)g.nsv * 3, 0.0);
+        for (int32_t s = 0; s < g.nsv; ++s) {
+            for (int32_t p = g.sv_ptr[s]; p < g.sv_ptr[s + 1]; ++p)
+                for (int d = 0; d < 3; ++d) g.xyz[s * 3 + d] += coords[(int64_t)g.sv_members[p] * 3 + d];
+            for (int d = 0; d < 3; ++d) g.xyz[s * 3 + d] /= g.size(s);
+        }
+    }
+    return g;
+}
+
 // ---------------------------------------------------------------------------
 // nested dissection
 // ---------------------------------------------------------------------------
@@ -1188,13 +1222,31 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
                            bool defer_device)
         : m_be{be},
           m_defer{defer_device} {
+    sanm_check(n > 0 && (int64_t)rowptr.size() == n + 1, "bad CSR pattern");
+    analyse(n, &rowptr, &col, nullptr, coords, rank, world);
+}
+
+Multifrontal::Multifrontal(Backend* be, int64_t n, const BlockPattern& blocks, const double* coords, int rank, int world,
+                           bool defer_device)
+        : m_be{be},
+          m_defer{defer_device} {
+    sanm_check(blocks.block >= 1 && n > 0 && n % blocks.block == 0 && blocks.qptr && blocks.qcol &&
+                       (int64_t)blocks.qptr->size() == n / blocks.block + 1 && blocks.qptr->back() == blocks.qcol->size(),
+               "bad block pattern");
+    analyse(n, nullptr, nullptr, &blocks, coords, rank, world);
+}
+
+void Multifrontal::analyse(int64_t n, const std::vector<uint32_t>* rowptr_p, const std::vector<uint32_t>* col_p,
+                           const BlockPattern* blocks, const double* coords, int rank, int world) {
+    Backend* const be = m_be;
+    const bool defer_device = m_defer;
+    (void)be;
     const auto t_ctor = std::chrono::steady_clock::now();
     // (the merged top block multiplies device blocks out while it is built: it cannot be deferred, and a constructor
     // that touches the backend must run on the backend's owner thread -- the caller's job, anm.cpp: `beside`)
     sanm_check(!(defer_device && std::getenv("SANM_MF_TOP") && std::atoi(std::getenv("SANM_MF_TOP")) > 0),
                "multifrontal: SANM_MF_TOP needs a constructor that is not deferred (owner thread of the backend)");
     sanm_check(world >= 1 && rank >= 0 && rank < world, "multifrontal: rank %d of %d", rank, world);
-    sanm_check(n > 0 && (int64_t)rowptr.size() == n + 1, "bad CSR pattern");
     sanm_check(n < INT32_MAX / 2, "system too large for 32-bit indices");
     const bool dbg_clock = std::getenv("SANM_MF_DEBUG") != nullptr;
     auto t_clock = std::chrono::steady_clock::now();
@@ -1204,7 +1256,8 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
         std::fprintf(stderr, "mf analysis: %-28s %.3f s\n", what, std::chrono::duration<double>(t1 - t_clock).count());
         t_clock = t1;
     };
-    SvGraph g = build_sv_graph(n, rowptr, col, coords);
+    SvGraph g = blocks ? build_sv_graph_of_blocks(n, blocks->block, *blocks->qptr, *blocks->qcol, coords)
+                       : build_sv_graph(n, *rowptr_p, *col_p, coords);
     lap("supervariable graph");
     nr_supervar = g.nsv;
     used_coords = coords != nullptr;
@@ -1689,8 +1742,9 @@ Multifrontal::Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& 
     // runs (mf_types.h, mf_scatter_slot: a search of a boundary list per entry, nothing on a device and 8 bytes per entry
     // that are neither computed here nor uploaded; round 6).  Every entry has its place because the supervariable graph
     // was built from these very rows; SANM_MF_DEBUG looks every one of them up.
-    const int64_t nnzA = col.size();
-    if (dbg_clock) {
+    const int64_t nnzA = blocks ? (int64_t)blocks->block * blocks->block * (int64_t)blocks->qcol->size() : (int64_t)col_p->size();
+    if (dbg_clock && rowptr_p) {
+        const std::vector<uint32_t>&rowptr = *rowptr_p, &col = *col_p;
         std::vector<std::string> errs(64);
         parallel_ranges(n, 2048, [&](int64_t r0, int64_t r1, int t) {
             for (int64_t i = r0; i < r1; ++i)

@@ -51,6 +51,17 @@ public:
     Multifrontal(Backend* be, int64_t n, const std::vector<uint32_t>& rowptr,
                  const std::vector<uint32_t>& col, const double* coords, int rank = 0, int world = 1,
                  bool defer_device = false);
+    //! The pattern given by BLOCKS: unknowns block * v .. block * v + block - 1 (v < n / block) have one column list, the
+    //! unknowns of the blocks qcol[qptr[v] .. qptr[v + 1]) (ascending; the block v itself among them) -- the Jacobian of
+    //! a mesh with `block` unknowns per vertex, whose block rows the driver knows before the rows themselves (round 6:
+    //! the analysis starts while the pattern of the unknowns is still being written out).  Same supervariables, ordering
+    //! and tables as the constructor above on the expanded pattern; nnz = block^2 * qcol.size() entries.
+    struct BlockPattern {
+        int block = 3;
+        std::shared_ptr<const std::vector<uint32_t>> qptr, qcol;
+    };
+    Multifrontal(Backend* be, int64_t n, const BlockPattern& blocks, const double* coords, int rank = 0, int world = 1,
+                 bool defer_device = false);
     ~Multifrontal();
     void finish_device();
     double analysis_seconds = 0;  // wall clock of the constructor
@@ -67,6 +78,9 @@ public:
     bool used_coords = false;
 
 private:
+    //! the constructors' body: rowptr / col may be null when `blocks` describes the pattern
+    void analyse(int64_t n, const std::vector<uint32_t>* rowptr, const std::vector<uint32_t>* col, const BlockPattern* blocks,
+                 const double* coords, int rank, int world);
     Backend* m_be;
     MfDev m_dev{};
     MfSchedule m_sched;

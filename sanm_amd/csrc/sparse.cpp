@@ -165,7 +165,8 @@ T* JacobianPattern::upload(const std::vector<T>& v) {
 
 JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const SparseDesc& ri, int64_t n,
                                  int64_t T, int64_t Tpad, int odim, int64_t tet_begin, int64_t tet_end, int idim,
-                                 const int64_t* tet_order, const int64_t* tet_inv, bool defer_device)
+                                 const int64_t* tet_order, const int64_t* tet_inv, bool defer_device,
+                                 const std::function<void(BlockRows, BlockRows)>& on_blocks)
         : m_be{be} {
     sanm_check(!tet_order == !tet_inv, "a renumbering of the batch items comes with its inverse");
     if (tet_end < 0) tet_end = T;
@@ -211,6 +212,136 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
         }
     });
     laps.lap("columns of the items");
+    std::vector<uint32_t>& rowptr = m_h_rowptr;
+    std::vector<uint32_t>& col = m_h_col;
+    // ---- 3 x 3 blocks (round 6): when the three rows of every vertex touch the same batch items and every item's columns
+    // are whole triples, a vertex's rows are its BLOCK row written out three times over -- a third of the walk, marks over
+    // vertices instead of unknowns, and the direct solver's analysis can start from the block rows before the rows of
+    // the unknowns exist (on_blocks).  Anything else: the rows one by one, below.  SANM_PATTERN_NO_BLOCKS: never.
+    bool blocked = n % 3 == 0 && n >= 3 && !m_has_t && !std::getenv("SANM_PATTERN_NO_BLOCKS");
+    if (blocked) {
+        std::vector<char> ok(64, 1);
+        parallel_ranges(T, 4096, [&](int64_t b0, int64_t b1, int t) {
+            bool good = true;
+            for (int64_t b = b0; good && b < b1; ++b) {
+                const uint32_t* lc = item_col + ri.rowptr[b * idim];
+                const uint32_t m = item_nr[b];
+                good = m % 3 == 0;
+                for (uint32_t q = 0; good && q < m; q += 3)
+                    good = lc[q] % 3 == 0 && lc[q + 1] == lc[q] + 1 && lc[q + 2] == lc[q] + 2 && (int64_t)lc[q + 2] < n;
+            }
+            if (!good) ok[t % 64] = 0;
+        });
+        for (char c : ok) blocked = blocked && c;
+    }
+    if (blocked) {
+        const int64_t nv = n / 3;
+        struct VPart {
+            std::vector<uint32_t> len, col;
+            int64_t contrib = 0;
+            bool good = true;
+            std::string error;
+        };
+        const int nvt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)host_thread_cap(), nv / 1024 + 1}));
+        std::vector<VPart> vparts(nvt);
+        auto vbuild = [&](int t) {
+            VPart& P = vparts[t];
+            const int64_t v0 = nv * t / nvt, v1 = nv * (t + 1) / nvt;
+            std::vector<uint8_t> mark(nv, 0);
+            std::vector<uint32_t> ucol;
+            std::vector<uint64_t> items, other;
+            for (int64_t v = v0; v < v1 && P.good; ++v) {
+                for (int c = 0; c < 3; ++c) {
+                    std::vector<uint64_t>& its = c == 0 ? items : other;
+                    its.clear();
+                    for (uint64_t p = ro.rowptr[3 * v + c]; p < ro.rowptr[3 * v + c + 1]; ++p) {
+                        const uint64_t b = odim == 9 ? ro.idx[p] / 9 : ro.idx[p] / odim;
+                        bool mine = true;
+                        if (sharded) {
+                            const int64_t bn = tet_inv ? tet_inv[b] : (int64_t)b;
+                            mine = bn >= tet_begin && bn < tet_end;
+                        }
+                        if (mine) P.contrib += (int64_t)(ri.rowptr[(b + 1) * idim] - ri.rowptr[b * idim]);
+                        if (its.empty() || its.back() != b) its.push_back(b);
+                    }
+                    if (c > 0 && other != items) P.good = false;
+                }
+                ucol.clear();
+                for (uint64_t b : items) {
+                    const uint32_t* lc = item_col + ri.rowptr[b * idim];
+                    for (uint32_t q = 0; q < item_nr[b]; q += 3) {
+                        const uint32_t u = lc[q] / 3;
+                        if (!mark[u]) {
+                            mark[u] = 1;
+                            ucol.push_back(u);
+                        }
+                    }
+                }
+                std::sort(ucol.begin(), ucol.end());
+                for (uint32_t u : ucol) mark[u] = 0;
+                if (ucol.empty()) P.error = "empty row " + std::to_string(3 * v);  // sparse_solver.cpp:251-252
+                P.col.insert(P.col.end(), ucol.begin(), ucol.end());
+                P.len.push_back((uint32_t)ucol.size());
+            }
+        };
+        {
+            JoinedThreads jt;
+            for (int t = 1; t < nvt; ++t) jt.run([&, t] { vbuild(t); });
+            vbuild(0);
+        }
+        for (const VPart& P : vparts) {
+            sanm_check(P.error.empty(), "%s", P.error.c_str());
+            blocked = blocked && P.good;
+        }
+        if (blocked) {
+            auto qptr = std::make_shared<std::vector<uint32_t>>(nv + 1, 0);
+            auto qcol = std::make_shared<std::vector<uint32_t>>();
+            {
+                size_t nq = 0;
+                int64_t v = 0;
+                for (const VPart& P : vparts) {
+                    for (uint32_t l : P.len) {
+                        (*qptr)[v + 1] = (*qptr)[v] + l;
+                        ++v;
+                    }
+                    nq += P.col.size();
+                    m_nr_contrib += P.contrib;
+                }
+                sanm_check(nq * 9 < std::numeric_limits<uint32_t>::max(), "Jacobian pattern too large");
+                qcol->resize(nq);
+                size_t at = 0;
+                for (const VPart& P : vparts) {
+                    std::copy(P.col.begin(), P.col.end(), qcol->begin() + at);
+                    at += P.col.size();
+                }
+            }
+            laps.lap("block rows");
+            if (on_blocks) on_blocks(qptr, qcol);
+            // the rows of the unknowns: row 3 v + c = the unknowns of the blocks of block row v
+            rowptr.resize(n + 1);
+            col.resize(qcol->size() * 9);
+            const std::vector<uint32_t>&QP = *qptr, &QC = *qcol;
+            parallel_ranges(nv, 2048, [&](int64_t v0, int64_t v1, int) {
+                for (int64_t v = v0; v < v1; ++v) {
+                    const uint32_t len = QP[v + 1] - QP[v];
+                    for (int c = 0; c < 3; ++c) {
+                        const uint32_t at = 9 * QP[v] + c * 3 * len;
+                        rowptr[3 * v + c] = at;
+                        uint32_t* out = col.data() + at;
+                        for (uint32_t q = 0; q < len; ++q) {
+                            const uint32_t u3 = 3 * QC[QP[v] + q];
+                            out[3 * q] = u3, out[3 * q + 1] = u3 + 1, out[3 * q + 2] = u3 + 2;
+                        }
+                    }
+                }
+            });
+            rowptr[n] = (uint32_t)col.size();
+            laps.lap("rows written out");
+        } else {
+            m_nr_contrib = 0;
+        }
+    }
+    if (!blocked) {
     auto build = [&](int t) {
         Part& P = parts[t];
         const int64_t r0 = n * t / nthread, r1 = n * (t + 1) / nthread;
@@ -277,8 +408,6 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
     }
     for (const Part& P : parts) sanm_check(P.error.empty(), "%s", P.error.c_str());
     laps.lap("rows");
-    std::vector<uint32_t>& rowptr = m_h_rowptr;
-    std::vector<uint32_t>& col = m_h_col;
     rowptr.assign(n + 1, 0);
     {
         size_t ncol = 0;
@@ -300,6 +429,7 @@ JacobianPattern::JacobianPattern(Backend* be, const SparseDesc& ro, const Sparse
         std::copy(parts[0].col.begin(), parts[0].col.end(), col.begin());
     }
     laps.lap("merge");
+    }  // (the rows one by one)
     m_n = n, m_T = T, m_tet_begin = tet_begin, m_tet_end = tet_end, m_odim = odim, m_idim = idim;
     m_tet_order = tet_order, m_tet_inv = tet_inv;
     if (!defer_device) finish_device(ro, ri);

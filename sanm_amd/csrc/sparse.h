@@ -10,6 +10,7 @@
 // per non-zero that a HIP kernel evaluates every step.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <vector>
 
@@ -73,9 +74,15 @@ public:
     //! batch-major [T][odim][idim])
     //! tet_order / tet_inv (optional, both or none): the device's batch item e is the maps' item tet_order[e]; the
     //! shard [tet_begin, tet_end) and the Jacobian blocks are in the device's numbering
+    //! on_blocks (optional): called -- from the constructor, before the rows of the unknowns are written out -- with the
+    //! pattern of the 3 x 3 BLOCKS when the maps have that structure (the three rows of a vertex touch the same batch
+    //! items, every item's columns come in whole triples, no t column): block row v lists the blocks of its columns,
+    //! ascending.  The rows of the pattern are then those lists written out.  Not called otherwise.
+    using BlockRows = std::shared_ptr<const std::vector<uint32_t>>;
     JacobianPattern(Backend* be, const SparseDesc& remap_out, const SparseDesc& remap_in, int64_t n,
                     int64_t T, int64_t Tpad, int odim, int64_t tet_begin = 0, int64_t tet_end = -1, int idim = 9,
-                    const int64_t* tet_order = nullptr, const int64_t* tet_inv = nullptr, bool defer_device = false);
+                    const int64_t* tet_order = nullptr, const int64_t* tet_inv = nullptr, bool defer_device = false,
+                    const std::function<void(BlockRows qptr, BlockRows qcol)>& on_blocks = {});
     ~JacobianPattern();
     //! defer_device: the constructor builds the host pattern only (h_rowptr / h_col are valid -- what the analysis of a
     //! direct solver needs --, nothing else is); finish_device, with the constructor's maps, makes the device side

@@ -382,6 +382,33 @@ def test_setup_loops_on_host_threads_are_deterministic(api, monkeypatch):
         assert np.array_equal(a, b)
 
 
+def test_pattern_and_analysis_from_block_rows(api, monkeypatch):
+    """the Jacobian of a tet mesh has a 3 x 3 block per pair of vertices: the pattern is built from its BLOCK rows and the
+    direct solver's analysis starts from them while the rows of the unknowns are written out (sparse.cpp, on_blocks;
+    multifrontal.h, BlockPattern; round 6).  The routes it replaced -- the analysis from the finished rows
+    (SANM_ANALYSIS_FROM_ROWS), the rows one by one (SANM_PATTERN_NO_BLOCKS), everything on one thread
+    (SANM_SETUP_SERIAL) -- give the same pattern, the same analysis (statistics of the solver) and the same bits of the
+    first step."""
+    cfg = {"material": {"young": 3e4, "poisson": 0.45, "density": 900.0}, "g": [0, -9.81, 0],
+           "boundary_thresh": 0.05, "boundary_proj_dir": [-1, 0, 0], "energy_model": "neohookean_c", "order": 5}
+    dims, sp = (18, 14, 11), 0.01
+    out = []
+    for env in (None, "SANM_ANALYSIS_FROM_ROWS", "SANM_PATTERN_NO_BLOCKS", "SANM_SETUP_SERIAL"):
+        if env:
+            monkeypatch.setenv(env, "1")
+        run = dfea.GravityRun(api, dfea.make_cuboid(*dims, sp), dict(cfg)).construct()
+        J = run.solver.jacobian_csr()
+        st = run.solver.stats()
+        out.append((J.indptr.copy(), J.indices.copy(), J.data.copy(), run.rms[-1], run.solver.get_x().copy(),
+                    np.array([st[k] for k in ("jacobian_nnz", "assembly_contribs", "factor_nnz", "factor_flops", "nr_front", "nr_level", "max_front") if k in st])))
+        if env:
+            monkeypatch.delenv(env)
+    assert out[0][5].size == 7
+    for other in out[1:]:
+        for a, b in zip(out[0], other):
+            assert np.array_equal(a, b)
+
+
 def test_remap_in_coefficients_packed_into_the_index_words(api, monkeypatch):
     """a remap_in table whose coefficients are all +1 / -1 / 0 (the edge vectors of a tet mesh) is kept as index words
     with the coefficient in their two top bits (program.h, RemapInDev: 4 bytes per entry instead of 12 in every Taylor
