@@ -50,6 +50,21 @@ int sanm_rtc_cache_probe(const char* source);
  * (12 + 2 S G + 2 S + 1 + 5 X) through *n_out; writes at most cap of them. */
 int sanm_direct_solver_dist_plan(const sanm_direct_solver* s, int64_t cap, double* out, int64_t* n_out);
 
+/* Point-to-point transfers of the distributed direct solver through a callback (tests: several ranks of the host harness
+ * over gloo run the branch that ncclSend / ncclRecv / ncclBroadcast serve on the library's own communicator).  A transfer
+ * moves doubles [off, off + cnt) of `base` (memory the callback can address: the harness's) from rank src to rank dst,
+ * the same range on both; dst < 0: from src to everyone.  Every rank is handed the same list; the callback returns when
+ * this rank's part is done, 0 = ok.  Solvers created while a callback is set use it for the exchanges between the
+ * stages (the all-reduce of the shard description still sums b_k, f(x0), the Jacobian values and the pivot status);
+ * fn == NULL: unset. */
+typedef struct sanm_test_xfer {
+    int32_t src, dst;
+    int64_t off, cnt;
+    int32_t src_stage;
+} sanm_test_xfer;
+typedef int (*sanm_test_p2p_fn)(void* user, double* base, const sanm_test_xfer* xfers, int n);
+int sanm_test_set_p2p(sanm_test_p2p_fn fn, void* user);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,7 +86,7 @@ SYMBOLS = [
     "sanm_hyper_param_default", "sanm_anm_eqn_solver_create", "sanm_anm_eqn_solver_create_sharded",
     "sanm_anm_vecscale_solver_create",
     "sanm_anm_implicit_solver_create", "sanm_anm_solver_destroy", "sanm_anm_next_iter",
-    "sanm_anm_update_approx", "sanm_anm_restart", "sanm_anm_run_steps", "sanm_anm_spec_source", "sanm_rtc_compile_check", "sanm_rtc_cache_stats", "sanm_rtc_cache_probe", "sanm_direct_solver_dist_plan", "sanm_anm_time_kernel", "sanm_anm_pass_timing", "sanm_anm_converged", "sanm_anm_residual_rms", "sanm_anm_get_x",
+    "sanm_anm_update_approx", "sanm_anm_restart", "sanm_anm_run_steps", "sanm_anm_spec_source", "sanm_rtc_compile_check", "sanm_rtc_cache_stats", "sanm_rtc_cache_probe", "sanm_direct_solver_dist_plan", "sanm_test_set_p2p", "sanm_anm_time_kernel", "sanm_anm_pass_timing", "sanm_anm_converged", "sanm_anm_residual_rms", "sanm_anm_get_x",
     "sanm_anm_get_t_upper", "sanm_anm_get_t_max_a", "sanm_anm_solve_a", "sanm_anm_eval",
     "sanm_anm_nr_iter", "sanm_anm_nr_xt_coeffs", "sanm_anm_xt_coeff", "sanm_anm_has_pade",
     "sanm_anm_get_stats", "sanm_anm_get_stats_sized", "sanm_anm_setup_profile", "sanm_rtc_cache_drop_memory", "sanm_fea_spec_source", "sanm_rtc_source_key", "sanm_rtc_compile_to_file", "sanm_rtc_embedded_hits", "sanm_anm_profile", "sanm_anm_profile_counts", "sanm_anm_profile_launches", "sanm_anm_set_profile", "sanm_anm_debug_inject", "sanm_anm_trace", "sanm_anm_pade_diag", "sanm_anm_verbose_text", "sanm_anm_jacobian_csr",

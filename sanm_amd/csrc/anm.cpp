@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <exception>
 #include <functional>
+#include <cstddef>
 #include <future>
 #include <cstdlib>
 #include <cstring>
@@ -1118,7 +1119,17 @@ void AnmDriver::construct_solver_and_vectors(const double* coords, std::unique_p
             // all-reduce form of the exchanges there too); the callback of the C ABI offers the all-reduce only
             PointToPoint p2p;
             const char* env_p2p = std::getenv("SANM_DIST_P2P");
-            if (!m_shard.allreduce && be->comm_p2p_available() && !(env_p2p && std::atoi(env_p2p) == 0))
+            if (test_p2p().fn) {  // (tests: the point-to-point branch over a callback, sanm_hip_test.h)
+                static_assert(sizeof(MfSchedule::Xfer) == 32 && offsetof(MfSchedule::Xfer, off) == 8 &&
+                                      offsetof(MfSchedule::Xfer, cnt) == 16 && offsetof(MfSchedule::Xfer, src_stage) == 24,
+                              "sanm_test_xfer mirrors MfSchedule::Xfer");
+                const TestP2p hook = test_p2p();
+                p2p = [be, hook](double* base, const MfSchedule::Xfer* x, int n) {
+                    be->sync();
+                    const int rc = hook.fn(hook.user, base, x, n);
+                    sanm_check(rc == 0, "point-to-point callback failed (%d)", rc);
+                };
+            } else if (!m_shard.allreduce && be->comm_p2p_available() && !(env_p2p && std::atoi(env_p2p) == 0))
                 p2p = [this](double* base, const MfSchedule::Xfer* x, int n) { exchange_p2p(base, x, n); };
             m_solver = make_direct_solver(be, *m_pattern, hp, coords, m_shard.rank, m_shard.world,
                                           [this](double* p, int64_t c) { allreduce(p, c); }, std::move(p2p),
@@ -1226,6 +1237,11 @@ void AnmDriver::allreduce(double* buf, int64_t count) {
     m_be->sync();  // the callback's collective runs outside this backend's stream
     int rc = m_shard.allreduce(m_shard.user, buf, count);
     if (rc != 0) sanm_throw(SANM_ERR_HIP, "all-reduce callback failed with code %d", rc);
+}
+
+TestP2p& test_p2p() {
+    static TestP2p hook;
+    return hook;
 }
 
 void AnmDriver::exchange_p2p(double* base, const MfSchedule::Xfer* x, int n) {

@@ -129,6 +129,12 @@ using Collective = std::function<void(double*, int64_t)>;
 //! grouped point-to-point transfers / broadcasts of ranges of one device buffer (MfSchedule::Xfer; Backend::
 //! comm_exchange on the backend's own communicator); empty: the communicator at hand offers the all-reduce only
 using PointToPoint = std::function<void(double*, const MfSchedule::Xfer*, int)>;
+//! a process-wide point-to-point callback that solvers under construction pick up (sanm_hip_test.h, sanm_test_set_p2p)
+struct TestP2p {
+    int (*fn)(void* user, double* base, const void* xfers, int n) = nullptr;
+    void* user = nullptr;
+};
+TestP2p& test_p2p();
 std::unique_ptr<LinearSolver> make_pcg_solver(Backend* be, const JacobianPattern& pat,
                                               const HyperParam& hp);
 //! multifrontal LU (multifrontal.h); coords: (n,3) ordering hint or null

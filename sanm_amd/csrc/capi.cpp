@@ -241,6 +241,12 @@ int sanm_direct_solver_create(int64_t n, const uint32_t* rowptr, const uint32_t*
         *out = s.release();
     });
 }
+int sanm_test_set_p2p(sanm_test_p2p_fn fn, void* user) {
+    return guard([&] {
+        test_p2p().fn = reinterpret_cast<int (*)(void*, double*, const void*, int)>(fn);
+        test_p2p().user = user;
+    });
+}
 int sanm_direct_solver_dist_plan(const sanm_direct_solver* s, int64_t cap, double* out, int64_t* n_out) {
     return guard([&] {
         const auto& D = s->mf->schedule().dist;

@@ -107,3 +107,83 @@ def make_staged_allreduce():
         torch.cuda.current_stream().synchronize()
 
     return allreduce
+
+
+class TestXfer(ctypes.Structure):
+    """sanm_test_xfer (include/sanm_hip_test.h)"""
+    _fields_ = [("src", ctypes.c_int32), ("dst", ctypes.c_int32), ("off", ctypes.c_int64), ("cnt", ctypes.c_int64),
+                ("src_stage", ctypes.c_int32)]
+
+
+_P2P_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(TestXfer), ctypes.c_int)
+
+
+def set_staged_p2p(api, log=None):
+    """set_host_p2p for DEVICE memory: every transfer through a host copy and a gloo group -- several ranks on ONE GPU run
+    the point-to-point branch of the distributed solver on the HIP backend (RCCL refuses two ranks on one device)."""
+    return set_host_p2p(api, log, staged=True)
+
+
+def set_host_p2p(api, log=None, staged=False):
+    """the distributed direct solver's point-to-point branch over torch.distributed on HOST memory (gloo; the host harness):
+    sanm_test_set_p2p with a callback that posts every transfer of the list this rank takes part in (isend / irecv,
+    broadcasts from their source) and waits for them.  `log`, a list, receives (sends, receives, broadcasts, doubles)
+    per call.  Returns the callback object: keep it alive while solvers use it."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank()
+
+    def view(base, off, cnt):
+        addr = ctypes.addressof(base.contents) + 8 * int(off)
+        if staged:
+            return torch.as_tensor(_DevicePtr(addr, cnt), device="cuda")
+        return torch.from_numpy(np.frombuffer((ctypes.c_double * int(cnt)).from_address(addr), dtype=np.float64))
+
+    def p2p(_user, base, xfers, n):
+        try:
+            reqs, stat, back = [], [0, 0, 0, 0], []
+            for i in range(n):
+                x = xfers[i]
+                if x.cnt == 0:
+                    continue
+                takes_part = x.dst < 0 or (x.src != x.dst and rank in (x.src, x.dst))
+                if not takes_part:
+                    continue
+                dev = view(base, x.off, x.cnt)
+                buf = dev.cpu() if staged else dev  # (staged: the host copy travels, receivers copy it back below)
+                if x.dst < 0:
+                    reqs.append(dist.broadcast(buf, src=x.src, async_op=True))
+                    stat[2] += 1
+                    receives = rank != x.src
+                elif rank == x.src:
+                    reqs.append(dist.isend(buf, dst=x.dst, tag=i))
+                    stat[0] += 1
+                    receives = False
+                else:
+                    reqs.append(dist.irecv(buf, src=x.src, tag=i))
+                    stat[1] += 1
+                    receives = True
+                if staged and receives:
+                    back.append((dev, buf))
+                stat[3] += int(x.cnt)
+            for r in reqs:
+                r.wait()
+            for dev, buf in back:
+                dev.copy_(buf)
+            if staged:
+                torch.cuda.current_stream().synchronize()
+            if log is not None:
+                log.append(tuple(stat))
+            return 0
+        except Exception:  # (never an exception through the C frames)
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    cb = _P2P_FN(p2p)
+    api.lib.sanm_test_set_p2p.restype = ctypes.c_int
+    api.lib.sanm_test_set_p2p.argtypes = [_P2P_FN, ctypes.c_void_p]
+    api.check(api.lib.sanm_test_set_p2p(cb, None))
+    return cb
+

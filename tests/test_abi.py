@@ -26,7 +26,7 @@ def test_the_interface_header_declares_no_test_hook():
                                                             "sanm_rtc_cache_stats", "sanm_rtc_cache_probe",
                                                             "sanm_rtc_cache_drop_memory", "sanm_direct_solver_dist_plan",
                                                             "sanm_fea_spec_source", "sanm_rtc_source_key",
-                                                            "sanm_rtc_compile_to_file", "sanm_rtc_embedded_hits"}
+                                                            "sanm_rtc_compile_to_file", "sanm_rtc_embedded_hits", "sanm_test_set_p2p"}
 
 
 def test_header_symbols_are_exported():

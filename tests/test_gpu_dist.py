@@ -159,12 +159,15 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 api = sanm_amd.get_api(0)
 assert api.backend_name() == "hip"
 cfg, mesh = dfea.load_named_config({name!r})
+p2p_log = []
+p2p_cb = sdist.set_staged_p2p(api, p2p_log) if os.environ.get("TEST_P2P") else None
 run = dfea.GravityRun(api, mesh, dict(cfg), shard=(rank, world, sdist.make_staged_allreduce())).run()
 gold = np.load(os.path.join({root!r}, "tests", "golden", "full_" + {name!r} + ".npz"))
 V, Vo = run.vertices(), gold["vertices"]
 print("RESULT " + json.dumps(dict(rank=rank, steps=int(run.solver.get_nr_iter()), gold_steps=int(gold["steps"]),
                                   err=float(np.abs(V - Vo).max() / np.abs(Vo).max()), rms=float(run.rms[-1]),
-                                  vsum=float(V.sum()), st=run.solver.stats())), flush=True)
+                                  vsum=float(V.sum()), st=run.solver.stats(),
+                                  p2p=[len(p2p_log)] + [int(sum(c[i] for c in p2p_log)) for i in range(4)])), flush=True)
 dist.barrier()
 dist.destroy_process_group()
 """
@@ -241,6 +244,21 @@ def test_tree_distributed_solver_three_stages_four_ranks_on_one_gpu():
     assert res[0]["st"]["nr_dist_stage"] >= 2
     assert sum(t > 0 for t in top_own) >= 2  # separators beside each other on different owners
     assert crit <= 0.75 * total
+
+
+def test_tree_distributed_solver_over_point_to_point_transfers_four_ranks_on_one_gpu():
+    """the three-stage case again with the exchanges as POINT-TO-POINT transfers (the branch a multi-GPU node takes with
+    `ncclSend` / `ncclRecv` / `ncclBroadcast`): the test hook `sanm_test_set_p2p`, every transfer staged through the host and
+    a gloo group because the four ranks share cuda:0 (sanm_amd/dist.py, set_staged_p2p).  Pack (copy2d_kernel), transfer,
+    unpack on the HIP backend; Schur complements and inbox rows to the one rank that needs them, every stage's pivots to
+    everyone.  Equilibrium, step count and bits as with the all-reduce form."""
+    res = _two_ranks_on_one_gpu("armadillo_small", {"SANM_DIST_SOLVER": "1", "TEST_P2P": "1"}, world=4)
+    _check_tree_distribution(res)
+    assert res[0]["st"]["nr_dist_stage"] >= 2
+    for r in res:
+        ncalls, sends, recvs, bcasts, doubles = r["p2p"]
+        assert ncalls > 0 and bcasts > 0 and doubles > 0
+    assert sum(r["p2p"][1] for r in res) == sum(r["p2p"][2] for r in res) > 0
 
 
 def test_subtree_distributed_solver_over_chains_and_two_phase_levels_on_the_device():

@@ -8,6 +8,8 @@ import socket
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 WORKER = r"""
@@ -251,13 +253,18 @@ def counted(ptr, count):
     ncall[0] += 1
     base(ptr, count)
 dims = {dims!r}
+p2p_log = []
+p2p_cb = sdist.set_host_p2p(api, p2p_log) if os.environ.get("TEST_P2P") else None
 run = dfea.GravityRun(api, dfea.make_cuboid(*dims, 0.025), dict(cfg), shard=(rank, world, counted), solver_rtol=1e-15).run()
 st = run.solver.stats()
+if p2p_cb is not None:
+    api.lib.sanm_test_set_p2p(type(p2p_cb)(), None)  # (the unsharded reference below: no callback)
 ref = dfea.GravityRun(api, dfea.make_cuboid(*dims, 0.025), dict(cfg), solver_rtol=1e-15).run()
 V, Vr = run.vertices(), ref.vertices()
 out = dict(rank=rank, steps=int(run.solver.get_nr_iter()), ref_steps=int(ref.solver.get_nr_iter()),
            err=float(np.abs(V - Vr).max() / np.abs(Vr).max()), ncall=ncall[0], rms=run.rms[-1], st=st,
-           ref_st=ref.solver.stats(), vsum=float(V.sum()))
+           ref_st=ref.solver.stats(), vsum=float(V.sum()),
+           p2p=[len(p2p_log)] + [int(sum(c[i] for c in p2p_log)) for i in range(4)])
 print("RESULT " + json.dumps(out), flush=True)
 dist.barrier()
 dist.destroy_process_group()
@@ -354,6 +361,31 @@ def test_subtree_distributed_factor_and_solve_four_ranks_with_pade():
     assert all(r["st"]["nr_subtree_own"] >= 1 for r in res) and res[0]["st"]["nr_dist_stage"] >= 3
     print("4 ranks: own GF", [o / 1e9 for o in own], "top own", [t / 1e9 for t in top_own], "total", total / 1e9,
           "critical", res[0]["st"]["factor_flops_critical"] / 1e9)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_subtree_distributed_solver_over_point_to_point_transfers(world):
+    """the exchanges between the stages as POINT-TO-POINT transfers -- what `ncclSend` / `ncclRecv` / `ncclBroadcast` do on
+    the library's own communicator, the branch `bench.py --gpus N` takes on a multi-GPU node -- through the test hook
+    `sanm_test_set_p2p` over gloo (sanm_amd/dist.py, set_host_p2p): the Schur complements and inbox rows go from the rank
+    that produced them to the one rank that needs them, the solution of every stage from its owner to everyone, and
+    nothing of them through the all-reduce any more (its calls are the driver's and the pivot status only).  Same checks
+    as the all-reduce form: the unsharded solve's steps and vertices, every rank bit for bit the same."""
+    res = _run_dist(world, (12, 6, 6), env_extra={"TEST_P2P": "1"})
+    S = res[0]["st"]["nr_dist_stage"]
+    assert S >= 2
+    for r in res:
+        st = r["st"]
+        assert r["steps"] == r["ref_steps"] and r["err"] < 1e-9 and r["rms"] < 1e-10 and r["vsum"] == res[0]["vsum"]
+        steps, order, solves = r["steps"], 10, st["nr_linear_solve"]
+        # the all-reduce: f(x0), Jacobian values, b_k per order (+ f(x0) of the converged call) and the pivot status
+        assert r["ncall"] == steps * (1 + 1 + (order - 1)) + 1 + steps
+        # the callback: per factorisation the Schur transfers before every top stage, per solve the inbox rows before
+        # every top stage and the broadcast of every stage's pivots
+        ncalls, sends, recvs, bcasts, doubles = r["p2p"]
+        assert ncalls >= (S - 1) * steps + (S - 1) * solves and bcasts >= S * solves and doubles > 0
+    # every send has its receive
+    assert sum(r["p2p"][1] for r in res) == sum(r["p2p"][2] for r in res) > 0
 
 
 def test_tree_mapping_gives_every_rank_a_subtree_at_world_8(monkeypatch):
