@@ -1621,6 +1621,24 @@ public:
         hipFuncAttributes attr;
         (void)hipFuncGetAttributes(&attr, (const void*)mfk::scatter_kernel);
         ensure_stage();
+        // ... and the runtime's own first-use set-up of the copy and fill paths (an API trace of a cold solve of
+        // armadillo_small, gpurun_out/r6hip1: the first hipMemcpyAsync 8 ms, the first hipMemset 6 ms -- its fill kernel's
+        // code object --, against 0.15 and 0.01 ms for every later one)
+        {
+            double tmp[8] = {};
+            HIP_CHECK(hipMemsetAsync(m_scalar, 0, 64, m_main));
+            HIP_CHECK(hipMemset(m_scalar, 0, 64));
+            h2d(m_scalar, tmp, sizeof(tmp));
+            d2h(tmp, m_scalar, sizeof(tmp));
+            // (a copy of every kind the solver makes: a MB from pinned memory, device to device, device to pinned memory)
+            void* dev = nullptr;
+            HIP_CHECK(hipMalloc(&dev, size_t(2) << 20));
+            HIP_CHECK(hipMemcpyAsync(dev, m_stage[0], size_t(1) << 20, hipMemcpyHostToDevice, m_main));
+            HIP_CHECK(hipMemcpyAsync(static_cast<char*>(dev) + (size_t(1) << 20), dev, size_t(1) << 20, hipMemcpyDeviceToDevice, m_main));
+            HIP_CHECK(hipMemcpyAsync(m_scalar_host, m_scalar, 64, hipMemcpyDeviceToHost, m_main));
+            HIP_CHECK(hipStreamSynchronize(m_main));
+            HIP_CHECK(hipFree(dev));
+        }
     }
     void forget_chains(const void* key) override {
         m_cur_sch = nullptr;
