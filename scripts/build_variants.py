@@ -1,5 +1,6 @@
 """A/B builds of libsanm_hip.so that differ in the flags of backend_hip.hip only (the kernels): sanm_amd/libsanm_hip_<name>.so,
-selected at run time with SANM_HIP_LIBRARY.   python scripts/build_variants.py name="flags" [name="flags" ...]
+selected at run time with SANM_HIP_LIBRARY -- and a copy sanm_amd/variant_<name>.so, which travels to the GPU box
+(.gpurunignore keeps libsanm_hip_*.so at home; both are git-ignored).   python scripts/build_variants.py name="flags" [name="flags" ...]
 e.g. python scripts/build_variants.py novf="-mllvm -amdgpu-mfma-vgpr-form=0" old="-DSANM_MF_OLD_STAGING" """
 import os
 import subprocess
@@ -24,4 +25,6 @@ for arg in sys.argv[1:]:
     objs = [os.path.join(objdir, s + ".o") for s in B.SOURCES if s != "backend_hip.hip"] + [obj]
     out = os.path.join(B.HERE, f"libsanm_hip_{name}.so")
     subprocess.run([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-Wl,-Bsymbolic", "-o", out] + objs + ["-ldl"], check=True)
+    import shutil
+    shutil.copy(out, os.path.join(B.HERE, f"variant_{name}.so"))
     print(out)
