@@ -34,6 +34,58 @@ struct SvGraph {
 //! the supervariables of one pattern by hashing the closed neighbourhoods of A + A' (no coordinates)
 SvGraph sv_graph_by_hash(int64_t n, const std::vector<uint32_t>& rowptr, const std::vector<uint32_t>& col) {
     SetupLaps laps("svgraph");
+    std::vector<int32_t> uptr(n + 1, 0);
+    std::vector<uint64_t> hash(n);
+    std::unique_ptr<int32_t[]> unb_raw;
+    int32_t* nb = nullptr;
+    // A pattern that is symmetric with ascending rows -- the block rows of a mesh Jacobian -- IS its symmetrised adjacency:
+    // the closed neighbourhoods are the rows (with the diagonal put in where it is missing), no transposed entries to
+    // collect and nothing to sort (round 6: a third of this function's time).  Checked, not assumed.
+    bool plain = true;
+    {
+        std::vector<char> ok(64, 1);
+        parallel_ranges(n, 2048, [&](int64_t r0, int64_t r1, int t) {
+            bool good = true;
+            for (int64_t i = r0; good && i < r1; ++i)
+                for (uint32_t p = rowptr[i]; good && p < rowptr[i + 1]; ++p) {
+                    const int64_t j = col[p];
+                    good = j < n && (p == rowptr[i] || col[p - 1] < col[p]);
+                    if (good && j != i) good = std::binary_search(col.begin() + rowptr[j], col.begin() + rowptr[j + 1], (uint32_t)i);
+                }
+            if (!good) ok[t % 64] = 0;
+        });
+        for (char c : ok) plain = plain && c;
+    }
+    if (plain) {
+        std::vector<int32_t> ulen(n);
+        parallel_ranges(n, 2048, [&](int64_t r0, int64_t r1, int) {
+            for (int64_t i = r0; i < r1; ++i)
+                ulen[i] = (int32_t)(rowptr[i + 1] - rowptr[i]) +
+                          (std::binary_search(col.begin() + rowptr[i], col.begin() + rowptr[i + 1], (uint32_t)i) ? 0 : 1);
+        });
+        for (int64_t i = 0; i < n; ++i) uptr[i + 1] = uptr[i] + ulen[i];
+        unb_raw = raw_array<int32_t>(uptr[n]);
+        nb = unb_raw.get();
+        parallel_ranges(n, 2048, [&](int64_t r0, int64_t r1, int) {
+            for (int64_t i = r0; i < r1; ++i) {
+                int32_t* out = nb + uptr[i];
+                bool self = false;
+                for (uint32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+                    const int32_t j = (int32_t)col[p];
+                    if (!self && j >= i) {
+                        if (j > i) *out++ = (int32_t)i;
+                        self = true;
+                    }
+                    *out++ = j;
+                }
+                if (!self) *out++ = (int32_t)i;
+                uint64_t h = 1469598103934665603ull;
+                for (int32_t q = uptr[i]; q < uptr[i + 1]; ++q) h = (h ^ (uint64_t)nb[q]) * 1099511628211ull;
+                hash[i] = h;
+            }
+        });
+        laps.lap("rows as neighbourhoods");
+    } else {
     // symmetrised adjacency including the diagonal.  Every thread scans ALL rows and keeps what lands in its own range
     // of unknowns (the entries of its rows and the transposed entries pointing into them): no shared counters, and
     // each list receives its entries in the order one thread would append them.
@@ -59,7 +111,7 @@ SvGraph sv_graph_by_hash(int64_t n, const std::vector<uint32_t>& rowptr, const s
     for (const auto& e : errs) sanm_check(e.empty(), "%s", e.c_str());
     for (int64_t i = 0; i < n; ++i) deg[i + 1] += deg[i] + 1;  // +1: self
     auto nb_raw = raw_array<int32_t>(deg[n]);
-    int32_t* nb = nb_raw.get();
+    nb = nb_raw.get();
     {
         std::vector<int32_t> fill(deg.begin(), deg.end() - 1);
         parallel_ranges(n, 2048, [&](int64_t r0, int64_t r1, int) {
@@ -77,9 +129,6 @@ SvGraph sv_graph_by_hash(int64_t n, const std::vector<uint32_t>& rowptr, const s
     }
     laps.lap("symmetrise");
     // sort + unique every list, hash it (rows in parallel, in place), then pack the lists
-    std::vector<int32_t> uptr(n + 1, 0);
-    std::vector<uint64_t> hash(n);
-    std::unique_ptr<int32_t[]> unb_raw;
     {
         std::vector<int32_t> ulen(n);
         parallel_ranges(n, 2048, [&](int64_t r0, int64_t r1, int) {
@@ -103,6 +152,7 @@ SvGraph sv_graph_by_hash(int64_t n, const std::vector<uint32_t>& rowptr, const s
         nb = dst;
     }
     laps.lap("sort lists, pack");
+    }  // (the pattern as it comes)
     // group indistinguishable unknowns (same closed neighbourhood)
     std::vector<int32_t> order(n);
     std::iota(order.begin(), order.end(), 0);
