@@ -261,6 +261,88 @@ def test_tree_distributed_solver_over_point_to_point_transfers_four_ranks_on_one
     assert sum(r["p2p"][1] for r in res) == sum(r["p2p"][2] for r in res) > 0
 
 
+WORKER_AT_SCALE = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+import torch
+import torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+import bench
+import sanm_amd
+from sanm_amd import fea as dfea, dist as sdist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+api = sanm_amd.get_api(0)
+cfg, mesh = bench.load_workload({name!r})
+p2p_log = []
+p2p_cb = sdist.set_staged_p2p(api, p2p_log) if os.environ.get("TEST_P2P") else None
+run = dfea.GravityRun(api, mesh, dict(cfg), shard=(rank, world, sdist.make_staged_allreduce())).run(max_iter=60)
+st = run.solver.stats()
+V = run.vertices()
+out = dict(rank=rank, steps=int(run.solver.get_nr_iter()), rms=float(run.rms[-1]), vsum=float(V.sum()), st=st,
+           p2p=[len(p2p_log)] + [int(sum(c[i] for c in p2p_log)) for i in range(4)])
+if rank == 0:
+    if p2p_cb is not None:
+        api.lib.sanm_test_set_p2p(type(p2p_cb)(), None)
+    del run
+    cfg1, mesh1 = bench.load_workload({name!r})
+    ref = dfea.GravityRun(api, mesh1, dict(cfg1)).run(max_iter=60)
+    Vr = ref.vertices()
+    out.update(ref_steps=int(ref.solver.get_nr_iter()), err=float(np.abs(V - Vr).max() / np.abs(Vr).max()),
+               ref_flops=ref.solver.stats()["factor_flops"])
+print("RESULT " + json.dumps(out), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_tree_distributed_solver_at_scale_two_ranks_on_one_gpu():
+    """the distributed direct solver where it is ON BY DEFAULT (from 50 GFLOP per factorisation): the 338 k-tet leg of the
+    bench, tet-sharded over two ranks that share cuda:0, the exchanges point to point (test hook, staged through the
+    host) -- levels of thousands of small fronts split between the ranks, stages, Schur transfers of tens of MB.  Both
+    ranks end on the same bits; rank 0 then solves the problem unsharded: same steps, vertices to 1e-9 (the tet-sharded
+    sums of b_k differ in their order), the two ranks' own flops plus the top's add up to the unsharded count."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    name, world = "refine:armadillo_small:1", 2
+    base_env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    base_env["TEST_P2P"] = "1"
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for rank in range(world):
+        env = dict(base_env, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER_AT_SCALE.format(root=root, name=name)],
+                                      env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = []
+    try:
+        for p in procs:
+            so, se = p.communicate(timeout=1200)
+            assert p.returncode == 0, se[-3000:]
+            res.append(json.loads([l for l in so.splitlines() if l.startswith("RESULT ")][0][7:]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    res.sort(key=lambda r: r["rank"])
+    r0, r1 = res
+    assert r0["vsum"] == r1["vsum"] and r0["steps"] == r1["steps"] == r0["ref_steps"]
+    assert r0["rms"] < 1e-10 and r0["err"] < 1e-9, r0["err"]
+    assert r0["st"]["nr_subtree"] >= 2 and all(r["st"]["nr_subtree_own"] >= 1 for r in res)
+    own = [r["st"]["factor_flops_own"] for r in res]
+    top = r0["st"]["factor_flops_top"]
+    assert abs(sum(own) + top - r0["ref_flops"]) <= 1e-9 * r0["ref_flops"] and max(own) < 0.7 * r0["ref_flops"]
+    assert sum(r["p2p"][1] for r in res) == sum(r["p2p"][2] for r in res)
+    print("at scale, 2 ranks: steps", r0["steps"], "err", r0["err"], "own GF", [o / 1e9 for o in own], "top GF", top / 1e9,
+          "stages", r0["st"]["nr_dist_stage"], "p2p calls / sends / receives / broadcasts / doubles", r0["p2p"], r1["p2p"])
+
+
 def test_subtree_distributed_solver_over_chains_and_two_phase_levels_on_the_device():
     """the same with the round-4 schedule features forced onto this mesh: fronts cut into chains (SANM_MF_SPLIT_K),
     every height two-phase (SANM_MF_TWO_PHASE: boundary operators not multiplied out, two launches per sweep) and the
