@@ -277,17 +277,18 @@ api = sanm_amd.get_api(0)
 cfg, mesh = bench.load_workload({name!r})
 p2p_log = []
 p2p_cb = sdist.set_staged_p2p(api, p2p_log) if os.environ.get("TEST_P2P") else None
-run = dfea.GravityRun(api, mesh, dict(cfg), shard=(rank, world, sdist.make_staged_allreduce())).run(max_iter=60)
+run = dfea.GravityRun(api, mesh, dict(cfg), shard=(rank, world, sdist.make_staged_allreduce())).run(max_iter={max_iter})
 st = run.solver.stats()
 V = run.vertices()
 out = dict(rank=rank, steps=int(run.solver.get_nr_iter()), rms=float(run.rms[-1]), vsum=float(V.sum()), st=st,
+           converged=bool(run.solver.converged()),
            p2p=[len(p2p_log)] + [int(sum(c[i] for c in p2p_log)) for i in range(4)])
 if rank == 0:
     if p2p_cb is not None:
         api.lib.sanm_test_set_p2p(type(p2p_cb)(), None)
     del run
     cfg1, mesh1 = bench.load_workload({name!r})
-    ref = dfea.GravityRun(api, mesh1, dict(cfg1)).run(max_iter=60)
+    ref = dfea.GravityRun(api, mesh1, dict(cfg1)).run(max_iter={max_iter})
     Vr = ref.vertices()
     out.update(ref_steps=int(ref.solver.get_nr_iter()), err=float(np.abs(V - Vr).max() / np.abs(Vr).max()),
                ref_flops=ref.solver.stats()["factor_flops"])
@@ -297,17 +298,19 @@ dist.destroy_process_group()
 """
 
 
-def test_tree_distributed_solver_at_scale_two_ranks_on_one_gpu():
-    """the distributed direct solver where it is ON BY DEFAULT (from 50 GFLOP per factorisation): the 338 k-tet leg of the
-    bench, tet-sharded over two ranks that share cuda:0, the exchanges point to point (test hook, staged through the
-    host) -- levels of thousands of small fronts split between the ranks, stages, Schur transfers of tens of MB.  Both
-    ranks end on the same bits; rank 0 then solves the problem unsharded: same steps, vertices to 1e-9 (the tet-sharded
-    sums of b_k differ in their order), the two ranks' own flops plus the top's add up to the unsharded count."""
+@pytest.mark.parametrize("name,world,max_iter", [("refine:armadillo_small:1", 2, 60), ("refine:armadillo_small:1", 4, 60), ("refine:armadillo_small:2", 2, 2)])
+def test_tree_distributed_solver_at_scale_ranks_on_one_gpu(name, world, max_iter):
+    """the distributed direct solver where it is ON BY DEFAULT (from 50 GFLOP per factorisation), tet-sharded over ranks that
+    share cuda:0, the exchanges point to point (test hook, staged through the host): the 338 k-tet leg of the bench over two
+    and over four ranks to convergence (the top of the tree mapped onto rank sets, three stages), and two continuation steps
+    of the 2.7 M-tet leg over two (6.6 TFLOP per factorisation, Schur transfers of hundreds of MB; every rank holds a whole
+    front store, and four of those do not fit one device).  All ranks
+    end on the same bits; rank 0 then runs the problem unsharded: same steps, vertices to 1e-9 (the tet-sharded sums of
+    b_k differ in their order), the ranks' own flops plus the top's add up to the unsharded count."""
     import json
     import subprocess
     import sys
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-    name, world = "refine:armadillo_small:1", 2
     base_env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     base_env["TEST_P2P"] = "1"
     s = socket.socket()
@@ -318,29 +321,37 @@ def test_tree_distributed_solver_at_scale_two_ranks_on_one_gpu():
     for rank in range(world):
         env = dict(base_env, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, "-c", WORKER_AT_SCALE.format(root=root, name=name)],
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER_AT_SCALE.format(root=root, name=name, max_iter=max_iter)],
                                       env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     res = []
     try:
-        for p in procs:
-            so, se = p.communicate(timeout=1200)
-            assert p.returncode == 0, se[-3000:]
+        outs = [p.communicate(timeout=1500) for p in procs]
+        bad = [(i, p.returncode) for i, p in enumerate(procs) if p.returncode != 0]
+        if bad:  # (every rank's own story: the first one to fail takes the others' collectives down with it)
+            os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+            for i, (_, se) in enumerate(outs):
+                open(os.path.join(root, "gpurun_out", f"dist_at_scale_rank{i}.err"), "w").write(se)
+        assert not bad, (bad, [o[1][-600:] for o in outs])
+        for so, _ in outs:
             res.append(json.loads([l for l in so.splitlines() if l.startswith("RESULT ")][0][7:]))
     finally:
         for p in procs:
             if p.poll() is None:
                 p.kill()
     res.sort(key=lambda r: r["rank"])
-    r0, r1 = res
-    assert r0["vsum"] == r1["vsum"] and r0["steps"] == r1["steps"] == r0["ref_steps"]
-    assert r0["rms"] < 1e-10 and r0["err"] < 1e-9, r0["err"]
-    assert r0["st"]["nr_subtree"] >= 2 and all(r["st"]["nr_subtree_own"] >= 1 for r in res)
+    r0 = res[0]
+    assert len({r["vsum"] for r in res}) == 1 and len({r["steps"] for r in res}) == 1 and r0["steps"] == r0["ref_steps"]
+    assert r0["err"] < 1e-9, r0["err"]
+    if max_iter >= 60:
+        assert r0["converged"] and r0["rms"] < 1e-10
+    assert r0["st"]["nr_subtree"] >= world and all(r["st"]["nr_subtree_own"] >= 1 for r in res)
     own = [r["st"]["factor_flops_own"] for r in res]
     top = r0["st"]["factor_flops_top"]
-    assert abs(sum(own) + top - r0["ref_flops"]) <= 1e-9 * r0["ref_flops"] and max(own) < 0.7 * r0["ref_flops"]
-    assert sum(r["p2p"][1] for r in res) == sum(r["p2p"][2] for r in res)
-    print("at scale, 2 ranks: steps", r0["steps"], "err", r0["err"], "own GF", [o / 1e9 for o in own], "top GF", top / 1e9,
-          "stages", r0["st"]["nr_dist_stage"], "p2p calls / sends / receives / broadcasts / doubles", r0["p2p"], r1["p2p"])
+    assert abs(sum(own) + top - r0["ref_flops"]) <= 1e-9 * r0["ref_flops"] and max(own) < 1.4 * r0["ref_flops"] / world
+    assert sum(r["p2p"][1] for r in res) == sum(r["p2p"][2] for r in res) > 0
+    print(name, world, "ranks: steps", r0["steps"], "err", r0["err"], "own GF", [round(o / 1e9, 1) for o in own], "top GF", round(top / 1e9, 1),
+          "critical GF", round(r0["st"]["factor_flops_critical"] / 1e9, 1), "stages", r0["st"]["nr_dist_stage"],
+          "p2p calls / sends / receives / broadcasts / doubles", [r["p2p"] for r in res])
 
 
 def test_subtree_distributed_solver_over_chains_and_two_phase_levels_on_the_device():
