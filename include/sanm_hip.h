@@ -277,6 +277,10 @@ typedef struct sanm_anm_stats {
      * i.e. the factorisation's critical path (factor_flops / factor_flops_critical = its speed-up if flops-bound) */
     double factor_flops_top_own, factor_flops_critical;
     int64_t nr_dist_stage;
+    /* doubles of this rank's front store: every front when the solver is replicated; with the distribution the fronts
+     * the rank factors and the Schur blocks it receives (a shorter caller struct simply does not get it:
+     * sanm_anm_get_stats_sized) */
+    int64_t front_store_doubles;
 } sanm_anm_stats;
 int sanm_anm_get_stats(const sanm_anm_solver* s, sanm_anm_stats* st);
 /* the same for a caller whose sanm_anm_stats may be older (shorter) than the library's: at most st_bytes are written */

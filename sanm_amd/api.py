@@ -63,7 +63,7 @@ class StatsC(C.Structure):
                 ("nr_subtree", C.c_int64), ("nr_subtree_own", C.c_int64),
                 ("dist_schur_doubles", C.c_int64), ("dist_inbox_doubles", C.c_int64),
                 ("factor_flops_top_own", C.c_double), ("factor_flops_critical", C.c_double),
-                ("nr_dist_stage", C.c_int64)]
+                ("nr_dist_stage", C.c_int64), ("front_store_doubles", C.c_int64)]
 
 
 ENERGY = {"neohookean_i": 0, "neohookean_c": 1, "arap": 2, "stvk_stretch": 3}

@@ -274,6 +274,7 @@ public:
         factor_flops_top_own = D.flops_top_own;
         factor_flops_critical = D.flops_critical;
         nr_dist_stage = D.enabled ? D.nr_stage : 0;
+        front_store_doubles = m_mf.front_doubles;
         nr_subtree = D.nr_subtree;
         nr_subtree_own = D.nr_subtree_own;
         dist_schur_doubles = D.schur_doubles;

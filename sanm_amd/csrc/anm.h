@@ -120,7 +120,7 @@ public:
     // top (top_own) --, the whole top, and the critical path of the factorisation (sum over the stages of the busiest
     // rank's flops)
     double factor_flops_own = 0, factor_flops_top = 0, factor_flops_top_own = 0, factor_flops_critical = 0;
-    int64_t nr_subtree = 0, nr_subtree_own = 0, nr_dist_stage = 0;
+    int64_t nr_subtree = 0, nr_subtree_own = 0, nr_dist_stage = 0, front_store_doubles = 0;
     int64_t dist_schur_doubles = 0, dist_inbox_doubles = 0;
 };
 //! sum over the ranks of `count` doubles at a device pointer, in place (the driver's all-reduce: RCCL on the solver's

@@ -770,6 +770,7 @@ int sanm_anm_get_stats(const sanm_anm_solver* s, sanm_anm_stats* st) {
         st->factor_flops_top_own = d.linear_solver().factor_flops_top_own;
         st->factor_flops_critical = d.linear_solver().factor_flops_critical;
         st->nr_dist_stage = d.linear_solver().nr_dist_stage;
+        st->front_store_doubles = d.linear_solver().front_store_doubles;
     });
 }
 int sanm_anm_debug_inject(sanm_anm_solver* s, int kind, int order, int64_t index, double value, int scale) {

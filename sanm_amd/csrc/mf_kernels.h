@@ -49,7 +49,7 @@ struct FactorArgs {
 __global__ void scatter_kernel(int64_t nnz, const int64_t* __restrict__ a_dst,
                                const double* __restrict__ val, double* __restrict__ store) {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < nnz) store[a_dst[p]] = val[p];
+    if (p < nnz && a_dst[p] >= 0) store[a_dst[p]] = val[p];  // (< 0: an entry of another rank's front)
 }
 
 // a_dst of every entry of A (mf_types.h, mf_scatter_slot), once per solver: a wavefront per row of A
@@ -59,13 +59,14 @@ __global__ void __launch_bounds__(256) scatter_map_kernel(MfDev mf, const uint32
     if (i >= mf.n) return;
     const int32_t pi = mf.perm[i];
     for (uint32_t p = rowptr[i] + (threadIdx.x & 63); p < rowptr[i + 1]; p += 64)
-        mf.a_dst[p] = mf_scatter_slot(mf.fronts, mf.own_front, mf.bnd_idx, pi, mf.perm[col[p]]);
+        mf.a_dst[p] = mf_scatter_slot(mf.fronts, mf.own_front, mf.bnd_idx, pi, mf.perm[col[p]], mf.front_here);
 }
 
 // identity blocks of the augmentation: F[r, k + r] = F[k + r, r] = 1 for r < k
 __global__ void aug_identity_kernel(MfDev mf) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= mf.n) return;
+    if (mf.front_here && !mf.front_here[mf.own_front[i]]) return;  // (another rank's front)
     const MfFrontDev f = mf.fronts[mf.own_front[i]];
     const int r = i - f.own_start;
     double* F = mf.front_store + f.off;

@@ -69,6 +69,9 @@ struct MfDev {
     // factorisation runs (mf_scatter_slot below; MfSchedule::a_dst_ready) -- 8 bytes per entry that the analysis neither
     // computes on the host nor uploads (round 6)
     int64_t* a_dst;
+    // distributed solver: 1 for the fronts this rank factors (it stores those, and the Schur blocks of the children it
+    // receives from other ranks -- nothing else has a place in its front store); nullptr: every front
+    const uint8_t* front_here;
     // extend-add: child lists per level and round
     double* front_store;          // sum of m*m
     double* work;                 // n doubles (permuted rhs / solution)
@@ -82,9 +85,12 @@ struct MfDev {
 
 //! where entry (i, j) of the matrix (new numbering: pi, pj) sits in the front storage: in the front that owns the smaller
 //! of the two, at the positions of both among its [pivots | augmentation | boundary]
+//! (-1: the front is another rank's, `here` says so)
 MF_HD inline int64_t mf_scatter_slot(const MfFrontDev* fronts, const int32_t* own_front, const int32_t* bnd_idx, int32_t pi,
-                                     int32_t pj) {
-    const MfFrontDev& f = fronts[own_front[pi < pj ? pi : pj]];
+                                     int32_t pj, const uint8_t* here = nullptr) {
+    const int32_t fi = own_front[pi < pj ? pi : pj];
+    if (here && !here[fi]) return -1;
+    const MfFrontDev& f = fronts[fi];
     int32_t pos[2];
     for (int w = 0; w < 2; ++w) {
         const int32_t x = w == 0 ? pi : pj;

@@ -1479,13 +1479,6 @@ void Multifrontal::analyse(int64_t n, const std::vector<uint32_t>* rowptr_p, con
         front_flops[f] = 2.0 / 3 * k * k * k + 2 * k * k * bb + 2 * k * bb * bb + 2 * k * k * (k + bb);
         factor_flops += front_flops[f];
     }
-    front_doubles = off;
-    // the front store's memory, asked for now on a thread of its own (deferred constructors only: the owner thread is
-    // busy with the driver's tables, and mapping tens of GB takes the device 0.1-1 s)
-    if (m_defer && off * sizeof(double) >= (size_t(1) << 28)) {
-        m_front_job.be = m_be;
-        m_front_job.job = std::async(std::launch::async, [be = m_be, bytes = (size_t)off * sizeof(double)] { return be->alloc_detached(bytes); });
-    }
 
     // ---- two-phase levels (mf_types.h, Level::two_phase) -----------------------------------------------------------
     // The boundary blocks of the solve operators, F[B,A] = -L21 L11^-1 and F[A,B] = -U11^-1 U12, cost k^2 b flops each;
@@ -1708,6 +1701,37 @@ void Multifrontal::analyse(int64_t n, const std::vector<uint32_t>* rowptr_p, con
         D.flops_top = factor_flops;
         D.flops_critical = factor_flops;
         D.nr_front_top = F;
+    }
+    // A rank of the distributed solver stores the fronts it factors and, of the children other ranks factor for its
+    // fronts, the Schur block it receives -- at the address the child's descriptor gives it, F[B,B] with the child's own
+    // row stride, so that the extend-add reads it like a child of its own (round 6; every rank used to hold the whole
+    // store: four ranks of a 2.7 M-tet mesh did not fit one device, and capacity did not grow with the ranks).  Nothing
+    // else of another rank's front is ever addressed (`front_here`: the scatter of A and the augmentation's identity
+    // skip those fronts).  SANM_DIST_FULL_STORE=1: the whole store on every rank, as before.
+    std::vector<uint8_t> front_here;
+    if (D.enabled && !std::getenv("SANM_DIST_FULL_STORE")) {
+        front_here.assign(F, 0);
+        off = 0;
+        for (int32_t f = 0; f < F; ++f) {
+            const int64_t k = fr[f].k, ld = fr[f].ld, b = fr[f].m - fr[f].k;
+            if (f_owner[f] == rank) {
+                front_here[f] = 1;
+                fr[f].off = off;
+                off += ld * ld;
+            } else if (parent[f] >= 0 && f_owner[parent[f]] == rank && b > 0) {
+                fr[f].off = off - (2 * k * ld + 2 * k);  // (so that F[B,B] starts at `off`)
+                off += (b - 1) * ld + b;
+            } else {
+                fr[f].off = 0;  // (never addressed)
+            }
+        }
+    }
+    front_doubles = off;
+    // the front store's memory, asked for now on a thread of its own (deferred constructors only: the owner thread is
+    // busy with the driver's tables, and mapping tens of GB takes the device 0.1-1 s)
+    if (m_defer && off * sizeof(double) >= (size_t(1) << 28)) {
+        m_front_job.be = m_be;
+        m_front_job.job = std::async(std::launch::async, [be = m_be, bytes = (size_t)off * sizeof(double)] { return be->alloc_detached(bytes); });
     }
 
     // position of a (new-numbered) variable x inside front f
@@ -2010,6 +2034,7 @@ void Multifrontal::analyse(int64_t n, const std::vector<uint32_t>* rowptr_p, con
     upload_kept(m_dev.rel, rel_keep, rel.data(), rel.size());
     upload_to(m_dev.perm, perm);
     upload_to(m_dev.own_front, std::move(owner));
+    if (!front_here.empty()) upload_to(m_dev.front_here, front_here);
     alloc_to(m_dev.a_dst, (size_t)std::max<int64_t>(nnzA, 1) * sizeof(int64_t), false);
     upload_to(m_sched.ea_children, ea_children);
     {

@@ -381,10 +381,11 @@ struct HostMf {
             if (!sch.a_dst_ready) {  // (as the HIP backend: where the entries of A go, on the first factorisation)
                 for (int64_t i = 0; i < mf.n; ++i)
                     for (uint32_t p = A.rowptr[i]; p < A.rowptr[i + 1]; ++p)
-                        mf.a_dst[p] = mf_scatter_slot(mf.fronts, mf.own_front, mf.bnd_idx, mf.perm[i], mf.perm[A.col[p]]);
+                        mf.a_dst[p] = mf_scatter_slot(mf.fronts, mf.own_front, mf.bnd_idx, mf.perm[i], mf.perm[A.col[p]], mf.front_here);
                 sch.a_dst_ready = true;
             }
-            for (int64_t p = 0; p < mf.nnzA; ++p) mf.front_store[mf.a_dst[p]] += A.val[p];
+            for (int64_t p = 0; p < mf.nnzA; ++p)
+                if (mf.a_dst[p] >= 0) mf.front_store[mf.a_dst[p]] += A.val[p];  // (< 0: an entry of another rank's front)
             double amax = 0;
             for (int64_t p = 0; p < mf.nnzA; ++p) amax = std::fmax(amax, std::fabs(A.val[p]));
             *mf.piv_amax = amax;

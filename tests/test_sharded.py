@@ -314,6 +314,10 @@ def _check_dist(res, world):
         assert r["ncall"] == steps * (1 + 1 + (order - 1)) + 1 + S * steps + (2 * S - 1) * solves
     # every front has one owner: the subtrees and the top fronts partition the work ...
     assert abs(sum(own) + top - total) <= 1e-9 * total and abs(sum(top_own) - top) <= 1e-9 * total
+    # ... and the storage: a rank holds the fronts it factors and the Schur blocks it receives, not the whole store
+    whole = res[0]["ref_st"]["front_store_doubles"]
+    held = [r["st"]["front_store_doubles"] for r in res]
+    assert whole > 0 and all(0 < h < whole for h in held) and whole <= sum(held) < 1.5 * whole, (held, whole)
     # ... and the critical path (sum over the stages of the busiest rank) is what a rank waits for
     crit = res[0]["st"]["factor_flops_critical"]
     assert max(o + t for o, t in zip(own, top_own)) <= crit * (1 + 1e-9) and crit < 0.8 * total
