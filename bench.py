@@ -568,6 +568,7 @@ class Leg:
         self.rank_stats = None
         if self.dist is not None:
             mine = {k: self.stats[k] for k in ("factor_flops_own", "factor_flops_top_own", "nr_subtree_own")}
+            mine["front_store_bytes"] = 8 * self.stats.get("front_store_doubles", 0)  # (what THIS rank holds of the fronts)
             gathered = [None] * self.world
             self.dist.all_gather_object(gathered, mine)
             self.rank_stats = gathered
@@ -618,6 +619,7 @@ class Leg:
                        "dist_solver": dict({k: stats[k] for k in ("nr_subtree", "nr_subtree_own", "factor_flops_own",
                                                                   "factor_flops_top", "factor_flops_top_own",
                                                                   "factor_flops_critical", "nr_dist_stage")},
+                                           front_store_bytes=8 * stats.get("front_store_doubles", 0),
                                            exchange_bytes={"schur_per_factorisation": 8 * stats["dist_schur_doubles"],
                                                            "inbox_per_solve": 8 * stats["dist_inbox_doubles"],
                                                            "solution_per_solve": 8 * n if stats["nr_subtree"] else 0},
