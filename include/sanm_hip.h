@@ -49,7 +49,7 @@ const char* sanm_hip_backend_name(void);
  * an entry point changes meaning.  A consumer compiled against this header checks
  * sanm_hip_abi_version() == SANM_HIP_ABI_VERSION once after loading the library (adapter/anm_hip.h does), or uses
  * the *_sized calls, which write no more than the caller's own record holds. */
-#define SANM_HIP_ABI_VERSION 6
+#define SANM_HIP_ABI_VERSION 7
 int sanm_hip_abi_version(void);
 
 /* ---- operator API: libsanm/oprs.h:14-103, oprs.cpp:16-102 --------------- */
@@ -277,7 +277,7 @@ typedef struct sanm_anm_stats {
      * i.e. the factorisation's critical path (factor_flops / factor_flops_critical = its speed-up if flops-bound) */
     double factor_flops_top_own, factor_flops_critical;
     int64_t nr_dist_stage;
-    /* doubles of this rank's front store: every front when the solver is replicated; with the distribution the fronts
+    /* (ABI 7) doubles of this rank's front store: every front when the solver is replicated; with the distribution the fronts
      * the rank factors and the Schur blocks it receives (a shorter caller struct simply does not get it:
      * sanm_anm_get_stats_sized) */
     int64_t front_store_doubles;
